@@ -1,0 +1,246 @@
+"""ctypes binding of libcfl_hip.so (include/cfl_hip.h) for torch-ROCm tensors.
+
+PyTorch is only plumbing here (device memory + streams); all arithmetic of the
+pair-distance hot path runs in the hand-written gfx950 kernels behind the C ABI.
+There is NO CPU / eager fallback: if the shared library is missing, importing
+this module's ``lib()`` raises, and every op raises on non-CUDA tensors.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), 'lib', 'libcfl_hip.so')
+
+DIST_TYPES = {'pcd': 0, 'monomer': 1, 'siamese': 2}
+ACT_TYPES = {None: 0, 'linear': 0, 'sigmoid': 1, 'tanh': 2, 'relu': 3}
+
+SCALAR_NAMES = ('total', 'reg', 'thres', 'loss_pos', 'loss_neg', 'cd', 'accuracy',
+                'mean_d_pos', 'mean_d_neg', 'mean_o_pos', 'mean_o_neg', 'threshold',
+                'dist_adapt_pos', 'dist_adapt_neg')
+S_COUNT = 16
+
+
+class CflShape(C.Structure):
+    _fields_ = [('D', C.c_int32), ('L', C.c_int32), ('K', C.c_int32),
+                ('dist_type', C.c_int32), ('weight_norm', C.c_int32),
+                ('has_bias', C.c_int32), ('act_type', C.c_int32),
+                ('directed', C.c_int32)]
+
+
+class CflHead(C.Structure):
+    _fields_ = [('w', C.c_int64), ('b', C.c_int64), ('g', C.c_int64),
+                ('n', C.c_int32), ('npad', C.c_int32)]
+
+
+class _CflEnc(C.Structure):
+    _fields_ = [('outputs', CflHead), ('proto', CflHead), ('mono', CflHead)]
+
+
+class CflLayout(C.Structure):
+    _fields_ = [('enc', _CflEnc * 2), ('thr', C.c_int64), ('total', C.c_int64)]
+
+
+class CflNorm(C.Structure):
+    _fields_ = [('mul', C.c_float), ('add', C.c_float), ('lo', C.c_float),
+                ('hi', C.c_float), ('has_lo', C.c_int32), ('has_hi', C.c_int32)]
+
+
+class CflLossCfg(C.Structure):
+    _fields_ = [('use_threshold', C.c_int32), ('pos_weight', C.c_float),
+                ('caffe_margin', C.c_float), ('lambda_m', C.c_float),
+                ('reg_const', C.c_float)]
+
+
+EXPORTS = ('cfl_version', 'cfl_last_error', 'cfl_layout', 'cfl_workspace_bytes',
+           'cfl_pair_scores', 'cfl_pair_step_fwd_bwd', 'cfl_adam_tf',
+           'cfl_gather_rows')
+
+_lib = None
+
+
+class CflHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libcfl_hip.so (built by ``__graft_entry__.build()``); fail loudly."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise CflHipError(
+            'HIP extension missing: {} (run `python -c "import __graft_entry__ as g; '
+            'g.build()"`); there is no CPU fallback for the cfl hot path'.format(LIB_PATH))
+    L = C.CDLL(LIB_PATH)
+    L.cfl_version.restype = C.c_int
+    L.cfl_last_error.restype = C.c_char_p
+    L.cfl_layout.argtypes = [C.POINTER(CflShape), C.POINTER(CflLayout)]
+    L.cfl_layout.restype = C.c_int
+    L.cfl_workspace_bytes.argtypes = [C.POINTER(CflShape), C.c_int64, C.c_int32]
+    L.cfl_workspace_bytes.restype = C.c_size_t
+    L.cfl_pair_scores.argtypes = [
+        C.POINTER(CflShape), C.POINTER(CflNorm), C.c_void_p, C.c_void_p, C.c_int64,
+        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    L.cfl_pair_scores.restype = C.c_int
+    L.cfl_pair_step_fwd_bwd.argtypes = [
+        C.POINTER(CflShape), C.POINTER(CflNorm), C.POINTER(CflLossCfg),
+        C.POINTER(C.c_void_p), C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+        C.c_void_p, C.c_size_t, C.c_void_p]
+    L.cfl_pair_step_fwd_bwd.restype = C.c_int
+    L.cfl_adam_tf.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                              C.c_int64, C.c_float, C.c_float, C.c_float,
+                              C.c_float, C.c_float, C.c_void_p]
+    L.cfl_adam_tf.restype = C.c_int
+    L.cfl_gather_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64,
+                                  C.c_void_p, C.c_void_p]
+    L.cfl_gather_rows.restype = C.c_int
+    if L.cfl_version() != 1:
+        raise CflHipError('libcfl_hip.so ABI version mismatch')
+    _lib = L
+    return L
+
+
+def _check(rc):
+    if rc != 0:
+        raise CflHipError('libcfl_hip error {}: {}'.format(
+            rc, lib().cfl_last_error().decode()))
+
+
+def make_shape(D, L, K, dist_type='pcd', weight_norm=False, has_bias=True,
+               act_type=None, directed=False):
+    return CflShape(int(D), int(L), int(K), DIST_TYPES[dist_type],
+                    int(bool(weight_norm)), int(bool(has_bias)),
+                    ACT_TYPES[act_type], int(bool(directed)))
+
+
+def make_norm(mul=1.0, add=0.0, lo=None, hi=None):
+    return CflNorm(float(mul), float(add), float(lo if lo is not None else 0.0),
+                   float(hi if hi is not None else 0.0), int(lo is not None),
+                   int(hi is not None))
+
+
+def make_loss(use_threshold=True, pos_weight=None, caffe_margin=None,
+              lambda_m=0.0, reg_const=0.0):
+    return CflLossCfg(int(bool(use_threshold)), float(pos_weight or 0.0),
+                      float(caffe_margin or 0.0), float(lambda_m or 0.0),
+                      float(reg_const or 0.0))
+
+
+def layout(shape):
+    lay = CflLayout()
+    _check(lib().cfl_layout(C.byref(shape), C.byref(lay)))
+    return lay
+
+
+def workspace_bytes(shape, rows, groups):
+    n = lib().cfl_workspace_bytes(C.byref(shape), int(rows), int(groups))
+    if n == 0:
+        raise CflHipError('cfl_workspace_bytes: ' + lib().cfl_last_error().decode())
+    return n
+
+
+def _dev(t, dtype=torch.float32):
+    if not (isinstance(t, torch.Tensor) and t.is_cuda):
+        raise CflHipError('cfl hot path needs CUDA/HIP tensors (no CPU fallback)')
+    if t.dtype != dtype or not t.is_contiguous():
+        raise CflHipError('expected contiguous {} tensor'.format(dtype))
+    return t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def pair_scores(shape, norm, xs, xt, theta, workspace, scores=None, dists=None):
+    n = xs.shape[0]
+    if scores is None:
+        scores = torch.empty(n, dtype=torch.float32, device=xs.device)
+    _check(lib().cfl_pair_scores(
+        C.byref(shape), C.byref(norm), _dev(xs), _dev(xt), n, _dev(theta),
+        _dev(scores), _dev(dists) if dists is not None else None,
+        workspace.data_ptr(), workspace.numel() * workspace.element_size(), _stream()))
+    return scores
+
+
+def pair_step_fwd_bwd(shape, norm, loss, x4, theta, grad, scalars, workspace):
+    B = x4[0].shape[0]
+    arr = (C.c_void_p * 4)(*[_dev(x) for x in x4])
+    _check(lib().cfl_pair_step_fwd_bwd(
+        C.byref(shape), C.byref(norm), C.byref(loss), arr, B, _dev(theta), _dev(grad),
+        _dev(scalars), workspace.data_ptr(),
+        workspace.numel() * workspace.element_size(), _stream()))
+
+
+def adam_tf(theta, m, v, grad, lr_t, beta1, beta2, eps=1e-8, grad_scale=1.0):
+    _check(lib().cfl_adam_tf(_dev(theta), _dev(m), _dev(v), _dev(grad), theta.numel(),
+                             float(lr_t), float(beta1), float(beta2), float(eps),
+                             float(grad_scale), _stream()))
+
+
+def gather_rows(table, idx, out=None):
+    n, D = idx.shape[0], table.shape[1]
+    if out is None:
+        out = torch.empty(n, D, dtype=torch.float32, device=table.device)
+    _check(lib().cfl_gather_rows(_dev(table), _dev(idx, torch.int64), n, D, _dev(out),
+                                 _stream()))
+    return out
+
+
+# ---------------------------------------------------------------------------
+# theta <-> named variables in the reference (TensorFlow) layout [D, N]
+# ---------------------------------------------------------------------------
+def head_views(lay, shape, e):
+    """Yield (scope-relative variable name, kind, CflHead) for encoder e."""
+    enc = lay.enc[e]
+    for name, h in (('outputs', enc.outputs), ('proto', enc.proto), ('mono', enc.mono)):
+        if h.w >= 0:
+            yield name, h
+
+
+def pack_theta(shape, params, params_dst=None, thr=1e-6, device='cpu'):
+    """Build the flat device array from {'outputs/W': [D,L], 'outputs/b': ..,
+    'outputs/g': .., 'proto/W': [D,K*L], .., 'mono/W': [L,K], 'mono/g'} dicts."""
+    lay = layout(shape)
+    theta = torch.zeros(lay.total, dtype=torch.float32)
+    D = shape.D
+    for e, p in enumerate((params, params_dst)):
+        if p is None:
+            continue
+        for name, h in head_views(lay, shape, e):
+            W = torch.as_tensor(np.asarray(p[name + '/W'], dtype=np.float32))
+            if name == 'mono':
+                blk = theta[h.w:h.w + shape.L * h.npad].view(shape.L, h.npad)
+                blk[:, :h.n] = W
+            else:
+                blk = theta[h.w:h.w + h.npad * D].view(h.npad, D)
+                blk[:h.n] = W.t()
+            if h.b >= 0:
+                theta[h.b:h.b + h.n] = torch.as_tensor(np.asarray(p[name + '/b'], dtype=np.float32))
+            if h.g >= 0:
+                theta[h.g:h.g + h.n] = torch.as_tensor(np.asarray(p[name + '/g'], dtype=np.float32))
+    theta[lay.thr] = float(thr)
+    return theta.to(device)
+
+
+def unpack_theta(shape, theta):
+    """Inverse of pack_theta: (params, params_dst|None, thr) as numpy arrays."""
+    lay = layout(shape)
+    th = theta.detach().cpu()
+    D = shape.D
+    out = []
+    for e in range(2 if shape.directed else 1):
+        p = {}
+        for name, h in head_views(lay, shape, e):
+            if name == 'mono':
+                p['mono/W'] = th[h.w:h.w + shape.L * h.npad].view(shape.L, h.npad)[:, :h.n].numpy().copy()
+            else:
+                p[name + '/W'] = th[h.w:h.w + h.npad * D].view(h.npad, D)[:h.n].t().numpy().copy()
+            if h.b >= 0:
+                p[name + '/b'] = th[h.b:h.b + h.n].numpy().copy()
+            if h.g >= 0:
+                p[name + '/g'] = th[h.g:h.g + h.n].numpy().copy()
+        out.append(p)
+    return out[0], (out[1] if shape.directed else None), float(th[lay.thr])

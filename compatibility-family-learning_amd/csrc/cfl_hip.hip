@@ -1,0 +1,1378 @@
+// cfl_hip.hip -- gfx950 (MI355X / CDNA4) kernels + C ABI for the cfl pair-distance
+// training / scoring hot path.  See include/cfl_hip.h for the boundary and
+// DESIGN.md for the data layout and the roofline of every kernel.
+//
+// One training step = 5 launches on the caller's stream:
+//   [colnorm]  (weight-norm only)  n2[c] = sum_d V[d][c]^2
+//   proj       skinny fp32-MFMA projection partials  Y_s = X[:, slice_s] . Wt[:, slice_s]^T
+//   mid        slice-sum + bias/scale/activation, distance, loss, dL/dY (transposed)
+//              (+ extra blocks: L2-regulariser partial sums)
+//   grad       skinny fp32-MFMA weight-gradient partials  dWt_p = dYt[:, rows_p] . X[rows_p, :]
+//   finalize   partial slabs -> flat gradient (+bias/gain/threshold grads, +reg) and scalars
+// followed by cfl_adam_tf (separate entry point so that a data-parallel caller
+// can all-reduce the flat gradient in between).
+//
+// Reference arithmetic restated (paths relative to the reference tree):
+//   heads      cfl/models/dist.py:43-68, cfl/layers.py:80-90, cfl/models/base.py:43-105
+//   distances  cfl/models/base.py:107-146 (== cfl/models/dist.py:70-89)
+//   threshold  cfl/models/blocks.py:18-22
+//   losses     cfl/models/cfl.py:868-949, cfl/models/dist.py:253-284
+//   Adam       tf.train.AdamOptimizer (TF-1.x), cfl/models/cfl.py:1077-1085
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+#include "../../include/cfl_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define CFL_MAX_JOBS 16
+#define CFL_MAX_REGIONS 20
+#define CFL_THR_FLOOR 1e-6f
+
+// ---------------------------------------------------------------------------
+// error plumbing
+// ---------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+static int set_err(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                              \
+    do {                                                                           \
+        hipError_t _e = (expr);                                                    \
+        if (_e != hipSuccess)                                                      \
+            return set_err(CFL_E_HIP, "%s failed: %s", #expr, hipGetErrorString(_e)); \
+    } while (0)
+
+static inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+
+// ---------------------------------------------------------------------------
+// device helpers
+// ---------------------------------------------------------------------------
+struct NormDev {
+    float mul, add, lo, hi;
+    int elementwise;  // 1: x_hat = clip(x*mul+add) at load; 0: mul folded into the epilogue
+};
+
+__device__ __forceinline__ f32x4 norm_apply(f32x4 v, const NormDev &n) {
+    if (n.elementwise) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = fminf(fmaxf(fmaf(v[i], n.mul, n.add), n.lo), n.hi);
+    }
+    return v;
+}
+
+__device__ __forceinline__ const float *row_ptr(const float *x0, const float *x1, int r, int B,
+                                                int R, int D) {
+    // rows [0,B) live in x0, rows [B,2B) in x1; rows >= R are clamped to a valid
+    // row (their products are never stored / are multiplied by zero dY).
+    int rc = r < R ? r : R - 1;
+    return rc < B ? x0 + (size_t)rc * D : x1 + (size_t)(rc - B) * D;
+}
+
+// ---------------------------------------------------------------------------
+// proj: Ypart[s][c][r] = sum_{d in slice s} X[r][d] * Wt[c][d]
+//   workgroup = 8 waves, one 32-row tile; wave w owns a d sub-range of slice s and
+//   computes the whole [32 x NT*16] tile for it with v_mfma_f32_16x16x4_f32.
+//   A fragment  lane(r16,q) : float4 X[row0+16mt+r16][d+4q .. d+4q+3]
+//   B fragment  lane(c16,q) : float4 Wt[16nt+c16][d+4q .. d+4q+3]
+//   MFMA k-step j uses element j of both, i.e. k index q <-> d + 4q + j.
+//   The 8 partial tiles are summed through LDS in a fixed order.
+// ---------------------------------------------------------------------------
+struct ProjJob {
+    const float *x0, *x1;  // pair-group row blocks
+    const float *wt;       // Wt chunk [nt*16][D]
+    float *ypart;          // chunk base inside [S][npad][Rpad]
+    long long sstride;     // floats between slices (npad * Rpad)
+    int nt;
+};
+
+struct ProjArgs {
+    ProjJob job[CFL_MAX_JOBS];
+    int B, R, Rpad, D, S;
+    NormDev norm;
+};
+
+template <int NT>
+__device__ __forceinline__ void proj_body(const ProjJob &jb, const ProjArgs &a, f32x4 *lds) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r16 = lane & 15, q = lane >> 4;
+    const int row0 = blockIdx.x * 32;
+    const int s = blockIdx.y;
+    const int G = a.D >> 4;  // 16-d groups
+    const int wg = s * 8 + wave, nw = a.S * 8;
+    const int g0 = (int)((long long)wg * G / nw), g1 = (int)((long long)(wg + 1) * G / nw);
+
+    const float *ap[2];
+    const float *bp[NT];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+        ap[mt] = row_ptr(jb.x0, jb.x1, row0 + mt * 16 + r16, a.B, a.R, a.D) + 4 * q;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) bp[nt] = jb.wt + (size_t)(nt * 16 + r16) * a.D + 4 * q;
+
+    f32x4 acc[2][NT];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    f32x4 ac[2], bc[NT], an[2], bn[NT];
+    if (g0 < g1) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) ac[mt] = *(const f32x4 *)(ap[mt] + g0 * 16);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) bc[nt] = *(const f32x4 *)(bp[nt] + g0 * 16);
+    }
+    for (int g = g0; g < g1; ++g) {
+        if (g + 1 < g1) {
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) an[mt] = *(const f32x4 *)(ap[mt] + (g + 1) * 16);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) bn[nt] = *(const f32x4 *)(bp[nt] + (g + 1) * 16);
+        }
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) ac[mt] = norm_apply(ac[mt], a.norm);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[mt][j], bc[nt][j],
+                                                                      acc[mt][nt], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) ac[mt] = an[mt];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) bc[nt] = bn[nt];
+    }
+
+    // cross-wave sum: lds[wave][tile][lane]
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) lds[(wave * 2 * NT + mt * NT + nt) * 64 + lane] = acc[mt][nt];
+    __syncthreads();
+    if (wave < 2 * NT) {
+        const int mt = wave / NT, nt = wave % NT;
+        f32x4 sum = lds[(0 * 2 * NT + wave) * 64 + lane];
+#pragma unroll
+        for (int w = 1; w < 8; ++w) sum += lds[(w * 2 * NT + wave) * 64 + lane];
+        // C layout: col = lane&15, rows 4*(lane>>4) .. +3  ->  Ypart_t[col][row0 + 16mt + 4q ..]
+        float *dst = jb.ypart + (size_t)s * jb.sstride + (size_t)(nt * 16 + r16) * a.Rpad + row0 +
+                     mt * 16 + 4 * q;
+        *(f32x4 *)dst = sum;
+    }
+}
+
+extern "C" __global__ __launch_bounds__(512) void cfl_proj_kernel(ProjArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    f32x4 *lds = (f32x4 *)smem;
+    const ProjJob &jb = a.job[blockIdx.z];
+    switch (jb.nt) {
+        case 1: proj_body<1>(jb, a, lds); break;
+        case 2: proj_body<2>(jb, a, lds); break;
+        case 3: proj_body<3>(jb, a, lds); break;
+        default: proj_body<4>(jb, a, lds); break;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// grad: Wpart[p][c][d] = sum_{r in range p} dYt[c][r] * X[r][d]
+//   workgroup = 4 waves, one 64-d tile and one row range; the waves split the range.
+//   A fragment  lane(i,kq), load j : float4 X[p0+4kq+j][dbase+4i .. +3]   (256 B per row)
+//   B fragment  lane(c16,kq)       : float4 dYt[16nt+c16][p0+4kq .. +3]
+//   MFMA (j,t): A elem = xa[j][t]  (row i <-> d = dbase+4i+t, k = kq <-> row p0+4kq+j)
+//               B elem = dy[nt][j]
+// ---------------------------------------------------------------------------
+struct GradJob {
+    const float *x0, *x1;
+    const float *dyt;      // chunk base inside [npad][Rpad]
+    float *wpart;          // chunk base inside [P][npad][D]
+    long long pstride;     // floats between row-range slabs (npad * D)
+    int nt;
+};
+
+struct GradArgs {
+    GradJob job[CFL_MAX_JOBS];
+    int B, R, Rpad, D, P;
+    NormDev norm;
+};
+
+template <int NT>
+__device__ __forceinline__ void grad_body(const GradJob &jb, const GradArgs &a, f32x4 *lds) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i16 = lane & 15, kq = lane >> 4;
+    const int dbase = blockIdx.x * 64;
+    const int p = blockIdx.y;
+    const int rows_wg = a.Rpad / a.P, rows_w = rows_wg >> 2;
+    const int rbeg = p * rows_wg + wave * rows_w, rend = rbeg + rows_w;
+
+    f32x4 acc[4][NT];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[t][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const float *dyp[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) dyp[nt] = jb.dyt + (size_t)(nt * 16 + i16) * a.Rpad + 4 * kq;
+
+    f32x4 xc[4], dc[NT], xn[4], dn[NT];
+    auto load = [&](int p0, f32x4 *x, f32x4 *dy) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            x[j] = *(const f32x4 *)(row_ptr(jb.x0, jb.x1, p0 + 4 * kq + j, a.B, a.R, a.D) + dbase +
+                                    4 * i16);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) dy[nt] = *(const f32x4 *)(dyp[nt] + p0);
+    };
+    // rows beyond R carry dY == 0 (written by the mid kernel); skip whole groups
+    // that are entirely padding.
+    const int r16 = (a.R + 15) & ~15;
+    const int rstop = rend < r16 ? rend : r16;
+    if (rbeg < rstop) load(rbeg, xc, dc);
+    for (int p0 = rbeg; p0 < rstop; p0 += 16) {
+        if (p0 + 16 < rstop) load(p0 + 16, xn, dn);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xc[j] = norm_apply(xc[j], a.norm);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(xc[j][t], dc[nt][j],
+                                                                     acc[t][nt], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xc[j] = xn[j];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) dc[nt] = dn[nt];
+    }
+
+    // cross-wave sum through LDS: lds[wave][nt][t][lane]
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) lds[((wave * NT + nt) * 4 + t) * 64 + lane] = acc[t][nt];
+    __syncthreads();
+    if (wave < NT) {
+        const int nt = wave;
+        f32x4 sum[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            sum[t] = lds[((0 * NT + nt) * 4 + t) * 64 + lane];
+#pragma unroll
+            for (int w = 1; w < 4; ++w) sum[t] += lds[((w * NT + nt) * 4 + t) * 64 + lane];
+        }
+        // acc[t][nt][e]: M row 4*kq+e <-> d = dbase + 16*kq + 4*e + t ; N col = lane&15
+        float *dst = jb.wpart + (size_t)p * jb.pstride + (size_t)(nt * 16 + i16) * a.D + dbase +
+                     16 * kq;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            f32x4 v = {sum[0][e], sum[1][e], sum[2][e], sum[3][e]};
+            *(f32x4 *)(dst + 4 * e) = v;
+        }
+    }
+}
+
+extern "C" __global__ __launch_bounds__(256) void cfl_grad_kernel(GradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    f32x4 *lds = (f32x4 *)smem;
+    const GradJob &jb = a.job[blockIdx.z];
+    switch (jb.nt) {
+        case 1: grad_body<1>(jb, a, lds); break;
+        case 2: grad_body<2>(jb, a, lds); break;
+        case 3: grad_body<3>(jb, a, lds); break;
+        default: grad_body<4>(jb, a, lds); break;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// mid: per pair row: slice-sum, head epilogue, distance, loss, dL/dY.
+//   workgroup = 64 threads = 16 rows x 4 column parts; lane (p = tid>>4, j = tid&15)
+//   owns the latent coordinates l == p (mod 4) of row blockIdx.x*16 + j, for every
+//   prototype k.  Sums over l are completed with two xor-shuffles (16, 32); sums
+//   over the 16 rows of the block (bias / weight-norm column sums) with four
+//   (1,2,4,8).  LDS is only per-lane runtime-indexed storage: [slot][64].
+// ---------------------------------------------------------------------------
+enum {
+    P_BCE_POS = 0, P_BCE_NEG, P_OK_POS, P_OK_NEG, P_D_POS, P_D_NEG, P_O_POS, P_O_NEG,
+    P_DTHR, P_HINGE_NEG, P_SQRT_POS, P_SQRT_NEG, P_NSCALAR = 16
+};
+
+struct MidSide {
+    const float *ypart;   // [S][npad][Rpad]
+    long long sstride;
+    const float *b;       // biases or null
+    const float *g;       // wn gains or null
+    const float *n2;      // wn squared column norms or null
+    float *dyt;           // [npad][Rpad]
+    int n, npad;
+    int is_proto;         // 1: columns are k*L + l ; 0: columns are l
+    int col_off;          // offset of this side's column sums inside a part vector
+};
+
+struct MidArgs {
+    MidSide side[2];      // 0 = src, 1 = dst
+    const float *mono_w, *mono_g, *mono_n2;  // monomer gate head V[L][kpad]
+    int kpad, mono_off;   // mono_off: offset of the mono sums inside a part vector
+    int S, L, K, Lq, dist_type, act, weight_norm;
+    float in_mul;
+    const float *thr;
+    int B, R, Rpad, groups;
+    int train, use_threshold;
+    float pos_weight, caffe_margin, lambda_m;
+    float *scores, *dists;
+    float *part;          // [nrb][partw]
+    int partw, nrb;
+    // regulariser blocks
+    const float *theta;
+    float *regpart;
+    int nreg_ranges;
+    long long reg_off[CFL_MAX_REGIONS], reg_cnt[CFL_MAX_REGIONS];
+    long long reg_total_groups;  // number of 64-float groups over all ranges
+};
+
+__device__ __forceinline__ float act_fn(float y, int act) {
+    switch (act) {
+        case CFL_ACT_SIGMOID: return 1.f / (1.f + expf(-y));
+        case CFL_ACT_TANH: return tanhf(y);
+        case CFL_ACT_RELU: return fmaxf(y, 0.f);
+        default: return y;
+    }
+}
+__device__ __forceinline__ float act_grad(float a, int act) {
+    switch (act) {
+        case CFL_ACT_SIGMOID: return a * (1.f - a);
+        case CFL_ACT_TANH: return 1.f - a * a;
+        case CFL_ACT_RELU: return a > 0.f ? 1.f : 0.f;
+        default: return 1.f;
+    }
+}
+__device__ __forceinline__ float sum4(float x) {  // over the 4 column parts
+    x += __shfl_xor(x, 16);
+    x += __shfl_xor(x, 32);
+    return x;
+}
+__device__ __forceinline__ float sum16(float x) {  // over the 16 rows of the block
+    x += __shfl_xor(x, 1);
+    x += __shfl_xor(x, 2);
+    x += __shfl_xor(x, 4);
+    x += __shfl_xor(x, 8);
+    return x;
+}
+__device__ __forceinline__ float sum64(float x) {
+    x = sum16(x);
+    return sum4(x);
+}
+
+__device__ void mid_reg_block(const MidArgs &a, int blk) {
+    // 64 threads; block handles 64 groups of 64 floats of the regularised ranges
+    const int tid = threadIdx.x;
+    float acc = 0.f;
+    for (int gi = 0; gi < 64; ++gi) {
+        long long g = (long long)blk * 64 + gi;
+        if (g >= a.reg_total_groups) break;
+        long long rem = g;
+        for (int k = 0; k < a.nreg_ranges; ++k) {
+            long long ng = a.reg_cnt[k] >> 6;
+            if (rem < ng) {
+                float v = a.theta[a.reg_off[k] + rem * 64 + tid];
+                acc = fmaf(v, v, acc);
+                break;
+            }
+            rem -= ng;
+        }
+    }
+    acc = sum64(acc);
+    if (tid == 0) a.regpart[blk] = acc;
+}
+
+extern "C" __global__ __launch_bounds__(64) void cfl_mid_kernel(MidArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *lds = (float *)smem;
+    if ((int)blockIdx.x >= a.nrb) {
+        mid_reg_block(a, blockIdx.x - a.nrb);
+        return;
+    }
+    const int tid = threadIdx.x, p = tid >> 4, j = tid & 15;
+    const int r = blockIdx.x * 16 + j;
+    const bool valid = r < a.R;
+    const int L = a.L, K = a.K, Lq = a.Lq;
+    const int myL = (L - p + 3) >> 2;  // number of l = p + 4*li < L
+    const MidSide &ss = a.side[0], &sd = a.side[1];
+    const int ks = ss.is_proto ? K : 1, kd = sd.is_proto ? K : 1;
+
+    // LDS carve, every array [slots][64]
+    float *As = lds;                           // src activations   ks*Lq
+    float *Ad = As + ks * Lq * 64;             // dst activations   kd*Lq
+    float *Xs = Ad + kd * Lq * 64;             // src raw x_hat.V (weight-norm)  ks*Lq
+    float *Xd = Xs + (a.weight_norm ? ks * Lq * 64 : 0);
+    float *Rl = Xd + (a.weight_norm ? kd * Lq * 64 : 0);   // Lq : pcd residual / monomer pre-act
+    float *Kv = Rl + Lq * 64;                  // 4 x K small vectors
+    float *Ks = Kv, *Kq = Kv + K * 64, *Ke = Kv + 2 * K * 64, *Ku = Kv + 3 * K * 64;
+
+    // ---- 1. slice sums + head epilogue ---------------------------------------
+    for (int side = 0; side < 2; ++side) {
+        const MidSide &sx = a.side[side];
+        float *A = side ? Ad : As, *X = side ? Xd : Xs;
+        const int kk = sx.is_proto ? K : 1;
+        for (int k = 0; k < kk; ++k)
+            for (int li = 0; li < myL; ++li) {
+                const int c = k * L + p + 4 * li;
+                const float *yp = sx.ypart + (size_t)c * a.Rpad + r;
+                float y = 0.f;
+                for (int s = 0; s < a.S; ++s) y += yp[(size_t)s * sx.sstride];
+                const float xv = y * a.in_mul;
+                float sc = 1.f;
+                if (a.weight_norm) sc = sx.g[c] / sqrtf(sx.n2[c]);
+                float yy = xv * sc;
+                if (sx.b) yy += sx.b[c];
+                const int slot = (k * Lq + li) * 64 + tid;
+                if (a.weight_norm) X[slot] = xv;
+                if (a.dist_type == CFL_DIST_MONOMER && side == 0) Rl[li * 64 + tid] = yy;
+                A[slot] = act_fn(yy, a.act);
+            }
+    }
+
+    // ---- 2. distance ---------------------------------------------------------
+    float d = 0.f;
+    if (a.dist_type == CFL_DIST_PCD) {
+        if (K > 1) {
+            float mx = -INFINITY;
+            for (int k = 0; k < K; ++k) {
+                float e = 0.f;
+                for (int li = 0; li < myL; ++li) {
+                    float df = Ad[li * 64 + tid] - As[(k * Lq + li) * 64 + tid];
+                    e = fmaf(df, df, e);
+                }
+                e = -sum4(e);
+                Ks[k * 64 + tid] = e;
+                mx = fmaxf(mx, e);
+            }
+            float den = 0.f;
+            for (int k = 0; k < K; ++k) {
+                float ex = expf(Ks[k * 64 + tid] - mx);
+                Ks[k * 64 + tid] = ex;
+                den += ex;
+                Kq[k * 64 + tid] = 0.f;
+            }
+            const float inv = 1.f / den;
+            for (int k = 0; k < K; ++k) Ks[k * 64 + tid] *= inv;
+            for (int li = 0; li < myL; ++li) {
+                const float v = Ad[li * 64 + tid];
+                float m = 0.f;
+                for (int k = 0; k < K; ++k) m = fmaf(Ks[k * 64 + tid], As[(k * Lq + li) * 64 + tid], m);
+                const float rl = v - m;
+                Rl[li * 64 + tid] = rl;
+                d = fmaf(rl, rl, d);
+                for (int k = 0; k < K; ++k) Kq[k * 64 + tid] += rl * As[(k * Lq + li) * 64 + tid];
+            }
+            d = sum4(d);
+        } else {
+            for (int li = 0; li < myL; ++li) {
+                float df = Ad[li * 64 + tid] - As[li * 64 + tid];
+                d = fmaf(df, df, d);
+            }
+            d = sum4(d);
+        }
+    } else if (a.dist_type == CFL_DIST_MONOMER) {
+        // gate u_k = (ya . Vm[:,k]) * scale_k from the PRE-activation outputs (base.py:96)
+        float mx = -INFINITY;
+        for (int k = 0; k < K; ++k) {
+            float u = 0.f, e = 0.f;
+            for (int li = 0; li < myL; ++li) {
+                const int l = p + 4 * li;
+                u = fmaf(Rl[li * 64 + tid], a.mono_w[l * a.kpad + k], u);
+                float df = As[li * 64 + tid] - Ad[(k * Lq + li) * 64 + tid];
+                e = fmaf(df, df, e);
+            }
+            u = sum4(u);
+            e = sum4(e);
+            Ku[k * 64 + tid] = u;  // raw ya.Vm (needed for the weight-norm gain grad)
+            if (a.weight_norm) u *= a.mono_g[k] / sqrtf(a.mono_n2[k]);
+            Ks[k * 64 + tid] = u;
+            Ke[k * 64 + tid] = e;
+            mx = fmaxf(mx, u);
+        }
+        float den = 0.f;
+        for (int k = 0; k < K; ++k) {
+            float ex = expf(Ks[k * 64 + tid] - mx);
+            Ks[k * 64 + tid] = ex;
+            den += ex;
+        }
+        const float inv = 1.f / den;
+        for (int k = 0; k < K; ++k) {
+            const float w = Ks[k * 64 + tid] * inv;
+            Ks[k * 64 + tid] = w;
+            d = fmaf(w, Ke[k * 64 + tid], d);
+        }
+    } else {
+        for (int li = 0; li < myL; ++li) {
+            float df = As[li * 64 + tid] - Ad[li * 64 + tid];
+            d = fmaf(df, df, d);
+        }
+        d = sum4(d);
+    }
+
+    // ---- 3. threshold, loss, dL/dd -------------------------------------------
+    const float thr_raw = *a.thr;
+    const float thr = fmaxf(thr_raw, CFL_THR_FLOOR);
+    const float o = thr - d;
+    if (!a.train) {
+        if (valid && p == 0) {
+            a.scores[r] = o;
+            if (a.dists) a.dists[r] = d;
+        }
+        return;
+    }
+    const bool is_pos = r < a.B;
+    const float invB = 1.f / (float)a.B;
+    const float pw = a.pos_weight != 0.f ? a.pos_weight : 1.f;
+    const float sp = log1pf(expf(-fabsf(o)));
+    const float bce = fmaxf(o, 0.f) - (is_pos ? o : 0.f) + sp;
+    const float sig = o >= 0.f ? 1.f / (1.f + expf(-o)) : expf(o) / (1.f + expf(o));
+    const float dlo = is_pos ? (sig - 1.f) * pw * invB : sig * invB;  // dL_thr/do
+    float dd = 0.f;
+    if (a.use_threshold) dd -= dlo;
+    float hinge = 0.f;
+    if (a.caffe_margin != 0.f) {
+        if (is_pos) dd += 0.5f * pw * invB;
+        else {
+            hinge = fmaxf(0.f, a.caffe_margin - d);
+            if (d < a.caffe_margin) dd -= 0.5f * invB;
+        }
+    } else if (a.lambda_m != 0.f) {
+        if (is_pos) dd += pw * a.lambda_m * invB;
+    }
+    if (!valid) dd = 0.f;
+
+    // per-block scalar partials (lanes p == 0 of valid rows contribute)
+    float *part = a.part + (size_t)blockIdx.x * a.partw;
+    {
+        const float w = (valid && p == 0) ? 1.f : 0.f;
+        const float wp = is_pos ? w : 0.f, wn = is_pos ? 0.f : w;
+        float v[12];
+        v[P_BCE_POS] = wp * bce;
+        v[P_BCE_NEG] = wn * bce;
+        v[P_OK_POS] = wp * (o > 0.f ? 1.f : 0.f);
+        v[P_OK_NEG] = wn * (o <= 0.f ? 1.f : 0.f);
+        v[P_D_POS] = wp * d;
+        v[P_D_NEG] = wn * d;
+        v[P_O_POS] = wp * o;
+        v[P_O_NEG] = wn * o;
+        v[P_DTHR] = w * dlo;
+        v[P_HINGE_NEG] = wn * hinge;
+        v[P_SQRT_POS] = wp * sqrtf(d + 1e-7f);
+        v[P_SQRT_NEG] = wn * sqrtf(d + 1e-7f);
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+            float t = sum64(v[i]);
+            if (tid == 0) part[i] = t;
+        }
+    }
+
+    // ---- 4. backward to dL/dY (transposed, scaled for the grad GEMM) ----------
+    // emit(): finish one column: activation grad, weight-norm / input scale,
+    // store dYt, accumulate the block column sums for bias and weight-norm gain.
+    auto emit = [&](const MidSide &sx, const float *A, const float *X, int k, int li, float dA,
+                    float extra_dy) {
+        const int c = k * L + p + 4 * li;
+        const int slot = (k * Lq + li) * 64 + tid;
+        float dy = dA * act_grad(A[slot], a.act) + extra_dy;
+        if (!valid) dy = 0.f;
+        float sc = a.in_mul;
+        if (a.weight_norm) sc *= sx.g[c] / sqrtf(sx.n2[c]);
+        sx.dyt[(size_t)c * a.Rpad + r] = dy * sc;
+        const float sb = sum16(dy);
+        float sw = 0.f;
+        if (a.weight_norm) sw = sum16(dy * X[slot]);
+        if (j == 0) {
+            part[P_NSCALAR + sx.col_off + c] = sb;
+            if (a.weight_norm) part[P_NSCALAR + sx.col_off + sx.npad + c] = sw;
+        }
+    };
+
+    if (a.dist_type == CFL_DIST_PCD) {
+        if (K > 1) {
+            float qbar = 0.f;
+            for (int k = 0; k < K; ++k) {
+                float qk = -2.f * sum4(Kq[k * 64 + tid]);
+                Kq[k * 64 + tid] = qk;
+                qbar = fmaf(Ks[k * 64 + tid], qk, qbar);
+            }
+            for (int k = 0; k < K; ++k)  // dl_k = s_k (q_k - qbar)
+                Kq[k * 64 + tid] = Ks[k * 64 + tid] * (Kq[k * 64 + tid] - qbar);
+            for (int li = 0; li < myL; ++li) {
+                const float v = Ad[li * 64 + tid], rl = Rl[li * 64 + tid];
+                float dv = 2.f * rl;
+                for (int k = 0; k < K; ++k) {
+                    const float vmP = v - As[(k * Lq + li) * 64 + tid];
+                    const float dl = Kq[k * 64 + tid];
+                    dv = fmaf(-2.f * dl, vmP, dv);
+                    const float dP = -2.f * Ks[k * 64 + tid] * rl + 2.f * dl * vmP;
+                    emit(ss, As, Xs, k, li, dP * dd, 0.f);
+                }
+                emit(sd, Ad, Xd, 0, li, dv * dd, 0.f);
+            }
+        } else {
+            for (int li = 0; li < myL; ++li) {
+                const float df = Ad[li * 64 + tid] - As[li * 64 + tid];
+                emit(ss, As, Xs, 0, li, -2.f * df * dd, 0.f);
+                emit(sd, Ad, Xd, 0, li, 2.f * df * dd, 0.f);
+            }
+        }
+    } else if (a.dist_type == CFL_DIST_MONOMER) {
+        // du_k = w_k (e_k - d) dd ; gate-head column sums for dVm, dgm
+        float *mp = part + P_NSCALAR + a.mono_off;
+        for (int k = 0; k < K; ++k) {
+            float du = Ks[k * 64 + tid] * (Ke[k * 64 + tid] - d) * dd;
+            float scm = 1.f;
+            if (a.weight_norm) scm = a.mono_g[k] / sqrtf(a.mono_n2[k]);
+            // weight-norm gain column sum: sum_r du * (ya.Vm)
+            if (a.weight_norm) {
+                const float cw = sum16(p == 0 ? du * Ku[k * 64 + tid] : 0.f);
+                if (tid == 0) mp[L * a.kpad + k] = cw;
+            }
+            Kq[k * 64 + tid] = du * scm;  // grad wrt raw ya.Vm
+        }
+        for (int li = 0; li < myL; ++li) {
+            const int l = p + 4 * li;
+            const float av = As[li * 64 + tid], ya = Rl[li * 64 + tid];
+            float da = 0.f, ex = 0.f;
+            for (int k = 0; k < K; ++k) {
+                const float amP = av - Ad[(k * Lq + li) * 64 + tid];
+                const float w = Ks[k * 64 + tid];
+                da = fmaf(2.f * w, amP, da);
+                emit(sd, Ad, Xd, k, li, -2.f * w * amP * dd, 0.f);
+                const float du = Kq[k * 64 + tid];
+                ex = fmaf(du, a.mono_w[l * a.kpad + k], ex);
+                const float s1 = sum16(ya * du);  // dVm[l][k] block sum
+                if (j == 0) mp[l * a.kpad + k] = s1;
+            }
+            emit(ss, As, Xs, 0, li, da * dd, ex);
+        }
+    } else {
+        for (int li = 0; li < myL; ++li) {
+            const float df = As[li * 64 + tid] - Ad[li * 64 + tid];
+            emit(ss, As, Xs, 0, li, 2.f * df * dd, 0.f);
+            emit(sd, Ad, Xd, 0, li, -2.f * df * dd, 0.f);
+        }
+    }
+    // zero the padding columns of dYt (read by the grad GEMM)
+    for (int side = 0; side < 2; ++side) {
+        const MidSide &sx = a.side[side];
+        for (int c = sx.n + p; c < sx.npad; c += 4) sx.dyt[(size_t)c * a.Rpad + r] = 0.f;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// colnorm (weight-norm): n2[c] = sum_d Wt[c][d]^2   (cfl/layers.py:81)
+// ---------------------------------------------------------------------------
+struct ColnormArgs {
+    const float *theta;
+    float *n2;            // [ncols_total]
+    int nheads;
+    long long w_off[8];
+    int npad[8], n2_off[8], rowlen[8], strided[8], ncol[8];
+    int D;
+};
+
+extern "C" __global__ __launch_bounds__(256) void cfl_colnorm_kernel(ColnormArgs a) {
+    // blockIdx.x enumerates columns over all heads
+    int c = blockIdx.x, h = 0;
+    while (h < a.nheads && c >= a.npad[h]) { c -= a.npad[h]; ++h; }
+    if (h >= a.nheads) return;
+    float acc = 0.f;
+    if (!a.strided[h]) {
+        const float *w = a.theta + a.w_off[h] + (size_t)c * a.rowlen[h];
+        for (int d = threadIdx.x; d < a.rowlen[h]; d += 256) acc = fmaf(w[d], w[d], acc);
+    } else {  // mono head V[L][kpad]: column c strided by kpad
+        const float *w = a.theta + a.w_off[h];
+        for (int l = threadIdx.x; l < a.rowlen[h]; l += 256) {
+            float v = w[l * a.npad[h] + c];
+            acc = fmaf(v, v, acc);
+        }
+    }
+    __shared__ float red[4];
+    acc = sum64(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) a.n2[a.n2_off[h] + c] = red[0] + red[1] + red[2] + red[3];
+}
+
+// ---------------------------------------------------------------------------
+// finalize: slabs + column sums -> flat gradient ; last block -> scalars
+// ---------------------------------------------------------------------------
+enum { RK_ZERO = 0, RK_W, RK_BIAS, RK_GAIN, RK_THR, RK_MONO_W, RK_MONO_G };
+
+struct Region {
+    long long off, cnt;        // floats (64-aligned)
+    int kind, reg;
+    const float *slab[2];      // weight-gradient slabs [P][npad][D] (one per contributing side)
+    int col_off[2];            // column-sum offsets in a part vector (-1: none)
+    int npad, n;               // padded / logical columns of the head
+    const float *g, *n2;       // weight-norm
+};
+
+struct FinArgs {
+    Region reg[CFL_MAX_REGIONS];
+    int nregions;
+    long long total;           // floats in theta
+    const float *theta;
+    float *grad;
+    const float *part;         // [nrb][partw]
+    int partw, nrb, P, D, L, kpad, mono_off, weight_norm;
+    float reg_const;
+    int use_threshold;
+    float pos_weight, caffe_margin, lambda_m;
+    int B;
+    const float *regpart;
+    int nregblocks;
+    float *scalars;
+    long long thr_off;
+    int nblocks_main;
+};
+
+__device__ __forceinline__ float part_colsum(const FinArgs &a, int off) {
+    float s = 0.f;
+    for (int b = 0; b < a.nrb; ++b) s += a.part[(size_t)b * a.partw + P_NSCALAR + off];
+    return s;
+}
+
+extern "C" __global__ __launch_bounds__(256) void cfl_finalize_kernel(FinArgs a) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if ((int)blockIdx.x == a.nblocks_main) {
+        // ---- scalars (cfl/models/cfl.py:868-949) -- one block, fixed order ----
+        __shared__ float sc[P_NSCALAR];
+        if (tid < 12) {
+            float s = 0.f;
+            for (int b = 0; b < a.nrb; ++b) s += a.part[(size_t)b * a.partw + tid];
+            sc[tid] = s;
+        }
+        __shared__ float regsum;
+        if (tid == 64) {
+            float s = 0.f;
+            for (int b = 0; b < a.nregblocks; ++b) s += a.regpart[b];
+            regsum = 0.5f * a.reg_const * s;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            const float invB = 1.f / (float)a.B;
+            const float pw = a.pos_weight != 0.f ? a.pos_weight : 1.f;
+            const float lpos = sc[P_BCE_POS] * invB, lneg = sc[P_BCE_NEG] * invB;
+            const float thres = lpos * pw + lneg;
+            float cd = 0.f;
+            if (a.caffe_margin != 0.f)
+                cd = 0.5f * (sc[P_D_POS] * invB * pw + sc[P_HINGE_NEG] * invB);
+            else if (a.lambda_m != 0.f)
+                cd = sc[P_D_POS] * invB * a.lambda_m * pw;
+            float total = regsum + cd;
+            if (a.use_threshold) total += thres;
+            float *o = a.scalars;
+            o[CFL_S_TOTAL] = total;
+            o[CFL_S_REG] = regsum;
+            o[CFL_S_THRES] = thres;
+            o[CFL_S_LOSS_POS] = lpos;
+            o[CFL_S_LOSS_NEG] = lneg;
+            o[CFL_S_CD] = cd;
+            o[CFL_S_ACCURACY] = 0.5f * (sc[P_OK_POS] * invB + sc[P_OK_NEG] * invB);
+            o[CFL_S_MEAN_D_POS] = sc[P_D_POS] * invB;
+            o[CFL_S_MEAN_D_NEG] = sc[P_D_NEG] * invB;
+            o[CFL_S_MEAN_O_POS] = sc[P_O_POS] * invB;
+            o[CFL_S_MEAN_O_NEG] = sc[P_O_NEG] * invB;
+            o[CFL_S_THRESHOLD] = fmaxf(a.theta[a.thr_off], CFL_THR_FLOOR);
+            o[CFL_S_DIST_ADAPT_POS] = sc[P_SQRT_POS] * invB;
+            o[CFL_S_DIST_ADAPT_NEG] = sc[P_SQRT_NEG] * invB;
+            o[14] = 0.f;
+            o[15] = 0.f;
+        }
+        return;
+    }
+    // main blocks: 4 waves x 4 groups of 64 floats
+    for (int gi = 0; gi < 4; ++gi) {
+        const long long g = ((long long)blockIdx.x * 4 + wave) * 4 + gi;
+        const long long base = g * 64;
+        if (base >= a.total) return;
+        int k = 0;
+        for (; k < a.nregions; ++k)
+            if (base >= a.reg[k].off && base < a.reg[k].off + a.reg[k].cnt) break;
+        const long long idx = base + lane;
+        float gr = 0.f;
+        if (k < a.nregions) {
+            const Region &rg = a.reg[k];
+            const long long rel = idx - rg.off;
+            const float th = a.theta[idx];
+            switch (rg.kind) {
+                case RK_W: {
+                    const int c = (int)(rel / a.D);  // wave-uniform (D % 64 == 0)
+                    for (int s = 0; s < 2; ++s)
+                        if (rg.slab[s]) {
+                            const float *sl = rg.slab[s] + rel;
+                            const long long ps = (long long)rg.npad * a.D;
+                            for (int pp = 0; pp < a.P; ++pp) gr += sl[pp * ps];
+                        }
+                    if (a.weight_norm && c < rg.n) {
+                        float cw = 0.f;
+                        for (int s = 0; s < 2; ++s)
+                            if (rg.col_off[s] >= 0) cw += part_colsum(a, rg.col_off[s] + rg.npad + c);
+                        const float n2 = rg.n2[c], n = sqrtf(n2);
+                        if (n2 > 0.f) gr -= rg.g[c] * cw / (n2 * n) * th;
+                    }
+                    break;
+                }
+                case RK_BIAS: {
+                    const int c = (int)rel;
+                    if (c < rg.n)
+                        for (int s = 0; s < 2; ++s)
+                            if (rg.col_off[s] >= 0) gr += part_colsum(a, rg.col_off[s] + c);
+                    break;
+                }
+                case RK_GAIN: {
+                    const int c = (int)rel;
+                    if (c < rg.n) {
+                        float cw = 0.f;
+                        for (int s = 0; s < 2; ++s)
+                            if (rg.col_off[s] >= 0) cw += part_colsum(a, rg.col_off[s] + rg.npad + c);
+                        const float n2 = rg.n2[c];
+                        gr = n2 > 0.f ? cw / sqrtf(n2) : 0.f;
+                    }
+                    break;
+                }
+                case RK_THR: {
+                    if (rel == 0) {
+                        float s = 0.f;
+                        for (int b = 0; b < a.nrb; ++b) s += a.part[(size_t)b * a.partw + P_DTHR];
+                        gr = th >= CFL_THR_FLOOR ? s : 0.f;
+                    }
+                    break;
+                }
+                case RK_MONO_W: {  // V[L][kpad]
+                    const int l = (int)(rel / a.kpad), kk = (int)(rel % a.kpad);
+                    if (l < a.L && kk < rg.n && rg.col_off[0] >= 0) {
+                        gr = part_colsum(a, rg.col_off[0] + (int)rel);
+                        if (a.weight_norm) {
+                            const float cw = part_colsum(a, rg.col_off[0] + a.L * a.kpad + kk);
+                            const float n2 = rg.n2[kk], n = sqrtf(n2);
+                            if (n2 > 0.f) gr -= rg.g[kk] * cw / (n2 * n) * th;
+                        }
+                    }
+                    break;
+                }
+                case RK_MONO_G: {
+                    const int kk = (int)rel;
+                    if (rg.col_off[0] >= 0 && kk < rg.n) {
+                        const float cw = part_colsum(a, rg.col_off[0] + a.L * a.kpad + kk);
+                        const float n2 = rg.n2[kk];
+                        gr = n2 > 0.f ? cw / sqrtf(n2) : 0.f;
+                    }
+                    break;
+                }
+                default: break;
+            }
+            if (rg.reg) gr = fmaf(a.reg_const, th, gr);
+        }
+        a.grad[idx] = gr;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// TF-1.x Adam, flat
+// ---------------------------------------------------------------------------
+extern "C" __global__ __launch_bounds__(256) void cfl_adam_kernel(float *theta, float *m, float *v,
+                                                                 const float *grad, long long n4,
+                                                                 float lr_t, float b1, float b2,
+                                                                 float eps, float gscale) {
+    long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long stride = (long long)gridDim.x * 256;
+    for (; i < n4; i += stride) {
+        f32x4 g = ((const f32x4 *)grad)[i] * gscale;
+        f32x4 mm = ((f32x4 *)m)[i], vv = ((f32x4 *)v)[i], th = ((f32x4 *)theta)[i];
+        mm = b1 * mm + (1.f - b1) * g;
+        vv = b2 * vv + (1.f - b2) * g * g;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) th[k] -= lr_t * mm[k] / (sqrtf(vv[k]) + eps);
+        ((f32x4 *)m)[i] = mm;
+        ((f32x4 *)v)[i] = vv;
+        ((f32x4 *)theta)[i] = th;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// row gather: out[i,:] = table[idx[i],:]   (one wave per row, 16 B per lane)
+// ---------------------------------------------------------------------------
+extern "C" __global__ __launch_bounds__(256) void cfl_gather_kernel(const float *table,
+                                                                   const long long *idx,
+                                                                   long long n, long long D,
+                                                                   float *out) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    long long row = (long long)blockIdx.x * 4 + wave;
+    const long long stride = (long long)gridDim.x * 4;
+    const long long d4 = D >> 2;
+    for (; row < n; row += stride) {
+        const f32x4 *src = (const f32x4 *)(table + idx[row] * D);
+        f32x4 *dst = (f32x4 *)(out + row * D);
+        for (long long k = lane; k < d4; k += 64) dst[k] = src[k];
+    }
+}
+
+// ===========================================================================
+// host side
+// ===========================================================================
+static int check_shape(const CflShape *s) {
+    if (!s) return set_err(CFL_E_SHAPE, "shape is NULL");
+    if (s->D <= 0 || s->D % 64 != 0)
+        return set_err(CFL_E_SHAPE, "D=%d must be a positive multiple of 64 (pad the inputs)", s->D);
+    if (s->L <= 0 || s->K <= 0) return set_err(CFL_E_SHAPE, "L=%d K=%d must be positive", s->L, s->K);
+    if (s->dist_type < 0 || s->dist_type > 2) return set_err(CFL_E_SHAPE, "bad dist_type %d", s->dist_type);
+    if (s->act_type < 0 || s->act_type > 3) return set_err(CFL_E_SHAPE, "bad act_type %d", s->act_type);
+    if (s->K > 64) return set_err(CFL_E_UNSUPPORTED, "num_components %d > 64", s->K);
+    return CFL_OK;
+}
+
+extern "C" int cfl_version(void) { return CFL_ABI_VERSION; }
+extern "C" const char *cfl_last_error(void) { return g_err; }
+
+extern "C" int cfl_layout(const CflShape *s, CflLayout *out) {
+    int rc = check_shape(s);
+    if (rc) return rc;
+    if (!out) return set_err(CFL_E_SHAPE, "layout out is NULL");
+    memset(out, 0, sizeof(*out));
+    int64_t off = 0;
+    auto head = [&](CflHead &h, int n, bool present, bool bias, bool gain) {
+        h.n = n;
+        h.npad = (int)round_up(n, 16);
+        h.w = h.b = h.g = -1;
+        if (!present) { h.n = h.npad = 0; return; }
+        h.w = off; off += (int64_t)h.npad * s->D;
+        if (bias) { h.b = off; off += round_up(h.npad, 64); }
+        if (gain) { h.g = off; off += round_up(h.npad, 64); }
+    };
+    const int nenc = s->directed ? 2 : 1;
+    const bool proto = s->dist_type != CFL_DIST_SIAMESE;
+    for (int e = 0; e < nenc; ++e) {
+        head(out->enc[e].outputs, s->L, true, s->has_bias, s->weight_norm);
+        head(out->enc[e].proto, s->L * s->K, proto, s->has_bias, s->weight_norm);
+        CflHead &m = out->enc[e].mono;
+        m.w = m.b = m.g = -1; m.n = m.npad = 0;
+        if (s->dist_type == CFL_DIST_MONOMER) {
+            m.n = s->K; m.npad = (int)round_up(s->K, 16);
+            m.w = off; off += round_up((int64_t)s->L * m.npad, 64);
+            if (s->weight_norm) { m.g = off; off += round_up(m.npad, 64); }
+        }
+    }
+    if (!s->directed) out->enc[1] = out->enc[0];
+    out->thr = off; off += 64;
+    out->total = off;
+    return CFL_OK;
+}
+
+// ---- execution plan --------------------------------------------------------
+struct Plan {
+    CflLayout lay;
+    int R, Rpad, S, P, nrb, partw, nregblocks;
+    int src_npad, dst_npad, src_n, dst_n;
+    int col_off[2], mono_off, kpad, Lq;
+    int n2_total;
+    // workspace offsets (floats)
+    size_t ypart[2], dyt[2], wpart[2], part, regpart, n2, total_floats;
+    size_t mid_lds;
+};
+
+static inline int pow2_floor(int x) { int p = 1; while (p * 2 <= x) p *= 2; return p; }
+
+static void side_heads(const CflShape *s, const CflLayout &lay, const CflHead **src,
+                       const CflHead **dst) {
+    switch (s->dist_type) {
+        case CFL_DIST_PCD: *src = &lay.enc[0].proto; *dst = &lay.enc[1].outputs; break;
+        case CFL_DIST_MONOMER: *src = &lay.enc[0].outputs; *dst = &lay.enc[1].proto; break;
+        default: *src = &lay.enc[0].outputs; *dst = &lay.enc[1].outputs; break;
+    }
+}
+
+static int make_plan(const CflShape *s, int64_t rows, int groups, bool train, Plan *pl) {
+    int rc = cfl_layout(s, &pl->lay);
+    if (rc) return rc;
+    if (rows <= 0 || groups < 1 || groups > 2) return set_err(CFL_E_SHAPE, "rows=%lld groups=%d", (long long)rows, groups);
+    if (rows * groups > (1ll << 30)) return set_err(CFL_E_SHAPE, "too many rows");
+    const CflHead *hs, *hd;
+    side_heads(s, pl->lay, &hs, &hd);
+    pl->src_npad = hs->npad; pl->dst_npad = hd->npad; pl->src_n = hs->n; pl->dst_n = hd->n;
+    pl->R = (int)(rows * groups);
+    const int njobs = (hs->npad / 16 + 3) / 4 + (hd->npad / 16 + 3) / 4;
+    // grad row split: aim at >= 512 workgroups, rows per workgroup >= 64
+    int P = 1;
+    if (train) {
+        const int dtiles = s->D / 64;
+        int want = (512 + dtiles * njobs - 1) / (dtiles * njobs);
+        P = pow2_floor(want < 1 ? 1 : want);
+        if (P > 8) P = 8;
+        while (P > 1 && pl->R / P < 64) P /= 2;
+    }
+    pl->P = P;
+    pl->Rpad = (int)round_up(pl->R, 64 * P);
+    // proj d split: aim at >= 512 workgroups, >= one 16-d group per wave
+    const int rtiles = (pl->R + 31) / 32;
+    int S = (512 + rtiles * njobs - 1) / (rtiles * njobs);
+    S = pow2_floor(S < 1 ? 1 : S);
+    const int maxS = s->D / 16 / 8 / 2 > 0 ? s->D / 16 / 8 / 2 : 1;  // >= 2 groups per wave
+    if (S > maxS) S = pow2_floor(maxS);
+    if (S > 16) S = 16;
+    pl->S = S;
+    pl->nrb = pl->Rpad / 16;
+    pl->kpad = pl->lay.enc[0].mono.npad;
+    pl->Lq = (s->L + 3) / 4;
+    pl->col_off[0] = 0;
+    pl->col_off[1] = 2 * hs->npad;
+    pl->mono_off = 2 * hs->npad + 2 * hd->npad;
+    const int mono_sz = s->dist_type == CFL_DIST_MONOMER ? s->L * pl->kpad + pl->kpad : 0;
+    pl->partw = (int)round_up(P_NSCALAR + pl->mono_off + mono_sz, 16);
+    pl->nregblocks = (int)((pl->lay.total / 64 + 63) / 64);
+    pl->n2_total = 0;
+    size_t off = 0;
+    auto take = [&](size_t n) { size_t o = off; off += round_up((int64_t)n, 64); return o; };
+    pl->ypart[0] = take((size_t)S * hs->npad * pl->Rpad);
+    pl->ypart[1] = take((size_t)S * hd->npad * pl->Rpad);
+    if (train) {
+        pl->dyt[0] = take((size_t)hs->npad * pl->Rpad);
+        pl->dyt[1] = take((size_t)hd->npad * pl->Rpad);
+        pl->wpart[0] = take((size_t)P * hs->npad * s->D);
+        pl->wpart[1] = take((size_t)P * hd->npad * s->D);
+        pl->part = take((size_t)pl->nrb * pl->partw);
+        pl->regpart = take((size_t)pl->nregblocks);
+    }
+    pl->n2 = take(6 * 1024);  // squared column norms of up to 6 heads (npad <= 1024 each)
+    pl->total_floats = off;
+    const int ks = s->dist_type == CFL_DIST_PCD ? s->K : 1;
+    const int kd = s->dist_type == CFL_DIST_MONOMER ? s->K : 1;
+    const int slots = (ks + kd) * pl->Lq * (s->weight_norm ? 2 : 1) + pl->Lq + 4 * s->K;
+    pl->mid_lds = (size_t)slots * 64 * sizeof(float);
+    if (pl->mid_lds > 160 * 1024) return set_err(CFL_E_UNSUPPORTED, "L*K too large for the mid kernel");
+    if (hs->npad > 1024 || hd->npad > 1024) return set_err(CFL_E_UNSUPPORTED, "more than 1024 head columns");
+    return CFL_OK;
+}
+
+extern "C" size_t cfl_workspace_bytes(const CflShape *s, int64_t rows, int32_t groups) {
+    Plan pl;
+    if (make_plan(s, rows, groups, groups == 2, &pl)) return 0;
+    return pl.total_floats * sizeof(float);
+}
+
+static NormDev make_norm(const CflNorm *n, float *in_mul) {
+    NormDev d;
+    d.mul = n ? n->mul : 1.f;
+    d.add = n ? n->add : 0.f;
+    d.lo = (n && n->has_lo) ? n->lo : -INFINITY;
+    d.hi = (n && n->has_hi) ? n->hi : INFINITY;
+    d.elementwise = n && (n->add != 0.f || n->has_lo || n->has_hi);
+    *in_mul = d.elementwise ? 1.f : d.mul;
+    return d;
+}
+
+// weight-norm squared column norms for every head of both encoders
+static int launch_colnorm(const CflShape *s, const Plan &pl, const float *theta, float *ws,
+                          int n2_off[2][3], hipStream_t st) {
+    ColnormArgs ca;
+    memset(&ca, 0, sizeof(ca));
+    ca.theta = theta;
+    ca.n2 = ws + pl.n2;
+    ca.D = s->D;
+    int nh = 0, off = 0, ncols = 0;
+    const int nenc = s->directed ? 2 : 1;
+    for (int e = 0; e < 2; ++e) {
+        const CflHead *hh[3] = {&pl.lay.enc[e].outputs, &pl.lay.enc[e].proto, &pl.lay.enc[e].mono};
+        for (int k = 0; k < 3; ++k) {
+            if (e >= nenc) { n2_off[e][k] = n2_off[0][k]; continue; }
+            n2_off[e][k] = -1;
+            if (hh[k]->w < 0) continue;
+            ca.w_off[nh] = hh[k]->w;
+            ca.npad[nh] = hh[k]->npad;
+            ca.n2_off[nh] = off;
+            ca.strided[nh] = k == 2;
+            ca.rowlen[nh] = k == 2 ? s->L : s->D;
+            n2_off[e][k] = off;
+            off += hh[k]->npad;
+            ncols += hh[k]->npad;
+            ++nh;
+        }
+    }
+    ca.nheads = nh;
+    if (s->weight_norm && ncols > 0)
+        hipLaunchKernelGGL(cfl_colnorm_kernel, dim3(ncols), dim3(256), 0, st, ca);
+    return CFL_OK;
+}
+
+struct SideRt {
+    const CflHead *head;
+    int enc;     // encoder index of the head
+    int which;   // 0 outputs, 1 proto
+};
+
+static int run_pairs(const CflShape *s, const CflNorm *norm, const CflLossCfg *loss,
+                     const float *const *x, int groups, int64_t rows, const float *theta,
+                     float *grad, float *scalars, float *scores, float *dists, void *workspace,
+                     size_t workspace_bytes, hipStream_t st) {
+    const bool train = grad != nullptr;
+    Plan pl;
+    int rc = make_plan(s, rows, groups, train, &pl);
+    if (rc) return rc;
+    if (!theta || !workspace) return set_err(CFL_E_SHAPE, "NULL theta/workspace");
+    if (workspace_bytes < pl.total_floats * sizeof(float))
+        return set_err(CFL_E_WORKSPACE, "workspace %zu < %zu bytes", workspace_bytes,
+                       pl.total_floats * sizeof(float));
+    if (((uintptr_t)workspace & 15) || ((uintptr_t)theta & 15))
+        return set_err(CFL_E_SHAPE, "theta / workspace must be 16-byte aligned");
+    for (int i = 0; i < 2 * groups; ++i)
+        if (!x[i] || ((uintptr_t)x[i] & 15)) return set_err(CFL_E_SHAPE, "input %d NULL or misaligned", i);
+    float *ws = (float *)workspace;
+    float in_mul;
+    NormDev nd = make_norm(norm, &in_mul);
+
+    SideRt side[2];
+    switch (s->dist_type) {
+        case CFL_DIST_PCD: side[0] = {&pl.lay.enc[0].proto, 0, 1}; side[1] = {&pl.lay.enc[1].outputs, 1, 0}; break;
+        case CFL_DIST_MONOMER: side[0] = {&pl.lay.enc[0].outputs, 0, 0}; side[1] = {&pl.lay.enc[1].proto, 1, 1}; break;
+        default: side[0] = {&pl.lay.enc[0].outputs, 0, 0}; side[1] = {&pl.lay.enc[1].outputs, 1, 0}; break;
+    }
+    // x layout: train: pos_src,pos_dst,neg_src,neg_dst ; score: src,dst
+    const float *xs[2][2];
+    for (int sd = 0; sd < 2; ++sd) {
+        xs[sd][0] = x[sd];
+        xs[sd][1] = groups == 2 ? x[2 + sd] : x[sd];
+    }
+
+    int n2_off[2][3] = {{-1, -1, -1}, {-1, -1, -1}};
+    launch_colnorm(s, pl, theta, ws, n2_off, st);
+    const float *n2base = ws + pl.n2;
+
+    // ---- proj ---------------------------------------------------------------
+    {
+        ProjArgs pa;
+        memset(&pa, 0, sizeof(pa));
+        int nj = 0;
+        for (int sd = 0; sd < 2; ++sd) {
+            const CflHead *h = side[sd].head;
+            const int tiles = h->npad / 16;
+            for (int c0 = 0; c0 < tiles; c0 += 4) {
+                if (nj >= CFL_MAX_JOBS) return set_err(CFL_E_UNSUPPORTED, "too many column chunks");
+                ProjJob &j = pa.job[nj++];
+                j.x0 = xs[sd][0]; j.x1 = xs[sd][1];
+                j.wt = theta + h->w + (size_t)c0 * 16 * s->D;
+                j.ypart = ws + pl.ypart[sd] + (size_t)c0 * 16 * pl.Rpad;
+                j.sstride = (long long)h->npad * pl.Rpad;
+                j.nt = tiles - c0 < 4 ? tiles - c0 : 4;
+            }
+        }
+        pa.B = (int)rows; pa.R = pl.R; pa.Rpad = pl.Rpad; pa.D = s->D; pa.S = pl.S; pa.norm = nd;
+        dim3 grid((pl.R + 31) / 32, pl.S, nj);
+        hipLaunchKernelGGL(cfl_proj_kernel, grid, dim3(512), 8 * 8 * 64 * sizeof(f32x4), st, pa);
+    }
+
+    // ---- mid ----------------------------------------------------------------
+    int ncolumns_reg = 0;
+    MidArgs ma;
+    memset(&ma, 0, sizeof(ma));
+    for (int sd = 0; sd < 2; ++sd) {
+        const CflHead *h = side[sd].head;
+        MidSide &m = ma.side[sd];
+        m.ypart = ws + pl.ypart[sd];
+        m.sstride = (long long)h->npad * pl.Rpad;
+        m.b = h->b >= 0 ? theta + h->b : nullptr;
+        m.g = h->g >= 0 ? theta + h->g : nullptr;
+        m.n2 = s->weight_norm ? n2base + n2_off[side[sd].enc][side[sd].which] : nullptr;
+        m.dyt = train ? ws + pl.dyt[sd] : nullptr;
+        m.n = h->n; m.npad = h->npad;
+        m.is_proto = side[sd].which == 1;
+        m.col_off = pl.col_off[sd];
+    }
+    const CflHead &mono = pl.lay.enc[0].mono;
+    if (s->dist_type == CFL_DIST_MONOMER) {
+        ma.mono_w = theta + mono.w;
+        ma.mono_g = mono.g >= 0 ? theta + mono.g : nullptr;
+        ma.mono_n2 = s->weight_norm ? n2base + n2_off[0][2] : nullptr;
+    }
+    ma.kpad = pl.kpad; ma.mono_off = pl.mono_off;
+    ma.S = pl.S; ma.L = s->L; ma.K = s->K; ma.Lq = pl.Lq; ma.dist_type = s->dist_type;
+    ma.act = s->act_type; ma.weight_norm = s->weight_norm; ma.in_mul = in_mul;
+    ma.thr = theta + pl.lay.thr;
+    ma.B = (int)rows; ma.R = pl.R; ma.Rpad = pl.Rpad; ma.groups = groups;
+    ma.train = train;
+    if (train) {
+        ma.use_threshold = loss->use_threshold;
+        ma.pos_weight = loss->pos_weight; ma.caffe_margin = loss->caffe_margin; ma.lambda_m = loss->lambda_m;
+        ma.part = ws + pl.part; ma.partw = pl.partw;
+        ma.regpart = ws + pl.regpart;
+        ma.theta = theta;
+    }
+    ma.scores = scores; ma.dists = dists;
+    ma.nrb = train ? pl.nrb : (pl.R + 15) / 16;
+
+    // regions (shared by the mid regulariser blocks and finalize)
+    FinArgs fa;
+    memset(&fa, 0, sizeof(fa));
+    int nreg_blocks = 0;
+    if (train) {
+        int nr = 0;
+        const int nenc = s->directed ? 2 : 1;
+        auto add = [&](int kind, int64_t off, int64_t cnt, int reg, int npad, int n) -> Region & {
+            Region &r = fa.reg[nr++];
+            r.off = off; r.cnt = round_up(cnt, 64); r.kind = kind; r.reg = reg; r.npad = npad; r.n = n;
+            r.slab[0] = r.slab[1] = nullptr; r.col_off[0] = r.col_off[1] = -1;
+            r.g = r.n2 = nullptr;
+            return r;
+        };
+        const int regon = loss->reg_const > 0.f;
+        for (int e = 0; e < nenc; ++e) {
+            const CflHead *hh[2] = {&pl.lay.enc[e].outputs, &pl.lay.enc[e].proto};
+            for (int k = 0; k < 2; ++k) {
+                const CflHead *h = hh[k];
+                if (h->w < 0) continue;
+                Region &rw = add(RK_W, h->w, (int64_t)h->npad * s->D, regon, h->npad, h->n);
+                Region *rb = h->b >= 0 ? &add(RK_BIAS, h->b, h->npad, regon, h->npad, h->n) : nullptr;
+                Region *rgn = h->g >= 0 ? &add(RK_GAIN, h->g, h->npad, 0, h->npad, h->n) : nullptr;
+                int ns = 0;
+                for (int sd = 0; sd < 2; ++sd) {
+                    // a side contributes when it projects through this head
+                    const bool same_enc = s->directed ? side[sd].enc == e : true;
+                    if (side[sd].head->w == h->w && same_enc && side[sd].which == k) {
+                        rw.slab[ns] = ws + pl.wpart[sd];
+                        rw.col_off[ns] = pl.col_off[sd];
+                        if (rb) rb->col_off[ns] = pl.col_off[sd];
+                        if (rgn) rgn->col_off[ns] = pl.col_off[sd];
+                        ++ns;
+                    }
+                }
+                if (s->weight_norm) {
+                    const float *n2p = n2base + n2_off[e][k];
+                    rw.g = theta + h->g; rw.n2 = n2p;
+                    if (rgn) { rgn->g = theta + h->g; rgn->n2 = n2p; }
+                }
+            }
+            const CflHead &m = pl.lay.enc[e].mono;
+            if (m.w >= 0) {
+                Region &rm = add(RK_MONO_W, m.w, (int64_t)s->L * m.npad, regon, m.npad, m.n);
+                if (e == 0) rm.col_off[0] = pl.mono_off;   // the gate head of the SRC encoder is used
+                if (s->weight_norm) { rm.g = theta + m.g; rm.n2 = n2base + n2_off[e][2]; }
+                if (m.g >= 0) {
+                    Region &rmg = add(RK_MONO_G, m.g, m.npad, 0, m.npad, m.n);
+                    if (e == 0) rmg.col_off[0] = pl.mono_off;
+                    rmg.g = theta + m.g; rmg.n2 = n2base + n2_off[e][2];
+                }
+            }
+        }
+        add(RK_THR, pl.lay.thr, 64, 0, 0, 1);
+        fa.nregions = nr;
+        // regulariser ranges for the mid kernel's extra blocks
+        if (regon) {
+            long long groups_total = 0;
+            int k = 0;
+            for (int i = 0; i < nr; ++i)
+                if (fa.reg[i].reg) {
+                    ma.reg_off[k] = fa.reg[i].off; ma.reg_cnt[k] = fa.reg[i].cnt;
+                    groups_total += fa.reg[i].cnt >> 6; ++k;
+                }
+            ma.nreg_ranges = k;
+            ma.reg_total_groups = groups_total;
+            nreg_blocks = (int)((groups_total + 63) / 64);
+            if (nreg_blocks > pl.nregblocks) return set_err(CFL_E_WORKSPACE, "regpart too small");
+        }
+        (void)ncolumns_reg;
+    }
+    hipLaunchKernelGGL(cfl_mid_kernel, dim3(ma.nrb + nreg_blocks), dim3(64), pl.mid_lds, st, ma);
+    if (!train) {
+        HIP_TRY(hipGetLastError());
+        return CFL_OK;
+    }
+
+    // ---- grad ---------------------------------------------------------------
+    {
+        GradArgs ga;
+        memset(&ga, 0, sizeof(ga));
+        int nj = 0;
+        for (int sd = 0; sd < 2; ++sd) {
+            const CflHead *h = side[sd].head;
+            const int tiles = h->npad / 16;
+            for (int c0 = 0; c0 < tiles; c0 += 4) {
+                GradJob &j = ga.job[nj++];
+                j.x0 = xs[sd][0]; j.x1 = xs[sd][1];
+                j.dyt = ws + pl.dyt[sd] + (size_t)c0 * 16 * pl.Rpad;
+                j.wpart = ws + pl.wpart[sd] + (size_t)c0 * 16 * s->D;
+                j.pstride = (long long)h->npad * s->D;
+                j.nt = tiles - c0 < 4 ? tiles - c0 : 4;
+            }
+        }
+        ga.B = (int)rows; ga.R = pl.R; ga.Rpad = pl.Rpad; ga.D = s->D; ga.P = pl.P; ga.norm = nd;
+        dim3 grid(s->D / 64, pl.P, nj);
+        hipLaunchKernelGGL(cfl_grad_kernel, grid, dim3(256), 4 * 4 * 4 * 64 * sizeof(f32x4), st, ga);
+    }
+
+    // ---- finalize -----------------------------------------------------------
+    fa.total = pl.lay.total; fa.theta = theta; fa.grad = grad;
+    fa.part = ws + pl.part; fa.partw = pl.partw; fa.nrb = pl.nrb; fa.P = pl.P; fa.D = s->D;
+    fa.L = s->L; fa.kpad = pl.kpad; fa.mono_off = pl.mono_off; fa.weight_norm = s->weight_norm;
+    fa.reg_const = loss->reg_const; fa.use_threshold = loss->use_threshold;
+    fa.pos_weight = loss->pos_weight; fa.caffe_margin = loss->caffe_margin; fa.lambda_m = loss->lambda_m;
+    fa.B = (int)rows; fa.regpart = ws + pl.regpart; fa.nregblocks = nreg_blocks;
+    fa.scalars = scalars; fa.thr_off = pl.lay.thr;
+    fa.nblocks_main = (int)((pl.lay.total / 64 + 15) / 16);
+    hipLaunchKernelGGL(cfl_finalize_kernel, dim3(fa.nblocks_main + 1), dim3(256), 0, st, fa);
+    HIP_TRY(hipGetLastError());
+    return CFL_OK;
+}
+
+extern "C" int cfl_pair_scores(const CflShape *shape, const CflNorm *norm, const float *xs,
+                               const float *xt, int64_t n, const float *theta, float *scores,
+                               float *dists, void *workspace, size_t workspace_bytes,
+                               cfl_stream_t stream) {
+    if (!scores) return set_err(CFL_E_SHAPE, "scores is NULL");
+    const float *x[2] = {xs, xt};
+    return run_pairs(shape, norm, nullptr, x, 1, n, theta, nullptr, nullptr, scores, dists,
+                     workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+extern "C" int cfl_pair_step_fwd_bwd(const CflShape *shape, const CflNorm *norm,
+                                     const CflLossCfg *loss, const float *const x4[4], int64_t B,
+                                     const float *theta, float *grad, float *scalars,
+                                     void *workspace, size_t workspace_bytes, cfl_stream_t stream) {
+    if (!loss || !x4 || !grad || !scalars) return set_err(CFL_E_SHAPE, "NULL loss/x4/grad/scalars");
+    if (loss->caffe_margin != 0.f && loss->lambda_m != 0.f)
+        return set_err(CFL_E_SHAPE, "caffe_margin and lambda_m are exclusive (cfl/utils.py:72-73)");
+    return run_pairs(shape, norm, loss, x4, 2, B, theta, grad, scalars, nullptr, nullptr, workspace,
+                     workspace_bytes, (hipStream_t)stream);
+}
+
+extern "C" int cfl_adam_tf(float *theta, float *m, float *v, const float *grad, int64_t n,
+                           float lr_t, float beta1, float beta2, float eps, float grad_scale,
+                           cfl_stream_t stream) {
+    if (!theta || !m || !v || !grad) return set_err(CFL_E_SHAPE, "NULL pointer");
+    if (n <= 0 || n % 4) return set_err(CFL_E_SHAPE, "n=%lld must be a positive multiple of 4", (long long)n);
+    const long long n4 = n / 4;
+    int blocks = (int)((n4 + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(cfl_adam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, theta, m, v,
+                       grad, n4, lr_t, beta1, beta2, eps, grad_scale);
+    HIP_TRY(hipGetLastError());
+    return CFL_OK;
+}
+
+extern "C" int cfl_gather_rows(const float *table, const int64_t *idx, int64_t n, int64_t D,
+                               float *out, cfl_stream_t stream) {
+    if (!table || !idx || !out) return set_err(CFL_E_SHAPE, "NULL pointer");
+    if (n <= 0 || D <= 0 || D % 4) return set_err(CFL_E_SHAPE, "n=%lld D=%lld", (long long)n, (long long)D);
+    int blocks = (int)((n + 3) / 4);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(cfl_gather_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, table,
+                       (const long long *)idx, (long long)n, (long long)D, out);
+    HIP_TRY(hipGetLastError());
+    return CFL_OK;
+}

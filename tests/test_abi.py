@@ -1,0 +1,71 @@
+"""CPU-side checks of the C-ABI library: it loads, exports every symbol that
+include/cfl_hip.h declares, and its host-only entry points behave."""
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope='module')
+def H():
+    import __graft_entry__ as g
+    g.build()
+    from cfl import hipabi
+    return hipabi
+
+
+def test_library_exports_every_declared_symbol(H):
+    hdr = open(os.path.join(ROOT, 'include', 'cfl_hip.h')).read()
+    declared = set(re.findall(r'\b(cfl_[a-z_0-9]+)\s*\(', hdr))
+    declared.discard('cfl_stream_t')
+    assert declared == set(H.EXPORTS), declared ^ set(H.EXPORTS)
+    lib = H.lib()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.cfl_version() == 1
+
+
+def test_layout_is_consistent(H):
+    sh = H.make_shape(4096, 20, 3)
+    lay = H.layout(sh)
+    assert lay.enc[0].outputs.n == 20 and lay.enc[0].outputs.npad == 32
+    assert lay.enc[0].proto.n == 60 and lay.enc[0].proto.npad == 64
+    assert lay.enc[0].mono.w == -1
+    assert lay.total % 64 == 0 and lay.thr + 64 == lay.total
+    # heads do not overlap
+    o, p = lay.enc[0].outputs, lay.enc[0].proto
+    assert o.w + o.npad * 4096 <= o.b and o.b + o.npad <= p.w
+    sh = H.make_shape(1024, 64, 3, 'monomer', weight_norm=True, has_bias=False, directed=True)
+    lay = H.layout(sh)
+    assert lay.enc[1].outputs.w > lay.enc[0].mono.g > lay.enc[0].mono.w > 0
+    assert lay.enc[0].outputs.b == -1 and lay.enc[0].outputs.g > 0
+
+
+def test_pack_unpack_roundtrip(H):
+    import numpy as np
+    from oracle import cfl_oracle as O
+    rng = np.random.RandomState(0)
+    for dist, style in (('pcd', 'dist'), ('monomer', 'cfl'), ('siamese', 'cfl')):
+        cfg = O.EncoderCfg(D=128, L=5, K=1 if dist == 'siamese' else 3, dist_type=dist, style=style)
+        p = O.init_encoder_params(cfg, rng)
+        for k in p:
+            p[k] = rng.randn(*p[k].shape).astype(np.float32)
+        sh = H.make_shape(cfg.D, cfg.L, cfg.K, dist, cfg.weight_norm, cfg.has_bias)
+        th = H.pack_theta(sh, p, None, 0.25)
+        q, qd, thr = H.unpack_theta(sh, th)
+        assert qd is None and thr == 0.25
+        assert set(q) == set(p)
+        for k in p:
+            assert np.array_equal(q[k], p[k]), k
+
+
+def test_bad_shapes_return_error_codes(H):
+    with pytest.raises(H.CflHipError, match='multiple of 64'):
+        H.layout(H.make_shape(100, 20, 3))
+    with pytest.raises(H.CflHipError):
+        H.workspace_bytes(H.make_shape(128, 0, 3), 10, 1)
+    with pytest.raises(H.CflHipError, match='no CPU fallback'):
+        import torch
+        H.adam_tf(*(torch.zeros(64) for _ in range(4)), 1e-3, 0.9, 0.999)

@@ -1,0 +1,241 @@
+"""GPU parity: the HIP path (through the C ABI) against the NumPy oracle on the
+same seeded inputs.  Tolerances: the north star asks loss / score parity within
+1e-5 in fp32; gradients are checked relative to the largest gradient entry.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import cfl_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+H = None
+
+
+@pytest.fixture(scope='module', autouse=True)
+def _hip():
+    global H
+    from cfl import hipabi
+    hipabi.lib()                      # raises if the extension is missing
+    assert torch.cuda.is_available(), 'gpu tests need a GPU'
+    H = hipabi
+    yield
+
+
+def _mk(cfg, rng, perturb=0.05):
+    p = O.init_encoder_params(cfg, rng, np.float32)
+    for k in p:
+        p[k] = (p[k] + perturb * rng.randn(*p[k].shape).astype(np.float32) *
+                (0.1 if k.endswith('/W') else 1.0)).astype(np.float32)
+    return p
+
+
+def _shape(cfg, directed=False):
+    return H.make_shape(cfg.D, cfg.L, cfg.K, cfg.dist_type, cfg.weight_norm,
+                        cfg.has_bias, cfg.act_type, directed)
+
+
+def _inputs(rng, n, D, scale):
+    return (np.abs(rng.randn(n, D)) * scale).astype(np.float32)
+
+
+def _to64(p):
+    return None if p is None else {k: v.astype(np.float64) for k, v in p.items()}
+
+
+SCORE_CASES = [
+    # style, dist, D, L, K, act, n, norm
+    ('dist', 'pcd', 4096, 20, 3, None, 500, 58.388599),
+    ('dist', 'pcd', 4096, 10, 4, None, 100, 58.388599),
+    ('dist', 'pcd', 2048, 20, 5, None, 333, 1.0),
+    ('dist', 'pcd', 256, 7, 1, None, 17, 1.0),
+    ('cfl', 'pcd', 1024, 64, 3, None, 250, 31.9098),
+    ('cfl', 'monomer', 1024, 64, 3, None, 250, 31.9098),
+    ('cfl', 'siamese', 1024, 256, 1, None, 129, 31.9098),
+    ('cfl', 'pcd', 512, 20, 4, 'tanh', 64, 1.0),
+    ('cfl', 'monomer', 512, 12, 2, 'sigmoid', 64, 1.0),
+]
+
+
+@pytest.mark.parametrize('style,dist,D,L,K,act,n,nv', SCORE_CASES)
+def test_pair_scores(style, dist, D, L, K, act, n, nv):
+    rng = np.random.RandomState(1234)
+    cfg = O.EncoderCfg(D=D, L=L, K=K, dist_type=dist, style=style, act_type=act)
+    p = _mk(cfg, rng)
+    thr = 0.37
+    xs = _inputs(rng, n, D, nv / 4)
+    xt = _inputs(rng, n, D, nv / 4)
+    ref = O.pair_scores(cfg, _to64(p), np.float64(thr),
+                        xs.astype(np.float64) / nv, xt.astype(np.float64) / nv)
+    sh = _shape(cfg)
+    theta = H.pack_theta(sh, p, None, thr, 'cuda')
+    ws = torch.empty(H.workspace_bytes(sh, n, 1) // 4, dtype=torch.float32, device='cuda')
+    dists = torch.empty(n, device='cuda')
+    got = H.pair_scores(sh, H.make_norm(1.0 / nv), torch.from_numpy(xs).cuda(),
+                        torch.from_numpy(xt).cuda(), theta, ws, dists=dists)
+    got = got.cpu().numpy().astype(np.float64)
+    scale = max(1.0, np.abs(ref).max())
+    assert np.abs(got - ref).max() <= 1e-5 * scale, (np.abs(got - ref).max(), scale)
+    assert np.abs((thr - dists.cpu().numpy()) - got).max() <= 1e-6 * scale
+
+
+def test_pair_scores_elementwise_norm():
+    """clip + mean path of cfl/ops.py:66-124 (not foldable into the epilogue)."""
+    rng = np.random.RandomState(5)
+    D, n = 256, 50
+    cfg = O.EncoderCfg(D=D, L=8, K=2, dist_type='pcd', style='cfl')
+    p = _mk(cfg, rng)
+    xs = rng.randn(n, D).astype(np.float32)
+    xt = rng.randn(n, D).astype(np.float32)
+    f = lambda x: O.normalize_v2(x.astype(np.float64), scale=None, mean=0.5, norm=0.5,
+                                 clip_min=-1.0, clip_max=1.0)
+    ref = O.pair_scores(cfg, _to64(p), np.float64(1e-6), f(xs), f(xt))
+    sh = _shape(cfg)
+    theta = H.pack_theta(sh, p, None, 1e-6, 'cuda')
+    ws = torch.empty(H.workspace_bytes(sh, n, 1) // 4, dtype=torch.float32, device='cuda')
+    got = H.pair_scores(sh, H.make_norm(1 / 0.5, -0.5 / 0.5, -1.0, 1.0),
+                        torch.from_numpy(xs).cuda(), torch.from_numpy(xt).cuda(), theta, ws)
+    assert np.abs(got.cpu().numpy() - ref).max() <= 1e-5 * max(1, np.abs(ref).max())
+
+
+STEP_CASES = [
+    # style, dist, D, L, K, act, B, nv, loss kwargs, directed
+    ('dist', 'pcd', 4096, 20, 3, None, 512, 58.388599, dict(), False),
+    ('dist', 'pcd', 4096, 10, 4, None, 100, 58.388599, dict(reg_const=1e-3), False),
+    ('dist', 'pcd', 2048, 20, 5, None, 96, 1.0, dict(), False),
+    ('dist', 'pcd', 256, 5, 1, None, 33, 1.0, dict(reg_const=1e-2), False),
+    ('cfl', 'pcd', 1024, 64, 3, None, 128, 31.9098,
+     dict(pos_weight=0.0625, lambda_m=0.5, reg_const=5e-4), False),
+    ('cfl', 'pcd', 1024, 16, 2, None, 64, 31.9098, dict(lambda_m=0.5), True),
+    ('cfl', 'monomer', 1024, 64, 3, None, 128, 31.9098, dict(pos_weight=0.0625), False),
+    ('cfl', 'monomer', 512, 12, 2, 'tanh', 40, 1.0, dict(reg_const=1e-3), True),
+    ('cfl', 'siamese', 1024, 256, 1, None, 64, 31.9098,
+     dict(use_threshold=False, caffe_margin=100.0, pos_weight=0.0625), False),
+    ('cfl', 'siamese', 512, 32, 1, 'sigmoid', 48, 1.0, dict(), False),
+    ('cfl', 'pcd', 512, 20, 4, 'relu', 64, 1.0, dict(use_threshold=False, lambda_m=0.3), False),
+]
+
+
+@pytest.mark.parametrize('style,dist,D,L,K,act,B,nv,lkw,directed', STEP_CASES)
+def test_step_fwd_bwd(style, dist, D, L, K, act, B, nv, lkw, directed):
+    rng = np.random.RandomState(4321)
+    cfg = O.EncoderCfg(D=D, L=L, K=K, dist_type=dist, style=style, act_type=act)
+    lcfg = O.LossCfg(**lkw)
+    p = _mk(cfg, rng)
+    pd = _mk(cfg, rng) if directed else None
+    thr = 0.9 if dist != 'siamese' else 40.0
+    batch = tuple(_inputs(rng, B, D, nv / 4) for _ in range(4))
+    b64 = tuple(b.astype(np.float64) / nv for b in batch)
+    sc, g, gd, dthr, dthr_aux = O.train_step_loss_and_grads(
+        cfg, lcfg, _to64(p), np.float64(thr), b64, _to64(pd))
+
+    sh = _shape(cfg, directed)
+    theta = H.pack_theta(sh, p, pd, thr, 'cuda')
+    grad = torch.full_like(theta, float('nan'))
+    scal = torch.zeros(H.S_COUNT, device='cuda')
+    ws = torch.empty(H.workspace_bytes(sh, B, 2) // 4, dtype=torch.float32, device='cuda')
+    ws.fill_(float('nan'))            # poison: nothing may depend on stale scratch
+    H.pair_step_fwd_bwd(sh, H.make_norm(1.0 / nv), H.make_loss(**lkw),
+                        [torch.from_numpy(b).cuda() for b in batch], theta, grad, scal, ws)
+    torch.cuda.synchronize()
+    s = dict(zip(H.SCALAR_NAMES, scal.cpu().numpy().astype(np.float64)))
+    for k in ('total', 'reg', 'thres', 'loss_pos', 'loss_neg', 'cd', 'accuracy',
+              'mean_d_pos', 'mean_d_neg'):
+        ref = float(sc[k])
+        assert abs(s[k] - ref) <= 1e-5 * max(1.0, abs(ref)), (k, s[k], ref)
+    assert not torch.isnan(grad).any()
+    gp, gpd, gthr = H.unpack_theta(sh, grad)
+    want_thr = dthr if lcfg.use_threshold else dthr_aux
+    assert abs(gthr - want_thr) <= 1e-5 * max(1.0, abs(want_thr)), (gthr, want_thr)
+    for got, ref in ((gp, g), (gpd, gd)):
+        if ref is None:
+            continue
+        for k in got:
+            r = np.asarray(ref.get(k, np.zeros_like(got[k])), dtype=np.float64)
+            scale = max(np.abs(r).max(), 1e-6)
+            err = np.abs(got[k] - r).max()
+            assert err <= 2e-4 * scale, (k, err, scale)
+
+
+def test_adam_tf_flat():
+    rng = np.random.RandomState(0)
+    n = 64 * 1000
+    th = rng.randn(n).astype(np.float32)
+    m = (0.1 * rng.randn(n)).astype(np.float32)
+    v = np.abs(0.01 * rng.randn(n)).astype(np.float32)
+    g = rng.randn(n).astype(np.float32)
+    ref = O.adam_tf_flat(th.astype(np.float64), m.astype(np.float64), v.astype(np.float64),
+                         0.5 * g.astype(np.float64), 3e-3, 0.9, 0.999, 1e-8)
+    t, tm, tv, tg = (torch.from_numpy(a.copy()).cuda() for a in (th, m, v, g))
+    H.adam_tf(t, tm, tv, tg, 3e-3, 0.9, 0.999, 1e-8, grad_scale=0.5)
+    for got, r in zip((t, tm, tv), ref):
+        assert np.abs(got.cpu().numpy() - r).max() <= 1e-6 * max(1, np.abs(r).max())
+
+
+def test_gather_rows_bit_exact():
+    rng = np.random.RandomState(3)
+    table = rng.randn(1000, 4096).astype(np.float32)
+    idx = rng.randint(0, 1000, size=777).astype(np.int64)
+    got = H.gather_rows(torch.from_numpy(table).cuda(), torch.from_numpy(idx).cuda())
+    assert np.array_equal(got.cpu().numpy(), table[idx])
+
+
+@pytest.mark.parametrize('style,dist,K,L,lkw', [
+    ('dist', 'pcd', 3, 20, dict()),
+    ('cfl', 'pcd', 3, 16, dict(pos_weight=0.25, lambda_m=0.5, reg_const=5e-4)),
+    ('cfl', 'monomer', 2, 12, dict()),
+])
+def test_training_trajectory(style, dist, K, L, lkw):
+    """Per-step loss within 1e-5 of the fp64 oracle over 40 Adam steps on identical
+    batches, and final scores / AUC within 1e-4 (north star)."""
+    rng = np.random.RandomState(99)
+    D, B, nv, steps = 1024, 128, 8.0, 40
+    cfg = O.EncoderCfg(D=D, L=L, K=K, dist_type=dist, style=style)
+    lcfg = O.LossCfg(**lkw)
+    p = O.init_encoder_params(cfg, rng, np.float32)
+    tr = O.OracleTrainer(cfg, lcfg, lr=1e-3, dtype=np.float64, params=_to64(p))
+    A = (rng.randn(D, D) * 0.03).astype(np.float32)
+    def batch():
+        xs = _inputs(rng, B, D, 2.0)
+        xp = np.abs(xs @ A + 0.1 * rng.randn(B, D)).astype(np.float32)
+        return xs, xp, _inputs(rng, B, D, 2.0), _inputs(rng, B, D, 2.0)
+    sh = _shape(cfg)
+    theta = H.pack_theta(sh, p, None, 1e-6, 'cuda')
+    m = torch.zeros_like(theta)
+    v = torch.zeros_like(theta)
+    grad = torch.zeros_like(theta)
+    scal = torch.zeros(H.S_COUNT, device='cuda')
+    ws = torch.empty(H.workspace_bytes(sh, B, 2) // 4, dtype=torch.float32, device='cuda')
+    norm, loss = H.make_norm(1.0 / nv), H.make_loss(**lkw)
+    b1p, b2p = np.float32(0.9), np.float32(0.999)
+    for it in range(steps):
+        b = batch()
+        sc = tr.step(tuple(x.astype(np.float64) / nv for x in b))
+        H.pair_step_fwd_bwd(sh, norm, loss, [torch.from_numpy(x).cuda() for x in b],
+                            theta, grad, scal, ws)
+        lr_t = np.float32(1e-3) * np.sqrt(np.float32(1) - b2p) / (np.float32(1) - b1p)
+        H.adam_tf(theta, m, v, grad, lr_t, 0.9, 0.999, 1e-8)
+        b1p, b2p = np.float32(b1p * np.float32(0.9)), np.float32(b2p * np.float32(0.999))
+        got = float(scal[0].item())
+        assert abs(got - sc['total']) <= 1e-5 * max(1.0, abs(sc['total'])), (it, got, sc['total'])
+    xs, xp, xn1, xn2 = batch()
+    ws2 = torch.empty(H.workspace_bytes(sh, B, 1) // 4, dtype=torch.float32, device='cuda')
+    sp = H.pair_scores(sh, norm, torch.from_numpy(xs).cuda(), torch.from_numpy(xp).cuda(), theta, ws2).cpu().numpy()
+    sn = H.pair_scores(sh, norm, torch.from_numpy(xn1).cuda(), torch.from_numpy(xn2).cuda(), theta, ws2).cpu().numpy()
+    rp = tr.scores(xs.astype(np.float64) / nv, xp.astype(np.float64) / nv)
+    rn = tr.scores(xn1.astype(np.float64) / nv, xn2.astype(np.float64) / nv)
+    assert np.abs(sp - rp).max() <= 1e-4 * max(1, np.abs(rp).max())
+    ev_h, ev_o = O.dist_eval(sp, sn), O.dist_eval(rp, rn)
+    assert abs(ev_h['auc'] - ev_o['auc']) <= 1e-4
+
+
+def test_errors_are_reported_not_thrown():
+    sh = H.make_shape(4096, 20, 3)
+    ws = torch.empty(16, dtype=torch.float32, device='cuda')
+    theta = torch.zeros(H.layout(sh).total, device='cuda')
+    x = torch.zeros(8, 4096, device='cuda')
+    with pytest.raises(H.CflHipError, match='workspace'):
+        H.pair_scores(sh, H.make_norm(), x, x, theta, ws)
+    with pytest.raises(H.CflHipError, match='no CPU fallback'):
+        H.pair_scores(sh, H.make_norm(), x.cpu(), x.cpu(), theta, ws)
