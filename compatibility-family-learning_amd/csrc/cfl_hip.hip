@@ -433,6 +433,7 @@ extern "C" __global__ __launch_bounds__(64) void cfl_mid_kernel(MidArgs a) {
                 const float *yp = sx.ypart + (size_t)c * a.Rpad + r;
                 float y = 0.f;
                 for (int s = 0; s < a.S; ++s) y += yp[(size_t)s * sx.sstride];
+                if (!valid) y = 0.f;  // rows >= R of the scratch slabs are never written
                 const float xv = y * a.in_mul;
                 float sc = 1.f;
                 if (a.weight_norm) sc = sx.g[c] / sqrtf(sx.n2[c]);
