@@ -1,0 +1,234 @@
+#!/usr/bin/env python
+"""bench.py -- training throughput of the cfl pair-distance hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): Amazon also_viewed / Monomer-style 4096-d
+image features, PCD K=3, latent_size L=20 (the reference default, cfl/utils.py:520),
+batch 512 rows per GPU per step, model = `Dist` of cfl/models/dist.py (plain FC
+heads + biases, learned-threshold sigmoid-CE), normalize_value 58.388599, TF-Adam
+lr 1e-3.  A "step" = forward + backward + Adam over one row batch of 4 x [512, 4096]
+fp32 inputs already resident in HBM.  Batches rotate through a pool larger than
+the 256 MiB Infinity Cache so the input stream really comes from HBM.
+
+N > 1: one process per GPU (torchrun), weak scaling (512 rows per GPU), one RCCL
+all-reduce of the flat fp32 gradient per step.
+
+Prints ONE JSON line (rank 0) with the driver's contract fields plus `roofline`
+(dominant kernel, HIP-event timed) and `cpu_baseline` (NumPy oracle on host cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, 'compatibility-family-learning_amd')
+for _p in (ROOT, PKG):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+FP32_MFMA_PEAK_TF = 157.3  # dense fp32 MFMA peak (same guide)
+NORMALIZE_VALUE = 58.388599
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=2000)
+    ap.add_argument('--warmup', type=int, default=200)
+    ap.add_argument('--batch-size', type=int, default=512)
+    ap.add_argument('--input-size', type=int, default=4096)
+    ap.add_argument('--num-components', type=int, default=3)
+    ap.add_argument('--latent-size', type=int, default=20)
+    ap.add_argument('--pool-mib', type=int, default=384,
+                    help='resident batch pool per GPU (> 256 MiB Infinity Cache)')
+    ap.add_argument('--cpu-seconds', type=float, default=10.0)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-kernel-profile', action='store_true')
+    return ap.parse_args()
+
+
+def make_pool(B, D, nbatches, device, seed):
+    """Synthetic post-ReLU-like CNN features: |N(0,1)| scaled so that max ~ the
+    Monomer normalize_value; positives planted by a hidden linear
+    teacher so that the loss is not degenerate."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    s = NORMALIZE_VALUE / 4.5
+    pool = []
+    teacher = torch.randn(D, 64, generator=g, device=device) / D ** 0.5
+    back = torch.randn(64, D, generator=g, device=device) / 8.0
+    for _ in range(nbatches):
+        ps = torch.randn(B, D, generator=g, device=device).abs_() * s
+        pd = ((ps @ teacher) @ back + 0.3 * s * torch.randn(B, D, generator=g, device=device)).abs_()
+        ns = torch.randn(B, D, generator=g, device=device).abs_() * s
+        ndd = torch.randn(B, D, generator=g, device=device).abs_() * s
+        pool.append((ps.contiguous(), pd.contiguous(), ns.contiguous(), ndd.contiguous()))
+    return pool
+
+
+def cpu_baseline(args, seconds):
+    """The oracle (a NumPy port of the reference step: fwd + analytic bwd + TF-Adam,
+    fp32) timed on this box's host cores on a bounded sample of the same workload."""
+    from oracle import cfl_oracle as O
+    rng = np.random.RandomState(0)
+    B, D = args.batch_size, args.input_size
+    cfg = O.EncoderCfg(D=D, L=args.latent_size, K=args.num_components)
+    tr = O.OracleTrainer(cfg, O.LossCfg(), lr=1e-3, dtype=np.float32)
+    batch = tuple((np.abs(rng.randn(B, D)) * (1 / 4.5)).astype(np.float32) for _ in range(4))
+    tr.step(batch)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        tr.step(batch)
+        n += 1
+        el = time.perf_counter() - t0
+        if el >= seconds and n >= 3:
+            break
+    try:
+        from threadpoolctl import threadpool_info
+        cores = max([i.get('num_threads', 1) for i in threadpool_info()] or [1])
+    except Exception:
+        cores = os.cpu_count()
+    return {'value': round(n * B / el, 1), 'unit': 'triplets/s', 'cores': int(cores),
+            'kind': 'port',
+            'sample': '%d steps of batch %d (%.1f s) of the same 4096-d K=%d L=%d step, '
+                      'NumPy fp32 oracle (fwd+bwd+TF-Adam)' % (
+                          n, B, el, args.num_components, args.latent_size)}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        dist.init_process_group('nccl', rank=rank, world_size=world)
+    if args.gpus != world and rank == 0 and world > 1:
+        print('warning: --gpus %d but WORLD_SIZE %d' % (args.gpus, world), file=sys.stderr)
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+
+    from cfl import hipabi as H
+    from cfl.engine import PairEngine
+    from oracle import cfl_oracle as O  # initial weights only (Xavier, seed 0)
+
+    B, D, K, L = args.batch_size, args.input_size, args.num_components, args.latent_size
+    cfg = O.EncoderCfg(D=D, L=L, K=K)
+    params = O.init_encoder_params(cfg, np.random.RandomState(0), np.float32)
+    eng = PairEngine(D, L, K, 'pcd', weight_norm=False, has_bias=True,
+                     norm=H.make_norm(1.0 / NORMALIZE_VALUE), loss=H.make_loss(),
+                     lr=1e-3, device=device, params=params, batch_size=B)
+
+    batch_bytes = 4 * B * D * 4
+    nb = max(2, (args.pool_mib * (1 << 20) + batch_bytes - 1) // batch_bytes)
+    pool = make_pool(B, D, nb, device, seed=633 + rank)
+
+    def run(nsteps, start):
+        for i in range(nsteps):
+            eng.step(pool[(start + i) % nb])
+
+    run(args.warmup, 0)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(args.steps, args.warmup)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    scal = eng.read_scalars()
+
+    out = None
+    if rank == 0:
+        rows = args.steps * B * world
+        out = {
+            'metric': 'triplets/sec',
+            'value': round(rows / elapsed, 1),
+            'unit': 'triplets/s',
+            'n_gpus': world,
+            'steps': args.steps,
+            'warmup': args.warmup,
+            'ms_per_step': round(1e3 * elapsed / args.steps, 5),
+            'higher_is_better': True,
+            'scaling': 'weak',
+            'vs_baseline': None,
+            'dtype': 'f32',
+            'data': 'synthetic',
+            'config': {
+                'workload': 'Monomer-style 4096-d image features, PCD K=%d L=%d, batch %d rows '
+                            '(4x[%d,%d] f32) per GPU per step, Dist model (FC heads+bias, '
+                            'thr-BCE), fwd+bwd+TF-Adam' % (K, L, B, B, D),
+                'input_size': D, 'num_components': K, 'latent_size': L,
+                'batch_rows_per_gpu': B, 'global_batch_rows': B * world,
+                'pool_mib_per_gpu': int(nb * batch_bytes >> 20),
+                'parallelism': 'dp%d' % world if world > 1 else 'single',
+                'final_loss': round(scal['total'], 6),
+            },
+        }
+
+    # ---- roofline of the dominant kernel: HIP events on the launch stream, a
+    # second pass of the same K steps (events perturb the step time slightly, so
+    # they are kept out of the pass that produces `value`) ----------------------
+    if rank == 0 and not args.no_kernel_profile:
+        H.profile_enable(True)
+        run(min(args.steps, 500), args.warmup + args.steps)
+        torch.cuda.synchronize()
+        H.profile_enable(False)
+        prof = H.profile_read()
+        kern = {k: {'avg_us': round(1e3 * ms / n, 3), 'launches': int(n)} for k, (ms, n) in prof.items()}
+        dom = max(('proj', 'grad'), key=lambda k: prof.get(k, (0, 1))[0])
+        avg_s = prof[dom][0] / prof[dom][1] * 1e-3
+        alg_bytes = 16.0 * D * B                       # 4 fp32 vectors per row, read once
+        alg_flops = 4.0 * D * L * (K + 1) * B          # one of fwd / dW: half of 8*D*L*(K+1)
+        traffic = None
+        tp = os.path.join(ROOT, 'profiles', 'traffic.json')
+        if os.path.exists(tp):
+            try:
+                traffic = json.load(open(tp)).get(dom)
+            except Exception:
+                traffic = None
+        out['roofline'] = {
+            'kernel': 'cfl_%s_kernel' % dom,
+            'bound': 'hbm',
+            'achieved': round(alg_bytes / avg_s / 1e9, 1),
+            'peak': HBM_PEAK_GBS,
+            'unit': 'GB/s',
+            'frac': round(alg_bytes / avg_s / 1e9 / HBM_PEAK_GBS, 4),
+            'traffic': traffic,
+            'avg_launch_us': round(avg_s * 1e6, 3),
+            'algorithmic_bytes_per_launch': alg_bytes,
+            'mfma_f32': {'achieved_tflops': round(alg_flops / avg_s / 1e12, 2),
+                         'peak_tflops': FP32_MFMA_PEAK_TF,
+                         'frac': round(alg_flops / avg_s / 1e12 / FP32_MFMA_PEAK_TF, 4)},
+            'kernels': kern,
+            'timing': 'hipEvent pairs around every launch, separate pass of %d steps' % min(args.steps, 500),
+        }
+    if rank == 0 and not args.no_cpu_baseline and world == 1:
+        out['cpu_baseline'] = cpu_baseline(args, args.cpu_seconds)
+    elif rank == 0:
+        out['cpu_baseline'] = None
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,118 @@
+"""PairEngine: device state + step driver of the pair-distance hot path.
+
+Owns the flat parameter array ``theta`` (layout: include/cfl_hip.h), its Adam
+slots, the flat gradient, the scalar read-back buffer and the scratch workspace,
+and drives one training step as
+
+    cfl_pair_step_fwd_bwd  ->  [RCCL all-reduce of the flat gradient]  ->  cfl_adam_tf
+
+which replaces the per-iteration ``sess.run([summary, [s_optim], ...])`` of
+cfl/bin/train_dist.py:81-82 and cfl/models/cfl.py:1399-1414.  Data parallelism
+(one process per GPU, torch.distributed backend "nccl" = RCCL over xGMI) is new
+functionality: the reference is single-device.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import hipabi as H
+
+
+class PairEngine(object):
+    def __init__(self, D, L, K, dist_type='pcd', weight_norm=False, has_bias=True,
+                 act_type=None, directed=False, norm=None, loss=None, lr=1e-3,
+                 beta1=0.9, beta2=0.999, eps=1e-8, device='cuda', params=None,
+                 params_dst=None, thr=1e-6, batch_size=None):
+        H.lib()
+        self.shape = H.make_shape(D, L, K, dist_type, weight_norm, has_bias, act_type, directed)
+        self.layout = H.layout(self.shape)
+        self.norm = norm if norm is not None else H.make_norm()
+        self.loss = loss if loss is not None else H.make_loss()
+        self.lr, self.beta1, self.beta2, self.eps = lr, beta1, beta2, eps
+        self.device = torch.device(device)
+        if self.device.type != 'cuda':
+            raise H.CflHipError('PairEngine runs on a HIP device only (no CPU fallback)')
+        self.theta = H.pack_theta(self.shape, params, params_dst, thr, self.device)
+        self.m = torch.zeros_like(self.theta)
+        self.v = torch.zeros_like(self.theta)
+        self.grad = torch.zeros_like(self.theta)
+        self.scalars = torch.zeros(H.S_COUNT, dtype=torch.float32, device=self.device)
+        # TF keeps beta1_power / beta2_power as float32 variables
+        self.beta1_power = np.float32(beta1)
+        self.beta2_power = np.float32(beta2)
+        self.global_step = 0
+        self._ws = {}
+        if batch_size:
+            self._workspace(batch_size, 2)
+
+    # -- plumbing ----------------------------------------------------------
+    def _workspace(self, rows, groups):
+        key = (int(rows), int(groups))
+        ws = self._ws.get(key)
+        if ws is None:
+            n = H.workspace_bytes(self.shape, rows, groups)
+            ws = torch.empty(n // 4, dtype=torch.float32, device=self.device)
+            self._ws = {k: v for k, v in self._ws.items() if k[1] != groups or k == key}
+            self._ws[key] = ws
+        return ws
+
+    def lr_t(self):
+        one = np.float32(1)
+        return float(np.float32(self.lr) * np.sqrt(one - self.beta2_power) /
+                     (one - self.beta1_power))
+
+    @property
+    def world_size(self):
+        return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+    # -- the hot path ------------------------------------------------------
+    def fwd_bwd(self, batch):
+        """batch = (pos_src, pos_dst, neg_src, neg_dst) device tensors [B, D]."""
+        ws = self._workspace(batch[0].shape[0], 2)
+        H.pair_step_fwd_bwd(self.shape, self.norm, self.loss, batch, self.theta,
+                            self.grad, self.scalars, ws)
+
+    def apply_adam(self, grad_scale=1.0):
+        H.adam_tf(self.theta, self.m, self.v, self.grad, self.lr_t(), self.beta1,
+                  self.beta2, self.eps, grad_scale)
+        self.beta1_power = np.float32(self.beta1_power * np.float32(self.beta1))
+        self.beta2_power = np.float32(self.beta2_power * np.float32(self.beta2))
+        self.global_step += 1
+
+    def step(self, batch):
+        """One training step on this rank's shard of the row batch."""
+        self.fwd_bwd(batch)
+        n = self.world_size
+        if n > 1:
+            # one exchange per step: sum of the flat fp32 gradient over xGMI
+            dist.all_reduce(self.grad, op=dist.ReduceOp.SUM)
+        self.apply_adam(1.0 / n)
+
+    def read_scalars(self):
+        """Host copy of the last step's scalars (synchronises the stream)."""
+        vals = self.scalars.cpu().numpy()
+        return dict(zip(H.SCALAR_NAMES, (float(x) for x in vals)))
+
+    def scores(self, xs, xt):
+        """max(thr,1e-6) - dist(src, dst), the value the reference fetches as
+        ``val_s_pos_predicts.outputs`` (cfl/utils.py:245)."""
+        ws = self._workspace(xs.shape[0], 1)
+        return H.pair_scores(self.shape, self.norm, xs, xt, self.theta, ws)
+
+    # -- checkpoint payload --------------------------------------------------
+    def state_dict(self):
+        return dict(theta=self.theta.cpu(), m=self.m.cpu(), v=self.v.cpu(),
+                    beta1_power=float(self.beta1_power), beta2_power=float(self.beta2_power),
+                    global_step=self.global_step)
+
+    def load_state_dict(self, sd):
+        self.theta.copy_(sd['theta'])
+        self.m.copy_(sd['m'])
+        self.v.copy_(sd['v'])
+        self.beta1_power = np.float32(sd['beta1_power'])
+        self.beta2_power = np.float32(sd['beta2_power'])
+        self.global_step = int(sd['global_step'])
+
+    def named_variables(self):
+        p, pd, thr = H.unpack_theta(self.shape, self.theta)
+        return p, pd, thr

@@ -56,7 +56,10 @@ class CflLossCfg(C.Structure):
 
 EXPORTS = ('cfl_version', 'cfl_last_error', 'cfl_layout', 'cfl_workspace_bytes',
            'cfl_pair_scores', 'cfl_pair_step_fwd_bwd', 'cfl_adam_tf',
-           'cfl_gather_rows')
+           'cfl_gather_rows', 'cfl_profile_enable', 'cfl_profile_read')
+
+KERNEL_NAMES = ('colnorm', 'proj', 'mid', 'grad', 'finalize', 'adam', 'gather')
+K_COUNT = 8
 
 _lib = None
 
@@ -97,6 +100,8 @@ def lib():
     L.cfl_gather_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64,
                                   C.c_void_p, C.c_void_p]
     L.cfl_gather_rows.restype = C.c_int
+    L.cfl_profile_enable.argtypes = [C.c_int]
+    L.cfl_profile_read.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     if L.cfl_version() != 1:
         raise CflHipError('libcfl_hip.so ABI version mismatch')
     _lib = L
@@ -178,6 +183,18 @@ def adam_tf(theta, m, v, grad, lr_t, beta1, beta2, eps=1e-8, grad_scale=1.0):
     _check(lib().cfl_adam_tf(_dev(theta), _dev(m), _dev(v), _dev(grad), theta.numel(),
                              float(lr_t), float(beta1), float(beta2), float(eps),
                              float(grad_scale), _stream()))
+
+
+def profile_enable(on):
+    lib().cfl_profile_enable(int(bool(on)))
+
+
+def profile_read():
+    """{kernel: (total_ms, launches)} since the last read (synchronises)."""
+    ms = (C.c_double * K_COUNT)()
+    cnt = (C.c_int64 * K_COUNT)()
+    _check(lib().cfl_profile_read(ms, cnt))
+    return {KERNEL_NAMES[i]: (ms[i], cnt[i]) for i in range(len(KERNEL_NAMES)) if cnt[i]}
 
 
 def gather_rows(table, idx, out=None):

@@ -53,6 +53,51 @@ static int set_err(int code, const char *fmt, ...) {
             return set_err(CFL_E_HIP, "%s failed: %s", #expr, hipGetErrorString(_e)); \
     } while (0)
 
+// ---------------------------------------------------------------------------
+// optional per-kernel event timing (cfl_profile_enable / cfl_profile_read)
+// ---------------------------------------------------------------------------
+#include <mutex>
+#include <vector>
+struct ProfRec { int kind; hipEvent_t a, b; };
+static bool g_prof_on = false;
+static std::vector<ProfRec> g_prof;
+static std::mutex g_prof_mu;
+
+struct ProfScope {
+    hipStream_t st; int kind; hipEvent_t a = nullptr, b = nullptr; bool on;
+    ProfScope(hipStream_t s, int k) : st(s), kind(k), on(g_prof_on) {
+        if (on) {
+            (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+            (void)hipEventRecord(a, st);
+        }
+    }
+    ~ProfScope() {
+        if (on) {
+            (void)hipEventRecord(b, st);
+            std::lock_guard<std::mutex> lk(g_prof_mu);
+            g_prof.push_back({kind, a, b});
+        }
+    }
+};
+
+extern "C" int cfl_profile_enable(int on) { g_prof_on = on != 0; return CFL_OK; }
+
+extern "C" int cfl_profile_read(double *ms_sum, int64_t *launches) {
+    if (!ms_sum || !launches) return CFL_E_SHAPE;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (auto &r : g_prof) {
+        float ms = 0.f;
+        (void)hipEventSynchronize(r.b);
+        if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess && r.kind >= 0 && r.kind < CFL_K_COUNT) {
+            ms_sum[r.kind] += ms;
+            launches[r.kind] += 1;
+        }
+        (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
+    }
+    g_prof.clear();
+    return CFL_OK;
+}
+
 static inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 
 // ---------------------------------------------------------------------------
@@ -1108,8 +1153,10 @@ static int launch_colnorm(const CflShape *s, const Plan &pl, const float *theta,
         }
     }
     ca.nheads = nh;
-    if (s->weight_norm && ncols > 0)
+    if (s->weight_norm && ncols > 0) {
+        ProfScope ps(st, CFL_K_COLNORM);
         hipLaunchKernelGGL(cfl_colnorm_kernel, dim3(ncols), dim3(256), 0, st, ca);
+    }
     return CFL_OK;
 }
 
@@ -1176,6 +1223,7 @@ static int run_pairs(const CflShape *s, const CflNorm *norm, const CflLossCfg *l
         }
         pa.B = (int)rows; pa.R = pl.R; pa.Rpad = pl.Rpad; pa.D = s->D; pa.S = pl.S; pa.norm = nd;
         dim3 grid((pl.R + 31) / 32, pl.S, nj);
+        ProfScope ps(st, CFL_K_PROJ);
         hipLaunchKernelGGL(cfl_proj_kernel, grid, dim3(512), 8 * 8 * 64 * sizeof(f32x4), st, pa);
     }
 
@@ -1289,7 +1337,10 @@ static int run_pairs(const CflShape *s, const CflNorm *norm, const CflLossCfg *l
         }
         (void)ncolumns_reg;
     }
-    hipLaunchKernelGGL(cfl_mid_kernel, dim3(ma.nrb + nreg_blocks), dim3(64), pl.mid_lds, st, ma);
+    {
+        ProfScope ps(st, CFL_K_MID);
+        hipLaunchKernelGGL(cfl_mid_kernel, dim3(ma.nrb + nreg_blocks), dim3(64), pl.mid_lds, st, ma);
+    }
     if (!train) {
         HIP_TRY(hipGetLastError());
         return CFL_OK;
@@ -1314,6 +1365,7 @@ static int run_pairs(const CflShape *s, const CflNorm *norm, const CflLossCfg *l
         }
         ga.B = (int)rows; ga.R = pl.R; ga.Rpad = pl.Rpad; ga.D = s->D; ga.P = pl.P; ga.norm = nd;
         dim3 grid(s->D / 64, pl.P, nj);
+        ProfScope ps(st, CFL_K_GRAD);
         hipLaunchKernelGGL(cfl_grad_kernel, grid, dim3(256), 4 * 4 * 4 * 64 * sizeof(f32x4), st, ga);
     }
 
@@ -1326,7 +1378,10 @@ static int run_pairs(const CflShape *s, const CflNorm *norm, const CflLossCfg *l
     fa.B = (int)rows; fa.regpart = ws + pl.regpart; fa.nregblocks = nreg_blocks;
     fa.scalars = scalars; fa.thr_off = pl.lay.thr;
     fa.nblocks_main = (int)((pl.lay.total / 64 + 15) / 16);
-    hipLaunchKernelGGL(cfl_finalize_kernel, dim3(fa.nblocks_main + 1), dim3(256), 0, st, fa);
+    {
+        ProfScope ps(st, CFL_K_FINALIZE);
+        hipLaunchKernelGGL(cfl_finalize_kernel, dim3(fa.nblocks_main + 1), dim3(256), 0, st, fa);
+    }
     HIP_TRY(hipGetLastError());
     return CFL_OK;
 }
@@ -1360,8 +1415,11 @@ extern "C" int cfl_adam_tf(float *theta, float *m, float *v, const float *grad, 
     const long long n4 = n / 4;
     int blocks = (int)((n4 + 255) / 256);
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(cfl_adam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, theta, m, v,
-                       grad, n4, lr_t, beta1, beta2, eps, grad_scale);
+    {
+        ProfScope ps((hipStream_t)stream, CFL_K_ADAM);
+        hipLaunchKernelGGL(cfl_adam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, theta, m,
+                           v, grad, n4, lr_t, beta1, beta2, eps, grad_scale);
+    }
     HIP_TRY(hipGetLastError());
     return CFL_OK;
 }
@@ -1372,8 +1430,11 @@ extern "C" int cfl_gather_rows(const float *table, const int64_t *idx, int64_t n
     if (n <= 0 || D <= 0 || D % 4) return set_err(CFL_E_SHAPE, "n=%lld D=%lld", (long long)n, (long long)D);
     int blocks = (int)((n + 3) / 4);
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(cfl_gather_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, table,
-                       (const long long *)idx, (long long)n, (long long)D, out);
+    {
+        ProfScope ps((hipStream_t)stream, CFL_K_GATHER);
+        hipLaunchKernelGGL(cfl_gather_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, table,
+                           (const long long *)idx, (long long)n, (long long)D, out);
+    }
     HIP_TRY(hipGetLastError());
     return CFL_OK;
 }

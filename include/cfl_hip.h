@@ -192,6 +192,18 @@ int cfl_adam_tf(float *theta, float *m, float *v, const float *grad, int64_t n,
 int cfl_gather_rows(const float *table, const int64_t *idx, int64_t n, int64_t D,
                     float *out, cfl_stream_t stream);
 
+/* Optional per-kernel timing (bench.py's roofline object).  While enabled,
+ * every kernel the library launches is bracketed by two HIP events recorded on
+ * the caller's stream.  cfl_profile_read() synchronises those events, adds the
+ * elapsed milliseconds / launch counts per kernel kind into the two arrays of
+ * CFL_K_COUNT entries and clears the record list.  Not for production steps.   */
+enum {
+    CFL_K_COLNORM = 0, CFL_K_PROJ, CFL_K_MID, CFL_K_GRAD, CFL_K_FINALIZE,
+    CFL_K_ADAM, CFL_K_GATHER, CFL_K_COUNT = 8
+};
+int cfl_profile_enable(int on);
+int cfl_profile_read(double *ms_sum, int64_t *launches);
+
 #ifdef __cplusplus
 }
 #endif
