@@ -75,17 +75,27 @@ class PairEngine(object):
     def apply_adam(self, grad_scale=1.0):
         H.adam_tf(self.theta, self.m, self.v, self.grad, self.lr_t(), self.beta1,
                   self.beta2, self.eps, grad_scale)
+        self._advance()
+
+    def _advance(self):
         self.beta1_power = np.float32(self.beta1_power * np.float32(self.beta1))
         self.beta2_power = np.float32(self.beta2_power * np.float32(self.beta2))
         self.global_step += 1
 
     def step(self, batch):
         """One training step on this rank's shard of the row batch."""
-        self.fwd_bwd(batch)
         n = self.world_size
-        if n > 1:
-            # one exchange per step: sum of the flat fp32 gradient over xGMI
-            dist.all_reduce(self.grad, op=dist.ReduceOp.SUM)
+        if n == 1:
+            # single GPU: Adam fused into the last kernel of the step
+            ws = self._workspace(batch[0].shape[0], 2)
+            H.pair_train_step(self.shape, self.norm, self.loss, batch, self.theta, self.m,
+                              self.v, self.grad, self.scalars, ws, self.lr_t(), self.beta1,
+                              self.beta2, self.eps)
+            self._advance()
+            return
+        self.fwd_bwd(batch)
+        # one exchange per step: sum of the flat fp32 gradient over xGMI
+        dist.all_reduce(self.grad, op=dist.ReduceOp.SUM)
         self.apply_adam(1.0 / n)
 
     def read_scalars(self):

@@ -55,7 +55,7 @@ class CflLossCfg(C.Structure):
 
 
 EXPORTS = ('cfl_version', 'cfl_last_error', 'cfl_layout', 'cfl_workspace_bytes',
-           'cfl_pair_scores', 'cfl_pair_step_fwd_bwd', 'cfl_adam_tf',
+           'cfl_pair_scores', 'cfl_pair_step_fwd_bwd', 'cfl_pair_train_step', 'cfl_adam_tf',
            'cfl_gather_rows', 'cfl_profile_enable', 'cfl_profile_read')
 
 KERNEL_NAMES = ('colnorm', 'proj', 'mid', 'grad', 'finalize', 'adam', 'gather')
@@ -93,6 +93,12 @@ def lib():
         C.POINTER(C.c_void_p), C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
         C.c_void_p, C.c_size_t, C.c_void_p]
     L.cfl_pair_step_fwd_bwd.restype = C.c_int
+    L.cfl_pair_train_step.argtypes = [
+        C.POINTER(CflShape), C.POINTER(CflNorm), C.POINTER(CflLossCfg),
+        C.POINTER(C.c_void_p), C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+        C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_size_t,
+        C.c_void_p]
+    L.cfl_pair_train_step.restype = C.c_int
     L.cfl_adam_tf.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                               C.c_int64, C.c_float, C.c_float, C.c_float,
                               C.c_float, C.c_float, C.c_void_p]
@@ -177,6 +183,16 @@ def pair_step_fwd_bwd(shape, norm, loss, x4, theta, grad, scalars, workspace):
         C.byref(shape), C.byref(norm), C.byref(loss), arr, B, _dev(theta), _dev(grad),
         _dev(scalars), workspace.data_ptr(),
         workspace.numel() * workspace.element_size(), _stream()))
+
+
+def pair_train_step(shape, norm, loss, x4, theta, m, v, grad, scalars, workspace, lr_t,
+                    beta1, beta2, eps=1e-8):
+    B = x4[0].shape[0]
+    arr = (C.c_void_p * 4)(*[_dev(x) for x in x4])
+    _check(lib().cfl_pair_train_step(
+        C.byref(shape), C.byref(norm), C.byref(loss), arr, B, _dev(theta), _dev(m), _dev(v),
+        _dev(grad), _dev(scalars), float(lr_t), float(beta1), float(beta2), float(eps),
+        workspace.data_ptr(), workspace.numel() * workspace.element_size(), _stream()))
 
 
 def adam_tf(theta, m, v, grad, lr_t, beta1, beta2, eps=1e-8, grad_scale=1.0):

@@ -125,7 +125,7 @@ __device__ __forceinline__ const float *row_ptr(const float *x0, const float *x1
 }
 
 // ---------------------------------------------------------------------------
-// proj: Ypart[s][c][r] = sum_{d in slice s} X[r][d] * Wt[c][d]
+// proj: Ypart[s][r][c] = sum_{d in slice s} X[r][d] * Wt[c][d]
 //   workgroup = 8 waves, one 32-row tile; wave w owns a d sub-range of slice s and
 //   computes the whole [32 x NT*16] tile for it with v_mfma_f32_16x16x4_f32.
 //   A fragment  lane(r16,q) : float4 X[row0+16mt+r16][d+4q .. d+4q+3]
@@ -136,9 +136,9 @@ __device__ __forceinline__ const float *row_ptr(const float *x0, const float *x1
 struct ProjJob {
     const float *x0, *x1;  // pair-group row blocks
     const float *wt;       // Wt chunk [nt*16][D]
-    float *ypart;          // chunk base inside [S][npad][Rpad]
-    long long sstride;     // floats between slices (npad * Rpad)
-    int nt;
+    float *ypart;          // chunk base (column offset applied) inside [S][Rpad][npad]
+    long long sstride;     // floats between slices (Rpad * npad)
+    int nt, npad;
 };
 
 struct ProjArgs {
@@ -212,10 +212,12 @@ __device__ __forceinline__ void proj_body(const ProjJob &jb, const ProjArgs &a, 
         f32x4 sum = lds[(0 * 2 * NT + wave) * 64 + lane];
 #pragma unroll
         for (int w = 1; w < 8; ++w) sum += lds[(w * 2 * NT + wave) * 64 + lane];
-        // C layout: col = lane&15, rows 4*(lane>>4) .. +3  ->  Ypart_t[col][row0 + 16mt + 4q ..]
-        float *dst = jb.ypart + (size_t)s * jb.sstride + (size_t)(nt * 16 + r16) * a.Rpad + row0 +
-                     mt * 16 + 4 * q;
-        *(f32x4 *)dst = sum;
+        // C layout: col = lane&15, rows 4*(lane>>4) .. +3  ->  Ypart[s][row][npad] (row-major:
+        // the mid kernel then reads whole rows with 16-byte loads)
+        float *dst = jb.ypart + (size_t)s * jb.sstride +
+                     (size_t)(row0 + mt * 16 + 4 * q) * jb.npad + nt * 16 + r16;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dst[(size_t)e * jb.npad] = sum[e];
     }
 }
 
@@ -247,10 +249,21 @@ struct GradJob {
     int nt;
 };
 
+// Row reductions that ride in the grad launch (z-slice 0): colsum[out] = sum_r A[a][r]
+// (B == null) or sum_r A[a][r] * B[b][r]; one wave per job, fixed summation order.
+struct RedRange {
+    const float *A, *B;   // [.][Rpad] transposed row buffers written by the mid kernel
+    int count, kdiv, ostride, out_off;
+};
+#define CFL_MAX_RED 10
+
 struct GradArgs {
     GradJob job[CFL_MAX_JOBS];
     int B, R, Rpad, D, P;
     NormDev norm;
+    RedRange red[CFL_MAX_RED];
+    int nred, red_total;
+    float *colsum;
 };
 
 template <int NT>
@@ -330,10 +343,41 @@ __device__ __forceinline__ void grad_body(const GradJob &jb, const GradArgs &a, 
     }
 }
 
+__device__ __forceinline__ float wave_sum(float x) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
+    return x;
+}
+
+__device__ void grad_red_block(const GradArgs &a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nblk = gridDim.x * gridDim.y;
+    const int blk = blockIdx.y * gridDim.x + blockIdx.x;
+    const int n4 = a.Rpad >> 2;
+    for (int job = blk * 4 + wave; job < a.red_total; job += nblk * 4) {
+        int k = 0, idx = job;
+        while (k < a.nred - 1 && idx >= a.red[k].count) { idx -= a.red[k].count; ++k; }
+        const RedRange &rr = a.red[k];
+        int ia = idx, ib = 0, out = idx;
+        if (rr.kdiv > 0) { ia = idx / rr.kdiv; ib = idx - ia * rr.kdiv; out = ia * rr.ostride + ib; }
+        const f32x4 *pa = (const f32x4 *)(rr.A + (size_t)ia * a.Rpad);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        if (rr.B) {
+            const f32x4 *pb = (const f32x4 *)(rr.B + (size_t)ib * a.Rpad);
+            for (int i = lane; i < n4; i += 64) acc += pa[i] * pb[i];
+        } else {
+            for (int i = lane; i < n4; i += 64) acc += pa[i];
+        }
+        const float t = wave_sum((acc[0] + acc[1]) + (acc[2] + acc[3]));
+        if (lane == 0) a.colsum[rr.out_off + out] = t;
+    }
+}
+
 extern "C" __global__ __launch_bounds__(256) void cfl_grad_kernel(GradArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     f32x4 *lds = (f32x4 *)smem;
-    const GradJob &jb = a.job[blockIdx.z];
+    if (blockIdx.z == 0) { grad_red_block(a); return; }
+    const GradJob &jb = a.job[blockIdx.z - 1];
     switch (jb.nt) {
         case 1: grad_body<1>(jb, a, lds); break;
         case 2: grad_body<2>(jb, a, lds); break;
@@ -344,42 +388,53 @@ extern "C" __global__ __launch_bounds__(256) void cfl_grad_kernel(GradArgs a) {
 
 // ---------------------------------------------------------------------------
 // mid: per pair row: slice-sum, head epilogue, distance, loss, dL/dY.
-//   workgroup = 64 threads = 16 rows x 4 column parts; lane (p = tid>>4, j = tid&15)
-//   owns the latent coordinates l == p (mod 4) of row blockIdx.x*16 + j, for every
-//   prototype k.  Sums over l are completed with two xor-shuffles (16, 32); sums
-//   over the 16 rows of the block (bias / weight-norm column sums) with four
-//   (1,2,4,8).  LDS is only per-lane runtime-indexed storage: [slot][64].
+//   workgroup = 64 threads = 4 rows x 16 column parts; lane (p = tid&15, j = tid>>4)
+//   owns the latent coordinates l == p (mod 16) of row blockIdx.x*4 + j, for every
+//   prototype k.
+//   phase 1: the block's 4 rows of every slice slab are read with coalesced
+//            16-byte loads (all slices in flight at once), summed in slice order
+//            and parked in LDS as Y[row][col];
+//   phase 2: per-lane math; sums over l are completed with xor-shuffles inside
+//            the 16-lane row group.  Per-lane runtime-indexed state lives in LDS
+//            as [slot][64].
+//   Everything that later needs a sum over ROWS (bias / gain / gate-head
+//   gradients, loss scalars) is written as a transposed row buffer [q][Rpad];
+//   the reductions ride in the grad launch (grad_red_block).
 // ---------------------------------------------------------------------------
+#define MID_RB 4
 enum {
     P_BCE_POS = 0, P_BCE_NEG, P_OK_POS, P_OK_NEG, P_D_POS, P_D_NEG, P_O_POS, P_O_NEG,
-    P_DTHR, P_HINGE_NEG, P_SQRT_POS, P_SQRT_NEG, P_NSCALAR = 16
+    P_DTHR, P_HINGE_NEG, P_SQRT_POS, P_SQRT_NEG, P_NROWQ = 12
 };
 
 struct MidSide {
-    const float *ypart;   // [S][npad][Rpad]
+    const float *ypart;   // [S][Rpad][npad]
     long long sstride;
     const float *b;       // biases or null
     const float *g;       // wn gains or null
     const float *n2;      // wn squared column norms or null
-    float *dyt;           // [npad][Rpad]
+    float *dyt;           // [npad][Rpad]  dL/d(x.V) scaled for the grad GEMM
+    float *raw;           // [npad][Rpad]  dL/dy (bias gradient rows) or null
+    float *cwx;           // [npad][Rpad]  dL/dy * (x_hat.V) (weight-norm gain rows) or null
     int n, npad;
     int is_proto;         // 1: columns are k*L + l ; 0: columns are l
-    int col_off;          // offset of this side's column sums inside a part vector
 };
 
 struct MidArgs {
     MidSide side[2];      // 0 = src, 1 = dst
     const float *mono_w, *mono_g, *mono_n2;  // monomer gate head V[L][kpad]
-    int kpad, mono_off;   // mono_off: offset of the mono sums inside a part vector
+    float *mono_ya, *mono_du, *mono_duc;     // [L][Rpad], [kpad][Rpad], [kpad][Rpad]
+    int kpad;
     int S, L, K, Lq, dist_type, act, weight_norm;
     float in_mul;
     const float *thr;
-    int B, R, Rpad, groups;
+    int B, R, Rpad;
     int train, use_threshold;
     float pos_weight, caffe_margin, lambda_m;
     float *scores, *dists;
-    float *part;          // [nrb][partw]
-    int partw, nrb;
+    float *rowq;          // [P_NROWQ][Rpad]
+    float *thr_copy;      // max(thr, 1e-6) of this step (read by finalize's scalar block)
+    int nrb, ys;          // row blocks; LDS row stride of Y (floats)
     // regulariser blocks
     const float *theta;
     float *regpart;
@@ -404,21 +459,12 @@ __device__ __forceinline__ float act_grad(float a, int act) {
         default: return 1.f;
     }
 }
-__device__ __forceinline__ float sum4(float x) {  // over the 4 column parts
-    x += __shfl_xor(x, 16);
-    x += __shfl_xor(x, 32);
-    return x;
-}
-__device__ __forceinline__ float sum16(float x) {  // over the 16 rows of the block
+__device__ __forceinline__ float sum_p(float x) {  // over the 16 column parts of a row
     x += __shfl_xor(x, 1);
     x += __shfl_xor(x, 2);
     x += __shfl_xor(x, 4);
     x += __shfl_xor(x, 8);
     return x;
-}
-__device__ __forceinline__ float sum64(float x) {
-    x = sum16(x);
-    return sum4(x);
 }
 
 __device__ void mid_reg_block(const MidArgs &a, int blk) {
@@ -439,8 +485,19 @@ __device__ void mid_reg_block(const MidArgs &a, int blk) {
             rem -= ng;
         }
     }
-    acc = sum64(acc);
+    acc = wave_sum(acc);
     if (tid == 0) a.regpart[blk] = acc;
+}
+
+template <int S>
+__device__ __forceinline__ f32x4 slab_sum(const float *src, long long sstride) {
+    f32x4 t[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) t[s] = *(const f32x4 *)(src + (size_t)s * sstride);
+    f32x4 acc = t[0];
+#pragma unroll
+    for (int s = 1; s < S; ++s) acc += t[s];
+    return acc;
 }
 
 extern "C" __global__ __launch_bounds__(64) void cfl_mid_kernel(MidArgs a) {
@@ -450,16 +507,22 @@ extern "C" __global__ __launch_bounds__(64) void cfl_mid_kernel(MidArgs a) {
         mid_reg_block(a, blockIdx.x - a.nrb);
         return;
     }
-    const int tid = threadIdx.x, p = tid >> 4, j = tid & 15;
-    const int r = blockIdx.x * 16 + j;
+    const int tid = threadIdx.x, p = tid & 15, j = tid >> 4;
+    const int row0 = blockIdx.x * MID_RB;
+    const int r = row0 + j;
     const bool valid = r < a.R;
     const int L = a.L, K = a.K, Lq = a.Lq;
-    const int myL = (L - p + 3) >> 2;  // number of l = p + 4*li < L
+    const int myL = p < L ? (L - p + 15) >> 4 : 0;  // number of l = p + 16*li < L
     const MidSide &ss = a.side[0], &sd = a.side[1];
     const int ks = ss.is_proto ? K : 1, kd = sd.is_proto ? K : 1;
 
-    // LDS carve, every array [slots][64]
-    float *As = lds;                           // src activations   ks*Lq
+    // LDS carve: Y[4][ys], per-column scale SC[ys] and bias BI[ys], gate weights
+    // MW[L*kpad], then per-lane arrays [slots][64]
+    float *Y = lds;
+    float *SC = Y + MID_RB * a.ys;
+    float *BI = SC + a.ys;
+    float *MW = BI + a.ys;
+    float *As = MW + (a.dist_type == CFL_DIST_MONOMER ? ((L * a.kpad + 3) & ~3) : 0);  // src activations ks*Lq
     float *Ad = As + ks * Lq * 64;             // dst activations   kd*Lq
     float *Xs = Ad + kd * Lq * 64;             // src raw x_hat.V (weight-norm)  ks*Lq
     float *Xd = Xs + (a.weight_norm ? ks * Lq * 64 : 0);
@@ -467,23 +530,49 @@ extern "C" __global__ __launch_bounds__(64) void cfl_mid_kernel(MidArgs a) {
     float *Kv = Rl + Lq * 64;                  // 4 x K small vectors
     float *Ks = Kv, *Kq = Kv + K * 64, *Ke = Kv + 2 * K * 64, *Ku = Kv + 3 * K * 64;
 
-    // ---- 1. slice sums + head epilogue ---------------------------------------
+    // ---- phase 1: slice sums -> LDS --------------------------------------------
+    for (int side = 0; side < 2; ++side) {
+        const MidSide &sx = a.side[side];
+        const int nq = sx.npad >> 2;
+        const int coloff = side ? a.side[0].npad : 0;
+        for (int idx = tid; idx < MID_RB * nq; idx += 64) {
+            const int jj = idx / nq, c4 = idx - jj * nq;
+            const float *src = sx.ypart + (size_t)(row0 + jj) * sx.npad + 4 * c4;
+            f32x4 acc;
+            switch (a.S) {
+                case 1: acc = slab_sum<1>(src, sx.sstride); break;
+                case 2: acc = slab_sum<2>(src, sx.sstride); break;
+                case 4: acc = slab_sum<4>(src, sx.sstride); break;
+                case 8: acc = slab_sum<8>(src, sx.sstride); break;
+                default: acc = slab_sum<16>(src, sx.sstride); break;
+            }
+            *(f32x4 *)(Y + jj * a.ys + coloff + 4 * c4) = acc;
+        }
+        for (int c = tid; c < sx.n; c += 64) {
+            SC[coloff + c] = a.weight_norm ? sx.g[c] / sqrtf(sx.n2[c]) : 1.f;
+            BI[coloff + c] = sx.b ? sx.b[c] : 0.f;
+        }
+    }
+    if (a.dist_type == CFL_DIST_MONOMER)
+        for (int i = tid; i < L * a.kpad; i += 64) MW[i] = a.mono_w[i];
+    const float thr_raw = *a.thr;
+    float scm_all = 1.f;  // (unused unless monomer + weight-norm: per-k scale read below)
+    (void)scm_all;
+    __syncthreads();
+
+    // ---- phase 2.1: head epilogue ------------------------------------------------
     for (int side = 0; side < 2; ++side) {
         const MidSide &sx = a.side[side];
         float *A = side ? Ad : As, *X = side ? Xd : Xs;
+        const int coloff = side ? a.side[0].npad : 0;
         const int kk = sx.is_proto ? K : 1;
         for (int k = 0; k < kk; ++k)
             for (int li = 0; li < myL; ++li) {
-                const int c = k * L + p + 4 * li;
-                const float *yp = sx.ypart + (size_t)c * a.Rpad + r;
-                float y = 0.f;
-                for (int s = 0; s < a.S; ++s) y += yp[(size_t)s * sx.sstride];
+                const int c = k * L + p + 16 * li;
+                float y = Y[j * a.ys + coloff + c];
                 if (!valid) y = 0.f;  // rows >= R of the scratch slabs are never written
                 const float xv = y * a.in_mul;
-                float sc = 1.f;
-                if (a.weight_norm) sc = sx.g[c] / sqrtf(sx.n2[c]);
-                float yy = xv * sc;
-                if (sx.b) yy += sx.b[c];
+                const float yy = xv * SC[coloff + c] + BI[coloff + c];
                 const int slot = (k * Lq + li) * 64 + tid;
                 if (a.weight_norm) X[slot] = xv;
                 if (a.dist_type == CFL_DIST_MONOMER && side == 0) Rl[li * 64 + tid] = yy;
@@ -491,7 +580,7 @@ extern "C" __global__ __launch_bounds__(64) void cfl_mid_kernel(MidArgs a) {
             }
     }
 
-    // ---- 2. distance ---------------------------------------------------------
+    // ---- phase 2.2: distance -----------------------------------------------------
     float d = 0.f;
     if (a.dist_type == CFL_DIST_PCD) {
         if (K > 1) {
@@ -502,7 +591,7 @@ extern "C" __global__ __launch_bounds__(64) void cfl_mid_kernel(MidArgs a) {
                     float df = Ad[li * 64 + tid] - As[(k * Lq + li) * 64 + tid];
                     e = fmaf(df, df, e);
                 }
-                e = -sum4(e);
+                e = -sum_p(e);
                 Ks[k * 64 + tid] = e;
                 mx = fmaxf(mx, e);
             }
@@ -524,13 +613,13 @@ extern "C" __global__ __launch_bounds__(64) void cfl_mid_kernel(MidArgs a) {
                 d = fmaf(rl, rl, d);
                 for (int k = 0; k < K; ++k) Kq[k * 64 + tid] += rl * As[(k * Lq + li) * 64 + tid];
             }
-            d = sum4(d);
+            d = sum_p(d);
         } else {
             for (int li = 0; li < myL; ++li) {
                 float df = Ad[li * 64 + tid] - As[li * 64 + tid];
                 d = fmaf(df, df, d);
             }
-            d = sum4(d);
+            d = sum_p(d);
         }
     } else if (a.dist_type == CFL_DIST_MONOMER) {
         // gate u_k = (ya . Vm[:,k]) * scale_k from the PRE-activation outputs (base.py:96)
@@ -538,13 +627,13 @@ extern "C" __global__ __launch_bounds__(64) void cfl_mid_kernel(MidArgs a) {
         for (int k = 0; k < K; ++k) {
             float u = 0.f, e = 0.f;
             for (int li = 0; li < myL; ++li) {
-                const int l = p + 4 * li;
-                u = fmaf(Rl[li * 64 + tid], a.mono_w[l * a.kpad + k], u);
+                const int l = p + 16 * li;
+                u = fmaf(Rl[li * 64 + tid], MW[l * a.kpad + k], u);
                 float df = As[li * 64 + tid] - Ad[(k * Lq + li) * 64 + tid];
                 e = fmaf(df, df, e);
             }
-            u = sum4(u);
-            e = sum4(e);
+            u = sum_p(u);
+            e = sum_p(e);
             Ku[k * 64 + tid] = u;  // raw ya.Vm (needed for the weight-norm gain grad)
             if (a.weight_norm) u *= a.mono_g[k] / sqrtf(a.mono_n2[k]);
             Ks[k * 64 + tid] = u;
@@ -568,11 +657,10 @@ extern "C" __global__ __launch_bounds__(64) void cfl_mid_kernel(MidArgs a) {
             float df = As[li * 64 + tid] - Ad[li * 64 + tid];
             d = fmaf(df, df, d);
         }
-        d = sum4(d);
+        d = sum_p(d);
     }
 
-    // ---- 3. threshold, loss, dL/dd -------------------------------------------
-    const float thr_raw = *a.thr;
+    // ---- phase 2.3: threshold, loss, dL/dd ----------------------------------------
     const float thr = fmaxf(thr_raw, CFL_THR_FLOOR);
     const float o = thr - d;
     if (!a.train) {
@@ -603,57 +691,48 @@ extern "C" __global__ __launch_bounds__(64) void cfl_mid_kernel(MidArgs a) {
     }
     if (!valid) dd = 0.f;
 
-    // per-block scalar partials (lanes p == 0 of valid rows contribute)
-    float *part = a.part + (size_t)blockIdx.x * a.partw;
-    {
-        const float w = (valid && p == 0) ? 1.f : 0.f;
+    if (blockIdx.x == 0 && tid == 0) a.thr_copy[0] = thr;
+    // per-row loss quantities (summed over rows by grad_red_block)
+    if (p == 0) {
+        const float w = valid ? 1.f : 0.f;
         const float wp = is_pos ? w : 0.f, wn = is_pos ? 0.f : w;
-        float v[12];
-        v[P_BCE_POS] = wp * bce;
-        v[P_BCE_NEG] = wn * bce;
-        v[P_OK_POS] = wp * (o > 0.f ? 1.f : 0.f);
-        v[P_OK_NEG] = wn * (o <= 0.f ? 1.f : 0.f);
-        v[P_D_POS] = wp * d;
-        v[P_D_NEG] = wn * d;
-        v[P_O_POS] = wp * o;
-        v[P_O_NEG] = wn * o;
-        v[P_DTHR] = w * dlo;
-        v[P_HINGE_NEG] = wn * hinge;
-        v[P_SQRT_POS] = wp * sqrtf(d + 1e-7f);
-        v[P_SQRT_NEG] = wn * sqrtf(d + 1e-7f);
-#pragma unroll
-        for (int i = 0; i < 12; ++i) {
-            float t = sum64(v[i]);
-            if (tid == 0) part[i] = t;
-        }
+        float *q = a.rowq + r;
+        const size_t rp = a.Rpad;
+        q[P_BCE_POS * rp] = wp != 0.f ? bce : 0.f;
+        q[P_BCE_NEG * rp] = wn != 0.f ? bce : 0.f;
+        q[P_OK_POS * rp] = (wp != 0.f && o > 0.f) ? 1.f : 0.f;
+        q[P_OK_NEG * rp] = (wn != 0.f && o <= 0.f) ? 1.f : 0.f;
+        q[P_D_POS * rp] = wp != 0.f ? d : 0.f;
+        q[P_D_NEG * rp] = wn != 0.f ? d : 0.f;
+        q[P_O_POS * rp] = wp != 0.f ? o : 0.f;
+        q[P_O_NEG * rp] = wn != 0.f ? o : 0.f;
+        q[P_DTHR * rp] = w != 0.f ? dlo : 0.f;
+        q[P_HINGE_NEG * rp] = wn != 0.f ? hinge : 0.f;
+        q[P_SQRT_POS * rp] = wp != 0.f ? sqrtf(d + 1e-7f) : 0.f;
+        q[P_SQRT_NEG * rp] = wn != 0.f ? sqrtf(d + 1e-7f) : 0.f;
     }
 
-    // ---- 4. backward to dL/dY (transposed, scaled for the grad GEMM) ----------
-    // emit(): finish one column: activation grad, weight-norm / input scale,
-    // store dYt, accumulate the block column sums for bias and weight-norm gain.
+    // ---- phase 2.4: backward to dL/dY (transposed, scaled for the grad GEMM) -------
+    // emit(): finish one column: activation grad, weight-norm / input scale, store
+    // dYt plus the bias / gain row buffers.
     auto emit = [&](const MidSide &sx, const float *A, const float *X, int k, int li, float dA,
                     float extra_dy) {
-        const int c = k * L + p + 4 * li;
+        const int c = k * L + p + 16 * li;
         const int slot = (k * Lq + li) * 64 + tid;
         float dy = dA * act_grad(A[slot], a.act) + extra_dy;
         if (!valid) dy = 0.f;
-        float sc = a.in_mul;
-        if (a.weight_norm) sc *= sx.g[c] / sqrtf(sx.n2[c]);
-        sx.dyt[(size_t)c * a.Rpad + r] = dy * sc;
-        const float sb = sum16(dy);
-        float sw = 0.f;
-        if (a.weight_norm) sw = sum16(dy * X[slot]);
-        if (j == 0) {
-            part[P_NSCALAR + sx.col_off + c] = sb;
-            if (a.weight_norm) part[P_NSCALAR + sx.col_off + sx.npad + c] = sw;
-        }
+        const float sc = a.in_mul * SC[(&sx == &a.side[1] ? a.side[0].npad : 0) + c];
+        const size_t o_ = (size_t)c * a.Rpad + r;
+        sx.dyt[o_] = dy * sc;
+        if (sx.raw) sx.raw[o_] = dy;
+        if (sx.cwx) sx.cwx[o_] = valid ? dy * X[slot] : 0.f;
     };
 
     if (a.dist_type == CFL_DIST_PCD) {
         if (K > 1) {
             float qbar = 0.f;
             for (int k = 0; k < K; ++k) {
-                float qk = -2.f * sum4(Kq[k * 64 + tid]);
+                float qk = -2.f * sum_p(Kq[k * 64 + tid]);
                 Kq[k * 64 + tid] = qk;
                 qbar = fmaf(Ks[k * 64 + tid], qk, qbar);
             }
@@ -679,32 +758,28 @@ extern "C" __global__ __launch_bounds__(64) void cfl_mid_kernel(MidArgs a) {
             }
         }
     } else if (a.dist_type == CFL_DIST_MONOMER) {
-        // du_k = w_k (e_k - d) dd ; gate-head column sums for dVm, dgm
-        float *mp = part + P_NSCALAR + a.mono_off;
+        // du_k = w_k (e_k - d) dd ; gate-head rows for dVm, dgm
         for (int k = 0; k < K; ++k) {
             float du = Ks[k * 64 + tid] * (Ke[k * 64 + tid] - d) * dd;
             float scm = 1.f;
             if (a.weight_norm) scm = a.mono_g[k] / sqrtf(a.mono_n2[k]);
-            // weight-norm gain column sum: sum_r du * (ya.Vm)
-            if (a.weight_norm) {
-                const float cw = sum16(p == 0 ? du * Ku[k * 64 + tid] : 0.f);
-                if (tid == 0) mp[L * a.kpad + k] = cw;
+            if (p == 0) {
+                a.mono_du[(size_t)k * a.Rpad + r] = du * scm;
+                if (a.weight_norm) a.mono_duc[(size_t)k * a.Rpad + r] = valid ? du * Ku[k * 64 + tid] : 0.f;
             }
             Kq[k * 64 + tid] = du * scm;  // grad wrt raw ya.Vm
         }
         for (int li = 0; li < myL; ++li) {
-            const int l = p + 4 * li;
+            const int l = p + 16 * li;
             const float av = As[li * 64 + tid], ya = Rl[li * 64 + tid];
+            a.mono_ya[(size_t)l * a.Rpad + r] = valid ? ya : 0.f;
             float da = 0.f, ex = 0.f;
             for (int k = 0; k < K; ++k) {
                 const float amP = av - Ad[(k * Lq + li) * 64 + tid];
                 const float w = Ks[k * 64 + tid];
                 da = fmaf(2.f * w, amP, da);
                 emit(sd, Ad, Xd, k, li, -2.f * w * amP * dd, 0.f);
-                const float du = Kq[k * 64 + tid];
-                ex = fmaf(du, a.mono_w[l * a.kpad + k], ex);
-                const float s1 = sum16(ya * du);  // dVm[l][k] block sum
-                if (j == 0) mp[l * a.kpad + k] = s1;
+                ex = fmaf(Kq[k * 64 + tid], MW[l * a.kpad + k], ex);
             }
             emit(ss, As, Xs, 0, li, da * dd, ex);
         }
@@ -718,9 +793,10 @@ extern "C" __global__ __launch_bounds__(64) void cfl_mid_kernel(MidArgs a) {
     // zero the padding columns of dYt (read by the grad GEMM)
     for (int side = 0; side < 2; ++side) {
         const MidSide &sx = a.side[side];
-        for (int c = sx.n + p; c < sx.npad; c += 4) sx.dyt[(size_t)c * a.Rpad + r] = 0.f;
+        for (int c = sx.n + p; c < sx.npad; c += 16) sx.dyt[(size_t)c * a.Rpad + r] = 0.f;
     }
 }
+
 
 // ---------------------------------------------------------------------------
 // colnorm (weight-norm): n2[c] = sum_d Wt[c][d]^2   (cfl/layers.py:81)
@@ -728,6 +804,8 @@ extern "C" __global__ __launch_bounds__(64) void cfl_mid_kernel(MidArgs a) {
 struct ColnormArgs {
     const float *theta;
     float *n2;            // [ncols_total]
+    float *gcopy;         // [ncols_total] snapshot of the gains (finalize may update theta in place)
+    long long g_off[8];
     int nheads;
     long long w_off[8];
     int npad[8], n2_off[8], rowlen[8], strided[8], ncol[8];
@@ -751,14 +829,19 @@ extern "C" __global__ __launch_bounds__(256) void cfl_colnorm_kernel(ColnormArgs
         }
     }
     __shared__ float red[4];
-    acc = sum64(acc);
+    acc = wave_sum(acc);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) a.n2[a.n2_off[h] + c] = red[0] + red[1] + red[2] + red[3];
+    if (threadIdx.x == 0) {
+        a.n2[a.n2_off[h] + c] = red[0] + red[1] + red[2] + red[3];
+        a.gcopy[a.n2_off[h] + c] = a.g_off[h] >= 0 ? a.theta[a.g_off[h] + c] : 1.f;
+    }
 }
 
 // ---------------------------------------------------------------------------
-// finalize: slabs + column sums -> flat gradient ; last block -> scalars
+// finalize: weight-gradient slabs + row-reduced column sums -> flat gradient ;
+//           last block -> scalars.  Purely element-wise: every reduction over rows
+//           was done by grad_red_block, every reduction over theta by mid_reg_block.
 // ---------------------------------------------------------------------------
 enum { RK_ZERO = 0, RK_W, RK_BIAS, RK_GAIN, RK_THR, RK_MONO_W, RK_MONO_G };
 
@@ -766,7 +849,7 @@ struct Region {
     long long off, cnt;        // floats (64-aligned)
     int kind, reg;
     const float *slab[2];      // weight-gradient slabs [P][npad][D] (one per contributing side)
-    int col_off[2];            // column-sum offsets in a part vector (-1: none)
+    int cs_raw[2], cs_cwx[2];  // colsum offsets of the bias / gain rows (-1: none)
     int npad, n;               // padded / logical columns of the head
     const float *g, *n2;       // weight-norm
 };
@@ -777,8 +860,9 @@ struct FinArgs {
     long long total;           // floats in theta
     const float *theta;
     float *grad;
-    const float *part;         // [nrb][partw]
-    int partw, nrb, P, D, L, kpad, mono_off, weight_norm;
+    const float *colsum;
+    int cs_rowq, cs_mono, cs_duc;
+    int P, D, L, kpad, weight_norm;
     float reg_const;
     int use_threshold;
     float pos_weight, caffe_margin, lambda_m;
@@ -788,32 +872,27 @@ struct FinArgs {
     float *scalars;
     long long thr_off;
     int nblocks_main;
+    // optional fused Adam (theta_out aliases theta)
+    float *adam_m, *adam_v, *theta_out;
+    float lr_t, b1, b2, eps;
+    const float *thr_copy;     // max(thr,1e-6) as seen by the mid kernel of this step
 };
-
-__device__ __forceinline__ float part_colsum(const FinArgs &a, int off) {
-    float s = 0.f;
-    for (int b = 0; b < a.nrb; ++b) s += a.part[(size_t)b * a.partw + P_NSCALAR + off];
-    return s;
-}
 
 extern "C" __global__ __launch_bounds__(256) void cfl_finalize_kernel(FinArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if ((int)blockIdx.x == a.nblocks_main) {
-        // ---- scalars (cfl/models/cfl.py:868-949) -- one block, fixed order ----
-        __shared__ float sc[P_NSCALAR];
-        if (tid < 12) {
+        // ---- scalars (cfl/models/cfl.py:868-949) ----------------------------------
+        __shared__ float regsum_s;
+        if (wave == 0) {
             float s = 0.f;
-            for (int b = 0; b < a.nrb; ++b) s += a.part[(size_t)b * a.partw + tid];
-            sc[tid] = s;
-        }
-        __shared__ float regsum;
-        if (tid == 64) {
-            float s = 0.f;
-            for (int b = 0; b < a.nregblocks; ++b) s += a.regpart[b];
-            regsum = 0.5f * a.reg_const * s;
+            for (int b = lane; b < a.nregblocks; b += 64) s += a.regpart[b];
+            s = wave_sum(s);
+            if (lane == 0) regsum_s = 0.5f * a.reg_const * s;
         }
         __syncthreads();
         if (tid == 0) {
+            const float *sc = a.colsum + a.cs_rowq;
+            const float regsum = regsum_s;
             const float invB = 1.f / (float)a.B;
             const float pw = a.pos_weight != 0.f ? a.pos_weight : 1.f;
             const float lpos = sc[P_BCE_POS] * invB, lneg = sc[P_BCE_NEG] * invB;
@@ -837,7 +916,7 @@ extern "C" __global__ __launch_bounds__(256) void cfl_finalize_kernel(FinArgs a)
             o[CFL_S_MEAN_D_NEG] = sc[P_D_NEG] * invB;
             o[CFL_S_MEAN_O_POS] = sc[P_O_POS] * invB;
             o[CFL_S_MEAN_O_NEG] = sc[P_O_NEG] * invB;
-            o[CFL_S_THRESHOLD] = fmaxf(a.theta[a.thr_off], CFL_THR_FLOOR);
+            o[CFL_S_THRESHOLD] = a.thr_copy[0];
             o[CFL_S_DIST_ADAPT_POS] = sc[P_SQRT_POS] * invB;
             o[CFL_S_DIST_ADAPT_NEG] = sc[P_SQRT_NEG] * invB;
             o[14] = 0.f;
@@ -845,90 +924,112 @@ extern "C" __global__ __launch_bounds__(256) void cfl_finalize_kernel(FinArgs a)
         }
         return;
     }
-    // main blocks: 4 waves x 4 groups of 64 floats
-    for (int gi = 0; gi < 4; ++gi) {
-        const long long g = ((long long)blockIdx.x * 4 + wave) * 4 + gi;
-        const long long base = g * 64;
-        if (base >= a.total) return;
-        int k = 0;
-        for (; k < a.nregions; ++k)
-            if (base >= a.reg[k].off && base < a.reg[k].off + a.reg[k].cnt) break;
-        const long long idx = base + lane;
-        float gr = 0.f;
-        if (k < a.nregions) {
-            const Region &rg = a.reg[k];
-            const long long rel = idx - rg.off;
-            const float th = a.theta[idx];
-            switch (rg.kind) {
-                case RK_W: {
-                    const int c = (int)(rel / a.D);  // wave-uniform (D % 64 == 0)
+    // main blocks: one float4 (4 consecutive parameters, same region) per thread; all
+    // loads of a thread are independent and issued together.
+    const long long base = ((long long)blockIdx.x * 256 + tid) * 4;
+    if (base >= a.total) return;
+    int k = 0;
+    for (; k < a.nregions; ++k)
+        if (base >= a.reg[k].off && base < a.reg[k].off + a.reg[k].cnt) break;
+    const f32x4 th = *(const f32x4 *)(a.theta + base);
+    f32x4 gr = {0.f, 0.f, 0.f, 0.f};
+    if (k < a.nregions) {
+        const Region &rg = a.reg[k];
+        const long long rel = base - rg.off;
+        switch (rg.kind) {
+            case RK_W: {
+                const int c = (int)(rel / a.D);  // same column for the 4 elements (D % 4 == 0)
+                const long long ps = (long long)rg.npad * a.D;
+                f32x4 t[2][8];
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+#pragma unroll
+                    for (int pp = 0; pp < 8; ++pp)
+                        t[s][pp] = (rg.slab[s] && pp < a.P) ? *(const f32x4 *)(rg.slab[s] + rel + pp * ps)
+                                                            : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+#pragma unroll
+                    for (int pp = 0; pp < 8; ++pp) gr += t[s][pp];
+                if (a.weight_norm && c < rg.n) {
+                    float cw = 0.f;
                     for (int s = 0; s < 2; ++s)
-                        if (rg.slab[s]) {
-                            const float *sl = rg.slab[s] + rel;
-                            const long long ps = (long long)rg.npad * a.D;
-                            for (int pp = 0; pp < a.P; ++pp) gr += sl[pp * ps];
-                        }
-                    if (a.weight_norm && c < rg.n) {
-                        float cw = 0.f;
-                        for (int s = 0; s < 2; ++s)
-                            if (rg.col_off[s] >= 0) cw += part_colsum(a, rg.col_off[s] + rg.npad + c);
-                        const float n2 = rg.n2[c], n = sqrtf(n2);
-                        if (n2 > 0.f) gr -= rg.g[c] * cw / (n2 * n) * th;
-                    }
-                    break;
+                        if (rg.cs_cwx[s] >= 0) cw += a.colsum[rg.cs_cwx[s] + c];
+                    const float n2 = rg.n2[c], n = sqrtf(n2);
+                    if (n2 > 0.f) gr -= (rg.g[c] * cw / (n2 * n)) * th;
                 }
-                case RK_BIAS: {
-                    const int c = (int)rel;
+                break;
+            }
+            case RK_BIAS: {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int c = (int)rel + e;
                     if (c < rg.n)
                         for (int s = 0; s < 2; ++s)
-                            if (rg.col_off[s] >= 0) gr += part_colsum(a, rg.col_off[s] + c);
-                    break;
+                            if (rg.cs_raw[s] >= 0) gr[e] += a.colsum[rg.cs_raw[s] + c];
                 }
-                case RK_GAIN: {
-                    const int c = (int)rel;
+                break;
+            }
+            case RK_GAIN: {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int c = (int)rel + e;
                     if (c < rg.n) {
                         float cw = 0.f;
                         for (int s = 0; s < 2; ++s)
-                            if (rg.col_off[s] >= 0) cw += part_colsum(a, rg.col_off[s] + rg.npad + c);
+                            if (rg.cs_cwx[s] >= 0) cw += a.colsum[rg.cs_cwx[s] + c];
                         const float n2 = rg.n2[c];
-                        gr = n2 > 0.f ? cw / sqrtf(n2) : 0.f;
+                        gr[e] = n2 > 0.f ? cw / sqrtf(n2) : 0.f;
                     }
-                    break;
                 }
-                case RK_THR: {
-                    if (rel == 0) {
-                        float s = 0.f;
-                        for (int b = 0; b < a.nrb; ++b) s += a.part[(size_t)b * a.partw + P_DTHR];
-                        gr = th >= CFL_THR_FLOOR ? s : 0.f;
-                    }
-                    break;
-                }
-                case RK_MONO_W: {  // V[L][kpad]
-                    const int l = (int)(rel / a.kpad), kk = (int)(rel % a.kpad);
-                    if (l < a.L && kk < rg.n && rg.col_off[0] >= 0) {
-                        gr = part_colsum(a, rg.col_off[0] + (int)rel);
-                        if (a.weight_norm) {
-                            const float cw = part_colsum(a, rg.col_off[0] + a.L * a.kpad + kk);
-                            const float n2 = rg.n2[kk], n = sqrtf(n2);
-                            if (n2 > 0.f) gr -= rg.g[kk] * cw / (n2 * n) * th;
-                        }
-                    }
-                    break;
-                }
-                case RK_MONO_G: {
-                    const int kk = (int)rel;
-                    if (rg.col_off[0] >= 0 && kk < rg.n) {
-                        const float cw = part_colsum(a, rg.col_off[0] + a.L * a.kpad + kk);
-                        const float n2 = rg.n2[kk];
-                        gr = n2 > 0.f ? cw / sqrtf(n2) : 0.f;
-                    }
-                    break;
-                }
-                default: break;
+                break;
             }
-            if (rg.reg) gr = fmaf(a.reg_const, th, gr);
+            case RK_THR: {
+                if (rel == 0) gr[0] = th[0] >= CFL_THR_FLOOR ? a.colsum[a.cs_rowq + P_DTHR] : 0.f;
+                break;
+            }
+            case RK_MONO_W: {  // V[L][kpad]; cs_raw[0] >= 0 marks the encoder whose gate is used
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int l = (int)((rel + e) / a.kpad), kk = (int)((rel + e) % a.kpad);
+                    if (l < a.L && kk < rg.n && rg.cs_raw[0] >= 0) {
+                        float g1 = a.colsum[a.cs_mono + l * a.kpad + kk];
+                        if (a.weight_norm) {
+                            const float cw = a.colsum[a.cs_duc + kk];
+                            const float n2 = rg.n2[kk], n = sqrtf(n2);
+                            if (n2 > 0.f) g1 -= rg.g[kk] * cw / (n2 * n) * th[e];
+                        }
+                        gr[e] = g1;
+                    }
+                }
+                break;
+            }
+            case RK_MONO_G: {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int kk = (int)rel + e;
+                    if (rg.cs_raw[0] >= 0 && kk < rg.n) {
+                        const float n2 = rg.n2[kk];
+                        gr[e] = n2 > 0.f ? a.colsum[a.cs_duc + kk] / sqrtf(n2) : 0.f;
+                    }
+                }
+                break;
+            }
+            default: break;
         }
-        a.grad[idx] = gr;
+        if (rg.reg) gr += a.reg_const * th;
+    }
+    *(f32x4 *)(a.grad + base) = gr;
+    if (a.adam_m) {  // fused TF-Adam apply (single-GPU step)
+        f32x4 mm = *(const f32x4 *)(a.adam_m + base), vv = *(const f32x4 *)(a.adam_v + base);
+        mm = a.b1 * mm + (1.f - a.b1) * gr;
+        vv = a.b2 * vv + (1.f - a.b2) * gr * gr;
+        f32x4 tn = th;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) tn[e] -= a.lr_t * mm[e] / (sqrtf(vv[e]) + a.eps);
+        *(f32x4 *)(a.adam_m + base) = mm;
+        *(f32x4 *)(a.adam_v + base) = vv;
+        *(f32x4 *)(a.theta_out + base) = tn;
     }
 }
 
@@ -1026,13 +1127,16 @@ extern "C" int cfl_layout(const CflShape *s, CflLayout *out) {
 // ---- execution plan --------------------------------------------------------
 struct Plan {
     CflLayout lay;
-    int R, Rpad, S, P, nrb, partw, nregblocks;
-    int src_npad, dst_npad, src_n, dst_n;
-    int col_off[2], mono_off, kpad, Lq;
-    int n2_total;
+    int R, Rpad, S, P, nrb, nregblocks;
+    int kpad, Lq;
+    bool has_raw, has_cwx, mono;
+    // colsum vector offsets
+    int cs_raw[2], cs_cwx[2], cs_mono, cs_duc, cs_rowq, cs_total;
     // workspace offsets (floats)
-    size_t ypart[2], dyt[2], wpart[2], part, regpart, n2, total_floats;
+    size_t ypart[2], dyt[2], raw[2], cwx[2], wpart[2];
+    size_t mono_ya, mono_du, mono_duc, rowq, colsum, regpart, n2, total_floats;
     size_t mid_lds;
+    int ys;
 };
 
 static inline int pow2_floor(int x) { int p = 1; while (p * 2 <= x) p *= 2; return p; }
@@ -1053,9 +1157,10 @@ static int make_plan(const CflShape *s, int64_t rows, int groups, bool train, Pl
     if (rows * groups > (1ll << 30)) return set_err(CFL_E_SHAPE, "too many rows");
     const CflHead *hs, *hd;
     side_heads(s, pl->lay, &hs, &hd);
-    pl->src_npad = hs->npad; pl->dst_npad = hd->npad; pl->src_n = hs->n; pl->dst_n = hd->n;
+    if (hs->npad > 1024 || hd->npad > 1024) return set_err(CFL_E_UNSUPPORTED, "more than 1024 head columns");
     pl->R = (int)(rows * groups);
     const int njobs = (hs->npad / 16 + 3) / 4 + (hd->npad / 16 + 3) / 4;
+    if (njobs > CFL_MAX_JOBS) return set_err(CFL_E_UNSUPPORTED, "too many column chunks");
     // grad row split: aim at >= 512 workgroups, rows per workgroup >= 64
     int P = 1;
     if (train) {
@@ -1067,44 +1172,61 @@ static int make_plan(const CflShape *s, int64_t rows, int groups, bool train, Pl
     }
     pl->P = P;
     pl->Rpad = (int)round_up(pl->R, 64 * P);
-    // proj d split: aim at >= 512 workgroups, >= one 16-d group per wave
+    // proj d split: aim at >= 512 workgroups, >= two 16-d groups per wave
     const int rtiles = (pl->R + 31) / 32;
     int S = (512 + rtiles * njobs - 1) / (rtiles * njobs);
     S = pow2_floor(S < 1 ? 1 : S);
-    const int maxS = s->D / 16 / 8 / 2 > 0 ? s->D / 16 / 8 / 2 : 1;  // >= 2 groups per wave
+    const int maxS = s->D / 16 / 8 / 2 > 0 ? s->D / 16 / 8 / 2 : 1;
     if (S > maxS) S = pow2_floor(maxS);
     if (S > 16) S = 16;
     pl->S = S;
-    pl->nrb = pl->Rpad / 16;
+    pl->nrb = pl->Rpad / MID_RB;
     pl->kpad = pl->lay.enc[0].mono.npad;
-    pl->Lq = (s->L + 3) / 4;
-    pl->col_off[0] = 0;
-    pl->col_off[1] = 2 * hs->npad;
-    pl->mono_off = 2 * hs->npad + 2 * hd->npad;
-    const int mono_sz = s->dist_type == CFL_DIST_MONOMER ? s->L * pl->kpad + pl->kpad : 0;
-    pl->partw = (int)round_up(P_NSCALAR + pl->mono_off + mono_sz, 16);
+    pl->Lq = (s->L + 15) / 16;
+    pl->has_raw = train && s->has_bias;
+    pl->has_cwx = train && s->weight_norm;
+    pl->mono = s->dist_type == CFL_DIST_MONOMER;
     pl->nregblocks = (int)((pl->lay.total / 64 + 63) / 64);
-    pl->n2_total = 0;
+    // colsum vector
+    int cs = 0;
+    auto cst = [&](int n) { int o = cs; cs += n; return o; };
+    pl->cs_raw[0] = cst(hs->npad); pl->cs_raw[1] = cst(hd->npad);
+    pl->cs_cwx[0] = cst(hs->npad); pl->cs_cwx[1] = cst(hd->npad);
+    pl->cs_mono = cst(pl->mono ? s->L * pl->kpad : 0);
+    pl->cs_duc = cst(pl->mono ? pl->kpad : 0);
+    pl->cs_rowq = cst(16);
+    pl->cs_total = cs;
+    // workspace
     size_t off = 0;
     auto take = [&](size_t n) { size_t o = off; off += round_up((int64_t)n, 64); return o; };
-    pl->ypart[0] = take((size_t)S * hs->npad * pl->Rpad);
-    pl->ypart[1] = take((size_t)S * hd->npad * pl->Rpad);
+    const size_t rp = pl->Rpad;
+    pl->ypart[0] = take((size_t)S * hs->npad * rp);
+    pl->ypart[1] = take((size_t)S * hd->npad * rp);
     if (train) {
-        pl->dyt[0] = take((size_t)hs->npad * pl->Rpad);
-        pl->dyt[1] = take((size_t)hd->npad * pl->Rpad);
+        pl->dyt[0] = take(hs->npad * rp);
+        pl->dyt[1] = take(hd->npad * rp);
+        pl->raw[0] = take(pl->has_raw ? hs->npad * rp : 0);
+        pl->raw[1] = take(pl->has_raw ? hd->npad * rp : 0);
+        pl->cwx[0] = take(pl->has_cwx ? hs->npad * rp : 0);
+        pl->cwx[1] = take(pl->has_cwx ? hd->npad * rp : 0);
+        pl->mono_ya = take(pl->mono ? s->L * rp : 0);
+        pl->mono_du = take(pl->mono ? pl->kpad * rp : 0);
+        pl->mono_duc = take(pl->mono ? pl->kpad * rp : 0);
+        pl->rowq = take(16 * rp);
+        pl->colsum = take(cs);
         pl->wpart[0] = take((size_t)P * hs->npad * s->D);
         pl->wpart[1] = take((size_t)P * hd->npad * s->D);
-        pl->part = take((size_t)pl->nrb * pl->partw);
         pl->regpart = take((size_t)pl->nregblocks);
     }
-    pl->n2 = take(6 * 1024);  // squared column norms of up to 6 heads (npad <= 1024 each)
+    pl->n2 = take(2 * 6 * 1024);  // squared column norms + gain snapshot of up to 6 heads
     pl->total_floats = off;
     const int ks = s->dist_type == CFL_DIST_PCD ? s->K : 1;
     const int kd = s->dist_type == CFL_DIST_MONOMER ? s->K : 1;
     const int slots = (ks + kd) * pl->Lq * (s->weight_norm ? 2 : 1) + pl->Lq + 4 * s->K;
-    pl->mid_lds = (size_t)slots * 64 * sizeof(float);
+    pl->ys = hs->npad + hd->npad + 4;
+    const int mw = pl->mono ? ((s->L * pl->kpad + 3) & ~3) : 0;
+    pl->mid_lds = ((size_t)(MID_RB + 2) * pl->ys + mw + (size_t)slots * 64) * sizeof(float);
     if (pl->mid_lds > 160 * 1024) return set_err(CFL_E_UNSUPPORTED, "L*K too large for the mid kernel");
-    if (hs->npad > 1024 || hd->npad > 1024) return set_err(CFL_E_UNSUPPORTED, "more than 1024 head columns");
     return CFL_OK;
 }
 
@@ -1132,6 +1254,7 @@ static int launch_colnorm(const CflShape *s, const Plan &pl, const float *theta,
     memset(&ca, 0, sizeof(ca));
     ca.theta = theta;
     ca.n2 = ws + pl.n2;
+    ca.gcopy = ws + pl.n2 + 6 * 1024;
     ca.D = s->D;
     int nh = 0, off = 0, ncols = 0;
     const int nenc = s->directed ? 2 : 1;
@@ -1142,6 +1265,7 @@ static int launch_colnorm(const CflShape *s, const Plan &pl, const float *theta,
             n2_off[e][k] = -1;
             if (hh[k]->w < 0) continue;
             ca.w_off[nh] = hh[k]->w;
+            ca.g_off[nh] = hh[k]->g;
             ca.npad[nh] = hh[k]->npad;
             ca.n2_off[nh] = off;
             ca.strided[nh] = k == 2;
@@ -1166,10 +1290,12 @@ struct SideRt {
     int which;   // 0 outputs, 1 proto
 };
 
+struct AdamFuse { float *theta, *m, *v; float lr_t, b1, b2, eps; };
+
 static int run_pairs(const CflShape *s, const CflNorm *norm, const CflLossCfg *loss,
                      const float *const *x, int groups, int64_t rows, const float *theta,
                      float *grad, float *scalars, float *scores, float *dists, void *workspace,
-                     size_t workspace_bytes, hipStream_t st) {
+                     size_t workspace_bytes, hipStream_t st, const AdamFuse *adam = nullptr) {
     const bool train = grad != nullptr;
     Plan pl;
     int rc = make_plan(s, rows, groups, train, &pl);
@@ -1185,6 +1311,7 @@ static int run_pairs(const CflShape *s, const CflNorm *norm, const CflLossCfg *l
     float *ws = (float *)workspace;
     float in_mul;
     NormDev nd = make_norm(norm, &in_mul);
+    const size_t rp = pl.Rpad;
 
     SideRt side[2];
     switch (s->dist_type) {
@@ -1202,6 +1329,7 @@ static int run_pairs(const CflShape *s, const CflNorm *norm, const CflLossCfg *l
     int n2_off[2][3] = {{-1, -1, -1}, {-1, -1, -1}};
     launch_colnorm(s, pl, theta, ws, n2_off, st);
     const float *n2base = ws + pl.n2;
+    const float *gbase = ws + pl.n2 + 6 * 1024;
 
     // ---- proj ---------------------------------------------------------------
     {
@@ -1212,13 +1340,13 @@ static int run_pairs(const CflShape *s, const CflNorm *norm, const CflLossCfg *l
             const CflHead *h = side[sd].head;
             const int tiles = h->npad / 16;
             for (int c0 = 0; c0 < tiles; c0 += 4) {
-                if (nj >= CFL_MAX_JOBS) return set_err(CFL_E_UNSUPPORTED, "too many column chunks");
                 ProjJob &j = pa.job[nj++];
                 j.x0 = xs[sd][0]; j.x1 = xs[sd][1];
                 j.wt = theta + h->w + (size_t)c0 * 16 * s->D;
-                j.ypart = ws + pl.ypart[sd] + (size_t)c0 * 16 * pl.Rpad;
-                j.sstride = (long long)h->npad * pl.Rpad;
+                j.ypart = ws + pl.ypart[sd] + (size_t)c0 * 16;
+                j.sstride = (long long)h->npad * rp;
                 j.nt = tiles - c0 < 4 ? tiles - c0 : 4;
+                j.npad = h->npad;
             }
         }
         pa.B = (int)rows; pa.R = pl.R; pa.Rpad = pl.Rpad; pa.D = s->D; pa.S = pl.S; pa.norm = nd;
@@ -1228,43 +1356,48 @@ static int run_pairs(const CflShape *s, const CflNorm *norm, const CflLossCfg *l
     }
 
     // ---- mid ----------------------------------------------------------------
-    int ncolumns_reg = 0;
     MidArgs ma;
     memset(&ma, 0, sizeof(ma));
     for (int sd = 0; sd < 2; ++sd) {
         const CflHead *h = side[sd].head;
         MidSide &m = ma.side[sd];
         m.ypart = ws + pl.ypart[sd];
-        m.sstride = (long long)h->npad * pl.Rpad;
+        m.sstride = (long long)h->npad * rp;
         m.b = h->b >= 0 ? theta + h->b : nullptr;
         m.g = h->g >= 0 ? theta + h->g : nullptr;
         m.n2 = s->weight_norm ? n2base + n2_off[side[sd].enc][side[sd].which] : nullptr;
         m.dyt = train ? ws + pl.dyt[sd] : nullptr;
+        m.raw = pl.has_raw ? ws + pl.raw[sd] : nullptr;
+        m.cwx = pl.has_cwx ? ws + pl.cwx[sd] : nullptr;
         m.n = h->n; m.npad = h->npad;
         m.is_proto = side[sd].which == 1;
-        m.col_off = pl.col_off[sd];
     }
     const CflHead &mono = pl.lay.enc[0].mono;
-    if (s->dist_type == CFL_DIST_MONOMER) {
+    if (pl.mono) {
         ma.mono_w = theta + mono.w;
         ma.mono_g = mono.g >= 0 ? theta + mono.g : nullptr;
         ma.mono_n2 = s->weight_norm ? n2base + n2_off[0][2] : nullptr;
+        if (train) {
+            ma.mono_ya = ws + pl.mono_ya; ma.mono_du = ws + pl.mono_du; ma.mono_duc = ws + pl.mono_duc;
+        }
     }
-    ma.kpad = pl.kpad; ma.mono_off = pl.mono_off;
+    ma.kpad = pl.kpad;
     ma.S = pl.S; ma.L = s->L; ma.K = s->K; ma.Lq = pl.Lq; ma.dist_type = s->dist_type;
     ma.act = s->act_type; ma.weight_norm = s->weight_norm; ma.in_mul = in_mul;
     ma.thr = theta + pl.lay.thr;
-    ma.B = (int)rows; ma.R = pl.R; ma.Rpad = pl.Rpad; ma.groups = groups;
+    ma.B = (int)rows; ma.R = pl.R; ma.Rpad = pl.Rpad;
     ma.train = train;
     if (train) {
         ma.use_threshold = loss->use_threshold;
         ma.pos_weight = loss->pos_weight; ma.caffe_margin = loss->caffe_margin; ma.lambda_m = loss->lambda_m;
-        ma.part = ws + pl.part; ma.partw = pl.partw;
+        ma.rowq = ws + pl.rowq;
+        ma.thr_copy = ws + pl.rowq + 15 * rp;
         ma.regpart = ws + pl.regpart;
         ma.theta = theta;
     }
     ma.scores = scores; ma.dists = dists;
-    ma.nrb = train ? pl.nrb : (pl.R + 15) / 16;
+    ma.nrb = train ? pl.nrb : (pl.R + MID_RB - 1) / MID_RB;
+    ma.ys = pl.ys;
 
     // regions (shared by the mid regulariser blocks and finalize)
     FinArgs fa;
@@ -1276,7 +1409,8 @@ static int run_pairs(const CflShape *s, const CflNorm *norm, const CflLossCfg *l
         auto add = [&](int kind, int64_t off, int64_t cnt, int reg, int npad, int n) -> Region & {
             Region &r = fa.reg[nr++];
             r.off = off; r.cnt = round_up(cnt, 64); r.kind = kind; r.reg = reg; r.npad = npad; r.n = n;
-            r.slab[0] = r.slab[1] = nullptr; r.col_off[0] = r.col_off[1] = -1;
+            r.slab[0] = r.slab[1] = nullptr;
+            r.cs_raw[0] = r.cs_raw[1] = r.cs_cwx[0] = r.cs_cwx[1] = -1;
             r.g = r.n2 = nullptr;
             return r;
         };
@@ -1295,27 +1429,27 @@ static int run_pairs(const CflShape *s, const CflNorm *norm, const CflLossCfg *l
                     const bool same_enc = s->directed ? side[sd].enc == e : true;
                     if (side[sd].head->w == h->w && same_enc && side[sd].which == k) {
                         rw.slab[ns] = ws + pl.wpart[sd];
-                        rw.col_off[ns] = pl.col_off[sd];
-                        if (rb) rb->col_off[ns] = pl.col_off[sd];
-                        if (rgn) rgn->col_off[ns] = pl.col_off[sd];
+                        rw.cs_cwx[ns] = pl.cs_cwx[sd];
+                        if (rb) rb->cs_raw[ns] = pl.cs_raw[sd];
+                        if (rgn) rgn->cs_cwx[ns] = pl.cs_cwx[sd];
                         ++ns;
                     }
                 }
                 if (s->weight_norm) {
                     const float *n2p = n2base + n2_off[e][k];
-                    rw.g = theta + h->g; rw.n2 = n2p;
-                    if (rgn) { rgn->g = theta + h->g; rgn->n2 = n2p; }
+                    rw.g = gbase + n2_off[e][k]; rw.n2 = n2p;
+                    if (rgn) { rgn->g = rw.g; rgn->n2 = n2p; }
                 }
             }
             const CflHead &m = pl.lay.enc[e].mono;
             if (m.w >= 0) {
                 Region &rm = add(RK_MONO_W, m.w, (int64_t)s->L * m.npad, regon, m.npad, m.n);
-                if (e == 0) rm.col_off[0] = pl.mono_off;   // the gate head of the SRC encoder is used
-                if (s->weight_norm) { rm.g = theta + m.g; rm.n2 = n2base + n2_off[e][2]; }
+                if (e == 0) rm.cs_raw[0] = 0;   // the gate head of the SRC encoder is the one used
+                if (s->weight_norm) { rm.g = gbase + n2_off[e][2]; rm.n2 = n2base + n2_off[e][2]; }
                 if (m.g >= 0) {
                     Region &rmg = add(RK_MONO_G, m.g, m.npad, 0, m.npad, m.n);
-                    if (e == 0) rmg.col_off[0] = pl.mono_off;
-                    rmg.g = theta + m.g; rmg.n2 = n2base + n2_off[e][2];
+                    if (e == 0) rmg.cs_raw[0] = 0;
+                    rmg.g = gbase + n2_off[e][2]; rmg.n2 = n2base + n2_off[e][2];
                 }
             }
         }
@@ -1335,7 +1469,6 @@ static int run_pairs(const CflShape *s, const CflNorm *norm, const CflLossCfg *l
             nreg_blocks = (int)((groups_total + 63) / 64);
             if (nreg_blocks > pl.nregblocks) return set_err(CFL_E_WORKSPACE, "regpart too small");
         }
-        (void)ncolumns_reg;
     }
     {
         ProfScope ps(st, CFL_K_MID);
@@ -1346,7 +1479,7 @@ static int run_pairs(const CflShape *s, const CflNorm *norm, const CflLossCfg *l
         return CFL_OK;
     }
 
-    // ---- grad ---------------------------------------------------------------
+    // ---- grad (+ row reductions in z-slice 0) ---------------------------------
     {
         GradArgs ga;
         memset(&ga, 0, sizeof(ga));
@@ -1357,27 +1490,50 @@ static int run_pairs(const CflShape *s, const CflNorm *norm, const CflLossCfg *l
             for (int c0 = 0; c0 < tiles; c0 += 4) {
                 GradJob &j = ga.job[nj++];
                 j.x0 = xs[sd][0]; j.x1 = xs[sd][1];
-                j.dyt = ws + pl.dyt[sd] + (size_t)c0 * 16 * pl.Rpad;
+                j.dyt = ws + pl.dyt[sd] + (size_t)c0 * 16 * rp;
                 j.wpart = ws + pl.wpart[sd] + (size_t)c0 * 16 * s->D;
                 j.pstride = (long long)h->npad * s->D;
                 j.nt = tiles - c0 < 4 ? tiles - c0 : 4;
             }
         }
         ga.B = (int)rows; ga.R = pl.R; ga.Rpad = pl.Rpad; ga.D = s->D; ga.P = pl.P; ga.norm = nd;
-        dim3 grid(s->D / 64, pl.P, nj);
+        int nr = 0, tot = 0;
+        auto red = [&](const float *A, const float *B, int count, int kdiv, int ostride, int out) {
+            if (count <= 0) return;
+            RedRange &r = ga.red[nr++];
+            r.A = A; r.B = B; r.count = count; r.kdiv = kdiv; r.ostride = ostride; r.out_off = out;
+            tot += count;
+        };
+        red(ws + pl.rowq, nullptr, P_NROWQ, 0, 0, pl.cs_rowq);
+        for (int sd = 0; sd < 2; ++sd) {
+            if (pl.has_raw) red(ws + pl.raw[sd], nullptr, side[sd].head->n, 0, 0, pl.cs_raw[sd]);
+            if (pl.has_cwx) red(ws + pl.cwx[sd], nullptr, side[sd].head->n, 0, 0, pl.cs_cwx[sd]);
+        }
+        if (pl.mono) {
+            red(ws + pl.mono_ya, ws + pl.mono_du, s->L * s->K, s->K, pl.kpad, pl.cs_mono);
+            if (s->weight_norm) red(ws + pl.mono_duc, nullptr, s->K, 0, 0, pl.cs_duc);
+        }
+        ga.nred = nr; ga.red_total = tot; ga.colsum = ws + pl.colsum;
+        dim3 grid(s->D / 64, pl.P, nj + 1);
         ProfScope ps(st, CFL_K_GRAD);
         hipLaunchKernelGGL(cfl_grad_kernel, grid, dim3(256), 4 * 4 * 4 * 64 * sizeof(f32x4), st, ga);
     }
 
     // ---- finalize -----------------------------------------------------------
     fa.total = pl.lay.total; fa.theta = theta; fa.grad = grad;
-    fa.part = ws + pl.part; fa.partw = pl.partw; fa.nrb = pl.nrb; fa.P = pl.P; fa.D = s->D;
-    fa.L = s->L; fa.kpad = pl.kpad; fa.mono_off = pl.mono_off; fa.weight_norm = s->weight_norm;
+    fa.colsum = ws + pl.colsum; fa.cs_rowq = pl.cs_rowq; fa.cs_mono = pl.cs_mono; fa.cs_duc = pl.cs_duc;
+    fa.P = pl.P; fa.D = s->D;
+    fa.L = s->L; fa.kpad = pl.kpad > 0 ? pl.kpad : 1; fa.weight_norm = s->weight_norm;
     fa.reg_const = loss->reg_const; fa.use_threshold = loss->use_threshold;
     fa.pos_weight = loss->pos_weight; fa.caffe_margin = loss->caffe_margin; fa.lambda_m = loss->lambda_m;
     fa.B = (int)rows; fa.regpart = ws + pl.regpart; fa.nregblocks = nreg_blocks;
     fa.scalars = scalars; fa.thr_off = pl.lay.thr;
-    fa.nblocks_main = (int)((pl.lay.total / 64 + 15) / 16);
+    fa.nblocks_main = (int)((pl.lay.total / 4 + 255) / 256);
+    fa.thr_copy = ws + pl.rowq + 15 * rp;
+    if (adam) {
+        fa.adam_m = adam->m; fa.adam_v = adam->v; fa.theta_out = adam->theta;
+        fa.lr_t = adam->lr_t; fa.b1 = adam->b1; fa.b2 = adam->b2; fa.eps = adam->eps;
+    }
     {
         ProfScope ps(st, CFL_K_FINALIZE);
         hipLaunchKernelGGL(cfl_finalize_kernel, dim3(fa.nblocks_main + 1), dim3(256), 0, st, fa);
@@ -1405,6 +1561,19 @@ extern "C" int cfl_pair_step_fwd_bwd(const CflShape *shape, const CflNorm *norm,
         return set_err(CFL_E_SHAPE, "caffe_margin and lambda_m are exclusive (cfl/utils.py:72-73)");
     return run_pairs(shape, norm, loss, x4, 2, B, theta, grad, scalars, nullptr, nullptr, workspace,
                      workspace_bytes, (hipStream_t)stream);
+}
+
+extern "C" int cfl_pair_train_step(const CflShape *shape, const CflNorm *norm,
+                                   const CflLossCfg *loss, const float *const x4[4], int64_t B,
+                                   float *theta, float *m, float *v, float *grad, float *scalars,
+                                   float lr_t, float beta1, float beta2, float eps,
+                                   void *workspace, size_t workspace_bytes, cfl_stream_t stream) {
+    if (!loss || !x4 || !grad || !scalars || !m || !v) return set_err(CFL_E_SHAPE, "NULL pointer");
+    if (loss->caffe_margin != 0.f && loss->lambda_m != 0.f)
+        return set_err(CFL_E_SHAPE, "caffe_margin and lambda_m are exclusive (cfl/utils.py:72-73)");
+    AdamFuse af = {theta, m, v, lr_t, beta1, beta2, eps};
+    return run_pairs(shape, norm, loss, x4, 2, B, theta, grad, scalars, nullptr, nullptr, workspace,
+                     workspace_bytes, (hipStream_t)stream, &af);
 }
 
 extern "C" int cfl_adam_tf(float *theta, float *m, float *v, const float *grad, int64_t n,

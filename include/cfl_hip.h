@@ -177,6 +177,16 @@ int cfl_pair_step_fwd_bwd(const CflShape *shape, const CflNorm *norm,
                           float *scalars, void *workspace,
                           size_t workspace_bytes, cfl_stream_t stream);
 
+/* Single-GPU fast path: cfl_pair_step_fwd_bwd with the TF-Adam apply fused into
+ * the last kernel (theta, m, v updated in place; grad still written).  Equals
+ * cfl_pair_step_fwd_bwd followed by cfl_adam_tf(..., grad_scale = 1); replaces the
+ * whole `sess.run([s_optim, ...])` of cfl/bin/train_dist.py:81-82.               */
+int cfl_pair_train_step(const CflShape *shape, const CflNorm *norm,
+                        const CflLossCfg *loss, const float *const x4[4], int64_t B,
+                        float *theta, float *m, float *v, float *grad, float *scalars,
+                        float lr_t, float beta1, float beta2, float eps,
+                        void *workspace, size_t workspace_bytes, cfl_stream_t stream);
+
 /* TF-1.x AdamOptimizer apply over a flat array:
  *   m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ; theta -= lr_t m / (sqrt(v)+eps)
  * Replaces tf.train.AdamOptimizer(...).minimize at cfl/models/dist.py:291-293,

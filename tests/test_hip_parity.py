@@ -239,3 +239,35 @@ def test_errors_are_reported_not_thrown():
         H.pair_scores(sh, H.make_norm(), x, x, theta, ws)
     with pytest.raises(H.CflHipError, match='no CPU fallback'):
         H.pair_scores(sh, H.make_norm(), x.cpu(), x.cpu(), theta, ws)
+
+
+@pytest.mark.parametrize('style,dist,K,L', [('dist', 'pcd', 3, 20), ('cfl', 'monomer', 2, 12),
+                                            ('cfl', 'siamese', 1, 32)])
+def test_fused_train_step_equals_fwd_bwd_plus_adam(style, dist, K, L):
+    """cfl_pair_train_step (Adam fused into the last kernel) == cfl_pair_step_fwd_bwd
+    followed by cfl_adam_tf, including the weight-norm gain snapshot."""
+    rng = np.random.RandomState(77)
+    D, B, nv = 512, 96, 4.0
+    cfg = O.EncoderCfg(D=D, L=L, K=K, dist_type=dist, style=style)
+    p = _mk(cfg, rng)
+    sh = _shape(cfg)
+    lkw = dict(reg_const=1e-3, pos_weight=0.5)
+    norm, loss = H.make_norm(1.0 / nv), H.make_loss(**lkw)
+    batch = [torch.from_numpy(_inputs(rng, B, D, 1.0)).cuda() for _ in range(4)]
+    ws = torch.empty(H.workspace_bytes(sh, B, 2) // 4, dtype=torch.float32, device='cuda')
+    res = []
+    for fused in (False, True):
+        theta = H.pack_theta(sh, p, None, 0.5, 'cuda')
+        m = torch.full_like(theta, 0.01)
+        v = torch.full_like(theta, 0.02)
+        grad = torch.zeros_like(theta)
+        scal = torch.zeros(H.S_COUNT, device='cuda')
+        for _ in range(3):
+            if fused:
+                H.pair_train_step(sh, norm, loss, batch, theta, m, v, grad, scal, ws, 2e-3, 0.9, 0.999)
+            else:
+                H.pair_step_fwd_bwd(sh, norm, loss, batch, theta, grad, scal, ws)
+                H.adam_tf(theta, m, v, grad, 2e-3, 0.9, 0.999)
+        res.append([t.cpu().numpy() for t in (theta, m, v, grad, scal)])
+    for a, b in zip(*res):
+        assert np.allclose(a, b, rtol=1e-6, atol=1e-9)
