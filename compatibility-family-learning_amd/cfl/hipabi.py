@@ -12,7 +12,8 @@ import numpy as np
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), 'lib', 'libcfl_hip.so')
+LIB_PATH = os.environ.get('CFL_HIP_LIB') or os.path.join(
+    os.path.dirname(_HERE), 'lib', 'libcfl_hip.so')
 
 DIST_TYPES = {'pcd': 0, 'monomer': 1, 'siamese': 2}
 ACT_TYPES = {None: 0, 'linear': 0, 'sigmoid': 1, 'tanh': 2, 'relu': 3}
@@ -225,6 +226,17 @@ def gather_rows(table, idx, out=None):
 # ---------------------------------------------------------------------------
 # theta <-> named variables in the reference (TensorFlow) layout [D, N]
 # ---------------------------------------------------------------------------
+def wt_to_frag(wt):
+    """Wt[npad][D] -> fragment-major Wf[nt][g][q][c16][e] (see csrc/cfl_hip.hip):
+    column c = 16nt + c16, d = 16g + 4q + e; one contiguous 1 KiB block per (nt, g)."""
+    npad, D = wt.shape
+    return wt.reshape(npad // 16, 16, D // 16, 4, 4).permute(0, 2, 3, 1, 4).contiguous()
+
+
+def frag_to_wt(flat, npad, D):
+    return flat.reshape(npad // 16, D // 16, 4, 16, 4).permute(0, 3, 1, 2, 4).reshape(npad, D)
+
+
 def head_views(lay, shape, e):
     """Yield (scope-relative variable name, kind, CflHead) for encoder e."""
     enc = lay.enc[e]
@@ -248,8 +260,9 @@ def pack_theta(shape, params, params_dst=None, thr=1e-6, device='cpu'):
                 blk = theta[h.w:h.w + shape.L * h.npad].view(shape.L, h.npad)
                 blk[:, :h.n] = W
             else:
-                blk = theta[h.w:h.w + h.npad * D].view(h.npad, D)
-                blk[:h.n] = W.t()
+                wt = torch.zeros(h.npad, D, dtype=torch.float32)
+                wt[:h.n] = W.t()
+                theta[h.w:h.w + h.npad * D] = wt_to_frag(wt).reshape(-1)
             if h.b >= 0:
                 theta[h.b:h.b + h.n] = torch.as_tensor(np.asarray(p[name + '/b'], dtype=np.float32))
             if h.g >= 0:
@@ -270,7 +283,8 @@ def unpack_theta(shape, theta):
             if name == 'mono':
                 p['mono/W'] = th[h.w:h.w + shape.L * h.npad].view(shape.L, h.npad)[:, :h.n].numpy().copy()
             else:
-                p[name + '/W'] = th[h.w:h.w + h.npad * D].view(h.npad, D)[:h.n].t().numpy().copy()
+                wt = frag_to_wt(th[h.w:h.w + h.npad * D], h.npad, D)
+                p[name + '/W'] = wt[:h.n].t().contiguous().numpy().copy()
             if h.b >= 0:
                 p[name + '/b'] = th[h.b:h.b + h.n].numpy().copy()
             if h.g >= 0:

@@ -2,15 +2,30 @@
 // training / scoring hot path.  See include/cfl_hip.h for the boundary and
 // DESIGN.md for the data layout and the roofline of every kernel.
 //
-// One training step = 5 launches on the caller's stream:
-//   [colnorm]  (weight-norm only)  n2[c] = sum_d V[d][c]^2
-//   proj       skinny fp32-MFMA projection partials  Y_s = X[:, slice_s] . Wt[:, slice_s]^T
-//   mid        slice-sum + bias/scale/activation, distance, loss, dL/dY (transposed)
+// One training step = 4 launches on the caller's stream (5 with weight-norm):
+//   [colnorm]  (weight-norm only)  n2[c] = sum_d V[d][c]^2, gain snapshot
+//   proj       skinny fp32-MFMA projection partials  Y_s = X[:, slice_s] . W[slice_s, :]
+//   mid        slice-sum + bias/scale/activation, distance, loss, dL/dY
 //              (+ extra blocks: L2-regulariser partial sums)
-//   grad       skinny fp32-MFMA weight-gradient partials  dWt_p = dYt[:, rows_p] . X[rows_p, :]
-//   finalize   partial slabs -> flat gradient (+bias/gain/threshold grads, +reg) and scalars
-// followed by cfl_adam_tf (separate entry point so that a data-parallel caller
-// can all-reduce the flat gradient in between).
+//   grad       skinny fp32-MFMA weight-gradient partials  dW_p = X[rows_p, :]^T . dY[rows_p, :]
+//              (+ z-slice 0: row reductions for bias / gain / loss scalars)
+//   finalize   partial slabs -> flat gradient (+bias/gain/threshold grads, +reg), scalars,
+//              optionally the fused TF-Adam apply
+// cfl_adam_tf is a separate entry point so that a data-parallel caller can
+// all-reduce the flat gradient between cfl_pair_step_fwd_bwd and the update.
+//
+// FRAGMENT-MAJOR LAYOUTS.  Every operand that the library owns is stored in the
+// order the 16x16x4 fp32 MFMA consumes it, so that each wave instruction moves one
+// contiguous 1 KiB block:
+//   weights (theta, Adam slots, gradient, gradient slabs)  Wf[nt][g][q][c16][e]
+//        = W[d = 16g + 4q + e][col = 16nt + c16]        (one 1 KiB block per (nt, g))
+//   dL/dY (scratch)                                       dYf[nt][rg][kq][c16][j]
+//        = dY[row = 16rg + 4kq + j][col = 16nt + c16]   (one 1 KiB block per (nt, rg))
+// Lane l of a wave reads the float4 at block + 16*l bytes: l&15 is the MFMA N index
+// (column), l>>4 the MFMA K index, and the four floats feed four consecutive MFMA
+// K-steps.  The input batches x are caller-owned row-major [B][D]; the projection
+// kernel reads them in full 256-byte row segments and transposes them into MFMA
+// order through a wave-private XOR-swizzled LDS tile.
 //
 // Reference arithmetic restated (paths relative to the reference tree):
 //   heads      cfl/models/dist.py:43-68, cfl/layers.py:80-90, cfl/models/base.py:43-105
@@ -23,7 +38,10 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <mutex>
+#include <vector>
 
 #include "../../include/cfl_hip.h"
 
@@ -56,8 +74,6 @@ static int set_err(int code, const char *fmt, ...) {
 // ---------------------------------------------------------------------------
 // optional per-kernel event timing (cfl_profile_enable / cfl_profile_read)
 // ---------------------------------------------------------------------------
-#include <mutex>
-#include <vector>
 struct ProfRec { int kind; hipEvent_t a, b; };
 static bool g_prof_on = false;
 static std::vector<ProfRec> g_prof;
@@ -124,18 +140,27 @@ __device__ __forceinline__ const float *row_ptr(const float *x0, const float *x1
     return rc < B ? x0 + (size_t)rc * D : x1 + (size_t)(rc - B) * D;
 }
 
+__device__ __forceinline__ float wave_sum(float x) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
+    return x;
+}
+
 // ---------------------------------------------------------------------------
-// proj: Ypart[s][r][c] = sum_{d in slice s} X[r][d] * Wt[c][d]
-//   workgroup = 8 waves, one 32-row tile; wave w owns a d sub-range of slice s and
-//   computes the whole [32 x NT*16] tile for it with v_mfma_f32_16x16x4_f32.
-//   A fragment  lane(r16,q) : float4 X[row0+16mt+r16][d+4q .. d+4q+3]
-//   B fragment  lane(c16,q) : float4 Wt[16nt+c16][d+4q .. d+4q+3]
-//   MFMA k-step j uses element j of both, i.e. k index q <-> d + 4q + j.
-//   The 8 partial tiles are summed through LDS in a fixed order.
+// proj: Ypart[s][r][c] = sum_{d in slice s} X[r][d] * W[d][c]
+//   workgroup = 4 waves, one 32-row tile; wave w owns chunks of 128 d (8 groups of
+//   16) and computes the whole [32 x NT*16] tile for them with v_mfma_f32_16x16x4_f32.
+//   * all 16 x-loads of a chunk (32 rows x 128 d, 16 KiB per wave) are issued up
+//     front, each instruction covering 4 rows x 256 contiguous bytes;
+//   * each 64-d half is transposed into MFMA A order through a wave-private LDS tile
+//     [32 rows][16 x 16 B], chunk position XOR-swizzled by the row so that both the
+//     ds_write_b128 and the ds_read_b128 are bank-conflict free;
+//   * the W fragments are contiguous 1 KiB blocks of Wf, prefetched one group ahead.
+//   The 4 partial tiles are summed through LDS in a fixed order.
 // ---------------------------------------------------------------------------
 struct ProjJob {
     const float *x0, *x1;  // pair-group row blocks
-    const float *wt;       // Wt chunk [nt*16][D]
+    const float *wf;       // Wf tile base: blocks [(nt)*G + g]
     float *ypart;          // chunk base (column offset applied) inside [S][Rpad][npad]
     long long sstride;     // floats between slices (Rpad * npad)
     int nt, npad;
@@ -149,21 +174,16 @@ struct ProjArgs {
 
 template <int NT>
 __device__ __forceinline__ void proj_body(const ProjJob &jb, const ProjArgs &a, f32x4 *lds) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int r16 = lane & 15, q = lane >> 4;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // provably uniform
+    const int r16 = lane & 15, q4 = lane >> 4;  // MFMA: row / k index
+    const int rr8 = lane >> 3, ch8 = lane & 7;  // load: row within 8-row group / 16-B chunk
     const int row0 = blockIdx.x * 32;
     const int s = blockIdx.y;
-    const int G = a.D >> 4;  // 16-d groups
-    const int wg = s * 8 + wave, nw = a.S * 8;
-    const int g0 = (int)((long long)wg * G / nw), g1 = (int)((long long)(wg + 1) * G / nw);
-
-    const float *ap[2];
-    const float *bp[NT];
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-        ap[mt] = row_ptr(jb.x0, jb.x1, row0 + mt * 16 + r16, a.B, a.R, a.D) + 4 * q;
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) bp[nt] = jb.wt + (size_t)(nt * 16 + r16) * a.D + 4 * q;
+    const int G = a.D >> 4;           // 16-d groups
+    const int NC = (G + 7) >> 3;      // 128-d chunks
+    const int nw = a.S * 4, wg = s * 4 + wave;
+    const int cbeg = wg * NC / nw, cend = (wg + 1) * NC / nw;  // NC <= 2^16, nw <= 64
 
     f32x4 acc[2][NT];
 #pragma unroll
@@ -171,57 +191,111 @@ __device__ __forceinline__ void proj_body(const ProjJob &jb, const ProjArgs &a, 
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    f32x4 ac[2], bc[NT], an[2], bn[NT];
-    if (g0 < g1) {
+    const float *xrow[4];
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) ac[mt] = *(const f32x4 *)(ap[mt] + g0 * 16);
+    for (int i = 0; i < 4; ++i) xrow[i] = row_ptr(jb.x0, jb.x1, row0 + 8 * i + rr8, a.B, a.R, a.D) + 4 * ch8;
+    const float *wfl = jb.wf + lane * 4;
+    f32x4 *tile = lds + wave * 256;  // 32 rows x 8 chunks of 16 B = 4 KiB per wave
+
+    for (int c = cbeg; c < cend; ++c) {
+        const int g0 = c * 8;
+        const bool full = G - g0 >= 8;  // uniform; otherwise 4 groups (D % 64 == 0)
+        // Loads are issued in consumption order (vmcnt retires in order): W fragments of
+        // quarter 0, x of quarter 0, W of quarter 1, x of quarters 1..3; the W fragments of
+        // quarters 2 and 3 are issued while quarters 0 and 1 are being multiplied.
+        f32x4 bq[2][2][NT], araw[4][4];
+        auto loadB = [&](int qq, f32x4 (*dst)[NT]) {
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) bc[nt] = *(const f32x4 *)(bp[nt] + g0 * 16);
-    }
-    for (int g = g0; g < g1; ++g) {
-        if (g + 1 < g1) {
+            for (int gg = 0; gg < 2; ++gg)
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt) an[mt] = *(const f32x4 *)(ap[mt] + (g + 1) * 16);
+                for (int nt = 0; nt < NT; ++nt)
+                    dst[gg][nt] = *(const f32x4 *)(wfl + ((size_t)nt * G + g0 + 2 * qq + gg) * 256);
+        };
+        auto loadA = [&](int qq) {
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) bn[nt] = *(const f32x4 *)(bp[nt] + (g + 1) * 16);
+            for (int i = 0; i < 4; ++i) araw[qq][i] = *(const f32x4 *)(xrow[i] + g0 * 16 + qq * 32);
+        };
+        // sched_barrier(0) pins the issue order (hipcc otherwise hoists the later quarters)
+#if !defined(ABL_PROJ_NOB)
+        loadB(0, bq[0]);
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+#if !defined(ABL_PROJ_NOA)
+        loadA(0);
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+#if !defined(ABL_PROJ_NOB)
+        loadB(1, bq[1]);
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+#if !defined(ABL_PROJ_NOA)
+        loadA(1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (full) {
+            loadA(2);
+            __builtin_amdgcn_sched_barrier(0);
+            loadA(3);
+            __builtin_amdgcn_sched_barrier(0);
         }
+#endif
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) ac[mt] = norm_apply(ac[mt], a.norm);
+        for (int qq = 0; qq < 4; ++qq) {
+            if (qq >= 2 && !full) break;
+            // transpose this 32-d quarter into MFMA A order (wave-private LDS, XOR swizzle)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+            for (int i = 0; i < 4; ++i) {
+                const int row = 8 * i + rr8;
+                tile[row * 8 + (ch8 ^ (row & 7))] = norm_apply(araw[qq][i], a.norm);
+            }
+            f32x4 af[2][2];
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[mt][j], bc[nt][j],
-                                                                      acc[mt][nt], 0, 0, 0);
+                for (int gg = 0; gg < 2; ++gg) af[mt][gg] = tile[(mt * 16 + r16) * 8 + ((4 * gg + q4) ^ (r16 & 7))];
+#ifndef ABL_PROJ_NOMFMA
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) ac[mt] = an[mt];
+            for (int gg = 0; gg < 2; ++gg)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) bc[nt] = bn[nt];
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                                af[mt][gg][e], bq[qq & 1][gg][nt][e], acc[mt][nt], 0, 0, 0);
+#else
+            asm volatile("" ::"v"(af[0][0]), "v"(af[0][1]), "v"(af[1][0]), "v"(af[1][1]));
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) asm volatile("" ::"v"(bq[qq & 1][0][nt]), "v"(bq[qq & 1][1][nt]));
+#endif
+#if !defined(ABL_PROJ_NOB)
+            if (qq < 2 && full) loadB(qq + 2, bq[qq & 1]);
+#endif
+        }
     }
 
     // cross-wave sum: lds[wave][tile][lane]
+    __syncthreads();
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) lds[(wave * 2 * NT + mt * NT + nt) * 64 + lane] = acc[mt][nt];
     __syncthreads();
-    if (wave < 2 * NT) {
-        const int mt = wave / NT, nt = wave % NT;
-        f32x4 sum = lds[(0 * 2 * NT + wave) * 64 + lane];
+    for (int t = wave; t < 2 * NT; t += 4) {
+        const int mt = t / NT, nt = t % NT;
+        f32x4 sum = lds[(0 * 2 * NT + t) * 64 + lane];
 #pragma unroll
-        for (int w = 1; w < 8; ++w) sum += lds[(w * 2 * NT + wave) * 64 + lane];
+        for (int w = 1; w < 4; ++w) sum += lds[(w * 2 * NT + t) * 64 + lane];
         // C layout: col = lane&15, rows 4*(lane>>4) .. +3  ->  Ypart[s][row][npad] (row-major:
         // the mid kernel then reads whole rows with 16-byte loads)
-        float *dst = jb.ypart + (size_t)s * jb.sstride +
-                     (size_t)(row0 + mt * 16 + 4 * q) * jb.npad + nt * 16 + r16;
+        float *dst = jb.ypart + (size_t)s * jb.sstride + (size_t)(row0 + mt * 16 + 4 * q4) * jb.npad +
+                     nt * 16 + r16;
 #pragma unroll
         for (int e = 0; e < 4; ++e) dst[(size_t)e * jb.npad] = sum[e];
     }
 }
 
-extern "C" __global__ __launch_bounds__(512) void cfl_proj_kernel(ProjArgs a) {
+extern "C" __global__ __launch_bounds__(256) void cfl_proj_kernel(ProjArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     f32x4 *lds = (f32x4 *)smem;
     const ProjJob &jb = a.job[blockIdx.z];
@@ -234,28 +308,33 @@ extern "C" __global__ __launch_bounds__(512) void cfl_proj_kernel(ProjArgs a) {
 }
 
 // ---------------------------------------------------------------------------
-// grad: Wpart[p][c][d] = sum_{r in range p} dYt[c][r] * X[r][d]
-//   workgroup = 4 waves, one 64-d tile and one row range; the waves split the range.
-//   A fragment  lane(i,kq), load j : float4 X[p0+4kq+j][dbase+4i .. +3]   (256 B per row)
-//   B fragment  lane(c16,kq)       : float4 dYt[16nt+c16][p0+4kq .. +3]
-//   MFMA (j,t): A elem = xa[j][t]  (row i <-> d = dbase+4i+t, k = kq <-> row p0+4kq+j)
+// grad: Wpart[p] (Wf layout) = sum_{r in range p} X[r][d] * dY[r][c]
+//   workgroup = 4 waves, one 64-d tile and one row range; the waves split the range
+//   in chunks of 64 rows.
+//   A fragment  lane(i,kq), load (rg,j) : float4 X[p0+16rg+4kq+j][dbase+4i .. +3]
+//                (each instruction: 4 rows x 256 contiguous bytes; 16 loads issued up front)
+//   B fragment  one contiguous 1 KiB block of dYf per (nt, rg)
+//   MFMA (j,t): A elem = xa[rg][j][t]  (M row i <-> d = dbase+4i+t, k = kq <-> row 16rg+4kq+j)
 //               B elem = dy[nt][j]
+//   z-slice 0 of the launch: row reductions (column sums of dYf etc.).
 // ---------------------------------------------------------------------------
 struct GradJob {
     const float *x0, *x1;
-    const float *dyt;      // chunk base inside [npad][Rpad]
-    float *wpart;          // chunk base inside [P][npad][D]
+    const float *dyf;      // dYf tile base: blocks [(nt)*RG + rg]
+    float *wpart;          // Wf tile base inside slab 0; slabs are pstride apart
     long long pstride;     // floats between row-range slabs (npad * D)
     int nt;
 };
 
-// Row reductions that ride in the grad launch (z-slice 0): colsum[out] = sum_r A[a][r]
-// (B == null) or sum_r A[a][r] * B[b][r]; one wave per job, fixed summation order.
+// Row reductions that ride in the grad launch (z-slice 0).
+//   kind 0: column sums of a fragment-major buffer: one job per 16-column tile
+//   kind 1: gate head  dVm[l][k] = sum_r ya[r][l] * du[r][k]  (row-major buffers), one job per l
+//   kind 2: column sums of a row-major buffer [Rpad][lda], columns 0..K-1, one job
 struct RedRange {
-    const float *A, *B;   // [.][Rpad] transposed row buffers written by the mid kernel
-    int count, kdiv, ostride, out_off;
+    const float *A, *B;
+    int kind, count, out_off, lda, ldb, K, kpad;
 };
-#define CFL_MAX_RED 10
+#define CFL_MAX_RED 8
 
 struct GradArgs {
     GradJob job[CFL_MAX_JOBS];
@@ -268,12 +347,16 @@ struct GradArgs {
 
 template <int NT>
 __device__ __forceinline__ void grad_body(const GradJob &jb, const GradArgs &a, f32x4 *lds) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // provably uniform
     const int i16 = lane & 15, kq = lane >> 4;
     const int dbase = blockIdx.x * 64;
     const int p = blockIdx.y;
-    const int rows_wg = a.Rpad / a.P, rows_w = rows_wg >> 2;
+    const int RG = a.Rpad >> 4, G = a.D >> 4;
+    const int rows_wg = a.Rpad / a.P, rows_w = rows_wg >> 2;  // multiple of 64
     const int rbeg = p * rows_wg + wave * rows_w, rend = rbeg + rows_w;
+    const int r64 = (a.R + 63) & ~63;
+    const int rstop = rend < r64 ? rend : r64;  // rows >= R carry dY == 0: skip whole chunks
 
     f32x4 acc[4][NT];
 #pragma unroll
@@ -281,40 +364,46 @@ __device__ __forceinline__ void grad_body(const GradJob &jb, const GradArgs &a, 
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[t][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const float *dyp[NT];
+    const float *dyl = jb.dyf + lane * 4;
+    for (int p0 = rbeg; p0 < rstop; p0 += 64) {
+        // straight-line chunk of 64 rows: the (L2-resident) dY fragments are issued first,
+        // then the 16 x loads in consumption order; vmcnt retires in issue order, so the
+        // MFMAs of row group rg wait only for x loads 0 .. 4rg+3.
+        f32x4 dy[4][NT], xa[4][4];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) dyp[nt] = jb.dyt + (size_t)(nt * 16 + i16) * a.Rpad + 4 * kq;
-
-    f32x4 xc[4], dc[NT], xn[4], dn[NT];
-    auto load = [&](int p0, f32x4 *x, f32x4 *dy) {
+        for (int rg = 0; rg < 4; ++rg)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            x[j] = *(const f32x4 *)(row_ptr(jb.x0, jb.x1, p0 + 4 * kq + j, a.B, a.R, a.D) + dbase +
-                                    4 * i16);
+            for (int nt = 0; nt < NT; ++nt)
+                dy[rg][nt] = *(const f32x4 *)(dyl + ((size_t)nt * RG + (p0 >> 4) + rg) * 256);
+        __builtin_amdgcn_sched_barrier(0);  // pin the issue order
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) dy[nt] = *(const f32x4 *)(dyp[nt] + p0);
-    };
-    // rows beyond R carry dY == 0 (written by the mid kernel); skip whole groups
-    // that are entirely padding.
-    const int r16 = (a.R + 15) & ~15;
-    const int rstop = rend < r16 ? rend : r16;
-    if (rbeg < rstop) load(rbeg, xc, dc);
-    for (int p0 = rbeg; p0 < rstop; p0 += 16) {
-        if (p0 + 16 < rstop) load(p0 + 16, xn, dn);
+        for (int rg = 0; rg < 4; ++rg) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) xc[j] = norm_apply(xc[j], a.norm);
+            for (int j = 0; j < 4; ++j)
+                xa[rg][j] = *(const f32x4 *)(row_ptr(jb.x0, jb.x1, p0 + 16 * rg + 4 * kq + j, a.B, a.R, a.D) +
+                                             dbase + 4 * i16);
+            __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int rg = 0; rg < 4; ++rg) {
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
+            for (int j = 0; j < 4; ++j) xa[rg][j] = norm_apply(xa[rg][j], a.norm);
+#ifndef ABL_GRAD_NOMFMA
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-                    acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(xc[j][t], dc[nt][j],
-                                                                     acc[t][nt], 0, 0, 0);
+            for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) xc[j] = xn[j];
+                for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) dc[nt] = dn[nt];
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[rg][j][t], dy[rg][nt][j],
+                                                                         acc[t][nt], 0, 0, 0);
+#else
+#pragma unroll
+            for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(xa[rg][j]));
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) asm volatile("" ::"v"(dy[rg][nt]));
+#endif
+        }
     }
 
     // cross-wave sum through LDS: lds[wave][nt][t][lane]
@@ -333,50 +422,73 @@ __device__ __forceinline__ void grad_body(const GradJob &jb, const GradArgs &a, 
             for (int w = 1; w < 4; ++w) sum[t] += lds[((w * NT + nt) * 4 + t) * 64 + lane];
         }
         // acc[t][nt][e]: M row 4*kq+e <-> d = dbase + 16*kq + 4*e + t ; N col = lane&15
-        float *dst = jb.wpart + (size_t)p * jb.pstride + (size_t)(nt * 16 + i16) * a.D + dbase +
-                     16 * kq;
+        // Wf block (nt, g = dbase/16 + kq), position ((q = e)*16 + c16)*4 + (e' = t)
+        float *dst = jb.wpart + (size_t)p * jb.pstride + ((size_t)nt * G + (dbase >> 4) + kq) * 256 +
+                     i16 * 4;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             f32x4 v = {sum[0][e], sum[1][e], sum[2][e], sum[3][e]};
-            *(f32x4 *)(dst + 4 * e) = v;
+            *(f32x4 *)(dst + e * 64) = v;
         }
     }
 }
 
-__device__ __forceinline__ float wave_sum(float x) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
-    return x;
-}
-
-__device__ void grad_red_block(const GradArgs &a) {
+__device__ void grad_red_block(const GradArgs &a, float *lds) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nblk = gridDim.x * gridDim.y;
-    const int blk = blockIdx.y * gridDim.x + blockIdx.x;
-    const int n4 = a.Rpad >> 2;
-    for (int job = blk * 4 + wave; job < a.red_total; job += nblk * 4) {
+    const int RG = a.Rpad >> 4;
+    for (int job = blockIdx.y * gridDim.x + blockIdx.x; job < a.red_total; job += nblk) {
         int k = 0, idx = job;
         while (k < a.nred - 1 && idx >= a.red[k].count) { idx -= a.red[k].count; ++k; }
         const RedRange &rr = a.red[k];
-        int ia = idx, ib = 0, out = idx;
-        if (rr.kdiv > 0) { ia = idx / rr.kdiv; ib = idx - ia * rr.kdiv; out = ia * rr.ostride + ib; }
-        const f32x4 *pa = (const f32x4 *)(rr.A + (size_t)ia * a.Rpad);
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        if (rr.B) {
-            const f32x4 *pb = (const f32x4 *)(rr.B + (size_t)ib * a.Rpad);
-            for (int i = lane; i < n4; i += 64) acc += pa[i] * pb[i];
+        if (rr.kind == 0) {
+            // column sums of tile `idx` of a fragment-major buffer: lane (kq, c16) adds its 4 rows
+            const f32x4 *pa = (const f32x4 *)(rr.A + (size_t)idx * RG * 256) + lane;
+            float acc = 0.f;
+            // 8 independent loads in flight per round (a serial load chain here would be the
+            // critical path of the whole launch)
+            for (int rg0 = wave; rg0 < RG; rg0 += 32) {
+                f32x4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    v[u] = rg0 + 4 * u < RG ? pa[(size_t)(rg0 + 4 * u) * 64] : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc += (v[u][0] + v[u][1]) + (v[u][2] + v[u][3]);
+            }
+            acc += __shfl_xor(acc, 16);
+            acc += __shfl_xor(acc, 32);
+            __syncthreads();
+            if (lane < 16) lds[wave * 16 + lane] = acc;
+            __syncthreads();
+            if (wave == 0 && lane < 16)
+                a.colsum[rr.out_off + idx * 16 + lane] =
+                    (lds[lane] + lds[16 + lane]) + (lds[32 + lane] + lds[48 + lane]);
         } else {
-            for (int i = lane; i < n4; i += 64) acc += pa[i];
+            // kind 1: gate head, l = idx, dVm[l][k] for all k ; kind 2: plain column sums
+            for (int kk = 0; kk < rr.K; ++kk) {
+                float acc = 0.f;
+                if (rr.kind == 1) {
+                    for (int r = threadIdx.x; r < a.Rpad; r += 256)
+                        acc = fmaf(rr.A[(size_t)r * rr.lda + idx], rr.B[(size_t)r * rr.ldb + kk], acc);
+                } else {
+                    for (int r = threadIdx.x; r < a.Rpad; r += 256) acc += rr.A[(size_t)r * rr.lda + kk];
+                }
+                acc = wave_sum(acc);
+                __syncthreads();
+                if (lane == 0) lds[wave] = acc;
+                __syncthreads();
+                if (threadIdx.x == 0)
+                    a.colsum[rr.out_off + (rr.kind == 1 ? idx * rr.kpad : 0) + kk] =
+                        (lds[0] + lds[1]) + (lds[2] + lds[3]);
+            }
         }
-        const float t = wave_sum((acc[0] + acc[1]) + (acc[2] + acc[3]));
-        if (lane == 0) a.colsum[rr.out_off + out] = t;
     }
 }
 
 extern "C" __global__ __launch_bounds__(256) void cfl_grad_kernel(GradArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     f32x4 *lds = (f32x4 *)smem;
-    if (blockIdx.z == 0) { grad_red_block(a); return; }
+    if (blockIdx.z == 0) { grad_red_block(a, (float *)smem); return; }
     const GradJob &jb = a.job[blockIdx.z - 1];
     switch (jb.nt) {
         case 1: grad_body<1>(jb, a, lds); break;
@@ -393,13 +505,16 @@ extern "C" __global__ __launch_bounds__(256) void cfl_grad_kernel(GradArgs a) {
 //   prototype k.
 //   phase 1: the block's 4 rows of every slice slab are read with coalesced
 //            16-byte loads (all slices in flight at once), summed in slice order
-//            and parked in LDS as Y[row][col];
+//            and parked in LDS as Y[row][col]; biases / weight-norm scales / gate
+//            weights are staged in LDS in the same round of loads;
 //   phase 2: per-lane math; sums over l are completed with xor-shuffles inside
 //            the 16-lane row group.  Per-lane runtime-indexed state lives in LDS
 //            as [slot][64].
-//   Everything that later needs a sum over ROWS (bias / gain / gate-head
-//   gradients, loss scalars) is written as a transposed row buffer [q][Rpad];
-//   the reductions ride in the grad launch (grad_red_block).
+//   dL/dy is written UNSCALED in fragment-major order (dYf) -- the weight-norm /
+//   input scale is applied to the finished weight gradient by finalize -- so its
+//   column sums are the bias gradients.  Everything else that needs a sum over
+//   rows is written as one more fragment-major tile; the reductions ride in the
+//   grad launch (grad_red_block).
 // ---------------------------------------------------------------------------
 #define MID_RB 4
 enum {
@@ -413,9 +528,8 @@ struct MidSide {
     const float *b;       // biases or null
     const float *g;       // wn gains or null
     const float *n2;      // wn squared column norms or null
-    float *dyt;           // [npad][Rpad]  dL/d(x.V) scaled for the grad GEMM
-    float *raw;           // [npad][Rpad]  dL/dy (bias gradient rows) or null
-    float *cwx;           // [npad][Rpad]  dL/dy * (x_hat.V) (weight-norm gain rows) or null
+    float *dyf;           // fragment-major dL/dy (unscaled)
+    float *cwf;           // fragment-major dL/dy * (x_hat.V) (weight-norm gain rows) or null
     int n, npad;
     int is_proto;         // 1: columns are k*L + l ; 0: columns are l
 };
@@ -423,8 +537,9 @@ struct MidSide {
 struct MidArgs {
     MidSide side[2];      // 0 = src, 1 = dst
     const float *mono_w, *mono_g, *mono_n2;  // monomer gate head V[L][kpad]
-    float *mono_ya, *mono_du, *mono_duc;     // [L][Rpad], [kpad][Rpad], [kpad][Rpad]
-    int kpad;
+    float *mono_ya, *mono_du;                // row-major [Rpad][lpad], [Rpad][kpad]
+    float *mono_duc;                         // row-major [Rpad][kpad] (weight-norm)
+    int kpad, lpad;
     int S, L, K, Lq, dist_type, act, weight_norm;
     float in_mul;
     const float *thr;
@@ -432,7 +547,7 @@ struct MidArgs {
     int train, use_threshold;
     float pos_weight, caffe_margin, lambda_m;
     float *scores, *dists;
-    float *rowq;          // [P_NROWQ][Rpad]
+    float *rowqf;         // fragment-major tile of the per-row loss quantities
     float *thr_copy;      // max(thr, 1e-6) of this step (read by finalize's scalar block)
     int nrb, ys;          // row blocks; LDS row stride of Y (floats)
     // regulariser blocks
@@ -500,6 +615,11 @@ __device__ __forceinline__ f32x4 slab_sum(const float *src, long long sstride) {
     return acc;
 }
 
+// float offset of (row r, column c) inside a fragment-major buffer with RG row groups
+__device__ __forceinline__ size_t frag_off(int r, int c, int RG) {
+    return ((size_t)(c >> 4) * RG + (r >> 4)) * 256 + (((r >> 2) & 3) * 16 + (c & 15)) * 4 + (r & 3);
+}
+
 extern "C" __global__ __launch_bounds__(64) void cfl_mid_kernel(MidArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *lds = (float *)smem;
@@ -511,7 +631,7 @@ extern "C" __global__ __launch_bounds__(64) void cfl_mid_kernel(MidArgs a) {
     const int row0 = blockIdx.x * MID_RB;
     const int r = row0 + j;
     const bool valid = r < a.R;
-    const int L = a.L, K = a.K, Lq = a.Lq;
+    const int L = a.L, K = a.K, Lq = a.Lq, RG = a.Rpad >> 4;
     const int myL = p < L ? (L - p + 15) >> 4 : 0;  // number of l = p + 16*li < L
     const MidSide &ss = a.side[0], &sd = a.side[1];
     const int ks = ss.is_proto ? K : 1, kd = sd.is_proto ? K : 1;
@@ -530,7 +650,7 @@ extern "C" __global__ __launch_bounds__(64) void cfl_mid_kernel(MidArgs a) {
     float *Kv = Rl + Lq * 64;                  // 4 x K small vectors
     float *Ks = Kv, *Kq = Kv + K * 64, *Ke = Kv + 2 * K * 64, *Ku = Kv + 3 * K * 64;
 
-    // ---- phase 1: slice sums -> LDS --------------------------------------------
+    // ---- phase 1: slice sums + parameters -> LDS ----------------------------------
     for (int side = 0; side < 2; ++side) {
         const MidSide &sx = a.side[side];
         const int nq = sx.npad >> 2;
@@ -556,9 +676,10 @@ extern "C" __global__ __launch_bounds__(64) void cfl_mid_kernel(MidArgs a) {
     if (a.dist_type == CFL_DIST_MONOMER)
         for (int i = tid; i < L * a.kpad; i += 64) MW[i] = a.mono_w[i];
     const float thr_raw = *a.thr;
-    float scm_all = 1.f;  // (unused unless monomer + weight-norm: per-k scale read below)
-    (void)scm_all;
     __syncthreads();
+#ifdef ABL_MID_P1ONLY
+    if (a.train) { if (tid == 0) a.rowqf[blockIdx.x] = Y[0] + thr_raw; return; }
+#endif
 
     // ---- phase 2.1: head epilogue ------------------------------------------------
     for (int side = 0; side < 2; ++side) {
@@ -691,41 +812,43 @@ extern "C" __global__ __launch_bounds__(64) void cfl_mid_kernel(MidArgs a) {
     }
     if (!valid) dd = 0.f;
 
+#ifdef ABL_MID_NOBWD
+    if (a.train) { if (tid == 0) a.rowqf[blockIdx.x] = dd; return; }
+#endif
     if (blockIdx.x == 0 && tid == 0) a.thr_copy[0] = thr;
-    // per-row loss quantities (summed over rows by grad_red_block)
-    if (p == 0) {
-        const float w = valid ? 1.f : 0.f;
-        const float wp = is_pos ? w : 0.f, wn = is_pos ? 0.f : w;
-        float *q = a.rowq + r;
-        const size_t rp = a.Rpad;
-        q[P_BCE_POS * rp] = wp != 0.f ? bce : 0.f;
-        q[P_BCE_NEG * rp] = wn != 0.f ? bce : 0.f;
-        q[P_OK_POS * rp] = (wp != 0.f && o > 0.f) ? 1.f : 0.f;
-        q[P_OK_NEG * rp] = (wn != 0.f && o <= 0.f) ? 1.f : 0.f;
-        q[P_D_POS * rp] = wp != 0.f ? d : 0.f;
-        q[P_D_NEG * rp] = wn != 0.f ? d : 0.f;
-        q[P_O_POS * rp] = wp != 0.f ? o : 0.f;
-        q[P_O_NEG * rp] = wn != 0.f ? o : 0.f;
-        q[P_DTHR * rp] = w != 0.f ? dlo : 0.f;
-        q[P_HINGE_NEG * rp] = wn != 0.f ? hinge : 0.f;
-        q[P_SQRT_POS * rp] = wp != 0.f ? sqrtf(d + 1e-7f) : 0.f;
-        q[P_SQRT_NEG * rp] = wn != 0.f ? sqrtf(d + 1e-7f) : 0.f;
+    // per-row loss quantities: lane p writes quantity #p of its row (one fragment tile,
+    // summed over rows by grad_red_block)
+    {
+        const bool pos = valid && is_pos, neg = valid && !is_pos;
+        float qv = 0.f;
+        switch (p) {
+            case P_BCE_POS: qv = pos ? bce : 0.f; break;
+            case P_BCE_NEG: qv = neg ? bce : 0.f; break;
+            case P_OK_POS: qv = (pos && o > 0.f) ? 1.f : 0.f; break;
+            case P_OK_NEG: qv = (neg && o <= 0.f) ? 1.f : 0.f; break;
+            case P_D_POS: qv = pos ? d : 0.f; break;
+            case P_D_NEG: qv = neg ? d : 0.f; break;
+            case P_O_POS: qv = pos ? o : 0.f; break;
+            case P_O_NEG: qv = neg ? o : 0.f; break;
+            case P_DTHR: qv = valid ? dlo : 0.f; break;
+            case P_HINGE_NEG: qv = neg ? hinge : 0.f; break;
+            case P_SQRT_POS: qv = pos ? sqrtf(d + 1e-7f) : 0.f; break;
+            case P_SQRT_NEG: qv = neg ? sqrtf(d + 1e-7f) : 0.f; break;
+            default: break;
+        }
+        a.rowqf[frag_off(r, p, RG)] = qv;
     }
 
-    // ---- phase 2.4: backward to dL/dY (transposed, scaled for the grad GEMM) -------
-    // emit(): finish one column: activation grad, weight-norm / input scale, store
-    // dYt plus the bias / gain row buffers.
+    // ---- phase 2.4: backward to dL/dY (fragment-major, unscaled) -------------------
     auto emit = [&](const MidSide &sx, const float *A, const float *X, int k, int li, float dA,
                     float extra_dy) {
         const int c = k * L + p + 16 * li;
         const int slot = (k * Lq + li) * 64 + tid;
         float dy = dA * act_grad(A[slot], a.act) + extra_dy;
         if (!valid) dy = 0.f;
-        const float sc = a.in_mul * SC[(&sx == &a.side[1] ? a.side[0].npad : 0) + c];
-        const size_t o_ = (size_t)c * a.Rpad + r;
-        sx.dyt[o_] = dy * sc;
-        if (sx.raw) sx.raw[o_] = dy;
-        if (sx.cwx) sx.cwx[o_] = valid ? dy * X[slot] : 0.f;
+        const size_t o_ = frag_off(r, c, RG);
+        sx.dyf[o_] = dy;
+        if (sx.cwf) sx.cwf[o_] = valid ? dy * X[slot] : 0.f;
     };
 
     if (a.dist_type == CFL_DIST_PCD) {
@@ -764,15 +887,15 @@ extern "C" __global__ __launch_bounds__(64) void cfl_mid_kernel(MidArgs a) {
             float scm = 1.f;
             if (a.weight_norm) scm = a.mono_g[k] / sqrtf(a.mono_n2[k]);
             if (p == 0) {
-                a.mono_du[(size_t)k * a.Rpad + r] = du * scm;
-                if (a.weight_norm) a.mono_duc[(size_t)k * a.Rpad + r] = valid ? du * Ku[k * 64 + tid] : 0.f;
+                a.mono_du[(size_t)r * a.kpad + k] = du * scm;
+                if (a.weight_norm) a.mono_duc[(size_t)r * a.kpad + k] = valid ? du * Ku[k * 64 + tid] : 0.f;
             }
             Kq[k * 64 + tid] = du * scm;  // grad wrt raw ya.Vm
         }
         for (int li = 0; li < myL; ++li) {
             const int l = p + 16 * li;
             const float av = As[li * 64 + tid], ya = Rl[li * 64 + tid];
-            a.mono_ya[(size_t)l * a.Rpad + r] = valid ? ya : 0.f;
+            a.mono_ya[(size_t)r * a.lpad + l] = valid ? ya : 0.f;
             float da = 0.f, ex = 0.f;
             for (int k = 0; k < K; ++k) {
                 const float amP = av - Ad[(k * Lq + li) * 64 + tid];
@@ -790,16 +913,18 @@ extern "C" __global__ __launch_bounds__(64) void cfl_mid_kernel(MidArgs a) {
             emit(sd, Ad, Xd, 0, li, -2.f * df * dd, 0.f);
         }
     }
-    // zero the padding columns of dYt (read by the grad GEMM)
+    // zero the padding columns of dYf (read by the grad GEMM and the column sums)
     for (int side = 0; side < 2; ++side) {
         const MidSide &sx = a.side[side];
-        for (int c = sx.n + p; c < sx.npad; c += 16) sx.dyt[(size_t)c * a.Rpad + r] = 0.f;
+        for (int c = sx.n + p; c < sx.npad; c += 16) {
+            sx.dyf[frag_off(r, c, RG)] = 0.f;
+            if (sx.cwf) sx.cwf[frag_off(r, c, RG)] = 0.f;
+        }
     }
 }
 
-
 // ---------------------------------------------------------------------------
-// colnorm (weight-norm): n2[c] = sum_d Wt[c][d]^2   (cfl/layers.py:81)
+// colnorm (weight-norm): n2[c] = sum_d V[d][c]^2   (cfl/layers.py:81) + gain snapshot
 // ---------------------------------------------------------------------------
 struct ColnormArgs {
     const float *theta;
@@ -808,7 +933,7 @@ struct ColnormArgs {
     long long g_off[8];
     int nheads;
     long long w_off[8];
-    int npad[8], n2_off[8], rowlen[8], strided[8], ncol[8];
+    int npad[8], n2_off[8], rowlen[8], strided[8];
     int D;
 };
 
@@ -819,8 +944,13 @@ extern "C" __global__ __launch_bounds__(256) void cfl_colnorm_kernel(ColnormArgs
     if (h >= a.nheads) return;
     float acc = 0.f;
     if (!a.strided[h]) {
-        const float *w = a.theta + a.w_off[h] + (size_t)c * a.rowlen[h];
-        for (int d = threadIdx.x; d < a.rowlen[h]; d += 256) acc = fmaf(w[d], w[d], acc);
+        // Wf layout: column c = 16nt + c16 lives at ((nt*G + g)*64 + q*16 + c16) float4s
+        const int G = a.D >> 4, nt = c >> 4, c16 = c & 15;
+        const f32x4 *w = (const f32x4 *)(a.theta + a.w_off[h]) + (size_t)nt * G * 64 + c16;
+        for (int i = threadIdx.x; i < G * 4; i += 256) {
+            const f32x4 v = w[(size_t)(i >> 2) * 64 + (i & 3) * 16];
+            acc += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+        }
     } else {  // mono head V[L][kpad]: column c strided by kpad
         const float *w = a.theta + a.w_off[h];
         for (int l = threadIdx.x; l < a.rowlen[h]; l += 256) {
@@ -833,7 +963,7 @@ extern "C" __global__ __launch_bounds__(256) void cfl_colnorm_kernel(ColnormArgs
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
     __syncthreads();
     if (threadIdx.x == 0) {
-        a.n2[a.n2_off[h] + c] = red[0] + red[1] + red[2] + red[3];
+        a.n2[a.n2_off[h] + c] = (red[0] + red[1]) + (red[2] + red[3]);
         a.gcopy[a.n2_off[h] + c] = a.g_off[h] >= 0 ? a.theta[a.g_off[h] + c] : 1.f;
     }
 }
@@ -848,10 +978,10 @@ enum { RK_ZERO = 0, RK_W, RK_BIAS, RK_GAIN, RK_THR, RK_MONO_W, RK_MONO_G };
 struct Region {
     long long off, cnt;        // floats (64-aligned)
     int kind, reg;
-    const float *slab[2];      // weight-gradient slabs [P][npad][D] (one per contributing side)
-    int cs_raw[2], cs_cwx[2];  // colsum offsets of the bias / gain rows (-1: none)
+    const float *slab[2];      // weight-gradient slabs [P] x Wf (one per contributing side)
+    int cs_dy[2], cs_cw[2];    // colsum offsets of the bias / gain column sums (-1: none)
     int npad, n;               // padded / logical columns of the head
-    const float *g, *n2;       // weight-norm
+    const float *g, *n2;       // weight-norm (gain snapshot, squared norms)
 };
 
 struct FinArgs {
@@ -863,14 +993,13 @@ struct FinArgs {
     const float *colsum;
     int cs_rowq, cs_mono, cs_duc;
     int P, D, L, kpad, weight_norm;
-    float reg_const;
+    float in_mul, reg_const;
     int use_threshold;
     float pos_weight, caffe_margin, lambda_m;
     int B;
     const float *regpart;
     int nregblocks;
     float *scalars;
-    long long thr_off;
     int nblocks_main;
     // optional fused Adam (theta_out aliases theta)
     float *adam_m, *adam_v, *theta_out;
@@ -938,7 +1067,9 @@ extern "C" __global__ __launch_bounds__(256) void cfl_finalize_kernel(FinArgs a)
         const long long rel = base - rg.off;
         switch (rg.kind) {
             case RK_W: {
-                const int c = (int)(rel / a.D);  // same column for the 4 elements (D % 4 == 0)
+                // Wf layout: block = rel/256 -> nt = block / G ; c16 = ((rel%256)/4) % 16
+                const int G = a.D >> 4;
+                const int c = (int)((rel >> 8) / G) * 16 + (int)((rel >> 2) & 15);
                 const long long ps = (long long)rg.npad * a.D;
                 f32x4 t[2][8];
 #pragma unroll
@@ -951,12 +1082,20 @@ extern "C" __global__ __launch_bounds__(256) void cfl_finalize_kernel(FinArgs a)
                 for (int s = 0; s < 2; ++s)
 #pragma unroll
                     for (int pp = 0; pp < 8; ++pp) gr += t[s][pp];
-                if (a.weight_norm && c < rg.n) {
-                    float cw = 0.f;
-                    for (int s = 0; s < 2; ++s)
-                        if (rg.cs_cwx[s] >= 0) cw += a.colsum[rg.cs_cwx[s] + c];
-                    const float n2 = rg.n2[c], n = sqrtf(n2);
-                    if (n2 > 0.f) gr -= (rg.g[c] * cw / (n2 * n)) * th;
+                // the slabs hold X^T dy with unscaled dy: apply the input / weight-norm scale
+                if (a.weight_norm) {
+                    if (c < rg.n) {
+                        const float n2 = rg.n2[c], n = sqrtf(n2);
+                        gr *= n2 > 0.f ? a.in_mul * rg.g[c] / n : 0.f;
+                        float cw = 0.f;
+                        for (int s = 0; s < 2; ++s)
+                            if (rg.cs_cw[s] >= 0) cw += a.colsum[rg.cs_cw[s] + c];
+                        if (n2 > 0.f) gr -= (rg.g[c] * cw / (n2 * n)) * th;
+                    } else {
+                        gr *= 0.f;
+                    }
+                } else {
+                    gr *= a.in_mul;
                 }
                 break;
             }
@@ -966,7 +1105,7 @@ extern "C" __global__ __launch_bounds__(256) void cfl_finalize_kernel(FinArgs a)
                     const int c = (int)rel + e;
                     if (c < rg.n)
                         for (int s = 0; s < 2; ++s)
-                            if (rg.cs_raw[s] >= 0) gr[e] += a.colsum[rg.cs_raw[s] + c];
+                            if (rg.cs_dy[s] >= 0) gr[e] += a.colsum[rg.cs_dy[s] + c];
                 }
                 break;
             }
@@ -977,7 +1116,7 @@ extern "C" __global__ __launch_bounds__(256) void cfl_finalize_kernel(FinArgs a)
                     if (c < rg.n) {
                         float cw = 0.f;
                         for (int s = 0; s < 2; ++s)
-                            if (rg.cs_cwx[s] >= 0) cw += a.colsum[rg.cs_cwx[s] + c];
+                            if (rg.cs_cw[s] >= 0) cw += a.colsum[rg.cs_cw[s] + c];
                         const float n2 = rg.n2[c];
                         gr[e] = n2 > 0.f ? cw / sqrtf(n2) : 0.f;
                     }
@@ -988,11 +1127,11 @@ extern "C" __global__ __launch_bounds__(256) void cfl_finalize_kernel(FinArgs a)
                 if (rel == 0) gr[0] = th[0] >= CFL_THR_FLOOR ? a.colsum[a.cs_rowq + P_DTHR] : 0.f;
                 break;
             }
-            case RK_MONO_W: {  // V[L][kpad]; cs_raw[0] >= 0 marks the encoder whose gate is used
+            case RK_MONO_W: {  // V[L][kpad]; cs_dy[0] >= 0 marks the encoder whose gate is used
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int l = (int)((rel + e) / a.kpad), kk = (int)((rel + e) % a.kpad);
-                    if (l < a.L && kk < rg.n && rg.cs_raw[0] >= 0) {
+                    if (l < a.L && kk < rg.n && rg.cs_dy[0] >= 0) {
                         float g1 = a.colsum[a.cs_mono + l * a.kpad + kk];
                         if (a.weight_norm) {
                             const float cw = a.colsum[a.cs_duc + kk];
@@ -1008,7 +1147,7 @@ extern "C" __global__ __launch_bounds__(256) void cfl_finalize_kernel(FinArgs a)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int kk = (int)rel + e;
-                    if (rg.cs_raw[0] >= 0 && kk < rg.n) {
+                    if (rg.cs_dy[0] >= 0 && kk < rg.n) {
                         const float n2 = rg.n2[kk];
                         gr[e] = n2 > 0.f ? a.colsum[a.cs_duc + kk] / sqrtf(n2) : 0.f;
                     }
@@ -1128,18 +1267,24 @@ extern "C" int cfl_layout(const CflShape *s, CflLayout *out) {
 struct Plan {
     CflLayout lay;
     int R, Rpad, S, P, nrb, nregblocks;
-    int kpad, Lq;
-    bool has_raw, has_cwx, mono;
+    int kpad, lpad, Lq;
+    bool has_cw, mono;
     // colsum vector offsets
-    int cs_raw[2], cs_cwx[2], cs_mono, cs_duc, cs_rowq, cs_total;
+    int cs_dy[2], cs_cw[2], cs_mono, cs_duc, cs_rowq, cs_total;
     // workspace offsets (floats)
-    size_t ypart[2], dyt[2], raw[2], cwx[2], wpart[2];
-    size_t mono_ya, mono_du, mono_duc, rowq, colsum, regpart, n2, total_floats;
+    size_t ypart[2], dyf[2], cwf[2], wpart[2];
+    size_t mono_ya, mono_du, mono_duc, rowqf, thr_copy, colsum, regpart, n2, total_floats;
     size_t mid_lds;
     int ys;
 };
 
 static inline int pow2_floor(int x) { int p = 1; while (p * 2 <= x) p *= 2; return p; }
+
+// tuning overrides for experiments (tools/kernel_probe.py): CFL_DEBUG_S / CFL_DEBUG_P
+static int debug_env(const char *name) {
+    const char *v = getenv(name);
+    return v ? atoi(v) : 0;
+}
 
 static void side_heads(const CflShape *s, const CflLayout &lay, const CflHead **src,
                        const CflHead **dst) {
@@ -1169,29 +1314,32 @@ static int make_plan(const CflShape *s, int64_t rows, int groups, bool train, Pl
         P = pow2_floor(want < 1 ? 1 : want);
         if (P > 8) P = 8;
         while (P > 1 && pl->R / P < 64) P /= 2;
+        if (debug_env("CFL_DEBUG_P") > 0) P = debug_env("CFL_DEBUG_P");
     }
     pl->P = P;
-    pl->Rpad = (int)round_up(pl->R, 64 * P);
-    // proj d split: aim at >= 512 workgroups, >= two 16-d groups per wave
+    pl->Rpad = (int)round_up(pl->R, 256 * P);  // grad: 64-row chunks x 4 waves x P ranges
+    // proj d split: one 128-d chunk per wave when that yields enough workgroups
     const int rtiles = (pl->R + 31) / 32;
+    const int nchunks = (s->D / 16 + 7) / 8;
     int S = (512 + rtiles * njobs - 1) / (rtiles * njobs);
     S = pow2_floor(S < 1 ? 1 : S);
-    const int maxS = s->D / 16 / 8 / 2 > 0 ? s->D / 16 / 8 / 2 : 1;
+    int maxS = (nchunks + 3) / 4;  // at least one chunk per wave
     if (S > maxS) S = pow2_floor(maxS);
     if (S > 16) S = 16;
+    if (debug_env("CFL_DEBUG_S") > 0) S = debug_env("CFL_DEBUG_S");
     pl->S = S;
     pl->nrb = pl->Rpad / MID_RB;
     pl->kpad = pl->lay.enc[0].mono.npad;
+    pl->lpad = (int)round_up(s->L, 16);
     pl->Lq = (s->L + 15) / 16;
-    pl->has_raw = train && s->has_bias;
-    pl->has_cwx = train && s->weight_norm;
+    pl->has_cw = train && s->weight_norm;
     pl->mono = s->dist_type == CFL_DIST_MONOMER;
     pl->nregblocks = (int)((pl->lay.total / 64 + 63) / 64);
     // colsum vector
     int cs = 0;
     auto cst = [&](int n) { int o = cs; cs += n; return o; };
-    pl->cs_raw[0] = cst(hs->npad); pl->cs_raw[1] = cst(hd->npad);
-    pl->cs_cwx[0] = cst(hs->npad); pl->cs_cwx[1] = cst(hd->npad);
+    pl->cs_dy[0] = cst(hs->npad); pl->cs_dy[1] = cst(hd->npad);
+    pl->cs_cw[0] = cst(hs->npad); pl->cs_cw[1] = cst(hd->npad);
     pl->cs_mono = cst(pl->mono ? s->L * pl->kpad : 0);
     pl->cs_duc = cst(pl->mono ? pl->kpad : 0);
     pl->cs_rowq = cst(16);
@@ -1203,16 +1351,15 @@ static int make_plan(const CflShape *s, int64_t rows, int groups, bool train, Pl
     pl->ypart[0] = take((size_t)S * hs->npad * rp);
     pl->ypart[1] = take((size_t)S * hd->npad * rp);
     if (train) {
-        pl->dyt[0] = take(hs->npad * rp);
-        pl->dyt[1] = take(hd->npad * rp);
-        pl->raw[0] = take(pl->has_raw ? hs->npad * rp : 0);
-        pl->raw[1] = take(pl->has_raw ? hd->npad * rp : 0);
-        pl->cwx[0] = take(pl->has_cwx ? hs->npad * rp : 0);
-        pl->cwx[1] = take(pl->has_cwx ? hd->npad * rp : 0);
-        pl->mono_ya = take(pl->mono ? s->L * rp : 0);
+        pl->dyf[0] = take(hs->npad * rp);
+        pl->dyf[1] = take(hd->npad * rp);
+        pl->cwf[0] = take(pl->has_cw ? hs->npad * rp : 0);
+        pl->cwf[1] = take(pl->has_cw ? hd->npad * rp : 0);
+        pl->mono_ya = take(pl->mono ? pl->lpad * rp : 0);
         pl->mono_du = take(pl->mono ? pl->kpad * rp : 0);
         pl->mono_duc = take(pl->mono ? pl->kpad * rp : 0);
-        pl->rowq = take(16 * rp);
+        pl->rowqf = take(16 * rp);
+        pl->thr_copy = take(64);
         pl->colsum = take(cs);
         pl->wpart[0] = take((size_t)P * hs->npad * s->D);
         pl->wpart[1] = take((size_t)P * hd->npad * s->D);
@@ -1312,6 +1459,7 @@ static int run_pairs(const CflShape *s, const CflNorm *norm, const CflLossCfg *l
     float in_mul;
     NormDev nd = make_norm(norm, &in_mul);
     const size_t rp = pl.Rpad;
+    const int G = s->D / 16, RG = pl.Rpad / 16;
 
     SideRt side[2];
     switch (s->dist_type) {
@@ -1342,7 +1490,7 @@ static int run_pairs(const CflShape *s, const CflNorm *norm, const CflLossCfg *l
             for (int c0 = 0; c0 < tiles; c0 += 4) {
                 ProjJob &j = pa.job[nj++];
                 j.x0 = xs[sd][0]; j.x1 = xs[sd][1];
-                j.wt = theta + h->w + (size_t)c0 * 16 * s->D;
+                j.wf = theta + h->w + (size_t)c0 * G * 256;
                 j.ypart = ws + pl.ypart[sd] + (size_t)c0 * 16;
                 j.sstride = (long long)h->npad * rp;
                 j.nt = tiles - c0 < 4 ? tiles - c0 : 4;
@@ -1352,7 +1500,7 @@ static int run_pairs(const CflShape *s, const CflNorm *norm, const CflLossCfg *l
         pa.B = (int)rows; pa.R = pl.R; pa.Rpad = pl.Rpad; pa.D = s->D; pa.S = pl.S; pa.norm = nd;
         dim3 grid((pl.R + 31) / 32, pl.S, nj);
         ProfScope ps(st, CFL_K_PROJ);
-        hipLaunchKernelGGL(cfl_proj_kernel, grid, dim3(512), 8 * 8 * 64 * sizeof(f32x4), st, pa);
+        hipLaunchKernelGGL(cfl_proj_kernel, grid, dim3(256), 4 * 8 * 64 * sizeof(f32x4), st, pa);  // 32 KiB: cross-wave sum (the 4 KiB/wave transpose tiles alias it)
     }
 
     // ---- mid ----------------------------------------------------------------
@@ -1366,9 +1514,8 @@ static int run_pairs(const CflShape *s, const CflNorm *norm, const CflLossCfg *l
         m.b = h->b >= 0 ? theta + h->b : nullptr;
         m.g = h->g >= 0 ? theta + h->g : nullptr;
         m.n2 = s->weight_norm ? n2base + n2_off[side[sd].enc][side[sd].which] : nullptr;
-        m.dyt = train ? ws + pl.dyt[sd] : nullptr;
-        m.raw = pl.has_raw ? ws + pl.raw[sd] : nullptr;
-        m.cwx = pl.has_cwx ? ws + pl.cwx[sd] : nullptr;
+        m.dyf = train ? ws + pl.dyf[sd] : nullptr;
+        m.cwf = pl.has_cw ? ws + pl.cwf[sd] : nullptr;
         m.n = h->n; m.npad = h->npad;
         m.is_proto = side[sd].which == 1;
     }
@@ -1381,7 +1528,7 @@ static int run_pairs(const CflShape *s, const CflNorm *norm, const CflLossCfg *l
             ma.mono_ya = ws + pl.mono_ya; ma.mono_du = ws + pl.mono_du; ma.mono_duc = ws + pl.mono_duc;
         }
     }
-    ma.kpad = pl.kpad;
+    ma.kpad = pl.kpad; ma.lpad = pl.lpad;
     ma.S = pl.S; ma.L = s->L; ma.K = s->K; ma.Lq = pl.Lq; ma.dist_type = s->dist_type;
     ma.act = s->act_type; ma.weight_norm = s->weight_norm; ma.in_mul = in_mul;
     ma.thr = theta + pl.lay.thr;
@@ -1390,8 +1537,8 @@ static int run_pairs(const CflShape *s, const CflNorm *norm, const CflLossCfg *l
     if (train) {
         ma.use_threshold = loss->use_threshold;
         ma.pos_weight = loss->pos_weight; ma.caffe_margin = loss->caffe_margin; ma.lambda_m = loss->lambda_m;
-        ma.rowq = ws + pl.rowq;
-        ma.thr_copy = ws + pl.rowq + 15 * rp;
+        ma.rowqf = ws + pl.rowqf;
+        ma.thr_copy = ws + pl.thr_copy;
         ma.regpart = ws + pl.regpart;
         ma.theta = theta;
     }
@@ -1410,7 +1557,7 @@ static int run_pairs(const CflShape *s, const CflNorm *norm, const CflLossCfg *l
             Region &r = fa.reg[nr++];
             r.off = off; r.cnt = round_up(cnt, 64); r.kind = kind; r.reg = reg; r.npad = npad; r.n = n;
             r.slab[0] = r.slab[1] = nullptr;
-            r.cs_raw[0] = r.cs_raw[1] = r.cs_cwx[0] = r.cs_cwx[1] = -1;
+            r.cs_dy[0] = r.cs_dy[1] = r.cs_cw[0] = r.cs_cw[1] = -1;
             r.g = r.n2 = nullptr;
             return r;
         };
@@ -1429,9 +1576,9 @@ static int run_pairs(const CflShape *s, const CflNorm *norm, const CflLossCfg *l
                     const bool same_enc = s->directed ? side[sd].enc == e : true;
                     if (side[sd].head->w == h->w && same_enc && side[sd].which == k) {
                         rw.slab[ns] = ws + pl.wpart[sd];
-                        rw.cs_cwx[ns] = pl.cs_cwx[sd];
-                        if (rb) rb->cs_raw[ns] = pl.cs_raw[sd];
-                        if (rgn) rgn->cs_cwx[ns] = pl.cs_cwx[sd];
+                        rw.cs_cw[ns] = pl.cs_cw[sd];
+                        if (rb) rb->cs_dy[ns] = pl.cs_dy[sd];
+                        if (rgn) rgn->cs_cw[ns] = pl.cs_cw[sd];
                         ++ns;
                     }
                 }
@@ -1444,11 +1591,11 @@ static int run_pairs(const CflShape *s, const CflNorm *norm, const CflLossCfg *l
             const CflHead &m = pl.lay.enc[e].mono;
             if (m.w >= 0) {
                 Region &rm = add(RK_MONO_W, m.w, (int64_t)s->L * m.npad, regon, m.npad, m.n);
-                if (e == 0) rm.cs_raw[0] = 0;   // the gate head of the SRC encoder is the one used
+                if (e == 0) rm.cs_dy[0] = 0;   // the gate head of the SRC encoder is the one used
                 if (s->weight_norm) { rm.g = gbase + n2_off[e][2]; rm.n2 = n2base + n2_off[e][2]; }
                 if (m.g >= 0) {
                     Region &rmg = add(RK_MONO_G, m.g, m.npad, 0, m.npad, m.n);
-                    if (e == 0) rmg.cs_raw[0] = 0;
+                    if (e == 0) rmg.cs_dy[0] = 0;
                     rmg.g = gbase + n2_off[e][2]; rmg.n2 = n2base + n2_off[e][2];
                 }
             }
@@ -1490,28 +1637,33 @@ static int run_pairs(const CflShape *s, const CflNorm *norm, const CflLossCfg *l
             for (int c0 = 0; c0 < tiles; c0 += 4) {
                 GradJob &j = ga.job[nj++];
                 j.x0 = xs[sd][0]; j.x1 = xs[sd][1];
-                j.dyt = ws + pl.dyt[sd] + (size_t)c0 * 16 * rp;
-                j.wpart = ws + pl.wpart[sd] + (size_t)c0 * 16 * s->D;
+                j.dyf = ws + pl.dyf[sd] + (size_t)c0 * RG * 256;
+                j.wpart = ws + pl.wpart[sd] + (size_t)c0 * G * 256;
                 j.pstride = (long long)h->npad * s->D;
                 j.nt = tiles - c0 < 4 ? tiles - c0 : 4;
             }
         }
         ga.B = (int)rows; ga.R = pl.R; ga.Rpad = pl.Rpad; ga.D = s->D; ga.P = pl.P; ga.norm = nd;
         int nr = 0, tot = 0;
-        auto red = [&](const float *A, const float *B, int count, int kdiv, int ostride, int out) {
-            if (count <= 0) return;
+        auto red = [&](int kind, const float *A, const float *B, int count, int out) -> RedRange & {
             RedRange &r = ga.red[nr++];
-            r.A = A; r.B = B; r.count = count; r.kdiv = kdiv; r.ostride = ostride; r.out_off = out;
+            memset(&r, 0, sizeof(r));
+            r.A = A; r.B = B; r.kind = kind; r.count = count; r.out_off = out;
             tot += count;
+            return r;
         };
-        red(ws + pl.rowq, nullptr, P_NROWQ, 0, 0, pl.cs_rowq);
+        red(0, ws + pl.rowqf, nullptr, 1, pl.cs_rowq);
         for (int sd = 0; sd < 2; ++sd) {
-            if (pl.has_raw) red(ws + pl.raw[sd], nullptr, side[sd].head->n, 0, 0, pl.cs_raw[sd]);
-            if (pl.has_cwx) red(ws + pl.cwx[sd], nullptr, side[sd].head->n, 0, 0, pl.cs_cwx[sd]);
+            red(0, ws + pl.dyf[sd], nullptr, side[sd].head->npad / 16, pl.cs_dy[sd]);
+            if (pl.has_cw) red(0, ws + pl.cwf[sd], nullptr, side[sd].head->npad / 16, pl.cs_cw[sd]);
         }
         if (pl.mono) {
-            red(ws + pl.mono_ya, ws + pl.mono_du, s->L * s->K, s->K, pl.kpad, pl.cs_mono);
-            if (s->weight_norm) red(ws + pl.mono_duc, nullptr, s->K, 0, 0, pl.cs_duc);
+            RedRange &r = red(1, ws + pl.mono_ya, ws + pl.mono_du, s->L, pl.cs_mono);
+            r.lda = pl.lpad; r.ldb = pl.kpad; r.K = s->K; r.kpad = pl.kpad;
+            if (s->weight_norm) {
+                RedRange &r2 = red(2, ws + pl.mono_duc, nullptr, 1, pl.cs_duc);
+                r2.lda = pl.kpad; r2.K = s->K; r2.kpad = pl.kpad;
+            }
         }
         ga.nred = nr; ga.red_total = tot; ga.colsum = ws + pl.colsum;
         dim3 grid(s->D / 64, pl.P, nj + 1);
@@ -1524,12 +1676,13 @@ static int run_pairs(const CflShape *s, const CflNorm *norm, const CflLossCfg *l
     fa.colsum = ws + pl.colsum; fa.cs_rowq = pl.cs_rowq; fa.cs_mono = pl.cs_mono; fa.cs_duc = pl.cs_duc;
     fa.P = pl.P; fa.D = s->D;
     fa.L = s->L; fa.kpad = pl.kpad > 0 ? pl.kpad : 1; fa.weight_norm = s->weight_norm;
+    fa.in_mul = in_mul;
     fa.reg_const = loss->reg_const; fa.use_threshold = loss->use_threshold;
     fa.pos_weight = loss->pos_weight; fa.caffe_margin = loss->caffe_margin; fa.lambda_m = loss->lambda_m;
     fa.B = (int)rows; fa.regpart = ws + pl.regpart; fa.nregblocks = nreg_blocks;
-    fa.scalars = scalars; fa.thr_off = pl.lay.thr;
+    fa.scalars = scalars;
     fa.nblocks_main = (int)((pl.lay.total / 4 + 255) / 256);
-    fa.thr_copy = ws + pl.rowq + 15 * rp;
+    fa.thr_copy = ws + pl.thr_copy;
     if (adam) {
         fa.adam_m = adam->m; fa.adam_v = adam->v; fa.theta_out = adam->theta;
         fa.lr_t = adam->lr_t; fa.b1 = adam->b1; fa.b2 = adam->b2; fa.eps = adam->eps;

@@ -23,9 +23,13 @@
  *
  * Device layout of the parameters ("theta"), its Adam slots m / v and the flat
  * gradient: ONE contiguous fp32 array each, laid out by cfl_layout().  Weight
- * matrices are stored TRANSPOSED and column-padded, Wt[Npad][D] (Npad = N
- * rounded up to 16, pad rows zero), because both the projection and the
- * weight-gradient MFMA kernels then fetch 16-byte fragments along D.
+ * matrices are column-padded to Npad = N rounded up to 16 (pad columns zero) and
+ * stored FRAGMENT-MAJOR, Wf[nt][g][q][c16][e] = W[d = 16g+4q+e][col = 16nt+c16]:
+ * one contiguous 1 KiB block per (16-column tile nt, 16-row group g), in exactly
+ * the order the v_mfma_f32_16x16x4_f32 B operand consumes it, so that both the
+ * projection and the weight-gradient kernels move whole 1 KiB blocks per wave
+ * instruction.  cfl/hipabi.py pack_theta()/unpack_theta() convert to and from
+ * the reference's [D, N] arrays.
  */
 #ifndef CFL_HIP_H
 #define CFL_HIP_H
@@ -79,7 +83,7 @@ typedef struct {
 
 /* One linear head inside theta (offsets in floats, -1 = absent).               */
 typedef struct {
-    int64_t w;     /* Wt[npad][D] (for the monomer gate head: V[L][kpad])       */
+    int64_t w;     /* Wf, npad*D floats (monomer gate head: V[L][kpad] row-major) */
     int64_t b;     /* biases[npad]                                              */
     int64_t g;     /* weight-norm gains g[npad]                                 */
     int32_t n;     /* logical columns                                           */

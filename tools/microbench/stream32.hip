@@ -1,0 +1,97 @@
+// Microbenchmark: what does ONE launch that reads 32 MiB cost on MI355X, for several
+// access patterns?  (experiment helper; not part of the product)
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
+
+// pattern 0: fully contiguous, each wave instr = 1 KiB, LOADS loads per thread up front
+template <int LOADS>
+__global__ __launch_bounds__(256) void k_contig(const f32x4 *x, float *out, long n4) {
+    long base = ((long)blockIdx.x * 256 + threadIdx.x);
+    long stride = (long)gridDim.x * 256;
+    f32x4 v[LOADS];
+#pragma unroll
+    for (int i = 0; i < LOADS; ++i) v[i] = x[base + i * stride];
+    f32x4 s = v[0];
+#pragma unroll
+    for (int i = 1; i < LOADS; ++i) s += v[i];
+    if (s[0] + s[1] + s[2] + s[3] == 12345.678f) out[0] = s[0];
+}
+// pattern 1: matrix [R][D]; wave instr = 4 rows x 256 B ; wave covers 32 rows x 128 d (proj v2)
+__global__ __launch_bounds__(256) void k_rows256(const float *x, float *out, int R, int D) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int rr = lane >> 4, ch = lane & 15;
+    const int row0 = blockIdx.x * 32, d0 = (blockIdx.y * 4 + wave) * 128;
+    f32x4 v[16];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            v[h * 8 + i] = *(const f32x4 *)(x + (size_t)(row0 + 4 * i + rr) * D + d0 + h * 64 + 4 * ch);
+    f32x4 s = v[0];
+#pragma unroll
+    for (int i = 1; i < 16; ++i) s += v[i];
+    if (s[0] + s[1] + s[2] + s[3] == 12345.678f) out[0] = s[0];
+}
+// pattern 2: wave instr = 16 rows x 64 B (proj v1), wave covers 32 rows x 64 d, 8 loads
+__global__ __launch_bounds__(512) void k_rows64(const float *x, float *out, int R, int D) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r16 = lane & 15, q = lane >> 4;
+    const int row0 = blockIdx.x * 32, d0 = (blockIdx.y * 8 + wave) * 64;
+    f32x4 v[8];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+            v[g * 2 + mt] = *(const f32x4 *)(x + (size_t)(row0 + mt * 16 + r16) * D + d0 + g * 16 + 4 * q);
+    f32x4 s = v[0];
+#pragma unroll
+    for (int i = 1; i < 8; ++i) s += v[i];
+    if (s[0] + s[1] + s[2] + s[3] == 12345.678f) out[0] = s[0];
+}
+// pattern 3: wave instr = 1 row x 1 KiB ; wave covers 16 rows x 256 d
+__global__ __launch_bounds__(256) void k_rows1k(const float *x, float *out, int R, int D) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row0 = blockIdx.x * 16, d0 = (blockIdx.y * 4 + wave) * 256;
+    f32x4 v[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = *(const f32x4 *)(x + (size_t)(row0 + i) * D + d0 + 4 * lane);
+    f32x4 s = v[0];
+#pragma unroll
+    for (int i = 1; i < 16; ++i) s += v[i];
+    if (s[0] + s[1] + s[2] + s[3] == 12345.678f) out[0] = s[0];
+}
+__global__ void k_empty(float *out) { if (threadIdx.x == 9999) out[0] = 1.f; }
+
+int main() {
+    const int R = 2048, D = 4096;            // one "batch" = 2048 x 4096 f32 = 32 MiB
+    const size_t nb = 12, bytes = (size_t)R * D * 4;
+    float *pool, *out;
+    CK(hipMalloc(&pool, nb * bytes));
+    CK(hipMalloc(&out, 64));
+    CK(hipMemset(pool, 0, nb * bytes));
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    const int iters = 600;
+    auto run = [&](const char *name, auto launch) {
+        for (int i = 0; i < 20; ++i) launch(pool + (i % nb) * (bytes / 4));
+        hipDeviceSynchronize();
+        hipEventRecord(e0);
+        for (int i = 0; i < iters; ++i) launch(pool + (i % nb) * (bytes / 4));
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        double us = ms * 1e3 / iters;
+        printf("%-34s %7.2f us/launch  %7.1f GB/s\n", name, us, bytes / us * 1e-3);
+    };
+    run("empty kernel (256 blocks)", [&](float *) { hipLaunchKernelGGL(k_empty, dim3(256), dim3(256), 0, 0, out); });
+    run("contig 1KiB/instr, 4 loads, 2048 blk", [&](float *p) { hipLaunchKernelGGL(k_contig<4>, dim3(2048), dim3(256), 0, 0, (const f32x4 *)p, out, (long)bytes / 16); });
+    run("contig 1KiB/instr, 8 loads, 1024 blk", [&](float *p) { hipLaunchKernelGGL(k_contig<8>, dim3(1024), dim3(256), 0, 0, (const f32x4 *)p, out, (long)bytes / 16); });
+    run("contig 1KiB/instr,16 loads,  512 blk", [&](float *p) { hipLaunchKernelGGL(k_contig<16>, dim3(512), dim3(256), 0, 0, (const f32x4 *)p, out, (long)bytes / 16); });
+    run("rows 4x256B/instr (proj v2)", [&](float *p) { hipLaunchKernelGGL(k_rows256, dim3(R / 32, D / 512), dim3(256), 0, 0, p, out, R, D); });
+    run("rows 16x64B/instr (proj v1)", [&](float *p) { hipLaunchKernelGGL(k_rows64, dim3(R / 32, D / 512), dim3(512), 0, 0, p, out, R, D); });
+    run("rows 1x1KiB/instr", [&](float *p) { hipLaunchKernelGGL(k_rows1k, dim3(R / 16, D / 1024), dim3(256), 0, 0, p, out, R, D); });
+    return 0;
+}
