@@ -574,13 +574,25 @@ __device__ __forceinline__ float act_grad(float a, int act) {
         default: return 1.f;
     }
 }
-__device__ __forceinline__ float sum_p(float x) {  // over the 16 column parts of a row
-    x += __shfl_xor(x, 1);
-    x += __shfl_xor(x, 2);
-    x += __shfl_xor(x, 4);
-    x += __shfl_xor(x, 8);
+// all-reduce over the 16 column parts of a row (one DPP row): pure VALU, no LDS crossbar.
+// quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror form a butterfly.
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float x) {
+    return x + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float sum_p(float x) {
+    x = dpp_add<0xB1>(x);   // lane ^ 1
+    x = dpp_add<0x4E>(x);   // lane ^ 2
+    x = dpp_add<0x141>(x);  // other quad of the 8-lane half
+    x = dpp_add<0x140>(x);  // other half of the 16-lane row
     return x;
 }
+// 1-ulp hardware transcendentals (v_exp_f32 / v_log_f32 / v_rcp_f32 / v_sqrt_f32): the
+// per-row math is one wave per block, so its instruction count is its latency.
+__device__ __forceinline__ float fexp(float x) { return __expf(x); }
+__device__ __forceinline__ float frcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float fsqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+__device__ __forceinline__ float flog1pexp(float negabs) { return __logf(1.f + __expf(negabs)); }
 
 __device__ void mid_reg_block(const MidArgs &a, int blk) {
     // 64 threads; block handles 64 groups of 64 floats of the regularised ranges
@@ -620,7 +632,271 @@ __device__ __forceinline__ size_t frag_off(int r, int c, int RG) {
     return ((size_t)(c >> 4) * RG + (r >> 4)) * 256 + (((r >> 2) & 3) * 16 + (c & 15)) * 4 + (r & 3);
 }
 
-extern "C" __global__ __launch_bounds__(64) void cfl_mid_kernel(MidArgs a) {
+
+// ---------------------------------------------------------------------------
+// Register-resident version of the per-row math of the mid kernel for small
+// (K <= KM, ceil(L/16) <= LQ): the same arithmetic as the generic LDS-array path
+// below, with every per-lane array in VGPRs and fully unrolled loops (entries
+// beyond the lane's own coordinates are zero-filled and contribute nothing), so
+// that the kernel is a short straight-line ALU sequence instead of a chain of
+// dependent LDS round trips.  Returns through the same row buffers.
+// ---------------------------------------------------------------------------
+template <int KM, int LQ>
+__device__ __forceinline__ void mid_math_reg(const MidArgs &a, const float *Y, const float *SC,
+                                             const float *BI, const float *MW, float thr_raw) {
+    const int tid = threadIdx.x, p = tid & 15, j = tid >> 4;
+    const int r = blockIdx.x * MID_RB + j;
+    const bool valid = r < a.R;
+    const int L = a.L, K = a.K, RG = a.Rpad >> 4;
+    const int myL = p < L ? (L - p + 15) >> 4 : 0;
+    const MidSide &ss = a.side[0], &sd = a.side[1];
+    const int ks = ss.is_proto ? K : 1, kd = sd.is_proto ? K : 1;
+    const int offd = ss.npad;
+
+    float As[KM][LQ], Ad[KM][LQ], Xs[KM][LQ], Xd[KM][LQ], Rl[LQ];
+    // ---- head epilogue ----
+#pragma unroll
+    for (int k = 0; k < KM; ++k)
+#pragma unroll
+        for (int li = 0; li < LQ; ++li) {
+            const int l = p + 16 * li;
+            {
+                const bool in = valid && li < myL && k < ks;
+                const int c = in ? k * L + l : 0;
+                const float xv = in ? Y[j * a.ys + c] * a.in_mul : 0.f;
+                const float yy = xv * SC[c] + BI[c];
+                Xs[k][li] = xv;
+                if (a.dist_type == CFL_DIST_MONOMER && k == 0) Rl[li] = in ? yy : 0.f;
+                As[k][li] = in ? act_fn(yy, a.act) : 0.f;
+            }
+            {
+                const bool in = valid && li < myL && k < kd;
+                const int c = in ? k * L + l : 0;
+                const float xv = in ? Y[j * a.ys + offd + c] * a.in_mul : 0.f;
+                const float yy = xv * SC[offd + c] + BI[offd + c];
+                Xd[k][li] = xv;
+                Ad[k][li] = in ? act_fn(yy, a.act) : 0.f;
+            }
+        }
+
+    // ---- distance ----
+    float d = 0.f, sK[KM], qK[KM], eK[KM], uK[KM];
+#pragma unroll
+    for (int k = 0; k < KM; ++k) sK[k] = qK[k] = eK[k] = uK[k] = 0.f;
+    if (a.dist_type == CFL_DIST_PCD) {
+        if (K > 1) {
+            float mx = -INFINITY;
+#pragma unroll
+            for (int k = 0; k < KM; ++k)
+                if (k < K) {
+                    float e = 0.f;
+#pragma unroll
+                    for (int li = 0; li < LQ; ++li) { const float df = Ad[0][li] - As[k][li]; e = fmaf(df, df, e); }
+                    e = -sum_p(e);
+                    sK[k] = e;
+                    mx = fmaxf(mx, e);
+                }
+            float den = 0.f;
+#pragma unroll
+            for (int k = 0; k < KM; ++k)
+                if (k < K) { sK[k] = fexp(sK[k] - mx); den += sK[k]; }
+            const float inv = frcp(den);
+#pragma unroll
+            for (int k = 0; k < KM; ++k) sK[k] = k < K ? sK[k] * inv : 0.f;
+#pragma unroll
+            for (int li = 0; li < LQ; ++li) {
+                float m = 0.f;
+#pragma unroll
+                for (int k = 0; k < KM; ++k) m = fmaf(sK[k], As[k][li], m);
+                const float rl = Ad[0][li] - m;
+                Rl[li] = rl;
+                d = fmaf(rl, rl, d);
+#pragma unroll
+                for (int k = 0; k < KM; ++k) qK[k] = fmaf(rl, As[k][li], qK[k]);
+            }
+            d = sum_p(d);
+        } else {
+#pragma unroll
+            for (int li = 0; li < LQ; ++li) { const float df = Ad[0][li] - As[0][li]; d = fmaf(df, df, d); }
+            d = sum_p(d);
+        }
+    } else if (a.dist_type == CFL_DIST_MONOMER) {
+        float mx = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < KM; ++k)
+            if (k < K) {
+                float u = 0.f, e = 0.f;
+#pragma unroll
+                for (int li = 0; li < LQ; ++li) {
+                    const int l = p + 16 * li;
+                    const float w = li < myL ? MW[l * a.kpad + k] : 0.f;
+                    u = fmaf(Rl[li], w, u);
+                    const float df = As[0][li] - Ad[k][li];
+                    e = fmaf(df, df, e);
+                }
+                u = sum_p(u);
+                e = sum_p(e);
+                uK[k] = u;
+                if (a.weight_norm) u *= a.mono_g[k] / sqrtf(a.mono_n2[k]);
+                sK[k] = u;
+                eK[k] = e;
+                mx = fmaxf(mx, u);
+            }
+        float den = 0.f;
+#pragma unroll
+        for (int k = 0; k < KM; ++k)
+            if (k < K) { sK[k] = fexp(sK[k] - mx); den += sK[k]; }
+        const float inv = frcp(den);
+#pragma unroll
+        for (int k = 0; k < KM; ++k) {
+            sK[k] = k < K ? sK[k] * inv : 0.f;
+            d = fmaf(sK[k], eK[k], d);
+        }
+    } else {
+#pragma unroll
+        for (int li = 0; li < LQ; ++li) { const float df = As[0][li] - Ad[0][li]; d = fmaf(df, df, d); }
+        d = sum_p(d);
+    }
+
+    // ---- threshold, loss, dL/dd ----
+    const float thr = fmaxf(thr_raw, CFL_THR_FLOOR);
+    const float o = thr - d;
+    if (!a.train) {
+        if (valid && p == 0) {
+            a.scores[r] = o;
+            if (a.dists) a.dists[r] = d;
+        }
+        return;
+    }
+    const bool is_pos = r < a.B;
+    const float invB = 1.f / (float)a.B;
+    const float pw = a.pos_weight != 0.f ? a.pos_weight : 1.f;
+    const float sp = flog1pexp(-fabsf(o));
+    const float bce = fmaxf(o, 0.f) - (is_pos ? o : 0.f) + sp;
+    const float eo = fexp(-fabsf(o));
+    const float sig = (o >= 0.f ? 1.f : eo) * frcp(1.f + eo);
+    const float dlo = is_pos ? (sig - 1.f) * pw * invB : sig * invB;
+    float dd = 0.f;
+    if (a.use_threshold) dd -= dlo;
+    float hinge = 0.f;
+    if (a.caffe_margin != 0.f) {
+        if (is_pos) dd += 0.5f * pw * invB;
+        else {
+            hinge = fmaxf(0.f, a.caffe_margin - d);
+            if (d < a.caffe_margin) dd -= 0.5f * invB;
+        }
+    } else if (a.lambda_m != 0.f) {
+        if (is_pos) dd += pw * a.lambda_m * invB;
+    }
+    if (!valid) dd = 0.f;
+    if (blockIdx.x == 0 && tid == 0) a.thr_copy[0] = thr;
+    {
+        const bool pos = valid && is_pos, neg = valid && !is_pos;
+        float qv = 0.f;
+        switch (p) {
+            case P_BCE_POS: qv = pos ? bce : 0.f; break;
+            case P_BCE_NEG: qv = neg ? bce : 0.f; break;
+            case P_OK_POS: qv = (pos && o > 0.f) ? 1.f : 0.f; break;
+            case P_OK_NEG: qv = (neg && o <= 0.f) ? 1.f : 0.f; break;
+            case P_D_POS: qv = pos ? d : 0.f; break;
+            case P_D_NEG: qv = neg ? d : 0.f; break;
+            case P_O_POS: qv = pos ? o : 0.f; break;
+            case P_O_NEG: qv = neg ? o : 0.f; break;
+            case P_DTHR: qv = valid ? dlo : 0.f; break;
+            case P_HINGE_NEG: qv = neg ? hinge : 0.f; break;
+            case P_SQRT_POS: qv = pos ? fsqrt(d + 1e-7f) : 0.f; break;
+            case P_SQRT_NEG: qv = neg ? fsqrt(d + 1e-7f) : 0.f; break;
+            default: break;
+        }
+        a.rowqf[frag_off(r, p, RG)] = qv;
+    }
+
+    // ---- backward ----
+    auto emit = [&](const MidSide &sx, float A, float X, int k, int li, float dA, float extra_dy) {
+        if (li >= myL) return;
+        const int c = k * L + p + 16 * li;
+        float dy = dA * act_grad(A, a.act) + extra_dy;
+        if (!valid) dy = 0.f;
+        const size_t o_ = frag_off(r, c, RG);
+        sx.dyf[o_] = dy;
+        if (sx.cwf) sx.cwf[o_] = dy * X;
+    };
+    if (a.dist_type == CFL_DIST_PCD) {
+        if (K > 1) {
+            float qbar = 0.f;
+#pragma unroll
+            for (int k = 0; k < KM; ++k) { qK[k] = -2.f * sum_p(qK[k]); qbar = fmaf(sK[k], qK[k], qbar); }
+#pragma unroll
+            for (int k = 0; k < KM; ++k) qK[k] = sK[k] * (qK[k] - qbar);  // dl_k
+#pragma unroll
+            for (int li = 0; li < LQ; ++li) {
+                const float v = Ad[0][li], rl = Rl[li];
+                float dv = 2.f * rl;
+#pragma unroll
+                for (int k = 0; k < KM; ++k)
+                    if (k < K) {
+                        const float vmP = v - As[k][li];
+                        dv = fmaf(-2.f * qK[k], vmP, dv);
+                        const float dP = -2.f * sK[k] * rl + 2.f * qK[k] * vmP;
+                        emit(ss, As[k][li], Xs[k][li], k, li, dP * dd, 0.f);
+                    }
+                emit(sd, Ad[0][li], Xd[0][li], 0, li, dv * dd, 0.f);
+            }
+        } else {
+#pragma unroll
+            for (int li = 0; li < LQ; ++li) {
+                const float df = Ad[0][li] - As[0][li];
+                emit(ss, As[0][li], Xs[0][li], 0, li, -2.f * df * dd, 0.f);
+                emit(sd, Ad[0][li], Xd[0][li], 0, li, 2.f * df * dd, 0.f);
+            }
+        }
+    } else if (a.dist_type == CFL_DIST_MONOMER) {
+#pragma unroll
+        for (int k = 0; k < KM; ++k)
+            if (k < K) {
+                const float du = sK[k] * (eK[k] - d) * dd;
+                float scm = 1.f;
+                if (a.weight_norm) scm = a.mono_g[k] / sqrtf(a.mono_n2[k]);
+                if (p == 0) {
+                    a.mono_du[(size_t)r * a.kpad + k] = du * scm;
+                    if (a.weight_norm) a.mono_duc[(size_t)r * a.kpad + k] = valid ? du * uK[k] : 0.f;
+                }
+                qK[k] = du * scm;
+            }
+#pragma unroll
+        for (int li = 0; li < LQ; ++li) {
+            const int l = p + 16 * li;
+            if (li < myL) a.mono_ya[(size_t)r * a.lpad + l] = valid ? Rl[li] : 0.f;
+            float da = 0.f, ex = 0.f;
+#pragma unroll
+            for (int k = 0; k < KM; ++k)
+                if (k < K) {
+                    const float amP = As[0][li] - Ad[k][li];
+                    da = fmaf(2.f * sK[k], amP, da);
+                    emit(sd, Ad[k][li], Xd[k][li], k, li, -2.f * sK[k] * amP * dd, 0.f);
+                    ex = fmaf(qK[k], li < myL ? MW[l * a.kpad + k] : 0.f, ex);
+                }
+            emit(ss, As[0][li], Xs[0][li], 0, li, da * dd, ex);
+        }
+    } else {
+#pragma unroll
+        for (int li = 0; li < LQ; ++li) {
+            const float df = As[0][li] - Ad[0][li];
+            emit(ss, As[0][li], Xs[0][li], 0, li, 2.f * df * dd, 0.f);
+            emit(sd, Ad[0][li], Xd[0][li], 0, li, -2.f * df * dd, 0.f);
+        }
+    }
+    for (int side = 0; side < 2; ++side) {
+        const MidSide &sx = a.side[side];
+        for (int c = sx.n + p; c < sx.npad; c += 16) {
+            sx.dyf[frag_off(r, c, RG)] = 0.f;
+            if (sx.cwf) sx.cwf[frag_off(r, c, RG)] = 0.f;
+        }
+    }
+}
+
+template <int KM, int LQ>
+__global__ __launch_bounds__(64) void cfl_mid_kernel(MidArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *lds = (float *)smem;
     if ((int)blockIdx.x >= a.nrb) {
@@ -669,7 +945,7 @@ extern "C" __global__ __launch_bounds__(64) void cfl_mid_kernel(MidArgs a) {
             *(f32x4 *)(Y + jj * a.ys + coloff + 4 * c4) = acc;
         }
         for (int c = tid; c < sx.n; c += 64) {
-            SC[coloff + c] = a.weight_norm ? sx.g[c] / sqrtf(sx.n2[c]) : 1.f;
+            SC[coloff + c] = a.weight_norm ? sx.g[c] * __builtin_amdgcn_rsqf(sx.n2[c]) : 1.f;
             BI[coloff + c] = sx.b ? sx.b[c] : 0.f;
         }
     }
@@ -677,6 +953,12 @@ extern "C" __global__ __launch_bounds__(64) void cfl_mid_kernel(MidArgs a) {
         for (int i = tid; i < L * a.kpad; i += 64) MW[i] = a.mono_w[i];
     const float thr_raw = *a.thr;
     __syncthreads();
+    // small shapes: register-resident math (same arithmetic as the generic path below); one
+    // kernel instantiation per shape class -- co-inlined variants made hipcc spill to scratch
+    if constexpr (KM > 0) {
+        mid_math_reg<KM, LQ>(a, Y, SC, BI, MW, thr_raw);
+        return;
+    }
 #ifdef ABL_MID_P1ONLY
     if (a.train) { if (tid == 0) a.rowqf[blockIdx.x] = Y[0] + thr_raw; return; }
 #endif
@@ -718,12 +1000,12 @@ extern "C" __global__ __launch_bounds__(64) void cfl_mid_kernel(MidArgs a) {
             }
             float den = 0.f;
             for (int k = 0; k < K; ++k) {
-                float ex = expf(Ks[k * 64 + tid] - mx);
+                float ex = fexp(Ks[k * 64 + tid] - mx);
                 Ks[k * 64 + tid] = ex;
                 den += ex;
                 Kq[k * 64 + tid] = 0.f;
             }
-            const float inv = 1.f / den;
+            const float inv = frcp(den);
             for (int k = 0; k < K; ++k) Ks[k * 64 + tid] *= inv;
             for (int li = 0; li < myL; ++li) {
                 const float v = Ad[li * 64 + tid];
@@ -763,11 +1045,11 @@ extern "C" __global__ __launch_bounds__(64) void cfl_mid_kernel(MidArgs a) {
         }
         float den = 0.f;
         for (int k = 0; k < K; ++k) {
-            float ex = expf(Ks[k * 64 + tid] - mx);
+            float ex = fexp(Ks[k * 64 + tid] - mx);
             Ks[k * 64 + tid] = ex;
             den += ex;
         }
-        const float inv = 1.f / den;
+        const float inv = frcp(den);
         for (int k = 0; k < K; ++k) {
             const float w = Ks[k * 64 + tid] * inv;
             Ks[k * 64 + tid] = w;
@@ -794,9 +1076,10 @@ extern "C" __global__ __launch_bounds__(64) void cfl_mid_kernel(MidArgs a) {
     const bool is_pos = r < a.B;
     const float invB = 1.f / (float)a.B;
     const float pw = a.pos_weight != 0.f ? a.pos_weight : 1.f;
-    const float sp = log1pf(expf(-fabsf(o)));
+    const float sp = flog1pexp(-fabsf(o));
     const float bce = fmaxf(o, 0.f) - (is_pos ? o : 0.f) + sp;
-    const float sig = o >= 0.f ? 1.f / (1.f + expf(-o)) : expf(o) / (1.f + expf(o));
+    const float eo = fexp(-fabsf(o));
+    const float sig = (o >= 0.f ? 1.f : eo) * frcp(1.f + eo);
     const float dlo = is_pos ? (sig - 1.f) * pw * invB : sig * invB;  // dL_thr/do
     float dd = 0.f;
     if (a.use_threshold) dd -= dlo;
@@ -832,8 +1115,8 @@ extern "C" __global__ __launch_bounds__(64) void cfl_mid_kernel(MidArgs a) {
             case P_O_NEG: qv = neg ? o : 0.f; break;
             case P_DTHR: qv = valid ? dlo : 0.f; break;
             case P_HINGE_NEG: qv = neg ? hinge : 0.f; break;
-            case P_SQRT_POS: qv = pos ? sqrtf(d + 1e-7f) : 0.f; break;
-            case P_SQRT_NEG: qv = neg ? sqrtf(d + 1e-7f) : 0.f; break;
+            case P_SQRT_POS: qv = pos ? fsqrt(d + 1e-7f) : 0.f; break;
+            case P_SQRT_NEG: qv = neg ? fsqrt(d + 1e-7f) : 0.f; break;
             default: break;
         }
         a.rowqf[frag_off(r, p, RG)] = qv;
@@ -1619,7 +1902,16 @@ static int run_pairs(const CflShape *s, const CflNorm *norm, const CflLossCfg *l
     }
     {
         ProfScope ps(st, CFL_K_MID);
-        hipLaunchKernelGGL(cfl_mid_kernel, dim3(ma.nrb + nreg_blocks), dim3(64), pl.mid_lds, st, ma);
+        const dim3 mgrid(ma.nrb + nreg_blocks), mblk(64);
+        const bool generic_only = debug_env("CFL_DEBUG_MID_GENERIC") > 0;
+        if (!generic_only && s->K <= 4 && pl.Lq <= 2)
+            hipLaunchKernelGGL((cfl_mid_kernel<4, 2>), mgrid, mblk, pl.mid_lds, st, ma);
+        else if (!generic_only && s->K <= 8 && pl.Lq <= 2)
+            hipLaunchKernelGGL((cfl_mid_kernel<8, 2>), mgrid, mblk, pl.mid_lds, st, ma);
+        else if (!generic_only && s->K <= 4 && pl.Lq <= 4)
+            hipLaunchKernelGGL((cfl_mid_kernel<4, 4>), mgrid, mblk, pl.mid_lds, st, ma);
+        else
+            hipLaunchKernelGGL((cfl_mid_kernel<0, 0>), mgrid, mblk, pl.mid_lds, st, ma);
     }
     if (!train) {
         HIP_TRY(hipGetLastError());
