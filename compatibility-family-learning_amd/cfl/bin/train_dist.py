@@ -1,0 +1,138 @@
+"""python -m cfl.bin.train_dist -- train the Monomer-data model on MI355X.
+
+Drop-in for the reference's cfl/bin/train_dist.py (same flags, checkpoint / log
+layout and best_acc_model bookkeeping, cfl/bin/train_dist.py:37-124).  The
+TensorFlow queues + enqueue threads are replaced by HBM-resident feature tables
+gathered on the GPU by pair index (cfl.input_data.ResidentFeatures), and the
+per-iteration ``sess.run`` by one fused HIP training step.
+"""
+import gc
+import logging
+import os
+import shutil
+
+from tqdm import trange
+
+from .. import engine as dp
+from ..input_data import ResidentFeatures, load_data_sets
+from ..models.dist import construct_model
+from ..ops import normalizer, unnormalizer
+from ..utils import (IncrementalAverage, Saver, dist_eval, load_best_stats, load_model, log_args,
+                     monomer_parser, reduce_product, save_best_stats)
+
+logger = logging.getLogger(__name__)
+
+SCALAR_EVERY = 25  # host read-back cadence of the display scalars (steps)
+
+
+def train_loop(model, data, aux, batch_size, start_epoch, epochs, log_dir, checkpoint_dir, saver):
+    best_saver = Saver()
+    nb_train = max(data.train.num_examples_labeled_pos, data.train.num_examples_labeled_neg)
+    logger.warning('%d examples', nb_train)
+    logger.warning('model: %s', model.get_name())
+    nb_batch = nb_train // batch_size
+
+    train_src = ResidentFeatures(aux.train, model.device)
+    val_src = ResidentFeatures(aux.val, model.device)
+
+    best_dir = os.path.join(checkpoint_dir, 'best_acc_model')
+    os.makedirs(best_dir, exist_ok=True)
+    best_accuracy_path = os.path.join(best_dir, 'best_accuracy')
+    stats = load_best_stats(best_accuracy_path)
+    scalar_log = open(os.path.join(log_dir, 'scalars.tsv'), 'a')
+
+    # data parallel (torchrun): every rank walks the same seeded index stream and
+    # trains on its contiguous slice of each global batch; rank 0 evaluates and saves
+    shard = dp.shard_rows(batch_size) if dp.world_size() > 1 else None
+    chief = dp.rank() == 0
+    for e in range(start_epoch, epochs):
+        t = trange(nb_batch, disable=not chief)
+        t.set_description('epoch {}'.format(e))
+        train_avg, val_avg = IncrementalAverage(), IncrementalAverage()
+        for i in t:
+            model.engine.step(train_src.next_batch(batch_size, shard))
+            if i % SCALAR_EVERY == 0 or i == nb_batch - 1:
+                s = model.scalars()
+                train_avg.add(s['accuracy'])
+                val_avg.add(model.batch_accuracy(val_src.next_batch(batch_size)))
+                t.set_postfix(train_acc=train_avg.average, val_acc=val_avg.average)
+                scalar_log.write('{}\t{}\t{}\t{}\n'.format(nb_batch * e + i, s['total'], s['accuracy'],
+                                                           s['threshold']))
+        scalar_log.flush()
+        gc.collect()
+        if not chief:
+            continue
+        saver.save(model, os.path.join(checkpoint_dir, 'model'), global_step=e)
+
+        val_stats = dist_eval(None, model, batch_size, data.val)
+        if val_stats.accuracy > stats.best_accuracy:
+            test_stats = dist_eval(None, model, batch_size, data.test)
+            logger.warning('epoch %d: current error = train: %f val: %f test: %f / auc = val: %f test: %f',
+                           e, 1. - train_avg.average, 1. - val_stats.accuracy,
+                           1. - test_stats.accuracy, val_stats.auc, test_stats.auc)
+            stats.best_accuracy, stats.best_auc, stats.best_epoch = val_stats.accuracy, val_stats.auc, e
+            best_saver.save(model, os.path.join(best_dir, 'model'), global_step=stats.best_epoch)
+            save_best_stats(best_accuracy_path, stats.best_epoch, stats.best_accuracy, stats.best_auc)
+        else:
+            logger.warning('epoch %d: avg error = train: %f val: %f', e, 1. - train_avg.average,
+                           1. - val_avg.average)
+    scalar_log.close()
+
+
+def setup_logging(log_dir):
+    log_format = '%(asctime)s [%(levelname)-5.5s] [%(name)s]  %(message)s'
+    logging.basicConfig(filename=os.path.join(log_dir, 'log.log'), format=log_format,
+                        level=logging.WARNING)
+    console = logging.StreamHandler()
+    console.setLevel(logging.INFO)
+    console.setFormatter(logging.Formatter(log_format))
+    logging.getLogger().addHandler(console)
+
+
+def train_monomer(data_name, data_root, checkpoint_root, log_root, run_tag, seed, normalize_value,
+                  input_shape, batch_size, num_components, latent_size, lr, beta1, beta2, epochs,
+                  reg_const, reset):
+    if int(os.environ.get('WORLD_SIZE', '1')) > 1 and not dp.dist.is_initialized():
+        import torch
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
+        dp.dist.init_process_group('nccl')
+    input_shape = tuple(input_shape)
+    input_size = reduce_product(input_shape)
+    data = load_data_sets(os.path.join(data_root, data_name), input_size, seed=seed)
+    model, aux = construct_model(
+        input_shape=input_shape, latent_size=latent_size, normalize_value=normalize_value, lr=lr,
+        beta1=beta1, beta2=beta2, num_components=num_components, batch_size=batch_size, data=data,
+        run_tag=run_tag, reg_const=reg_const, data_normalizer=normalizer(normalize_value, 0., None, None),
+        data_unnormalizer=unnormalizer(normalize_value, 0.), seed=seed)
+
+    checkpoint_dir = os.path.join(checkpoint_root, data_name, model.get_name())
+    log_dir = os.path.join(log_root, data_name, model.get_name())
+    for path in (checkpoint_dir, log_dir):
+        if reset and os.path.exists(path) and dp.rank() == 0:
+            shutil.rmtree(path)
+        os.makedirs(path, exist_ok=True)
+    if dp.world_size() > 1:
+        dp.dist.barrier()
+    setup_logging(log_dir)
+    saver, start_epoch = load_model(model, checkpoint_dir)
+    train_loop(model=model, aux=aux, data=data, batch_size=batch_size, start_epoch=start_epoch,
+               epochs=epochs, log_dir=log_dir, checkpoint_dir=checkpoint_dir, saver=saver)
+
+
+def parse_args(argv=None):
+    parser = monomer_parser()
+    parser.add_argument('--epochs', type=int, default=120)
+    parser.add_argument('--reset', action='store_true')
+    return parser.parse_args(argv)
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    log_args(args)
+    train_monomer(**vars(args))
+
+
+if __name__ == '__main__':
+    main()

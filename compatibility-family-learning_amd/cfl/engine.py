@@ -18,6 +18,36 @@ import torch.distributed as dist
 from . import hipabi as H
 
 
+def world_size():
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def rank():
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
+def reduce_gradients(flat_grad):
+    """The ONE exchange of a data-parallel step: sum the flat fp32
+    gradient (same layout on every rank) over all ranks; returns the factor that turns
+    the sum into the gradient of the global-batch mean loss.  Backend "nccl" is RCCL
+    over xGMI on MI355X; the CPU tests run the same code over gloo."""
+    n = world_size()
+    if n > 1:
+        dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM)
+    return 1.0 / n
+
+
+def shard_rows(n_rows, rank_=None, world=None):
+    """Rows [lo, hi) of a global batch that belong to this rank: contiguous, equal
+    slices, so the union over ranks is the single-GPU batch bit-exactly."""
+    world = world_size() if world is None else world
+    rank_ = rank() if rank_ is None else rank_
+    if n_rows % world:
+        raise ValueError('global batch %d is not divisible by world size %d' % (n_rows, world))
+    per = n_rows // world
+    return rank_ * per, (rank_ + 1) * per
+
+
 class PairEngine(object):
     def __init__(self, D, L, K, dist_type='pcd', weight_norm=False, has_bias=True,
                  act_type=None, directed=False, norm=None, loss=None, lr=1e-3,
@@ -63,7 +93,7 @@ class PairEngine(object):
 
     @property
     def world_size(self):
-        return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        return world_size()
 
     # -- the hot path ------------------------------------------------------
     def fwd_bwd(self, batch):
@@ -95,8 +125,7 @@ class PairEngine(object):
             return
         self.fwd_bwd(batch)
         # one exchange per step: sum of the flat fp32 gradient over xGMI
-        dist.all_reduce(self.grad, op=dist.ReduceOp.SUM)
-        self.apply_adam(1.0 / n)
+        self.apply_adam(reduce_gradients(self.grad))
 
     def read_scalars(self):
         """Host copy of the last step's scalars (synchronises the stream)."""

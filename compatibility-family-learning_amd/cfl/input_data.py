@@ -1,0 +1,349 @@
+"""Dataset readers and the pair-batch generator of the cfl hot path.
+
+Mirrors the vector-dataset side of the reference's ``cfl/input_data.py`` (same
+function / class / attribute names, same NumPy ``RandomState`` call sequence, so
+that batch *indices* are bit-identical for a given seed -- pinned by
+tests/golden/data_goldens.npz which was captured by importing the reference):
+
+    dump_array, load_features, load_features_by_positions,
+    load_asins_by_positions, load_features_indices, load_meta_lines,
+    load_data_sets, SemiDataSet (next_batch / whole_pos_batches / ...)
+
+Differences, all host-side mechanics rather than behaviour:
+  * ``features.b`` is memory-mapped once as a structured array instead of one
+    ``seek`` + ``fromfile`` per row (cfl/input_data.py:212-228 is the reference's
+    real CPU bottleneck);
+  * ``SemiDataSet.next_batch_indices`` exposes the index arrays so that a
+    device-resident feature table can be gathered on the GPU
+    (``ResidentFeatures``, include/cfl_hip.h cfl_gather_rows);
+  * image / image+latent ("double") datasets (cfl/input_data.py:34-192) are not
+    part of the linear hot path and raise NotImplementedError.
+"""
+import os
+from argparse import Namespace
+from collections import defaultdict
+
+import numpy as np
+from numpy.random import RandomState
+
+ID_BYTES = 10  # every item id is exactly 10 ASCII bytes
+
+
+def _record_dtype(input_size):
+    return np.dtype([('id', 'S%d' % ID_BYTES), ('x', '<f4', (int(input_size),))])
+
+
+def dump_array(outfile, floats):
+    """Append one little-endian float32 vector (cfl/input_data.py:23-31)."""
+    np.asarray(floats, dtype='<f4').tofile(outfile)
+
+
+class FeatureFile(object):
+    """Read-only memory map of a vector ``features.b``: records of
+    ``10 + 4*D`` bytes, position p at byte ``(4*D + 10) * p``."""
+
+    def __init__(self, path, input_size):
+        self.path = path
+        self.input_size = int(input_size)
+        size = os.path.getsize(path)
+        rec = ID_BYTES + 4 * self.input_size
+        if size % rec:
+            raise ValueError('%s: size %d is not a multiple of the %d-byte record' % (path, size, rec))
+        self.n = size // rec
+        self.records = (np.memmap(path, dtype=_record_dtype(input_size), mode='r', shape=(self.n,))
+                        if self.n else np.zeros(0, _record_dtype(input_size)))
+
+    def features(self, positions):
+        return np.ascontiguousarray(self.records['x'][np.asarray(positions, dtype=np.int64)])
+
+    def ids(self, positions=None):
+        raw = self.records['id'] if positions is None else self.records['id'][np.asarray(positions, dtype=np.int64)]
+        return [b.decode('ascii') for b in raw]
+
+    def all_features(self):
+        return np.ascontiguousarray(self.records['x'])
+
+
+_FILES = {}
+
+
+def _open(path, input_size):
+    key = (os.path.abspath(path), int(input_size), os.path.getmtime(path), os.path.getsize(path))
+    ff = _FILES.get(key)
+    if ff is None:
+        ff = _FILES[key] = FeatureFile(path, input_size)
+    return ff
+
+
+def load_features(path, input_size=28 * 28):
+    """Yield (id, vector) for every record (cfl/input_data.py:195-209)."""
+    ff = _open(path, input_size)
+    for i, asin in enumerate(ff.ids()):
+        yield asin, ff.records['x'][i]
+
+
+def load_features_by_positions(path, positions, input_size=28 * 28):
+    """[len(positions), input_size] float32 (cfl/input_data.py:212-228)."""
+    return _open(path, input_size).features(positions)
+
+
+def load_asins_by_positions(path, positions, input_size=28 * 28):
+    """cfl/input_data.py:231-245."""
+    return _open(path, input_size).ids(positions)
+
+
+def load_features_indices(path, input_size=28 * 28):
+    """{id: position}; a repeated id keeps its last position (cfl/input_data.py:248-265)."""
+    return {asin: i for i, asin in enumerate(_open(path, input_size).ids())}
+
+
+def load_meta_lines(path):
+    """Group a meta.txt into (id, lines): a line starting with a space continues
+    the current item (cfl/input_data.py:268-287)."""
+    current, lines = None, []
+    with open(path) as infile:
+        for line in infile:
+            if line.startswith(' '):
+                assert lines and current, 'must have valid id'
+                lines.append(line)
+                continue
+            if current:
+                yield current, lines
+            current, lines = line.split(' ', 1)[0].strip(), [line]
+    if current:
+        yield current, lines
+
+
+def _read_pairs(path, index, reorder=False):
+    pairs = []
+    with open(path) as infile:
+        rows = [line.strip().split() for line in infile]
+    rows = [(r[0], r[2]) for r in rows if r]
+    if reorder:
+        # round-robin over first-character buckets, popping from the back
+        # (cfl/input_data.py:434-447), used for ordered visualisation sets
+        buckets = defaultdict(list)
+        for a, b in rows:
+            buckets[a[0]].append((a, b))
+        rows = []
+        while any(buckets.values()):
+            for key in sorted(buckets):
+                if buckets[key]:
+                    rows.append(buckets[key].pop())
+    for a, b in rows:
+        pairs.append([index[a], index[b]])
+    return np.array(pairs)
+
+
+def _read_ids(path):
+    with open(path) as infile:
+        return [line.strip() for line in infile]
+
+
+def load_data_sets(path, input_size, data_switch=False, raw_latent=False, is_image=False,
+                   is_double=False, directed=False, reorder=False, seed=633):
+    """train / val / test splits (cfl/input_data.py:290-341): ``data_switch`` only
+    on train, ``reorder`` only on test, the same seed for all three."""
+    common = dict(input_size=input_size, raw_latent=raw_latent, is_image=is_image,
+                  is_double=is_double, directed=directed, seed=seed)
+    return Namespace(
+        train=SemiDataSet(os.path.join(path, 'train'), data_switch=data_switch, **common),
+        val=SemiDataSet(os.path.join(path, 'val'), **common),
+        test=SemiDataSet(os.path.join(path, 'test'), reorder=reorder, **common))
+
+
+class SemiDataSet(object):
+    """Positive / negative pair lists over one ``features.b`` plus the seeded batch
+    streams of cfl/input_data.py:344-690 (vector datasets)."""
+
+    def __init__(self, path, input_size=28 * 28, data_switch=False, is_image=False,
+                 is_double=False, directed=False, reorder=False, raw_latent=False, seed=633):
+        if is_image or is_double:
+            raise NotImplementedError(
+                'image / double datasets (cfl/input_data.py:34-192) are outside the linear '
+                'pair-distance hot path')
+        self._rng = RandomState(seed)
+        self.input_size = input_size
+        self.feature_path = os.path.join(path, 'features.b')
+        self.is_image, self.is_double = False, False
+        self.directed = directed
+        self.data_switch = data_switch
+        self.raw_latent = raw_latent
+        self._file = _open(self.feature_path, input_size)
+
+        self.asins_to_index = load_features_indices(self.feature_path, input_size)
+        self.index_to_asins = {i: a for a, i in self.asins_to_index.items()}
+        # quirk kept on purpose: the LAST item is never drawn as unlabeled
+        # (cfl/input_data.py:399)
+        self.num_examples = max(self.index_to_asins)
+        self.item_indices = np.arange(self.num_examples)
+        self.head_unlabeled = 0
+
+        if directed:
+            for name in ('source', 'target'):
+                idx = np.array(sorted(self.asins_to_index[a] for a in _read_ids(os.path.join(path, name + '.txt'))))
+                idx = idx[self._rng.permutation(idx.shape[0])]
+                setattr(self, name + '_indices', idx)
+                setattr(self, 'num_' + name, idx.shape[0])
+                setattr(self, 'head_' + name, 0)
+
+        self.pairs_pos = _read_pairs(os.path.join(path, 'pairs_pos.txt'), self.asins_to_index, reorder)
+        self.pairs_neg = _read_pairs(os.path.join(path, 'pairs_neg.txt'), self.asins_to_index)
+        self.head_labeled_pos = self.head_labeled_neg = 0
+        self.num_examples_labeled_pos = self.pairs_pos.shape[0]
+        self.num_examples_labeled_neg = self.pairs_neg.shape[0]
+
+    # -- feature access ------------------------------------------------------
+    def _load_features_by_positions(self, indices):
+        return self._file.features(indices)
+
+    def _load_asins_by_positions(self, indices):
+        return self._file.ids(indices)
+
+    # -- labeled stream --------------------------------------------------------
+    def _draw(self, which, batch_size):
+        pairs = getattr(self, 'pairs_' + which)
+        n = pairs.shape[0]
+        head = getattr(self, 'head_labeled_' + which)
+        if head + batch_size > n:           # epoch wrap: reshuffle in place
+            head = 0
+            pairs = pairs[self._rng.permutation(n)]
+            setattr(self, 'pairs_' + which, pairs)
+        setattr(self, 'head_labeled_' + which, head)
+        return pairs, head, n
+
+    def next_batch_indices(self, batch_size):
+        """The integer side of next_labeled_batch (cfl/input_data.py:542-580):
+        returns (pos_pairs [B,2], neg_pairs [B,2], switched) and advances the
+        stream with exactly the reference's RandomState call sequence."""
+        pp, hp, npos = self._draw('pos', batch_size)
+        pn, hn, nneg = self._draw('neg', batch_size)
+        positions_pos = pp[hp:hp + batch_size]
+        positions_neg = pn[hn:hn + batch_size]
+        if batch_size > npos:
+            positions_pos = pp[self._rng.choice(npos, batch_size)]
+        if batch_size > nneg:
+            positions_neg = pn[self._rng.choice(nneg, batch_size)]
+        assert positions_pos.shape[0] == batch_size
+        assert positions_neg.shape[0] == batch_size
+        switched = bool(self.data_switch and self._rng.rand() > 0.5)
+        self.head_labeled_pos += batch_size
+        self.head_labeled_neg += batch_size
+        return positions_pos, positions_neg, switched
+
+    def next_labeled_batch(self, batch_size, return_labels=False):
+        if return_labels:
+            raise NotImplementedError()
+        pos, neg, switched = self.next_batch_indices(batch_size)
+        cols = (1, 0) if switched else (0, 1)
+        load = self._load_features_by_positions
+        return (load(pos[:, cols[0]]), load(pos[:, cols[1]]),
+                load(neg[:, cols[0]]), load(neg[:, cols[1]]))
+
+    def next_batch(self, batch_size, return_labels=False):
+        return self.next_labeled_batch(batch_size, return_labels)
+
+    # -- whole-set iterators (dist_eval / dist_predict) --------------------------
+    def _whole(self, pairs, batch_size, source_ids):
+        for i in range(0, pairs.shape[0], batch_size):
+            chunk = pairs[i:i + batch_size]
+            out = (self._load_features_by_positions(chunk[:, 0]),
+                   self._load_features_by_positions(chunk[:, 1]))
+            if source_ids:
+                out += (self._load_asins_by_positions(chunk[:, 0]),)
+            yield out
+
+    def whole_pos_batches(self, batch_size, source_ids=False):
+        return self._whole(self.pairs_pos, batch_size, source_ids)
+
+    def whole_neg_batches(self, batch_size, source_ids=False):
+        return self._whole(self.pairs_neg, batch_size, source_ids)
+
+    def whole_unlabeled_batches(self, batch_size, source_ids=False):
+        for i in range(0, self.num_examples, batch_size):
+            positions = self.item_indices[i:i + batch_size]
+            data = [self._load_features_by_positions(positions)]
+            if source_ids:
+                data.append(self._load_asins_by_positions(positions))
+            yield data
+
+    # -- unlabeled / directed streams (cfl/input_data.py:591-690) ------------------
+    def _stream(self, attr, head_attr, n, batch_size, allow_choice):
+        head = getattr(self, head_attr)
+        idx = getattr(self, attr)
+        if head + batch_size > n:
+            head = 0
+            idx = idx[self._rng.permutation(n)]
+            setattr(self, attr, idx)
+        positions = idx[head:head + batch_size]
+        if allow_choice and batch_size > n:
+            positions = idx[self._rng.choice(n, batch_size)]
+            assert positions.shape[0] == batch_size
+        setattr(self, head_attr, head + batch_size)
+        return positions
+
+    def _finish(self, positions, return_labels, source_ids):
+        data = [self._load_features_by_positions(positions)]
+        if return_labels or source_ids:
+            asins = self._load_asins_by_positions(positions)
+            if return_labels:
+                data.append(np.array([self.categories[a] for a in asins]))
+            if source_ids:
+                data.append(asins)
+        return data
+
+    def next_unlabeled_batch(self, batch_size, return_labels=False, source_ids=False):
+        pos = self._stream('item_indices', 'head_unlabeled', self.num_examples, batch_size, False)
+        return self._finish(pos, return_labels, source_ids)
+
+    def next_source_batch(self, batch_size, return_labels=False, source_ids=False):
+        if not self.directed:
+            return self.next_unlabeled_batch(batch_size, return_labels, source_ids)
+        pos = self._stream('source_indices', 'head_source', self.num_source, batch_size, True)
+        return self._finish(pos, return_labels, source_ids)
+
+    def next_target_batch(self, batch_size, return_labels=False, source_ids=False):
+        if not self.directed:
+            return self.next_unlabeled_batch(batch_size, return_labels, source_ids)
+        # the reference applies no oversampling to the target stream
+        pos = self._stream('target_indices', 'head_target', self.num_target, batch_size, False)
+        return self._finish(pos, return_labels, source_ids)
+
+
+class ResidentFeatures(object):
+    """The whole ``features.b`` of a split kept in HBM; batches are assembled on
+    the GPU with cfl_gather_rows from the index arrays of
+    ``SemiDataSet.next_batch_indices``.  The feature dimension
+    is zero-padded to a multiple of 64 for the kernels."""
+
+    def __init__(self, dataset, device='cuda'):
+        import torch
+        from . import hipabi
+        self._h = hipabi
+        x = dataset._file.all_features()
+        D = x.shape[1]
+        self.input_size = D
+        self.padded_size = (D + 63) // 64 * 64
+        t = torch.from_numpy(x)
+        if self.padded_size != D:
+            t = torch.nn.functional.pad(t, (0, self.padded_size - D))
+        self.table = t.contiguous().to(device)
+        self.device = self.table.device
+        self.dataset = dataset
+
+    def gather(self, positions, out=None):
+        import torch
+        idx = torch.as_tensor(np.ascontiguousarray(positions, dtype=np.int64)).to(self.device, non_blocking=True)
+        return self._h.gather_rows(self.table, idx, out)
+
+    def next_batch(self, batch_size, shard=None):
+        """Device tensors (pos_src, pos_dst, neg_src, neg_dst), same rows as
+        ``SemiDataSet.next_batch`` would return for this call.  ``shard=(lo, hi)``
+        keeps only that row range of the global batch (data parallelism: every rank
+        advances the same seeded index stream and gathers its own slice)."""
+        pos, neg, switched = self.dataset.next_batch_indices(batch_size)
+        if shard is not None:
+            pos, neg = pos[shard[0]:shard[1]], neg[shard[0]:shard[1]]
+        c = (1, 0) if switched else (0, 1)
+        return (self.gather(pos[:, c[0]]), self.gather(pos[:, c[1]]),
+                self.gather(neg[:, c[0]]), self.gather(neg[:, c[1]]))

@@ -1,0 +1,199 @@
+"""The CFL model, distance phase (cfl/models/cfl.py:364-949, 1065-1085, 1348-1482)
+for ``--model-type linear``: FCPCD encoders (weight-normalised heads,
+cfl/models/blocks.py:477-527 + cfl/models/base.py:43-105), pcd / monomer / siamese
+distance, learned-threshold BCE with pos_weight, lambda_m pull term or the
+caffe-margin contrastive hinge, L2 regulariser, Adam (+ the separate threshold
+Adam when --use-threshold is off) -- all inside the fused HIP pair kernels.
+
+Not built in this round (raise NotImplementedError): the conv
+encoder (``--model-type conv``), image / double datasets and the MrCGAN
+post-epoch phase (``--gan``).
+"""
+import logging
+import os
+
+import numpy as np
+
+from .. import hipabi as H
+from ..utils import dist_eval, load_best_stats, reduce_product, save_best_stats
+from .base import PairModel
+
+logger = logging.getLogger(__name__)
+
+
+class CFL(PairModel):
+    MODEL_SCOPE = 'CFL'
+    HEAD_SCOPES = {
+        'outputs': ('outputs/fully_connected', {'W': 'V', 'b': 'biases', 'g': 'g'}),
+        'proto': ('prototype_outputs/fully_connected', {'W': 'V', 'b': 'biases', 'g': 'g'}),
+        'mono': ('monomer_outputs/fully_connected', {'W': 'V', 'g': 'g'}),
+    }
+
+    def __init__(self, is_double, disable_double, latent_shape, source_shape, input_shape, ae_shape,
+                 batch_size, data_norm, data_type, num_components, pos_weight, latent_size,
+                 caffe_margin, gan, cgan, t_dim, dist_type, act_type, use_threshold, lr, beta1,
+                 beta2, z_dim, z_stddev, g_dim, g_lr, g_beta1, g_beta2, m_prj, m_enc, d_dim, d_lr,
+                 d_beta1, d_beta2, lambda_gp, lambda_m, lambda_dra, directed, data_directed,
+                 model_type, gan_type, reg_const, batches=None, val_batches=None,
+                 unlabeled_batches=None, train_data_transformer=None, val_data_transformer=None,
+                 ae_transformer=None, data_normalizer=None, data_unnormalizer=None,
+                 ae_normalizer=None, ae_unnormalizer=None, latent_normalizer=None, run_tag=None,
+                 name='CFL', reuse=False, seed=0, device=None):
+        for k, v in list(locals().items()):
+            if k not in ('self', 'name', 'reuse', 'batches', 'val_batches', 'unlabeled_batches'):
+                setattr(self, k, v)
+        self.input_shape = tuple(input_shape)
+        self.ae_shape = tuple(ae_shape) if ae_shape else self.input_shape
+        self.source_shape = tuple(source_shape) if source_shape else self.input_shape
+        if model_type != 'linear':
+            raise NotImplementedError('--model-type conv (ConvPCD, cfl/models/blocks.py:530-590) '
+                                      'is not built yet; the HIP pair path covers --model-type linear')
+        if is_double:
+            raise NotImplementedError('image + latent ("double") datasets are not built yet')
+        if gan:
+            raise NotImplementedError('the MrCGAN post-epoch phase (--gan) is not built yet')
+        self.ENCODER_SCOPES = ('DistEncoderSrc', 'DistEncoderDst') if directed else ('DistEncoder',)
+        norm = data_normalizer.to_cfl_norm() if data_normalizer is not None else H.make_norm()
+        loss = H.make_loss(use_threshold=use_threshold, pos_weight=pos_weight,
+                           caffe_margin=caffe_margin, lambda_m=lambda_m, reg_const=reg_const)
+        self._setup_engine(
+            reduce_product(self.input_shape), latent_size, num_components, dist_type,
+            weight_norm=True, has_bias=dist_type.startswith('pcd'), act_type=act_type,
+            directed=directed, norm=norm, loss=loss, lr=lr, beta1=beta1, beta2=beta2,
+            batch_size=batch_size, seed=seed, device=device)
+        self._ema = {}
+
+    def init(self, sess=None):
+        pass
+
+    def get_name(self, no_gan=False):
+        """Byte-for-byte cfl/models/cfl.py:368-412 (names checkpoint / predict dirs)."""
+        parts = ['cfl', self.dist_type, self.model_type]
+        if self.directed:
+            parts.append('di')
+        if self.pos_weight:
+            parts.append('pw_{}'.format(self.pos_weight))
+        if self.caffe_margin:
+            parts.append('margin_{}'.format(self.caffe_margin))
+        parts += [self.data_type, 'ls_{}'.format(self.latent_size)]
+        if self.dist_type != 'siamese':
+            parts.append('nc_{}'.format(self.num_components))
+        if self.act_type:
+            parts.append('act_{}'.format(self.act_type))
+        if self.disable_double:
+            parts.append('dd')
+        if self.use_threshold:
+            parts.append('ut')
+        if self.reg_const:
+            parts.append('reg_{}'.format(self.reg_const))
+        if self.data_norm:
+            parts.append('norm_{}'.format('_'.join(str(n) for n in self.data_norm)))
+        if self.lambda_m:
+            parts.append('lm_{}'.format(self.lambda_m))
+        if self.gan and not no_gan:
+            if self.cgan:
+                parts.append('cgan_z_{}'.format(self.z_dim))
+                if self.t_dim:
+                    parts.append('t_{}'.format(self.t_dim))
+            else:
+                parts.append('gan_z_{}'.format(self.z_dim))
+                if self.m_prj:
+                    parts.append('m_prj_{}'.format(self.m_prj))
+                if self.m_enc:
+                    parts.append('m_enc_{}'.format(self.m_enc))
+            if self.lambda_gp:
+                parts.append('dra_{}_{}'.format(self.lambda_gp, self.lambda_dra))
+            if self.gan_type != 'conv':
+                parts.append(self.gan_type)
+        name = '_'.join(parts)
+        if self.run_tag:
+            name += '_run_' + self.run_tag
+        return name
+
+    # ExponentialMovingAverage(0.99), zero-initialised shadow, no debias
+    # (cfl/models/cfl.py:528, 896-949; display only)
+    def _ema_update(self, key, value):
+        self._ema[key] = 0.99 * self._ema.get(key, 0.0) + 0.01 * value
+        return self._ema[key]
+
+    def train(self, sess, data, start_iter, epochs, post_epochs, best_dir, best_acc_dir,
+              checkpoint_dir, epoch_callback=None, post_epoch_callback=None, save_epochs=1,
+              eval_epochs=1, save_iters=None, disable_eval=False, saver=None, best_saver=None,
+              best_acc_saver=None, writer=None, check=None, val_every=1):
+        """Distance epochs of cfl/models/cfl.py:1348-1511 (same bookkeeping, same
+        best_model / best_acc_model files, including the reference's habit of
+        writing the AUC-best stats into best_accuracy_by_th)."""
+        from tqdm import trange
+        nb_train = max(data.train.num_examples_labeled_pos, data.train.num_examples_labeled_neg)
+        logger.warning('%d pairs / %d images', nb_train, data.train.num_examples)
+        nb_batch = nb_train // self.batch_size
+        logger.warning('%d batches per epoch', nb_batch)
+        best_auc_path = os.path.join(best_dir, 'best_accuracy')
+        best_acc_path = os.path.join(best_acc_dir, 'best_accuracy_by_th')
+        stats = load_best_stats(best_auc_path)
+        stats_acc = load_best_stats(best_acc_path)
+        start_epoch = start_iter // nb_batch
+        logger.warning('start epoch %d of %d', start_epoch, epochs)
+        for e in range(start_epoch, epochs):
+            t = trange(start_iter % nb_batch if e == start_epoch else 0, nb_batch)
+            t.set_description('epoch {}'.format(e))
+            train_avg = val_avg = 0.0
+            for i in t:
+                self.train_step(data.train.next_batch(self.batch_size))
+                if save_iters and i > 0 and i % save_iters == 0 and saver is not None:
+                    saver.save(self, os.path.join(checkpoint_dir, 'model'), global_step=nb_batch * e + i)
+                if i % 50 == 0 or i == nb_batch - 1:      # host read-back only now and then
+                    s = self.scalars()
+                    train_avg = self._ema_update('acc', s['accuracy'])
+                    val_avg = self._ema_update('val_acc', self.batch_accuracy(
+                        data.val.next_batch(self.batch_size)))
+                    t.set_postfix(error=1. - train_avg, val_error=1. - val_avg,
+                                  pos_avg=self._ema_update('pos', s['dist_adapt_pos']),
+                                  neg_avg=self._ema_update('neg', s['dist_adapt_neg']))
+            if e % eval_epochs == 0 and not disable_eval:
+                val_stats = dist_eval(None, self, self.batch_size, data.val)
+                if val_stats.auc > stats.best_auc or val_stats.accuracy > stats_acc.best_accuracy:
+                    test_stats = dist_eval(None, self, self.batch_size, data.test)
+                    logger.warning('epoch %d: current error = train: %f val: %f test: %f / auc = val: %f test: %f',
+                                   e, 1. - train_avg, 1. - val_stats.accuracy, 1. - test_stats.accuracy,
+                                   val_stats.auc, test_stats.auc)
+                    if val_stats.auc > stats.best_auc:
+                        stats.best_accuracy, stats.best_auc, stats.best_epoch = \
+                            val_stats.accuracy, val_stats.auc, e
+                        best_saver.save(self, os.path.join(best_dir, 'model'), global_step=stats.best_epoch)
+                        save_best_stats(best_auc_path, stats.best_epoch, stats.best_accuracy, stats.best_auc)
+                    if val_stats.accuracy > stats_acc.best_accuracy:
+                        stats_acc.best_accuracy, stats_acc.best_auc, stats_acc.best_epoch = \
+                            val_stats.accuracy, val_stats.auc, e
+                        # reference quirk (cfl/models/cfl.py:1463-1470): step and file
+                        # carry the AUC-best `stats`, not `stats_acc`
+                        step = stats.best_epoch if stats.best_epoch is not None else e
+                        best_acc_saver.save(self, os.path.join(best_acc_dir, 'model'), global_step=step)
+                        save_best_stats(best_acc_path, stats.best_epoch, stats.best_accuracy, stats.best_auc)
+                else:
+                    logger.warning('epoch %d: current error = train: %f val: %f / auc = val: %f',
+                                   e, 1. - train_avg, 1. - val_stats.accuracy, val_stats.auc)
+            else:
+                logger.warning('epoch %d: avg error = train: %f val: %f', e, 1. - train_avg, 1. - val_avg)
+            if e % save_epochs == 0 and saver is not None:
+                saver.save(self, os.path.join(checkpoint_dir, 'model'), global_step=(e + 1) * nb_batch)
+
+
+def construct_model(is_double, disable_double, latent_shape, source_shape, input_shape, ae_shape,
+                    batch_size, data_norm, data_type, model_type, gan_type, num_components,
+                    latent_size, pos_weight, caffe_margin, gan, cgan, t_dim, dist_type, act_type,
+                    use_threshold, lr, beta1, beta2, z_dim, z_stddev, g_dim, g_lr, g_beta1,
+                    g_beta2, m_prj, m_enc, d_dim, d_lr, d_beta1, d_beta2, lambda_dra, lambda_gp,
+                    lambda_m, directed, data_directed, reg_const, data=None, run_tag=None,
+                    train_data_transformer=None, val_data_transformer=None, ae_transformer=None,
+                    data_normalizer=None, data_unnormalizer=None, ae_normalizer=None,
+                    ae_unnormalizer=None, latent_normalizer=None, enable_input_producer=False,
+                    seed=0, device=None):
+    """(model, aux) with the argument list of cfl/models/cfl.py:1514-1523."""
+    from argparse import Namespace
+    kw = dict(locals())
+    for k in ('data', 'enable_input_producer', 'Namespace'):
+        kw.pop(k)
+    model = CFL(**kw)
+    aux = None if data is None else Namespace(train=data.train, unlabeled=data.train, val=data.val)
+    return model, aux

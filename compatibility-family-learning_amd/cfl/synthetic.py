@@ -1,0 +1,53 @@
+"""Synthetic datasets in the reference's on-disk format.
+
+There is no network for the Amazon / Polyvore data, so tests, the CLI smoke runs and
+the benchmark use a generator that writes exactly what the Monomer split tool emits
+(experiments/monomer/monomer.patch:71-150): ``<split>/features.b`` (10-byte id +
+D little-endian f32), ``pairs_pos.txt`` / ``pairs_neg.txt``.  Positives are planted by
+a hidden K-prototype teacher (dst = proto_k(src) + noise) so AUC is non-trivial;
+negatives are uniform random pairs."""
+import os
+
+import numpy as np
+
+from .input_data import dump_array
+
+
+def make_split(path, n_items, D, n_pos, n_neg, rng, teacher, scale, noise=0.15, relation='also_viewed'):
+    os.makedirs(path, exist_ok=True)
+    k_protos, latent = teacher
+    half = n_items // 2
+    z = rng.randn(half, latent.shape[0]).astype(np.float32)
+    src = np.abs(z @ latent + 0.3 * rng.randn(half, D).astype(np.float32))
+    which = rng.randint(0, len(k_protos), size=half)
+    dst = np.empty_like(src)
+    for k, P in enumerate(k_protos):
+        m = which == k
+        dst[m] = np.abs((z[m] @ P) @ latent + noise * rng.randn(int(m.sum()), D).astype(np.float32))
+    feats = (np.concatenate([src, dst]) * scale).astype(np.float32)
+    ids = ['%010d' % i for i in range(feats.shape[0])]
+    with open(os.path.join(path, 'features.b'), 'wb') as f:
+        for i, a in enumerate(ids):
+            f.write(a.encode('ascii'))
+            dump_array(f, feats[i])
+    s = rng.randint(0, half, size=n_pos)
+    pos = np.stack([s, s + half], 1)
+    neg = np.stack([rng.randint(0, half, size=n_neg), half + rng.randint(0, half, size=n_neg)], 1)
+    neg = neg[neg[:, 0] + half != neg[:, 1]]
+    for name, pairs in (('pairs_pos.txt', pos), ('pairs_neg.txt', neg)):
+        with open(os.path.join(path, name), 'w') as f:
+            for a, b in pairs:
+                f.write('{} {} {}\n'.format(ids[a], relation, ids[b]))
+    return feats, pos, neg
+
+
+def make_dataset(root, D=4096, n_items=2000, n_pos=4000, n_neg=4000, k=3, latent=16, seed=633,
+                 scale=58.388599 / 4.5, splits=(('train', 1.0), ('val', 0.25), ('test', 0.25))):
+    """Write <root>/{train,val,test}; returns root."""
+    rng = np.random.RandomState(seed)
+    lat = (rng.randn(latent, D) / np.sqrt(latent)).astype(np.float32)
+    protos = [np.linalg.qr(rng.randn(latent, latent))[0].astype(np.float32) for _ in range(k)]
+    for name, frac in splits:
+        make_split(os.path.join(root, name), max(8, int(n_items * frac)) // 2 * 2, D,
+                   max(4, int(n_pos * frac)), max(4, int(n_neg * frac)), rng, (protos, lat), scale)
+    return root

@@ -1,0 +1,287 @@
+"""Flag parsers, evaluation / prediction loops and checkpoint helpers.
+
+Host-side mirror of the reference's cfl/utils.py for the pair-distance path:
+same function names, flag surface and file grammars; the
+TensorFlow session is replaced by the model objects of cfl.models (the ``sess``
+positional argument is kept for call-site compatibility and ignored).
+"""
+import argparse
+import logging
+import os
+import re
+from argparse import Namespace
+
+import numpy as np
+
+logger = logging.getLogger(__name__)
+
+
+def log_args(args):
+    for name, value in sorted(vars(args).items()):
+        logger.warning('%s = %r', name, value)
+
+
+def reduce_product(xs):
+    out = 1
+    for x in xs:
+        out *= x
+    return out
+
+
+class IncrementalAverage(object):
+    """Running mean (cfl/utils.py:500-507)."""
+
+    def __init__(self):
+        self.average = 0.0
+        self.count = 0
+
+    def add(self, value):
+        self.count += 1
+        self.average += (value - self.average) / self.count
+
+
+# ---------------------------------------------------------------------------
+# best-stats file: "<epoch>\t<accuracy>\t<auc>" without newline (App. B)
+# ---------------------------------------------------------------------------
+def load_best_stats(path):
+    stats = Namespace(best_epoch=None, best_accuracy=0.0, best_auc=0.0)
+    if os.path.exists(path):
+        with open(path) as infile:
+            tokens = infile.read().split('\t')
+        stats.best_epoch = int(tokens[0])
+        stats.best_accuracy = float(tokens[1])
+        if len(tokens) >= 3:
+            stats.best_auc = float(tokens[2])
+    return stats
+
+
+def save_best_stats(path, epoch, accuracy, auc):
+    with open(path, 'w') as outfile:
+        outfile.write('{}\t{}\t{}'.format(epoch, accuracy, auc))
+
+
+# ---------------------------------------------------------------------------
+# flag surface
+# ---------------------------------------------------------------------------
+def monomer_parser(data_name='monomer/Baby-also_viewed', data_root='parsed_data',
+                   checkpoint_root='checkpoints', log_root='logs', run_tag=None, seed=633,
+                   input_shape=(4096,), batch_size=100, normalize_value=1.0, num_components=2,
+                   latent_size=20, lr=0.001, beta1=0.9, beta2=0.999, reg_const=0.0):
+    """cfl/utils.py:510-553."""
+    p = argparse.ArgumentParser()
+    for flag, default in (('--data-name', data_name), ('--data-root', data_root),
+                          ('--checkpoint-root', checkpoint_root), ('--log-root', log_root),
+                          ('--run-tag', run_tag)):
+        p.add_argument(flag, default=default)
+    p.add_argument('--seed', type=int, default=seed)
+    p.add_argument('--normalize-value', type=float, default=normalize_value)
+    p.add_argument('--input-shape', nargs='+', type=int, default=input_shape, help='shape of input')
+    p.add_argument('--batch-size', type=int, default=batch_size)
+    p.add_argument('--num-components', type=int, default=num_components)
+    p.add_argument('--latent-size', type=int, default=latent_size)
+    for flag, default in (('--lr', lr), ('--beta1', beta1), ('--beta2', beta2),
+                          ('--reg-const', reg_const)):
+        p.add_argument(flag, type=float, default=default)
+    return p
+
+
+_CHOICES = ('sigmoid', 'tanh', 'relu', 'linear')
+
+
+def dist_parser(data_name='mnist', data_root='parsed_data', checkpoint_root='checkpoints',
+                log_root='logs', run_tag=None, seed=633, source_shape=None, input_shape=(28, 28, 1),
+                ae_shape=None, batch_size=100, data_scale=None, data_mean=None, data_norm=None,
+                latent_norm=None, data_type='sigmoid', model_type='conv', dist_type='pcd',
+                act_type=None, num_components=2, latent_size=20, pos_weight=None, lr=0.001,
+                beta1=0.9, beta2=0.999, z_dim=20, z_stddev=1., g_dim=64, g_lr=0.0002, g_beta1=0.5,
+                g_beta2=0.999, m_prj=None, m_enc=None, gan_type='conv', caffe_margin=None,
+                d_dim=64, t_dim=None, d_lr=0.0002, d_beta1=0.5, d_beta2=0.999, lambda_dra=0.5,
+                lambda_gp=None, lambda_m=0.0, reg_const=0.0):
+    """cfl/utils.py:84-224 -- the whole flag set is accepted; flags that belong to
+    the MrCGAN phase are parsed and carried, see cfl.models.cfl for what is built."""
+    p = argparse.ArgumentParser()
+    A = p.add_argument
+    # run
+    A('--data-name', default=data_name)
+    A('--data-root', default=data_root)
+    A('--checkpoint-root', default=checkpoint_root)
+    A('--log-root', default=log_root)
+    A('--run-tag', default=run_tag)
+    A('--seed', type=int, default=seed)
+    # data: (data * data_scale - mean) / normalize_value
+    A('--source-shape', nargs='+', type=int, default=source_shape, help='shape of input source')
+    A('--input-shape', nargs='+', type=int, default=input_shape, help='shape to crop for model')
+    A('--ae-shape', nargs='+', type=int, default=ae_shape, help='shape for autoencoder / generator')
+    A('--batch-size', type=int, default=batch_size)
+    A('--data-scale', type=float, default=data_scale)
+    A('--data-mean', nargs='+', type=float, default=data_mean)
+    A('--data-norm', nargs='+', type=float, default=data_norm)
+    A('--data-type', default=data_type, choices=_CHOICES, help='range of input data; enforce clip as well')
+    for flag in ('--data-mirror', '--data-random-crop', '--data-is-image', '--data-is-double',
+                 '--data-disable-double', '--raw-latent'):
+        A(flag, action='store_true')
+    A('--latent-shape', type=int, nargs='+')
+    A('--latent-norm', type=float, default=latent_norm)
+    # model
+    A('--pos-weight', type=float, default=pos_weight)
+    A('--model-type', default=model_type, choices=('linear', 'conv'))
+    A('--num-components', type=int, default=num_components)
+    A('--latent-size', type=int, default=latent_size)
+    for flag, default in (('--lr', lr), ('--beta1', beta1), ('--beta2', beta2)):
+        A(flag, type=float, default=default)
+    A('--z-dim', type=int, default=z_dim)
+    A('--z-stddev', type=float, default=z_stddev)
+    A('--g-dim', type=int, default=g_dim)
+    for flag, default in (('--g-lr', g_lr), ('--g-beta1', g_beta1), ('--g-beta2', g_beta2),
+                          ('--m-prj', m_prj), ('--m-enc', m_enc)):
+        A(flag, type=float, default=default)
+    A('--d-dim', type=int, default=d_dim)
+    for flag, default in (('--d-lr', d_lr), ('--d-beta1', d_beta1), ('--d-beta2', d_beta2),
+                          ('--lambda-dra', lambda_dra), ('--lambda-gp', lambda_gp),
+                          ('--lambda-m', lambda_m)):
+        A(flag, type=float, default=default)
+    A('--gan-type', default=gan_type)
+    A('--gan', action='store_true', help='enable GAN')
+    A('--cgan', action='store_true', help='enable CGAN')
+    A('--t-dim', type=int, default=t_dim)
+    A('--dist-type', help='distance type', choices=('monomer', 'pcd', 'siamese'), default=dist_type)
+    A('--act-type', help='act type', choices=_CHOICES, default=act_type)
+    A('--use-threshold', action='store_true')
+    A('--caffe-margin', type=float, default=caffe_margin, help='margin for CD loss for siamese training')
+    A('--directed', action='store_true')
+    A('--data-directed', action='store_true')
+    A('--reg-const', type=float, default=reg_const)
+    return p
+
+
+def dist_check_args(args):
+    """Validation rules of cfl/utils.py:45-81 (same assertions)."""
+    if args.data_is_double:
+        assert args.data_is_image
+        assert args.latent_shape is not None
+        args.latent_shape = tuple(args.latent_shape)
+    for name in ('input_shape', 'ae_shape', 'source_shape', 'data_mean', 'data_norm'):
+        if getattr(args, name):
+            setattr(args, name, tuple(getattr(args, name)))
+    if args.caffe_margin and args.caffe_margin > 0:
+        assert args.dist_type == 'siamese', 'only use cd loss in siamese'
+    if args.caffe_margin and args.caffe_margin < 0:
+        assert args.lambda_m > 0
+    if args.lambda_m > 0:
+        assert not args.caffe_margin
+    if args.dist_type != 'siamese':
+        assert args.use_threshold, 'must use entropy loss'
+    if not args.cgan:
+        assert not args.t_dim
+    log_args(args)
+
+
+# ---------------------------------------------------------------------------
+# evaluation / prediction over whole splits
+# ---------------------------------------------------------------------------
+def _scores(model, data, batch_size, negative):
+    """Concatenated scores [n] of all positive (or negative) pairs of a split, through
+    the model's scoring entry (``val_s_pos_predicts.outputs`` in the reference)."""
+    it = data.whole_neg_batches(batch_size) if negative else data.whole_pos_batches(batch_size)
+    out = [model.predict(src, dst).reshape(-1) for src, dst in it]
+    return np.concatenate(out) if out else np.zeros(0, np.float32)
+
+
+def dist_eval(sess, model, batch_size, data):
+    """cfl/utils.py:227-274: accuracy by the sign of the score, AUC, ROC."""
+    from sklearn.metrics import roc_auc_score, roc_curve
+    pos = _scores(model, data, batch_size, False)
+    neg = _scores(model, data, batch_size, True)
+    total = pos.shape[0] + neg.shape[0]
+    correct = int((pos > 0).sum()) + int((neg <= 0).sum())
+    y_true = [1] * pos.shape[0] + [0] * neg.shape[0]
+    y_score = np.concatenate([pos, neg])
+    return Namespace(error=(total - correct) / total, accuracy=correct / total,
+                     auc=roc_auc_score(y_true, y_score), roc=roc_curve(y_true, y_score))
+
+
+def dist_predict(sess, model, data, batch_size, predict_dir, output_name):
+    """cfl/utils.py:277-321: '<id1> match <id2> <score>' per pair, positives first;
+    the score is printed as ``str(np.float32)``."""
+    logger.warning('predict %s...', output_name)
+    os.makedirs(predict_dir, exist_ok=True)
+    with open(os.path.join(predict_dir, output_name), 'w') as outfile:
+        for negative, pairs in ((False, data.pairs_pos), (True, data.pairs_neg)):
+            scores = _scores(model, data, batch_size, negative).astype(np.float32)
+            for s, (i1, i2) in zip(scores, pairs):
+                outfile.write('{} match {} {}\n'.format(data.index_to_asins[i1],
+                                                        data.index_to_asins[i2], s))
+
+
+# ---------------------------------------------------------------------------
+# checkpoints: reference directory layout, own tensor container
+# ---------------------------------------------------------------------------
+class Saver(object):
+    """Stand-in for tf.train.Saver: ``<dir>/checkpoint`` state file in TensorFlow's
+    text grammar plus ``<prefix>-<step>.pt`` (torch.save of {TF variable name:
+    array in the reference layout, Adam slots, beta powers}); keeps the last 5."""
+
+    def __init__(self, max_to_keep=5):
+        self.max_to_keep = max_to_keep
+        self._kept = []
+
+    def save(self, model, save_path, global_step):
+        import torch
+        path = '{}-{}'.format(save_path, global_step)
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        torch.save(model.checkpoint_state(), path + '.pt')
+        self._kept = [p for p in self._kept if p != path] + [path]
+        while len(self._kept) > self.max_to_keep:
+            old = self._kept.pop(0)
+            if os.path.exists(old + '.pt'):
+                os.remove(old + '.pt')
+        names = [os.path.basename(p) for p in self._kept]
+        with open(os.path.join(os.path.dirname(path), 'checkpoint'), 'w') as f:
+            f.write('model_checkpoint_path: "{}"\n'.format(names[-1]))
+            for n in names:
+                f.write('all_model_checkpoint_paths: "{}"\n'.format(n))
+        return path
+
+    def restore(self, model, path):
+        import torch
+        model.load_checkpoint_state(torch.load(path + '.pt', weights_only=False))
+
+
+def latest_checkpoint(checkpoint_dir):
+    state = os.path.join(checkpoint_dir, 'checkpoint')
+    if not os.path.exists(state):
+        return None
+    with open(state) as f:
+        m = re.search(r'model_checkpoint_path:\s*"([^"]+)"', f.read())
+    if not m:
+        return None
+    path = os.path.join(checkpoint_dir, os.path.basename(m.group(1)))
+    return path if os.path.exists(path + '.pt') else None
+
+
+def _step_of(path):
+    return int(re.search(r'(\d+)', os.path.basename(path).split('-')[-1]).group(1)) + 1
+
+
+def load_model(model, checkpoint_dir, load_pre_weights=None):
+    """cfl/utils.py:465-497: restore the latest checkpoint of ``checkpoint_dir`` and
+    resume at (its step + 1); otherwise optionally warm-start the trainable
+    variables from ``<load_pre_weights>/best_model`` and take the start step from
+    that run's latest checkpoint.  Returns (saver, start_step)."""
+    saver = Saver()
+    path = latest_checkpoint(checkpoint_dir)
+    if path:
+        saver.restore(model, path)
+        logger.info('%s loaded', path)
+        return saver, _step_of(path)
+    start_step = 0
+    if load_pre_weights:
+        best = latest_checkpoint(os.path.join(load_pre_weights, 'best_model'))
+        last = latest_checkpoint(load_pre_weights)
+        if not (best and last):
+            raise Exception('must have best model! %s' % os.path.join(load_pre_weights, 'best_model'))
+        import torch
+        model.assign_trainable(torch.load(best + '.pt', weights_only=False), ignore_missing=True)
+        start_step = _step_of(last)
+        logger.info('%s loaded', best)
+    return saver, start_step

@@ -1,0 +1,147 @@
+"""GPU end-to-end: the drop-in command lines of experiments/monomer/{run,eval}.sh and
+experiments/dyadic/{run,eval}.sh on a synthetic dataset in the reference's on-disk
+format: train -> checkpoints -> predict files -> evaluate_total; resume; the model
+objects against the oracle on the batches the data pipeline produces."""
+import contextlib
+import io
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import cfl_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def dataset(tmp_path_factory):
+    from cfl.synthetic import make_dataset
+    root = tmp_path_factory.mktemp('data')
+    make_dataset(str(root / 'syn' / 'toy'), D=200, n_items=600, n_pos=3000, n_neg=3000, k=3,
+                 latent=8, seed=1, scale=4.0)
+    return str(root)
+
+
+def _common(dataset, tmp):
+    return ['--data-name', 'syn/toy', '--data-root', dataset, '--checkpoint-root', str(tmp / 'ck'),
+            '--log-root', str(tmp / 'logs')]
+
+
+def test_train_dist_predict_evaluate(dataset, tmp_path):
+    from cfl.bin import evaluate_total, predict_dist, train_dist
+    flags = _common(dataset, tmp_path) + ['--input-shape', '200', '--num-components', '3',
+                                          '--latent-size', '10', '--normalize-value', '16.0',
+                                          '--seed', '0', '--batch-size', '100', '--lr', '0.01']
+    train_dist.main(flags + ['--epochs', '3', '--reset'])
+    name = 'linear_dist_ls_10_nc_3_reg_0.0_norm_16.0'
+    ck = tmp_path / 'ck' / 'syn' / 'toy' / name
+    assert (ck / 'checkpoint').exists() and (ck / 'model-2.pt').exists()
+    best = ck / 'best_acc_model' / 'best_accuracy'
+    epoch, acc, auc = best.read_text().split('\t')
+    assert float(auc) > 0.8 and float(acc) > 0.6
+    state = torch.load(str(ck / 'model-2.pt'), weights_only=False)
+    v = state['variables']
+    assert v['Dist/Encoder/latent_outputs/fully_connected/weights'].shape == (200, 10)
+    assert v['Dist/Encoder/pcd_outputs/fully_connected/weights'].shape == (200, 30)
+    assert v['Dist/Encoder/pcd_outputs/fully_connected/biases'].shape == (30,)
+    assert 'Dist/Thresholder/threshold/threshold' in v and state['global_step'] == 90
+    # resume: epochs 3 -> 4 starts at epoch 3 and adds exactly one epoch of steps
+    train_dist.main(flags + ['--epochs', '4'])
+    assert torch.load(str(ck / 'model-3.pt'), weights_only=False)['global_step'] == 120
+
+    predict_dist.main(flags + ['--predict-root', str(tmp_path / 'pred')])
+    pdir = tmp_path / 'pred' / 'syn' / 'toy' / name
+    lines = (pdir / 'predict_acc.txt').read_text().splitlines()
+    a, rel, b, score = lines[0].split()
+    assert rel == 'match' and len(a) == len(b) == 10 and float(score) == float(np.float32(score))
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        evaluate_total.evaluate([os.path.join(dataset, 'syn/toy')], [str(pdir)], select_auc=False,
+                                name='m', avg=False, auc_model=False, only_larger=None)
+    cells = buf.getvalue().strip().split('\t')
+    assert len(cells) == 7 and cells[-1] == 'm'
+    assert float(cells[5].rstrip('%')) > 80.0            # test AUC
+
+
+def test_cfl_train_predict_linear(dataset, tmp_path):
+    from cfl.bin import predict, train
+    flags = _common(dataset, tmp_path) + [
+        '--model-type', 'linear', '--data-type', 'linear', '--data-norm', '16.0', '--input-shape', '200',
+        '--pos-weight', '0.5', '--data-switch', '--use-threshold', '--num-components', '3',
+        '--latent-size', '8', '--dist-type', 'monomer', '--lambda-m', '0.5', '--lr', '0.01', '--seed', '1']
+    train.main(flags + ['--epochs', '2', '--reset'])
+    name = 'cfl_monomer_linear_pw_0.5_linear_ls_8_nc_3_ut_norm_16.0_lm_0.5'
+    ck = tmp_path / 'ck' / 'syn' / 'toy' / name
+    assert (ck / 'best_model' / 'best_accuracy').exists()
+    assert (ck / 'best_acc_model' / 'best_accuracy_by_th').exists()
+    v = torch.load(str(ck / 'model-60.pt'), weights_only=False)['variables']
+    assert v['CFL/DistEncoder/outputs/fully_connected/V'].shape == (200, 8)
+    assert v['CFL/DistEncoder/prototype_outputs/fully_connected/g'].shape == (24,)
+    assert v['CFL/DistEncoder/monomer_outputs/fully_connected/V'].shape == (8, 3)
+    pflags = [f for f in flags if f not in ('--data-switch',)]
+    predict.start(pflags + ['--predict-root', str(tmp_path / 'pred')])
+    pdir = tmp_path / 'pred' / 'syn' / 'toy' / name
+    for f in ('predict.txt', 'predict_val.txt', 'predict_train.txt', 'predict_acc.txt'):
+        assert (pdir / f).exists()
+
+
+def test_unbuilt_parts_fail_loudly(dataset, tmp_path):
+    from cfl.bin import train
+    with pytest.raises(NotImplementedError, match='conv'):
+        train.main(_common(dataset, tmp_path) + ['--model-type', 'conv', '--use-threshold', '--input-shape', '200'])
+    with pytest.raises(NotImplementedError, match='MrCGAN'):
+        train.main(_common(dataset, tmp_path) + ['--model-type', 'linear', '--use-threshold', '--gan',
+                                                 '--input-shape', '200'])
+
+
+def test_model_matches_oracle_on_pipeline_batches(dataset):
+    """Dist (D=200 -> zero-padded to 256 on the device) vs the oracle, same seeded
+    SemiDataSet batches, 15 Adam steps; then dist_eval AUC parity."""
+    from cfl import input_data, ops, utils
+    from cfl.models.dist import construct_model
+    path = os.path.join(dataset, 'syn/toy')
+    data = input_data.load_data_sets(path, 200, seed=5)
+    data_o = input_data.load_data_sets(path, 200, seed=5)
+    model, _ = construct_model(input_shape=(200,), latent_size=6, num_components=2, lr=2e-3, beta1=0.9,
+                               beta2=0.999, batch_size=50, normalize_value=16.0, reg_const=1e-3,
+                               data_normalizer=ops.normalizer(16.0, 0.), data=data, seed=3)
+    p, _, thr = model.engine.named_variables()
+    cfg = O.EncoderCfg(D=200, L=6, K=2)
+    p64 = {k: (v[:200] if k.endswith('/W') else v).astype(np.float64) for k, v in p.items()}
+    tr = O.OracleTrainer(cfg, O.LossCfg(reg_const=1e-3), lr=2e-3, dtype=np.float64, params=p64)
+    for i in range(15):
+        b = data.train.next_batch(50)
+        bo = data_o.train.next_batch(50)
+        assert all(np.array_equal(x, y) for x, y in zip(b, bo))
+        model.train_step(b)
+        sc = tr.step(tuple(x.astype(np.float64) / 16.0 for x in bo))
+        got = model.scalars()['total']
+        assert abs(got - sc['total']) <= 1e-5 * max(1.0, abs(sc['total'])), (i, got, sc['total'])
+    ev = utils.dist_eval(None, model, 64, data.val)
+
+    class _OM(object):
+        def predict(self, s, d):
+            return tr.scores(s.astype(np.float64) / 16.0, d.astype(np.float64) / 16.0).reshape(-1, 1)
+    ev_o = utils.dist_eval(None, _OM(), 64, data_o.val)
+    assert abs(ev.auc - ev_o.auc) <= 1e-4 and abs(ev.accuracy - ev_o.accuracy) <= 2.0 / 700
+
+
+def test_resident_gather_equals_host_batches(dataset):
+    from cfl import input_data
+    path = os.path.join(dataset, 'syn/toy', 'train')
+    a = input_data.SemiDataSet(path, input_size=200, data_switch=True, seed=9)
+    b = input_data.SemiDataSet(path, input_size=200, data_switch=True, seed=9)
+    res = input_data.ResidentFeatures(a)
+    assert res.padded_size == 256
+    for _ in range(5):
+        dev = res.next_batch(37)
+        host = b.next_batch(37)
+        for x, y in zip(dev, host):
+            assert np.array_equal(x.cpu().numpy()[:, :200], y)
+            assert not x[:, 200:].any()
+    lo_hi = (10, 20)
+    sh = res.next_batch(40, lo_hi)
+    full = b.next_batch(40)
+    assert np.array_equal(sh[1].cpu().numpy()[:, :200], full[1][10:20])
