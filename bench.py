@@ -191,6 +191,15 @@ def main():
         torch.cuda.synchronize()
         H.profile_enable(False)
         prof = H.profile_read()
+        # dispatch latency contained in every event interval: event-time a 64-float Adam launch
+        tiny = [torch.zeros(64, device=device) for _ in range(4)]
+        H.profile_enable(True)
+        for _ in range(200):
+            H.adam_tf(tiny[0], tiny[1], tiny[2], tiny[3], 1e-3, 0.9, 0.999)
+        torch.cuda.synchronize()
+        H.profile_enable(False)
+        ov = H.profile_read().get('adam', (0.0, 1))
+        event_overhead_us = round(1e3 * ov[0] / max(ov[1], 1), 3)
         kern = {k: {'avg_us': round(1e3 * ms / n, 3), 'launches': int(n)} for k, (ms, n) in prof.items()}
         dom = max(('proj', 'grad'), key=lambda k: prof.get(k, (0, 1))[0])
         avg_s = prof[dom][0] / prof[dom][1] * 1e-3
@@ -217,7 +226,10 @@ def main():
                          'peak_tflops': FP32_MFMA_PEAK_TF,
                          'frac': round(alg_flops / avg_s / 1e12 / FP32_MFMA_PEAK_TF, 4)},
             'kernels': kern,
-            'timing': 'hipEvent pairs around every launch, separate pass of %d steps' % min(args.steps, 500),
+            'timing': 'hipEvent pairs around every launch on the launch stream, separate pass of %d steps; '
+                      'each interval includes the dispatch latency (see event_overhead_us), so rocprofv3 '
+                      'kernel durations are shorter by about that much' % min(args.steps, 500),
+            'event_overhead_us': event_overhead_us,
         }
     if rank == 0 and not args.no_cpu_baseline and world == 1:
         out['cpu_baseline'] = cpu_baseline(args, args.cpu_seconds)
