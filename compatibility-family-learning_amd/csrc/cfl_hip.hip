@@ -116,6 +116,31 @@ extern "C" int cfl_profile_read(double *ms_sum, int64_t *launches) {
 
 static inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 
+#ifdef CFL_STAMPS
+// Diagnostic build only (tools/stamp_probe.py): per-wave s_memtime stamps of the proj / grad
+// kernels, written to a buffer no other code reads.
+__device__ unsigned long long cfl_stamps[16384 * 8];
+#define STAMP(slot)                                                                          \
+    do {                                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+        unsigned long long _t = __builtin_readcyclecounter();                                \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+        if ((threadIdx.x & 63) == 0)                                                         \
+            cfl_stamps[(((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 + \
+                        (threadIdx.x >> 6)) * 8 + (slot)] = _t;                                \
+    } while (0)
+extern "C" int cfl_debug_read_stamps(unsigned long long *host, size_t n) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(cfl_stamps), n * sizeof(unsigned long long)) == hipSuccess ? 0 : -2;
+}
+extern "C" int cfl_debug_clear_stamps(void) {
+    void *p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(cfl_stamps)) != hipSuccess) return -2;
+    return hipMemset(p, 0, sizeof(unsigned long long) * 16384 * 8) == hipSuccess ? 0 : -2;
+}
+#else
+#define STAMP(slot) do {} while (0)
+#endif
+
 // ---------------------------------------------------------------------------
 // device helpers
 // ---------------------------------------------------------------------------
@@ -196,6 +221,7 @@ __device__ __forceinline__ void proj_body(const ProjJob &jb, const ProjArgs &a, 
     for (int i = 0; i < 4; ++i) xrow[i] = row_ptr(jb.x0, jb.x1, row0 + 8 * i + rr8, a.B, a.R, a.D) + 4 * ch8;
     const float *wfl = jb.wf + lane * 4;
     f32x4 *tile = lds + wave * 256;  // 32 rows x 8 chunks of 16 B = 4 KiB per wave
+    STAMP(0);
 
     for (int c = cbeg; c < cend; ++c) {
         const int g0 = c * 8;
@@ -252,6 +278,7 @@ __device__ __forceinline__ void proj_body(const ProjJob &jb, const ProjArgs &a, 
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                 for (int gg = 0; gg < 2; ++gg) af[mt][gg] = tile[(mt * 16 + r16) * 8 + ((4 * gg + q4) ^ (r16 & 7))];
+            if (qq == 0) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); STAMP(1); }
 #ifndef ABL_PROJ_NOMFMA
 #pragma unroll
             for (int gg = 0; gg < 2; ++gg)
@@ -271,11 +298,13 @@ __device__ __forceinline__ void proj_body(const ProjJob &jb, const ProjArgs &a, 
 #if !defined(ABL_PROJ_NOB)
             if (qq < 2 && full) loadB(qq + 2, bq[qq & 1]);
 #endif
+            STAMP(2 + qq);
         }
     }
 
     // cross-wave sum: lds[wave][tile][lane]
     __syncthreads();
+    STAMP(6);
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -293,6 +322,7 @@ __device__ __forceinline__ void proj_body(const ProjJob &jb, const ProjArgs &a, 
 #pragma unroll
         for (int e = 0; e < 4; ++e) dst[(size_t)e * jb.npad] = sum[e];
     }
+    STAMP(7);
 }
 
 extern "C" __global__ __launch_bounds__(256) void cfl_proj_kernel(ProjArgs a) {
@@ -1589,11 +1619,12 @@ static int make_plan(const CflShape *s, int64_t rows, int groups, bool train, Pl
     pl->R = (int)(rows * groups);
     const int njobs = (hs->npad / 16 + 3) / 4 + (hd->npad / 16 + 3) / 4;
     if (njobs > CFL_MAX_JOBS) return set_err(CFL_E_UNSUPPORTED, "too many column chunks");
-    // grad row split: aim at >= 512 workgroups, rows per workgroup >= 64
+    // grad row split: aim at >= 256 workgroups (one per CU; measured: fewer, fatter
+    // workgroups beat 512 because every extra row range costs a full-size gradient slab)
     int P = 1;
     if (train) {
         const int dtiles = s->D / 64;
-        int want = (512 + dtiles * njobs - 1) / (dtiles * njobs);
+        int want = (256 + dtiles * njobs - 1) / (dtiles * njobs);
         P = pow2_floor(want < 1 ? 1 : want);
         if (P > 8) P = 8;
         while (P > 1 && pl->R / P < 64) P /= 2;
