@@ -1236,6 +1236,183 @@ __global__ __launch_bounds__(64) void cfl_mid_kernel(MidArgs a) {
     }
 }
 
+
+// ---------------------------------------------------------------------------
+// mid, wave-per-row form for PCD with at most 64 padded columns per side (the
+// Monomer / Polyvore / dyadic pcd shapes): one wave owns one pair row, lane c owns
+// source column c = k*L + l (and, for c < L, destination column c).  The per-wave
+// instruction count -- which IS the latency of this one-wave-per-row kernel -- drops
+// ~4x against the 16-lanes-per-row form: slice sums are one coalesced 256-byte load
+// per slice, every per-column quantity is one VALU op, and the few cross-column sums
+// go through a 1 KiB wave-private LDS scratch.  Same arithmetic, same outputs.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cfl_mid_row_kernel(MidArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if ((int)blockIdx.x >= a.nrb) {
+        if (wave == 0) mid_reg_block(a, blockIdx.x - a.nrb);
+        return;
+    }
+    float *W = (float *)smem + wave * 384;  // Pl[64] Vl[64] Rl[64] T[64] S[64] Q[64]
+    float *Pl = W, *Vl = W + 64, *Rl = W + 128, *T = W + 192, *S = W + 256, *Q = W + 320;
+    const int r = blockIdx.x * 4 + wave;
+    const bool valid = r < a.R;
+    const int L = a.L, K = a.K, RG = a.Rpad >> 4;
+    const MidSide &ss = a.side[0], &sd = a.side[1];
+    const int c = lane, ns = ss.n;
+    const bool cs = c < ns, cd = c < L;
+    const int k = cs ? c / L : 0, l = cs ? c - k * L : 0;
+
+    // ---- slice sums + head epilogue (one column per lane) -------------------------
+    // all slice loads of both sides are independent and in flight together (summed in
+    // slice order afterwards)
+    float ts[16], td[16];
+    const float *srcs = ss.ypart + (size_t)r * ss.npad + (c < ss.npad ? c : 0);
+    const float *srcd = sd.ypart + (size_t)r * sd.npad + (c < sd.npad ? c : 0);
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        ts[s] = s < a.S ? srcs[(size_t)s * ss.sstride] : 0.f;
+        td[s] = s < a.S ? srcd[(size_t)s * sd.sstride] : 0.f;
+    }
+    float ys = 0.f, yd = 0.f;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) { ys += ts[s]; yd += td[s]; }
+    float scs = 1.f, scd = 1.f, bs = 0.f, bd = 0.f;
+    if (cs) {
+        if (a.weight_norm) scs = ss.g[c] * __builtin_amdgcn_rsqf(ss.n2[c]);
+        if (ss.b) bs = ss.b[c];
+    }
+    if (cd) {
+        if (a.weight_norm) scd = sd.g[c] * __builtin_amdgcn_rsqf(sd.n2[c]);
+        if (sd.b) bd = sd.b[c];
+    }
+    const float thr_raw = *a.thr;
+    const float xvs = (valid && cs) ? ys * a.in_mul : 0.f;
+    const float xvd = (valid && cd) ? yd * a.in_mul : 0.f;
+    const float P = (valid && cs) ? act_fn(xvs * scs + bs, a.act) : 0.f;
+    const float v = (valid && cd) ? act_fn(xvd * scd + bd, a.act) : 0.f;
+    Pl[c] = P;
+    Vl[c] = v;
+    const float vl = Vl[l];           // destination coordinate l of this source column
+    const float diff = cs ? vl - P : 0.f;
+
+    // ---- distance ----------------------------------------------------------------
+    float d, sk = 1.f, rl = 0.f, dlk = 0.f;
+    if (K > 1) {
+        T[c] = diff * diff;
+        float e = 0.f;
+        if (c < K)
+            for (int i = 0; i < L; ++i) e += T[c * L + i];
+        S[c] = -e;                    // logits (lanes >= K: unused)
+        float mx = -INFINITY;
+        for (int i = 0; i < K; ++i) mx = fmaxf(mx, S[i]);
+        float den = 0.f;
+        for (int i = 0; i < K; ++i) den += fexp(S[i] - mx);
+        const float inv = frcp(den);
+        const float sme = c < K ? fexp(-e - mx) * inv : 0.f;   // s_c for lanes < K
+        Q[c] = sme;
+        sk = Q[k];                    // softmax weight of this column's prototype
+        float m = 0.f;
+        if (cd)
+            for (int i = 0; i < K; ++i) m = fmaf(Q[i], Pl[i * L + c], m);
+        rl = cd ? v - m : 0.f;
+        Rl[c] = rl;
+        d = wave_sum(rl * rl);
+        T[c] = cs ? Rl[l] * P : 0.f;
+        float q = 0.f;
+        if (c < K)
+            for (int i = 0; i < L; ++i) q += T[c * L + i];
+        q *= -2.f;
+        S[c] = q;                     // q_k (lanes < K)
+        float qbar = 0.f;
+        for (int i = 0; i < K; ++i) qbar = fmaf(Q[i], S[i], qbar);
+        const float dl_me = c < K ? sme * (q - qbar) : 0.f;
+        T[c] = dl_me;                 // dl_k (lanes < K)
+        dlk = T[k];
+    } else {
+        d = wave_sum(diff * diff);
+    }
+
+    // ---- threshold, loss, dL/dd ------------------------------------------------------
+    const float thr = fmaxf(thr_raw, CFL_THR_FLOOR);
+    const float o = thr - d;
+    if (!a.train) {
+        if (valid && lane == 0) {
+            a.scores[r] = o;
+            if (a.dists) a.dists[r] = d;
+        }
+        return;
+    }
+    const bool is_pos = r < a.B;
+    const float invB = 1.f / (float)a.B;
+    const float pw = a.pos_weight != 0.f ? a.pos_weight : 1.f;
+    const float eo = fexp(-fabsf(o));
+    const float sp = __logf(1.f + eo);
+    const float bce = fmaxf(o, 0.f) - (is_pos ? o : 0.f) + sp;
+    const float sig = (o >= 0.f ? 1.f : eo) * frcp(1.f + eo);
+    const float dlo = is_pos ? (sig - 1.f) * pw * invB : sig * invB;
+    float dd = 0.f;
+    if (a.use_threshold) dd -= dlo;
+    float hinge = 0.f;
+    if (a.caffe_margin != 0.f) {
+        if (is_pos) dd += 0.5f * pw * invB;
+        else {
+            hinge = fmaxf(0.f, a.caffe_margin - d);
+            if (d < a.caffe_margin) dd -= 0.5f * invB;
+        }
+    } else if (a.lambda_m != 0.f) {
+        if (is_pos) dd += pw * a.lambda_m * invB;
+    }
+    if (!valid) dd = 0.f;
+    if (blockIdx.x == 0 && threadIdx.x == 0) a.thr_copy[0] = thr;
+    if (lane < 16) {
+        const bool pos = valid && is_pos, neg = valid && !is_pos;
+        float qv = 0.f;
+        switch (lane) {
+            case P_BCE_POS: qv = pos ? bce : 0.f; break;
+            case P_BCE_NEG: qv = neg ? bce : 0.f; break;
+            case P_OK_POS: qv = (pos && o > 0.f) ? 1.f : 0.f; break;
+            case P_OK_NEG: qv = (neg && o <= 0.f) ? 1.f : 0.f; break;
+            case P_D_POS: qv = pos ? d : 0.f; break;
+            case P_D_NEG: qv = neg ? d : 0.f; break;
+            case P_O_POS: qv = pos ? o : 0.f; break;
+            case P_O_NEG: qv = neg ? o : 0.f; break;
+            case P_DTHR: qv = valid ? dlo : 0.f; break;
+            case P_HINGE_NEG: qv = neg ? hinge : 0.f; break;
+            case P_SQRT_POS: qv = pos ? fsqrt(d + 1e-7f) : 0.f; break;
+            case P_SQRT_NEG: qv = neg ? fsqrt(d + 1e-7f) : 0.f; break;
+            default: break;
+        }
+        a.rowqf[frag_off(r, lane, RG)] = qv;
+    }
+
+    // ---- backward: one source column and (lanes < L) one destination column per lane --
+    float dP, dv;
+    if (K > 1) {
+        const float rls = Rl[l];
+        dP = -2.f * sk * rls + 2.f * dlk * diff;
+        dv = 2.f * rl;
+        if (cd)
+            for (int i = 0; i < K; ++i) dv = fmaf(-2.f * T[i], v - Pl[i * L + c], dv);
+    } else {
+        dP = -2.f * diff;
+        dv = 2.f * (v - Pl[c]);
+    }
+    if (c < ss.npad) {
+        const float dy = cs ? dP * dd * act_grad(P, a.act) : 0.f;
+        const size_t o_ = frag_off(r, c, RG);
+        ss.dyf[o_] = dy;
+        if (ss.cwf) ss.cwf[o_] = dy * xvs;
+    }
+    if (c < sd.npad) {
+        const float dy = cd ? dv * dd * act_grad(v, a.act) : 0.f;
+        const size_t o_ = frag_off(r, c, RG);
+        sd.dyf[o_] = dy;
+        if (sd.cwf) sd.cwf[o_] = dy * xvd;
+    }
+}
+
 // ---------------------------------------------------------------------------
 // colnorm (weight-norm): n2[c] = sum_d V[d][c]^2   (cfl/layers.py:81) + gain snapshot
 // ---------------------------------------------------------------------------
@@ -1935,7 +2112,11 @@ static int run_pairs(const CflShape *s, const CflNorm *norm, const CflLossCfg *l
         ProfScope ps(st, CFL_K_MID);
         const dim3 mgrid(ma.nrb + nreg_blocks), mblk(64);
         const bool generic_only = debug_env("CFL_DEBUG_MID_GENERIC") > 0;
-        if (!generic_only && s->K <= 4 && pl.Lq <= 2)
+        const bool row_ok = s->dist_type == CFL_DIST_PCD && side[0].head->npad <= 64 &&
+                            side[1].head->npad <= 64 && debug_env("CFL_DEBUG_MID_NOROW") == 0;
+        if (!generic_only && row_ok)
+            hipLaunchKernelGGL(cfl_mid_row_kernel, dim3(ma.nrb + nreg_blocks), dim3(256), 4 * 384 * sizeof(float), st, ma);
+        else if (!generic_only && s->K <= 4 && pl.Lq <= 2)
             hipLaunchKernelGGL((cfl_mid_kernel<4, 2>), mgrid, mblk, pl.mid_lds, st, ma);
         else if (!generic_only && s->K <= 8 && pl.Lq <= 2)
             hipLaunchKernelGGL((cfl_mid_kernel<8, 2>), mgrid, mblk, pl.mid_lds, st, ma);
