@@ -114,6 +114,14 @@ STEP_CASES = [
      dict(use_threshold=False, caffe_margin=100.0, pos_weight=0.0625), False),
     ('cfl', 'siamese', 512, 32, 1, 'sigmoid', 48, 1.0, dict(), False),
     ('cfl', 'pcd', 512, 20, 4, 'relu', 64, 1.0, dict(use_threshold=False, lambda_m=0.3), False),
+    # BASELINE.json full-size configs 4 and 3
+    ('cfl', 'pcd', 2048, 20, 5, None, 1024, 1.0, dict(pos_weight=0.25), False),
+    ('cfl', 'siamese', 1024, 256, 1, None, 512, 31.9098,
+     dict(use_threshold=False, caffe_margin=100.0, pos_weight=0.0625), False),
+    # edge shapes: single row, odd batch, minimum D, many prototypes (40 column tiles)
+    ('dist', 'pcd', 64, 3, 2, None, 1, 1.0, dict(), False),
+    ('cfl', 'monomer', 64, 5, 3, None, 3, 1.0, dict(reg_const=1e-3), False),
+    ('cfl', 'pcd', 256, 40, 16, None, 70, 1.0, dict(), False),
 ]
 
 
@@ -156,6 +164,48 @@ def test_step_fwd_bwd(style, dist, D, L, K, act, B, nv, lkw, directed):
             scale = max(np.abs(r).max(), 1e-6)
             err = np.abs(got[k] - r).max()
             assert err <= 2e-4 * scale, (k, err, scale)
+
+
+def test_full_size_properties():
+    """Size-independent properties at the headline size (B=512, D=4096, K=3, L=20):
+    (i) the loss is invariant under a permutation of the rows inside the positive and the
+    negative group and the gradient changes only by summation order; (ii) the gradient of the
+    batch equals the mean of the gradients of its two half-batches (the identity the
+    data-parallel all-reduce relies on); (iii) scoring is row-wise: scores of a batch equal
+    the scores of its rows taken one chunk at a time."""
+    rng = np.random.RandomState(2026)
+    B, D, K, L, nv = 512, 4096, 3, 20, 58.388599
+    cfg = O.EncoderCfg(D=D, L=L, K=K)
+    p = _mk(cfg, rng)
+    sh = _shape(cfg)
+    theta = H.pack_theta(sh, p, None, 0.8, 'cuda')
+    norm, loss = H.make_norm(1.0 / nv), H.make_loss()
+    batch = [torch.from_numpy(_inputs(rng, B, D, nv / 4)).cuda() for _ in range(4)]
+
+    def run(b):
+        n = b[0].shape[0]
+        g = torch.empty_like(theta)
+        sc = torch.zeros(H.S_COUNT, device='cuda')
+        ws = torch.empty(H.workspace_bytes(sh, n, 2) // 4, dtype=torch.float32, device='cuda')
+        H.pair_step_fwd_bwd(sh, norm, loss, b, theta, g, sc, ws)
+        return g, sc.cpu().numpy()
+    g0, s0 = run(batch)
+    pp, pn = torch.randperm(B, device='cuda'), torch.randperm(B, device='cuda')
+    g1, s1 = run([batch[0][pp].contiguous(), batch[1][pp].contiguous(),
+                  batch[2][pn].contiguous(), batch[3][pn].contiguous()])
+    assert abs(s0[0] - s1[0]) <= 2e-6 * max(1.0, abs(s0[0]))
+    gmax = float(g0.abs().max())
+    assert float((g0 - g1).abs().max()) <= 1e-5 * gmax
+    h = B // 2
+    ga, _ = run([x[:h].contiguous() for x in batch])
+    gb, _ = run([x[h:].contiguous() for x in batch])
+    assert float((0.5 * (ga + gb) - g0).abs().max()) <= 1e-5 * gmax
+    ws = torch.empty(H.workspace_bytes(sh, B, 1) // 4, dtype=torch.float32, device='cuda')
+    full = H.pair_scores(sh, norm, batch[0], batch[1], theta, ws)
+    parts = torch.cat([H.pair_scores(sh, norm, batch[0][i:i + 100].contiguous(),
+                                     batch[1][i:i + 100].contiguous(), theta, ws)
+                       for i in range(0, B, 100)])
+    assert torch.equal(full, parts)          # bit-exact: no cross-row arithmetic
 
 
 def test_adam_tf_flat():
