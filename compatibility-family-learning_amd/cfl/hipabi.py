@@ -55,9 +55,16 @@ class CflLossCfg(C.Structure):
                 ('reg_const', C.c_float)]
 
 
+class CflConv(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ('B', 'H', 'W', 'Ci', 'Co', 'KH', 'KW', 'stride', 'act')]
+
+
+CONV_ACTS = {None: 0, 'linear': 0, 'lrelu': 1, 'relu': 2}
+
 EXPORTS = ('cfl_version', 'cfl_last_error', 'cfl_layout', 'cfl_workspace_bytes',
            'cfl_pair_scores', 'cfl_pair_step_fwd_bwd', 'cfl_pair_train_step', 'cfl_adam_tf',
-           'cfl_gather_rows', 'cfl_profile_enable', 'cfl_profile_read')
+           'cfl_gather_rows', 'cfl_profile_enable', 'cfl_profile_read', 'cfl_pair_input_grad',
+           'cfl_conv_workspace_bytes', 'cfl_conv2d_wn_fwd', 'cfl_conv2d_wn_bwd')
 
 KERNEL_NAMES = ('colnorm', 'proj', 'mid', 'grad', 'finalize', 'adam', 'gather')
 K_COUNT = 8
@@ -107,6 +114,16 @@ def lib():
     L.cfl_gather_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64,
                                   C.c_void_p, C.c_void_p]
     L.cfl_gather_rows.restype = C.c_int
+    L.cfl_pair_input_grad.argtypes = [C.POINTER(CflShape), C.POINTER(CflNorm), C.c_int64, C.c_void_p,
+                                      C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.cfl_pair_input_grad.restype = C.c_int
+    L.cfl_conv_workspace_bytes.argtypes = [C.POINTER(CflConv)]
+    L.cfl_conv_workspace_bytes.restype = C.c_size_t
+    L.cfl_conv2d_wn_fwd.argtypes = [C.POINTER(CflConv)] + [C.c_void_p] * 6 + [C.c_size_t, C.c_void_p]
+    L.cfl_conv2d_wn_fwd.restype = C.c_int
+    L.cfl_conv2d_wn_bwd.argtypes = ([C.POINTER(CflConv)] + [C.c_void_p] * 5 + [C.c_float] +
+                                    [C.c_void_p] * 5 + [C.c_size_t, C.c_void_p])
+    L.cfl_conv2d_wn_bwd.restype = C.c_int
     L.cfl_profile_enable.argtypes = [C.c_int]
     L.cfl_profile_read.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     if L.cfl_version() != 1:
@@ -200,6 +217,60 @@ def adam_tf(theta, m, v, grad, lr_t, beta1, beta2, eps=1e-8, grad_scale=1.0):
     _check(lib().cfl_adam_tf(_dev(theta), _dev(m), _dev(v), _dev(grad), theta.numel(),
                              float(lr_t), float(beta1), float(beta2), float(eps),
                              float(grad_scale), _stream()))
+
+
+def pair_input_grad(shape, norm, B, theta, workspace, dx_src=None, dx_dst=None):
+    """dL/d(input rows) of the last cfl_pair_step_fwd_bwd on this workspace: two [2B, D]
+    tensors (source side, destination side; positive rows first)."""
+    D = shape.D
+    if dx_src is None:
+        dx_src = torch.empty(2 * B, D, dtype=torch.float32, device=theta.device)
+    if dx_dst is None:
+        dx_dst = torch.empty(2 * B, D, dtype=torch.float32, device=theta.device)
+    _check(lib().cfl_pair_input_grad(C.byref(shape), C.byref(norm), B, _dev(theta), workspace.data_ptr(),
+                                     workspace.numel() * workspace.element_size(), _dev(dx_src),
+                                     _dev(dx_dst), _stream()))
+    return dx_src, dx_dst
+
+
+def make_conv(B, H, W, Ci, Co, KH, KW, stride, act=None):
+    return CflConv(B, H, W, Ci, Co, KH, KW, stride, CONV_ACTS[act])
+
+
+def conv_out_hw(conv):
+    return -(-conv.H // conv.stride), -(-conv.W // conv.stride)
+
+
+def conv_workspace(conv, device):
+    n = lib().cfl_conv_workspace_bytes(C.byref(conv))
+    if n == 0:
+        raise CflHipError('cfl_conv_workspace_bytes: ' + lib().cfl_last_error().decode())
+    return torch.empty((n + 3) // 4, dtype=torch.float32, device=device)
+
+
+def conv2d_wn_fwd(conv, x, V, g, b, ws, y=None):
+    """x [B,H,W,Ci] NHWC, V [KH,KW,Ci,Co] HWIO -> y [B,OH,OW,Co]."""
+    oh, ow = conv_out_hw(conv)
+    if y is None:
+        y = torch.empty(conv.B, oh, ow, conv.Co, dtype=torch.float32, device=x.device)
+    _check(lib().cfl_conv2d_wn_fwd(C.byref(conv), _dev(x), _dev(V), _dev(g) if g is not None else None,
+                                   _dev(b) if b is not None else None, _dev(y), ws.data_ptr(),
+                                   ws.numel() * 4, _stream()))
+    return y
+
+
+def conv2d_wn_bwd(conv, x, V, g, y, dy, ws, reg_const=0.0, need_dx=True, need_db=True):
+    dx = torch.empty_like(x) if need_dx else None
+    dV = torch.empty_like(V)
+    dg = torch.empty_like(g) if g is not None else None
+    db = torch.empty(conv.Co, dtype=torch.float32, device=x.device) if need_db else None
+    _check(lib().cfl_conv2d_wn_bwd(C.byref(conv), _dev(x), _dev(V), _dev(g) if g is not None else None,
+                                   _dev(y), _dev(dy), float(reg_const),
+                                   _dev(dx) if dx is not None else None, _dev(dV),
+                                   _dev(dg) if dg is not None else None,
+                                   _dev(db) if db is not None else None, ws.data_ptr(), ws.numel() * 4,
+                                   _stream()))
+    return dx, dV, dg, db
 
 
 def profile_enable(on):

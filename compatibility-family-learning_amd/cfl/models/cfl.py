@@ -5,9 +5,11 @@ distance, learned-threshold BCE with pos_weight, lambda_m pull term or the
 caffe-margin contrastive hinge, L2 regulariser, Adam (+ the separate threshold
 Adam when --use-threshold is off) -- all inside the fused HIP pair kernels.
 
-Not built in this round (raise NotImplementedError): the conv
-encoder (``--model-type conv``), image / double datasets and the MrCGAN
-post-epoch phase (``--gan``).
+``--model-type conv`` adds the ConvPCD trunk (cfl.models.conv_encoder, weight-normalised
+5x5 stride-2 convolutions on the GPU) in front of the same heads.
+
+Not built in this round (raise NotImplementedError): image / double
+datasets and the MrCGAN post-epoch phase (``--gan``).
 """
 import logging
 import os
@@ -45,9 +47,10 @@ class CFL(PairModel):
         self.input_shape = tuple(input_shape)
         self.ae_shape = tuple(ae_shape) if ae_shape else self.input_shape
         self.source_shape = tuple(source_shape) if source_shape else self.input_shape
-        if model_type != 'linear':
-            raise NotImplementedError('--model-type conv (ConvPCD, cfl/models/blocks.py:530-590) '
-                                      'is not built yet; the HIP pair path covers --model-type linear')
+        if model_type not in ('linear', 'conv'):
+            raise ValueError(model_type)
+        if model_type == 'conv' and directed:
+            raise NotImplementedError('directed conv encoders are not built yet')
         if is_double:
             raise NotImplementedError('image + latent ("double") datasets are not built yet')
         if gan:
@@ -56,8 +59,19 @@ class CFL(PairModel):
         norm = data_normalizer.to_cfl_norm() if data_normalizer is not None else H.make_norm()
         loss = H.make_loss(use_threshold=use_threshold, pos_weight=pos_weight,
                            caffe_margin=caffe_margin, lambda_m=lambda_m, reg_const=reg_const)
+        self.trunk = None
+        head_inputs = reduce_product(self.input_shape)
+        if model_type == 'conv':
+            # ConvPCD: the normaliser applies to the pixels; the heads see the flattened trunk
+            from .conv_encoder import ConvTrunk
+            import torch
+            dev = torch.device(device if device is not None else 'cuda')
+            shape3 = self.input_shape if len(self.input_shape) == 3 else self.input_shape + (1,)
+            self.trunk = ConvTrunk(shape3, 4 * batch_size, norm, reg_const, lr, beta1, beta2, 1e-8,
+                                   np.random.RandomState(seed + 1), dev)
+            head_inputs, norm = self.trunk.feature_size, H.make_norm()
         self._setup_engine(
-            reduce_product(self.input_shape), latent_size, num_components, dist_type,
+            head_inputs, latent_size, num_components, dist_type,
             weight_norm=True, has_bias=dist_type.startswith('pcd'), act_type=act_type,
             directed=directed, norm=norm, loss=loss, lr=lr, beta1=beta1, beta2=beta2,
             batch_size=batch_size, seed=seed, device=device)
@@ -65,6 +79,75 @@ class CFL(PairModel):
 
     def init(self, sess=None):
         pass
+
+    # -- ConvPCD: trunk + heads ---------------------------------------------------
+    def _pixels(self, x):
+        import torch
+        t = x if isinstance(x, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(x, np.float32))
+        return self.trunk.normalize(t.to(self.device, torch.float32))
+
+    def train_step(self, batch):
+        if self.trunk is None:
+            return PairModel.train_step(self, batch)
+        import torch
+        eng = self.engine
+        B = batch[0].shape[0]
+        # rows ordered [pos_src, neg_src, pos_dst, neg_dst]: each side's 2B rows contiguous
+        x = torch.cat([self._pixels(batch[0]), self._pixels(batch[2]),
+                       self._pixels(batch[1]), self._pixels(batch[3])])
+        F = self.trunk.forward(x)
+        rows = (F[0:B], F[2 * B:3 * B], F[B:2 * B], F[3 * B:4 * B])
+        eng.fwd_bwd(rows)
+        dF = torch.empty_like(F)
+        ws = eng._workspace(B, 2)
+        H.pair_input_grad(eng.shape, eng.norm, B, eng.theta, ws, dF[0:2 * B], dF[2 * B:4 * B])
+        self.trunk.backward(dF)
+        lr_t = eng.lr_t()
+        scale = 1.0
+        if eng.world_size > 1:
+            from ..engine import reduce_gradients
+            scale = reduce_gradients(eng.grad)
+            reduce_gradients(self.trunk.grad)
+        self.trunk.apply_adam(lr_t, scale)
+        eng.apply_adam(scale)
+
+    def predict(self, src, dst):
+        if self.trunk is None:
+            return PairModel.predict(self, src, dst)
+        import torch
+        n = src.shape[0]
+        F = self.trunk.forward(torch.cat([self._pixels(src), self._pixels(dst)]))
+        return self.engine.scores(F[:n], F[n:]).cpu().numpy().reshape(-1, 1)
+
+    def batch_accuracy(self, batch):
+        if self.trunk is None:
+            return PairModel.batch_accuracy(self, batch)
+        sp, sn = self.predict(batch[0], batch[1]), self.predict(batch[2], batch[3])
+        return 0.5 * float((sp > 0).mean() + (sn <= 0).mean())
+
+    def scalars(self):
+        s = PairModel.scalars(self)
+        if self.trunk is not None and self.reg_const:
+            extra = self.trunk.reg_loss()     # conv V regulariser (cfl/models/blocks.py:585)
+            s['reg'] += extra
+            s['total'] += extra
+        return s
+
+    def checkpoint_state(self):
+        st = PairModel.checkpoint_state(self)
+        if self.trunk is not None:
+            pre = 'CFL/' + self.ENCODER_SCOPES[0] + '/'
+            for key, base in (('variables', None), ('adam_m', self.trunk.m), ('adam_v', self.trunk.v)):
+                st[key].update({pre + k: v for k, v in self.trunk.named(base).items()})
+        return st
+
+    def load_checkpoint_state(self, state):
+        PairModel.load_checkpoint_state(self, state)
+        if self.trunk is not None:
+            pre = 'CFL/' + self.ENCODER_SCOPES[0] + '/'
+            for key, base in (('variables', None), ('adam_m', self.trunk.m), ('adam_v', self.trunk.v)):
+                self.trunk.load_named({k[len(pre):]: v for k, v in state[key].items()
+                                       if k.startswith(pre + 'conv')}, base)
 
     def get_name(self, no_gan=False):
         """Byte-for-byte cfl/models/cfl.py:368-412 (names checkpoint / predict dirs)."""

@@ -1,0 +1,241 @@
+// cfl_conv.hip -- weight-normalised convolution building blocks (NHWC activations, HWIO
+// filters, TensorFlow 'SAME' padding) of the cfl conv encoder / MrCGAN stacks:
+//   forward   y = act( conv(x, g * V / ||V||) + b )                 cfl/layers.py:100-187
+//   backward  dx, dV, dg, db (dV includes the weight-norm correction and the L2 term)
+// First-correct form: implicit GEMM on fp32 MFMA through the generic gathered-operand GEMM
+// of gemm_gather.h (scalar im2col gathers).  See DESIGN.md section 6 for what remains.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+
+#include "../../include/cfl_hip.h"
+#include "gemm_gather.h"
+
+extern int cfl_set_err(int code, const char *fmt, ...);
+
+struct ConvGeom {
+    int B, H, W, Ci, Co, KH, KW, S, OH, OW, pt, pl, act;
+};
+
+static inline void same_pad(int n, int k, int s, int *out, int *lo) {
+    *out = (n + s - 1) / s;
+    int total = (*out - 1) * s + k - n;
+    if (total < 0) total = 0;
+    *lo = total / 2;
+}
+
+static int make_geom(const CflConv *c, ConvGeom *g) {
+    if (!c) return cfl_set_err(CFL_E_SHAPE, "conv shape is NULL");
+    if (c->B <= 0 || c->H <= 0 || c->W <= 0 || c->Ci <= 0 || c->Co <= 0 || c->KH <= 0 || c->KW <= 0 ||
+        c->stride <= 0 || c->act < 0 || c->act > 2)
+        return cfl_set_err(CFL_E_SHAPE, "bad conv shape");
+    g->B = c->B; g->H = c->H; g->W = c->W; g->Ci = c->Ci; g->Co = c->Co; g->KH = c->KH; g->KW = c->KW;
+    g->S = c->stride; g->act = c->act;
+    same_pad(c->H, c->KH, c->stride, &g->OH, &g->pt);
+    same_pad(c->W, c->KW, c->stride, &g->OW, &g->pl);
+    return CFL_OK;
+}
+
+__device__ __forceinline__ float act_apply(float y, int act) {
+    if (act == 1) return y > 0.f ? y : 0.2f * y;   // lrelu(x) = relu(x) - 0.2 relu(-x), cfl/ops.py:10-12
+    if (act == 2) return fmaxf(y, 0.f);
+    return y;
+}
+// d act / d pre-activation, from the POST-activation value (both are monotone through 0)
+__device__ __forceinline__ float act_slope(float y, int act) {
+    if (act == 1) return y > 0.f ? 1.f : 0.2f;
+    if (act == 2) return y > 0.f ? 1.f : 0.f;
+    return 1.f;
+}
+
+// ---- per-output-channel weight-norm scale: g / sqrt(max(sum V^2, 1e-12)) ----------------
+__global__ __launch_bounds__(256) void conv_scale_kernel(const float *V, const float *g, int rows, int Co,
+                                                         float *scale, float *n2out) {
+    const int co = blockIdx.x;
+    float acc = 0.f;
+    for (int r = threadIdx.x; r < rows; r += 256) {
+        const float v = V[(size_t)r * Co + co];
+        acc = fmaf(v, v, acc);
+    }
+    __shared__ float red[256];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float n2 = fmaxf(red[0], 1e-12f);
+        n2out[co] = n2;
+        scale[co] = (g ? g[co] : 1.f) * rsqrtf(n2);
+    }
+}
+
+// ---- operand functors -------------------------------------------------------------------
+struct Im2colX {   // A(m = (b,oh,ow), k = (kh,kw,ci)) = x[b, oh*S+kh-pt, ow*S+kw-pl, ci]
+    const float *x; ConvGeom g;
+    __device__ float operator()(int m, int k) const {
+        const int ow = m % g.OW, t = m / g.OW, oh = t % g.OH, b = t / g.OH;
+        const int ci = k % g.Ci, t2 = k / g.Ci, kw = t2 % g.KW, kh = t2 / g.KW;
+        const int ih = oh * g.S + kh - g.pt, iw = ow * g.S + kw - g.pl;
+        if (ih < 0 || ih >= g.H || iw < 0 || iw >= g.W) return 0.f;
+        return x[(((size_t)b * g.H + ih) * g.W + iw) * g.Ci + ci];
+    }
+};
+struct FilterKN {  // B(k, n = co) = V[k][co]
+    const float *V; int Co;
+    __device__ float operator()(int k, int n) const { return V[(size_t)k * Co + n]; }
+};
+struct StoreFwd {
+    float *y; const float *scale, *bias; int Co, act;
+    __device__ void operator()(int m, int n, float v, int) const {
+        y[(size_t)m * Co + n] = act_apply(v * scale[n] + (bias ? bias[n] : 0.f), act);
+    }
+};
+struct DyGather {  // A(m = (b,ih,iw), k = (kh,kw,co)) = dy_pre[b,(ih+pt-kh)/S,(iw+pl-kw)/S,co] * scale[co]
+    const float *dy, *y, *scale; ConvGeom g;
+    __device__ float operator()(int m, int k) const {
+        const int iw = m % g.W, t = m / g.W, ih = t % g.H, b = t / g.H;
+        const int co = k % g.Co, t2 = k / g.Co, kw = t2 % g.KW, kh = t2 / g.KW;
+        const int nh = ih + g.pt - kh, nw = iw + g.pl - kw;
+        if (nh < 0 || nw < 0 || nh % g.S || nw % g.S) return 0.f;
+        const int oh = nh / g.S, ow = nw / g.S;
+        if (oh >= g.OH || ow >= g.OW) return 0.f;
+        const size_t o = (((size_t)b * g.OH + oh) * g.OW + ow) * g.Co + co;
+        return dy[o] * act_slope(y[o], g.act) * scale[co];
+    }
+};
+struct FilterT {   // B(k = (kh,kw,co), n = ci) = V[kh,kw,ci,co]
+    const float *V; ConvGeom g;
+    __device__ float operator()(int k, int n) const {
+        const int co = k % g.Co, t = k / g.Co;  // t = kh*KW + kw
+        return V[((size_t)t * g.Ci + n) * g.Co + co];
+    }
+};
+struct StorePlain {
+    float *out; int ld;
+    __device__ void operator()(int m, int n, float v, int) const { out[(size_t)m * ld + n] = v; }
+};
+struct Im2colXT {  // A(m = (kh,kw,ci), k = (b,oh,ow)) : the same gather with the roles swapped
+    Im2colX f;
+    __device__ float operator()(int m, int k) const { return f(k, m); }
+};
+struct DyPre {     // B(k = (b,oh,ow), n = co) = dy * act'(y)
+    const float *dy, *y; int Co, act;
+    __device__ float operator()(int k, int n) const {
+        const size_t o = (size_t)k * Co + n;
+        return dy[o] * act_slope(y[o], act);
+    }
+};
+struct StoreSlab {
+    float *slab; size_t stride; int ld;
+    __device__ void operator()(int m, int n, float v, int z) const { slab[z * stride + (size_t)m * ld + n] = v; }
+};
+
+// ---- finalize: dV = s*dW - (s/n^2)(dW.V) V + reg*V ; dg = (dW.V)/n ; db = sum dy_pre --------
+__global__ __launch_bounds__(256) void conv_wfinal_kernel(const float *slab, int splits, size_t stride,
+                                                          const float *V, const float *scale,
+                                                          const float *n2, int rows, int Co, float reg,
+                                                          float *dV, float *dg) {
+    // one block per output channel: c = sum_rows dW * V
+    const int co = blockIdx.x;
+    float acc = 0.f;
+    for (int r = threadIdx.x; r < rows; r += 256) {
+        const size_t o = (size_t)r * Co + co;
+        float dw = 0.f;
+        for (int z = 0; z < splits; ++z) dw += slab[z * stride + o];
+        dV[o] = dw;   // parked; rewritten below
+        acc = fmaf(dw, V[o], acc);
+    }
+    __shared__ float red[256];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    const float c = red[0], s = scale[co], nn = n2[co];
+    if (threadIdx.x == 0 && dg) dg[co] = c * rsqrtf(nn);
+    for (int r = threadIdx.x; r < rows; r += 256) {
+        const size_t o = (size_t)r * Co + co;
+        dV[o] = s * dV[o] - (s / nn) * c * V[o] + reg * V[o];
+    }
+}
+
+__global__ __launch_bounds__(256) void conv_bgrad_kernel(const float *dy, const float *y, int rows, int Co,
+                                                         int act, float *db) {
+    const int co = blockIdx.x;
+    float acc = 0.f;
+    for (int r = threadIdx.x; r < rows; r += 256) {
+        const size_t o = (size_t)r * Co + co;
+        acc += dy[o] * act_slope(y[o], act);
+    }
+    __shared__ float red[256];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) db[co] = red[0];
+}
+
+// ---- C ABI --------------------------------------------------------------------------------
+static int wgrad_klen(const ConvGeom &g) {
+    const long long K = (long long)g.B * g.OH * g.OW;
+    int s = (int)(K / 1024);
+    if (s > 32) s = 32;
+    return gg_klen(K, s);
+}
+static int wgrad_splits(const ConvGeom &g) { return gg_splits((long long)g.B * g.OH * g.OW, wgrad_klen(g)); }
+
+extern "C" size_t cfl_conv_workspace_bytes(const CflConv *c) {
+    ConvGeom g;
+    if (make_geom(c, &g)) return 0;
+    const size_t rows = (size_t)g.KH * g.KW * g.Ci;
+    return (2 * (size_t)g.Co + 64 + (size_t)wgrad_splits(g) * rows * g.Co) * sizeof(float);
+}
+
+extern "C" int cfl_conv2d_wn_fwd(const CflConv *c, const float *x, const float *V, const float *gain,
+                                 const float *bias, float *y, void *workspace, size_t workspace_bytes,
+                                 cfl_stream_t stream) {
+    ConvGeom g;
+    int rc = make_geom(c, &g);
+    if (rc) return rc;
+    if (!x || !V || !y || !workspace) return cfl_set_err(CFL_E_SHAPE, "NULL pointer");
+    if (workspace_bytes < cfl_conv_workspace_bytes(c)) return cfl_set_err(CFL_E_WORKSPACE, "conv workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    float *scale = (float *)workspace, *n2 = scale + g.Co;
+    const int rows = g.KH * g.KW * g.Ci;
+    hipLaunchKernelGGL(conv_scale_kernel, dim3(g.Co), dim3(256), 0, st, V, gain, rows, g.Co, scale, n2);
+    gemm_gather(g.B * g.OH * g.OW, g.Co, rows, gg_klen(rows, 1), Im2colX{x, g}, FilterKN{V, g.Co},
+                StoreFwd{y, scale, bias, g.Co, g.act}, st);
+    return hipGetLastError() == hipSuccess ? CFL_OK : cfl_set_err(CFL_E_HIP, "conv fwd launch failed");
+}
+
+extern "C" int cfl_conv2d_wn_bwd(const CflConv *c, const float *x, const float *V, const float *gain,
+                                 const float *y, const float *dy, float reg_const, float *dx, float *dV,
+                                 float *dg, float *db, void *workspace, size_t workspace_bytes,
+                                 cfl_stream_t stream) {
+    ConvGeom g;
+    int rc = make_geom(c, &g);
+    if (rc) return rc;
+    if (!x || !V || !y || !dy || !dV || !workspace) return cfl_set_err(CFL_E_SHAPE, "NULL pointer");
+    if (workspace_bytes < cfl_conv_workspace_bytes(c)) return cfl_set_err(CFL_E_WORKSPACE, "conv workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    float *scale = (float *)workspace, *n2 = scale + g.Co;
+    float *slab = (float *)workspace + 2 * (size_t)g.Co + 64;
+    const int rows = g.KH * g.KW * g.Ci;
+    const int npix = g.B * g.OH * g.OW;
+    hipLaunchKernelGGL(conv_scale_kernel, dim3(g.Co), dim3(256), 0, st, V, gain, rows, g.Co, scale, n2);
+    if (dx)
+        gemm_gather(g.B * g.H * g.W, g.Ci, g.KH * g.KW * g.Co, gg_klen(g.KH * g.KW * g.Co, 1), DyGather{dy, y, scale, g}, FilterT{V, g},
+                    StorePlain{dx, g.Ci}, st);
+    const int splits = wgrad_splits(g);
+    gemm_gather(rows, g.Co, npix, wgrad_klen(g), Im2colXT{Im2colX{x, g}}, DyPre{dy, y, g.Co, g.act},
+                StoreSlab{slab, (size_t)rows * g.Co, g.Co}, st);
+    hipLaunchKernelGGL(conv_wfinal_kernel, dim3(g.Co), dim3(256), 0, st, slab, splits, (size_t)rows * g.Co, V,
+                       scale, n2, rows, g.Co, reg_const, dV, gain ? dg : nullptr);
+    if (db) hipLaunchKernelGGL(conv_bgrad_kernel, dim3(g.Co), dim3(256), 0, st, dy, y, npix, g.Co, g.act, db);
+    return hipGetLastError() == hipSuccess ? CFL_OK : cfl_set_err(CFL_E_HIP, "conv bwd launch failed");
+}

@@ -44,6 +44,7 @@
 #include <vector>
 
 #include "../../include/cfl_hip.h"
+#include "gemm_gather.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -57,6 +58,15 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 static thread_local char g_err[512] = "";
 
 static int set_err(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+// shared with cfl_conv.hip
+int cfl_set_err(int code, const char *fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
@@ -2231,6 +2241,75 @@ extern "C" int cfl_pair_train_step(const CflShape *shape, const CflNorm *norm,
     AdamFuse af = {theta, m, v, lr_t, beta1, beta2, eps};
     return run_pairs(shape, norm, loss, x4, 2, B, theta, grad, scalars, nullptr, nullptr, workspace,
                      workspace_bytes, (hipStream_t)stream, &af);
+}
+
+// ---- input gradient of the two heads (needed when the pair rows are not leaves: ConvPCD) --
+struct DyfScaled {   // A(m = row, k = col) = dy[row][col] * sc[col]   (dYf is fragment-major)
+    const float *dyf, *g, *n2; int RG, n; float in_mul;
+    __device__ float operator()(int m, int k) const {
+        if (k >= n) return 0.f;
+        const size_t o = ((size_t)(k >> 4) * RG + (m >> 4)) * 256 + (((m >> 2) & 3) * 16 + (k & 15)) * 4 + (m & 3);
+        float sc = in_mul;
+        if (g) sc *= g[k] * rsqrtf(n2[k]);
+        return dyf[o] * sc;
+    }
+};
+struct WfKN {        // B(k = col, n = d) = W[d][col]   (Wf is fragment-major)
+    const float *wf; int G;
+    __device__ float operator()(int k, int n) const {
+        return wf[((size_t)(k >> 4) * G + (n >> 4)) * 256 + (((n >> 2) & 3) * 16 + (k & 15)) * 4 + (n & 3)];
+    }
+};
+struct StoreRowMajor {
+    float *out; int ld;
+    __device__ void operator()(int m, int n, float v, int) const { out[(size_t)m * ld + n] = v; }
+};
+
+extern "C" int cfl_pair_input_grad(const CflShape *s, const CflNorm *norm, int64_t B, const float *theta,
+                                   const void *workspace, size_t workspace_bytes, float *dx_src,
+                                   float *dx_dst, cfl_stream_t stream) {
+    Plan pl;
+    int rc = make_plan(s, B, 2, true, &pl);
+    if (rc) return rc;
+    if (!theta || !workspace || !dx_src || !dx_dst) return set_err(CFL_E_SHAPE, "NULL pointer");
+    if (workspace_bytes < pl.total_floats * sizeof(float)) return set_err(CFL_E_WORKSPACE, "workspace too small");
+    float in_mul;
+    NormDev nd = make_norm(norm, &in_mul);
+    if (nd.elementwise) return set_err(CFL_E_UNSUPPORTED, "input gradient with an element-wise normaliser");
+    const float *ws = (const float *)workspace;
+    const CflHead *hs, *hd;
+    side_heads(s, pl.lay, &hs, &hd);
+    // gain snapshot / squared norms were left in the workspace by the step (same order as
+    // launch_colnorm: encoder 0 outputs, proto, mono, then encoder 1)
+    int n2_off[2][3], off = 0;
+    const int nenc = s->directed ? 2 : 1;
+    for (int e = 0; e < 2; ++e) {
+        const CflHead *hh[3] = {&pl.lay.enc[e].outputs, &pl.lay.enc[e].proto, &pl.lay.enc[e].mono};
+        for (int k = 0; k < 3; ++k) {
+            if (e >= nenc) { n2_off[e][k] = n2_off[0][k]; continue; }
+            n2_off[e][k] = -1;
+            if (hh[k]->w < 0) continue;
+            n2_off[e][k] = off;
+            off += hh[k]->npad;
+        }
+    }
+    const int which[2] = {s->dist_type == CFL_DIST_PCD ? 1 : 0, s->dist_type == CFL_DIST_MONOMER ? 1 : 0};
+    const CflHead *heads[2] = {hs, hd};
+    float *outs[2] = {dx_src, dx_dst};
+    const int G = s->D / 16, RG = pl.Rpad / 16;
+    for (int sd = 0; sd < 2; ++sd) {
+        const float *gp = nullptr, *n2p = nullptr;
+        if (s->weight_norm) {
+            const int o = n2_off[sd == 0 ? 0 : 1][which[sd]];
+            n2p = ws + pl.n2 + o;
+            gp = ws + pl.n2 + 6 * 1024 + o;
+        }
+        gemm_gather(pl.R, s->D, heads[sd]->npad, gg_klen(heads[sd]->npad, 1),
+                    DyfScaled{ws + pl.dyf[sd], gp, n2p, RG, heads[sd]->n, in_mul},
+                    WfKN{theta + heads[sd]->w, G}, StoreRowMajor{outs[sd], s->D}, (hipStream_t)stream);
+    }
+    HIP_TRY(hipGetLastError());
+    return CFL_OK;
 }
 
 extern "C" int cfl_adam_tf(float *theta, float *m, float *v, const float *grad, int64_t n,

@@ -206,6 +206,34 @@ int cfl_adam_tf(float *theta, float *m, float *v, const float *grad, int64_t n,
 int cfl_gather_rows(const float *table, const int64_t *idx, int64_t n, int64_t D,
                     float *out, cfl_stream_t stream);
 
+/* Gradient of the step's loss with respect to the (normalised) input rows, for callers
+ * whose pair rows are not leaves (the conv encoder ConvPCD, cfl/models/blocks.py:530-590).
+ * Must follow cfl_pair_step_fwd_bwd / cfl_pair_train_step on the SAME shape, B and
+ * workspace (it reads dL/dY and the weight-norm scales the step left there; with the
+ * fused train step theta is already updated, so use cfl_pair_step_fwd_bwd before it).
+ *   dx_src, dx_dst : dev [2B, D] row-major: rows [0,B) = positive pairs, [B,2B) = negative */
+int cfl_pair_input_grad(const CflShape *shape, const CflNorm *norm, int64_t B, const float *theta,
+                        const void *workspace, size_t workspace_bytes, float *dx_src,
+                        float *dx_dst, cfl_stream_t stream);
+
+/* Weight-normalised 2-D convolution, NHWC activations, HWIO filters, TensorFlow 'SAME'
+ * padding: y = act(conv(x, g * V / sqrt(max(sum_{h,w,i} V^2, 1e-12)), stride) + b).
+ * Replaces conv2d_weight_norm, cfl/layers.py:100-187 (act: 0 none, 1 lrelu of
+ * cfl/ops.py:10-12, 2 relu).  The backward returns d/dx (nullable), d/dV (with the
+ * weight-norm correction and + reg_const * V), d/dg, d/db (nullable) given the layer's
+ * POST-activation output y and dL/dy.                                            */
+typedef struct {
+    int32_t B, H, W, Ci, Co, KH, KW, stride, act;
+} CflConv;
+size_t cfl_conv_workspace_bytes(const CflConv *conv);
+int cfl_conv2d_wn_fwd(const CflConv *conv, const float *x, const float *V, const float *g,
+                      const float *b, float *y, void *workspace, size_t workspace_bytes,
+                      cfl_stream_t stream);
+int cfl_conv2d_wn_bwd(const CflConv *conv, const float *x, const float *V, const float *g,
+                      const float *y, const float *dy, float reg_const, float *dx, float *dV,
+                      float *dg, float *db, void *workspace, size_t workspace_bytes,
+                      cfl_stream_t stream);
+
 /* Optional per-kernel timing (bench.py's roofline object).  While enabled,
  * every kernel the library launches is bracketed by two HIP events recorded on
  * the caller's stream.  cfl_profile_read() synchronises those events, adds the

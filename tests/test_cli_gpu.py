@@ -89,8 +89,6 @@ def test_cfl_train_predict_linear(dataset, tmp_path):
 
 def test_unbuilt_parts_fail_loudly(dataset, tmp_path):
     from cfl.bin import train
-    with pytest.raises(NotImplementedError, match='conv'):
-        train.main(_common(dataset, tmp_path) + ['--model-type', 'conv', '--use-threshold', '--input-shape', '200'])
     with pytest.raises(NotImplementedError, match='MrCGAN'):
         train.main(_common(dataset, tmp_path) + ['--model-type', 'linear', '--use-threshold', '--gan',
                                                  '--input-shape', '200'])
@@ -145,3 +143,26 @@ def test_resident_gather_equals_host_batches(dataset):
     sh = res.next_batch(40, lo_hi)
     full = b.next_batch(40)
     assert np.array_equal(sh[1].cpu().numpy()[:, :200], full[1][10:20])
+
+
+def test_cfl_train_conv_model(tmp_path):
+    """--model-type conv end to end on an MNIST-shaped synthetic pair set (8x8x1 images so
+    the trunk is one 5x5 stride-2 layer), the command line of experiments/fashion_30/run.sh."""
+    from cfl.bin import predict, train
+    from cfl.synthetic import make_dataset
+    root = tmp_path / 'data'
+    make_dataset(str(root / 'syn' / 'img'), D=64, n_items=400, n_pos=1500, n_neg=1500, k=2, latent=6,
+                 seed=3, scale=0.25)
+    flags = ['--data-name', 'syn/img', '--data-root', str(root), '--checkpoint-root', str(tmp_path / 'ck'),
+             '--log-root', str(tmp_path / 'logs'), '--model-type', 'conv', '--data-type', 'sigmoid',
+             '--dist-type', 'pcd', '--use-threshold', '--reg-const', '5e-4', '--num-components', '2',
+             '--latent-size', '8', '--input-shape', '8', '8', '1', '--lr', '0.005', '--seed', '10']
+    train.main(flags + ['--epochs', '3', '--batch-size', '100', '--reset'])
+    name = 'cfl_pcd_conv_sigmoid_ls_8_nc_2_ut_reg_0.0005'
+    ck = tmp_path / 'ck' / 'syn' / 'img' / name
+    auc = float((ck / 'best_model' / 'best_accuracy').read_text().split('\t')[2])
+    assert auc > 0.7
+    v = torch.load(str(ck / 'model-45.pt'), weights_only=False)['variables']
+    assert v['CFL/DistEncoder/conv1/Conv/V'].shape == (5, 5, 1, 64)
+    predict.start(flags + ['--predict-root', str(tmp_path / 'pred')])
+    assert (tmp_path / 'pred' / 'syn' / 'img' / name / 'predict_acc.txt').exists()

@@ -1,0 +1,190 @@
+"""GPU parity of the convolution building blocks and of the head input-gradient against
+the torch-CPU float64 oracle (oracle/conv_oracle.py)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import cfl_oracle as O
+from oracle import conv_oracle as CO
+
+pytestmark = pytest.mark.gpu
+
+H = None
+
+
+@pytest.fixture(scope='module', autouse=True)
+def _hip():
+    global H
+    from cfl import hipabi
+    hipabi.lib()
+    H = hipabi
+    yield
+
+
+CONV_CASES = [
+    # B, H, W, Ci, Co, K, stride, act, bias
+    (6, 28, 28, 1, 64, 5, 2, 'lrelu', True),       # ConvPCD conv1 (Fashion-MNIST)
+    (6, 14, 14, 64, 128, 5, 2, 'lrelu', True),     # ConvPCD conv2
+    (3, 7, 9, 5, 20, 3, 1, None, False),           # odd sizes, residual-block style 3x3 s1
+    (2, 8, 8, 6, 70, 4, 2, 'relu', True),          # 4x4 s2 (SRDiscriminator), even kernel -> asymmetric SAME pad
+    (2, 5, 5, 3, 12, 3, 2, 'lrelu', True),         # odd input with stride 2
+    (48, 14, 14, 64, 128, 5, 2, 'lrelu', True),    # training-size conv2: split-K weight gradient
+    (48, 28, 28, 1, 64, 5, 2, 'lrelu', True),      # training-size conv1
+]
+
+
+@pytest.mark.parametrize('B,Hh,Ww,Ci,Co,K,S,act,bias', CONV_CASES)
+def test_conv2d_wn_fwd_bwd(B, Hh, Ww, Ci, Co, K, S, act, bias):
+    rng = np.random.RandomState(11)
+    x = rng.randn(B, Hh, Ww, Ci)
+    V = rng.randn(K, K, Ci, Co) * 0.2
+    g = 1.0 + 0.3 * rng.randn(Co)
+    b = 0.1 * rng.randn(Co) if bias else None
+    reg = 1e-3
+    tx, tV, tg = (torch.tensor(a, requires_grad=True) for a in (x, V, g))
+    tb = torch.tensor(b, requires_grad=True) if bias else None
+    y = CO.conv2d_weight_norm(tx, tV, tg, tb, S, act)
+    dy = torch.tensor(rng.randn(*y.shape))
+    ((y * dy).sum() + 0.5 * reg * (tV * tV).sum()).backward()
+
+    conv = H.make_conv(B, Hh, Ww, Ci, Co, K, K, S, act)
+    ws = H.conv_workspace(conv, 'cuda')
+    f = lambda a: torch.tensor(a, dtype=torch.float32, device='cuda').contiguous()
+    dx_, dV_, dg_, db_ = None, None, None, None
+    gy = H.conv2d_wn_fwd(conv, f(x), f(V), f(g), f(b) if bias else None, ws)
+    assert gy.shape == y.shape
+    scale = max(1.0, float(y.abs().max()))
+    assert float((gy.cpu().double() - y.detach()).abs().max()) <= 1e-5 * scale
+    dx_, dV_, dg_, db_ = H.conv2d_wn_bwd(conv, f(x), f(V), f(g), gy, f(dy.numpy()), ws, reg_const=reg,
+                                         need_db=bias)
+    for got, ref, name in ((dx_, tx.grad, 'dx'), (dV_, tV.grad, 'dV'), (dg_, tg.grad, 'dg'),
+                           (db_, tb.grad if bias else None, 'db')):
+        if ref is None:
+            continue
+        err = float((got.cpu().double() - ref).abs().max())
+        assert err <= 2e-5 * max(1e-2, float(ref.abs().max())), (name, err, float(ref.abs().max()))
+
+
+def test_same_padding_and_subpixel_kats():
+    """TF 'SAME' for even kernels pads the extra pixel on the bottom/right; the oracle's
+    depth_to_space is block-major."""
+    assert CO.same_pads(64, 4, 2) == (32, 1, 1)
+    assert CO.same_pads(28, 5, 2) == (14, 1, 2)
+    assert CO.same_pads(7, 3, 1) == (7, 1, 1)
+    x = torch.arange(2 * 2 * 8, dtype=torch.float64).reshape(1, 2, 2, 8)
+    y = CO.conv2d_subpixel(x, 2)
+    for h in range(2):
+        for w in range(2):
+            for i in range(2):
+                for j in range(2):
+                    for c in range(2):
+                        assert y[0, 2 * h + i, 2 * w + j, c] == x[0, h, w, (i * 2 + j) * 2 + c]
+
+
+@pytest.mark.parametrize('style,dist,K,L', [('cfl', 'pcd', 3, 10), ('cfl', 'monomer', 2, 12),
+                                            ('cfl', 'siamese', 1, 24), ('dist', 'pcd', 2, 6)])
+def test_pair_input_grad(style, dist, K, L):
+    """dL/dx of the pair step (needed by ConvPCD) against the oracle's fc_head_bwd dx."""
+    rng = np.random.RandomState(8)
+    D, B = 128, 20
+    cfg = O.EncoderCfg(D=D, L=L, K=K, dist_type=dist, style=style)
+    lcfg = O.LossCfg(pos_weight=0.5, lambda_m=0.25)
+    p = O.init_encoder_params(cfg, rng, np.float64)
+    for k in p:
+        p[k] = p[k] + 0.05 * rng.randn(*p[k].shape)
+    batch = tuple(rng.randn(B, D) for _ in range(4))
+    thr = 0.7
+    tb = [torch.tensor(b, requires_grad=True) for b in batch]
+    tp = {k: torch.tensor(v) for k, v in p.items()}
+    import tests.test_oracle as TO
+    total, _, _ = TO._torch_forward(cfg, lcfg, tp, torch.tensor(thr), tuple(tb))
+    total.backward()
+    sh = H.make_shape(D, L, K, dist, cfg.weight_norm, cfg.has_bias)
+    theta = H.pack_theta(sh, {k: v.astype(np.float32) for k, v in p.items()}, None, thr, 'cuda')
+    grad = torch.empty_like(theta)
+    scal = torch.zeros(H.S_COUNT, device='cuda')
+    ws = torch.empty(H.workspace_bytes(sh, B, 2) // 4, dtype=torch.float32, device='cuda')
+    norm = H.make_norm()
+    dev = [torch.tensor(b, dtype=torch.float32, device='cuda') for b in batch]
+    H.pair_step_fwd_bwd(sh, norm, H.make_loss(pos_weight=0.5, lambda_m=0.25), dev, theta, grad, scal, ws)
+    dsrc, ddst = H.pair_input_grad(sh, norm, B, theta, ws)
+    ref_src = torch.cat([tb[0].grad, tb[2].grad])
+    ref_dst = torch.cat([tb[1].grad, tb[3].grad])
+    for got, ref in ((dsrc, ref_src), (ddst, ref_dst)):
+        err = float((got.cpu().double() - ref).abs().max())
+        assert err <= 2e-5 * max(1e-3, float(ref.abs().max())), err
+
+
+def test_convpcd_model_matches_oracle():
+    """BASELINE config 0 shape (Fashion-MNIST 28x28x1, conv encoder, PCD K=1, latent 30,
+    sigmoid data, reg 5e-4): CFL --model-type conv against the torch-autograd float64 oracle
+    (conv trunk of oracle/conv_oracle.py + heads/distance/loss of tests/test_oracle.py +
+    TF-Adam of oracle/cfl_oracle.py), 6 training steps on identical batches."""
+    import tests.test_oracle as TO
+    from cfl import ops
+    from cfl.models.cfl import construct_model
+    rng = np.random.RandomState(4)
+    B, shape, L, K, reg = 12, (28, 28, 1), 30, 1, 5e-4
+    dn = ops.dist_normalizer(shape, None, None, None, None, None, 'sigmoid')
+    kw = dict(is_double=False, disable_double=False, latent_shape=None, source_shape=None, input_shape=shape,
+              ae_shape=None, batch_size=B, data_norm=None, data_type='sigmoid', model_type='conv',
+              gan_type='conv', num_components=K, latent_size=L, pos_weight=None, caffe_margin=None, gan=False,
+              cgan=False, t_dim=None, dist_type='pcd', act_type=None, use_threshold=True, lr=1e-3, beta1=0.9,
+              beta2=0.999, z_dim=20, z_stddev=1., g_dim=64, g_lr=2e-4, g_beta1=.5, g_beta2=.999, m_prj=None,
+              m_enc=None, d_dim=64, d_lr=2e-4, d_beta1=.5, d_beta2=.999, lambda_dra=.5, lambda_gp=None,
+              lambda_m=0.0, directed=False, data_directed=False, reg_const=reg, data_normalizer=dn[0],
+              data_unnormalizer=dn[1], seed=2)
+    model, _ = construct_model(**kw)
+    assert model.get_name() == 'cfl_pcd_conv_sigmoid_ls_30_nc_1_ut_reg_0.0005'
+    assert model.trunk.feature_size == 6272
+
+    # oracle parameters = the model's initial variables
+    model.engine.theta[model.engine.layout.thr] = 0.3   # off the max(thr, 1e-6) tie: torch.maximum
+    hp, _, thr = model.engine.named_variables()         # splits the gradient there, TF does not
+    cfg = O.EncoderCfg(D=6272, L=L, K=K, dist_type='pcd', style='cfl')
+    params = {'head/' + k: v.astype(np.float64) for k, v in hp.items()}
+    for k, v in model.trunk.named().items():
+        params['conv/' + k] = v.astype(np.float64)
+    params['thr'] = np.float64(thr)
+    adam = O.AdamState(1e-3)
+    lcfg = O.LossCfg(reg_const=reg)
+
+    def oracle_loss(p, batch):
+        tp = {k: torch.tensor(v, requires_grad=True) for k, v in p.items()}
+        cp = {k.split('/', 1)[1].replace('/Conv/', '/').replace('biases', 'b'): v
+              for k, v in tp.items() if k.startswith('conv/')}
+        feats = [CO.convpcd_features(torch.clamp(torch.tensor(b, dtype=torch.float64), 0., 1.), shape, cp)
+                 for b in batch]
+        head = {k.split('/', 1)[1]: v for k, v in tp.items() if k.startswith('head/')}
+        total, _, _ = TO._torch_forward(cfg, lcfg, head, tp['thr'], tuple(feats))
+        total = total + sum(0.5 * reg * (v * v).sum() for k, v in cp.items() if k.endswith('/V'))
+        total.backward()
+        return float(total), {k: (v.grad.numpy() if v.grad is not None else np.zeros_like(p[k]))
+                              for k, v in tp.items()}
+
+    for step in range(6):
+        batch = tuple(rng.rand(B, 784).astype(np.float32) * 1.2 - 0.1 for _ in range(4))   # exercises the clip
+        ref, grads = oracle_loss(params, batch)
+        model.train_step(batch)
+        got = model.scalars()['total']
+        # fp32-vs-fp64 sign flips of near-zero lrelu pre-activations change single slopes
+        # (0.2 <-> 1), so the conv trajectory is held to 5e-4 instead of 1e-5
+        assert abs(got - ref) <= (2e-5 if step == 0 else 5e-4) * max(1.0, abs(ref)), (step, got, ref)
+        adam.apply(params, grads)
+    # variables after 6 Adam steps
+    hp, _, thr = model.engine.named_variables()
+    # Adam's first steps move every weight by ~lr * sign(g): one flipped lrelu slope changes the
+    # sign of a few tiny gradients of one channel, hence a robust comparison (>= 99 % of the
+    # entries agree to 1e-4 of the tensor scale; nothing is off by more than 2 * steps * lr)
+    def close(v, ref, k):
+        diff, scale = np.abs(v - ref), max(1e-2, np.abs(ref).max())
+        tol = max(1e-4 * scale, 0.05 * 6 * 1e-3)     # 5 % of the distance Adam can travel
+        assert np.mean(diff <= tol) >= 0.97, (k, np.mean(diff <= tol))
+        assert diff.max() <= 2 * 6 * 1e-3, (k, diff.max())
+    for k, v in hp.items():
+        close(v, params['head/' + k], k)
+    for k, v in model.trunk.named().items():
+        close(v, params['conv/' + k], k)
+    st = model.checkpoint_state()['variables']
+    assert st['CFL/DistEncoder/conv2/Conv/V'].shape == (5, 5, 64, 128)
+    assert st['CFL/DistEncoder/outputs/fully_connected/V'].shape == (6272, 30)
