@@ -1,0 +1,160 @@
+"""ctypes binding of the MrCGAN part of libcfl_hip.so (include/cfl_hip.h: transposed conv,
+element-wise / permutation / loss kernels).  Same rules as cfl/hipabi.py: tensors must be
+contiguous fp32 on the GPU, no CPU fallback."""
+import ctypes as C
+
+import torch
+
+from . import hipabi as H
+from .hipabi import CflConv, _check, _dev, _stream
+
+EXPORTS = ('cfl_conv_transpose_workspace_bytes', 'cfl_conv2d_transpose_wn_fwd', 'cfl_conv2d_transpose_wn_bwd',
+           'cfl_ew_act_fwd', 'cfl_ew_act_bwd', 'cfl_ew_add_act', 'cfl_ew_axpy', 'cfl_subpixel2x_fwd',
+           'cfl_subpixel2x_bwd', 'cfl_concat_cols', 'cfl_gather_prototype', 'cfl_bce_logits',
+           'cfl_rowdist_loss', 'cfl_perturb_workspace_bytes', 'cfl_perturb', 'cfl_grad_penalty')
+
+EW = {None: 0, 'linear': 0, 'lrelu': 1, 'relu': 2, 'tanh': 3, 'sigmoid': 4}
+
+_ready = False
+
+
+def lib():
+    global _ready
+    L = H.lib()
+    if _ready:
+        return L
+    vp, i64, i32, f32, sz = C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_size_t
+    L.cfl_conv_transpose_workspace_bytes.argtypes = [C.POINTER(CflConv)]
+    L.cfl_conv_transpose_workspace_bytes.restype = sz
+    L.cfl_conv2d_transpose_wn_fwd.argtypes = [C.POINTER(CflConv)] + [vp] * 6 + [sz, vp]
+    L.cfl_conv2d_transpose_wn_bwd.argtypes = [C.POINTER(CflConv)] + [vp] * 5 + [f32] + [vp] * 5 + [sz, vp]
+    L.cfl_ew_act_fwd.argtypes = [vp, vp, i64, i32, vp]
+    L.cfl_ew_act_bwd.argtypes = [vp, vp, vp, i64, i32, vp]
+    L.cfl_ew_add_act.argtypes = [vp, vp, vp, i64, i32, vp]
+    L.cfl_ew_axpy.argtypes = [f32, vp, vp, i64, vp]
+    L.cfl_subpixel2x_fwd.argtypes = [vp, vp, i64, i32, i32, i32, i32, vp]
+    L.cfl_subpixel2x_bwd.argtypes = [vp, vp, vp, i64, i32, i32, i32, i32, vp]
+    L.cfl_concat_cols.argtypes = [vp, i32, vp, i32, i64, vp, vp]
+    L.cfl_gather_prototype.argtypes = [vp, vp, i64, i32, i32, vp, vp]
+    L.cfl_bce_logits.argtypes = [vp, i64, f32, f32, vp, vp, vp, i32, vp]
+    L.cfl_rowdist_loss.argtypes = [vp, vp, i64, i32, i32, f32, f32, vp, vp, i32, vp]
+    L.cfl_perturb_workspace_bytes.argtypes = []
+    L.cfl_perturb_workspace_bytes.restype = sz
+    L.cfl_perturb.argtypes = [vp, vp, i64, i64, f32, vp, vp, sz, vp]
+    L.cfl_grad_penalty.argtypes = [vp, i64, i64, f32, vp, vp, vp, vp]
+    for n in EXPORTS:
+        if n not in ('cfl_conv_transpose_workspace_bytes', 'cfl_perturb_workspace_bytes'):
+            getattr(L, n).restype = C.c_int
+    _ready = True
+    return L
+
+
+def _opt(t):
+    return _dev(t) if t is not None else None
+
+
+# ---- layers writing into caller-provided buffers (views of the flat parameter / gradient arrays) ----
+def conv_ws_bytes(conv, transposed=False):
+    L = lib()
+    n = (L.cfl_conv_transpose_workspace_bytes if transposed else L.cfl_conv_workspace_bytes)(C.byref(conv))
+    if n == 0:
+        raise H.CflHipError('conv workspace: ' + L.cfl_last_error().decode())
+    return n
+
+
+def conv_fwd(conv, x, V, g, b, y, ws, transposed=False):
+    L = lib()
+    fn = L.cfl_conv2d_transpose_wn_fwd if transposed else L.cfl_conv2d_wn_fwd
+    _check(fn(C.byref(conv), _dev(x), _dev(V), _opt(g), _opt(b), _dev(y), ws.data_ptr(), ws.numel() * 4, _stream()))
+    return y
+
+
+def conv_bwd(conv, x, V, g, y, dy, ws, dx=None, dV=None, dg=None, db=None, reg_const=0.0, transposed=False):
+    L = lib()
+    fn = L.cfl_conv2d_transpose_wn_bwd if transposed else L.cfl_conv2d_wn_bwd
+    _check(fn(C.byref(conv), _opt(x), _dev(V), _opt(g), _opt(y), _dev(dy), float(reg_const), _opt(dx), _opt(dV),
+              _opt(dg), _opt(db), ws.data_ptr(), ws.numel() * 4, _stream()))
+    return dx
+
+
+# ---- element-wise glue ----------------------------------------------------------------------------
+def act_fwd(x, act, out=None):
+    out = torch.empty_like(x) if out is None else out
+    _check(lib().cfl_ew_act_fwd(_dev(x), _dev(out), x.numel(), EW[act], _stream()))
+    return out
+
+
+def act_bwd(y, dy, act, out=None):
+    out = torch.empty_like(dy) if out is None else out
+    _check(lib().cfl_ew_act_bwd(_dev(y), _dev(dy), _dev(out), dy.numel(), EW[act], _stream()))
+    return out
+
+
+def add_act(a, b, act, out=None):
+    out = torch.empty_like(a) if out is None else out
+    _check(lib().cfl_ew_add_act(_dev(a), _dev(b), _dev(out), a.numel(), EW[act], _stream()))
+    return out
+
+
+def axpy(alpha, x, y):
+    _check(lib().cfl_ew_axpy(float(alpha), _dev(x), _dev(y), x.numel(), _stream()))
+    return y
+
+
+def subpixel_fwd(x, act=None):
+    B, Hh, W, Cc = x.shape
+    y = torch.empty(B, 2 * Hh, 2 * W, Cc // 4, dtype=torch.float32, device=x.device)
+    _check(lib().cfl_subpixel2x_fwd(_dev(x), _dev(y), B, Hh, W, Cc, EW[act], _stream()))
+    return y
+
+
+def subpixel_bwd(y, dy, act=None):
+    B, H2, W2, Cq = dy.shape
+    dx = torch.empty(B, H2 // 2, W2 // 2, Cq * 4, dtype=torch.float32, device=dy.device)
+    _check(lib().cfl_subpixel2x_bwd(_opt(y) if EW[act] else None, _dev(dy), _dev(dx), B, H2 // 2, W2 // 2, Cq * 4,
+                                    EW[act], _stream()))
+    return dx
+
+
+def concat_cols(a, b, out=None):
+    if out is None:
+        out = torch.empty(a.shape[0], a.shape[1] + b.shape[1], dtype=torch.float32, device=a.device)
+    _check(lib().cfl_concat_cols(_dev(a), a.shape[1], _dev(b), b.shape[1], a.shape[0], _dev(out), _stream()))
+    return out
+
+
+def gather_prototype(P, c):
+    """P [B,K,L] fp32, c [B] int32 -> [B,L]."""
+    B, K, Ld = P.shape
+    out = torch.empty(B, Ld, dtype=torch.float32, device=P.device)
+    _check(lib().cfl_gather_prototype(_dev(P), _dev(c, torch.int32), B, K, Ld, _dev(out), _stream()))
+    return out
+
+
+def bce_logits(logits, label, weight, loss, frac_pos=None, dlogits=None, accumulate=False):
+    """loss / frac_pos: 1-element device views."""
+    _check(lib().cfl_bce_logits(_dev(logits), logits.numel(), float(label), float(weight), _opt(loss),
+                                _opt(frac_pos), _opt(dlogits), int(bool(accumulate)), _stream()))
+
+
+def rowdist_loss(a, b, mode, margin, weight, loss, da=None, accumulate=False):
+    B, Ld = a.shape
+    _check(lib().cfl_rowdist_loss(_dev(a), _dev(b), B, Ld, int(mode), float(margin or 0.0), float(weight),
+                                  _opt(loss), _opt(da), int(bool(accumulate)), _stream()))
+
+
+def perturb(x, eps, lambda_dra, out=None):
+    B, N = x.shape
+    out = torch.empty_like(x) if out is None else out
+    ws = torch.empty(lib().cfl_perturb_workspace_bytes() // 4, dtype=torch.float32, device=x.device)
+    _check(lib().cfl_perturb(_dev(x), _dev(eps), B, N, float(lambda_dra), _dev(out), ws.data_ptr(), ws.numel() * 4,
+                             _stream()))
+    return out
+
+
+def grad_penalty(u, lambda_gp, loss, need_v=True):
+    B, N = u.shape
+    v = torch.empty_like(u) if need_v else None
+    rowloss = torch.empty(B, dtype=torch.float32, device=u.device)
+    _check(lib().cfl_grad_penalty(_dev(u), B, N, float(lambda_gp), _dev(loss), _opt(v), _dev(rowloss), _stream()))
+    return v

@@ -1,0 +1,426 @@
+"""MrCGAN generator / discriminator stacks on the GPU with hand-written backward passes.
+
+    SRGenerator             cfl/models/blocks.py:25-109
+    SRDiscriminator         cfl/models/blocks.py:112-247
+    ConvTransposeGenerator  cfl/models/blocks.py:250-332
+    ConvDiscriminator       cfl/models/blocks.py:335-438
+
+Every layer is a call into libcfl_hip.so (weight-norm conv / transposed conv / FC on fp32
+MFMA, element-wise and permutation kernels of csrc/cfl_gan.hip); torch only owns the buffers.
+Each network keeps its variables, Adam slots and gradients in ONE flat fp32 array each, so the
+optimiser is a single cfl_adam_tf launch.  There is no autograd: a forward pass records a tape
+of (layer, input, output) and the backward walks it; the gradient-penalty term needs the
+double backward of the discriminator, which for this piecewise-linear network is a second,
+bias-free forward pass with the activation slopes frozen (see `gp_grads`).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from .. import hipabi as H
+from .. import hipgan as G
+
+
+def up_count(shape, min_dim=4):
+    start = min(shape[0], shape[1])
+    n = 0
+    while start % 2 == 0 and start > min_dim:
+        start //= 2
+        n += 1
+    return n, start
+
+
+def xavier(rng, shape, fan_in, fan_out):
+    lim = np.sqrt(6.0 / (fan_in + fan_out))
+    return np.asarray(rng.uniform(-lim, lim, size=shape), np.float32)
+
+
+class ParamPool(object):
+    """Flat fp32 storage of a network's variables (theta), Adam slots (m, v), gradient (grad)
+    and a second gradient buffer (grad2: the gradient-penalty term before it is added)."""
+
+    def __init__(self, device):
+        self.device = device
+        self.specs = {}      # name -> (offset, shape)
+        self.order = []
+        self._init = {}
+        self.total = 0
+        self.theta = None
+
+    def add(self, name, value):
+        value = np.asarray(value, np.float32)
+        self.specs[name] = (self.total, value.shape)
+        self.order.append(name)
+        self._init[name] = value
+        self.total += (value.size + 63) // 64 * 64
+
+    def finalize(self):
+        host = np.zeros(self.total, np.float32)
+        for n in self.order:
+            o, shp = self.specs[n]
+            host[o:o + int(np.prod(shp))] = self._init[n].reshape(-1)
+        self.theta = torch.from_numpy(host).to(self.device)
+        self.m = torch.zeros_like(self.theta)
+        self.v = torch.zeros_like(self.theta)
+        self.grad = torch.zeros_like(self.theta)
+        self.grad2 = torch.zeros_like(self.theta)
+        self._init = None
+
+    def view(self, name, base=None):
+        o, shp = self.specs[name]
+        base = self.theta if base is None else base
+        return base[o:o + int(np.prod(shp))].view(shp)
+
+    def named(self, base=None):
+        return {n: self.view(n, base).detach().cpu().numpy().copy() for n in self.order}
+
+    def load(self, values, base=None):
+        for n in self.order:
+            if n in values:
+                self.view(n, base).copy_(torch.as_tensor(np.asarray(values[n], np.float32)).to(self.device))
+
+
+class WNLayer(object):
+    """One weight-normalised layer: kind 'conv' (V [KH,KW,Ci,Co]), 'convt' (V [KH,KW,Co,Ci]) or
+    'fc' (V [Ci,Co], run as a 1x1 convolution on a 1x1 image)."""
+
+    def __init__(self, pool, scope, kind, kh, kw, ci, co, stride, act, rng):
+        self.pool, self.scope, self.kind = pool, scope, kind
+        self.kh, self.kw, self.ci, self.co, self.stride, self.act = kh, kw, ci, co, stride, act
+        if kind == 'convt':
+            V = xavier(rng, (kh, kw, co, ci), kh * kw * co, kh * kw * ci)
+        elif kind == 'conv':
+            V = xavier(rng, (kh, kw, ci, co), kh * kw * ci, kh * kw * co)
+        else:
+            V = xavier(rng, (ci, co), ci, co)
+        pool.add(scope + '/V', V)
+        pool.add(scope + '/g', np.ones(co, np.float32))
+        pool.add(scope + '/biases', np.zeros(co, np.float32))
+        self._desc = {}
+
+    def p(self, what, base=None):
+        return self.pool.view(self.scope + '/' + what, base)
+
+    def desc(self, B, Hh, W, act):
+        key = (B, Hh, W, act)
+        d = self._desc.get(key)
+        if d is None:
+            d = self._desc[key] = H.CflConv(B, Hh, W, self.ci, self.co, self.kh, self.kw, self.stride,
+                                            H.CONV_ACTS[act])
+        return d
+
+    def out_hw(self, Hh, W):
+        if self.kind == 'convt':
+            return Hh * self.stride, W * self.stride
+        return -(-Hh // self.stride), -(-W // self.stride)
+
+    def fwd(self, x, ws, act='layer', bias=True):
+        """x [B,H,W,Ci] -> y [B,OH,OW,Co]."""
+        act = self.act if act == 'layer' else act
+        B, Hh, W, _ = x.shape
+        d = self.desc(B, Hh, W, act)
+        t = self.kind == 'convt'
+        oh, ow = self.out_hw(Hh, W)
+        y = torch.empty(B, oh, ow, self.co, dtype=torch.float32, device=x.device)
+        G.conv_fwd(d, x, self.p('V'), self.p('g'), self.p('biases') if bias else None, y, ws.get(d, t), t)
+        return y
+
+    def bwd(self, x, y, dy, ws, need_dx=True, need_dw=True, grad=None, need_db=True):
+        """dx (or None); parameter gradients are written into `grad` (a flat buffer shaped like theta)."""
+        t = self.kind == 'convt'
+        B, Hh, W, _ = x.shape
+        d = self.desc(B, Hh, W, self.act)
+        dx = torch.empty(B, Hh, W, self.ci, dtype=torch.float32, device=dy.device) if need_dx else None
+        G.conv_bwd(d, x, self.p('V'), self.p('g'), y, dy, ws.get(d, t), dx=dx,
+                   dV=self.p('V', grad) if need_dw else None, dg=self.p('g', grad) if need_dw else None,
+                   db=self.p('biases', grad) if (need_dw and need_db) else None, transposed=t)
+        return dx
+
+
+class Workspace(object):
+    def __init__(self, device):
+        self.device = device
+        self.buf = torch.empty(1024, dtype=torch.float32, device=device)
+        self._need = {}
+
+    def get(self, d, transposed):
+        key = (d.B, d.H, d.W, d.Ci, d.Co, d.KH, d.KW, d.stride, transposed)
+        n = self._need.get(key)
+        if n is None:
+            n = self._need[key] = (G.conv_ws_bytes(d, transposed) + 3) // 4
+        if self.buf.numel() < n:
+            self.buf = torch.empty(n, dtype=torch.float32, device=self.device)
+        return self.buf
+
+
+class _Net(object):
+    def __init__(self, device, lr, beta1, beta2, eps=1e-8):
+        self.device = device
+        self.pool = ParamPool(device)
+        self.ws = Workspace(device)
+        self.lr, self.beta1, self.beta2, self.eps = lr, beta1, beta2, eps
+        self.beta1_power, self.beta2_power = np.float32(beta1), np.float32(beta2)
+
+    def lr_t(self):
+        return float(np.float32(self.lr) * np.sqrt(np.float32(1) - self.beta2_power) /
+                     (np.float32(1) - self.beta1_power))
+
+    def adam(self):
+        p = self.pool
+        H.adam_tf(p.theta, p.m, p.v, p.grad, self.lr_t(), self.beta1, self.beta2, self.eps)
+        self.beta1_power = np.float32(self.beta1_power * np.float32(self.beta1))
+        self.beta2_power = np.float32(self.beta2_power * np.float32(self.beta2))
+
+    def state(self):
+        return {'variables': self.pool.named(), 'adam_m': self.pool.named(self.pool.m),
+                'adam_v': self.pool.named(self.pool.v), 'beta1_power': float(self.beta1_power),
+                'beta2_power': float(self.beta2_power)}
+
+    def load_state(self, st):
+        self.pool.load(st['variables'])
+        self.pool.load(st.get('adam_m', {}), self.pool.m)
+        self.pool.load(st.get('adam_v', {}), self.pool.v)
+        self.beta1_power = np.float32(st.get('beta1_power', self.beta1))
+        self.beta2_power = np.float32(st.get('beta2_power', self.beta2))
+
+
+class Generator(_Net):
+    """gan_type 'srgan' = SRGenerator, 'conv' = ConvTransposeGenerator.  Input: concat(z, c)."""
+
+    def __init__(self, gan_type, ae_shape, in_dim, data_type, rng, device, lr=2e-4, beta1=0.5, beta2=0.999,
+                 dim=64, scope='Generator'):
+        super(Generator, self).__init__(device, lr, beta1, beta2)
+        self.gan_type, self.ae_shape, self.data_type, self.dim = gan_type, tuple(ae_shape), data_type, dim
+        nb, start = up_count(self.ae_shape)
+        self.nb, self.start = nb, start
+        ch = self.ae_shape[2]
+        self.blocks = []
+        if gan_type == 'srgan':
+            self.fc_dim = dim
+            self.fc1 = WNLayer(self.pool, scope + '/fc1/fully_connected', 'fc', 1, 1, in_dim, dim * start * start, 1,
+                               'relu', rng)
+            ci = dim
+            for i in range(nb - 1):
+                co = 4 * dim * (2 ** (nb - i - 1))
+                self.blocks.append(WNLayer(self.pool, scope + '/subpixel_block%d/Conv' % (i + 1), 'conv', 3, 3, ci,
+                                           co, 1, None, rng))
+                ci = co // 4
+            self.out = WNLayer(self.pool, scope + '/outputs/Conv', 'conv', 3, 3, ci, 4 * ch, 1, None, rng)
+        elif gan_type == 'conv':
+            scale = 2 ** (nb - 1)
+            self.fc_dim = dim * scale
+            self.fc1 = WNLayer(self.pool, scope + '/fc1/fully_connected', 'fc', 1, 1, in_dim,
+                               dim * scale * start * start, 1, 'relu', rng)
+            ci = dim * scale
+            for i in range(nb - 1):
+                co = dim * (2 ** (nb - i - 1))
+                self.blocks.append(WNLayer(self.pool, scope + '/conv_t%d/Conv2d_transpose' % (i + 1), 'convt', 5, 5,
+                                           ci, co, 2, 'relu', rng))
+                ci = co
+            self.out = WNLayer(self.pool, scope + '/outputs/Conv2d_transpose', 'convt', 5, 5, ci, ch, 2, None, rng)
+        else:
+            raise ValueError('unknown gan_type %r' % (gan_type,))
+        self.pool.finalize()
+
+    def forward(self, zc):
+        """zc [N, z_dim + c_dim] -> (activations [N, prod(ae_shape)], tape)."""
+        N = zc.shape[0]
+        tape = []
+        x = zc.view(N, 1, 1, -1)
+        h = self.fc1.fwd(x, self.ws)
+        tape.append(('layer', self.fc1, x, h))
+        h = h.view(N, self.start, self.start, self.fc_dim)
+        sr = self.gan_type == 'srgan'
+        for blk in self.blocks:
+            y = blk.fwd(h, self.ws)
+            tape.append(('layer', blk, h, y))
+            if sr:
+                s = G.subpixel_fwd(y, 'relu')
+                tape.append(('subpixel', 'relu', s))
+                y = s
+            h = y
+        y = self.out.fwd(h, self.ws)
+        tape.append(('layer', self.out, h, y))
+        if sr:
+            y = G.subpixel_fwd(y, None)
+            tape.append(('subpixel', None, None))
+        outputs = y.view(N, -1)
+        acts = G.act_fwd(outputs, self.data_type) if self.data_type != 'linear' else outputs
+        tape.append(('data_act', acts))
+        return acts, tape
+
+    def backward(self, tape, d_acts):
+        """Writes d g_total / d generator variables into pool.grad (d_acts = d g_total / d activations)."""
+        N = d_acts.shape[0]
+        acts = tape[-1][1]
+        d = G.act_bwd(acts, d_acts, self.data_type) if self.data_type != 'linear' else d_acts
+        for item in reversed(tape[:-1]):
+            if item[0] == 'subpixel':
+                _, act, s = item
+                shape = s.shape if s is not None else (N,) + self.ae_shape
+                d = G.subpixel_bwd(s, d.reshape(shape), act)
+            else:
+                _, layer, x, y = item
+                d = layer.bwd(x, y, d.reshape(y.shape), self.ws, need_dx=layer is not self.fc1, need_dw=True,
+                              grad=self.pool.grad)
+
+
+class Discriminator(_Net):
+    """gan_type 'srgan' = SRDiscriminator, 'conv' = ConvDiscriminator; heads disc_outputs (1 logit)
+    and latent_outputs (latent_size)."""
+
+    def __init__(self, gan_type, ae_shape, latent_size, rng, device, lr=2e-4, beta1=0.5, beta2=0.999,
+                 scope='Discriminator'):
+        super(Discriminator, self).__init__(device, lr, beta1, beta2)
+        self.gan_type, self.ae_shape, self.latent_size = gan_type, tuple(ae_shape), latent_size
+        nb, _ = up_count(self.ae_shape)
+        h, w, ch = self.ae_shape
+        self.stages = []   # srgan: [(res convs a1,b1,a2,b2, down)]
+        if gan_type == 'srgan':
+            dim = 32
+            self.stem = WNLayer(self.pool, scope + '/conv/Conv', 'conv', 4, 4, ch, dim, 2, 'lrelu', rng)
+            h, w = -(-h // 2), -(-w // 2)
+            for i in range(nb):
+                s = scope + '/conv%d/' % (i + 1)
+                cn = lambda j: 'Conv' if j == 0 else 'Conv_%d' % j
+                res = []
+                for j in range(2):
+                    a = WNLayer(self.pool, s + cn(2 * j), 'conv', 3, 3, dim, dim, 1, 'lrelu', rng)
+                    b = WNLayer(self.pool, s + cn(2 * j + 1), 'conv', 3, 3, dim, dim, 1, None, rng)
+                    res.append((a, b))
+                down = WNLayer(self.pool, s + cn(4), 'conv', 4, 4, dim, dim * 2, 2, 'lrelu', rng)
+                self.stages.append((res, down))
+                dim *= 2
+                h, w = -(-h // 2), -(-w // 2)
+            feat = h * w * dim
+        elif gan_type == 'conv':
+            dim, ci = 64, ch
+            self.stem = None
+            for i in range(nb):
+                down = WNLayer(self.pool, scope + '/conv%d/Conv' % (i + 1), 'conv', 5, 5, ci, dim, 2, 'lrelu', rng)
+                self.stages.append(([], down))
+                ci, dim = dim, min(dim * 2, 512)
+                h, w = -(-h // 2), -(-w // 2)
+            feat = h * w * ci
+        else:
+            raise ValueError('unknown gan_type %r' % (gan_type,))
+        self.feat = feat
+        self.disc_head = WNLayer(self.pool, scope + '/disc_outputs/fully_connected', 'fc', 1, 1, feat, 1, 1, None, rng)
+        self.lat_head = WNLayer(self.pool, scope + '/latent_outputs/fully_connected', 'fc', 1, 1, feat, latent_size,
+                                1, None, rng)
+        self.pool.finalize()
+
+    # tape entries: ('conv', layer, x, y) | ('res', a, b, h, r1, r2, out)
+    def forward(self, x_flat):
+        N = x_flat.shape[0]
+        tape = []
+        h = x_flat.view((N,) + self.ae_shape)
+        if self.stem is not None:
+            y = self.stem.fwd(h, self.ws)
+            tape.append(('conv', self.stem, h, y))
+            h = y
+        for res, down in self.stages:
+            for a, b in res:
+                r1 = a.fwd(h, self.ws)
+                r2 = b.fwd(r1, self.ws)
+                out = G.add_act(r2, h, 'lrelu')
+                tape.append(('res', a, b, h, r1, r2, out))
+                h = out
+            y = down.fwd(h, self.ws)
+            tape.append(('conv', down, h, y))
+            h = y
+        f = h.view(N, 1, 1, self.feat)
+        disc = self.disc_head.fwd(f, self.ws).view(N, 1)
+        lat = self.lat_head.fwd(f, self.ws).view(N, self.latent_size)
+        return disc, lat, (tape, f)
+
+    def backward(self, tapef, lo, hi, d_disc, d_lat, need_dx, need_dw, grad=None, record=None):
+        """Backward over the rows [lo, hi) of a recorded forward.  d_disc [n,1] / d_lat [n,L] (either
+        may be None).  Returns d/d input rows [n, prod(ae_shape)] when need_dx.  `record`, when a
+        list, receives the upstream gradient of every layer (for `gp_grads`)."""
+        tape, f = tapef
+        n = hi - lo
+        grad = self.pool.grad if grad is None else grad
+        fr = f[lo:hi]
+        df = None
+        if d_disc is not None:
+            dy = d_disc.view(n, 1, 1, 1)
+            if record is not None:
+                record.append(dy)
+            df = self.disc_head.bwd(fr, None, dy, self.ws, True, need_dw, grad)
+        elif need_dw:
+            for w in ('V', 'g', 'biases'):
+                self.disc_head.p(w, grad).zero_()
+        if d_lat is not None:
+            dl = self.lat_head.bwd(fr, None, d_lat.view(n, 1, 1, self.latent_size), self.ws, True, need_dw, grad)
+            df = dl if df is None else G.axpy(1.0, dl, df)
+        elif need_dw:
+            for w in ('V', 'g', 'biases'):
+                self.lat_head.p(w, grad).zero_()
+        first_layer = tape[0][1]
+        d = None
+        for item in reversed(tape):
+            if item[0] == 'conv':
+                _, layer, x, y = item
+                d = df.view(y[lo:hi].shape) if d is None else d
+                if record is not None:
+                    record.append(d)
+                last = layer is first_layer and item is tape[0]
+                d = layer.bwd(x[lo:hi], y[lo:hi], d, self.ws, need_dx or not last, need_dw, grad)
+            else:
+                _, a, b, h, r1, r2, out = item
+                d = df.view(out[lo:hi].shape) if d is None else d
+                dpre = G.act_bwd(out[lo:hi], d, 'lrelu')          # d (r2 + h)
+                if record is not None:
+                    record.append(dpre)
+                dr1 = b.bwd(r1[lo:hi], r2[lo:hi], dpre, self.ws, True, need_dw, grad)
+                if record is not None:
+                    record.append(dr1)
+                dh = a.bwd(h[lo:hi], r1[lo:hi], dr1, self.ws, True, need_dw, grad)
+                d = G.axpy(1.0, dpre, dh)
+        return d.view(n, -1) if (need_dx and d is not None) else None
+
+    def gp_grads(self, tapef, lo, hi, lambda_gp, loss_out, grad):
+        """Gradient penalty lambda * mean((||dD/dX_hat|| - 1)^2) over the rows [lo, hi) of a recorded
+        forward (the X_hat rows) and its gradient w.r.t. the discriminator variables, into `grad`.
+
+        With u_l the backward signal (u = d disc / d layer input) the penalty depends on the weights
+        only through the linear maps of the backward chain u_l = A_l^T (s_l * u_{l+1}) (the lrelu slopes
+        s_l are piecewise constant, the biases drop out).  Its adjoint is a forward pass
+        v_{l+1} = s_l * (A_l v_l) started from v_0 = d penalty / d u_0, and
+        d penalty / d A_l = (s_l * u_{l+1}) (x) v_l -- the ordinary weight gradient with the layer
+        input replaced by v_l and the upstream gradient by the recorded u_{l+1}."""
+        tape, f = tapef
+        n = hi - lo
+        ones = torch.ones(n, 1, dtype=torch.float32, device=self.device)
+        rec = []
+        u0 = self.backward(tapef, lo, hi, ones, None, True, False, record=rec)
+        v = G.grad_penalty(u0.contiguous(), lambda_gp, loss_out, need_v=True)
+        # rec was filled from the head back to the input; walk it in forward order
+        it = iter(reversed(rec))
+        v = v.view((n,) + self.ae_shape)
+        for item in tape:
+            if item[0] == 'conv':
+                _, layer, x, y = item
+                dy = next(it)
+                layer.bwd(v, y[lo:hi], dy, self.ws, False, True, grad, need_db=False)
+                lin = layer.fwd(v, self.ws, act=None, bias=False)
+                v = G.act_bwd(y[lo:hi], lin, layer.act) if layer.act else lin
+            else:
+                _, a, b, h, r1, r2, out = item
+                dr1 = next(it)     # upstream of conv a (recorded after dpre, so it comes first in reverse)
+                dpre = next(it)    # upstream of conv b
+                a.bwd(v, r1[lo:hi], dr1, self.ws, False, True, grad, need_db=False)
+                lin = a.fwd(v, self.ws, act=None, bias=False)
+                v1 = G.act_bwd(r1[lo:hi], lin, 'lrelu')
+                b.bwd(v1, None, dpre, self.ws, False, True, grad, need_db=False)
+                v2 = b.fwd(v1, self.ws, act=None, bias=False)
+                G.axpy(1.0, v, v2)                                   # v_r2 + v_h
+                v = G.act_bwd(out[lo:hi], v2, 'lrelu')
+        dy = next(it)
+        self.disc_head.bwd(v.reshape(n, 1, 1, self.feat), None, dy, self.ws, False, True, grad, need_db=False)
+        for layer_bias in [nme for nme in self.pool.order if nme.endswith('/biases')]:
+            self.pool.view(layer_bias, grad).zero_()
+        for w in ('V', 'g'):
+            self.lat_head.p(w, grad).zero_()

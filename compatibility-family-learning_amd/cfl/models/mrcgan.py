@@ -1,0 +1,121 @@
+"""The MrCGAN post-epoch step (non-cgan branch) on the GPU.
+
+Graph:   cfl/models/cfl.py:784-806   g = G(z, enc_dst(unlabeled target)), g_prj = G(z, one prototype of
+                                      the unlabeled source), g_neg = G(z, one prototype of the negative
+                                      source); D on real / g / g_prj / g_neg / X_hat
+Losses:  cfl/models/cfl.py:951-1063
+Update:  cfl/models/cfl.py:1087-1096 (two TF-Adams), run in ONE sess.run at cfl/models/cfl.py:1491-1497,
+         i.e. both gradients are taken at the same (pre-update) weights.
+
+The three generator evaluations share one batched pass (rows [g | g_prj | g_neg]) and the five
+discriminator evaluations one batched forward (rows [real | g | g_prj | g_neg | X_hat]); weight
+normalisation has no cross-sample statistics, so batching is exact.  Backward passes run on the row
+ranges that carry gradient: d-loss on [real | g | g_prj] (variables only), g-loss on [g | g_prj | g_neg]
+(inputs only, then through the generator), gradient penalty on [X_hat].
+"""
+import numpy as np
+import torch
+
+from .. import hipgan as G
+from .gan_blocks import Discriminator, Generator
+
+# indices into GanPhase.scalars (device floats)
+S_D_REAL, S_D_ENC, S_D_PRJ, S_D_GP, S_D_LAT, S_G_ENC, S_G_PRJ, S_G_LAT, S_G_NEG, S_FRAC_REAL, S_FRAC_FAKE, \
+    S_FRAC_PRJ = range(12)
+
+
+class GanPhase(object):
+    def __init__(self, gan_type, ae_shape, data_type, z_dim, latent_size, batch_size, device, rng,
+                 g_lr=2e-4, g_beta1=0.5, g_beta2=0.999, d_lr=2e-4, d_beta1=0.5, d_beta2=0.999,
+                 lambda_gp=None, lambda_dra=0.5, m_enc=None, m_prj=None):
+        self.gan_type, self.ae_shape, self.data_type = gan_type, tuple(ae_shape), data_type
+        self.z_dim, self.latent_size, self.B = z_dim, latent_size, batch_size
+        self.device = device
+        self.lambda_gp, self.lambda_dra, self.m_enc, self.m_prj = lambda_gp, lambda_dra, m_enc, m_prj
+        self.gen = Generator(gan_type, ae_shape, z_dim + latent_size, data_type, rng, device, g_lr, g_beta1,
+                             g_beta2)
+        self.disc = Discriminator(gan_type, ae_shape, latent_size, rng, device, d_lr, d_beta1, d_beta2)
+        self.scalars = torch.zeros(16, dtype=torch.float32, device=device)
+        self.ae_size = int(np.prod(self.ae_shape))
+
+    def generate(self, z, c):
+        """Generator activations for display / sampling (cfl.bin.sample)."""
+        acts, _ = self.gen.forward(G.concat_cols(z, c))
+        return acts
+
+    def step(self, real, enc_act, prj_c, neg_c, neg_tgt_act, z, eps, apply=True):
+        """One post-epoch iteration.  All arguments are fp32 device tensors:
+             real [B, prod(ae_shape)]  ae-normalised unlabeled target images
+             enc_act, prj_c, neg_c, neg_tgt_act [B, L]  encoder-side constants (see module docstring)
+             z [B, z_dim], eps [B, 1]
+           Returns the scalars tensor (a view; read it after the step)."""
+        B, Ld, sc = self.B, self.latent_size, self.scalars
+        gen, disc = self.gen, self.disc
+        # ---- generator: rows [g | g_prj | g_neg] ------------------------------------------------
+        zc = torch.empty(3 * B, self.z_dim + Ld, dtype=torch.float32, device=self.device)
+        for i, c in enumerate((enc_act, prj_c, neg_c)):
+            G.concat_cols(z, c, out=zc[i * B:(i + 1) * B])
+        fake, g_tape = gen.forward(zc)
+        # ---- discriminator: rows [real | g | g_prj | g_neg | X_hat] -----------------------------
+        nrow = 5 * B if self.lambda_gp else 4 * B
+        x_all = torch.empty(nrow, self.ae_size, dtype=torch.float32, device=self.device)
+        x_all[:B].copy_(real)
+        x_all[B:4 * B].copy_(fake)
+        if self.lambda_gp:
+            G.perturb(real, eps, self.lambda_dra, out=x_all[4 * B:5 * B])
+        d_logit, d_lat, d_tape = disc.forward(x_all)
+
+        # ---- discriminator loss and gradient (variables only) -----------------------------------
+        dd = torch.zeros(3 * B, 1, dtype=torch.float32, device=self.device)
+        dl = torch.zeros(3 * B, Ld, dtype=torch.float32, device=self.device)
+        G.bce_logits(d_logit[0:B], 1.0, 1.0, sc[S_D_REAL:S_D_REAL + 1], sc[S_FRAC_REAL:S_FRAC_REAL + 1], dd[0:B])
+        G.bce_logits(d_logit[B:2 * B], 0.0, 0.5, sc[S_D_ENC:S_D_ENC + 1], sc[S_FRAC_FAKE:S_FRAC_FAKE + 1],
+                     dd[B:2 * B])
+        G.bce_logits(d_logit[2 * B:3 * B], 0.0, 0.5, sc[S_D_PRJ:S_D_PRJ + 1], sc[S_FRAC_PRJ:S_FRAC_PRJ + 1],
+                     dd[2 * B:3 * B])
+        G.rowdist_loss(d_lat[0:B], enc_act, 0, 0.0, 1.0, sc[S_D_LAT:S_D_LAT + 1], dl[0:B])
+        disc.backward(d_tape, 0, 3 * B, dd, dl, need_dx=False, need_dw=True, grad=disc.pool.grad)
+        if self.lambda_gp:
+            disc.gp_grads(d_tape, 4 * B, 5 * B, self.lambda_gp, sc[S_D_GP:S_D_GP + 1], disc.pool.grad2)
+            G.axpy(1.0, disc.pool.grad2, disc.pool.grad)
+
+        # ---- generator loss: gradient w.r.t. the images [g | g_prj | g_neg], then through G ------
+        gd = torch.zeros(3 * B, 1, dtype=torch.float32, device=self.device)
+        gl = torch.zeros(3 * B, Ld, dtype=torch.float32, device=self.device)
+        G.bce_logits(d_logit[B:2 * B], 1.0, 0.5, sc[S_G_ENC:S_G_ENC + 1], None, gd[0:B])
+        G.bce_logits(d_logit[2 * B:3 * B], 1.0, 0.5, sc[S_G_PRJ:S_G_PRJ + 1], None, gd[B:2 * B])
+        if self.m_enc:
+            G.rowdist_loss(d_lat[B:2 * B], enc_act, 1, self.m_enc, 1.0, sc[S_G_LAT:S_G_LAT + 1], gl[0:B])
+        else:
+            G.rowdist_loss(d_lat[B:2 * B], enc_act, 0, 0.0, 1.0, sc[S_G_LAT:S_G_LAT + 1], gl[0:B])
+        if self.m_prj:
+            G.rowdist_loss(d_lat[3 * B:4 * B], neg_tgt_act, 2, self.m_prj, 1.0, sc[S_G_NEG:S_G_NEG + 1],
+                           gl[2 * B:3 * B])
+        d_img = disc.backward(d_tape, B, 4 * B, gd, gl, need_dx=True, need_dw=False)
+        gen.backward(g_tape, d_img.contiguous())
+
+        if apply:
+            disc.adam()
+            gen.adam()
+        return sc
+
+    def read_scalars(self):
+        s = self.scalars.detach().cpu().numpy()
+        out = {
+            'd_loss_real': float(s[S_D_REAL]), 'd_loss_fake': float(s[S_D_ENC] + s[S_D_PRJ]),
+            'd_grad_loss': float(s[S_D_GP]) if self.lambda_gp else 0.0, 'd_loss_d': float(s[S_D_LAT]),
+            'g_loss': float(s[S_G_ENC] + s[S_G_PRJ]), 'g_loss_d': float(s[S_G_LAT]),
+            'g_loss_d_neg': float(s[S_G_NEG]) if self.m_prj else 0.0,
+            'd_real_accuracy': float(s[S_FRAC_REAL]), 'd_fake_accuracy': float(1.0 - s[S_FRAC_FAKE]),
+            'g_accuracy': float(s[S_FRAC_FAKE]),
+        }
+        out['d_total_loss'] = out['d_loss_real'] + out['d_loss_fake'] + out['d_grad_loss'] + out['d_loss_d']
+        out['g_total_loss'] = out['g_loss'] + out['g_loss_d'] + out['g_loss_d_neg']
+        return out
+
+    def state(self):
+        return {'generator': self.gen.state(), 'discriminator': self.disc.state()}
+
+    def load_state(self, st):
+        self.gen.load_state(st['generator'])
+        self.disc.load_state(st['discriminator'])

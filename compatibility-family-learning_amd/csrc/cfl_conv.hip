@@ -42,8 +42,9 @@ __device__ __forceinline__ float act_apply(float y, int act) {
     return y;
 }
 // d act / d pre-activation, from the POST-activation value (both are monotone through 0)
+// (TF: relu'(0) = 0, so lrelu(x) = relu(x) - 0.2 relu(-x) has slope 0 exactly at 0)
 __device__ __forceinline__ float act_slope(float y, int act) {
-    if (act == 1) return y > 0.f ? 1.f : 0.2f;
+    if (act == 1) return y > 0.f ? 1.f : (y < 0.f ? 0.2f : 0.f);
     if (act == 2) return y > 0.f ? 1.f : 0.f;
     return 1.f;
 }
@@ -220,7 +221,11 @@ extern "C" int cfl_conv2d_wn_bwd(const CflConv *c, const float *x, const float *
     ConvGeom g;
     int rc = make_geom(c, &g);
     if (rc) return rc;
-    if (!x || !V || !y || !dy || !dV || !workspace) return cfl_set_err(CFL_E_SHAPE, "NULL pointer");
+    if (!V || !dy || !workspace || (!x && dV) || (!dV && !dx)) return cfl_set_err(CFL_E_SHAPE, "NULL pointer");
+    if (!y) {
+        if (g.act != 0) return cfl_set_err(CFL_E_SHAPE, "conv bwd: y is required when act != 0");
+        y = dy;  // never dereferenced for act == 0 slopes, but keeps the functors simple
+    }
     if (workspace_bytes < cfl_conv_workspace_bytes(c)) return cfl_set_err(CFL_E_WORKSPACE, "conv workspace too small");
     hipStream_t st = (hipStream_t)stream;
     float *scale = (float *)workspace, *n2 = scale + g.Co;
@@ -231,11 +236,192 @@ extern "C" int cfl_conv2d_wn_bwd(const CflConv *c, const float *x, const float *
     if (dx)
         gemm_gather(g.B * g.H * g.W, g.Ci, g.KH * g.KW * g.Co, gg_klen(g.KH * g.KW * g.Co, 1), DyGather{dy, y, scale, g}, FilterT{V, g},
                     StorePlain{dx, g.Ci}, st);
-    const int splits = wgrad_splits(g);
-    gemm_gather(rows, g.Co, npix, wgrad_klen(g), Im2colXT{Im2colX{x, g}}, DyPre{dy, y, g.Co, g.act},
-                StoreSlab{slab, (size_t)rows * g.Co, g.Co}, st);
-    hipLaunchKernelGGL(conv_wfinal_kernel, dim3(g.Co), dim3(256), 0, st, slab, splits, (size_t)rows * g.Co, V,
-                       scale, n2, rows, g.Co, reg_const, dV, gain ? dg : nullptr);
+    if (dV) {
+        const int splits = wgrad_splits(g);
+        gemm_gather(rows, g.Co, npix, wgrad_klen(g), Im2colXT{Im2colX{x, g}}, DyPre{dy, y, g.Co, g.act},
+                    StoreSlab{slab, (size_t)rows * g.Co, g.Co}, st);
+        hipLaunchKernelGGL(conv_wfinal_kernel, dim3(g.Co), dim3(256), 0, st, slab, splits, (size_t)rows * g.Co, V,
+                           scale, n2, rows, g.Co, reg_const, dV, gain ? dg : nullptr);
+    }
     if (db) hipLaunchKernelGGL(conv_bgrad_kernel, dim3(g.Co), dim3(256), 0, st, dy, y, npix, g.Co, g.act, db);
     return hipGetLastError() == hipSuccess ? CFL_OK : cfl_set_err(CFL_E_HIP, "conv bwd launch failed");
+}
+
+// =============================================================================================
+// Weight-normalised TRANSPOSED convolution (cfl/layers.py:253-361): x [B,H,W,Ci], V [KH,KW,Co,Ci],
+// y [B,H*S,W*S,Co] = act( conv2d_transpose(x, g[co] * V / ||V[:,:,co,:]||) + b ), 'SAME'.
+// conv2d_transpose is the adjoint of the 'SAME' stride-S convolution F: [B,H*S,W*S,Co] -> [B,H,W,Ci]
+// with the same HWIO filter; `gt` below is the geometry of F.
+// =============================================================================================
+static int make_geom_t(const CflConv *c, ConvGeom *g) {
+    if (!c) return cfl_set_err(CFL_E_SHAPE, "conv shape is NULL");
+    if (c->B <= 0 || c->H <= 0 || c->W <= 0 || c->Ci <= 0 || c->Co <= 0 || c->KH <= 0 || c->KW <= 0 ||
+        c->stride <= 0 || c->act < 0 || c->act > 2)
+        return cfl_set_err(CFL_E_SHAPE, "bad transposed conv shape");
+    g->B = c->B; g->H = c->H * c->stride; g->W = c->W * c->stride;
+    g->Ci = c->Co;   // F's input channels  = the transposed layer's outputs
+    g->Co = c->Ci;   // F's output channels = the transposed layer's inputs
+    g->KH = c->KH; g->KW = c->KW; g->S = c->stride; g->act = c->act;
+    same_pad(g->H, g->KH, g->S, &g->OH, &g->pt);
+    same_pad(g->W, g->KW, g->S, &g->OW, &g->pl);
+    return CFL_OK;
+}
+
+// per-OUTPUT-channel scale of the transposed layer: norm over (kh, kw, ci) of V[kh,kw,co,ci]
+__global__ __launch_bounds__(256) void convt_scale_kernel(const float *V, const float *g, int taps, int Co,
+                                                          int Ci, float *scale, float *n2out) {
+    const int co = blockIdx.x;
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < taps * Ci; i += 256) {
+        const float v = V[((size_t)(i / Ci) * Co + co) * Ci + (i % Ci)];
+        acc = fmaf(v, v, acc);
+    }
+    __shared__ float red[256];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float n2 = fmaxf(red[0], 1e-12f);
+        n2out[co] = n2;
+        scale[co] = (g ? g[co] : 1.f) * rsqrtf(n2);
+    }
+}
+
+struct TGatherX {  // A(m = (b,oh,ow) of y, k = (kh,kw,ci)) = x[b,(oh+pt-kh)/S,(ow+pl-kw)/S,ci]
+    const float *x; ConvGeom g;   // g = geometry of F (g.Co = channels of x)
+    __device__ float operator()(int m, int k) const {
+        const int iw = m % g.W, t = m / g.W, ih = t % g.H, b = t / g.H;
+        const int ci = k % g.Co, t2 = k / g.Co, kw = t2 % g.KW, kh = t2 / g.KW;
+        const int nh = ih + g.pt - kh, nw = iw + g.pl - kw;
+        if (nh < 0 || nw < 0 || nh % g.S || nw % g.S) return 0.f;
+        const int oh = nh / g.S, ow = nw / g.S;
+        if (oh >= g.OH || ow >= g.OW) return 0.f;
+        return x[(((size_t)b * g.OH + oh) * g.OW + ow) * g.Co + ci];
+    }
+};
+struct TFilterFwd {  // B(k = (kh,kw,ci), n = co) = V[kh,kw,co,ci]
+    const float *V; int Co, Ci;
+    __device__ float operator()(int k, int n) const {
+        return V[((size_t)(k / Ci) * Co + n) * Ci + (k % Ci)];
+    }
+};
+struct TIm2colDy {  // A(m = (b,p,q) of x, k = (kh,kw,co)) = dy_pre[b,p*S+kh-pt,q*S+kw-pl,co] (* scale[co])
+    const float *dy, *y, *scale; ConvGeom g;
+    __device__ float operator()(int m, int k) const {
+        const int ow = m % g.OW, t = m / g.OW, oh = t % g.OH, b = t / g.OH;
+        const int co = k % g.Ci, t2 = k / g.Ci, kw = t2 % g.KW, kh = t2 / g.KW;
+        const int ih = oh * g.S + kh - g.pt, iw = ow * g.S + kw - g.pl;
+        if (ih < 0 || ih >= g.H || iw < 0 || iw >= g.W) return 0.f;
+        const size_t o = (((size_t)b * g.H + ih) * g.W + iw) * g.Ci + co;
+        return dy[o] * act_slope(y[o], g.act) * (scale ? scale[co] : 1.f);
+    }
+};
+struct TIm2colDyT {
+    TIm2colDy f;
+    __device__ float operator()(int m, int k) const { return f(k, m); }
+};
+struct PlainKN {
+    const float *p; int ld;
+    __device__ float operator()(int k, int n) const { return p[(size_t)k * ld + n]; }
+};
+
+// dV[t,co,ci] = s dW - (s/n^2)(sum_{t,ci} dW V) V + reg V ; dg[co] = (dW . V)/n
+__global__ __launch_bounds__(256) void convt_wfinal_kernel(const float *slab, int splits, size_t stride,
+                                                           const float *V, const float *scale, const float *n2,
+                                                           int taps, int Co, int Ci, float reg, float *dV,
+                                                           float *dg) {
+    const int co = blockIdx.x;
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < taps * Ci; i += 256) {
+        const size_t o = ((size_t)(i / Ci) * Co + co) * Ci + (i % Ci);
+        float dw = 0.f;
+        for (int z = 0; z < splits; ++z) dw += slab[z * stride + o];
+        dV[o] = dw;
+        acc = fmaf(dw, V[o], acc);
+    }
+    __shared__ float red[256];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    const float c = red[0], s = scale[co], nn = n2[co];
+    if (threadIdx.x == 0 && dg) dg[co] = c * rsqrtf(nn);
+    for (int i = threadIdx.x; i < taps * Ci; i += 256) {
+        const size_t o = ((size_t)(i / Ci) * Co + co) * Ci + (i % Ci);
+        dV[o] = s * dV[o] - (s / nn) * c * V[o] + reg * V[o];
+    }
+}
+
+static int wgrad_t_klen(const ConvGeom &g) {
+    const long long K = (long long)g.B * g.OH * g.OW;
+    int s = (int)(K / 1024);
+    if (s > 32) s = 32;
+    return gg_klen(K, s);
+}
+
+extern "C" size_t cfl_conv_transpose_workspace_bytes(const CflConv *c) {
+    ConvGeom g;
+    if (make_geom_t(c, &g)) return 0;
+    const size_t welems = (size_t)g.KH * g.KW * g.Ci * g.Co;
+    return (2 * (size_t)g.Ci + 64 + (size_t)gg_splits((long long)g.B * g.OH * g.OW, wgrad_t_klen(g)) * welems) *
+           sizeof(float);
+}
+
+extern "C" int cfl_conv2d_transpose_wn_fwd(const CflConv *c, const float *x, const float *V, const float *gain,
+                                           const float *bias, float *y, void *workspace, size_t workspace_bytes,
+                                           cfl_stream_t stream) {
+    ConvGeom g;
+    int rc = make_geom_t(c, &g);
+    if (rc) return rc;
+    if (!x || !V || !y || !workspace) return cfl_set_err(CFL_E_SHAPE, "NULL pointer");
+    if (workspace_bytes < cfl_conv_transpose_workspace_bytes(c))
+        return cfl_set_err(CFL_E_WORKSPACE, "transposed conv workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    const int Co = g.Ci, Ci = g.Co, taps = g.KH * g.KW;   // of the transposed layer
+    float *scale = (float *)workspace, *n2 = scale + Co;
+    hipLaunchKernelGGL(convt_scale_kernel, dim3(Co), dim3(256), 0, st, V, gain, taps, Co, Ci, scale, n2);
+    gemm_gather(g.B * g.H * g.W, Co, taps * Ci, gg_klen(taps * Ci, 1), TGatherX{x, g}, TFilterFwd{V, Co, Ci},
+                StoreFwd{y, scale, bias, Co, g.act}, st);
+    return hipGetLastError() == hipSuccess ? CFL_OK : cfl_set_err(CFL_E_HIP, "transposed conv fwd launch failed");
+}
+
+extern "C" int cfl_conv2d_transpose_wn_bwd(const CflConv *c, const float *x, const float *V, const float *gain,
+                                           const float *y, const float *dy, float reg_const, float *dx,
+                                           float *dV, float *dg, float *db, void *workspace,
+                                           size_t workspace_bytes, cfl_stream_t stream) {
+    ConvGeom g;
+    int rc = make_geom_t(c, &g);
+    if (rc) return rc;
+    if (!V || !dy || !workspace || (!x && dV) || (!dV && !dx)) return cfl_set_err(CFL_E_SHAPE, "NULL pointer");
+    if (!y) {
+        if (g.act != 0) return cfl_set_err(CFL_E_SHAPE, "transposed conv bwd: y is required when act != 0");
+        y = dy;
+    }
+    if (workspace_bytes < cfl_conv_transpose_workspace_bytes(c))
+        return cfl_set_err(CFL_E_WORKSPACE, "transposed conv workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    const int Co = g.Ci, Ci = g.Co, taps = g.KH * g.KW;
+    float *scale = (float *)workspace, *n2 = scale + Co;
+    float *slab = (float *)workspace + 2 * (size_t)Co + 64;
+    const int npix_in = g.B * g.OH * g.OW;   // pixels of x
+    hipLaunchKernelGGL(convt_scale_kernel, dim3(Co), dim3(256), 0, st, V, gain, taps, Co, Ci, scale, n2);
+    if (dx)
+        gemm_gather(npix_in, Ci, taps * Co, gg_klen(taps * Co, 1), TIm2colDy{dy, y, scale, g}, PlainKN{V, Ci},
+                    StorePlain{dx, Ci}, st);
+    if (dV) {
+        const int klen = wgrad_t_klen(g);
+        const int splits = gg_splits(npix_in, klen);
+        const size_t welems = (size_t)taps * Co * Ci;
+        gemm_gather(taps * Co, Ci, npix_in, klen, TIm2colDyT{TIm2colDy{dy, y, nullptr, g}}, PlainKN{x, Ci},
+                    StoreSlab{slab, welems, Ci}, st);
+        hipLaunchKernelGGL(convt_wfinal_kernel, dim3(Co), dim3(256), 0, st, slab, splits, welems, V, scale, n2,
+                           taps, Co, Ci, reg_const, dV, gain ? dg : nullptr);
+    }
+    if (db) hipLaunchKernelGGL(conv_bgrad_kernel, dim3(Co), dim3(256), 0, st, dy, y, g.B * g.H * g.W, Co, g.act, db);
+    return hipGetLastError() == hipSuccess ? CFL_OK : cfl_set_err(CFL_E_HIP, "transposed conv bwd launch failed");
 }

@@ -1,0 +1,362 @@
+// cfl_gan.hip -- element-wise, permutation and loss kernels of the MrCGAN post-epoch step
+// (generator / discriminator stacks of cfl/models/blocks.py:25-438 and the losses of
+// cfl/models/cfl.py:951-1063).  The heavy layers (weight-norm conv / transposed conv / FC) live in
+// cfl_conv.hip; everything here is HBM-streaming glue: one pass, float4 where the shape allows,
+// fixed-order reductions (single block) so that every scalar is bit-reproducible run to run.
+#include <hip/hip_runtime.h>
+
+#include "../../include/cfl_hip.h"
+
+extern int cfl_set_err(int code, const char *fmt, ...);
+
+namespace {
+
+constexpr int EW_THREADS = 256;
+
+__device__ __forceinline__ float ew_act(float x, int act) {
+    switch (act) {
+        case CFL_EW_LRELU: return x > 0.f ? x : 0.2f * x;
+        case CFL_EW_RELU: return fmaxf(x, 0.f);
+        case CFL_EW_TANH: return tanhf(x);
+        case CFL_EW_SIGMOID: return 1.f / (1.f + __expf(-x));
+        default: return x;
+    }
+}
+// derivative from the POST-activation value y
+__device__ __forceinline__ float ew_slope(float y, int act) {
+    switch (act) {
+        case CFL_EW_LRELU: return y > 0.f ? 1.f : (y < 0.f ? 0.2f : 0.f);
+        case CFL_EW_RELU: return y > 0.f ? 1.f : 0.f;
+        case CFL_EW_TANH: return 1.f - y * y;
+        case CFL_EW_SIGMOID: return y * (1.f - y);
+        default: return 1.f;
+    }
+}
+
+inline int ew_blocks(int64_t n) {
+    int64_t b = (n + EW_THREADS - 1) / EW_THREADS;
+    return (int)(b < 1 ? 1 : (b > 65535 * 16 ? 65535 * 16 : b));
+}
+
+__global__ __launch_bounds__(EW_THREADS) void ew_act_fwd_kernel(const float *x, float *y, int64_t n, int act) {
+    for (int64_t i = blockIdx.x * (int64_t)EW_THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * EW_THREADS)
+        y[i] = ew_act(x[i], act);
+}
+__global__ __launch_bounds__(EW_THREADS) void ew_act_bwd_kernel(const float *y, const float *dy, float *dx,
+                                                                int64_t n, int act) {
+    for (int64_t i = blockIdx.x * (int64_t)EW_THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * EW_THREADS)
+        dx[i] = dy[i] * ew_slope(y[i], act);
+}
+__global__ __launch_bounds__(EW_THREADS) void ew_add_act_kernel(const float *a, const float *b, float *y,
+                                                                int64_t n, int act) {
+    for (int64_t i = blockIdx.x * (int64_t)EW_THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * EW_THREADS)
+        y[i] = ew_act(a[i] + b[i], act);
+}
+__global__ __launch_bounds__(EW_THREADS) void ew_axpy_kernel(float alpha, const float *x, float *y, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)EW_THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * EW_THREADS)
+        y[i] = fmaf(alpha, x[i], y[i]);
+}
+
+// sub-pixel shuffle (cfl/layers.py:212-250): out[b,2h+i,2w+j,c] = in[b,h,w,(2i+j)*Cq+c], Cq = C/4
+__global__ __launch_bounds__(EW_THREADS) void subpixel_fwd_kernel(const float *x, float *y, int64_t n, int H,
+                                                                  int W, int C, int act) {
+    const int Cq = C >> 2;
+    for (int64_t o = blockIdx.x * (int64_t)EW_THREADS + threadIdx.x; o < n; o += (int64_t)gridDim.x * EW_THREADS) {
+        const int c = (int)(o % Cq);
+        int64_t t = o / Cq;
+        const int ow = (int)(t % (2 * W));
+        t /= 2 * W;
+        const int oh = (int)(t % (2 * H));
+        const int64_t b = t / (2 * H);
+        const int64_t src = (((b * H + (oh >> 1)) * W + (ow >> 1)) * C) + ((oh & 1) * 2 + (ow & 1)) * Cq + c;
+        y[o] = ew_act(x[src], act);
+    }
+}
+__global__ __launch_bounds__(EW_THREADS) void subpixel_bwd_kernel(const float *y, const float *dy, float *dx,
+                                                                  int64_t n, int H, int W, int C, int act) {
+    const int Cq = C >> 2;
+    for (int64_t o = blockIdx.x * (int64_t)EW_THREADS + threadIdx.x; o < n; o += (int64_t)gridDim.x * EW_THREADS) {
+        const int c = (int)(o % Cq);
+        int64_t t = o / Cq;
+        const int ow = (int)(t % (2 * W));
+        t /= 2 * W;
+        const int oh = (int)(t % (2 * H));
+        const int64_t b = t / (2 * H);
+        const int64_t src = (((b * H + (oh >> 1)) * W + (ow >> 1)) * C) + ((oh & 1) * 2 + (ow & 1)) * Cq + c;
+        dx[src] = dy[o] * (y ? ew_slope(y[o], act) : 1.f);
+    }
+}
+
+__global__ __launch_bounds__(EW_THREADS) void concat_cols_kernel(const float *a, int na, const float *b, int nb,
+                                                                 int64_t rows, float *out) {
+    const int nc = na + nb;
+    const int64_t n = rows * nc;
+    for (int64_t i = blockIdx.x * (int64_t)EW_THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * EW_THREADS) {
+        const int64_t r = i / nc;
+        const int c = (int)(i % nc);
+        out[i] = c < na ? a[r * na + c] : b[r * nb + (c - na)];
+    }
+}
+
+// one_prototype_activations = gather_nd(P, stack([range(B), c])) (cfl/models/base.py, cfl.py:546)
+__global__ __launch_bounds__(EW_THREADS) void gather_proto_kernel(const float *P, const int32_t *c, int64_t B,
+                                                                  int K, int L, float *out) {
+    const int64_t n = B * L;
+    for (int64_t i = blockIdx.x * (int64_t)EW_THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * EW_THREADS) {
+        const int64_t r = i / L;
+        int k = c[r];
+        k = k < 0 ? 0 : (k >= K ? K - 1 : k);
+        out[i] = P[(r * K + k) * L + (i % L)];
+    }
+}
+
+__device__ __forceinline__ float block_sum(float v, float *red) {
+    red[threadIdx.x] = v;
+    __syncthreads();
+    for (int o = EW_THREADS / 2; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    const float r = red[0];
+    __syncthreads();
+    return r;
+}
+
+// weight * mean(sigmoid_cross_entropy_with_logits(x, label)); d/dx = weight/n * (sigmoid(x) - label)
+__global__ __launch_bounds__(EW_THREADS) void bce_kernel(const float *x, int64_t n, float label, float weight,
+                                                         float *loss, float *frac_pos, float *dx, int accumulate) {
+    __shared__ float red[EW_THREADS];
+    float l = 0.f, cnt = 0.f;
+    const float inv = 1.f / (float)n;
+    for (int64_t i = threadIdx.x; i < n; i += EW_THREADS) {
+        const float v = x[i];
+        l += fmaxf(v, 0.f) - v * label + log1pf(__expf(-fabsf(v)));
+        cnt += v > 0.f ? 1.f : 0.f;
+        if (dx) {
+            const float s = 1.f / (1.f + __expf(-v));
+            const float d = weight * inv * (s - label);
+            dx[i] = accumulate ? dx[i] + d : d;
+        }
+    }
+    l = block_sum(l, red);
+    cnt = block_sum(cnt, red);
+    if (threadIdx.x == 0) {
+        if (loss) *loss = weight * l * inv;
+        if (frac_pos) *frac_pos = cnt * inv;
+    }
+}
+
+// per-row d = sum_j (a - b)^2 and one of the latent losses of cfl/models/cfl.py:1001-1063
+//   mode 0: weight * mean(d)                                 (d_loss_d, g_loss_d without m_enc)
+//   mode 1: weight * mean(max(0, sqrt(d + 1e-7) - margin)^2) (g_loss_d with m_enc)
+//   mode 2: weight * mean(max(0, margin - sqrt(d + 1e-7))^2) (g_loss_d_neg with m_prj)
+// one wave-sized slice of the block per row; da = d loss / d a (overwrite or accumulate)
+__global__ __launch_bounds__(EW_THREADS) void rowdist_kernel(const float *a, const float *b, int64_t B, int L,
+                                                             int mode, float margin, float weight, float *loss,
+                                                             float *da, int accumulate) {
+    __shared__ float red[EW_THREADS];
+    float total = 0.f;
+    const float invB = 1.f / (float)B;
+    for (int64_t r = 0; r < B; ++r) {
+        float d = 0.f;
+        for (int j = threadIdx.x; j < L; j += EW_THREADS) {
+            const float t = a[r * L + j] - b[r * L + j];
+            d = fmaf(t, t, d);
+        }
+        d = block_sum(d, red);
+        float li, coef;   // coef = d loss_i / d d
+        if (mode == 0) {
+            li = d;
+            coef = 1.f;
+        } else {
+            const float s = sqrtf(d + 1e-7f);
+            const float h = mode == 1 ? fmaxf(0.f, s - margin) : fmaxf(0.f, margin - s);
+            li = h * h;
+            coef = (mode == 1 ? 1.f : -1.f) * h / s;   // 2h * (+-1) * 1/(2s)
+        }
+        total += li;
+        if (da)
+            for (int j = threadIdx.x; j < L; j += EW_THREADS) {
+                const float t = a[r * L + j] - b[r * L + j];
+                const float gval = weight * invB * coef * 2.f * t;
+                da[r * L + j] = accumulate ? da[r * L + j] + gval : gval;
+            }
+    }
+    if (threadIdx.x == 0 && loss) *loss = weight * total * invB;
+}
+
+// population mean / variance of all elements, two stages in fixed order
+__global__ __launch_bounds__(EW_THREADS) void moments_stage1(const float *x, int64_t n, float *part) {
+    __shared__ float red[EW_THREADS];
+    const int64_t per = (n + gridDim.x - 1) / gridDim.x;
+    const int64_t lo = blockIdx.x * per, hi = lo + per < n ? lo + per : n;
+    float s = 0.f, s2 = 0.f;
+    for (int64_t i = lo + threadIdx.x; i < hi; i += EW_THREADS) {
+        const float v = x[i];
+        s += v;
+        s2 = fmaf(v, v, s2);
+    }
+    s = block_sum(s, red);
+    s2 = block_sum(s2, red);
+    if (threadIdx.x == 0) {
+        part[2 * blockIdx.x] = s;
+        part[2 * blockIdx.x + 1] = s2;
+    }
+}
+__global__ void moments_stage2(const float *part, int nblocks, int64_t n, float *std_out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        double s = 0.0, s2 = 0.0;
+        for (int i = 0; i < nblocks; ++i) {
+            s += part[2 * i];
+            s2 += part[2 * i + 1];
+        }
+        const double mean = s / (double)n;
+        double var = s2 / (double)n - mean * mean;
+        if (var < 0.0) var = 0.0;
+        *std_out = (float)sqrt(var);
+    }
+}
+// X_hat = X + lambda_dra * std(X) * eps[row]  (cfl/models/cfl.py:742-745)
+__global__ __launch_bounds__(EW_THREADS) void perturb_kernel(const float *x, const float *eps, int64_t n, int64_t N,
+                                                             float lambda_dra, const float *stdp, float *out) {
+    const float k = lambda_dra * (*stdp);
+    for (int64_t i = blockIdx.x * (int64_t)EW_THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * EW_THREADS)
+        out[i] = fmaf(k, eps[i / N], x[i]);
+}
+
+// gradient penalty (cfl/models/cfl.py:986-991): s_b = ||u_b||, loss = lambda * mean((s_b - 1)^2),
+// v_b = d loss / d u_b = lambda * (2/B) (s_b - 1) / s_b * u_b.   One block per row.
+__global__ __launch_bounds__(EW_THREADS) void gp_rows_kernel(const float *u, int64_t B, int64_t N, float lambda_gp,
+                                                             float *rowloss, float *v) {
+    __shared__ float red[EW_THREADS];
+    const int64_t r = blockIdx.x;
+    float s2 = 0.f;
+    for (int64_t j = threadIdx.x; j < N; j += EW_THREADS) {
+        const float t = u[r * N + j];
+        s2 = fmaf(t, t, s2);
+    }
+    s2 = block_sum(s2, red);
+    const float s = sqrtf(s2);
+    const float coef = s > 0.f ? lambda_gp * (2.f / (float)B) * (s - 1.f) / s : 0.f;
+    if (v)
+        for (int64_t j = threadIdx.x; j < N; j += EW_THREADS) v[r * N + j] = coef * u[r * N + j];
+    if (threadIdx.x == 0) rowloss[r] = (s - 1.f) * (s - 1.f);
+}
+__global__ void gp_final_kernel(const float *rowloss, int64_t B, float lambda_gp, float *loss) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        float t = 0.f;
+        for (int64_t i = 0; i < B; ++i) t += rowloss[i];
+        *loss = lambda_gp * t / (float)B;
+    }
+}
+
+inline int done(const char *what) {
+    return hipGetLastError() == hipSuccess ? CFL_OK : cfl_set_err(CFL_E_HIP, "%s launch failed", what);
+}
+
+}  // namespace
+
+extern "C" int cfl_ew_act_fwd(const float *x, float *y, int64_t n, int act, cfl_stream_t stream) {
+    if (!x || !y || n < 0 || act < 0 || act > CFL_EW_SIGMOID) return cfl_set_err(CFL_E_SHAPE, "cfl_ew_act_fwd: bad argument");
+    if (n == 0) return CFL_OK;
+    hipLaunchKernelGGL(ew_act_fwd_kernel, dim3(ew_blocks(n)), dim3(EW_THREADS), 0, (hipStream_t)stream, x, y, n, act);
+    return done("ew_act_fwd");
+}
+
+extern "C" int cfl_ew_act_bwd(const float *y, const float *dy, float *dx, int64_t n, int act, cfl_stream_t stream) {
+    if (!y || !dy || !dx || n < 0 || act < 0 || act > CFL_EW_SIGMOID) return cfl_set_err(CFL_E_SHAPE, "cfl_ew_act_bwd: bad argument");
+    if (n == 0) return CFL_OK;
+    hipLaunchKernelGGL(ew_act_bwd_kernel, dim3(ew_blocks(n)), dim3(EW_THREADS), 0, (hipStream_t)stream, y, dy, dx, n, act);
+    return done("ew_act_bwd");
+}
+
+extern "C" int cfl_ew_add_act(const float *a, const float *b, float *y, int64_t n, int act, cfl_stream_t stream) {
+    if (!a || !b || !y || n < 0 || act < 0 || act > CFL_EW_SIGMOID) return cfl_set_err(CFL_E_SHAPE, "cfl_ew_add_act: bad argument");
+    if (n == 0) return CFL_OK;
+    hipLaunchKernelGGL(ew_add_act_kernel, dim3(ew_blocks(n)), dim3(EW_THREADS), 0, (hipStream_t)stream, a, b, y, n, act);
+    return done("ew_add_act");
+}
+
+extern "C" int cfl_ew_axpy(float alpha, const float *x, float *y, int64_t n, cfl_stream_t stream) {
+    if (!x || !y || n < 0) return cfl_set_err(CFL_E_SHAPE, "cfl_ew_axpy: bad argument");
+    if (n == 0) return CFL_OK;
+    hipLaunchKernelGGL(ew_axpy_kernel, dim3(ew_blocks(n)), dim3(EW_THREADS), 0, (hipStream_t)stream, alpha, x, y, n);
+    return done("ew_axpy");
+}
+
+extern "C" int cfl_subpixel2x_fwd(const float *x, float *y, int64_t B, int H, int W, int C, int act,
+                                  cfl_stream_t stream) {
+    if (!x || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3) || act < 0 || act > CFL_EW_SIGMOID)
+        return cfl_set_err(CFL_E_SHAPE, "cfl_subpixel2x_fwd: bad argument (C must be a multiple of 4)");
+    const int64_t n = B * H * W * C;
+    hipLaunchKernelGGL(subpixel_fwd_kernel, dim3(ew_blocks(n)), dim3(EW_THREADS), 0, (hipStream_t)stream, x, y, n, H, W, C, act);
+    return done("subpixel_fwd");
+}
+
+extern "C" int cfl_subpixel2x_bwd(const float *y, const float *dy, float *dx, int64_t B, int H, int W, int C,
+                                  int act, cfl_stream_t stream) {
+    if (!dy || !dx || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3) || act < 0 || act > CFL_EW_SIGMOID ||
+        (!y && act != CFL_EW_NONE))
+        return cfl_set_err(CFL_E_SHAPE, "cfl_subpixel2x_bwd: bad argument");
+    const int64_t n = B * H * W * C;
+    hipLaunchKernelGGL(subpixel_bwd_kernel, dim3(ew_blocks(n)), dim3(EW_THREADS), 0, (hipStream_t)stream,
+                       act == CFL_EW_NONE ? nullptr : y, dy, dx, n, H, W, C, act);
+    return done("subpixel_bwd");
+}
+
+extern "C" int cfl_concat_cols(const float *a, int na, const float *b, int nb, int64_t rows, float *out,
+                               cfl_stream_t stream) {
+    if (!a || !b || !out || na <= 0 || nb <= 0 || rows <= 0) return cfl_set_err(CFL_E_SHAPE, "cfl_concat_cols: bad argument");
+    hipLaunchKernelGGL(concat_cols_kernel, dim3(ew_blocks(rows * (na + nb))), dim3(EW_THREADS), 0, (hipStream_t)stream,
+                       a, na, b, nb, rows, out);
+    return done("concat_cols");
+}
+
+extern "C" int cfl_gather_prototype(const float *P, const int32_t *c, int64_t B, int K, int L, float *out,
+                                    cfl_stream_t stream) {
+    if (!P || !c || !out || B <= 0 || K <= 0 || L <= 0) return cfl_set_err(CFL_E_SHAPE, "cfl_gather_prototype: bad argument");
+    hipLaunchKernelGGL(gather_proto_kernel, dim3(ew_blocks(B * L)), dim3(EW_THREADS), 0, (hipStream_t)stream, P, c, B, K, L, out);
+    return done("gather_prototype");
+}
+
+extern "C" int cfl_bce_logits(const float *logits, int64_t n, float label, float weight, float *loss,
+                              float *frac_pos, float *dlogits, int accumulate, cfl_stream_t stream) {
+    if (!logits || n <= 0) return cfl_set_err(CFL_E_SHAPE, "cfl_bce_logits: bad argument");
+    hipLaunchKernelGGL(bce_kernel, dim3(1), dim3(EW_THREADS), 0, (hipStream_t)stream, logits, n, label, weight, loss,
+                       frac_pos, dlogits, accumulate);
+    return done("bce_logits");
+}
+
+extern "C" int cfl_rowdist_loss(const float *a, const float *b, int64_t B, int L, int mode, float margin,
+                                float weight, float *loss, float *da, int accumulate, cfl_stream_t stream) {
+    if (!a || !b || B <= 0 || L <= 0 || mode < 0 || mode > 2) return cfl_set_err(CFL_E_SHAPE, "cfl_rowdist_loss: bad argument");
+    hipLaunchKernelGGL(rowdist_kernel, dim3(1), dim3(EW_THREADS), 0, (hipStream_t)stream, a, b, B, L, mode, margin,
+                       weight, loss, da, accumulate);
+    return done("rowdist_loss");
+}
+
+extern "C" size_t cfl_perturb_workspace_bytes(void) { return (2 * 1024 + 64) * sizeof(float); }
+
+extern "C" int cfl_perturb(const float *x, const float *eps, int64_t B, int64_t N, float lambda_dra, float *out,
+                           void *workspace, size_t workspace_bytes, cfl_stream_t stream) {
+    if (!x || !eps || !out || !workspace || B <= 0 || N <= 0) return cfl_set_err(CFL_E_SHAPE, "cfl_perturb: bad argument");
+    if (workspace_bytes < cfl_perturb_workspace_bytes()) return cfl_set_err(CFL_E_WORKSPACE, "cfl_perturb: workspace too small");
+    const int64_t n = B * N;
+    int nb = (int)((n + 4095) / 4096);
+    if (nb > 1024) nb = 1024;
+    float *part = (float *)workspace, *stdp = part + 2 * 1024;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(moments_stage1, dim3(nb), dim3(EW_THREADS), 0, st, x, n, part);
+    hipLaunchKernelGGL(moments_stage2, dim3(1), dim3(64), 0, st, part, nb, n, stdp);
+    hipLaunchKernelGGL(perturb_kernel, dim3(ew_blocks(n)), dim3(EW_THREADS), 0, st, x, eps, n, N, lambda_dra, stdp, out);
+    return done("perturb");
+}
+
+extern "C" int cfl_grad_penalty(const float *u, int64_t B, int64_t N, float lambda_gp, float *loss, float *v,
+                                float *rowloss, cfl_stream_t stream) {
+    if (!u || !loss || !rowloss || B <= 0 || N <= 0) return cfl_set_err(CFL_E_SHAPE, "cfl_grad_penalty: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(gp_rows_kernel, dim3((unsigned)B), dim3(EW_THREADS), 0, st, u, B, N, lambda_gp, rowloss, v);
+    hipLaunchKernelGGL(gp_final_kernel, dim3(1), dim3(64), 0, st, rowloss, B, lambda_gp, loss);
+    return done("grad_penalty");
+}

@@ -221,7 +221,8 @@ int cfl_pair_input_grad(const CflShape *shape, const CflNorm *norm, int64_t B, c
  * Replaces conv2d_weight_norm, cfl/layers.py:100-187 (act: 0 none, 1 lrelu of
  * cfl/ops.py:10-12, 2 relu).  The backward returns d/dx (nullable), d/dV (with the
  * weight-norm correction and + reg_const * V), d/dg, d/db (nullable) given the layer's
- * POST-activation output y and dL/dy.                                            */
+ * POST-activation output y and dL/dy.  In the backward dx, (dV, dg) and db may each be NULL
+ * (that product is skipped; x may be NULL when dV is), and y may be NULL when act == 0.     */
 typedef struct {
     int32_t B, H, W, Ci, Co, KH, KW, stride, act;
 } CflConv;
@@ -233,6 +234,62 @@ int cfl_conv2d_wn_bwd(const CflConv *conv, const float *x, const float *V, const
                       const float *y, const float *dy, float reg_const, float *dx, float *dV,
                       float *dg, float *db, void *workspace, size_t workspace_bytes,
                       cfl_stream_t stream);
+
+/* Weight-normalised TRANSPOSED convolution (conv2d_transpose_weight_norm, cfl/layers.py:253-361):
+ * x [B,H,W,Ci], V [KH,KW,Co,Ci] (norm over kh,kw,ci per OUTPUT channel), y [B,H*stride,W*stride,Co],
+ * 'SAME'.  `conv` describes the layer in its own terms (H,W,Ci = input; Co = output).  Same
+ * nullable-pointer rules as cfl_conv2d_wn_bwd.                                              */
+size_t cfl_conv_transpose_workspace_bytes(const CflConv *conv);
+int cfl_conv2d_transpose_wn_fwd(const CflConv *conv, const float *x, const float *V, const float *g,
+                                const float *b, float *y, void *workspace, size_t workspace_bytes,
+                                cfl_stream_t stream);
+int cfl_conv2d_transpose_wn_bwd(const CflConv *conv, const float *x, const float *V, const float *g,
+                                const float *y, const float *dy, float reg_const, float *dx, float *dV,
+                                float *dg, float *db, void *workspace, size_t workspace_bytes,
+                                cfl_stream_t stream);
+
+/* ---- glue of the MrCGAN stacks (cfl/models/blocks.py:25-438, cfl/models/cfl.py:730-806, 951-1063).
+ * A fully connected weight-norm layer (cfl/layers.py:28-97) is cfl_conv2d_wn_* with H = W = KH =
+ * KW = stride = 1, Ci = inputs, Co = outputs.                                                */
+#define CFL_EW_NONE 0
+#define CFL_EW_LRELU 1   /* cfl/ops.py:10-12 */
+#define CFL_EW_RELU 2
+#define CFL_EW_TANH 3
+#define CFL_EW_SIGMOID 4
+/* y = act(x);  dx = dy * act'(.) evaluated from the POST-activation y (also used to apply the
+ * fixed lrelu masks of the gradient-penalty double backward);  y = act(a + b) (residual join);
+ * y += alpha * x.                                                                            */
+int cfl_ew_act_fwd(const float *x, float *y, int64_t n, int act, cfl_stream_t stream);
+int cfl_ew_act_bwd(const float *y, const float *dy, float *dx, int64_t n, int act, cfl_stream_t stream);
+int cfl_ew_add_act(const float *a, const float *b, float *y, int64_t n, int act, cfl_stream_t stream);
+int cfl_ew_axpy(float alpha, const float *x, float *y, int64_t n, cfl_stream_t stream);
+/* conv2d_subpixel scale 2 (cfl/layers.py:212-250): x [B,H,W,C] -> y [B,2H,2W,C/4],
+ * y[b,2h+i,2w+j,c] = act(x[b,h,w,(2i+j)*C/4+c]); bwd scatters dy * act'(y) back (y may be NULL
+ * when act == CFL_EW_NONE).                                                                  */
+int cfl_subpixel2x_fwd(const float *x, float *y, int64_t B, int H, int W, int C, int act, cfl_stream_t stream);
+int cfl_subpixel2x_bwd(const float *y, const float *dy, float *dx, int64_t B, int H, int W, int C, int act,
+                       cfl_stream_t stream);
+/* out[r] = [a[r, :na], b[r, :nb]]  (tf.concat(zs, -1), cfl/models/blocks.py:65)               */
+int cfl_concat_cols(const float *a, int na, const float *b, int nb, int64_t rows, float *out, cfl_stream_t stream);
+/* one_prototype_activations: out[r, :] = P[r, c[r], :], P [B,K,L] (cfl/models/cfl.py:535-546)   */
+int cfl_gather_prototype(const float *P, const int32_t *c, int64_t B, int K, int L, float *out, cfl_stream_t stream);
+/* *loss = weight * mean(sigmoid_cross_entropy_with_logits(logits, label)); *frac_pos = mean(logits > 0);
+ * dlogits (nullable) = or += weight/n * (sigmoid - label).   cfl/models/cfl.py:955-1037         */
+int cfl_bce_logits(const float *logits, int64_t n, float label, float weight, float *loss, float *frac_pos,
+                   float *dlogits, int accumulate, cfl_stream_t stream);
+/* latent losses on d_r = sum_j (a[r,j]-b[r,j])^2 (cfl/models/cfl.py:1001-1063): mode 0 weight*mean(d);
+ * mode 1 weight*mean(max(0, sqrt(d+1e-7) - margin)^2); mode 2 weight*mean(max(0, margin - sqrt(d+1e-7))^2).
+ * da (nullable) = or += d loss / d a.                                                           */
+int cfl_rowdist_loss(const float *a, const float *b, int64_t B, int L, int mode, float margin, float weight,
+                     float *loss, float *da, int accumulate, cfl_stream_t stream);
+/* X_hat = X + lambda_dra * sqrt(population variance of all of X) * eps[row] (cfl/models/cfl.py:742-745) */
+size_t cfl_perturb_workspace_bytes(void);
+int cfl_perturb(const float *x, const float *eps, int64_t B, int64_t N, float lambda_dra, float *out,
+                void *workspace, size_t workspace_bytes, cfl_stream_t stream);
+/* gradient penalty (cfl/models/cfl.py:986-991) from u = d D(X_hat) / d X_hat [B,N]:
+ * *loss = lambda_gp * mean((||u_r|| - 1)^2);  v (nullable) = d loss / d u;  rowloss: dev scratch [B]. */
+int cfl_grad_penalty(const float *u, int64_t B, int64_t N, float lambda_gp, float *loss, float *v,
+                     float *rowloss, cfl_stream_t stream);
 
 /* Optional per-kernel timing (bench.py's roofline object).  While enabled,
  * every kernel the library launches is bracketed by two HIP events recorded on

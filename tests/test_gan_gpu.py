@@ -1,0 +1,227 @@
+"""MI355X parity of the MrCGAN stacks / post-epoch step against the torch-fp64 oracle
+(oracle/gan_oracle.py).  Small shapes so that the CPU oracle (double backward through
+the discriminator) finishes in seconds."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _mods():
+    from cfl import hipgan as G
+    from cfl.models import gan_blocks as GB
+    from cfl.models import mrcgan as M
+    from oracle import gan_oracle as GO
+    from oracle import conv_oracle as CO
+    return G, GB, M, GO, CO
+
+
+def _dev(a):
+    return torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+
+
+def _close(name, got, want, rtol=2e-4, atol=None):
+    got = np.asarray(got, np.float64)
+    want = np.asarray(want, np.float64)
+    scale = max(np.abs(want).max(), 1e-30)
+    tol = rtol * scale if atol is None else atol
+    err = np.abs(got - want).max()
+    assert err <= tol, '%s: max err %.3e (scale %.3e, tol %.3e)' % (name, err, scale, tol)
+
+
+@pytest.mark.parametrize('act', [None, 'lrelu', 'relu', 'tanh', 'sigmoid'])
+def test_elementwise(act):
+    G, _, _, _, _ = _mods()
+    rng = np.random.RandomState(0)
+    x = rng.randn(1000).astype(np.float32)
+    dy = rng.randn(1000).astype(np.float32)
+    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    f = {None: lambda t: t, 'lrelu': lambda t: torch.relu(t) - 0.2 * torch.relu(-t), 'relu': torch.relu,
+         'tanh': torch.tanh, 'sigmoid': torch.sigmoid}[act]
+    yt = f(xt)
+    yt.backward(torch.tensor(dy, dtype=torch.float64))
+    y = G.act_fwd(_dev(x), act)
+    dx = G.act_bwd(y, _dev(dy), act)
+    _close('y', y.cpu().numpy(), yt.detach().numpy(), 1e-6)
+    _close('dx', dx.cpu().numpy(), xt.grad.numpy(), 1e-5)
+    a = G.add_act(_dev(x), _dev(dy), act)
+    _close('add_act', a.cpu().numpy(), f(torch.tensor(x + dy, dtype=torch.float64)).numpy(), 1e-6)
+
+
+def test_subpixel_concat_gather():
+    G, _, _, _, CO = _mods()
+    rng = np.random.RandomState(1)
+    x = rng.randn(3, 4, 5, 8).astype(np.float32)
+    want = CO.conv2d_subpixel(torch.tensor(x, dtype=torch.float64), 2, 'relu').numpy()
+    y = G.subpixel_fwd(_dev(x), 'relu')
+    assert np.array_equal(y.cpu().numpy(), want.astype(np.float32))
+    dy = rng.randn(*want.shape).astype(np.float32)
+    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    CO.conv2d_subpixel(xt, 2, 'relu').backward(torch.tensor(dy, dtype=torch.float64))
+    dx = G.subpixel_bwd(y, _dev(dy), 'relu')
+    assert np.array_equal(dx.cpu().numpy(), xt.grad.numpy().astype(np.float32))
+    a, b = rng.randn(7, 3).astype(np.float32), rng.randn(7, 5).astype(np.float32)
+    assert np.array_equal(G.concat_cols(_dev(a), _dev(b)).cpu().numpy(), np.concatenate([a, b], 1))
+    P = rng.randn(6, 3, 4).astype(np.float32)
+    c = rng.randint(0, 3, size=6).astype(np.int32)
+    got = G.gather_prototype(_dev(P), torch.as_tensor(c).cuda())
+    assert np.array_equal(got.cpu().numpy(), P[np.arange(6), c])
+
+
+def test_losses():
+    G, _, _, GO, _ = _mods()
+    rng = np.random.RandomState(2)
+    x = (3 * rng.randn(37)).astype(np.float32)
+    sc = torch.zeros(4, device='cuda')
+    for label, w in ((1.0, 0.5), (0.0, 1.0)):
+        xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+        l = w * GO.bce(xt, label)
+        l.backward()
+        dx = torch.zeros(37, device='cuda')
+        G.bce_logits(_dev(x), label, w, sc[0:1], sc[1:2], dx)
+        _close('bce', sc[0].item(), l.item(), 1e-6)
+        _close('dbce', dx.cpu().numpy(), xt.grad.numpy(), 1e-5)
+        assert abs(sc[1].item() - (x > 0).mean()) < 1e-6
+    a, b = rng.randn(9, 6).astype(np.float32) * 0.2, rng.randn(9, 6).astype(np.float32) * 0.2
+    for mode, margin in ((0, 0.0), (1, 0.3), (2, 0.8)):
+        at = torch.tensor(a, dtype=torch.float64, requires_grad=True)
+        d = ((at - torch.tensor(b, dtype=torch.float64)) ** 2).sum(-1)
+        if mode == 0:
+            l = d.mean()
+        elif mode == 1:
+            l = (torch.clamp(torch.sqrt(d + 1e-7) - margin, min=0) ** 2).mean()
+        else:
+            l = (torch.clamp(margin - torch.sqrt(d + 1e-7), min=0) ** 2).mean()
+        l.backward()
+        da = torch.zeros(9, 6, device='cuda')
+        G.rowdist_loss(_dev(a), _dev(b), mode, margin, 1.0, sc[2:3], da)
+        _close('rowdist%d' % mode, sc[2].item(), l.item(), 1e-5)
+        _close('drowdist%d' % mode, da.cpu().numpy(), at.grad.numpy(), 1e-5)
+    X = rng.rand(5, 300).astype(np.float32)
+    eps = rng.rand(5, 1).astype(np.float32)
+    want = X + 0.5 * X.astype(np.float64).std() * eps
+    _close('perturb', G.perturb(_dev(X), _dev(eps), 0.5).cpu().numpy(), want, 1e-6)
+    u = rng.randn(5, 300).astype(np.float32) * 0.05
+    ut = torch.tensor(u, dtype=torch.float64, requires_grad=True)
+    l = 0.5 * ((torch.sqrt((ut * ut).sum(1)) - 1) ** 2).mean()
+    l.backward()
+    v = G.grad_penalty(_dev(u), 0.5, sc[3:4])
+    _close('gp', sc[3].item(), l.item(), 1e-5)
+    _close('dgp', v.cpu().numpy(), ut.grad.numpy(), 1e-5)
+
+
+def _load(pool, params, prefix):
+    pool.load({prefix + k: v.numpy() if torch.is_tensor(v) else v for k, v in params.items()})
+
+
+@pytest.mark.parametrize('gan_type,shape', [('srgan', (16, 16, 3)), ('conv', (16, 16, 1))])
+def test_generator_fwd_bwd(gan_type, shape):
+    G, GB, _, GO, _ = _mods()
+    rng = np.random.RandomState(3)
+    N, ind = 6, 11
+    p = GO.GENERATORS[gan_type][0](shape, ind, rng)
+    gen = GB.Generator(gan_type, shape, ind, 'tanh', np.random.RandomState(0), torch.device('cuda'))
+    _load(gen.pool, p, 'Generator/')
+    zc = rng.randn(N, ind)
+    dA = rng.randn(N, int(np.prod(shape)))
+    pt = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in p.items()}
+    out = GO.GENERATORS[gan_type][1](torch.tensor(zc), pt, shape, 'tanh')
+    out.backward(torch.tensor(dA))
+    acts, tape = gen.forward(_dev(zc))
+    _close('acts', acts.cpu().numpy(), out.detach().numpy(), 2e-5)
+    gen.backward(tape, _dev(dA))
+    got = gen.pool.named(gen.pool.grad)
+    for k in p:
+        _close('d' + k, got['Generator/' + k], pt[k].grad.numpy(), 3e-4)
+
+
+@pytest.mark.parametrize('gan_type,shape', [('srgan', (16, 16, 3)), ('conv', (16, 16, 1))])
+def test_discriminator_fwd_bwd_gp(gan_type, shape):
+    G, GB, _, GO, _ = _mods()
+    rng = np.random.RandomState(4)
+    N, Ld = 6, 5
+    p = GO.DISCRIMINATORS[gan_type][0](shape, Ld, rng)
+    for k in p:   # non-trivial gains / biases
+        if k.endswith('/g'):
+            p[k] = 1.0 + 0.1 * rng.randn(*p[k].shape)
+        if k.endswith('/biases'):
+            p[k] = 0.1 * rng.randn(*p[k].shape)
+    disc = GB.Discriminator(gan_type, shape, Ld, np.random.RandomState(0), torch.device('cuda'))
+    _load(disc.pool, p, 'Discriminator/')
+    x = np.tanh(rng.randn(N, int(np.prod(shape))))
+    dd, dl = rng.randn(N, 1), rng.randn(N, Ld)
+    pt = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in p.items()}
+    xt = torch.tensor(x, requires_grad=True)
+    o, l = GO.DISCRIMINATORS[gan_type][1](xt, pt, shape)
+    ((o * torch.tensor(dd)).sum() + (l * torch.tensor(dl)).sum()).backward()
+    logit, lat, tape = disc.forward(_dev(x))
+    _close('logit', logit.cpu().numpy(), o.detach().numpy(), 2e-5)
+    _close('latent', lat.cpu().numpy(), l.detach().numpy(), 2e-5)
+    dx = disc.backward(tape, 0, N, _dev(dd), _dev(dl), need_dx=True, need_dw=True)
+    _close('dx', dx.cpu().numpy(), xt.grad.numpy(), 3e-4)
+    got = disc.pool.named(disc.pool.grad)
+    for k in p:
+        _close('d' + k, got['Discriminator/' + k], pt[k].grad.numpy(), 3e-4)
+    # row-range backward: rows [2, 5) only
+    pt2 = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in p.items()}
+    o2, l2 = GO.DISCRIMINATORS[gan_type][1](torch.tensor(x[2:5]), pt2, shape)
+    ((o2 * torch.tensor(dd[2:5])).sum() + (l2 * torch.tensor(dl[2:5])).sum()).backward()
+    disc.backward(tape, 2, 5, _dev(dd[2:5]), _dev(dl[2:5]), need_dx=False, need_dw=True)
+    got = disc.pool.named(disc.pool.grad)
+    for k in p:
+        _close('rows d' + k, got['Discriminator/' + k], pt2[k].grad.numpy(), 3e-4)
+    # gradient penalty and its gradient (double backward)
+    pt3 = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in p.items()}
+    xh = torch.tensor(x[1:5], requires_grad=True)
+    o3, _ = GO.DISCRIMINATORS[gan_type][1](xh, pt3, shape)
+    g, = torch.autograd.grad(o3.sum(), xh, create_graph=True)
+    gp = 0.5 * ((torch.sqrt((g * g).sum(1)) - 1.0) ** 2).mean()
+    grads = torch.autograd.grad(gp, [pt3[k] for k in p], allow_unused=True)
+    sc = torch.zeros(1, device='cuda')
+    disc.gp_grads(tape, 1, 5, 0.5, sc, disc.pool.grad2)
+    _close('gp', sc.item(), gp.item(), 1e-4)
+    got = disc.pool.named(disc.pool.grad2)
+    gscale = max(float(t.abs().max()) for t in grads if t is not None)
+    for k, t in zip(p, grads):
+        want = np.zeros(p[k].shape) if t is None else t.numpy()
+        _close('gp d' + k, got['Discriminator/' + k], want, atol=3e-4 * gscale)
+
+
+@pytest.mark.parametrize('gan_type,shape,m_enc,m_prj,lambda_gp', [
+    ('srgan', (16, 16, 3), 0.05, 0.2, 0.5),
+    ('conv', (16, 16, 1), None, None, 0.5),
+    ('srgan', (8, 8, 3), 0.05, 0.2, None),
+])
+def test_post_epoch_step_matches_oracle(gan_type, shape, m_enc, m_prj, lambda_gp):
+    G, GB, M, GO, _ = _mods()
+    B, Ld, zd = 4, 6, 5
+    o = GO.GanOracle(gan_type, shape, 'tanh', zd, Ld, seed=1, m_enc=m_enc, m_prj=m_prj, lambda_gp=lambda_gp)
+    ph = M.GanPhase(gan_type, shape, 'tanh', zd, Ld, B, torch.device('cuda'), np.random.RandomState(0),
+                    lambda_gp=lambda_gp, lambda_dra=0.5, m_enc=m_enc, m_prj=m_prj)
+    _load(ph.gen.pool, o.gp, 'Generator/')
+    _load(ph.disc.pool, o.dp, 'Discriminator/')
+    rng = np.random.RandomState(5)
+    N = int(np.prod(shape))
+    for it in range(3):
+        batch = [np.tanh(rng.randn(B, N)), 0.3 * rng.randn(B, Ld), 0.3 * rng.randn(B, Ld), 0.3 * rng.randn(B, Ld),
+                 0.3 * rng.randn(B, Ld), rng.randn(B, zd), rng.rand(B, 1)]
+        d_total, g_total, parts = o.step(*[torch.tensor(b) for b in batch])
+        ph.step(*[_dev(b) for b in batch])
+        s = ph.read_scalars()
+        tol = 5e-5 if it == 0 else 2e-3
+        for k in ('d_loss_real', 'd_loss_fake', 'd_loss_d', 'g_loss', 'g_loss_d'):
+            assert abs(s[k] - float(parts[k])) <= tol * max(1.0, abs(float(parts[k]))), (it, k, s[k], float(parts[k]))
+        if lambda_gp:
+            assert abs(s['d_grad_loss'] - float(parts['d_grad_loss'])) <= tol, (it, s['d_grad_loss'])
+        if m_prj:
+            assert abs(s['g_loss_d_neg'] - float(parts['g_loss_d_neg'])) <= tol
+        assert abs(s['d_total_loss'] - float(d_total)) <= tol * max(1.0, abs(float(d_total)))
+        assert abs(s['g_total_loss'] - float(g_total)) <= tol * max(1.0, abs(float(g_total)))
+    # variables after 3 simultaneous Adam steps (Adam's first steps are +-lr per element, so a
+    # handful of sign flips of ~zero gradients are tolerated)
+    for pool, ref, pre in ((ph.gen.pool, o.gp, 'Generator/'), (ph.disc.pool, o.dp, 'Discriminator/')):
+        got = pool.named()
+        for k, v in ref.items():
+            diff = np.abs(got[pre + k] - v.numpy())
+            assert (diff <= 2e-4).mean() >= 0.97, (k, diff.max())
