@@ -16,12 +16,16 @@ Differences, all host-side mechanics rather than behaviour:
   * ``SemiDataSet.next_batch_indices`` exposes the index arrays so that a
     device-resident feature table can be gathered on the GPU
     (``ResidentFeatures``, include/cfl_hip.h cfl_gather_rows);
-  * image / image+latent ("double") datasets (cfl/input_data.py:34-192) are not
-    part of the linear hot path and raise NotImplementedError.
+  * image / image+latent ("double") datasets (cfl/input_data.py:34-192, used by the
+    MrCGAN phase) decode with PIL instead of the removed ``scipy.misc.imread``; item
+    "positions" of such files are byte offsets, exactly as in the reference.
 """
 import os
+import struct
 from argparse import Namespace
+from array import array
 from collections import defaultdict
+from io import BytesIO
 
 import numpy as np
 from numpy.random import RandomState
@@ -114,6 +118,104 @@ def load_meta_lines(path):
         yield current, lines
 
 
+# ---- image / double record files (cfl/input_data.py:34-192) -----------------------------------
+#   image  record: id[10] | int32 size | encoded image
+#   double record: id[10] | int32 size1 | int32 size2 | encoded image | latent
+#                  (latent = raw little-endian f32 when raw_latent, else an .npz with key 'data')
+def imread(file_or_bytes):
+    """Decode to an ndarray (HxW or HxWxC uint8), the contract of scipy.misc.imread."""
+    from PIL import Image
+    with Image.open(file_or_bytes) as im:
+        return np.asarray(im)
+
+
+def dump_image(outfile, image, image_format='png'):
+    """Append int32 size + the encoded image (cfl/input_data.py:34-47); `image` is uint8 or float in [0,1]."""
+    from PIL import Image
+    arr = np.asarray(image)
+    if arr.dtype != np.uint8:
+        arr = np.clip(np.rint(arr * 255.0), 0, 255).astype(np.uint8)
+    buf = BytesIO()
+    Image.fromarray(arr).save(buf, format=image_format)
+    outfile.write(struct.pack('<i', buf.getbuffer().nbytes))
+    outfile.write(buf.getvalue())
+
+
+def _scan_offsets(path, n_sizes):
+    offset, offsets = 0, {}
+    with open(path, 'rb') as infile:
+        while True:
+            asin = infile.read(ID_BYTES).decode('ascii')
+            if not asin:
+                break
+            offsets[asin] = offset
+            sizes = struct.unpack('<' + 'i' * n_sizes, infile.read(4 * n_sizes))
+            offset += ID_BYTES + 4 * n_sizes + sum(sizes)
+            infile.seek(offset)
+    return offsets
+
+
+def load_images_offsets(path):
+    """{id: byte offset} of an image file (cfl/input_data.py:173-192)."""
+    return _scan_offsets(path, 1)
+
+
+def load_double_offsets(path):
+    """{id: byte offset} of an image+latent file (cfl/input_data.py:151-170)."""
+    return _scan_offsets(path, 2)
+
+
+def load_asins_by_offsets(path, offsets):
+    """cfl/input_data.py:136-148."""
+    asins = []
+    with open(path, 'rb') as infile:
+        for offset in offsets:
+            infile.seek(int(offset))
+            asins.append(infile.read(ID_BYTES).decode('ascii'))
+    return asins
+
+
+def load_images(path):
+    """Yield (id, flattened float32 image / 255) (cfl/input_data.py:50-64)."""
+    with open(path, 'rb') as infile:
+        while True:
+            asin = infile.read(ID_BYTES).decode('ascii')
+            if not asin:
+                break
+            size = struct.unpack('<i', infile.read(4))[0]
+            image = imread(BytesIO(infile.read(size))).astype(np.float32) / 255.
+            yield asin, image.reshape((-1,))
+
+
+def load_images_by_offsets(path, offsets):
+    """[len(offsets), H*W*C] float32 in [0,1] (cfl/input_data.py:67-84)."""
+    images = []
+    with open(path, 'rb') as infile:
+        for offset in offsets:
+            infile.seek(int(offset) + ID_BYTES)
+            size = struct.unpack('<i', infile.read(4))[0]
+            images.append(imread(BytesIO(infile.read(size))).astype(np.float32) / 255.)
+    return np.array(images).reshape((len(offsets), -1))
+
+
+def load_double_images_by_offsets(path, offsets, raw_latent=False):
+    """(images [n, H*W*C] in [0,1], latents [n, Dlat]) (cfl/input_data.py:107-133)."""
+    images, latents = [], []
+    with open(path, 'rb') as infile:
+        for offset in offsets:
+            infile.seek(int(offset) + ID_BYTES)
+            size1, size2 = struct.unpack('<ii', infile.read(8))
+            images.append(imread(BytesIO(infile.read(size1))).astype(np.float32) / 255.)
+            if raw_latent:
+                latent = array('f')
+                latent.fromfile(infile, size2 // 4)
+            else:
+                latent = np.load(BytesIO(infile.read(size2)))['data']
+            latents.append(latent)
+    return (np.array(images).reshape((len(offsets), -1)),
+            np.array(latents, dtype=np.float32).reshape((len(offsets), -1)))
+
+
 def _read_pairs(path, index, reorder=False):
     pairs = []
     with open(path) as infile:
@@ -154,29 +256,35 @@ def load_data_sets(path, input_size, data_switch=False, raw_latent=False, is_ima
 
 class SemiDataSet(object):
     """Positive / negative pair lists over one ``features.b`` plus the seeded batch
-    streams of cfl/input_data.py:344-690 (vector datasets)."""
+    streams of cfl/input_data.py:344-690 (vector, image and image+latent datasets)."""
 
     def __init__(self, path, input_size=28 * 28, data_switch=False, is_image=False,
                  is_double=False, directed=False, reorder=False, raw_latent=False, seed=633):
-        if is_image or is_double:
-            raise NotImplementedError(
-                'image / double datasets (cfl/input_data.py:34-192) are outside the linear '
-                'pair-distance hot path')
         self._rng = RandomState(seed)
         self.input_size = input_size
         self.feature_path = os.path.join(path, 'features.b')
-        self.is_image, self.is_double = False, False
+        self.is_image, self.is_double = is_image, is_double
         self.directed = directed
         self.data_switch = data_switch
         self.raw_latent = raw_latent
-        self._file = _open(self.feature_path, input_size)
 
-        self.asins_to_index = load_features_indices(self.feature_path, input_size)
-        self.index_to_asins = {i: a for a, i in self.asins_to_index.items()}
-        # quirk kept on purpose: the LAST item is never drawn as unlabeled
-        # (cfl/input_data.py:399, SURVEY.md App. G)
-        self.num_examples = max(self.index_to_asins)
-        self.item_indices = np.arange(self.num_examples)
+        if is_image:
+            # positions are byte offsets; the unlabeled order is permuted once up front
+            # (cfl/input_data.py:379-391)
+            self._file = None
+            self.asins_to_index = (load_double_offsets if is_double else load_images_offsets)(self.feature_path)
+            self.index_to_asins = {i: a for a, i in self.asins_to_index.items()}
+            self.num_examples = len(self.index_to_asins)
+            self.item_indices = np.array(sorted(self.index_to_asins))
+            self.item_indices = self.item_indices[self._rng.permutation(self.num_examples)]
+        else:
+            self._file = _open(self.feature_path, input_size)
+            self.asins_to_index = load_features_indices(self.feature_path, input_size)
+            self.index_to_asins = {i: a for a, i in self.asins_to_index.items()}
+            # quirk kept on purpose: the LAST item is never drawn as unlabeled
+            # (cfl/input_data.py:399, SURVEY.md App. G)
+            self.num_examples = max(self.index_to_asins)
+            self.item_indices = np.arange(self.num_examples)
         self.head_unlabeled = 0
 
         if directed:
@@ -195,10 +303,20 @@ class SemiDataSet(object):
 
     # -- feature access ------------------------------------------------------
     def _load_features_by_positions(self, indices):
+        if self.is_image:
+            if self.is_double:
+                return load_double_images_by_offsets(self.feature_path, indices, raw_latent=self.raw_latent)
+            return load_images_by_offsets(self.feature_path, indices)
         return self._file.features(indices)
 
     def _load_asins_by_positions(self, indices):
+        if self.is_image:
+            return load_asins_by_offsets(self.feature_path, indices)
         return self._file.ids(indices)
+
+    def _parts(self, loaded):
+        """A loaded item batch as a list of arrays: [x] or, for double data, [image, latent]."""
+        return list(loaded) if self.is_double else [loaded]
 
     # -- labeled stream --------------------------------------------------------
     def _draw(self, which, batch_size):
@@ -236,9 +354,11 @@ class SemiDataSet(object):
             raise NotImplementedError()
         pos, neg, switched = self.next_batch_indices(batch_size)
         cols = (1, 0) if switched else (0, 1)
-        load = self._load_features_by_positions
-        return (load(pos[:, cols[0]]), load(pos[:, cols[1]]),
-                load(neg[:, cols[0]]), load(neg[:, cols[1]]))
+        out = []
+        for pairs in (pos, neg):
+            for c in cols:
+                out.extend(self._parts(self._load_features_by_positions(pairs[:, c])))
+        return tuple(out)   # 4 arrays, or 8 (image, latent interleaved) for double data
 
     def next_batch(self, batch_size, return_labels=False):
         return self.next_labeled_batch(batch_size, return_labels)
@@ -247,8 +367,8 @@ class SemiDataSet(object):
     def _whole(self, pairs, batch_size, source_ids):
         for i in range(0, pairs.shape[0], batch_size):
             chunk = pairs[i:i + batch_size]
-            out = (self._load_features_by_positions(chunk[:, 0]),
-                   self._load_features_by_positions(chunk[:, 1]))
+            out = tuple(self._parts(self._load_features_by_positions(chunk[:, 0])) +
+                        self._parts(self._load_features_by_positions(chunk[:, 1])))
             if source_ids:
                 out += (self._load_asins_by_positions(chunk[:, 0]),)
             yield out
@@ -262,7 +382,7 @@ class SemiDataSet(object):
     def whole_unlabeled_batches(self, batch_size, source_ids=False):
         for i in range(0, self.num_examples, batch_size):
             positions = self.item_indices[i:i + batch_size]
-            data = [self._load_features_by_positions(positions)]
+            data = self._parts(self._load_features_by_positions(positions))
             if source_ids:
                 data.append(self._load_asins_by_positions(positions))
             yield data
@@ -283,7 +403,7 @@ class SemiDataSet(object):
         return positions
 
     def _finish(self, positions, return_labels, source_ids):
-        data = [self._load_features_by_positions(positions)]
+        data = self._parts(self._load_features_by_positions(positions))
         if return_labels or source_ids:
             asins = self._load_asins_by_positions(positions)
             if return_labels:

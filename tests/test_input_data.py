@@ -129,11 +129,6 @@ def test_meta_lines(tmp_path):
     assert [len(g[1]) for g in got] == [3, 1, 2]
 
 
-def test_image_datasets_are_out_of_scope(root):
-    with pytest.raises(NotImplementedError):
-        D.SemiDataSet(os.path.join(root, 'train'), input_size=DIM, is_image=True)
-
-
 def test_bad_feature_file(tmp_path):
     (tmp_path / 'features.b').write_bytes(b'x' * 31)
     with pytest.raises(ValueError):
