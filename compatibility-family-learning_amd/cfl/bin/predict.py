@@ -1,6 +1,6 @@
 """python -m cfl.bin.predict -- score files for cfl.bin.evaluate_total from the
 best_model (AUC-selected) and best_acc_model checkpoints of cfl.bin.train
-(drop-in for cfl/bin/predict.py:19-199, ``--model-type linear``)."""
+(drop-in for cfl/bin/predict.py:19-199)."""
 import logging
 import os
 
@@ -16,11 +16,10 @@ def main(predict_root, data_name, data_root, checkpoint_root, log_root, seed, da
          data_random_crop, data_is_image, raw_latent, data_scale, data_mean, latent_norm,
          **model_args):
     a = model_args
-    if data_is_image:
-        raise NotImplementedError('image datasets are outside the linear pair-distance hot path')
     input_size = reduce_product(a['input_shape'])
     source_size = reduce_product(a['source_shape']) if a['source_shape'] else input_size
-    data = load_data_sets(os.path.join(data_root, data_name), source_size,
+    data = load_data_sets(os.path.join(data_root, data_name), source_size, is_image=data_is_image,
+                          is_double=a['data_is_double'], raw_latent=raw_latent,
                           directed=a['directed'] or a['data_directed'], seed=seed)
     (data_normalizer, data_unnormalizer, ae_normalizer, ae_unnormalizer,
      latent_normalizer) = dist_normalizer(

@@ -1,9 +1,9 @@
-"""python -m cfl.bin.train -- CFL distance training (``--model-type linear``).
+"""python -m cfl.bin.train -- CFL training: distance epochs (``--model-type linear|conv``) followed,
+with ``--gan``, by the MrCGAN post epochs.
 
 Drop-in for the reference's cfl/bin/train.py flag surface and directory layout
 (checkpoints/<data>/<model.get_name()>/{model-*, best_model/, best_acc_model/}).
-The conv encoder, image datasets and the MrCGAN post-epochs are not built yet and
-fail loudly (cfl.models.cfl)."""
+The random-crop / mirror input transformers and ``--cgan`` are not built and fail loudly."""
 import logging
 import os
 import shutil
@@ -22,12 +22,13 @@ def train_dist(load_pre_weights, data_switch, epochs, post_epochs, eval_epochs, 
                data_mirror, data_random_crop, data_is_image, raw_latent, data_scale, data_mean,
                latent_norm, **model_args):
     a = model_args
-    if data_is_image or data_mirror or data_random_crop:
-        raise NotImplementedError('image datasets / crop / mirror transformers are outside the '
-                                  'linear pair-distance hot path (cfl/ops.py:38-63,262-299)')
+    if data_mirror or data_random_crop:
+        raise NotImplementedError('random crop / mirror input transformers (cfl/ops.py:38-63,262-299) '
+                                  'are not built')
     input_size = reduce_product(a['input_shape'])
     source_size = reduce_product(a['source_shape']) if a['source_shape'] else input_size
-    data = load_data_sets(os.path.join(data_root, data_name), source_size,
+    data = load_data_sets(os.path.join(data_root, data_name), source_size, is_image=data_is_image,
+                          is_double=a['data_is_double'], raw_latent=raw_latent,
                           directed=a['directed'] or a['data_directed'], data_switch=data_switch, seed=seed)
     (data_normalizer, data_unnormalizer, ae_normalizer, ae_unnormalizer,
      latent_normalizer) = dist_normalizer(

@@ -9,7 +9,7 @@ from . import hipabi as H
 from .hipabi import CflConv, _check, _dev, _stream
 
 EXPORTS = ('cfl_conv_transpose_workspace_bytes', 'cfl_conv2d_transpose_wn_fwd', 'cfl_conv2d_transpose_wn_bwd',
-           'cfl_ew_act_fwd', 'cfl_ew_act_bwd', 'cfl_ew_add_act', 'cfl_ew_axpy', 'cfl_subpixel2x_fwd',
+           'cfl_ew_act_fwd', 'cfl_ew_act_bwd', 'cfl_ew_add_act', 'cfl_ew_axpy', 'cfl_ew_affine_clip', 'cfl_subpixel2x_fwd',
            'cfl_subpixel2x_bwd', 'cfl_concat_cols', 'cfl_gather_prototype', 'cfl_bce_logits',
            'cfl_rowdist_loss', 'cfl_perturb_workspace_bytes', 'cfl_perturb', 'cfl_grad_penalty')
 
@@ -32,6 +32,7 @@ def lib():
     L.cfl_ew_act_bwd.argtypes = [vp, vp, vp, i64, i32, vp]
     L.cfl_ew_add_act.argtypes = [vp, vp, vp, i64, i32, vp]
     L.cfl_ew_axpy.argtypes = [f32, vp, vp, i64, vp]
+    L.cfl_ew_affine_clip.argtypes = [vp, vp, i64, C.POINTER(H.CflNorm), vp]
     L.cfl_subpixel2x_fwd.argtypes = [vp, vp, i64, i32, i32, i32, i32, vp]
     L.cfl_subpixel2x_bwd.argtypes = [vp, vp, vp, i64, i32, i32, i32, i32, vp]
     L.cfl_concat_cols.argtypes = [vp, i32, vp, i32, i64, vp, vp]
@@ -99,6 +100,13 @@ def add_act(a, b, act, out=None):
 def axpy(alpha, x, y):
     _check(lib().cfl_ew_axpy(float(alpha), _dev(x), _dev(y), x.numel(), _stream()))
     return y
+
+
+def affine_clip(x, norm, out=None):
+    """norm: hipabi.CflNorm (Normalizer.to_cfl_norm())."""
+    out = torch.empty_like(x) if out is None else out
+    _check(lib().cfl_ew_affine_clip(_dev(x), _dev(out), x.numel(), C.byref(norm), _stream()))
+    return out
 
 
 def subpixel_fwd(x, act=None):

@@ -8,8 +8,10 @@ Adam when --use-threshold is off) -- all inside the fused HIP pair kernels.
 ``--model-type conv`` adds the ConvPCD trunk (cfl.models.conv_encoder, weight-normalised
 5x5 stride-2 convolutions on the GPU) in front of the same heads.
 
-Not built in this round (raise NotImplementedError): image / double
-datasets and the MrCGAN post-epoch phase (``--gan``).
+``--gan`` adds the MrCGAN post epochs (cfl/models/cfl.py:730-806, 951-1063, 1087-1096,
+1484-1504): generator / discriminator stacks and the post-epoch step of cfl.models.mrcgan,
+conditioned on the frozen distance encoder (cfl.models.encoder_heads).  Image and
+image+latent ("double") datasets feed it; the cgan variant (``--cgan``) is not built.
 """
 import logging
 import os
@@ -51,16 +53,26 @@ class CFL(PairModel):
             raise ValueError(model_type)
         if model_type == 'conv' and directed:
             raise NotImplementedError('directed conv encoders are not built yet')
-        if is_double:
-            raise NotImplementedError('image + latent ("double") datasets are not built yet')
-        if gan:
-            raise NotImplementedError('the MrCGAN post-epoch phase (--gan) is not built yet')
+        if gan and cgan:
+            raise NotImplementedError('the conditional variant (--cgan, cfl/models/cfl.py:747-782) is not built yet')
+        if gan and model_type == 'conv':
+            raise NotImplementedError('--gan with the conv encoder is not built yet')
         self.ENCODER_SCOPES = ('DistEncoderSrc', 'DistEncoderDst') if directed else ('DistEncoder',)
-        norm = data_normalizer.to_cfl_norm() if data_normalizer is not None else H.make_norm()
+        # double data: the encoder reads the pre-computed latents unless --data-disable-double
+        # (cfl/models/cfl.py:176-193, 578)
+        self.uses_latent = bool(is_double and not disable_double)
+        if self.uses_latent:
+            if not latent_shape:
+                raise ValueError('double data needs --latent-shape')
+            self.latent_shape = tuple(latent_shape) if not isinstance(latent_shape, int) else (latent_shape,)
+            enc_norm = latent_normalizer
+        else:
+            enc_norm = data_normalizer
+        norm = enc_norm.to_cfl_norm() if enc_norm is not None else H.make_norm()
         loss = H.make_loss(use_threshold=use_threshold, pos_weight=pos_weight,
                            caffe_margin=caffe_margin, lambda_m=lambda_m, reg_const=reg_const)
         self.trunk = None
-        head_inputs = reduce_product(self.input_shape)
+        head_inputs = reduce_product(self.latent_shape if self.uses_latent else self.input_shape)
         if model_type == 'conv':
             # ConvPCD: the normaliser applies to the pixels; the heads see the flattened trunk
             from .conv_encoder import ConvTrunk
@@ -76,9 +88,72 @@ class CFL(PairModel):
             directed=directed, norm=norm, loss=loss, lr=lr, beta1=beta1, beta2=beta2,
             batch_size=batch_size, seed=seed, device=device)
         self._ema = {}
+        self.gan_phase = None
+        if gan:
+            from .mrcgan import GanPhase
+            self.gan_phase = GanPhase(
+                gan_type, self.ae_shape if len(self.ae_shape) == 3 else self.ae_shape + (1,), data_type, z_dim,
+                latent_size, batch_size, self.device, np.random.RandomState(seed + 2), g_lr=g_lr, g_beta1=g_beta1,
+                g_beta2=g_beta2, d_lr=d_lr, d_beta1=d_beta1, d_beta2=d_beta2, lambda_gp=lambda_gp,
+                lambda_dra=lambda_dra, m_enc=m_enc, m_prj=m_prj)
+            self._heads = None
+            import torch
+            self._gen = torch.Generator(device=self.device)
+            self._gen.manual_seed(int(seed) + 3)
 
     def init(self, sess=None):
         pass
+
+    # -- double data ---------------------------------------------------------------
+    def select_batch(self, batch):
+        """The 4 encoder inputs of a labeled batch: 8-tuples (image, latent interleaved,
+        cfl/input_data.py:581-584) reduce to the latents, or to the images with --data-disable-double."""
+        if len(batch) == 8:
+            o = 1 if self.uses_latent else 0
+            return (batch[o], batch[2 + o], batch[4 + o], batch[6 + o])
+        return batch
+
+    def select_pair(self, b):
+        """(src, dst) encoder inputs of a whole_pos/neg_batches chunk (cfl/utils.py:234-244)."""
+        if self.is_double:
+            o = 1 if self.uses_latent else 0
+            return b[o], b[2 + o]
+        return b[0], b[1]
+
+    # -- MrCGAN post-epoch iteration (cfl/models/cfl.py:1487-1497) -----------------------
+    def _dev(self, x):
+        import torch
+        t = x if isinstance(x, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(x, np.float32))
+        return t.to(self.device, torch.float32).contiguous()
+
+    def gan_inputs(self, labeled, unl_src, unl_dst):
+        """Device inputs of GanPhase.step from one labeled batch and the unlabeled source / target item
+        batches (lists [x] or [image, latent]).  Draws z ~ N(0, z_stddev), eps ~ U[0,1), gate c ~ U{0..K-1}
+        (cfl/models/cfl.py:70-100, 535-546)."""
+        import torch
+        from .. import hipgan as G
+        from .encoder_heads import FrozenHeads
+        if self._heads is None:
+            self._heads = FrozenHeads(self.engine, self.act_type)
+        hd, B = self._heads, self.batch_size
+        o = 1 if self.uses_latent else 0
+        enc_in = lambda parts: self.to_device(parts[o] if len(parts) > 1 else parts[0])
+        img = lambda parts: self._dev(parts[0])
+        lab = self.select_batch(labeled)
+        dst_side = 1 if self.directed else 0
+        real = G.affine_clip(img(unl_dst), self.ae_normalizer.to_cfl_norm()) if self.ae_normalizer is not None \
+            else img(unl_dst)
+        c = torch.randint(0, self.num_components, (B,), generator=self._gen, device=self.device, dtype=torch.int32)
+        enc_act = hd.activations(enc_in(unl_dst), dst_side)
+        prj_c = G.gather_prototype(hd.prototype_activations(enc_in(unl_src), 0), c)
+        neg_c = G.gather_prototype(hd.prototype_activations(self.to_device(lab[2]), 0), c)
+        neg_tgt_act = hd.activations(self.to_device(lab[3]), dst_side)
+        z = torch.randn(B, self.z_dim, generator=self._gen, device=self.device) * float(self.z_stddev)
+        eps = torch.rand(B, 1, generator=self._gen, device=self.device)
+        return real, enc_act, prj_c, neg_c, neg_tgt_act, z.contiguous(), eps
+
+    def post_step(self, labeled, unl_src, unl_dst):
+        self.gan_phase.step(*self.gan_inputs(labeled, unl_src, unl_dst))
 
     # -- ConvPCD: trunk + heads ---------------------------------------------------
     def _pixels(self, x):
@@ -87,6 +162,7 @@ class CFL(PairModel):
         return self.trunk.normalize(t.to(self.device, torch.float32))
 
     def train_step(self, batch):
+        batch = self.select_batch(batch)
         if self.trunk is None:
             return PairModel.train_step(self, batch)
         import torch
@@ -120,6 +196,7 @@ class CFL(PairModel):
         return self.engine.scores(F[:n], F[n:]).cpu().numpy().reshape(-1, 1)
 
     def batch_accuracy(self, batch):
+        batch = self.select_batch(batch)
         if self.trunk is None:
             return PairModel.batch_accuracy(self, batch)
         sp, sn = self.predict(batch[0], batch[1]), self.predict(batch[2], batch[3])
@@ -139,6 +216,13 @@ class CFL(PairModel):
             pre = 'CFL/' + self.ENCODER_SCOPES[0] + '/'
             for key, base in (('variables', None), ('adam_m', self.trunk.m), ('adam_v', self.trunk.v)):
                 st[key].update({pre + k: v for k, v in self.trunk.named(base).items()})
+        if self.gan_phase is not None:
+            for net in (self.gan_phase.gen, self.gan_phase.disc):
+                ns = net.state()
+                for key in ('variables', 'adam_m', 'adam_v'):
+                    st[key].update({'CFL/' + k: v for k, v in ns[key].items()})
+            st['gan_powers'] = {n: (float(net.beta1_power), float(net.beta2_power))
+                                for n, net in (('g', self.gan_phase.gen), ('d', self.gan_phase.disc))}
         return st
 
     def load_checkpoint_state(self, state):
@@ -148,6 +232,12 @@ class CFL(PairModel):
             for key, base in (('variables', None), ('adam_m', self.trunk.m), ('adam_v', self.trunk.v)):
                 self.trunk.load_named({k[len(pre):]: v for k, v in state[key].items()
                                        if k.startswith(pre + 'conv')}, base)
+        if self.gan_phase is not None and 'gan_powers' in state:
+            for n, net in (('g', self.gan_phase.gen), ('d', self.gan_phase.disc)):
+                strip = lambda d: {k[4:]: v for k, v in d.items() if k.startswith('CFL/')}
+                net.load_state({'variables': strip(state['variables']), 'adam_m': strip(state['adam_m']),
+                                'adam_v': strip(state['adam_v']), 'beta1_power': state['gan_powers'][n][0],
+                                'beta2_power': state['gan_powers'][n][1]})
 
     def get_name(self, no_gan=False):
         """Byte-for-byte cfl/models/cfl.py:368-412 (names checkpoint / predict dirs)."""
@@ -215,10 +305,19 @@ class CFL(PairModel):
         best_acc_path = os.path.join(best_acc_dir, 'best_accuracy_by_th')
         stats = load_best_stats(best_auc_path)
         stats_acc = load_best_stats(best_acc_path)
+        if not self.gan:
+            logger.info('post epochs disabled due to disabled gan')
+            post_epochs = 0
+        total_epochs = epochs + post_epochs
         start_epoch = start_iter // nb_batch
-        logger.warning('start epoch %d of %d', start_epoch, epochs)
-        for e in range(start_epoch, epochs):
+        logger.warning('start epoch %d of %d', start_epoch, total_epochs)
+        for e in range(start_epoch, total_epochs):
             t = trange(start_iter % nb_batch if e == start_epoch else 0, nb_batch)
+            if e >= epochs:
+                self._post_epoch(e, t, data, nb_batch, save_iters, saver, checkpoint_dir)
+                if e % save_epochs == 0 and saver is not None:
+                    saver.save(self, os.path.join(checkpoint_dir, 'model'), global_step=(e + 1) * nb_batch)
+                continue
             t.set_description('epoch {}'.format(e))
             train_avg = val_avg = 0.0
             for i in t:
@@ -260,6 +359,30 @@ class CFL(PairModel):
                 logger.warning('epoch %d: avg error = train: %f val: %f', e, 1. - train_avg, 1. - val_avg)
             if e % save_epochs == 0 and saver is not None:
                 saver.save(self, os.path.join(checkpoint_dir, 'model'), global_step=(e + 1) * nb_batch)
+
+
+    def _post_epoch(self, e, t, data, nb_batch, save_iters, saver, checkpoint_dir):
+        """One MrCGAN post epoch (cfl/models/cfl.py:1484-1504): every iteration draws a labeled batch and
+        an unlabeled source / target batch (cfl/bin/train.py:29-40) and updates D and G."""
+        t.set_description('post epoch {}'.format(e))
+        tr = data.train
+        for i in t:
+            labeled = tr.next_batch(self.batch_size)
+            if self.directed or self.data_directed:
+                unl_src, unl_dst = tr.next_source_batch(self.batch_size), tr.next_target_batch(self.batch_size)
+            else:
+                unl_src = unl_dst = tr.next_unlabeled_batch(self.batch_size)
+            self.post_step(labeled, unl_src, unl_dst)
+            if save_iters and i > 0 and i % save_iters == 0 and saver is not None:
+                saver.save(self, os.path.join(checkpoint_dir, 'model'), global_step=nb_batch * e + i)
+            if i % 20 == 0 or i == nb_batch - 1:
+                s = self.gan_phase.read_scalars()
+                t.set_postfix(d_loss=s['d_total_loss'], g_loss=s['g_total_loss'], d_real=s['d_real_accuracy'],
+                              d_fake=s['d_fake_accuracy'])
+        s = self.gan_phase.read_scalars()
+        logger.warning('post epoch %d: d_total %f (real %f fake %f gp %f lat %f) g_total %f (adv %f enc %f neg %f)',
+                       e, s['d_total_loss'], s['d_loss_real'], s['d_loss_fake'], s['d_grad_loss'], s['d_loss_d'],
+                       s['g_total_loss'], s['g_loss'], s['g_loss_d'], s['g_loss_d_neg'])
 
 
 def construct_model(is_double, disable_double, latent_shape, source_shape, input_shape, ae_shape,

@@ -76,14 +76,13 @@ class ConvTrunk(object):
         return plan
 
     def normalize(self, x):
-        """data_normalizer (cfl/ops.py:66-124) on the raw [rows, prod(shape)] pixels; element-wise
-        torch ops are plumbing here (the trunk's first conv reads the result)."""
+        """data_normalizer (cfl/ops.py:66-124) on the raw [rows, prod(shape)] pixels (cfl_ew_affine_clip)."""
+        from .. import hipgan
         n = self.norm
-        if n.mul != 1.0 or n.add != 0.0:
-            x = x * n.mul + n.add
-        if n.has_lo or n.has_hi:
-            x = torch.clamp(x, n.lo if n.has_lo else None, n.hi if n.has_hi else None)
-        return x.contiguous()
+        x = x.contiguous()
+        if n.mul == 1.0 and n.add == 0.0 and not (n.has_lo or n.has_hi):
+            return x
+        return hipgan.affine_clip(x, n)
 
     def forward(self, x_rows):
         """x_rows: [rows, H*W*C] device tensor (already normalised) -> features [rows, F]."""

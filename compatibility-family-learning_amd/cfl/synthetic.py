@@ -51,3 +51,67 @@ def make_dataset(root, D=4096, n_items=2000, n_pos=4000, n_neg=4000, k=3, latent
         make_split(os.path.join(root, name), max(8, int(n_items * frac)) // 2 * 2, D,
                    max(4, int(n_pos * frac)), max(4, int(n_neg * frac)), rng, (protos, lat), scale)
     return root
+
+
+def make_double_dataset(root, image_shape=(16, 16, 3), latent_dim=64, n_items=120, n_pos=160, n_neg=160, k=2,
+                        seed=633, latent_scale=31.9098 / 4.0, raw_latent=True,
+                        splits=(('train', 1.0), ('val', 0.5), ('test', 0.5))):
+    """Image + latent ("double") dataset in the reference's record format (cfl/input_data.py:107-170):
+    id[10] | int32 size1 | int32 size2 | png | latent, plus pairs_pos/neg.txt and source.txt / target.txt
+    (for --data-directed).  Every item's image is a smooth colour pattern decoded from its latent, so the
+    generator has something to learn; positives are planted by a K-prototype teacher on the latents."""
+    import struct
+    from io import BytesIO
+    from .input_data import dump_image
+    rng = np.random.RandomState(seed)
+    H, W, C = image_shape
+    hid = 8
+    lat_basis = (rng.randn(hid, latent_dim) / np.sqrt(hid)).astype(np.float32)
+    img_basis = rng.randn(hid, 4, 4, C).astype(np.float32)
+    protos = [np.linalg.qr(rng.randn(hid, hid))[0].astype(np.float32) for _ in range(k)]
+
+    def render(z):
+        low = np.tensordot(z, img_basis, axes=(1, 0))                 # [n, 4, 4, C]
+        up = low.repeat(H // 4, axis=1).repeat(W // 4, axis=2)
+        return (255.0 / (1.0 + np.exp(-up))).astype(np.uint8)
+
+    for name, frac in splits:
+        path = os.path.join(root, name)
+        os.makedirs(path, exist_ok=True)
+        half = max(8, int(n_items * frac)) // 2
+        z = rng.randn(half, hid).astype(np.float32)
+        which = rng.randint(0, k, size=half)
+        zd = np.stack([z[i] @ protos[which[i]] for i in range(half)]) + 0.1 * rng.randn(half, hid).astype(np.float32)
+        zs = np.concatenate([z, zd]).astype(np.float32)
+        latents = (np.abs(zs @ lat_basis) * latent_scale).astype(np.float32)
+        images = render(zs)
+        ids = ['%010d' % i for i in range(2 * half)]
+        with open(os.path.join(path, 'features.b'), 'wb') as f:
+            for i, a in enumerate(ids):
+                img = BytesIO()
+                dump_image(img, images[i])
+                img = img.getvalue()[4:]                              # dump_image prefixes its own size
+                if raw_latent:
+                    lat = latents[i].astype('<f4').tobytes()
+                else:
+                    b = BytesIO()
+                    np.savez(b, data=latents[i])
+                    lat = b.getvalue()
+                f.write(a.encode('ascii'))
+                f.write(struct.pack('<ii', len(img), len(lat)))
+                f.write(img)
+                f.write(lat)
+        npos, nneg = max(4, int(n_pos * frac)), max(4, int(n_neg * frac))
+        s = rng.randint(0, half, size=npos)
+        pos = np.stack([s, s + half], 1)
+        neg = np.stack([rng.randint(0, half, size=nneg), half + rng.randint(0, half, size=nneg)], 1)
+        neg = neg[neg[:, 0] + half != neg[:, 1]]
+        for fname, pairs in (('pairs_pos.txt', pos), ('pairs_neg.txt', neg)):
+            with open(os.path.join(path, fname), 'w') as f:
+                for a, b in pairs:
+                    f.write('{} match {}\n'.format(ids[a], ids[b]))
+        with open(os.path.join(path, 'source.txt'), 'w') as f:
+            f.writelines(a + '\n' for a in ids[:half])
+        with open(os.path.join(path, 'target.txt'), 'w') as f:
+            f.writelines(a + '\n' for a in ids[half:])
+    return root

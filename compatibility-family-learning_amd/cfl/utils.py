@@ -183,7 +183,9 @@ def _scores(model, data, batch_size, negative):
     """Concatenated scores [n] of all positive (or negative) pairs of a split, through
     the model's scoring entry (``val_s_pos_predicts.outputs`` in the reference)."""
     it = data.whole_neg_batches(batch_size) if negative else data.whole_pos_batches(batch_size)
-    out = [model.predict(src, dst).reshape(-1) for src, dst in it]
+    # double (image + latent) data: the encoder reads the latents (cfl/utils.py:234-244)
+    pick = getattr(model, 'select_pair', lambda b: (b[0], b[1]))
+    out = [model.predict(*pick(b)).reshape(-1) for b in it]
     return np.concatenate(out) if out else np.zeros(0, np.float32)
 
 

@@ -57,6 +57,18 @@ __global__ __launch_bounds__(EW_THREADS) void ew_axpy_kernel(float alpha, const 
         y[i] = fmaf(alpha, x[i], y[i]);
 }
 
+// y = clip(x * mul + add, lo, hi): the normalisers of cfl/ops.py:66-143 on image / latent batches
+__global__ __launch_bounds__(EW_THREADS) void ew_affine_clip_kernel(const float *x, float *y, int64_t n, float mul,
+                                                                    float add, float lo, float hi, int has_lo,
+                                                                    int has_hi) {
+    for (int64_t i = blockIdx.x * (int64_t)EW_THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * EW_THREADS) {
+        float v = fmaf(x[i], mul, add);
+        if (has_lo) v = fmaxf(v, lo);
+        if (has_hi) v = fminf(v, hi);
+        y[i] = v;
+    }
+}
+
 // sub-pixel shuffle (cfl/layers.py:212-250): out[b,2h+i,2w+j,c] = in[b,h,w,(2i+j)*Cq+c], Cq = C/4
 __global__ __launch_bounds__(EW_THREADS) void subpixel_fwd_kernel(const float *x, float *y, int64_t n, int H,
                                                                   int W, int C, int act) {
@@ -282,6 +294,14 @@ extern "C" int cfl_ew_axpy(float alpha, const float *x, float *y, int64_t n, cfl
     if (n == 0) return CFL_OK;
     hipLaunchKernelGGL(ew_axpy_kernel, dim3(ew_blocks(n)), dim3(EW_THREADS), 0, (hipStream_t)stream, alpha, x, y, n);
     return done("ew_axpy");
+}
+
+extern "C" int cfl_ew_affine_clip(const float *x, float *y, int64_t n, const CflNorm *norm, cfl_stream_t stream) {
+    if (!x || !y || !norm || n < 0) return cfl_set_err(CFL_E_SHAPE, "cfl_ew_affine_clip: bad argument");
+    if (n == 0) return CFL_OK;
+    hipLaunchKernelGGL(ew_affine_clip_kernel, dim3(ew_blocks(n)), dim3(EW_THREADS), 0, (hipStream_t)stream, x, y, n,
+                       norm->mul, norm->add, norm->lo, norm->hi, norm->has_lo, norm->has_hi);
+    return done("ew_affine_clip");
 }
 
 extern "C" int cfl_subpixel2x_fwd(const float *x, float *y, int64_t B, int H, int W, int C, int act,

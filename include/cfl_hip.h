@@ -263,6 +263,9 @@ int cfl_ew_act_fwd(const float *x, float *y, int64_t n, int act, cfl_stream_t st
 int cfl_ew_act_bwd(const float *y, const float *dy, float *dx, int64_t n, int act, cfl_stream_t stream);
 int cfl_ew_add_act(const float *a, const float *b, float *y, int64_t n, int act, cfl_stream_t stream);
 int cfl_ew_axpy(float alpha, const float *x, float *y, int64_t n, cfl_stream_t stream);
+/* y = clip(x * mul + add, lo, hi): data / ae / latent normaliser (cfl/ops.py:66-143, 302-349) applied
+ * to a batch that does not enter the fused pair kernels (images for the conv stacks, GAN inputs). */
+int cfl_ew_affine_clip(const float *x, float *y, int64_t n, const CflNorm *norm, cfl_stream_t stream);
 /* conv2d_subpixel scale 2 (cfl/layers.py:212-250): x [B,H,W,C] -> y [B,2H,2W,C/4],
  * y[b,2h+i,2w+j,c] = act(x[b,h,w,(2i+j)*C/4+c]); bwd scatters dy * act'(y) back (y may be NULL
  * when act == CFL_EW_NONE).                                                                  */

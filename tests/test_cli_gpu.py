@@ -89,8 +89,11 @@ def test_cfl_train_predict_linear(dataset, tmp_path):
 
 def test_unbuilt_parts_fail_loudly(dataset, tmp_path):
     from cfl.bin import train
-    with pytest.raises(NotImplementedError, match='MrCGAN'):
-        train.main(_common(dataset, tmp_path) + ['--model-type', 'linear', '--use-threshold', '--gan',
+    with pytest.raises(NotImplementedError, match='cgan'):
+        train.main(_common(dataset, tmp_path) + ['--model-type', 'linear', '--use-threshold', '--gan', '--cgan',
+                                                 '--input-shape', '200'])
+    with pytest.raises(NotImplementedError, match='mirror'):
+        train.main(_common(dataset, tmp_path) + ['--model-type', 'linear', '--use-threshold', '--data-mirror',
                                                  '--input-shape', '200'])
 
 
@@ -166,3 +169,50 @@ def test_cfl_train_conv_model(tmp_path):
     assert v['CFL/DistEncoder/conv1/Conv/V'].shape == (5, 5, 1, 64)
     predict.start(flags + ['--predict-root', str(tmp_path / 'pred')])
     assert (tmp_path / 'pred' / 'syn' / 'img' / name / 'predict_acc.txt').exists()
+
+
+def test_cfl_double_data_then_gan_post_epochs(tmp_path):
+    """experiments/dyadic/run_gen.sh in miniature: distance epochs on an image+latent dataset, then
+    `--load-pre-weights --gan --gan-type srgan --lambda-gp ... --post-epochs` (MrCGAN), then resume."""
+    from cfl.bin import predict, train
+    from cfl.synthetic import make_double_dataset
+    root = tmp_path / 'data'
+    make_double_dataset(str(root / 'dy'), image_shape=(16, 16, 3), latent_dim=64, n_items=120, n_pos=160,
+                        n_neg=160, k=2, seed=5)
+    base = ['--data-name', 'dy', '--data-root', str(root), '--checkpoint-root', str(tmp_path / 'ck'),
+            '--log-root', str(tmp_path / 'logs'), '--model-type', 'linear', '--data-type', 'tanh',
+            '--data-mean', '0.5', '--data-norm', '0.5', '--data-directed', '--latent-norm', '31.9098',
+            '--data-is-image', '--data-is-double', '--raw-latent', '--latent-shape', '64', '--input-shape', '16',
+            '16', '3', '--dist-type', 'pcd', '--lambda-m', '0.5', '--use-threshold', '--num-components', '2',
+            '--latent-size', '8', '--batch-size', '16', '--lr', '0.01', '--seed', '3']
+    train.main(base + ['--epochs', '3', '--reset'])
+    name = 'cfl_pcd_linear_tanh_ls_8_nc_2_ut_norm_0.5_lm_0.5'
+    ck = tmp_path / 'ck' / 'dy' / name
+    epoch, acc, auc = (ck / 'best_model' / 'best_accuracy').read_text().split('\t')
+    assert float(auc) > 0.6
+    gan = ['--m-prj', '0.2', '--m-enc', '0.05', '--d-lr', '0.0002', '--d-beta1', '0.5', '--g-lr', '0.0002',
+           '--g-beta1', '0.5', '--gan', '--gan-type', 'srgan', '--lambda-gp', '0.5', '--z-dim', '6']
+    train.main(base + gan + ['--load-pre-weights', '--epochs', '3', '--post-epochs', '1', '--disable-eval'])
+    gname = name + '_gan_z_6_m_prj_0.2_m_enc_0.05_dra_0.5_0.5_srgan'
+    gck = tmp_path / 'ck' / 'dy' / gname
+    nb = 160 // 16
+    st = torch.load(str(gck / 'model-{}.pt'.format(4 * nb)), weights_only=False)
+    v = st['variables']
+    assert v['CFL/Generator/fc1/fully_connected/V'].shape == (14, 1024)
+    assert v['CFL/Generator/subpixel_block1/Conv/V'].shape == (3, 3, 64, 512)
+    assert v['CFL/Discriminator/conv2/Conv_4/V'].shape == (4, 4, 64, 128)
+    assert v['CFL/Discriminator/latent_outputs/fully_connected/V'].shape[1] == 8
+    # the encoder was warm-started from the no-gan run's best model and stays frozen in the post epoch
+    from cfl.utils import latest_checkpoint
+    best = torch.load(latest_checkpoint(str(ck / 'best_model')) + '.pt', weights_only=False)['variables']
+    k = 'CFL/DistEncoder/outputs/fully_connected/V'
+    assert np.array_equal(v[k], best[k])
+    # the generator moved away from its initialisation and every scalar is finite
+    assert np.isfinite(list(st['gan_powers']['g'])).all()
+    m = st['adam_m']['CFL/Generator/outputs/Conv/V']
+    assert np.isfinite(m).all() and np.abs(m).max() > 0
+    # resume: one more post epoch
+    train.main(base + gan + ['--load-pre-weights', '--epochs', '3', '--post-epochs', '2', '--disable-eval'])
+    assert (gck / 'model-{}.pt'.format(5 * nb)).exists()
+    predict.start(base + ['--predict-root', str(tmp_path / 'pred')])
+    assert (tmp_path / 'pred' / 'dy' / name / 'predict_acc.txt').exists()
