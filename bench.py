@@ -179,6 +179,10 @@ def main():
                 'pool_mib_per_gpu': int(nb * batch_bytes >> 20),
                 'parallelism': 'dp%d' % world if world > 1 else 'single',
                 'final_loss': round(scal['total'], 6),
+                'arithmetic': 'fp32 everywhere; the weight-gradient contraction runs on the bf16 matrix cores with '
+                              'every fp32 operand split exactly in three bf16 values (six partial products, fp32 '
+                              'accumulate; error vs fp64 equal to the fp32-MFMA kernel, tests/test_hip_parity.py); '
+                              'CFL_EXACT_FP32=1 selects k-ordered fp32 MFMA for it',
             },
         }
 

@@ -181,6 +181,37 @@ __device__ __forceinline__ float wave_sum(float x) {
     return x;
 }
 
+// bf16x3 operand splitting (used by the grad x3 kernel below, which documents the numerics)
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void split3(float v, float &h, float &m, float &l) {
+    h = __uint_as_float(__float_as_uint(v) & 0xffff0000u);
+    const float r = v - h;
+    m = __uint_as_float(__float_as_uint(r) & 0xffff0000u);
+    l = r - m;
+}
+// {bf16(e1), bf16(e0)} by truncation: the high halves of the two floats
+__device__ __forceinline__ unsigned pack_hi16(float e0, float e1) {
+    return __builtin_amdgcn_perm(__float_as_uint(e1), __float_as_uint(e0), 0x07060302u);
+}
+// three bf16x8 fragments (levels h, m, l) of the 8 floats v[0..7]
+__device__ __forceinline__ void split_frag(const float (&v)[8], bf16x8 (&f)[3]) {
+    float h[8], m[8], l[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) split3(v[i], h[i], m[i], l[i]);
+    u32x4 ph, pm, pl;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        ph[i] = pack_hi16(h[2 * i], h[2 * i + 1]);
+        pm[i] = pack_hi16(m[2 * i], m[2 * i + 1]);
+        pl[i] = pack_hi16(l[2 * i], l[2 * i + 1]);
+    }
+    f[0] = __builtin_bit_cast(bf16x8, ph);
+    f[1] = __builtin_bit_cast(bf16x8, pm);
+    f[2] = __builtin_bit_cast(bf16x8, pl);
+}
+
 // ---------------------------------------------------------------------------
 // proj: Ypart[s][r][c] = sum_{d in slice s} X[r][d] * W[d][c]
 //   workgroup = 4 waves, one 32-row tile; wave w owns chunks of 128 d (8 groups of
@@ -535,6 +566,128 @@ extern "C" __global__ __launch_bounds__(256) void cfl_grad_kernel(GradArgs a) {
         case 2: grad_body<2>(jb, a, lds); break;
         case 3: grad_body<3>(jb, a, lds); break;
         default: grad_body<4>(jb, a, lds); break;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// grad, bf16x3 variant: the same contraction on the bf16 matrix cores at fp32-level accuracy.
+// Every fp32 operand v is split EXACTLY into three bf16 values v = h + m + l (8 + 8 + 8
+// significand bits, by truncation: h = v & 0xffff0000, m = (v - h) & 0xffff0000, l = v - h - m;
+// both subtractions are exact), and a product a*b is accumulated in fp32 from the six partial
+// products whose weight is >= 2^-16 of it: ah*bh, ah*bm, am*bh, ah*bl, al*bh, am*bm.  The dropped
+// terms (am*bl, al*bm, al*bl) are <= 2^-23 |a*b|, the size of one fp32 rounding.
+// v_mfma_f32_16x16x32_bf16 runs 16x the fp32 MFMA rate, so six of them over K = 32 cost 96
+// cycles against 256 for the eight v_mfma_f32_16x16x4_f32 they replace; the splits are VALU work
+// that co-issues in the MFMA shadows.  Data layouts (row-major x, fragment-major dYf, Wf slabs)
+// and the C/D mapping are those of the fp32 kernel; only the k <-> row assignment inside a
+// 32-row group differs (k = 8*kq + jj <-> row 32*R2 + 8*kq + jj).
+// ---------------------------------------------------------------------------
+template <int NT>
+__device__ __forceinline__ void grad_body_x3(const GradJob &jb, const GradArgs &a, f32x4 *lds) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int i16 = lane & 15, kq = lane >> 4;
+    const int dbase = blockIdx.x * 64;
+    const int p = blockIdx.y;
+    const int RG = a.Rpad >> 4, G = a.D >> 4;
+    const int rows_wg = a.Rpad / a.P, rows_w = rows_wg >> 2;
+    const int rbeg = p * rows_wg + wave * rows_w, rend = rbeg + rows_w;
+    const int r64 = (a.R + 63) & ~63;
+    const int rstop = rend < r64 ? rend : r64;
+
+    f32x4 acc[4][NT];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[t][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // dYf block (nt, rg) holds [kq'][c16][j] <-> row 16rg + 4kq' + j; this lane's k-group covers rows
+    // 32*R2 + 8*kq + jj: rg = 2*R2 + (kq >> 1), kq' = 2*(kq & 1) + (jj >> 2), j = jj & 3.  The dY
+    // fragments are L2 hits that land long before x does, so splitting them costs no wall time.
+    const float *dyl = jb.dyf + ((size_t)(kq >> 1) * 256 + (2 * (kq & 1) * 16 + i16) * 4);
+    for (int p0 = rbeg; p0 < rstop; p0 += 64) {
+        f32x4 dyr[2][NT][2], xr[2][8];
+#pragma unroll
+        for (int r2 = 0; r2 < 2; ++r2)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const float *q = dyl + ((size_t)nt * RG + (p0 >> 4) + 2 * r2) * 256;
+                dyr[r2][nt][0] = *(const f32x4 *)q;
+                dyr[r2][nt][1] = *(const f32x4 *)(q + 64);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r2 = 0; r2 < 2; ++r2) {
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj)
+                xr[r2][jj] = *(const f32x4 *)(row_ptr(jb.x0, jb.x1, p0 + 32 * r2 + 8 * kq + jj, a.B, a.R, a.D) +
+                                              dbase + 4 * i16);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int r2 = 0; r2 < 2; ++r2) {
+            bf16x8 bf[NT][3];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                float v[8];
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) v[jj] = dyr[r2][nt][jj >> 2][jj & 3];
+                split_frag(v, bf[nt]);
+            }
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) xr[r2][jj] = norm_apply(xr[r2][jj], a.norm);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                float v[8];
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) v[jj] = xr[r2][jj][t];
+                bf16x8 af[3];
+                split_frag(v, af);
+                // small terms first; consecutive MFMAs hit different accumulators
+#define CFL_X3(LA, LB)                                                                               \
+    _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) acc[t][nt] =                                   \
+        __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[LA], bf[nt][LB], acc[t][nt], 0, 0, 0);
+                CFL_X3(1, 1) CFL_X3(2, 0) CFL_X3(0, 2) CFL_X3(1, 0) CFL_X3(0, 1) CFL_X3(0, 0)
+#undef CFL_X3
+            }
+        }
+    }
+
+    // cross-wave sum and slab store: identical to the fp32 body (same C/D mapping)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) lds[((wave * NT + nt) * 4 + t) * 64 + lane] = acc[t][nt];
+    __syncthreads();
+    if (wave < NT) {
+        const int nt = wave;
+        f32x4 sum[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            sum[t] = lds[((0 * NT + nt) * 4 + t) * 64 + lane];
+#pragma unroll
+            for (int w = 1; w < 4; ++w) sum[t] += lds[((w * NT + nt) * 4 + t) * 64 + lane];
+        }
+        float *dst = jb.wpart + (size_t)p * jb.pstride + ((size_t)nt * G + (dbase >> 4) + kq) * 256 +
+                     i16 * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            f32x4 v = {sum[0][e], sum[1][e], sum[2][e], sum[3][e]};
+            *(f32x4 *)(dst + e * 64) = v;
+        }
+    }
+}
+
+extern "C" __global__ __launch_bounds__(256) void cfl_grad_x3_kernel(GradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    f32x4 *lds = (f32x4 *)smem;
+    if (blockIdx.z == 0) { grad_red_block(a, (float *)smem); return; }
+    const GradJob &jb = a.job[blockIdx.z - 1];
+    switch (jb.nt) {
+        case 1: grad_body_x3<1>(jb, a, lds); break;
+        case 2: grad_body_x3<2>(jb, a, lds); break;
+        case 3: grad_body_x3<3>(jb, a, lds); break;
+        default: grad_body_x3<4>(jb, a, lds); break;
     }
 }
 
@@ -1773,6 +1926,7 @@ struct Plan {
     int cs_dy[2], cs_cw[2], cs_mono, cs_duc, cs_rowq, cs_total;
     // workspace offsets (floats)
     size_t ypart[2], dyf[2], cwf[2], wpart[2];
+    bool x3;   // bf16x3 matrix-core path for the weight gradient
     size_t mono_ya, mono_du, mono_duc, rowqf, thr_copy, colsum, regpart, n2, total_floats;
     size_t mid_lds;
     int ys;
@@ -1817,6 +1971,11 @@ static int make_plan(const CflShape *s, int64_t rows, int groups, bool train, Pl
         while (P > 1 && pl->R / P < 64) P /= 2;
         if (debug_env("CFL_DEBUG_P") > 0) P = debug_env("CFL_DEBUG_P");
     }
+    // matrix-core arithmetic of the weight-gradient contraction: bf16x3 (fp32-equivalent, default) or,
+    // with CFL_EXACT_FP32=1 in the environment, the k-ordered fp32 FMA chains of v_mfma_f32_16x16x4_f32
+    // (the forward projection always uses the latter: measured, bf16x3 buys nothing there because each
+    // W fragment is shared by only two row tiles, so the splits cost what the MFMAs save)
+    pl->x3 = debug_env("CFL_EXACT_FP32") <= 0;
     pl->P = P;
     pl->Rpad = (int)round_up(pl->R, 256 * P);  // grad: 64-row chunks x 4 waves x P ranges
     // proj d split: one 128-d chunk per wave when that yields enough workgroups
@@ -2182,7 +2341,10 @@ static int run_pairs(const CflShape *s, const CflNorm *norm, const CflLossCfg *l
         ga.nred = nr; ga.red_total = tot; ga.colsum = ws + pl.colsum;
         dim3 grid(s->D / 64, pl.P, nj + 1);
         ProfScope ps(st, CFL_K_GRAD);
-        hipLaunchKernelGGL(cfl_grad_kernel, grid, dim3(256), 4 * 4 * 4 * 64 * sizeof(f32x4), st, ga);
+        if (pl.x3)
+            hipLaunchKernelGGL(cfl_grad_x3_kernel, grid, dim3(256), 4 * 4 * 4 * 64 * sizeof(f32x4), st, ga);
+        else
+            hipLaunchKernelGGL(cfl_grad_kernel, grid, dim3(256), 4 * 4 * 4 * 64 * sizeof(f32x4), st, ga);
     }
 
     // ---- finalize -----------------------------------------------------------

@@ -321,3 +321,34 @@ def test_fused_train_step_equals_fwd_bwd_plus_adam(style, dist, K, L):
         res.append([t.cpu().numpy() for t in (theta, m, v, grad, scal)])
     for a, b in zip(*res):
         assert np.allclose(a, b, rtol=1e-6, atol=1e-9)
+
+
+def test_bf16x3_matrix_core_path_is_fp32_equivalent(monkeypatch):
+    """The weight-gradient contraction runs on the bf16 matrix cores with every fp32 operand split exactly
+    in three bf16 values (6 partial products).  Against the fp64 oracle its error must be the same size as
+    that of the k-ordered fp32 MFMA kernel (CFL_EXACT_FP32=1); the forward is the fp32 kernel either way."""
+    from cfl import hipabi as H
+    from cfl.engine import PairEngine
+    B, D, K, L = 256, 1024, 3, 20
+    cfg = O.EncoderCfg(D=D, L=L, K=K)
+    rng = np.random.RandomState(7)
+    params = O.init_encoder_params(cfg, rng, np.float32)
+    batch = [np.abs(rng.randn(B, D)).astype(np.float32) * 13 for _ in range(4)]
+    p64 = {k: v.astype(np.float64) for k, v in params.items()}
+    xs = tuple(b.astype(np.float64) / 58.388599 for b in batch)
+    sc, grads, _, _, _ = O.train_step_loss_and_grads(cfg, O.LossCfg(), p64, 1e-6, xs)
+    dev = [torch.from_numpy(b).cuda() for b in batch]
+    errs = {}
+    for mode, env in (('x3', '0'), ('fp32', '1')):
+        monkeypatch.setenv('CFL_EXACT_FP32', env)
+        eng = PairEngine(D, L, K, norm=H.make_norm(1 / 58.388599), params=params, batch_size=B)
+        eng.fwd_bwd(dev)
+        g, _, _ = H.unpack_theta(eng.shape, eng.grad)
+        e = {'loss': abs(eng.read_scalars()['total'] - sc['total'])}
+        for k in ('outputs/W', 'proto/W'):
+            e[k] = np.abs(g[k].astype(np.float64) - grads[k]).max() / np.abs(grads[k]).max()
+        errs[mode] = e
+    for k in ('outputs/W', 'proto/W'):
+        assert errs['x3'][k] < 2e-6 and errs['fp32'][k] < 2e-6, errs
+        assert errs['x3'][k] <= 2.0 * errs['fp32'][k] + 1e-7, errs
+    assert errs['x3']['loss'] <= 1e-6 and errs['fp32']['loss'] <= 1e-6, errs
