@@ -233,9 +233,10 @@ def main():
                          'frac': round(alg_flops / avg_s / 1e12 / FP32_MFMA_PEAK_TF, 4)},
             'kernels': kern,
             'timing': 'hipEvent pairs around every launch on the launch stream, separate pass of %d steps; '
-                      'each interval includes the dispatch latency (see event_overhead_us), so rocprofv3 '
-                      'kernel durations are shorter by about that much' % min(args.steps, 500),
-            'event_overhead_us': event_overhead_us,
+                      'each interval includes event + dispatch latency (2-3 us: compare profiles/*kernel_stats.csv; the '
+                      'same interval around a 64-float kernel is reported below), so rocprofv3 kernel durations '
+                      'are shorter' % min(args.steps, 500),
+            'event_interval_of_64_float_kernel_us': event_overhead_us,
         }
     if rank == 0 and not args.no_cpu_baseline and world == 1:
         out['cpu_baseline'] = cpu_baseline(args, args.cpu_seconds)

@@ -11,7 +11,7 @@ import csv, glob, json, os, sys
 from collections import defaultdict
 
 KEYS = {'cfl_proj_kernel': 'proj', 'cfl_mid_row_kernel': 'mid', 'cfl_mid_kernel': 'mid',
-        'cfl_grad_kernel': 'grad', 'cfl_finalize_kernel': 'finalize', 'cfl_adam_kernel': 'adam'}
+        'cfl_grad_kernel': 'grad', 'cfl_grad_x3_kernel': 'grad', 'cfl_finalize_kernel': 'finalize', 'cfl_adam_kernel': 'adam'}
 
 
 def collect(d, counter):
