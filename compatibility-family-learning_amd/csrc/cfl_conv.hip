@@ -82,10 +82,18 @@ struct Im2colX {   // A(m = (b,oh,ow), k = (kh,kw,ci)) = x[b, oh*S+kh-pt, ow*S+k
         if (ih < 0 || ih >= g.H || iw < 0 || iw >= g.W) return 0.f;
         return x[(((size_t)b * g.H + ih) * g.W + iw) * g.Ci + ci];
     }
+    __device__ gg_f32x4 v4(int m, int k) const {   // k .. k+3 = 4 consecutive ci (Ci % 4 == 0)
+        const int ow = m % g.OW, t = m / g.OW, oh = t % g.OH, b = t / g.OH;
+        const int ci = k % g.Ci, t2 = k / g.Ci, kw = t2 % g.KW, kh = t2 / g.KW;
+        const int ih = oh * g.S + kh - g.pt, iw = ow * g.S + kw - g.pl;
+        if (ih < 0 || ih >= g.H || iw < 0 || iw >= g.W) return (gg_f32x4){0.f, 0.f, 0.f, 0.f};
+        return *(const gg_f32x4 *)(x + (((size_t)b * g.H + ih) * g.W + iw) * g.Ci + ci);
+    }
 };
 struct FilterKN {  // B(k, n = co) = V[k][co]
     const float *V; int Co;
     __device__ float operator()(int k, int n) const { return V[(size_t)k * Co + n]; }
+    __device__ gg_f32x4 v4(int k, int n) const { return *(const gg_f32x4 *)(V + (size_t)k * Co + n); }  // n .. n+3
 };
 struct StoreFwd {
     float *y; const float *scale, *bias; int Co, act;
@@ -105,12 +113,32 @@ struct DyGather {  // A(m = (b,ih,iw), k = (kh,kw,co)) = dy_pre[b,(ih+pt-kh)/S,(
         const size_t o = (((size_t)b * g.OH + oh) * g.OW + ow) * g.Co + co;
         return dy[o] * act_slope(y[o], g.act) * scale[co];
     }
+    __device__ gg_f32x4 v4(int m, int k) const {   // k .. k+3 = 4 consecutive co (Co % 4 == 0)
+        const gg_f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        const int iw = m % g.W, t = m / g.W, ih = t % g.H, b = t / g.H;
+        const int co = k % g.Co, t2 = k / g.Co, kw = t2 % g.KW, kh = t2 / g.KW;
+        const int nh = ih + g.pt - kh, nw = iw + g.pl - kw;
+        if (nh < 0 || nw < 0 || nh % g.S || nw % g.S) return zero;
+        const int oh = nh / g.S, ow = nw / g.S;
+        if (oh >= g.OH || ow >= g.OW) return zero;
+        const size_t o = (((size_t)b * g.OH + oh) * g.OW + ow) * g.Co + co;
+        const gg_f32x4 d = *(const gg_f32x4 *)(dy + o), yy = *(const gg_f32x4 *)(y + o),
+                       sc = *(const gg_f32x4 *)(scale + co);
+        gg_f32x4 r;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) r[e] = d[e] * act_slope(yy[e], g.act) * sc[e];
+        return r;
+    }
 };
 struct FilterT {   // B(k = (kh,kw,co), n = ci) = V[kh,kw,ci,co]
     const float *V; ConvGeom g;
     __device__ float operator()(int k, int n) const {
         const int co = k % g.Co, t = k / g.Co;  // t = kh*KW + kw
         return V[((size_t)t * g.Ci + n) * g.Co + co];
+    }
+    __device__ gg_f32x4 v4(int k, int n) const {   // k .. k+3 = 4 consecutive co
+        const int co = k % g.Co, t = k / g.Co;
+        return *(const gg_f32x4 *)(V + ((size_t)t * g.Ci + n) * g.Co + co);
     }
 };
 struct StorePlain {
@@ -120,12 +148,21 @@ struct StorePlain {
 struct Im2colXT {  // A(m = (kh,kw,ci), k = (b,oh,ow)) : the same gather with the roles swapped
     Im2colX f;
     __device__ float operator()(int m, int k) const { return f(k, m); }
+    __device__ gg_f32x4 v4(int m, int k) const { return f.v4(k, m); }   // m .. m+3 = 4 consecutive ci
 };
 struct DyPre {     // B(k = (b,oh,ow), n = co) = dy * act'(y)
     const float *dy, *y; int Co, act;
     __device__ float operator()(int k, int n) const {
         const size_t o = (size_t)k * Co + n;
         return dy[o] * act_slope(y[o], act);
+    }
+    __device__ gg_f32x4 v4(int k, int n) const {   // n .. n+3
+        const size_t o = (size_t)k * Co + n;
+        const gg_f32x4 d = *(const gg_f32x4 *)(dy + o), yy = *(const gg_f32x4 *)(y + o);
+        gg_f32x4 r;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) r[e] = d[e] * act_slope(yy[e], act);
+        return r;
     }
 };
 struct StoreSlab {
@@ -209,8 +246,13 @@ extern "C" int cfl_conv2d_wn_fwd(const CflConv *c, const float *x, const float *
     float *scale = (float *)workspace, *n2 = scale + g.Co;
     const int rows = g.KH * g.KW * g.Ci;
     hipLaunchKernelGGL(conv_scale_kernel, dim3(g.Co), dim3(256), 0, st, V, gain, rows, g.Co, scale, n2);
-    gemm_gather(g.B * g.OH * g.OW, g.Co, rows, gg_klen(rows, 1), Im2colX{x, g}, FilterKN{V, g.Co},
-                StoreFwd{y, scale, bias, g.Co, g.act}, st);
+    const bool vec = (g.Ci % 4 == 0) && (g.Co % 4 == 0);   // 16-byte gathers along the channel dimension
+    if (vec)
+        gemm_gather_modes<GG_VEC_K, GG_VEC_MN>(g.B * g.OH * g.OW, g.Co, rows, gg_klen(rows, 1), Im2colX{x, g},
+                                               FilterKN{V, g.Co}, StoreFwd{y, scale, bias, g.Co, g.act}, st);
+    else
+        gemm_gather(g.B * g.OH * g.OW, g.Co, rows, gg_klen(rows, 1), Im2colX{x, g}, FilterKN{V, g.Co},
+                    StoreFwd{y, scale, bias, g.Co, g.act}, st);
     return hipGetLastError() == hipSuccess ? CFL_OK : cfl_set_err(CFL_E_HIP, "conv fwd launch failed");
 }
 
@@ -233,13 +275,25 @@ extern "C" int cfl_conv2d_wn_bwd(const CflConv *c, const float *x, const float *
     const int rows = g.KH * g.KW * g.Ci;
     const int npix = g.B * g.OH * g.OW;
     hipLaunchKernelGGL(conv_scale_kernel, dim3(g.Co), dim3(256), 0, st, V, gain, rows, g.Co, scale, n2);
-    if (dx)
-        gemm_gather(g.B * g.H * g.W, g.Ci, g.KH * g.KW * g.Co, gg_klen(g.KH * g.KW * g.Co, 1), DyGather{dy, y, scale, g}, FilterT{V, g},
-                    StorePlain{dx, g.Ci}, st);
+    const bool vec = (g.Ci % 4 == 0) && (g.Co % 4 == 0);
+    if (dx) {
+        if (g.Co % 4 == 0)
+            gemm_gather_modes<GG_VEC_K, GG_VEC_K>(g.B * g.H * g.W, g.Ci, g.KH * g.KW * g.Co,
+                                                  gg_klen(g.KH * g.KW * g.Co, 1), DyGather{dy, y, scale, g},
+                                                  FilterT{V, g}, StorePlain{dx, g.Ci}, st);
+        else
+            gemm_gather(g.B * g.H * g.W, g.Ci, g.KH * g.KW * g.Co, gg_klen(g.KH * g.KW * g.Co, 1),
+                        DyGather{dy, y, scale, g}, FilterT{V, g}, StorePlain{dx, g.Ci}, st);
+    }
     if (dV) {
         const int splits = wgrad_splits(g);
-        gemm_gather(rows, g.Co, npix, wgrad_klen(g), Im2colXT{Im2colX{x, g}}, DyPre{dy, y, g.Co, g.act},
-                    StoreSlab{slab, (size_t)rows * g.Co, g.Co}, st);
+        if (vec)
+            gemm_gather_modes<GG_VEC_MN, GG_VEC_MN>(rows, g.Co, npix, wgrad_klen(g), Im2colXT{Im2colX{x, g}},
+                                                    DyPre{dy, y, g.Co, g.act},
+                                                    StoreSlab{slab, (size_t)rows * g.Co, g.Co}, st);
+        else
+            gemm_gather(rows, g.Co, npix, wgrad_klen(g), Im2colXT{Im2colX{x, g}}, DyPre{dy, y, g.Co, g.act},
+                        StoreSlab{slab, (size_t)rows * g.Co, g.Co}, st);
         hipLaunchKernelGGL(conv_wfinal_kernel, dim3(g.Co), dim3(256), 0, st, slab, splits, (size_t)rows * g.Co, V,
                            scale, n2, rows, g.Co, reg_const, dV, gain ? dg : nullptr);
     }
@@ -301,11 +355,24 @@ struct TGatherX {  // A(m = (b,oh,ow) of y, k = (kh,kw,ci)) = x[b,(oh+pt-kh)/S,(
         if (oh >= g.OH || ow >= g.OW) return 0.f;
         return x[(((size_t)b * g.OH + oh) * g.OW + ow) * g.Co + ci];
     }
+    __device__ gg_f32x4 v4(int m, int k) const {   // k .. k+3 = 4 consecutive ci
+        const gg_f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        const int iw = m % g.W, t = m / g.W, ih = t % g.H, b = t / g.H;
+        const int ci = k % g.Co, t2 = k / g.Co, kw = t2 % g.KW, kh = t2 / g.KW;
+        const int nh = ih + g.pt - kh, nw = iw + g.pl - kw;
+        if (nh < 0 || nw < 0 || nh % g.S || nw % g.S) return zero;
+        const int oh = nh / g.S, ow = nw / g.S;
+        if (oh >= g.OH || ow >= g.OW) return zero;
+        return *(const gg_f32x4 *)(x + (((size_t)b * g.OH + oh) * g.OW + ow) * g.Co + ci);
+    }
 };
 struct TFilterFwd {  // B(k = (kh,kw,ci), n = co) = V[kh,kw,co,ci]
     const float *V; int Co, Ci;
     __device__ float operator()(int k, int n) const {
         return V[((size_t)(k / Ci) * Co + n) * Ci + (k % Ci)];
+    }
+    __device__ gg_f32x4 v4(int k, int n) const {   // k .. k+3 = 4 consecutive ci
+        return *(const gg_f32x4 *)(V + ((size_t)(k / Ci) * Co + n) * Ci + (k % Ci));
     }
 };
 struct TIm2colDy {  // A(m = (b,p,q) of x, k = (kh,kw,co)) = dy_pre[b,p*S+kh-pt,q*S+kw-pl,co] (* scale[co])
@@ -318,14 +385,28 @@ struct TIm2colDy {  // A(m = (b,p,q) of x, k = (kh,kw,co)) = dy_pre[b,p*S+kh-pt,
         const size_t o = (((size_t)b * g.H + ih) * g.W + iw) * g.Ci + co;
         return dy[o] * act_slope(y[o], g.act) * (scale ? scale[co] : 1.f);
     }
+    __device__ gg_f32x4 v4(int m, int k) const {   // k .. k+3 = 4 consecutive co
+        const int ow = m % g.OW, t = m / g.OW, oh = t % g.OH, b = t / g.OH;
+        const int co = k % g.Ci, t2 = k / g.Ci, kw = t2 % g.KW, kh = t2 / g.KW;
+        const int ih = oh * g.S + kh - g.pt, iw = ow * g.S + kw - g.pl;
+        if (ih < 0 || ih >= g.H || iw < 0 || iw >= g.W) return (gg_f32x4){0.f, 0.f, 0.f, 0.f};
+        const size_t o = (((size_t)b * g.H + ih) * g.W + iw) * g.Ci + co;
+        const gg_f32x4 d = *(const gg_f32x4 *)(dy + o), yy = *(const gg_f32x4 *)(y + o);
+        gg_f32x4 r;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) r[e] = d[e] * act_slope(yy[e], g.act) * (scale ? scale[co + e] : 1.f);
+        return r;
+    }
 };
 struct TIm2colDyT {
     TIm2colDy f;
     __device__ float operator()(int m, int k) const { return f(k, m); }
+    __device__ gg_f32x4 v4(int m, int k) const { return f.v4(k, m); }   // m .. m+3 = 4 consecutive co
 };
 struct PlainKN {
     const float *p; int ld;
     __device__ float operator()(int k, int n) const { return p[(size_t)k * ld + n]; }
+    __device__ gg_f32x4 v4(int k, int n) const { return *(const gg_f32x4 *)(p + (size_t)k * ld + n); }  // n .. n+3
 };
 
 // dV[t,co,ci] = s dW - (s/n^2)(sum_{t,ci} dW V) V + reg V ; dg[co] = (dW . V)/n
@@ -385,8 +466,12 @@ extern "C" int cfl_conv2d_transpose_wn_fwd(const CflConv *c, const float *x, con
     const int Co = g.Ci, Ci = g.Co, taps = g.KH * g.KW;   // of the transposed layer
     float *scale = (float *)workspace, *n2 = scale + Co;
     hipLaunchKernelGGL(convt_scale_kernel, dim3(Co), dim3(256), 0, st, V, gain, taps, Co, Ci, scale, n2);
-    gemm_gather(g.B * g.H * g.W, Co, taps * Ci, gg_klen(taps * Ci, 1), TGatherX{x, g}, TFilterFwd{V, Co, Ci},
-                StoreFwd{y, scale, bias, Co, g.act}, st);
+    if (Ci % 4 == 0)
+        gemm_gather_modes<GG_VEC_K, GG_VEC_K>(g.B * g.H * g.W, Co, taps * Ci, gg_klen(taps * Ci, 1), TGatherX{x, g},
+                                              TFilterFwd{V, Co, Ci}, StoreFwd{y, scale, bias, Co, g.act}, st);
+    else
+        gemm_gather(g.B * g.H * g.W, Co, taps * Ci, gg_klen(taps * Ci, 1), TGatherX{x, g}, TFilterFwd{V, Co, Ci},
+                    StoreFwd{y, scale, bias, Co, g.act}, st);
     return hipGetLastError() == hipSuccess ? CFL_OK : cfl_set_err(CFL_E_HIP, "transposed conv fwd launch failed");
 }
 
@@ -410,15 +495,26 @@ extern "C" int cfl_conv2d_transpose_wn_bwd(const CflConv *c, const float *x, con
     float *slab = (float *)workspace + 2 * (size_t)Co + 64;
     const int npix_in = g.B * g.OH * g.OW;   // pixels of x
     hipLaunchKernelGGL(convt_scale_kernel, dim3(Co), dim3(256), 0, st, V, gain, taps, Co, Ci, scale, n2);
-    if (dx)
-        gemm_gather(npix_in, Ci, taps * Co, gg_klen(taps * Co, 1), TIm2colDy{dy, y, scale, g}, PlainKN{V, Ci},
-                    StorePlain{dx, Ci}, st);
+    const bool vec = (Ci % 4 == 0) && (Co % 4 == 0);
+    if (dx) {
+        if (vec)
+            gemm_gather_modes<GG_VEC_K, GG_VEC_MN>(npix_in, Ci, taps * Co, gg_klen(taps * Co, 1),
+                                                   TIm2colDy{dy, y, scale, g}, PlainKN{V, Ci}, StorePlain{dx, Ci}, st);
+        else
+            gemm_gather(npix_in, Ci, taps * Co, gg_klen(taps * Co, 1), TIm2colDy{dy, y, scale, g}, PlainKN{V, Ci},
+                        StorePlain{dx, Ci}, st);
+    }
     if (dV) {
         const int klen = wgrad_t_klen(g);
         const int splits = gg_splits(npix_in, klen);
         const size_t welems = (size_t)taps * Co * Ci;
-        gemm_gather(taps * Co, Ci, npix_in, klen, TIm2colDyT{TIm2colDy{dy, y, nullptr, g}}, PlainKN{x, Ci},
-                    StoreSlab{slab, welems, Ci}, st);
+        if (vec)
+            gemm_gather_modes<GG_VEC_MN, GG_VEC_MN>(taps * Co, Ci, npix_in, klen,
+                                                    TIm2colDyT{TIm2colDy{dy, y, nullptr, g}}, PlainKN{x, Ci},
+                                                    StoreSlab{slab, welems, Ci}, st);
+        else
+            gemm_gather(taps * Co, Ci, npix_in, klen, TIm2colDyT{TIm2colDy{dy, y, nullptr, g}}, PlainKN{x, Ci},
+                        StoreSlab{slab, welems, Ci}, st);
         hipLaunchKernelGGL(convt_wfinal_kernel, dim3(Co), dim3(256), 0, st, slab, splits, welems, V, scale, n2,
                            taps, Co, Ci, reg_const, dV, gain ? dg : nullptr);
     }
