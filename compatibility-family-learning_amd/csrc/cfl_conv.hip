@@ -145,10 +145,15 @@ struct StorePlain {
     float *out; int ld;
     __device__ void operator()(int m, int n, float v, int) const { out[(size_t)m * ld + n] = v; }
 };
-struct Im2colXT {  // A(m = (kh,kw,ci), k = (b,oh,ow)) : the same gather with the roles swapped
-    Im2colX f;
-    __device__ float operator()(int m, int k) const { return f(k, m); }
-    __device__ gg_f32x4 v4(int m, int k) const { return f.v4(k, m); }   // m .. m+3 = 4 consecutive ci
+struct Im2colXT {  // A(m = (kh,kw,ci), k = (b,oh,ow)) : the same gather with the roles swapped.
+    // Row m == rows is all ones (rows rows+1 .. rows+3 zero), so that slab row `rows` of the weight
+    // gradient is sum_k dy_pre[k][co] = the bias gradient: no separate pass over dy.
+    Im2colX f; int rows;
+    __device__ float operator()(int m, int k) const { return m < rows ? f(k, m) : (m == rows ? 1.f : 0.f); }
+    __device__ gg_f32x4 v4(int m, int k) const {   // m .. m+3 = 4 consecutive ci
+        if (m >= rows) return (gg_f32x4){m == rows ? 1.f : 0.f, 0.f, 0.f, 0.f};
+        return f.v4(k, m);
+    }
 };
 struct DyPre {     // B(k = (b,oh,ow), n = co) = dy * act'(y)
     const float *dy, *y; int Co, act;
@@ -170,12 +175,13 @@ struct StoreSlab {
     __device__ void operator()(int m, int n, float v, int z) const { slab[z * stride + (size_t)m * ld + n] = v; }
 };
 
-// ---- finalize: dV = s*dW - (s/n^2)(dW.V) V + reg*V ; dg = (dW.V)/n ; db = sum dy_pre --------
+// ---- finalize: dV = s*dW - (s/n^2)(dW.V) V + reg*V ; dg = (dW.V)/n ; db = slab row `rows` ----------
+// one block per output channel (measured: blocking 16 / 64 channels per block for coalescing leaves
+// too few blocks on the narrow layers and is 10x slower)
 __global__ __launch_bounds__(256) void conv_wfinal_kernel(const float *slab, int splits, size_t stride,
                                                           const float *V, const float *scale,
                                                           const float *n2, int rows, int Co, float reg,
-                                                          float *dV, float *dg) {
-    // one block per output channel: c = sum_rows dW * V
+                                                          float *dV, float *dg, float *db) {
     const int co = blockIdx.x;
     float acc = 0.f;
     for (int r = threadIdx.x; r < rows; r += 256) {
@@ -193,7 +199,14 @@ __global__ __launch_bounds__(256) void conv_wfinal_kernel(const float *slab, int
         __syncthreads();
     }
     const float c = red[0], s = scale[co], nn = n2[co];
-    if (threadIdx.x == 0 && dg) dg[co] = c * rsqrtf(nn);
+    if (threadIdx.x == 0) {
+        if (dg) dg[co] = c * rsqrtf(nn);
+        if (db) {
+            float t = 0.f;
+            for (int z = 0; z < splits; ++z) t += slab[z * stride + (size_t)rows * Co + co];
+            db[co] = t;
+        }
+    }
     for (int r = threadIdx.x; r < rows; r += 256) {
         const size_t o = (size_t)r * Co + co;
         dV[o] = s * dV[o] - (s / nn) * c * V[o] + reg * V[o];
@@ -231,7 +244,7 @@ extern "C" size_t cfl_conv_workspace_bytes(const CflConv *c) {
     ConvGeom g;
     if (make_geom(c, &g)) return 0;
     const size_t rows = (size_t)g.KH * g.KW * g.Ci;
-    return (2 * (size_t)g.Co + 64 + (size_t)wgrad_splits(g) * rows * g.Co) * sizeof(float);
+    return (2 * (size_t)g.Co + 64 + (size_t)wgrad_splits(g) * (rows + 4) * g.Co) * sizeof(float);
 }
 
 extern "C" int cfl_conv2d_wn_fwd(const CflConv *c, const float *x, const float *V, const float *gain,
@@ -286,18 +299,20 @@ extern "C" int cfl_conv2d_wn_bwd(const CflConv *c, const float *x, const float *
                         DyGather{dy, y, scale, g}, FilterT{V, g}, StorePlain{dx, g.Ci}, st);
     }
     if (dV) {
+        // M = rows + 4: the extra row block carries the bias gradient (see Im2colXT)
         const int splits = wgrad_splits(g);
+        const size_t sstride = (size_t)(rows + 4) * g.Co;
         if (vec)
-            gemm_gather_modes<GG_VEC_MN, GG_VEC_MN>(rows, g.Co, npix, wgrad_klen(g), Im2colXT{Im2colX{x, g}},
-                                                    DyPre{dy, y, g.Co, g.act},
-                                                    StoreSlab{slab, (size_t)rows * g.Co, g.Co}, st);
+            gemm_gather_modes<GG_VEC_MN, GG_VEC_MN>(rows + 4, g.Co, npix, wgrad_klen(g), Im2colXT{Im2colX{x, g}, rows},
+                                                    DyPre{dy, y, g.Co, g.act}, StoreSlab{slab, sstride, g.Co}, st);
         else
-            gemm_gather(rows, g.Co, npix, wgrad_klen(g), Im2colXT{Im2colX{x, g}}, DyPre{dy, y, g.Co, g.act},
-                        StoreSlab{slab, (size_t)rows * g.Co, g.Co}, st);
-        hipLaunchKernelGGL(conv_wfinal_kernel, dim3(g.Co), dim3(256), 0, st, slab, splits, (size_t)rows * g.Co, V,
-                           scale, n2, rows, g.Co, reg_const, dV, gain ? dg : nullptr);
+            gemm_gather(rows + 4, g.Co, npix, wgrad_klen(g), Im2colXT{Im2colX{x, g}, rows}, DyPre{dy, y, g.Co, g.act},
+                        StoreSlab{slab, sstride, g.Co}, st);
+        hipLaunchKernelGGL(conv_wfinal_kernel, dim3(g.Co), dim3(256), 0, st, slab, splits, sstride, V, scale, n2, rows,
+                           g.Co, reg_const, dV, gain ? dg : nullptr, db);
+    } else if (db) {
+        hipLaunchKernelGGL(conv_bgrad_kernel, dim3(g.Co), dim3(256), 0, st, dy, y, npix, g.Co, g.act, db);
     }
-    if (db) hipLaunchKernelGGL(conv_bgrad_kernel, dim3(g.Co), dim3(256), 0, st, dy, y, npix, g.Co, g.act, db);
     return hipGetLastError() == hipSuccess ? CFL_OK : cfl_set_err(CFL_E_HIP, "conv bwd launch failed");
 }
 
