@@ -141,6 +141,60 @@ struct FilterT {   // B(k = (kh,kw,co), n = ci) = V[kh,kw,ci,co]
         return *(const gg_f32x4 *)(V + ((size_t)t * g.Ci + n) * g.Co + co);
     }
 };
+// ---- stride-2 input gradient by output-pixel parity ------------------------------------------
+// With stride 2 an input pixel (ih, iw) only meets the taps kh == (ih + pt) mod 2, kw == (iw + pl) mod 2,
+// so the plain gather multiplies 3/4 zeros.  Per parity class (ph, pw) = (ih & 1, iw & 1) the gradient is
+// a dense GEMM over the taps kh = 2 kh' + oh0, kw = 2 kw' + ow0 (K = ceil(KH/2) ceil(KW/2) Co).
+struct DyGatherS2 {   // A(m = (b, i, j), k = (kh', kw', co)), input pixel (2i + ph, 2j + pw)
+    const float *dy, *y, *scale; ConvGeom g; int ph, pw, oh0, ow0, KH2, KW2, H2, W2;
+    __device__ bool locate(int m, int k, size_t *o, int *co) const {
+        const int j = m % W2, t = m / W2, i = t % H2, b = t / H2;
+        *co = k % g.Co;
+        const int t2 = k / g.Co, kw = 2 * (t2 % KW2) + ow0, kh = 2 * (t2 / KW2) + oh0;
+        if (kh >= g.KH || kw >= g.KW) return false;
+        const int nh = 2 * i + ph + g.pt - kh, nw = 2 * j + pw + g.pl - kw;   // even by construction
+        if (nh < 0 || nw < 0) return false;
+        const int oh = nh >> 1, ow = nw >> 1;
+        if (oh >= g.OH || ow >= g.OW) return false;
+        *o = (((size_t)b * g.OH + oh) * g.OW + ow) * g.Co + *co;
+        return true;
+    }
+    __device__ float operator()(int m, int k) const {
+        size_t o; int co;
+        if (!locate(m, k, &o, &co)) return 0.f;
+        return dy[o] * act_slope(y[o], g.act) * scale[co];
+    }
+    __device__ gg_f32x4 v4(int m, int k) const {
+        size_t o; int co;
+        if (!locate(m, k, &o, &co)) return (gg_f32x4){0.f, 0.f, 0.f, 0.f};
+        const gg_f32x4 d = *(const gg_f32x4 *)(dy + o), yy = *(const gg_f32x4 *)(y + o),
+                       sc = *(const gg_f32x4 *)(scale + co);
+        gg_f32x4 r;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) r[e] = d[e] * act_slope(yy[e], g.act) * sc[e];
+        return r;
+    }
+};
+struct FilterTS2 {    // B(k = (kh', kw', co), n = ci) = V[2kh'+oh0, 2kw'+ow0, ci, co]
+    const float *V; ConvGeom g; int oh0, ow0, KW2;
+    __device__ float operator()(int k, int n) const {
+        const int co = k % g.Co, t2 = k / g.Co, kw = 2 * (t2 % KW2) + ow0, kh = 2 * (t2 / KW2) + oh0;
+        if (kh >= g.KH || kw >= g.KW) return 0.f;
+        return V[((size_t)(kh * g.KW + kw) * g.Ci + n) * g.Co + co];
+    }
+    __device__ gg_f32x4 v4(int k, int n) const {
+        const int co = k % g.Co, t2 = k / g.Co, kw = 2 * (t2 % KW2) + ow0, kh = 2 * (t2 / KW2) + oh0;
+        if (kh >= g.KH || kw >= g.KW) return (gg_f32x4){0.f, 0.f, 0.f, 0.f};
+        return *(const gg_f32x4 *)(V + ((size_t)(kh * g.KW + kw) * g.Ci + n) * g.Co + co);
+    }
+};
+struct StoreS2 {      // class-local pixel m = (b, i, j) -> dx[b, 2i+ph, 2j+pw, n]
+    float *out; int ld, H, W, H2, W2, ph, pw;
+    __device__ void operator()(int m, int n, float v, int) const {
+        const int j = m % W2, t = m / W2, i = t % H2, b = t / H2;
+        out[(((size_t)b * H + 2 * i + ph) * W + 2 * j + pw) * ld + n] = v;
+    }
+};
 struct StorePlain {
     float *out; int ld;
     __device__ void operator()(int m, int n, float v, int) const { out[(size_t)m * ld + n] = v; }
@@ -290,7 +344,22 @@ extern "C" int cfl_conv2d_wn_bwd(const CflConv *c, const float *x, const float *
     hipLaunchKernelGGL(conv_scale_kernel, dim3(g.Co), dim3(256), 0, st, V, gain, rows, g.Co, scale, n2);
     const bool vec = (g.Ci % 4 == 0) && (g.Co % 4 == 0);
     if (dx) {
-        if (g.Co % 4 == 0)
+        if (g.S == 2 && g.H % 2 == 0 && g.W % 2 == 0) {
+            // four dense sub-problems, one per parity class of the input pixel
+            const int KH2 = (g.KH + 1) / 2, KW2 = (g.KW + 1) / 2, H2 = g.H / 2, W2 = g.W / 2;
+            const int K2 = KH2 * KW2 * g.Co;
+            for (int ph = 0; ph < 2; ++ph)
+                for (int pw = 0; pw < 2; ++pw) {
+                    const int oh0 = (ph + g.pt) & 1, ow0 = (pw + g.pl) & 1;
+                    DyGatherS2 fa{dy, y, scale, g, ph, pw, oh0, ow0, KH2, KW2, H2, W2};
+                    FilterTS2 fb{V, g, oh0, ow0, KW2};
+                    StoreS2 fs{dx, g.Ci, g.H, g.W, H2, W2, ph, pw};
+                    if (g.Co % 4 == 0)
+                        gemm_gather_modes<GG_VEC_K, GG_VEC_K>(g.B * H2 * W2, g.Ci, K2, gg_klen(K2, 1), fa, fb, fs, st);
+                    else
+                        gemm_gather(g.B * H2 * W2, g.Ci, K2, gg_klen(K2, 1), fa, fb, fs, st);
+                }
+        } else if (g.Co % 4 == 0)
             gemm_gather_modes<GG_VEC_K, GG_VEC_K>(g.B * g.H * g.W, g.Ci, g.KH * g.KW * g.Co,
                                                   gg_klen(g.KH * g.KW * g.Co, 1), DyGather{dy, y, scale, g},
                                                   FilterT{V, g}, StorePlain{dx, g.Ci}, st);
