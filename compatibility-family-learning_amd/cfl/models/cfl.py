@@ -155,6 +155,43 @@ class CFL(PairModel):
     def post_step(self, labeled, unl_src, unl_dst):
         self.gan_phase.step(*self.gan_inputs(labeled, unl_src, unl_dst))
 
+    # -- sampling (cfl/models/cfl.py:808-860: s_encoder_sample, g_target, g_prototypes, d_prototypes) --------
+    def _sample_heads(self):
+        from .encoder_heads import FrozenHeads
+        if self._heads is None:
+            self._heads = FrozenHeads(self.engine, self.act_type)
+        return self._heads
+
+    def _sample_z(self, n):
+        import torch
+        return (torch.randn(n, self.z_dim, generator=self._gen, device=self.device) * float(self.z_stddev)).contiguous()
+
+    def generate_prototypes(self, src_rows):
+        """[G(z, prototype_k(src)) for k < K] and the discriminator's sigmoid outputs on them; `src_rows` are
+        raw encoder inputs [n, D] (n = batch_size).  One z is shared by all components, as in the reference
+        graph (self.z)."""
+        import torch
+        from .. import hipgan as G
+        hd = self._sample_heads()
+        x = self.to_device(src_rows)
+        P = hd.prototype_activations(x, 0)
+        z = self._sample_z(x.shape[0])
+        images, preds = [], []
+        for k in range(self.num_components):
+            c = torch.full((x.shape[0],), k, dtype=torch.int32, device=self.device)
+            acts = self.gan_phase.generate(z, G.gather_prototype(P, c))
+            logit, _, _ = self.gan_phase.disc.forward(acts)
+            images.append(acts.cpu().numpy())
+            preds.append(G.act_fwd(logit.contiguous(), 'sigmoid').cpu().numpy())
+        return images, preds
+
+    def generate_target(self, dst_rows):
+        """G(z, activations of the target encoder) (self.g_target)."""
+        hd = self._sample_heads()
+        x = self.to_device(dst_rows)
+        acts = self.gan_phase.generate(self._sample_z(x.shape[0]), hd.activations(x, 1 if self.directed else 0))
+        return acts.cpu().numpy()
+
     # -- ConvPCD: trunk + heads ---------------------------------------------------
     def _pixels(self, x):
         import torch

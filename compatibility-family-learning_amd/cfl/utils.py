@@ -216,6 +216,106 @@ def dist_predict(sess, model, data, batch_size, predict_dir, output_name):
 
 
 # ---------------------------------------------------------------------------
+# sampling grids of the MrCGAN generator (cfl/utils.py:324-462, cfl/ops.py:245-259)
+# ---------------------------------------------------------------------------
+def np_arrange_grid(rows, num_rows, num_cols, image_shape, transpose=False):
+    """cfl/ops.py:245-259: [num_rows*num_cols, H*W*C] -> one [1, rows*H, cols*W, C] image."""
+    rows = np.reshape(rows, (num_rows, num_cols, image_shape[0], image_shape[1], image_shape[2]))
+    if transpose:
+        num_rows, num_cols = num_cols, num_rows
+        rows = np.transpose(rows, (1, 0, 2, 3, 4))
+    height, width = image_shape[0] * num_rows, image_shape[1] * num_cols
+    rows = np.transpose(rows, (0, 1, 3, 2, 4))
+    rows = np.reshape(rows, (num_rows, width, image_shape[0], image_shape[2]))
+    rows = np.transpose(rows, (0, 2, 1, 3))
+    return np.reshape(rows, (1, height, width, image_shape[2]))
+
+
+def imsave(path, image):
+    """scipy.misc.imsave semantics: the array's min..max is stretched to 0..255."""
+    from PIL import Image
+    a = np.asarray(image, np.float64)
+    if a.ndim == 3 and a.shape[2] == 1:
+        a = a[:, :, 0]
+    lo, hi = a.min(), a.max()
+    a = np.zeros_like(a) if hi == lo else (a - lo) * (255.0 / (hi - lo))
+    Image.fromarray(np.clip(np.rint(a), 0, 255).astype(np.uint8)).save(path)
+
+
+def _tile_parts(model, parts, repeats):
+    """Encoder input of a 10-item chunk tiled to batch_size rows + the images (cfl/utils.py:331-340)."""
+    o = 1 if (model.is_double and model.uses_latent) else 0
+    return np.tile(parts[o], (repeats, 1)), parts[0]
+
+
+def dist_sample(sess, model, data, batch_size, sample_dir, output_name):
+    """'project': per chunk of 10 positive pairs, row 0 = the source images, then batch_size/10 rows per
+    component of G(z, prototype_k(source)) (gen_grid_all, cfl/models/cfl.py:1265-1288)."""
+    os.makedirs(sample_dir, exist_ok=True)
+    logger.warning('sample %s...', output_name)
+    repeats, K = batch_size // 10, model.num_components
+    for i, batches in enumerate(data.whole_pos_batches(10)):
+        src = batches[:2] if model.is_double else batches[:1]
+        enc, images = _tile_parts(model, src, repeats)
+        if enc.shape[0] != batch_size:
+            continue
+        protos, _ = model.generate_prototypes(enc)
+        rows = [model.ae_normalizer(images[:10]) if model.ae_normalizer is not None else images[:10]]
+        for r in range(repeats):
+            for k in range(K):
+                rows.append(protos[k][10 * r:10 * r + 10])
+        rows = np.concatenate(rows, 0)
+        if model.ae_unnormalizer is not None:
+            rows = model.ae_unnormalizer(rows)
+        grid = np_arrange_grid(rows, K * repeats + 1, 10, model.ae_shape, transpose=True)[0]
+        imsave(os.path.join(sample_dir, '{}_{:010d}.png'.format(output_name, i)), grid)
+
+
+def dist_sample_near(sess, model, data, batch_size, sample_dir, output_name):
+    """'near': row 0 = the target images, then G(z, encoder(target)) (gen_grid_all_target)."""
+    os.makedirs(sample_dir, exist_ok=True)
+    logger.warning('sample %s...', output_name)
+    repeats = batch_size // 10
+    for i, batches in enumerate(data.whole_pos_batches(10)):
+        dst = batches[2:4] if model.is_double else batches[1:2]
+        enc, images = _tile_parts(model, dst, repeats)
+        if enc.shape[0] != batch_size:
+            continue
+        gen = model.generate_target(enc)
+        rows = np.concatenate([model.ae_normalizer(images[:10]) if model.ae_normalizer is not None else images[:10],
+                               gen[:10 * repeats]], 0)
+        if model.ae_unnormalizer is not None:
+            rows = model.ae_unnormalizer(rows)
+        grid = np_arrange_grid(rows, 1 + repeats, 10, model.ae_shape, transpose=True)[0]
+        imsave(os.path.join(sample_dir, '{}_{:010d}.png'.format(output_name, i)), grid)
+
+
+def dist_sample_project_disc(sess, model, data, batch_size, sample_dir, output_name):
+    """'project_disc': for every positive pair, batch_size samples per component sorted by the
+    discriminator's score, plus the pair's own images (cfl/utils.py:381-462)."""
+    os.makedirs(sample_dir, exist_ok=True)
+    logger.warning('sample %s...', output_name)
+    K = model.num_components
+    o = 1 if (model.is_double and model.uses_latent) else 0
+    per = 2 if model.is_double else 1
+    for batches in data.whole_pos_batches(batch_size, source_ids=True):
+        for item in zip(*batches):
+            enc = np.tile(np.asarray(item[o]).reshape(1, -1), (batch_size, 1))
+            protos, preds = model.generate_prototypes(enc)
+            images = np.concatenate(protos)
+            if model.ae_unnormalizer is not None:
+                images = model.ae_unnormalizer(images)
+            images = np.reshape(images, (images.shape[0], -1))
+            order = np.argsort(-np.concatenate(preds).flatten())
+            grid = np_arrange_grid(images[order], batch_size // 10 * K, 10, model.ae_shape)[0]
+            imsave(os.path.join(sample_dir, '{}_{}.png'.format(output_name, item[-1])), grid)
+            imsave(os.path.join(sample_dir, '{}_{}_src.png'.format(output_name, item[-1])),
+                   np.asarray(item[0]).reshape(model.ae_shape))
+            imsave(os.path.join(sample_dir, '{}_{}_dst.png'.format(output_name, item[-1])),
+                   np.asarray(item[per]).reshape(model.ae_shape))
+
+
+# ---------------------------------------------------------------------------
 # checkpoints: reference directory layout, own tensor container
 # ---------------------------------------------------------------------------
 class Saver(object):

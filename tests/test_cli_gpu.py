@@ -216,3 +216,19 @@ def test_cfl_double_data_then_gan_post_epochs(tmp_path):
     assert (gck / 'model-{}.pt'.format(5 * nb)).exists()
     predict.start(base + ['--predict-root', str(tmp_path / 'pred')])
     assert (tmp_path / 'pred' / 'dy' / name / 'predict_acc.txt').exists()
+    # cfl.bin.sample: grids from the trained generator (experiments/dyadic/sample_gen.sh)
+    from PIL import Image
+    from cfl.bin import sample
+    sb = [f for f in base if f not in ('16',)]    # batch size 16 -> 20 (grids are 10 columns wide)
+    sb = base[:base.index('--batch-size')] + ['--batch-size', '20'] + base[base.index('--batch-size') + 2:]
+    for st in ('project', 'near', 'project_disc'):
+        sample.start(sb + gan + ['--sample-root', str(tmp_path / 'samples'), '--sample-type', st])
+    sdir = tmp_path / 'samples' / 'dy' / gname
+    g = Image.open(str(sdir / 'project' / 'test_0000000000.png'))
+    assert g.size == (16 * (2 * 2 + 1), 16 * 10)          # transposed grid: (K * B/10 + 1) columns of 10 images
+    g = Image.open(str(sdir / 'near' / 'test_0000000000.png'))
+    assert g.size == (16 * 3, 16 * 10)
+    pd = sorted(os.listdir(str(sdir / 'project_disc')))
+    assert any(f.endswith('_src.png') for f in pd) and any(f.endswith('_dst.png') for f in pd)
+    main_png = [f for f in pd if not f.endswith(('_src.png', '_dst.png'))][0]
+    assert Image.open(str(sdir / 'project_disc' / main_png)).size == (160, 16 * 2 * 2)
