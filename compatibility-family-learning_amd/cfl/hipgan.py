@@ -11,7 +11,8 @@ from .hipabi import CflConv, _check, _dev, _stream
 EXPORTS = ('cfl_conv_transpose_workspace_bytes', 'cfl_conv2d_transpose_wn_fwd', 'cfl_conv2d_transpose_wn_bwd',
            'cfl_ew_act_fwd', 'cfl_ew_act_bwd', 'cfl_ew_add_act', 'cfl_ew_axpy', 'cfl_ew_affine_clip', 'cfl_subpixel2x_fwd',
            'cfl_subpixel2x_bwd', 'cfl_concat_cols', 'cfl_gather_prototype', 'cfl_bce_logits',
-           'cfl_rowdist_loss', 'cfl_perturb_workspace_bytes', 'cfl_perturb', 'cfl_grad_penalty')
+           'cfl_rowdist_loss', 'cfl_perturb_workspace_bytes', 'cfl_perturb', 'cfl_grad_penalty', 'cfl_copy_cols',
+           'cfl_tile_concat_channels', 'cfl_tile_concat_channels_bwd')
 
 EW = {None: 0, 'linear': 0, 'lrelu': 1, 'relu': 2, 'tanh': 3, 'sigmoid': 4}
 
@@ -36,6 +37,9 @@ def lib():
     L.cfl_subpixel2x_fwd.argtypes = [vp, vp, i64, i32, i32, i32, i32, vp]
     L.cfl_subpixel2x_bwd.argtypes = [vp, vp, vp, i64, i32, i32, i32, i32, vp]
     L.cfl_concat_cols.argtypes = [vp, i32, vp, i32, i64, vp, vp]
+    L.cfl_copy_cols.argtypes = [vp, i32, i32, vp, i32, i32, i32, i64, vp]
+    L.cfl_tile_concat_channels.argtypes = [vp, i32, vp, i32, i64, i32, vp, vp]
+    L.cfl_tile_concat_channels_bwd.argtypes = [vp, i32, i32, i64, i32, vp, vp, vp]
     L.cfl_gather_prototype.argtypes = [vp, vp, i64, i32, i32, vp, vp]
     L.cfl_bce_logits.argtypes = [vp, i64, f32, f32, vp, vp, vp, i32, vp]
     L.cfl_rowdist_loss.argtypes = [vp, vp, i64, i32, i32, f32, f32, vp, vp, i32, vp]
@@ -129,6 +133,31 @@ def concat_cols(a, b, out=None):
         out = torch.empty(a.shape[0], a.shape[1] + b.shape[1], dtype=torch.float32, device=a.device)
     _check(lib().cfl_concat_cols(_dev(a), a.shape[1], _dev(b), b.shape[1], a.shape[0], _dev(out), _stream()))
     return out
+
+
+def copy_cols(src, src_off, dst, dst_off, ncols):
+    """dst[:, dst_off:dst_off+ncols] = src[:, src_off:src_off+ncols] for row-major 2-D tensors."""
+    _check(lib().cfl_copy_cols(_dev(src), src.shape[1], src_off, _dev(dst), dst.shape[1], dst_off, ncols,
+                               src.shape[0], _stream()))
+    return dst
+
+
+def tile_concat_channels(h, t, C2=None):
+    """h [N,H,W,C1], t [N,C2] (or None: C2 zero channels) -> [N,H,W,C1+C2]."""
+    N, Hh, W, C1 = h.shape
+    C2 = t.shape[1] if t is not None else C2
+    out = torch.empty(N, Hh, W, C1 + C2, dtype=torch.float32, device=h.device)
+    _check(lib().cfl_tile_concat_channels(_dev(h), C1, _opt(t), C2, N, Hh * W, _dev(out), _stream()))
+    return out
+
+
+def tile_concat_channels_bwd(d, C1, need_dh=True, need_dt=True):
+    N, Hh, W, C = d.shape
+    C2 = C - C1
+    dh = torch.empty(N, Hh, W, C1, dtype=torch.float32, device=d.device) if need_dh else None
+    dt = torch.empty(N, C2, dtype=torch.float32, device=d.device) if need_dt else None
+    _check(lib().cfl_tile_concat_channels_bwd(_dev(d), C1, C2, N, Hh * W, _opt(dh), _opt(dt), _stream()))
+    return dh, dt
 
 
 def gather_prototype(P, c):

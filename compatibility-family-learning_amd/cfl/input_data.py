@@ -135,6 +135,8 @@ def dump_image(outfile, image, image_format='png'):
     arr = np.asarray(image)
     if arr.dtype != np.uint8:
         arr = np.clip(np.rint(arr * 255.0), 0, 255).astype(np.uint8)
+    if arr.ndim == 3 and arr.shape[2] == 1:
+        arr = arr[:, :, 0]          # single-channel images are stored as greyscale
     buf = BytesIO()
     Image.fromarray(arr).save(buf, format=image_format)
     outfile.write(struct.pack('<i', buf.getbuffer().nbytes))

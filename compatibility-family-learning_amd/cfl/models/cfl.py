@@ -11,7 +11,7 @@ Adam when --use-threshold is off) -- all inside the fused HIP pair kernels.
 ``--gan`` adds the MrCGAN post epochs (cfl/models/cfl.py:730-806, 951-1063, 1087-1096,
 1484-1504): generator / discriminator stacks and the post-epoch step of cfl.models.mrcgan,
 conditioned on the frozen distance encoder (cfl.models.encoder_heads).  Image and
-image+latent ("double") datasets feed it; the cgan variant (``--cgan``) is not built.
+image+latent ("double") datasets feed it; ``--cgan`` selects the conditional-GAN baseline (optionally ``--t-dim``).
 """
 import logging
 import os
@@ -53,8 +53,6 @@ class CFL(PairModel):
             raise ValueError(model_type)
         if model_type == 'conv' and directed:
             raise NotImplementedError('directed conv encoders are not built yet')
-        if gan and cgan:
-            raise NotImplementedError('the conditional variant (--cgan, cfl/models/cfl.py:747-782) is not built yet')
         if gan and model_type == 'conv':
             raise NotImplementedError('--gan with the conv encoder is not built yet')
         self.ENCODER_SCOPES = ('DistEncoderSrc', 'DistEncoderDst') if directed else ('DistEncoder',)
@@ -95,7 +93,8 @@ class CFL(PairModel):
                 gan_type, self.ae_shape if len(self.ae_shape) == 3 else self.ae_shape + (1,), data_type, z_dim,
                 latent_size, batch_size, self.device, np.random.RandomState(seed + 2), g_lr=g_lr, g_beta1=g_beta1,
                 g_beta2=g_beta2, d_lr=d_lr, d_beta1=d_beta1, d_beta2=d_beta2, lambda_gp=lambda_gp,
-                lambda_dra=lambda_dra, m_enc=m_enc, m_prj=m_prj)
+                lambda_dra=lambda_dra, m_enc=m_enc, m_prj=m_prj, cgan=cgan,
+                c_dim=(head_inputs if t_dim else latent_size) if cgan else None, t_dim=t_dim if cgan else None)
             self._heads = None
             import torch
             self._gen = torch.Generator(device=self.device)
@@ -152,8 +151,34 @@ class CFL(PairModel):
         eps = torch.rand(B, 1, generator=self._gen, device=self.device)
         return real, enc_act, prj_c, neg_c, neg_tgt_act, z.contiguous(), eps
 
-    def post_step(self, labeled, unl_src, unl_dst):
-        self.gan_phase.step(*self.gan_inputs(labeled, unl_src, unl_dst))
+    def cgan_inputs(self, labeled):
+        """Device inputs of GanPhase.step_cgan (cfl/models/cfl.py:747-782): positive / negative TARGET images
+        and the source-side conditions -- the source encoder's activations, or with --t-dim the (normalised)
+        source inputs themselves."""
+        import torch
+        from .. import hipgan as G
+        from .encoder_heads import FrozenHeads
+        if self._heads is None:
+            self._heads = FrozenHeads(self.engine, self.act_type)
+        hd, B = self._heads, self.batch_size
+        lab = self.select_batch(labeled)
+        per = 2 if len(labeled) == 8 else 1
+        an = self.ae_normalizer.to_cfl_norm() if self.ae_normalizer is not None else None
+        img = lambda a: G.affine_clip(self._dev(a), an) if an is not None else self._dev(a)
+        real_pos, real_neg = img(labeled[1 * per]), img(labeled[3 * per])
+        if self.t_dim:
+            cond = lambda a: hd.normalize(self.to_device(a))[:, :self.input_size].contiguous()
+        else:
+            cond = lambda a: hd.activations(self.to_device(a), 0)
+        z = torch.randn(B, self.z_dim, generator=self._gen, device=self.device) * float(self.z_stddev)
+        eps = torch.rand(B, 1, generator=self._gen, device=self.device)
+        return real_pos, real_neg, cond(lab[0]), cond(lab[2]), z.contiguous(), eps
+
+    def post_step(self, labeled, unl_src=None, unl_dst=None):
+        if self.cgan:
+            self.gan_phase.step_cgan(*self.cgan_inputs(labeled))
+        else:
+            self.gan_phase.step(*self.gan_inputs(labeled, unl_src, unl_dst))
 
     # -- sampling (cfl/models/cfl.py:808-860: s_encoder_sample, g_target, g_prototypes, d_prototypes) --------
     def _sample_heads(self):
@@ -174,9 +199,18 @@ class CFL(PairModel):
         from .. import hipgan as G
         hd = self._sample_heads()
         x = self.to_device(src_rows)
+        images, preds = [], []
+        if self.cgan:
+            # cgan: one condition, a fresh z per "prototype" (self.zs[i], cfl/models/cfl.py:831-846)
+            c = hd.normalize(x)[:, :self.input_size].contiguous() if self.t_dim else hd.activations(x, 0)
+            for k in range(self.num_components):
+                acts = self.gan_phase.generate(self._sample_z(x.shape[0]), c)
+                logit, _, _ = self.gan_phase.disc.forward(acts, c)
+                images.append(acts.cpu().numpy())
+                preds.append(G.act_fwd(logit.contiguous(), 'sigmoid').cpu().numpy())
+            return images, preds
         P = hd.prototype_activations(x, 0)
         z = self._sample_z(x.shape[0])
-        images, preds = [], []
         for k in range(self.num_components):
             c = torch.full((x.shape[0],), k, dtype=torch.int32, device=self.device)
             acts = self.gan_phase.generate(z, G.gather_prototype(P, c))
@@ -405,11 +439,14 @@ class CFL(PairModel):
         tr = data.train
         for i in t:
             labeled = tr.next_batch(self.batch_size)
-            if self.directed or self.data_directed:
-                unl_src, unl_dst = tr.next_source_batch(self.batch_size), tr.next_target_batch(self.batch_size)
+            if self.cgan:
+                self.post_step(labeled)
             else:
-                unl_src = unl_dst = tr.next_unlabeled_batch(self.batch_size)
-            self.post_step(labeled, unl_src, unl_dst)
+                if self.directed or self.data_directed:
+                    unl_src, unl_dst = tr.next_source_batch(self.batch_size), tr.next_target_batch(self.batch_size)
+                else:
+                    unl_src = unl_dst = tr.next_unlabeled_batch(self.batch_size)
+                self.post_step(labeled, unl_src, unl_dst)
             if save_iters and i > 0 and i % save_iters == 0 and saver is not None:
                 saver.save(self, os.path.join(checkpoint_dir, 'model'), global_step=nb_batch * e + i)
             if i % 20 == 0 or i == nb_batch - 1:

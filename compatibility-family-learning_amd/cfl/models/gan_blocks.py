@@ -189,13 +189,20 @@ class Generator(_Net):
     """gan_type 'srgan' = SRGenerator, 'conv' = ConvTransposeGenerator.  Input: concat(z, c)."""
 
     def __init__(self, gan_type, ae_shape, in_dim, data_type, rng, device, lr=2e-4, beta1=0.5, beta2=0.999,
-                 dim=64, scope='Generator'):
+                 dim=64, scope='Generator', c_dim=None, t_dim=None):
+        """in_dim = z_dim + c_dim.  With t_dim (cgan --t-dim) the last c_dim input columns first go through
+        the weight-norm layer fc_t (lrelu) (cfl/models/blocks.py:55-64)."""
         super(Generator, self).__init__(device, lr, beta1, beta2)
         self.gan_type, self.ae_shape, self.data_type, self.dim = gan_type, tuple(ae_shape), data_type, dim
         nb, start = up_count(self.ae_shape)
         self.nb, self.start = nb, start
         ch = self.ae_shape[2]
         self.blocks = []
+        self.fc_t = None
+        self.c_dim, self.z_dim = c_dim, (in_dim - c_dim if c_dim else None)
+        if t_dim:
+            self.fc_t = WNLayer(self.pool, scope + '/fc_t/fully_connected', 'fc', 1, 1, c_dim, t_dim, 1, 'lrelu', rng)
+            in_dim = in_dim - c_dim + t_dim
         if gan_type == 'srgan':
             self.fc_dim = dim
             self.fc1 = WNLayer(self.pool, scope + '/fc1/fully_connected', 'fc', 1, 1, in_dim, dim * start * start, 1,
@@ -227,6 +234,15 @@ class Generator(_Net):
         """zc [N, z_dim + c_dim] -> (activations [N, prod(ae_shape)], tape)."""
         N = zc.shape[0]
         tape = []
+        if self.fc_t is not None:
+            c = torch.empty(N, self.c_dim, dtype=torch.float32, device=self.device)
+            G.copy_cols(zc, self.z_dim, c, 0, self.c_dim)
+            ct = self.fc_t.fwd(c.view(N, 1, 1, -1), self.ws)
+            tape.append(('fc_t', c.view(N, 1, 1, -1), ct))
+            zt = torch.empty(N, self.z_dim + self.fc_t.co, dtype=torch.float32, device=self.device)
+            G.copy_cols(zc, 0, zt, 0, self.z_dim)
+            G.copy_cols(ct.view(N, -1), 0, zt, self.z_dim, self.fc_t.co)
+            zc = zt
         x = zc.view(N, 1, 1, -1)
         h = self.fc1.fwd(x, self.ws)
         tape.append(('layer', self.fc1, x, h))
@@ -260,10 +276,15 @@ class Generator(_Net):
                 _, act, s = item
                 shape = s.shape if s is not None else (N,) + self.ae_shape
                 d = G.subpixel_bwd(s, d.reshape(shape), act)
+            elif item[0] == 'fc_t':
+                _, c, ct = item      # d = d loss / d [z | fc_t(c)]: only the fc_t columns carry on
+                dct = torch.empty(N, self.fc_t.co, dtype=torch.float32, device=self.device)
+                G.copy_cols(d.reshape(N, -1), self.z_dim, dct, 0, self.fc_t.co)
+                self.fc_t.bwd(c, ct, dct.view(ct.shape), self.ws, need_dx=False, need_dw=True, grad=self.pool.grad)
             else:
                 _, layer, x, y = item
-                d = layer.bwd(x, y, d.reshape(y.shape), self.ws, need_dx=layer is not self.fc1, need_dw=True,
-                              grad=self.pool.grad)
+                need_dx = layer is not self.fc1 or self.fc_t is not None
+                d = layer.bwd(x, y, d.reshape(y.shape), self.ws, need_dx=need_dx, need_dw=True, grad=self.pool.grad)
 
 
 class Discriminator(_Net):
@@ -271,12 +292,23 @@ class Discriminator(_Net):
     and latent_outputs (latent_size)."""
 
     def __init__(self, gan_type, ae_shape, latent_size, rng, device, lr=2e-4, beta1=0.5, beta2=0.999,
-                 scope='Discriminator'):
+                 scope='Discriminator', c_dim=None, t_dim=None):
+        """c_dim: width of the cgan condition t, tiled over the feature map and concatenated in front of
+        the down-sampling conv of stage 3 (srgan, cfl/models/blocks.py:182-195; images >= 64 pixels only) or
+        after conv(nb-1) (conv, :382-395); with t_dim it first goes through <stage>/fc_t (lrelu)."""
         super(Discriminator, self).__init__(device, lr, beta1, beta2)
         self.gan_type, self.ae_shape, self.latent_size = gan_type, tuple(ae_shape), latent_size
         nb, _ = up_count(self.ae_shape)
         h, w, ch = self.ae_shape
-        self.stages = []   # srgan: [(res convs a1,b1,a2,b2, down)]
+        self.stages = []   # [(res conv pairs, down conv)]
+        self.cond_stage, self.fc_t, self.t_channels = None, None, 0
+
+        def cond(stage_scope):
+            self.t_channels = t_dim or c_dim
+            if t_dim:
+                self.fc_t = WNLayer(self.pool, stage_scope + 'fc_t/fully_connected', 'fc', 1, 1, c_dim, t_dim, 1,
+                                    'lrelu', rng)
+            return self.t_channels
         if gan_type == 'srgan':
             dim = 32
             self.stem = WNLayer(self.pool, scope + '/conv/Conv', 'conv', 4, 4, ch, dim, 2, 'lrelu', rng)
@@ -289,7 +321,11 @@ class Discriminator(_Net):
                     a = WNLayer(self.pool, s + cn(2 * j), 'conv', 3, 3, dim, dim, 1, 'lrelu', rng)
                     b = WNLayer(self.pool, s + cn(2 * j + 1), 'conv', 3, 3, dim, dim, 1, None, rng)
                     res.append((a, b))
-                down = WNLayer(self.pool, s + cn(4), 'conv', 4, 4, dim, dim * 2, 2, 'lrelu', rng)
+                extra = 0
+                if c_dim and i == 3:
+                    self.cond_stage = i          # concat BEFORE this stage's down conv
+                    extra = cond(s)
+                down = WNLayer(self.pool, s + cn(4), 'conv', 4, 4, dim + extra, dim * 2, 2, 'lrelu', rng)
                 self.stages.append((res, down))
                 dim *= 2
                 h, w = -(-h // 2), -(-w // 2)
@@ -301,6 +337,9 @@ class Discriminator(_Net):
                 down = WNLayer(self.pool, scope + '/conv%d/Conv' % (i + 1), 'conv', 5, 5, ci, dim, 2, 'lrelu', rng)
                 self.stages.append(([], down))
                 ci, dim = dim, min(dim * 2, 512)
+                if c_dim and i == nb - 2:
+                    self.cond_stage = i + 1      # concat AFTER conv(i+1) = before the next stage's conv
+                    ci += cond(scope + '/conv%d/' % (i + 1))
                 h, w = -(-h // 2), -(-w // 2)
             feat = h * w * ci
         else:
@@ -311,8 +350,8 @@ class Discriminator(_Net):
                                 1, None, rng)
         self.pool.finalize()
 
-    # tape entries: ('conv', layer, x, y) | ('res', a, b, h, r1, r2, out)
-    def forward(self, x_flat):
+    # tape entries: ('conv', layer, x, y) | ('res', a, b, h, r1, r2, out) | ('tcat', C1, t_in, t_out)
+    def forward(self, x_flat, t=None):
         N = x_flat.shape[0]
         tape = []
         h = x_flat.view((N,) + self.ae_shape)
@@ -320,13 +359,21 @@ class Discriminator(_Net):
             y = self.stem.fwd(h, self.ws)
             tape.append(('conv', self.stem, h, y))
             h = y
-        for res, down in self.stages:
+        for si, (res, down) in enumerate(self.stages):
             for a, b in res:
                 r1 = a.fwd(h, self.ws)
                 r2 = b.fwd(r1, self.ws)
                 out = G.add_act(r2, h, 'lrelu')
                 tape.append(('res', a, b, h, r1, r2, out))
                 h = out
+            if self.cond_stage == si:
+                if t is None:
+                    raise H.CflHipError('this discriminator is conditional: pass t')
+                t_in = t.contiguous()
+                t_out = self.fc_t.fwd(t_in.view(N, 1, 1, -1), self.ws).view(N, -1) if self.fc_t is not None else t_in
+                C1 = h.shape[3]
+                h = G.tile_concat_channels(h, t_out)
+                tape.append(('tcat', C1, t_in, t_out))
             y = down.fwd(h, self.ws)
             tape.append(('conv', down, h, y))
             h = y
@@ -361,6 +408,14 @@ class Discriminator(_Net):
         first_layer = tape[0][1]
         d = None
         for item in reversed(tape):
+            if item[0] == 'tcat':
+                _, C1, t_in, t_out = item
+                dh, dt = G.tile_concat_channels_bwd(d.contiguous(), C1, True, need_dw and self.fc_t is not None)
+                if dt is not None:
+                    self.fc_t.bwd(t_in[lo:hi].view(n, 1, 1, -1), t_out[lo:hi].view(n, 1, 1, -1),
+                                  dt.view(n, 1, 1, -1), self.ws, False, True, grad)
+                d = dh
+                continue
             if item[0] == 'conv':
                 _, layer, x, y = item
                 d = df.view(y[lo:hi].shape) if d is None else d
@@ -401,6 +456,9 @@ class Discriminator(_Net):
         it = iter(reversed(rec))
         v = v.view((n,) + self.ae_shape)
         for item in tape:
+            if item[0] == 'tcat':
+                v = G.tile_concat_channels(v.contiguous(), None, self.t_channels)   # t does not depend on X_hat
+                continue
             if item[0] == 'conv':
                 _, layer, x, y = item
                 dy = next(it)
@@ -424,3 +482,5 @@ class Discriminator(_Net):
             self.pool.view(layer_bias, grad).zero_()
         for w in ('V', 'g'):
             self.lat_head.p(w, grad).zero_()
+            if self.fc_t is not None:
+                self.fc_t.p(w, grad).zero_()

@@ -1,4 +1,4 @@
-"""The MrCGAN post-epoch step (non-cgan branch) on the GPU.
+"""The MrCGAN post-epoch step on the GPU (MrCGAN branch and the conditional-GAN baseline `--cgan`).
 
 Graph:   cfl/models/cfl.py:784-806   g = G(z, enc_dst(unlabeled target)), g_prj = G(z, one prototype of
                                       the unlabeled source), g_neg = G(z, one prototype of the negative
@@ -12,6 +12,10 @@ discriminator evaluations one batched forward (rows [real | g | g_prj | g_neg | 
 normalisation has no cross-sample statistics, so batching is exact.  Backward passes run on the row
 ranges that carry gradient: d-loss on [real | g | g_prj] (variables only), g-loss on [g | g_prj | g_neg]
 (inputs only, then through the generator), gradient penalty on [X_hat].
+
+--cgan (cfl/models/cfl.py:747-782, 969-981, 1022-1038): g = G(z, c_pos), g_int = G(z[:B/2], (c_pos[:B/2] + c_pos[B/2:])/2);
+D(x, t) on (pos target, c_pos) / (g, c_pos) / (neg target, c_neg) / (g_int, c_half) / (X_hat, c_pos);
+d = BCE(real,1) + (BCE(fake,0) + BCE(neg,0))/2 + GP;  g = BCE(fake,1) + BCE(int,1).
 """
 import numpy as np
 import torch
@@ -19,7 +23,8 @@ import torch
 from .. import hipgan as G
 from .gan_blocks import Discriminator, Generator
 
-# indices into GanPhase.scalars (device floats)
+# indices into GanPhase.scalars (device floats); the cgan branch reuses S_D_PRJ for d_loss_neg and
+# S_G_PRJ for g_loss_int
 S_D_REAL, S_D_ENC, S_D_PRJ, S_D_GP, S_D_LAT, S_G_ENC, S_G_PRJ, S_G_LAT, S_G_NEG, S_FRAC_REAL, S_FRAC_FAKE, \
     S_FRAC_PRJ = range(12)
 
@@ -27,14 +32,26 @@ S_D_REAL, S_D_ENC, S_D_PRJ, S_D_GP, S_D_LAT, S_G_ENC, S_G_PRJ, S_G_LAT, S_G_NEG,
 class GanPhase(object):
     def __init__(self, gan_type, ae_shape, data_type, z_dim, latent_size, batch_size, device, rng,
                  g_lr=2e-4, g_beta1=0.5, g_beta2=0.999, d_lr=2e-4, d_beta1=0.5, d_beta2=0.999,
-                 lambda_gp=None, lambda_dra=0.5, m_enc=None, m_prj=None):
+                 lambda_gp=None, lambda_dra=0.5, m_enc=None, m_prj=None, cgan=False, c_dim=None, t_dim=None):
+        """cgan: conditional-GAN baseline; c_dim = width of the condition (latent_size, or the raw source
+        latent size with t_dim, which then adds the fc_t layers)."""
         self.gan_type, self.ae_shape, self.data_type = gan_type, tuple(ae_shape), data_type
         self.z_dim, self.latent_size, self.B = z_dim, latent_size, batch_size
         self.device = device
         self.lambda_gp, self.lambda_dra, self.m_enc, self.m_prj = lambda_gp, lambda_dra, m_enc, m_prj
-        self.gen = Generator(gan_type, ae_shape, z_dim + latent_size, data_type, rng, device, g_lr, g_beta1,
-                             g_beta2)
-        self.disc = Discriminator(gan_type, ae_shape, latent_size, rng, device, d_lr, d_beta1, d_beta2)
+        self.cgan = bool(cgan)
+        self.c_dim = (c_dim or latent_size) if cgan else latent_size
+        if cgan:
+            if batch_size % 2:
+                raise ValueError('--cgan needs an even batch size (cfl/models/cfl.py:752)')
+            self.gen = Generator(gan_type, ae_shape, z_dim + self.c_dim, data_type, rng, device, g_lr, g_beta1,
+                                 g_beta2, c_dim=self.c_dim, t_dim=t_dim)
+            self.disc = Discriminator(gan_type, ae_shape, latent_size, rng, device, d_lr, d_beta1, d_beta2,
+                                      c_dim=self.c_dim, t_dim=t_dim)
+        else:
+            self.gen = Generator(gan_type, ae_shape, z_dim + latent_size, data_type, rng, device, g_lr, g_beta1,
+                                 g_beta2)
+            self.disc = Discriminator(gan_type, ae_shape, latent_size, rng, device, d_lr, d_beta1, d_beta2)
         self.scalars = torch.zeros(16, dtype=torch.float32, device=device)
         self.ae_size = int(np.prod(self.ae_shape))
 
@@ -99,8 +116,71 @@ class GanPhase(object):
             gen.adam()
         return sc
 
+    def step_cgan(self, real_pos, real_neg, pos_c, neg_c, z, eps, apply=True):
+        """One post-epoch iteration of the --cgan branch.  real_pos / real_neg: ae-normalised positive / negative
+        TARGET images [B, prod(ae_shape)]; pos_c / neg_c [B, c_dim]: the conditions (source side)."""
+        B, sc, hb = self.B, self.scalars, self.B // 2
+        gen, disc = self.gen, self.disc
+        cd = self.c_dim
+        # conditions of the rows [real | g | neg | int | X_hat]
+        half = pos_c[:hb].clone()
+        G.axpy(1.0, pos_c[hb:], half)
+        half.mul_(0.5)              # (c[:B/2] + c[B/2:]) / 2  (in-place scale of a scratch tensor: plumbing)
+        nrow = 3 * B + hb + (B if self.lambda_gp else 0)
+        t_all = torch.empty(nrow, cd, dtype=torch.float32, device=self.device)
+        t_all[0:B].copy_(pos_c)
+        t_all[B:2 * B].copy_(pos_c)
+        t_all[2 * B:3 * B].copy_(neg_c)
+        t_all[3 * B:3 * B + hb].copy_(half)
+        if self.lambda_gp:
+            t_all[3 * B + hb:].copy_(pos_c)
+        # generator rows [g | g_int]
+        zc = torch.empty(B + hb, self.z_dim + cd, dtype=torch.float32, device=self.device)
+        G.concat_cols(z, pos_c, out=zc[:B])
+        G.concat_cols(z[:hb], half, out=zc[B:])
+        fake, g_tape = gen.forward(zc)
+        x_all = torch.empty(nrow, self.ae_size, dtype=torch.float32, device=self.device)
+        x_all[0:B].copy_(real_pos)
+        x_all[B:2 * B].copy_(fake[:B])
+        x_all[2 * B:3 * B].copy_(real_neg)
+        x_all[3 * B:3 * B + hb].copy_(fake[B:])
+        if self.lambda_gp:
+            G.perturb(real_pos, eps, self.lambda_dra, out=x_all[3 * B + hb:])
+        d_logit, _, d_tape = disc.forward(x_all, t_all)
+
+        dd = torch.zeros(3 * B, 1, dtype=torch.float32, device=self.device)
+        G.bce_logits(d_logit[0:B], 1.0, 1.0, sc[S_D_REAL:S_D_REAL + 1], sc[S_FRAC_REAL:S_FRAC_REAL + 1], dd[0:B])
+        G.bce_logits(d_logit[B:2 * B], 0.0, 0.5, sc[S_D_ENC:S_D_ENC + 1], sc[S_FRAC_FAKE:S_FRAC_FAKE + 1], dd[B:2 * B])
+        G.bce_logits(d_logit[2 * B:3 * B], 0.0, 0.5, sc[S_D_PRJ:S_D_PRJ + 1], None, dd[2 * B:3 * B])
+        disc.backward(d_tape, 0, 3 * B, dd, None, need_dx=False, need_dw=True, grad=disc.pool.grad)
+        if self.lambda_gp:
+            disc.gp_grads(d_tape, 3 * B + hb, nrow, self.lambda_gp, sc[S_D_GP:S_D_GP + 1], disc.pool.grad2)
+            G.axpy(1.0, disc.pool.grad2, disc.pool.grad)
+
+        gd1 = torch.zeros(B, 1, dtype=torch.float32, device=self.device)
+        gd2 = torch.zeros(hb, 1, dtype=torch.float32, device=self.device)
+        G.bce_logits(d_logit[B:2 * B], 1.0, 1.0, sc[S_G_ENC:S_G_ENC + 1], None, gd1)
+        G.bce_logits(d_logit[3 * B:3 * B + hb], 1.0, 1.0, sc[S_G_PRJ:S_G_PRJ + 1], None, gd2)
+        d_img = torch.empty(B + hb, self.ae_size, dtype=torch.float32, device=self.device)
+        d_img[:B].copy_(disc.backward(d_tape, B, 2 * B, gd1, None, need_dx=True, need_dw=False))
+        d_img[B:].copy_(disc.backward(d_tape, 3 * B, 3 * B + hb, gd2, None, need_dx=True, need_dw=False))
+        gen.backward(g_tape, d_img)
+        if apply:
+            disc.adam()
+            gen.adam()
+        return sc
+
     def read_scalars(self):
         s = self.scalars.detach().cpu().numpy()
+        if self.cgan:
+            out = {'d_loss_real': float(s[S_D_REAL]), 'd_loss_fake': float(2.0 * s[S_D_ENC]),
+                   'd_loss_neg': float(2.0 * s[S_D_PRJ]), 'd_grad_loss': float(s[S_D_GP]) if self.lambda_gp else 0.0,
+                   'g_loss': float(s[S_G_ENC]), 'g_loss_int': float(s[S_G_PRJ]),
+                   'd_real_accuracy': float(s[S_FRAC_REAL]), 'd_fake_accuracy': float(1.0 - s[S_FRAC_FAKE]),
+                   'g_accuracy': float(s[S_FRAC_FAKE]), 'd_loss_d': 0.0, 'g_loss_d': 0.0, 'g_loss_d_neg': 0.0}
+            out['d_total_loss'] = out['d_loss_real'] + 0.5 * (out['d_loss_fake'] + out['d_loss_neg']) + out['d_grad_loss']
+            out['g_total_loss'] = out['g_loss'] + out['g_loss_int']
+            return out
         out = {
             'd_loss_real': float(s[S_D_REAL]), 'd_loss_fake': float(s[S_D_ENC] + s[S_D_PRJ]),
             'd_grad_loss': float(s[S_D_GP]) if self.lambda_gp else 0.0, 'd_loss_d': float(s[S_D_LAT]),

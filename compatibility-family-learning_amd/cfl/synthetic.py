@@ -55,9 +55,10 @@ def make_dataset(root, D=4096, n_items=2000, n_pos=4000, n_neg=4000, k=3, latent
 
 def make_double_dataset(root, image_shape=(16, 16, 3), latent_dim=64, n_items=120, n_pos=160, n_neg=160, k=2,
                         seed=633, latent_scale=31.9098 / 4.0, raw_latent=True,
-                        splits=(('train', 1.0), ('val', 0.5), ('test', 0.5))):
+                        splits=(('train', 1.0), ('val', 0.5), ('test', 0.5)), double=True):
     """Image + latent ("double") dataset in the reference's record format (cfl/input_data.py:107-170):
-    id[10] | int32 size1 | int32 size2 | png | latent, plus pairs_pos/neg.txt and source.txt / target.txt
+    id[10] | int32 size1 | int32 size2 | png | latent (double=False: image-only records id | int32 size | png,
+    cfl/input_data.py:34-84), plus pairs_pos/neg.txt and source.txt / target.txt
     (for --data-directed).  Every item's image is a smooth colour pattern decoded from its latent, so the
     generator has something to learn; positives are planted by a K-prototype teacher on the latents."""
     import struct
@@ -98,9 +99,13 @@ def make_double_dataset(root, image_shape=(16, 16, 3), latent_dim=64, n_items=12
                     np.savez(b, data=latents[i])
                     lat = b.getvalue()
                 f.write(a.encode('ascii'))
-                f.write(struct.pack('<ii', len(img), len(lat)))
-                f.write(img)
-                f.write(lat)
+                if double:
+                    f.write(struct.pack('<ii', len(img), len(lat)))
+                    f.write(img)
+                    f.write(lat)
+                else:
+                    f.write(struct.pack('<i', len(img)))
+                    f.write(img)
         npos, nneg = max(4, int(n_pos * frac)), max(4, int(n_neg * frac))
         s = rng.randint(0, half, size=npos)
         pos = np.stack([s, s + half], 1)

@@ -110,6 +110,47 @@ __global__ __launch_bounds__(EW_THREADS) void concat_cols_kernel(const float *a,
     }
 }
 
+// conditioning of the cgan discriminator (cfl/models/blocks.py:182-195, 382-395):
+// out[p, :C1] = h[p, :], out[p, C1:] = t[p / HW, :]   (tile over the HW pixels of a sample + channel concat)
+__global__ __launch_bounds__(EW_THREADS) void tile_concat_kernel(const float *h, int C1, const float *t, int C2,
+                                                                 int64_t pixels, int HW, float *out) {
+    const int C = C1 + C2;
+    const int64_t n = pixels * C;
+    for (int64_t i = blockIdx.x * (int64_t)EW_THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * EW_THREADS) {
+        const int64_t p = i / C;
+        const int c = (int)(i % C);
+        out[i] = c < C1 ? h[p * C1 + c] : (t ? t[(p / HW) * C2 + (c - C1)] : 0.f);
+    }
+}
+// backward: dh[p, :] = d[p, :C1];  dt[n, c] = sum over the HW pixels of sample n of d[p, C1 + c]
+__global__ __launch_bounds__(EW_THREADS) void split_channels_kernel(const float *d, int C1, int C2, int64_t pixels,
+                                                                    float *dh) {
+    const int C = C1 + C2;
+    const int64_t n = pixels * C1;
+    for (int64_t i = blockIdx.x * (int64_t)EW_THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * EW_THREADS)
+        dh[i] = d[(i / C1) * C + (i % C1)];
+}
+__global__ __launch_bounds__(EW_THREADS) void tile_sum_kernel(const float *d, int C1, int C2, int HW, float *dt) {
+    // one block per sample; fixed-order sum over its pixels
+    const int C = C1 + C2;
+    const int64_t base = (int64_t)blockIdx.x * HW;
+    for (int c = threadIdx.x; c < C2; c += EW_THREADS) {
+        float acc = 0.f;
+        for (int p = 0; p < HW; ++p) acc += d[(base + p) * C + C1 + c];
+        dt[(int64_t)blockIdx.x * C2 + c] = acc;
+    }
+}
+// generic strided 2-D copy: dst[r, doff + c] = src[r, soff + c], c < ncols (column slices / concats)
+__global__ __launch_bounds__(EW_THREADS) void copy_cols_kernel(const float *src, int sld, int soff, float *dst, int dld,
+                                                               int doff, int ncols, int64_t rows) {
+    const int64_t n = rows * ncols;
+    for (int64_t i = blockIdx.x * (int64_t)EW_THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * EW_THREADS) {
+        const int64_t r = i / ncols;
+        const int c = (int)(i % ncols);
+        dst[r * dld + doff + c] = src[r * sld + soff + c];
+    }
+}
+
 // one_prototype_activations = gather_nd(P, stack([range(B), c])) (cfl/models/base.py, cfl.py:546)
 __global__ __launch_bounds__(EW_THREADS) void gather_proto_kernel(const float *P, const int32_t *c, int64_t B,
                                                                   int K, int L, float *out) {
@@ -330,6 +371,37 @@ extern "C" int cfl_concat_cols(const float *a, int na, const float *b, int nb, i
     hipLaunchKernelGGL(concat_cols_kernel, dim3(ew_blocks(rows * (na + nb))), dim3(EW_THREADS), 0, (hipStream_t)stream,
                        a, na, b, nb, rows, out);
     return done("concat_cols");
+}
+
+extern "C" int cfl_tile_concat_channels(const float *h, int C1, const float *t, int C2, int64_t samples, int HW,
+                                        float *out, cfl_stream_t stream) {
+    if (!h || !out || C1 <= 0 || C2 <= 0 || samples <= 0 || HW <= 0)
+        return cfl_set_err(CFL_E_SHAPE, "cfl_tile_concat_channels: bad argument");
+    const int64_t pixels = samples * HW;
+    hipLaunchKernelGGL(tile_concat_kernel, dim3(ew_blocks(pixels * (C1 + C2))), dim3(EW_THREADS), 0, (hipStream_t)stream,
+                       h, C1, t, C2, pixels, HW, out);
+    return done("tile_concat_channels");
+}
+
+extern "C" int cfl_tile_concat_channels_bwd(const float *d, int C1, int C2, int64_t samples, int HW, float *dh,
+                                            float *dt, cfl_stream_t stream) {
+    if (!d || C1 <= 0 || C2 <= 0 || samples <= 0 || HW <= 0 || (!dh && !dt))
+        return cfl_set_err(CFL_E_SHAPE, "cfl_tile_concat_channels_bwd: bad argument");
+    const int64_t pixels = samples * HW;
+    hipStream_t st = (hipStream_t)stream;
+    if (dh) hipLaunchKernelGGL(split_channels_kernel, dim3(ew_blocks(pixels * C1)), dim3(EW_THREADS), 0, st, d, C1, C2, pixels, dh);
+    if (dt) hipLaunchKernelGGL(tile_sum_kernel, dim3((unsigned)samples), dim3(EW_THREADS), 0, st, d, C1, C2, HW, dt);
+    return done("tile_concat_channels_bwd");
+}
+
+extern "C" int cfl_copy_cols(const float *src, int src_ld, int src_off, float *dst, int dst_ld, int dst_off, int ncols,
+                             int64_t rows, cfl_stream_t stream) {
+    if (!src || !dst || ncols <= 0 || rows <= 0 || src_off < 0 || dst_off < 0 || src_off + ncols > src_ld ||
+        dst_off + ncols > dst_ld)
+        return cfl_set_err(CFL_E_SHAPE, "cfl_copy_cols: bad argument");
+    hipLaunchKernelGGL(copy_cols_kernel, dim3(ew_blocks(rows * ncols)), dim3(EW_THREADS), 0, (hipStream_t)stream, src,
+                       src_ld, src_off, dst, dst_ld, dst_off, ncols, rows);
+    return done("copy_cols");
 }
 
 extern "C" int cfl_gather_prototype(const float *P, const int32_t *c, int64_t B, int K, int L, float *out,

@@ -274,6 +274,16 @@ int cfl_subpixel2x_bwd(const float *y, const float *dy, float *dx, int64_t B, in
                        cfl_stream_t stream);
 /* out[r] = [a[r, :na], b[r, :nb]]  (tf.concat(zs, -1), cfl/models/blocks.py:65)               */
 int cfl_concat_cols(const float *a, int na, const float *b, int nb, int64_t rows, float *out, cfl_stream_t stream);
+/* dst[r, dst_off + c] = src[r, src_off + c], c < ncols: column slices / concats of row-major matrices.   */
+int cfl_copy_cols(const float *src, int src_ld, int src_off, float *dst, int dst_ld, int dst_off, int ncols,
+                  int64_t rows, cfl_stream_t stream);
+/* cgan conditioning of the discriminator (cfl/models/blocks.py:182-195, 382-395): out[b,h,w,:] =
+ * concat(hmap[b,h,w,:C1], t[b,:C2]) (t == NULL: zeros); backward: dh = d[..., :C1] (nullable),
+ * dt[b,:] = sum_{h,w} d[b,h,w,C1:] (nullable).  HW = pixels per sample.                                  */
+int cfl_tile_concat_channels(const float *hmap, int C1, const float *t, int C2, int64_t samples, int HW, float *out,
+                             cfl_stream_t stream);
+int cfl_tile_concat_channels_bwd(const float *d, int C1, int C2, int64_t samples, int HW, float *dh, float *dt,
+                                 cfl_stream_t stream);
 /* one_prototype_activations: out[r, :] = P[r, c[r], :], P [B,K,L] (cfl/models/cfl.py:535-546)   */
 int cfl_gather_prototype(const float *P, const int32_t *c, int64_t B, int K, int L, float *out, cfl_stream_t stream);
 /* *loss = weight * mean(sigmoid_cross_entropy_with_logits(logits, label)); *frac_pos = mean(logits > 0);

@@ -81,9 +81,27 @@ def _fc_p(p, name, rng, d, n, bias=True):
         p[name + '/biases'] = np.zeros(n)
 
 
-def init_sr_generator(ae_shape, in_dim, rng, dim=64):
+def _gen_in(p, rng, in_dim, c_dim, t_dim):
+    """cgan with --t-dim: the condition first goes through fc_t (cfl/models/blocks.py:55-64); returns fc1's fan-in."""
+    if t_dim:
+        _fc_p(p, 'fc_t/fully_connected', rng, c_dim, t_dim)
+        return in_dim - c_dim + t_dim
+    return in_dim
+
+
+def _gen_cat(zc, p, c_dim):
+    if 'fc_t/fully_connected/V' in p:
+        z, c = zc[:, :zc.shape[1] - c_dim], zc[:, zc.shape[1] - c_dim:]
+        n = 'fc_t/fully_connected'
+        c = fc_wn(c, p[n + '/V'], p[n + '/g'], p[n + '/biases'], 'lrelu')
+        return torch.cat([z, c], 1)
+    return zc
+
+
+def init_sr_generator(ae_shape, in_dim, rng, dim=64, c_dim=None, t_dim=None):
     nb, start = _up_count(ae_shape)
     p = {}
+    in_dim = _gen_in(p, rng, in_dim, c_dim, t_dim)
     _fc_p(p, 'fc1/fully_connected', rng, in_dim, dim * start * start)
     ci = dim
     for i in range(nb - 1):
@@ -94,8 +112,9 @@ def init_sr_generator(ae_shape, in_dim, rng, dim=64):
     return p
 
 
-def sr_generator(zc, p, ae_shape, data_type, dim=64):
+def sr_generator(zc, p, ae_shape, data_type, dim=64, c_dim=None):
     nb, start = _up_count(ae_shape)
+    zc = _gen_cat(zc, p, c_dim)
     h = fc_wn(zc, p['fc1/fully_connected/V'], p['fc1/fully_connected/g'], p['fc1/fully_connected/biases'], 'relu')
     h = h.reshape(-1, start, start, dim)
     for i in range(nb - 1):
@@ -116,7 +135,25 @@ def _cname(i):
     return 'Conv' if i == 0 else 'Conv_%d' % i
 
 
-def init_sr_discriminator(ae_shape, latent_size, rng, dim=32):
+def _cond(p, scope, rng, c_dim, t_dim):
+    """channels the tiled condition adds; with --t-dim it first goes through <scope>/fc_t"""
+    if t_dim:
+        _fc_p(p, scope + 'fc_t/fully_connected', rng, c_dim, t_dim)
+        return t_dim
+    return c_dim
+
+
+def _tile_t(h, t, p, scope):
+    n = scope + 'fc_t/fully_connected'
+    if n + '/V' in p:
+        t = fc_wn(t, p[n + '/V'], p[n + '/g'], p[n + '/biases'], 'lrelu')
+    tt = t[:, None, None, :].expand(-1, h.shape[1], h.shape[2], -1)
+    return torch.cat([h, tt], 3)
+
+
+def init_sr_discriminator(ae_shape, latent_size, rng, dim=32, c_dim=None, t_dim=None):
+    """c_dim: width of the cgan condition t (None: unconditional).  It enters at stage i == 3 only
+    (cfl/models/blocks.py:182), i.e. for images of 64 pixels and more."""
     nb, start = _up_count(ae_shape)
     p = {}
     _conv_p(p, 'conv/Conv', rng, 4, 4, ae_shape[2], dim)
@@ -124,7 +161,8 @@ def init_sr_discriminator(ae_shape, latent_size, rng, dim=32):
         s = 'conv%d/' % (i + 1)
         for j in range(4):
             _conv_p(p, s + _cname(j), rng, 3, 3, dim, dim)
-        _conv_p(p, s + _cname(4), rng, 4, 4, dim, dim * 2)
+        extra = _cond(p, s, rng, c_dim, t_dim) if (c_dim and i == 3) else 0
+        _conv_p(p, s + _cname(4), rng, 4, 4, dim + extra, dim * 2)
         dim *= 2
     side_h, side_w = ae_shape[0] >> (nb + 1), ae_shape[1] >> (nb + 1)
     feat = side_h * side_w * dim
@@ -133,7 +171,7 @@ def init_sr_discriminator(ae_shape, latent_size, rng, dim=32):
     return p
 
 
-def sr_discriminator(x_flat, p, ae_shape):
+def sr_discriminator(x_flat, p, ae_shape, t=None):
     nb, _ = _up_count(ae_shape)
     h = x_flat.reshape((-1,) + tuple(ae_shape))
     h = CO.conv2d_weight_norm(h, p['conv/Conv/V'], p['conv/Conv/g'], p['conv/Conv/biases'], 2, 'lrelu')
@@ -144,6 +182,8 @@ def sr_discriminator(x_flat, p, ae_shape):
             r = CO.conv2d_weight_norm(h, p[a + '/V'], p[a + '/g'], p[a + '/biases'], 1, 'lrelu')
             r = CO.conv2d_weight_norm(r, p[b + '/V'], p[b + '/g'], p[b + '/biases'], 1, None)
             h = CO.lrelu(r + h)
+        if t is not None and i == 3:
+            h = _tile_t(h, t, p, s)
         c = s + _cname(4)
         h = CO.conv2d_weight_norm(h, p[c + '/V'], p[c + '/g'], p[c + '/biases'], 2, 'lrelu')
     f = h.reshape(h.shape[0], -1)
@@ -153,10 +193,11 @@ def sr_discriminator(x_flat, p, ae_shape):
             fc_wn(f, p[l + '/V'], p[l + '/g'], p[l + '/biases']))
 
 
-def init_convt_generator(ae_shape, in_dim, rng, dim=64):
+def init_convt_generator(ae_shape, in_dim, rng, dim=64, c_dim=None, t_dim=None):
     nb, start = _up_count(ae_shape)
     scale = 2 ** (nb - 1)
     p = {}
+    in_dim = _gen_in(p, rng, in_dim, c_dim, t_dim)
     _fc_p(p, 'fc1/fully_connected', rng, in_dim, dim * scale * start * start)
     ci = dim * scale
     for i in range(nb - 1):
@@ -173,9 +214,10 @@ def init_convt_generator(ae_shape, in_dim, rng, dim=64):
     return p
 
 
-def convt_generator(zc, p, ae_shape, data_type, dim=64):
+def convt_generator(zc, p, ae_shape, data_type, dim=64, c_dim=None):
     nb, start = _up_count(ae_shape)
     scale = 2 ** (nb - 1)
+    zc = _gen_cat(zc, p, c_dim)
     h = fc_wn(zc, p['fc1/fully_connected/V'], p['fc1/fully_connected/g'], p['fc1/fully_connected/biases'], 'relu')
     h = h.reshape(-1, start, start, dim * scale)
     for i in range(nb - 1):
@@ -186,7 +228,8 @@ def convt_generator(zc, p, ae_shape, data_type, dim=64):
     return _data_act(h.reshape(h.shape[0], -1), data_type)
 
 
-def init_conv_discriminator(ae_shape, latent_size, rng, dim=64, max_dim=512):
+def init_conv_discriminator(ae_shape, latent_size, rng, dim=64, max_dim=512, c_dim=None, t_dim=None):
+    """the cgan condition is concatenated after conv(nb-1) (cfl/models/blocks.py:382-395)"""
     nb, _ = _up_count(ae_shape)
     p = {}
     ci = ae_shape[2]
@@ -194,6 +237,8 @@ def init_conv_discriminator(ae_shape, latent_size, rng, dim=64, max_dim=512):
     for i in range(nb):
         _conv_p(p, 'conv%d/Conv' % (i + 1), rng, 5, 5, ci, dim)
         ci = dim
+        if c_dim and i == nb - 2:
+            ci += _cond(p, 'conv%d/' % (i + 1), rng, c_dim, t_dim)
         dim = min(dim * 2, max_dim)
         h, w = -(-h // 2), -(-w // 2)
     feat = h * w * ci
@@ -202,12 +247,14 @@ def init_conv_discriminator(ae_shape, latent_size, rng, dim=64, max_dim=512):
     return p
 
 
-def conv_discriminator(x_flat, p, ae_shape):
+def conv_discriminator(x_flat, p, ae_shape, t=None):
     nb, _ = _up_count(ae_shape)
     h = x_flat.reshape((-1,) + tuple(ae_shape))
     for i in range(nb):
         n = 'conv%d/Conv' % (i + 1)
         h = CO.conv2d_weight_norm(h, p[n + '/V'], p[n + '/g'], p[n + '/biases'], 2, 'lrelu')
+        if t is not None and i == nb - 2:
+            h = _tile_t(h, t, p, 'conv%d/' % (i + 1))
     f = h.reshape(h.shape[0], -1)
     d = 'disc_outputs/fully_connected'
     l = 'latent_outputs/fully_connected'
@@ -278,6 +325,42 @@ def gan_losses(gp, dp, gan_type, ae_shape, data_type, real, enc_act, prj_c, neg_
     return d_total, g_total, parts
 
 
+def cgan_losses(gp, dp, gan_type, ae_shape, data_type, real_pos, real_neg, pos_c, neg_c, z, eps, lambda_gp,
+                lambda_dra):
+    """The --cgan branch (cfl/models/cfl.py:747-782, 969-981, 1022-1038).
+      real_pos / real_neg  data_pos_ae_target / data_neg_ae_target [B, prod(ae_shape)]
+      pos_c / neg_c        the condition: source encoder activations, or the raw source latents with --t-dim"""
+    gen = GENERATORS[gan_type][1]
+    disc = DISCRIMINATORS[gan_type][1]
+    B, cd = pos_c.shape
+    g = gen(torch.cat([z, pos_c], 1), gp, ae_shape, data_type, c_dim=cd)
+    half = (pos_c[:B // 2] + pos_c[B // 2:]) / 2.0
+    g_int = gen(torch.cat([z[:B // 2], half], 1), gp, ae_shape, data_type, c_dim=cd)
+    d_real, _ = disc(real_pos, dp, ae_shape, t=pos_c)
+    d_fake, _ = disc(g, dp, ae_shape, t=pos_c)
+    d_neg, _ = disc(real_neg, dp, ae_shape, t=neg_c)
+    d_int, _ = disc(g_int, dp, ae_shape, t=half)
+    parts = {}
+    parts['d_loss_real'] = bce(d_real, 1.0)
+    parts['d_loss_fake'] = bce(d_fake, 0.0)
+    parts['d_loss_neg'] = bce(d_neg, 0.0)
+    d_total = parts['d_loss_real'] + (parts['d_loss_fake'] + parts['d_loss_neg']) / 2.0
+    if lambda_gp:
+        std = torch.sqrt(real_pos.var(unbiased=False))
+        x_hat = (real_pos + lambda_dra * std * eps).detach().requires_grad_(True)
+        d_hat, _ = disc(x_hat, dp, ae_shape, t=pos_c)
+        grad, = torch.autograd.grad(d_hat.sum(), x_hat, create_graph=True)
+        parts['d_grad_loss'] = lambda_gp * ((torch.sqrt((grad * grad).sum(1)) - 1.0) ** 2).mean()
+        d_total = d_total + parts['d_grad_loss']
+    parts['g_loss'] = bce(d_fake, 1.0)
+    parts['g_loss_int'] = bce(d_int, 1.0)
+    g_total = parts['g_loss'] + parts['g_loss_int']
+    parts['d_real_accuracy'] = (d_real > 0).double().mean()
+    parts['d_fake_accuracy'] = (d_fake <= 0).double().mean()
+    parts['g_accuracy'] = (d_fake > 0).double().mean()
+    return d_total, g_total, parts
+
+
 class AdamTF:
     """TF-1 AdamOptimizer over a dict of tensors (cfl/models/cfl.py:1090-1096)."""
 
@@ -304,22 +387,30 @@ class AdamTF:
 class GanOracle:
     def __init__(self, gan_type, ae_shape, data_type, z_dim, latent_size, seed=0, d_lr=2e-4, d_beta1=0.5,
                  d_beta2=0.999, g_lr=2e-4, g_beta1=0.5, g_beta2=0.999, lambda_gp=0.5, lambda_dra=0.5,
-                 m_enc=None, m_prj=None, dtype=torch.float64):
+                 m_enc=None, m_prj=None, dtype=torch.float64, cgan=False, c_dim=None, t_dim=None):
         rng = np.random.RandomState(seed)
         self.gan_type, self.ae_shape, self.data_type = gan_type, tuple(ae_shape), data_type
-        self.cfg = dict(lambda_gp=lambda_gp, lambda_dra=lambda_dra, m_enc=m_enc, m_prj=m_prj)
-        gp = GENERATORS[gan_type][0](self.ae_shape, z_dim + latent_size, rng)
-        dp = DISCRIMINATORS[gan_type][0](self.ae_shape, latent_size, rng)
+        self.cgan = cgan
+        if cgan:
+            c_dim = c_dim or latent_size
+            self.cfg = dict(lambda_gp=lambda_gp, lambda_dra=lambda_dra)
+            gp = GENERATORS[gan_type][0](self.ae_shape, z_dim + c_dim, rng, c_dim=c_dim, t_dim=t_dim)
+            dp = DISCRIMINATORS[gan_type][0](self.ae_shape, latent_size, rng, c_dim=c_dim, t_dim=t_dim)
+        else:
+            self.cfg = dict(lambda_gp=lambda_gp, lambda_dra=lambda_dra, m_enc=m_enc, m_prj=m_prj)
+            gp = GENERATORS[gan_type][0](self.ae_shape, z_dim + latent_size, rng)
+            dp = DISCRIMINATORS[gan_type][0](self.ae_shape, latent_size, rng)
         self.gp = {k: torch.tensor(v, dtype=dtype) for k, v in gp.items()}
         self.dp = {k: torch.tensor(v, dtype=dtype) for k, v in dp.items()}
         self.g_adam = AdamTF(self.gp, g_lr, g_beta1, g_beta2)
         self.d_adam = AdamTF(self.dp, d_lr, d_beta1, d_beta2)
 
-    def losses_and_grads(self, real, enc_act, prj_c, neg_c, neg_tgt_act, z, eps):
+    def losses_and_grads(self, *batch):
+        """non-cgan: (real, enc_act, prj_c, neg_c, neg_tgt_act, z, eps); cgan: (real_pos, real_neg, pos_c, neg_c, z, eps)"""
         gp = {k: v.detach().requires_grad_(True) for k, v in self.gp.items()}
         dp = {k: v.detach().requires_grad_(True) for k, v in self.dp.items()}
-        d_total, g_total, parts = gan_losses(gp, dp, self.gan_type, self.ae_shape, self.data_type, real,
-                                             enc_act, prj_c, neg_c, neg_tgt_act, z, eps, **self.cfg)
+        fn = cgan_losses if self.cgan else gan_losses
+        d_total, g_total, parts = fn(gp, dp, self.gan_type, self.ae_shape, self.data_type, *batch, **self.cfg)
         dk, gk = list(dp), list(gp)
         dg = torch.autograd.grad(d_total, [dp[k] for k in dk], retain_graph=True, allow_unused=True)
         gg = torch.autograd.grad(g_total, [gp[k] for k in gk], allow_unused=True)

@@ -89,8 +89,8 @@ def test_cfl_train_predict_linear(dataset, tmp_path):
 
 def test_unbuilt_parts_fail_loudly(dataset, tmp_path):
     from cfl.bin import train
-    with pytest.raises(NotImplementedError, match='cgan'):
-        train.main(_common(dataset, tmp_path) + ['--model-type', 'linear', '--use-threshold', '--gan', '--cgan',
+    with pytest.raises(NotImplementedError, match='conv encoder'):
+        train.main(_common(dataset, tmp_path) + ['--model-type', 'conv', '--use-threshold', '--gan',
                                                  '--input-shape', '200'])
     with pytest.raises(NotImplementedError, match='mirror'):
         train.main(_common(dataset, tmp_path) + ['--model-type', 'linear', '--use-threshold', '--data-mirror',
@@ -232,3 +232,30 @@ def test_cfl_double_data_then_gan_post_epochs(tmp_path):
     assert any(f.endswith('_src.png') for f in pd) and any(f.endswith('_dst.png') for f in pd)
     main_png = [f for f in pd if not f.endswith(('_src.png', '_dst.png'))][0]
     assert Image.open(str(sdir / 'project_disc' / main_png)).size == (160, 16 * 2 * 2)
+
+
+def test_cfl_cgan_on_image_dataset(tmp_path):
+    """experiments/mnist_30/run_cgan.sh in miniature: image-only dataset, linear encoder on the pixels, then the
+    conditional-GAN baseline (--cgan, conv GAN type, gradient penalty), with and without --t-dim."""
+    from cfl.bin import train
+    from cfl.synthetic import make_double_dataset
+    root = tmp_path / 'data'
+    make_double_dataset(str(root / 'im'), image_shape=(16, 16, 1), n_items=120, n_pos=160, n_neg=160, k=2, seed=6,
+                        double=False)
+    base = ['--data-name', 'im', '--data-root', str(root), '--checkpoint-root', str(tmp_path / 'ck'),
+            '--log-root', str(tmp_path / 'logs'), '--model-type', 'linear', '--data-type', 'sigmoid',
+            '--data-is-image', '--input-shape', '16', '16', '1', '--dist-type', 'pcd', '--use-threshold',
+            '--num-components', '2', '--latent-size', '8', '--batch-size', '16', '--lr', '0.01', '--seed', '4']
+    train.main(base + ['--epochs', '2', '--reset', '--disable-eval'])
+    for extra, tag in (([], '_cgan_z_6_dra_0.5_0.5'), (['--t-dim', '5'], '_cgan_z_6_t_5_dra_0.5_0.5')):
+        gan = ['--gan', '--cgan', '--gan-type', 'conv', '--lambda-gp', '0.5', '--z-dim', '6'] + extra
+        train.main(base + gan + ['--epochs', '0', '--post-epochs', '1', '--disable-eval'])
+        gck = tmp_path / 'ck' / 'im' / ('cfl_pcd_linear_sigmoid_ls_8_nc_2_ut' + tag)
+        st = torch.load(str(gck / 'model-10.pt'), weights_only=False)
+        v = st['variables']
+        assert ('CFL/Generator/fc_t/fully_connected/V' in v) == bool(extra)
+        assert ('CFL/Discriminator/conv1/fc_t/fully_connected/V' in v) == bool(extra)
+        cin = 64 + (5 if extra else 8)
+        assert v['CFL/Discriminator/conv2/Conv/V'].shape == (5, 5, cin, 128)
+        m = st['adam_m']['CFL/Generator/outputs/Conv2d_transpose/V']
+        assert np.isfinite(m).all() and np.abs(m).max() > 0

@@ -225,3 +225,64 @@ def test_post_epoch_step_matches_oracle(gan_type, shape, m_enc, m_prj, lambda_gp
         for k, v in ref.items():
             diff = np.abs(got[pre + k] - v.numpy())
             assert (diff <= 2e-4).mean() >= 0.97, (k, diff.max())
+
+
+def test_conditional_discriminator_srgan_64():
+    """SRDiscriminator with the cgan condition tiled in at stage 3 (64x64 images) and fc_t: forward, parameter
+    and input gradients against the oracle."""
+    G, GB, _, GO, _ = _mods()
+    rng = np.random.RandomState(6)
+    shape, Ld, cd, td, N = (64, 64, 3), 5, 9, 7, 2
+    p = GO.init_sr_discriminator(shape, Ld, rng, c_dim=cd, t_dim=td)
+    disc = GB.Discriminator('srgan', shape, Ld, np.random.RandomState(0), torch.device('cuda'), c_dim=cd, t_dim=td)
+    assert set(disc.pool.order) == set('Discriminator/' + k for k in p)
+    _load(disc.pool, p, 'Discriminator/')
+    x = np.tanh(rng.randn(N, int(np.prod(shape))))
+    t = rng.randn(N, cd)
+    dd = rng.randn(N, 1)
+    pt = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in p.items()}
+    xt = torch.tensor(x, requires_grad=True)
+    o, _ = GO.sr_discriminator(xt, pt, shape, t=torch.tensor(t))
+    (o * torch.tensor(dd)).sum().backward()
+    logit, _, tape = disc.forward(_dev(x), _dev(t))
+    _close('logit', logit.cpu().numpy(), o.detach().numpy(), 5e-5)
+    dx = disc.backward(tape, 0, N, _dev(dd), None, need_dx=True, need_dw=True)
+    _close('dx', dx.cpu().numpy(), xt.grad.numpy(), 5e-4)
+    got = disc.pool.named(disc.pool.grad)
+    for k in p:
+        want = np.zeros(p[k].shape) if pt[k].grad is None else pt[k].grad.numpy()
+        if np.abs(want).max() > 0:
+            _close('d' + k, got['Discriminator/' + k], want, 5e-4)
+
+
+@pytest.mark.parametrize('t_dim', [None, 7])
+def test_cgan_step_matches_oracle(t_dim):
+    G, GB, M, GO, _ = _mods()
+    gan_type, shape = 'conv', (16, 16, 1)
+    B, Ld, zd = 4, 6, 5
+    cd = 9 if t_dim else Ld
+    o = GO.GanOracle(gan_type, shape, 'tanh', zd, Ld, seed=2, lambda_gp=0.5, cgan=True, c_dim=cd, t_dim=t_dim)
+    ph = M.GanPhase(gan_type, shape, 'tanh', zd, Ld, B, torch.device('cuda'), np.random.RandomState(0),
+                    lambda_gp=0.5, lambda_dra=0.5, cgan=True, c_dim=cd, t_dim=t_dim)
+    assert set(ph.gen.pool.order) == set('Generator/' + k for k in o.gp)
+    assert set(ph.disc.pool.order) == set('Discriminator/' + k for k in o.dp)
+    _load(ph.gen.pool, o.gp, 'Generator/')
+    _load(ph.disc.pool, o.dp, 'Discriminator/')
+    rng = np.random.RandomState(7)
+    N = int(np.prod(shape))
+    for it in range(3):
+        batch = [np.tanh(rng.randn(B, N)), np.tanh(rng.randn(B, N)), 0.5 * rng.randn(B, cd), 0.5 * rng.randn(B, cd),
+                 rng.randn(B, zd), rng.rand(B, 1)]
+        d_total, g_total, parts = o.step(*[torch.tensor(b) for b in batch])
+        ph.step_cgan(*[_dev(b) for b in batch])
+        s = ph.read_scalars()
+        tol = 5e-5 if it == 0 else 2e-3
+        for k in ('d_loss_real', 'd_loss_fake', 'd_loss_neg', 'd_grad_loss', 'g_loss', 'g_loss_int'):
+            assert abs(s[k] - float(parts[k])) <= tol * max(1.0, abs(float(parts[k]))), (it, k, s[k], float(parts[k]))
+        assert abs(s['d_total_loss'] - float(d_total)) <= tol * max(1.0, abs(float(d_total)))
+        assert abs(s['g_total_loss'] - float(g_total)) <= tol * max(1.0, abs(float(g_total)))
+    for pool, ref, pre in ((ph.gen.pool, o.gp, 'Generator/'), (ph.disc.pool, o.dp, 'Discriminator/')):
+        got = pool.named()
+        for k, v in ref.items():
+            diff = np.abs(got[pre + k] - v.numpy())
+            assert (diff <= 2e-4).mean() >= 0.97, (k, diff.max())
