@@ -3,7 +3,7 @@ with ``--gan``, by the MrCGAN post epochs.
 
 Drop-in for the reference's cfl/bin/train.py flag surface and directory layout
 (checkpoints/<data>/<model.get_name()>/{model-*, best_model/, best_acc_model/}).
-The random-crop / mirror input transformers and ``--cgan`` are not built and fail loudly."""
+The random-crop / mirror input transformers are not built and fail loudly."""
 import logging
 import os
 import shutil

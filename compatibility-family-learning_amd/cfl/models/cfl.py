@@ -53,8 +53,6 @@ class CFL(PairModel):
             raise ValueError(model_type)
         if model_type == 'conv' and directed:
             raise NotImplementedError('directed conv encoders are not built yet')
-        if gan and model_type == 'conv':
-            raise NotImplementedError('--gan with the conv encoder is not built yet')
         self.ENCODER_SCOPES = ('DistEncoderSrc', 'DistEncoderDst') if directed else ('DistEncoder',)
         # double data: the encoder reads the pre-computed latents unless --data-disable-double
         # (cfl/models/cfl.py:176-193, 578)
@@ -94,7 +92,8 @@ class CFL(PairModel):
                 latent_size, batch_size, self.device, np.random.RandomState(seed + 2), g_lr=g_lr, g_beta1=g_beta1,
                 g_beta2=g_beta2, d_lr=d_lr, d_beta1=d_beta1, d_beta2=d_beta2, lambda_gp=lambda_gp,
                 lambda_dra=lambda_dra, m_enc=m_enc, m_prj=m_prj, cgan=cgan,
-                c_dim=(head_inputs if t_dim else latent_size) if cgan else None, t_dim=t_dim if cgan else None)
+                c_dim=((reduce_product(self.input_shape) if self.trunk is not None else head_inputs) if t_dim
+                       else latent_size) if cgan else None, t_dim=t_dim if cgan else None)
             self._heads = None
             import torch
             self._gen = torch.Generator(device=self.device)
@@ -125,6 +124,13 @@ class CFL(PairModel):
         t = x if isinstance(x, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(x, np.float32))
         return t.to(self.device, torch.float32).contiguous()
 
+    def _enc_rows(self, x):
+        """What the encoder heads read for raw input rows x: the padded rows themselves (linear model) or the
+        flattened ConvPCD trunk features of the normalised pixels (conv model; frozen in the post epochs)."""
+        if self.trunk is None:
+            return self.to_device(x)
+        return self.trunk.forward(self._pixels(x)).clone()   # the trunk reuses its activation buffers per row count
+
     def gan_inputs(self, labeled, unl_src, unl_dst):
         """Device inputs of GanPhase.step from one labeled batch and the unlabeled source / target item
         batches (lists [x] or [image, latent]).  Draws z ~ N(0, z_stddev), eps ~ U[0,1), gate c ~ U{0..K-1}
@@ -136,7 +142,7 @@ class CFL(PairModel):
             self._heads = FrozenHeads(self.engine, self.act_type)
         hd, B = self._heads, self.batch_size
         o = 1 if self.uses_latent else 0
-        enc_in = lambda parts: self.to_device(parts[o] if len(parts) > 1 else parts[0])
+        enc_in = lambda parts: self._enc_rows(parts[o] if len(parts) > 1 else parts[0])
         img = lambda parts: self._dev(parts[0])
         lab = self.select_batch(labeled)
         dst_side = 1 if self.directed else 0
@@ -145,8 +151,8 @@ class CFL(PairModel):
         c = torch.randint(0, self.num_components, (B,), generator=self._gen, device=self.device, dtype=torch.int32)
         enc_act = hd.activations(enc_in(unl_dst), dst_side)
         prj_c = G.gather_prototype(hd.prototype_activations(enc_in(unl_src), 0), c)
-        neg_c = G.gather_prototype(hd.prototype_activations(self.to_device(lab[2]), 0), c)
-        neg_tgt_act = hd.activations(self.to_device(lab[3]), dst_side)
+        neg_c = G.gather_prototype(hd.prototype_activations(self._enc_rows(lab[2]), 0), c)
+        neg_tgt_act = hd.activations(self._enc_rows(lab[3]), dst_side)
         z = torch.randn(B, self.z_dim, generator=self._gen, device=self.device) * float(self.z_stddev)
         eps = torch.rand(B, 1, generator=self._gen, device=self.device)
         return real, enc_act, prj_c, neg_c, neg_tgt_act, z.contiguous(), eps
@@ -166,13 +172,20 @@ class CFL(PairModel):
         an = self.ae_normalizer.to_cfl_norm() if self.ae_normalizer is not None else None
         img = lambda a: G.affine_clip(self._dev(a), an) if an is not None else self._dev(a)
         real_pos, real_neg = img(labeled[1 * per]), img(labeled[3 * per])
-        if self.t_dim:
-            cond = lambda a: hd.normalize(self.to_device(a))[:, :self.input_size].contiguous()
-        else:
-            cond = lambda a: hd.activations(self.to_device(a), 0)
+        cond = self._cgan_condition
         z = torch.randn(B, self.z_dim, generator=self._gen, device=self.device) * float(self.z_stddev)
         eps = torch.rand(B, 1, generator=self._gen, device=self.device)
         return real_pos, real_neg, cond(lab[0]), cond(lab[2]), z.contiguous(), eps
+
+    def _cgan_condition(self, a):
+        """pos_src / neg_src of cfl/models/cfl.py:748-749: the source encoder's activations, or with --t-dim the
+        normalised encoder input itself (pixels for the conv model)."""
+        hd = self._sample_heads()
+        if not self.t_dim:
+            return hd.activations(self._enc_rows(a), 0)
+        if self.trunk is not None:
+            return self._pixels(a)
+        return hd.normalize(self.to_device(a))[:, :self.input_size].contiguous()
 
     def post_step(self, labeled, unl_src=None, unl_dst=None):
         if self.cgan:
@@ -198,17 +211,18 @@ class CFL(PairModel):
         import torch
         from .. import hipgan as G
         hd = self._sample_heads()
-        x = self.to_device(src_rows)
         images, preds = [], []
         if self.cgan:
             # cgan: one condition, a fresh z per "prototype" (self.zs[i], cfl/models/cfl.py:831-846)
-            c = hd.normalize(x)[:, :self.input_size].contiguous() if self.t_dim else hd.activations(x, 0)
+            c = self._cgan_condition(src_rows)
             for k in range(self.num_components):
+                x = c
                 acts = self.gan_phase.generate(self._sample_z(x.shape[0]), c)
                 logit, _, _ = self.gan_phase.disc.forward(acts, c)
                 images.append(acts.cpu().numpy())
                 preds.append(G.act_fwd(logit.contiguous(), 'sigmoid').cpu().numpy())
             return images, preds
+        x = self._enc_rows(src_rows)
         P = hd.prototype_activations(x, 0)
         z = self._sample_z(x.shape[0])
         for k in range(self.num_components):
@@ -222,7 +236,7 @@ class CFL(PairModel):
     def generate_target(self, dst_rows):
         """G(z, activations of the target encoder) (self.g_target)."""
         hd = self._sample_heads()
-        x = self.to_device(dst_rows)
+        x = self._enc_rows(dst_rows)
         acts = self.gan_phase.generate(self._sample_z(x.shape[0]), hd.activations(x, 1 if self.directed else 0))
         return acts.cpu().numpy()
 

@@ -89,9 +89,6 @@ def test_cfl_train_predict_linear(dataset, tmp_path):
 
 def test_unbuilt_parts_fail_loudly(dataset, tmp_path):
     from cfl.bin import train
-    with pytest.raises(NotImplementedError, match='conv encoder'):
-        train.main(_common(dataset, tmp_path) + ['--model-type', 'conv', '--use-threshold', '--gan',
-                                                 '--input-shape', '200'])
     with pytest.raises(NotImplementedError, match='mirror'):
         train.main(_common(dataset, tmp_path) + ['--model-type', 'linear', '--use-threshold', '--data-mirror',
                                                  '--input-shape', '200'])
@@ -259,3 +256,28 @@ def test_cfl_cgan_on_image_dataset(tmp_path):
         assert v['CFL/Discriminator/conv2/Conv/V'].shape == (5, 5, cin, 128)
         m = st['adam_m']['CFL/Generator/outputs/Conv2d_transpose/V']
         assert np.isfinite(m).all() and np.abs(m).max() > 0
+
+
+def test_cfl_conv_encoder_then_gan(tmp_path):
+    """experiments/mnist_30/run_gen.sh in miniature: vector dataset of 16x16 "pixels", ConvPCD encoder, then
+    --gan (default conv GAN type) with m_prj / m_enc."""
+    from cfl.bin import train
+    from cfl.synthetic import make_dataset
+    root = tmp_path / 'data'
+    make_dataset(str(root / 'px'), D=256, n_items=200, n_pos=200, n_neg=200, k=2, latent=6, seed=2, scale=0.3)
+    base = ['--data-name', 'px', '--data-root', str(root), '--checkpoint-root', str(tmp_path / 'ck'),
+            '--log-root', str(tmp_path / 'logs'), '--model-type', 'conv', '--data-type', 'sigmoid', '--input-shape',
+            '16', '16', '1', '--dist-type', 'pcd', '--lambda-m', '0.5', '--use-threshold', '--num-components', '2',
+            '--latent-size', '8', '--batch-size', '20', '--seed', '5']
+    train.main(base + ['--epochs', '1', '--reset', '--disable-eval'])
+    gan = ['--m-prj', '0.5', '--m-enc', '0.1', '--d-lr', '0.001', '--d-beta1', '0.9', '--g-lr', '0.001', '--g-beta1',
+           '0.9', '--gan', '--z-dim', '6']
+    train.main(base + gan + ['--epochs', '0', '--post-epochs', '1', '--disable-eval'])
+    gck = tmp_path / 'ck' / 'px' / 'cfl_pcd_conv_sigmoid_ls_8_nc_2_ut_lm_0.5_gan_z_6_m_prj_0.5_m_enc_0.1'
+    st = torch.load(str(gck / 'model-10.pt'), weights_only=False)
+    v = st['variables']
+    assert v['CFL/DistEncoder/conv1/Conv/V'].shape == (5, 5, 1, 64)
+    assert v['CFL/Generator/conv_t1/Conv2d_transpose/V'].shape == (5, 5, 128, 128)
+    assert v['CFL/Discriminator/conv2/Conv/V'].shape == (5, 5, 64, 128)
+    m = st['adam_m']['CFL/Generator/fc1/fully_connected/V']
+    assert np.isfinite(m).all() and np.abs(m).max() > 0
