@@ -36,6 +36,7 @@ import torch.distributed as dist  # noqa: E402
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 FP32_MFMA_PEAK_TF = 157.3  # dense fp32 MFMA peak (same guide)
 NORMALIZE_VALUE = 58.388599
+NOISE = float(os.environ.get("CFL_BENCH_NOISE", "0.3"))  # target-side noise of the planted positives
 
 
 def parse():
@@ -57,19 +58,24 @@ def parse():
 
 def make_pool(B, D, nbatches, device, seed):
     """Synthetic post-ReLU-like CNN features: |N(0,1)| scaled so that max ~ the
-    Monomer normalize_value; positives planted by a hidden linear
-    teacher so that the loss is not degenerate."""
+    Monomer normalize_value; positive targets planted by a hidden linear
+    teacher, negative targets planted from unrelated sources."""
     g = torch.Generator(device=device)
     g.manual_seed(seed)
+    gt = torch.Generator(device=device)
+    gt.manual_seed(20261002)                  # the hidden teacher is the same for every pool / rank / eval split
     s = NORMALIZE_VALUE / 4.5
     pool = []
-    teacher = torch.randn(D, 64, generator=g, device=device) / D ** 0.5
-    back = torch.randn(64, D, generator=g, device=device) / 8.0
+    teacher = torch.randn(D, 64, generator=gt, device=device) / D ** 0.5
+    back = torch.randn(64, D, generator=gt, device=device) / 8.0
     for _ in range(nbatches):
         ps = torch.randn(B, D, generator=g, device=device).abs_() * s
-        pd = ((ps @ teacher) @ back + 0.3 * s * torch.randn(B, D, generator=g, device=device)).abs_()
+        pd = ((ps @ teacher) @ back + NOISE * s * torch.randn(B, D, generator=g, device=device)).abs_()
         ns = torch.randn(B, D, generator=g, device=device).abs_() * s
-        ndd = torch.randn(B, D, generator=g, device=device).abs_() * s
+        # negatives: the target of an UNRELATED source, so that both targets have the same marginal and only the
+        # pairing separates the classes
+        other = torch.randn(B, D, generator=g, device=device).abs_() * s
+        ndd = ((other @ teacher) @ back + NOISE * s * torch.randn(B, D, generator=g, device=device)).abs_()
         pool.append((ps.contiguous(), pd.contiguous(), ns.contiguous(), ndd.contiguous()))
     return pool
 
@@ -101,6 +107,30 @@ def cpu_baseline(args, seconds):
             'sample': '%d steps of batch %d (%.1f s) of the same 4096-d K=%d L=%d step, '
                       'NumPy fp32 oracle (fwd+bwd+TF-Adam)' % (
                           n, B, el, args.num_components, args.latent_size)}
+
+
+def eval_auc(args, eng, device, seed):
+    """The second half of BASELINE.json's metric: AUC of the just-trained weights on held-out synthetic pairs,
+    scored by the HIP scoring path (cfl_pair_scores) and by the fp64 oracle on the same weights and pairs
+    (a bounded sample: 2 x 2048 pairs).  The oracle is only the checker here."""
+    from oracle import cfl_oracle as O
+    from cfl import hipabi as H
+    B, D = 2048, args.input_size
+    ps, pd, ns, nd = make_pool(B, D, 1, device, seed)[0]
+    sp = eng.scores(ps, pd).cpu().numpy().astype(np.float64)
+    sn = eng.scores(ns, nd).cpu().numpy().astype(np.float64)
+    hip = O.dist_eval(sp, sn)
+    p, _, thr = H.unpack_theta(eng.shape, eng.theta)
+    cfg = O.EncoderCfg(D=D, L=args.latent_size, K=args.num_components)
+    p64 = {k: v.astype(np.float64) for k, v in p.items()}
+    f = lambda t: t.cpu().numpy().astype(np.float64) / NORMALIZE_VALUE
+    op = O.pair_scores(cfg, p64, np.float64(thr), f(ps), f(pd))
+    on = O.pair_scores(cfg, p64, np.float64(thr), f(ns), f(nd))
+    ora = O.dist_eval(op, on)
+    return {'pairs': 2 * B, 'hip': round(hip['auc'], 6), 'oracle_fp64': round(ora['auc'], 6),
+            'abs_diff': float(abs(hip['auc'] - ora['auc'])), 'accuracy_hip': round(hip['accuracy'], 6),
+            'accuracy_oracle': round(ora['accuracy'], 6),
+            'max_abs_score_diff': float(max(np.abs(sp - op).max(), np.abs(sn - on).max()))}
 
 
 def main():
@@ -239,6 +269,7 @@ def main():
             'event_interval_of_64_float_kernel_us': event_overhead_us,
         }
     if rank == 0 and not args.no_cpu_baseline and world == 1:
+        out['eval_auc'] = eval_auc(args, eng, device, seed=99)
         out['cpu_baseline'] = cpu_baseline(args, args.cpu_seconds)
     elif rank == 0:
         out['cpu_baseline'] = None
