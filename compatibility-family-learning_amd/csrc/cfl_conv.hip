@@ -15,7 +15,12 @@ extern int cfl_set_err(int code, const char *fmt, ...);
 
 struct ConvGeom {
     int B, H, W, Ci, Co, KH, KW, S, OH, OW, pt, pl, act;
+    gg_div dOW, dOH, dW, dH, dCi, dCo, dKW, dS;   // fast division by the geometry constants
 };
+static void geom_divs(ConvGeom *g) {
+    g->dOW = gg_make_div(g->OW); g->dOH = gg_make_div(g->OH); g->dW = gg_make_div(g->W); g->dH = gg_make_div(g->H);
+    g->dCi = gg_make_div(g->Ci); g->dCo = gg_make_div(g->Co); g->dKW = gg_make_div(g->KW); g->dS = gg_make_div(g->S);
+}
 
 static inline void same_pad(int n, int k, int s, int *out, int *lo) {
     *out = (n + s - 1) / s;
@@ -33,6 +38,7 @@ static int make_geom(const CflConv *c, ConvGeom *g) {
     g->S = c->stride; g->act = c->act;
     same_pad(c->H, c->KH, c->stride, &g->OH, &g->pt);
     same_pad(c->W, c->KW, c->stride, &g->OW, &g->pl);
+    geom_divs(g);
     return CFL_OK;
 }
 
@@ -76,15 +82,17 @@ __global__ __launch_bounds__(256) void conv_scale_kernel(const float *V, const f
 struct Im2colX {   // A(m = (b,oh,ow), k = (kh,kw,ci)) = x[b, oh*S+kh-pt, ow*S+kw-pl, ci]
     const float *x; ConvGeom g;
     __device__ float operator()(int m, int k) const {
-        const int ow = m % g.OW, t = m / g.OW, oh = t % g.OH, b = t / g.OH;
-        const int ci = k % g.Ci, t2 = k / g.Ci, kw = t2 % g.KW, kh = t2 / g.KW;
+        int ow, t, oh, b, ci, t2, kw, kh;
+        gg_divmod(m, g.dOW, t, ow); gg_divmod(t, g.dOH, b, oh);
+        gg_divmod(k, g.dCi, t2, ci); gg_divmod(t2, g.dKW, kh, kw);
         const int ih = oh * g.S + kh - g.pt, iw = ow * g.S + kw - g.pl;
         if (ih < 0 || ih >= g.H || iw < 0 || iw >= g.W) return 0.f;
         return x[(((size_t)b * g.H + ih) * g.W + iw) * g.Ci + ci];
     }
     __device__ gg_f32x4 v4(int m, int k) const {   // k .. k+3 = 4 consecutive ci (Ci % 4 == 0)
-        const int ow = m % g.OW, t = m / g.OW, oh = t % g.OH, b = t / g.OH;
-        const int ci = k % g.Ci, t2 = k / g.Ci, kw = t2 % g.KW, kh = t2 / g.KW;
+        int ow, t, oh, b, ci, t2, kw, kh;
+        gg_divmod(m, g.dOW, t, ow); gg_divmod(t, g.dOH, b, oh);
+        gg_divmod(k, g.dCi, t2, ci); gg_divmod(t2, g.dKW, kh, kw);
         const int ih = oh * g.S + kh - g.pt, iw = ow * g.S + kw - g.pl;
         if (ih < 0 || ih >= g.H || iw < 0 || iw >= g.W) return (gg_f32x4){0.f, 0.f, 0.f, 0.f};
         return *(const gg_f32x4 *)(x + (((size_t)b * g.H + ih) * g.W + iw) * g.Ci + ci);
@@ -104,22 +112,26 @@ struct StoreFwd {
 struct DyGather {  // A(m = (b,ih,iw), k = (kh,kw,co)) = dy_pre[b,(ih+pt-kh)/S,(iw+pl-kw)/S,co] * scale[co]
     const float *dy, *y, *scale; ConvGeom g;
     __device__ float operator()(int m, int k) const {
-        const int iw = m % g.W, t = m / g.W, ih = t % g.H, b = t / g.H;
-        const int co = k % g.Co, t2 = k / g.Co, kw = t2 % g.KW, kh = t2 / g.KW;
+        int iw, t, ih, b, co, t2, kw, kh, oh, ow, rh, rw;
+        gg_divmod(m, g.dW, t, iw); gg_divmod(t, g.dH, b, ih);
+        gg_divmod(k, g.dCo, t2, co); gg_divmod(t2, g.dKW, kh, kw);
         const int nh = ih + g.pt - kh, nw = iw + g.pl - kw;
-        if (nh < 0 || nw < 0 || nh % g.S || nw % g.S) return 0.f;
-        const int oh = nh / g.S, ow = nw / g.S;
+        if (nh < 0 || nw < 0) return 0.f;
+        gg_divmod(nh, g.dS, oh, rh); gg_divmod(nw, g.dS, ow, rw);
+        if (rh || rw) return 0.f;
         if (oh >= g.OH || ow >= g.OW) return 0.f;
         const size_t o = (((size_t)b * g.OH + oh) * g.OW + ow) * g.Co + co;
         return dy[o] * act_slope(y[o], g.act) * scale[co];
     }
     __device__ gg_f32x4 v4(int m, int k) const {   // k .. k+3 = 4 consecutive co (Co % 4 == 0)
         const gg_f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-        const int iw = m % g.W, t = m / g.W, ih = t % g.H, b = t / g.H;
-        const int co = k % g.Co, t2 = k / g.Co, kw = t2 % g.KW, kh = t2 / g.KW;
+        int iw, t, ih, b, co, t2, kw, kh, oh, ow, rh, rw;
+        gg_divmod(m, g.dW, t, iw); gg_divmod(t, g.dH, b, ih);
+        gg_divmod(k, g.dCo, t2, co); gg_divmod(t2, g.dKW, kh, kw);
         const int nh = ih + g.pt - kh, nw = iw + g.pl - kw;
-        if (nh < 0 || nw < 0 || nh % g.S || nw % g.S) return zero;
-        const int oh = nh / g.S, ow = nw / g.S;
+        if (nh < 0 || nw < 0) return zero;
+        gg_divmod(nh, g.dS, oh, rh); gg_divmod(nw, g.dS, ow, rw);
+        if (rh || rw) return zero;
         if (oh >= g.OH || ow >= g.OW) return zero;
         const size_t o = (((size_t)b * g.OH + oh) * g.OW + ow) * g.Co + co;
         const gg_f32x4 d = *(const gg_f32x4 *)(dy + o), yy = *(const gg_f32x4 *)(y + o),
@@ -133,11 +145,13 @@ struct DyGather {  // A(m = (b,ih,iw), k = (kh,kw,co)) = dy_pre[b,(ih+pt-kh)/S,(
 struct FilterT {   // B(k = (kh,kw,co), n = ci) = V[kh,kw,ci,co]
     const float *V; ConvGeom g;
     __device__ float operator()(int k, int n) const {
-        const int co = k % g.Co, t = k / g.Co;  // t = kh*KW + kw
+        int co, t;  // t = kh*KW + kw
+        gg_divmod(k, g.dCo, t, co);
         return V[((size_t)t * g.Ci + n) * g.Co + co];
     }
     __device__ gg_f32x4 v4(int k, int n) const {   // k .. k+3 = 4 consecutive co
-        const int co = k % g.Co, t = k / g.Co;
+        int co, t;
+        gg_divmod(k, g.dCo, t, co);
         return *(const gg_f32x4 *)(V + ((size_t)t * g.Ci + n) * g.Co + co);
     }
 };
@@ -146,11 +160,12 @@ struct FilterT {   // B(k = (kh,kw,co), n = ci) = V[kh,kw,ci,co]
 // so the plain gather multiplies 3/4 zeros.  Per parity class (ph, pw) = (ih & 1, iw & 1) the gradient is
 // a dense GEMM over the taps kh = 2 kh' + oh0, kw = 2 kw' + ow0 (K = ceil(KH/2) ceil(KW/2) Co).
 struct DyGatherS2 {   // A(m = (b, i, j), k = (kh', kw', co)), input pixel (2i + ph, 2j + pw)
-    const float *dy, *y, *scale; ConvGeom g; int ph, pw, oh0, ow0, KH2, KW2, H2, W2;
+    const float *dy, *y, *scale; ConvGeom g; int ph, pw, oh0, ow0, KH2, KW2, H2, W2; gg_div dKW2, dH2, dW2;
     __device__ bool locate(int m, int k, size_t *o, int *co) const {
-        const int j = m % W2, t = m / W2, i = t % H2, b = t / H2;
-        *co = k % g.Co;
-        const int t2 = k / g.Co, kw = 2 * (t2 % KW2) + ow0, kh = 2 * (t2 / KW2) + oh0;
+        int j, t, i, b, t2, a0, a1;
+        gg_divmod(m, dW2, t, j); gg_divmod(t, dH2, b, i);
+        gg_divmod(k, g.dCo, t2, *co); gg_divmod(t2, dKW2, a1, a0);
+        const int kw = 2 * a0 + ow0, kh = 2 * a1 + oh0;
         if (kh >= g.KH || kw >= g.KW) return false;
         const int nh = 2 * i + ph + g.pt - kh, nw = 2 * j + pw + g.pl - kw;   // even by construction
         if (nh < 0 || nw < 0) return false;
@@ -176,22 +191,27 @@ struct DyGatherS2 {   // A(m = (b, i, j), k = (kh', kw', co)), input pixel (2i +
     }
 };
 struct FilterTS2 {    // B(k = (kh', kw', co), n = ci) = V[2kh'+oh0, 2kw'+ow0, ci, co]
-    const float *V; ConvGeom g; int oh0, ow0, KW2;
+    const float *V; ConvGeom g; int oh0, ow0, KW2; gg_div dKW2;
     __device__ float operator()(int k, int n) const {
-        const int co = k % g.Co, t2 = k / g.Co, kw = 2 * (t2 % KW2) + ow0, kh = 2 * (t2 / KW2) + oh0;
+        int co, t2, a0, a1;
+        gg_divmod(k, g.dCo, t2, co); gg_divmod(t2, dKW2, a1, a0);
+        const int kw = 2 * a0 + ow0, kh = 2 * a1 + oh0;
         if (kh >= g.KH || kw >= g.KW) return 0.f;
         return V[((size_t)(kh * g.KW + kw) * g.Ci + n) * g.Co + co];
     }
     __device__ gg_f32x4 v4(int k, int n) const {
-        const int co = k % g.Co, t2 = k / g.Co, kw = 2 * (t2 % KW2) + ow0, kh = 2 * (t2 / KW2) + oh0;
+        int co, t2, a0, a1;
+        gg_divmod(k, g.dCo, t2, co); gg_divmod(t2, dKW2, a1, a0);
+        const int kw = 2 * a0 + ow0, kh = 2 * a1 + oh0;
         if (kh >= g.KH || kw >= g.KW) return (gg_f32x4){0.f, 0.f, 0.f, 0.f};
         return *(const gg_f32x4 *)(V + ((size_t)(kh * g.KW + kw) * g.Ci + n) * g.Co + co);
     }
 };
 struct StoreS2 {      // class-local pixel m = (b, i, j) -> dx[b, 2i+ph, 2j+pw, n]
-    float *out; int ld, H, W, H2, W2, ph, pw;
+    float *out; int ld, H, W, H2, W2, ph, pw; gg_div dH2, dW2;
     __device__ void operator()(int m, int n, float v, int) const {
-        const int j = m % W2, t = m / W2, i = t % H2, b = t / H2;
+        int j, t, i, b;
+        gg_divmod(m, dW2, t, j); gg_divmod(t, dH2, b, i);
         out[(((size_t)b * H + 2 * i + ph) * W + 2 * j + pw) * ld + n] = v;
     }
 };
@@ -286,11 +306,20 @@ __global__ __launch_bounds__(256) void conv_bgrad_kernel(const float *dy, const 
 }
 
 // ---- C ABI --------------------------------------------------------------------------------
+// split-K of the weight-gradient GEMM (M = taps*Ci + 4, N = Co, K = pixels): enough splits for ~2048
+// workgroups given the output tile the GEMM will pick for this N, at least 512 pixels per split, <= 256 slabs
+static int wgrad_split_count(long long K, long long M, int N) {
+    const int tm = N <= 16 ? 256 : (N <= 32 ? 128 : 64), tn = 64 * 64 / tm;
+    const long long tiles = ((M + tm - 1) / tm) * ((N + tn - 1) / tn);
+    long long s = (2048 + tiles - 1) / tiles;
+    if (s > K / 512) s = K / 512;
+    if (s > 256) s = 256;
+    if (s < 1) s = 1;
+    return (int)s;
+}
 static int wgrad_klen(const ConvGeom &g) {
     const long long K = (long long)g.B * g.OH * g.OW;
-    int s = (int)(K / 1024);
-    if (s > 32) s = 32;
-    return gg_klen(K, s);
+    return gg_klen(K, wgrad_split_count(K, (long long)g.KH * g.KW * g.Ci + 4, g.Co));
 }
 static int wgrad_splits(const ConvGeom &g) { return gg_splits((long long)g.B * g.OH * g.OW, wgrad_klen(g)); }
 
@@ -351,9 +380,10 @@ extern "C" int cfl_conv2d_wn_bwd(const CflConv *c, const float *x, const float *
             for (int ph = 0; ph < 2; ++ph)
                 for (int pw = 0; pw < 2; ++pw) {
                     const int oh0 = (ph + g.pt) & 1, ow0 = (pw + g.pl) & 1;
-                    DyGatherS2 fa{dy, y, scale, g, ph, pw, oh0, ow0, KH2, KW2, H2, W2};
-                    FilterTS2 fb{V, g, oh0, ow0, KW2};
-                    StoreS2 fs{dx, g.Ci, g.H, g.W, H2, W2, ph, pw};
+                    const gg_div dKW2 = gg_make_div(KW2), dH2 = gg_make_div(H2), dW2 = gg_make_div(W2);
+                    DyGatherS2 fa{dy, y, scale, g, ph, pw, oh0, ow0, KH2, KW2, H2, W2, dKW2, dH2, dW2};
+                    FilterTS2 fb{V, g, oh0, ow0, KW2, dKW2};
+                    StoreS2 fs{dx, g.Ci, g.H, g.W, H2, W2, ph, pw, dH2, dW2};
                     if (g.Co % 4 == 0)
                         gemm_gather_modes<GG_VEC_K, GG_VEC_K>(g.B * H2 * W2, g.Ci, K2, gg_klen(K2, 1), fa, fb, fs, st);
                     else
@@ -402,6 +432,7 @@ static int make_geom_t(const CflConv *c, ConvGeom *g) {
     g->KH = c->KH; g->KW = c->KW; g->S = c->stride; g->act = c->act;
     same_pad(g->H, g->KH, g->S, &g->OH, &g->pt);
     same_pad(g->W, g->KW, g->S, &g->OW, &g->pl);
+    geom_divs(g);
     return CFL_OK;
 }
 
@@ -431,47 +462,57 @@ __global__ __launch_bounds__(256) void convt_scale_kernel(const float *V, const 
 struct TGatherX {  // A(m = (b,oh,ow) of y, k = (kh,kw,ci)) = x[b,(oh+pt-kh)/S,(ow+pl-kw)/S,ci]
     const float *x; ConvGeom g;   // g = geometry of F (g.Co = channels of x)
     __device__ float operator()(int m, int k) const {
-        const int iw = m % g.W, t = m / g.W, ih = t % g.H, b = t / g.H;
-        const int ci = k % g.Co, t2 = k / g.Co, kw = t2 % g.KW, kh = t2 / g.KW;
+        int iw, t, ih, b, ci, t2, kw, kh, oh, ow, rh, rw;
+        gg_divmod(m, g.dW, t, iw); gg_divmod(t, g.dH, b, ih);
+        gg_divmod(k, g.dCo, t2, ci); gg_divmod(t2, g.dKW, kh, kw);
         const int nh = ih + g.pt - kh, nw = iw + g.pl - kw;
-        if (nh < 0 || nw < 0 || nh % g.S || nw % g.S) return 0.f;
-        const int oh = nh / g.S, ow = nw / g.S;
+        if (nh < 0 || nw < 0) return 0.f;
+        gg_divmod(nh, g.dS, oh, rh); gg_divmod(nw, g.dS, ow, rw);
+        if (rh || rw) return 0.f;
         if (oh >= g.OH || ow >= g.OW) return 0.f;
         return x[(((size_t)b * g.OH + oh) * g.OW + ow) * g.Co + ci];
     }
     __device__ gg_f32x4 v4(int m, int k) const {   // k .. k+3 = 4 consecutive ci
         const gg_f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-        const int iw = m % g.W, t = m / g.W, ih = t % g.H, b = t / g.H;
-        const int ci = k % g.Co, t2 = k / g.Co, kw = t2 % g.KW, kh = t2 / g.KW;
+        int iw, t, ih, b, ci, t2, kw, kh, oh, ow, rh, rw;
+        gg_divmod(m, g.dW, t, iw); gg_divmod(t, g.dH, b, ih);
+        gg_divmod(k, g.dCo, t2, ci); gg_divmod(t2, g.dKW, kh, kw);
         const int nh = ih + g.pt - kh, nw = iw + g.pl - kw;
-        if (nh < 0 || nw < 0 || nh % g.S || nw % g.S) return zero;
-        const int oh = nh / g.S, ow = nw / g.S;
+        if (nh < 0 || nw < 0) return zero;
+        gg_divmod(nh, g.dS, oh, rh); gg_divmod(nw, g.dS, ow, rw);
+        if (rh || rw) return zero;
         if (oh >= g.OH || ow >= g.OW) return zero;
         return *(const gg_f32x4 *)(x + (((size_t)b * g.OH + oh) * g.OW + ow) * g.Co + ci);
     }
 };
 struct TFilterFwd {  // B(k = (kh,kw,ci), n = co) = V[kh,kw,co,ci]
-    const float *V; int Co, Ci;
+    const float *V; int Co, Ci; gg_div dCi;
     __device__ float operator()(int k, int n) const {
-        return V[((size_t)(k / Ci) * Co + n) * Ci + (k % Ci)];
+        int t, ci;
+        gg_divmod(k, dCi, t, ci);
+        return V[((size_t)t * Co + n) * Ci + ci];
     }
     __device__ gg_f32x4 v4(int k, int n) const {   // k .. k+3 = 4 consecutive ci
-        return *(const gg_f32x4 *)(V + ((size_t)(k / Ci) * Co + n) * Ci + (k % Ci));
+        int t, ci;
+        gg_divmod(k, dCi, t, ci);
+        return *(const gg_f32x4 *)(V + ((size_t)t * Co + n) * Ci + ci);
     }
 };
 struct TIm2colDy {  // A(m = (b,p,q) of x, k = (kh,kw,co)) = dy_pre[b,p*S+kh-pt,q*S+kw-pl,co] (* scale[co])
     const float *dy, *y, *scale; ConvGeom g;
     __device__ float operator()(int m, int k) const {
-        const int ow = m % g.OW, t = m / g.OW, oh = t % g.OH, b = t / g.OH;
-        const int co = k % g.Ci, t2 = k / g.Ci, kw = t2 % g.KW, kh = t2 / g.KW;
+        int ow, t, oh, b, co, t2, kw, kh;
+        gg_divmod(m, g.dOW, t, ow); gg_divmod(t, g.dOH, b, oh);
+        gg_divmod(k, g.dCi, t2, co); gg_divmod(t2, g.dKW, kh, kw);
         const int ih = oh * g.S + kh - g.pt, iw = ow * g.S + kw - g.pl;
         if (ih < 0 || ih >= g.H || iw < 0 || iw >= g.W) return 0.f;
         const size_t o = (((size_t)b * g.H + ih) * g.W + iw) * g.Ci + co;
         return dy[o] * act_slope(y[o], g.act) * (scale ? scale[co] : 1.f);
     }
     __device__ gg_f32x4 v4(int m, int k) const {   // k .. k+3 = 4 consecutive co
-        const int ow = m % g.OW, t = m / g.OW, oh = t % g.OH, b = t / g.OH;
-        const int co = k % g.Ci, t2 = k / g.Ci, kw = t2 % g.KW, kh = t2 / g.KW;
+        int ow, t, oh, b, co, t2, kw, kh;
+        gg_divmod(m, g.dOW, t, ow); gg_divmod(t, g.dOH, b, oh);
+        gg_divmod(k, g.dCi, t2, co); gg_divmod(t2, g.dKW, kh, kw);
         const int ih = oh * g.S + kh - g.pt, iw = ow * g.S + kw - g.pl;
         if (ih < 0 || ih >= g.H || iw < 0 || iw >= g.W) return (gg_f32x4){0.f, 0.f, 0.f, 0.f};
         const size_t o = (((size_t)b * g.H + ih) * g.W + iw) * g.Ci + co;
@@ -522,11 +563,9 @@ __global__ __launch_bounds__(256) void convt_wfinal_kernel(const float *slab, in
     }
 }
 
-static int wgrad_t_klen(const ConvGeom &g) {
+static int wgrad_t_klen(const ConvGeom &g) {   // transposed layer: M = taps * Co_t (= g.Ci), N = Ci_t (= g.Co)
     const long long K = (long long)g.B * g.OH * g.OW;
-    int s = (int)(K / 1024);
-    if (s > 32) s = 32;
-    return gg_klen(K, s);
+    return gg_klen(K, wgrad_split_count(K, (long long)g.KH * g.KW * g.Ci, g.Co));
 }
 
 extern "C" size_t cfl_conv_transpose_workspace_bytes(const CflConv *c) {
@@ -552,9 +591,9 @@ extern "C" int cfl_conv2d_transpose_wn_fwd(const CflConv *c, const float *x, con
     hipLaunchKernelGGL(convt_scale_kernel, dim3(Co), dim3(256), 0, st, V, gain, taps, Co, Ci, scale, n2);
     if (Ci % 4 == 0)
         gemm_gather_modes<GG_VEC_K, GG_VEC_K>(g.B * g.H * g.W, Co, taps * Ci, gg_klen(taps * Ci, 1), TGatherX{x, g},
-                                              TFilterFwd{V, Co, Ci}, StoreFwd{y, scale, bias, Co, g.act}, st);
+                                              TFilterFwd{V, Co, Ci, gg_make_div(Ci)}, StoreFwd{y, scale, bias, Co, g.act}, st);
     else
-        gemm_gather(g.B * g.H * g.W, Co, taps * Ci, gg_klen(taps * Ci, 1), TGatherX{x, g}, TFilterFwd{V, Co, Ci},
+        gemm_gather(g.B * g.H * g.W, Co, taps * Ci, gg_klen(taps * Ci, 1), TGatherX{x, g}, TFilterFwd{V, Co, Ci, gg_make_div(Ci)},
                     StoreFwd{y, scale, bias, Co, g.act}, st);
     return hipGetLastError() == hipSuccess ? CFL_OK : cfl_set_err(CFL_E_HIP, "transposed conv fwd launch failed");
 }

@@ -12,6 +12,33 @@
 
 typedef float gg_f32x4 __attribute__((ext_vector_type(4)));
 
+// Division by a launch-time constant for the gather index arithmetic: q = floor(n / d) for 0 <= n < 2^31 as
+// one v_mul_hi_u32 and a shift (M = ceil(2^(31+l) / d), l = ceil(log2 d)); a plain `/` by a runtime value
+// costs ~25 VALU instructions, and an im2col gather needs six of them.
+struct gg_div {
+    unsigned M;
+    int sh, d;
+};
+static inline gg_div gg_make_div(int d) {
+    gg_div r;
+    r.d = d;
+    if (d <= 1) { r.M = 0; r.sh = 0; return r; }
+    int l = 0;
+    while ((1ll << l) < d) ++l;
+    const int p = 31 + l;
+    r.M = (unsigned)(((1ull << p) + (unsigned long long)d - 1) / (unsigned long long)d);
+    r.sh = p - 32;
+    return r;
+}
+__device__ __forceinline__ int gg_quot(int n, const gg_div &dv) {
+    return dv.d <= 1 ? n : (int)(__umulhi((unsigned)n, dv.M) >> dv.sh);
+}
+// n = q * d + r
+__device__ __forceinline__ void gg_divmod(int n, const gg_div &dv, int &q, int &r) {
+    q = gg_quot(n, dv);
+    r = n - q * dv.d;
+}
+
 // Operand staging modes.  A tile is As[m][k] (64 x 16), B tile is Bs[n][k] (64 x 16).
 //   GG_SCALAR : one functor call per element, f(m, k) / f(k, n)
 //   GG_VEC_K  : functor.v4(m, k) / v4(k, n) returns the 4 elements k .. k+3 (k % 4 == 0): one
@@ -22,77 +49,109 @@ typedef float gg_f32x4 __attribute__((ext_vector_type(4)));
 // callers fall back to GG_SCALAR otherwise (e.g. 3-channel image inputs).
 enum { GG_SCALAR = 0, GG_VEC_K = 1, GG_VEC_MN = 2 };
 
-template <int AMODE, int BMODE, class LoadA, class LoadB, class Store>
+// MT = 16-row tiles per wave (1, 2 or 4); the wave's 16 MFMAs per K step are MT x NT with NT = 4 / MT
+// 16-column tiles, so the workgroup tile is (64 MT) x (64 / MT): narrow outputs (N <= 16 / <= 32, e.g. the
+// 12-channel image layer or the 32-channel discriminator stage) do not pay for 64 columns.
+template <int MT, int AMODE, int BMODE, class LoadA, class LoadB, class Store>
 __global__ __launch_bounds__(256) void gemm_gather_kernel(int M, int N, int K, int klen, LoadA la,
                                                           LoadB lb, Store st) {
-    __shared__ __attribute__((aligned(16))) float As[64][20];  // [m][k], 80-byte rows: conflict-free b128
-    __shared__ __attribute__((aligned(16))) float Bs[64][20];  // [n][k]
+    constexpr int NT = 4 / MT, TM = 64 * MT, TN = 64 / MT;
+    __shared__ __attribute__((aligned(16))) float As[TM][20];  // [m][k], 80-byte rows: conflict-free b128
+    __shared__ __attribute__((aligned(16))) float Bs[TN][20];  // [n][k]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r16 = lane & 15, q = lane >> 4;
-    const int m0 = blockIdx.x * 64, n0 = blockIdx.y * 64;
+    const int m0 = blockIdx.x * TM, n0 = blockIdx.y * TN;
     const int kbeg = blockIdx.z * klen, kend = min(K, kbeg + klen);
     const int lm = tid >> 2, lk = (tid & 3) * 4;    // scalar / vec-k staging: 4 k's of one row / column
-    const int tk = tid >> 4, tm = (tid & 15) * 4;   // vec-mn staging: one k, 4 rows / columns
-    gg_f32x4 acc[4];
+    const int tk = tid >> 4, tm = (tid & 15) * 4;   // vec-mn staging of A: one k, 4 rows (per 64-row pass)
+    const int bk = tid / (TN / 4), bn = (tid % (TN / 4)) * 4;   // vec-mn staging of B (threads < 4 TN)
+    const bool bact = tid < 4 * TN;                 // B tile = TN x 16 elements = 4 TN float4
+    gg_f32x4 acc[MT][NT];
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) acc[nt] = (gg_f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (gg_f32x4){0.f, 0.f, 0.f, 0.f};
     const gg_f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    // software pipeline: the gathers of K step i+1 are issued before the MFMAs of step i
+    auto gather = [&](int k0, gg_f32x4 (&av)[MT], gg_f32x4 &bv) {
+#pragma unroll
+        for (int p = 0; p < MT; ++p) {
+            if constexpr (AMODE == GG_VEC_K) {
+                const int m = m0 + p * 64 + lm;
+                av[p] = (m < M && k0 + lk < kend) ? la.v4(m, k0 + lk) : zero;
+            } else if constexpr (AMODE == GG_VEC_MN) {
+                const int m = m0 + p * 64 + tm;
+                av[p] = (m < M && k0 + tk < kend) ? la.v4(m, k0 + tk) : zero;
+            } else {
+                const int m = m0 + p * 64 + lm;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int k = k0 + lk + e;
+                    av[p][e] = (m < M && k < kend) ? la(m, k) : 0.f;
+                }
+            }
+        }
+        bv = zero;
+        if (bact) {
+            if constexpr (BMODE == GG_VEC_K) {
+                if (n0 + lm < N && k0 + lk < kend) bv = lb.v4(k0 + lk, n0 + lm);
+            } else if constexpr (BMODE == GG_VEC_MN) {
+                if (n0 + bn < N && k0 + bk < kend) bv = lb.v4(k0 + bk, n0 + bn);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int k = k0 + lk + e;
+                    bv[e] = (n0 + lm < N && k < kend) ? lb(k, n0 + lm) : 0.f;
+                }
+            }
+        }
+    };
+    gg_f32x4 av[MT], bv;
+    if (kbeg < kend) gather(kbeg, av, bv);
     for (int k0 = kbeg; k0 < kend; k0 += 16) {
-        gg_f32x4 av, bv;
-        if constexpr (AMODE == GG_VEC_K) {
-            av = (m0 + lm < M && k0 + lk < kend) ? la.v4(m0 + lm, k0 + lk) : zero;
-        } else if constexpr (AMODE == GG_VEC_MN) {
-            av = (m0 + tm < M && k0 + tk < kend) ? la.v4(m0 + tm, k0 + tk) : zero;
-        } else {
+        __syncthreads();
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int k = k0 + lk + e;
-                av[e] = (m0 + lm < M && k < kend) ? la(m0 + lm, k) : 0.f;
+        for (int p = 0; p < MT; ++p) {
+            if constexpr (AMODE == GG_VEC_MN) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) As[p * 64 + tm + e][tk] = av[p][e];
+            } else {
+                *(gg_f32x4 *)&As[p * 64 + lm][lk] = av[p];
             }
         }
-        if constexpr (BMODE == GG_VEC_K) {
-            bv = (n0 + lm < N && k0 + lk < kend) ? lb.v4(k0 + lk, n0 + lm) : zero;
-        } else if constexpr (BMODE == GG_VEC_MN) {
-            bv = (n0 + tm < N && k0 + tk < kend) ? lb.v4(k0 + tk, n0 + tm) : zero;
-        } else {
+        if (bact) {
+            if constexpr (BMODE == GG_VEC_MN) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int k = k0 + lk + e;
-                bv[e] = (n0 + lm < N && k < kend) ? lb(k, n0 + lm) : 0.f;
+                for (int e = 0; e < 4; ++e) Bs[bn + e][bk] = bv[e];
+            } else {
+                *(gg_f32x4 *)&Bs[lm][lk] = bv;
             }
         }
         __syncthreads();
-        if constexpr (AMODE == GG_VEC_MN) {
+        if (k0 + 16 < kend) gather(k0 + 16, av, bv);
+        gg_f32x4 a[MT], b[NT];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) As[tm + e][tk] = av[e];
-        } else {
-            *(gg_f32x4 *)&As[lm][lk] = av;
-        }
-        if constexpr (BMODE == GG_VEC_MN) {
+        for (int mt = 0; mt < MT; ++mt) a[mt] = *(const gg_f32x4 *)&As[(wave * MT + mt) * 16 + r16][4 * q];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) Bs[tm + e][tk] = bv[e];
-        } else {
-            *(gg_f32x4 *)&Bs[lm][lk] = bv;
-        }
-        __syncthreads();
-        const gg_f32x4 a = *(const gg_f32x4 *)&As[wave * 16 + r16][4 * q];
-        gg_f32x4 b[4];
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) b[nt] = *(const gg_f32x4 *)&Bs[nt * 16 + r16][4 * q];
+        for (int nt = 0; nt < NT; ++nt) b[nt] = *(const gg_f32x4 *)&Bs[nt * 16 + r16][4 * q];
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
-                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b[nt][e], acc[nt], 0, 0, 0);
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][e], b[nt][e], acc[mt][nt], 0, 0, 0);
     }
     // C layout: col = lane & 15, rows 4*(lane>>4) + e
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int m = m0 + wave * 16 + 4 * q + e, n = n0 + nt * 16 + r16;
-            if (m < M && n < N) st(m, n, acc[nt][e], (int)blockIdx.z);
-        }
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int m = m0 + (wave * MT + mt) * 16 + 4 * q + e, n = n0 + nt * 16 + r16;
+                if (m < M && n < N) st(m, n, acc[mt][nt][e], (int)blockIdx.z);
+            }
 }
 
 // K-range per split (multiple of 16) for about `want` splits; the split count is ceil(K / klen)
@@ -106,9 +165,19 @@ template <int AMODE, int BMODE, class LoadA, class LoadB, class Store>
 static inline void gemm_gather_modes(int M, int N, int K, int klen, LoadA la, LoadB lb, Store st,
                                      hipStream_t stream) {
     const int splits = gg_splits(K, klen);
-    dim3 grid((M + 63) / 64, (N + 63) / 64, splits);
-    hipLaunchKernelGGL((gemm_gather_kernel<AMODE, BMODE, LoadA, LoadB, Store>), grid, dim3(256), 0, stream, M,
-                       N, K, klen, la, lb, st);
+    if (N <= 16) {
+        dim3 grid((M + 255) / 256, (N + 15) / 16, splits);
+        hipLaunchKernelGGL((gemm_gather_kernel<4, AMODE, BMODE, LoadA, LoadB, Store>), grid, dim3(256), 0, stream,
+                           M, N, K, klen, la, lb, st);
+    } else if (N <= 32) {
+        dim3 grid((M + 127) / 128, (N + 31) / 32, splits);
+        hipLaunchKernelGGL((gemm_gather_kernel<2, AMODE, BMODE, LoadA, LoadB, Store>), grid, dim3(256), 0, stream,
+                           M, N, K, klen, la, lb, st);
+    } else {
+        dim3 grid((M + 63) / 64, (N + 63) / 64, splits);
+        hipLaunchKernelGGL((gemm_gather_kernel<1, AMODE, BMODE, LoadA, LoadB, Store>), grid, dim3(256), 0, stream,
+                           M, N, K, klen, la, lb, st);
+    }
 }
 
 template <class LoadA, class LoadB, class Store>
