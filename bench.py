@@ -133,20 +133,34 @@ def eval_auc(args, eng, device, seed):
             'max_abs_score_diff': float(max(np.abs(sp - op).max(), np.abs(sn - on).max()))}
 
 
+def _trace(msg):
+    if os.environ.get('CFL_BENCH_TRACE'):
+        print('[bench rank %s] %s' % (os.environ.get('RANK', '0'), msg), file=sys.stderr, flush=True)
+
+
 def main():
     args = parse()
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    torch.cuda.set_device(local_rank)
-    device = torch.device('cuda', local_rank)
+    # one process per GPU; CFL_DIST_BACKEND=gloo (+ fewer GPUs than ranks) is a functional test mode of the
+    # data-parallel path on a single-GPU box, not a measurement
+    backend = os.environ.get('CFL_DIST_BACKEND', 'nccl')
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank if (backend == 'nccl' or local_rank < ndev) else local_rank % max(ndev, 1)
+    torch.cuda.set_device(dev_index)
+    device = torch.device('cuda', dev_index)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     if args.gpus != world and rank == 0 and world > 1:
         print('warning: --gpus %d but WORLD_SIZE %d' % (args.gpus, world), file=sys.stderr)
 
+    _trace('process group ready (backend %s, device %s)' % (backend if world > 1 else '-', device))
     from cfl import hipabi as H
     from cfl.engine import PairEngine
     from oracle import cfl_oracle as O  # initial weights only (Xavier, seed 0)
@@ -166,8 +180,10 @@ def main():
         for i in range(nsteps):
             eng.step(pool[(start + i) % nb])
 
+    _trace('pool ready (%d batches)' % nb)
     run(args.warmup, 0)
     torch.cuda.synchronize()
+    _trace('warm-up done')
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -178,6 +194,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    _trace('timed region done: %.3f s' % elapsed)
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -219,6 +236,12 @@ def main():
     # ---- roofline of the dominant kernel: HIP events on the launch stream, a
     # second pass of the same K steps (events perturb the step time slightly, so
     # they are kept out of the pass that produces `value`) ----------------------
+    # With N > 1 every step contains a collective, so EVERY rank runs these extra steps (a rank-0-only
+    # pass would dead-lock in the all-reduce); only rank 0 records events and reports.
+    if not args.no_kernel_profile and rank != 0 and world > 1:
+        run(min(args.steps, 500), args.warmup + args.steps)
+        run(100, 0)
+        torch.cuda.synchronize()
     if rank == 0 and not args.no_kernel_profile:
         H.profile_enable(True)
         run(min(args.steps, 500), args.warmup + args.steps)
@@ -249,7 +272,8 @@ def main():
             except Exception:
                 traffic = None
         out['roofline'] = {
-            'kernel': 'cfl_%s_kernel' % dom,
+            'kernel': ('cfl_grad_x3_kernel' if dom == 'grad' and os.environ.get('CFL_EXACT_FP32', '0') in ('', '0')
+                       else 'cfl_%s_kernel' % dom),
             'bound': 'hbm',
             'achieved': round(alg_bytes / avg_s / 1e9, 1),
             'peak': HBM_PEAK_GBS,
