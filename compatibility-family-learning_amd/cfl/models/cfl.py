@@ -396,8 +396,26 @@ class CFL(PairModel):
         total_epochs = epochs + post_epochs
         start_epoch = start_iter // nb_batch
         logger.warning('start epoch %d of %d', start_epoch, total_epochs)
+        # vector datasets: features.b of a split lives in HBM and batches are gathered there by index
+        # (cfl_gather_rows); under torchrun every rank walks the same seeded index stream and trains on
+        # its own slice of each global batch
+        from .. import engine as dp
+        from ..input_data import ResidentFeatures
+        resident = None
+        if not data.train.is_image and self.trunk is None:
+            resident = (ResidentFeatures(data.train, self.device), ResidentFeatures(data.val, self.device))
+        shard = dp.shard_rows(self.batch_size) if dp.world_size() > 1 else None
+        if shard is not None and resident is None:
+            raise NotImplementedError('data-parallel training needs a vector dataset (resident features)')
+        chief = dp.rank() == 0
+
+        def next_train():
+            return resident[0].next_batch(self.batch_size, shard) if resident else data.train.next_batch(self.batch_size)
+
+        def next_val():
+            return resident[1].next_batch(self.batch_size) if resident else data.val.next_batch(self.batch_size)
         for e in range(start_epoch, total_epochs):
-            t = trange(start_iter % nb_batch if e == start_epoch else 0, nb_batch)
+            t = trange(start_iter % nb_batch if e == start_epoch else 0, nb_batch, disable=not chief)
             if e >= epochs:
                 self._post_epoch(e, t, data, nb_batch, save_iters, saver, checkpoint_dir)
                 if e % save_epochs == 0 and saver is not None:
@@ -406,17 +424,18 @@ class CFL(PairModel):
             t.set_description('epoch {}'.format(e))
             train_avg = val_avg = 0.0
             for i in t:
-                self.train_step(data.train.next_batch(self.batch_size))
-                if save_iters and i > 0 and i % save_iters == 0 and saver is not None:
+                self.train_step(next_train())
+                if save_iters and i > 0 and i % save_iters == 0 and saver is not None and chief:
                     saver.save(self, os.path.join(checkpoint_dir, 'model'), global_step=nb_batch * e + i)
                 if i % 50 == 0 or i == nb_batch - 1:      # host read-back only now and then
                     s = self.scalars()
                     train_avg = self._ema_update('acc', s['accuracy'])
-                    val_avg = self._ema_update('val_acc', self.batch_accuracy(
-                        data.val.next_batch(self.batch_size)))
+                    val_avg = self._ema_update('val_acc', self.batch_accuracy(next_val()))
                     t.set_postfix(error=1. - train_avg, val_error=1. - val_avg,
                                   pos_avg=self._ema_update('pos', s['dist_adapt_pos']),
                                   neg_avg=self._ema_update('neg', s['dist_adapt_neg']))
+            if not chief:
+                continue
             if e % eval_epochs == 0 and not disable_eval:
                 val_stats = dist_eval(None, self, self.batch_size, data.val)
                 if val_stats.auc > stats.best_auc or val_stats.accuracy > stats_acc.best_accuracy:
