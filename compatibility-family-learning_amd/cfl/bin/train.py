@@ -11,7 +11,7 @@ import shutil
 from ..input_data import load_data_sets
 from ..models.cfl import construct_model
 from ..ops import dist_normalizer
-from ..utils import Saver, dist_check_args, dist_parser, load_model, reduce_product
+from ..utils import Saver, ScalarWriter, dist_check_args, dist_parser, load_model, reduce_product
 from .train_dist import setup_logging
 
 logger = logging.getLogger(__name__)
@@ -56,10 +56,14 @@ def train_dist(load_pre_weights, data_switch, epochs, post_epochs, eval_epochs, 
     best_acc_dir = os.path.join(checkpoint_dir, 'best_acc_model')
     os.makedirs(best_dir, exist_ok=True)
     os.makedirs(best_acc_dir, exist_ok=True)
-    model.train(sess=None, data=data, start_iter=start_iter, epochs=epochs, post_epochs=post_epochs,
-                best_dir=best_dir, best_acc_dir=best_acc_dir, checkpoint_dir=checkpoint_dir,
-                eval_epochs=eval_epochs, disable_eval=disable_eval, saver=saver, best_saver=Saver(),
-                best_acc_saver=Saver(), save_iters=save_iters)
+    writer = ScalarWriter(log_dir)
+    try:
+        model.train(sess=None, data=data, start_iter=start_iter, epochs=epochs, post_epochs=post_epochs,
+                    best_dir=best_dir, best_acc_dir=best_acc_dir, checkpoint_dir=checkpoint_dir,
+                    eval_epochs=eval_epochs, disable_eval=disable_eval, saver=saver, best_saver=Saver(),
+                    best_acc_saver=Saver(), save_iters=save_iters, writer=writer)
+    finally:
+        writer.close()
 
 
 def parse_args(argv=None):

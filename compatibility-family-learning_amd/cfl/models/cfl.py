@@ -417,7 +417,7 @@ class CFL(PairModel):
         for e in range(start_epoch, total_epochs):
             t = trange(start_iter % nb_batch if e == start_epoch else 0, nb_batch, disable=not chief)
             if e >= epochs:
-                self._post_epoch(e, t, data, nb_batch, save_iters, saver, checkpoint_dir)
+                self._post_epoch(e, t, data, nb_batch, save_iters, saver, checkpoint_dir, writer)
                 if e % save_epochs == 0 and saver is not None:
                     saver.save(self, os.path.join(checkpoint_dir, 'model'), global_step=(e + 1) * nb_batch)
                 continue
@@ -429,6 +429,8 @@ class CFL(PairModel):
                     saver.save(self, os.path.join(checkpoint_dir, 'model'), global_step=nb_batch * e + i)
                 if i % 50 == 0 or i == nb_batch - 1:      # host read-back only now and then
                     s = self.scalars()
+                    if writer is not None and chief:
+                        writer.add_scalars('scalars', nb_batch * e + i, s)
                     train_avg = self._ema_update('acc', s['accuracy'])
                     val_avg = self._ema_update('val_acc', self.batch_accuracy(next_val()))
                     t.set_postfix(error=1. - train_avg, val_error=1. - val_avg,
@@ -465,7 +467,7 @@ class CFL(PairModel):
                 saver.save(self, os.path.join(checkpoint_dir, 'model'), global_step=(e + 1) * nb_batch)
 
 
-    def _post_epoch(self, e, t, data, nb_batch, save_iters, saver, checkpoint_dir):
+    def _post_epoch(self, e, t, data, nb_batch, save_iters, saver, checkpoint_dir, writer=None):
         """One MrCGAN post epoch (cfl/models/cfl.py:1484-1504): every iteration draws a labeled batch and
         an unlabeled source / target batch (cfl/bin/train.py:29-40) and updates D and G."""
         t.set_description('post epoch {}'.format(e))
@@ -484,6 +486,8 @@ class CFL(PairModel):
                 saver.save(self, os.path.join(checkpoint_dir, 'model'), global_step=nb_batch * e + i)
             if i % 20 == 0 or i == nb_batch - 1:
                 s = self.gan_phase.read_scalars()
+                if writer is not None:
+                    writer.add_scalars('gan_scalars', nb_batch * e + i, s)
                 t.set_postfix(d_loss=s['d_total_loss'], g_loss=s['g_total_loss'], d_real=s['d_real_accuracy'],
                               d_fake=s['d_fake_accuracy'])
         s = self.gan_phase.read_scalars()

@@ -315,6 +315,33 @@ def dist_sample_project_disc(sess, model, data, batch_size, sample_dir, output_n
                    np.asarray(item[per]).reshape(model.ae_shape))
 
 
+class ScalarWriter(object):
+    """Stand-in for tf.summary.FileWriter (cfl/bin/train.py:55): appends the scalar summaries of the
+    reference's `summary` / `post_summary` ops (cfl/models/cfl.py:1107-1243) to <log_dir>/<name>.tsv, one
+    header line per file, one row per logged step."""
+
+    def __init__(self, log_dir):
+        self.log_dir = log_dir
+        self._files = {}
+
+    def add_scalars(self, name, step, values):
+        f = self._files.get(name)
+        keys = sorted(values)
+        if f is None:
+            path = os.path.join(self.log_dir, name + '.tsv')
+            new = not os.path.exists(path) or os.path.getsize(path) == 0
+            f = self._files[name] = open(path, 'a')
+            if new:
+                f.write('step\t' + '\t'.join(keys) + '\n')
+        f.write(str(step) + '\t' + '\t'.join(repr(float(values[k])) for k in keys) + '\n')
+        f.flush()
+
+    def close(self):
+        for f in self._files.values():
+            f.close()
+        self._files = {}
+
+
 # ---------------------------------------------------------------------------
 # checkpoints: reference directory layout, own tensor container
 # ---------------------------------------------------------------------------

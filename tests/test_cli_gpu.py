@@ -208,6 +208,9 @@ def test_cfl_double_data_then_gan_post_epochs(tmp_path):
     assert np.isfinite(list(st['gan_powers']['g'])).all()
     m = st['adam_m']['CFL/Generator/outputs/Conv/V']
     assert np.isfinite(m).all() and np.abs(m).max() > 0
+    rows = (tmp_path / 'logs' / 'dy' / gname / 'gan_scalars.tsv').read_text().splitlines()
+    assert rows[0].split('\t')[0] == 'step' and 'd_total_loss' in rows[0] and len(rows) >= 2
+    assert all(np.isfinite(float(c)) for c in rows[1].split('\t'))
     # resume: one more post epoch
     train.main(base + gan + ['--load-pre-weights', '--epochs', '3', '--post-epochs', '2', '--disable-eval'])
     assert (gck / 'model-{}.pt'.format(5 * nb)).exists()
