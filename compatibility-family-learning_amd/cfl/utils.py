@@ -182,11 +182,44 @@ def dist_check_args(args):
 def _scores(model, data, batch_size, negative):
     """Concatenated scores [n] of all positive (or negative) pairs of a split, through
     the model's scoring entry (``val_s_pos_predicts.outputs`` in the reference)."""
+    fast = _resident_scores(model, data, negative)
+    if fast is not None:
+        return fast
     it = data.whole_neg_batches(batch_size) if negative else data.whole_pos_batches(batch_size)
     # double (image + latent) data: the encoder reads the latents (cfl/utils.py:234-244)
     pick = getattr(model, 'select_pair', lambda b: (b[0], b[1]))
     out = [model.predict(*pick(b)).reshape(-1) for b in it]
     return np.concatenate(out) if out else np.zeros(0, np.float32)
+
+
+RESIDENT_EVAL_ROWS = 8192   # pairs per scoring launch when the split's features live in HBM
+
+
+def _resident_scores(model, data, negative):
+    """Vector datasets with a linear encoder: the split's features.b is uploaded once (cached on the dataset
+    object), pair rows are gathered on the GPU by index (cfl_gather_rows) and scored in large chunks -- the
+    same scores as the per-batch path, without one host-to-device copy of 2 x [batch, D] floats per batch.
+    Returns None when the fast path does not apply (image data, conv encoder, models without an engine)."""
+    if getattr(data, 'is_image', True) or getattr(model, 'trunk', None) is not None or not hasattr(model, 'engine'):
+        return None
+    try:
+        import torch
+        from .input_data import ResidentFeatures
+    except Exception:          # pragma: no cover
+        return None
+    if not torch.cuda.is_available():
+        return None
+    res = getattr(data, '_resident', None)
+    if res is None or res.device != model.device:
+        res = data._resident = ResidentFeatures(data, model.device)
+    if res.padded_size != model.padded_size:
+        return None
+    pairs = data.pairs_neg if negative else data.pairs_pos
+    out = []
+    for i in range(0, pairs.shape[0], RESIDENT_EVAL_ROWS):
+        chunk = pairs[i:i + RESIDENT_EVAL_ROWS]
+        out.append(model.engine.scores(res.gather(chunk[:, 0]), res.gather(chunk[:, 1])).cpu().numpy())
+    return np.concatenate(out).astype(np.float32) if out else np.zeros(0, np.float32)
 
 
 def dist_eval(sess, model, batch_size, data):
