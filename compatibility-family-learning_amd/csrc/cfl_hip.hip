@@ -1409,6 +1409,7 @@ __global__ __launch_bounds__(64) void cfl_mid_kernel(MidArgs a) {
 // per slice, every per-column quantity is one VALU op, and the few cross-column sums
 // go through a 1 KiB wave-private LDS scratch.  Same arithmetic, same outputs.
 // ---------------------------------------------------------------------------
+template <int J>   // J = columns per lane: sides of up to 64 * J padded columns
 __global__ __launch_bounds__(256) void cfl_mid_row_kernel(MidArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
@@ -1417,84 +1418,121 @@ __global__ __launch_bounds__(256) void cfl_mid_row_kernel(MidArgs a) {
         if (wave == 0) mid_reg_block(a, blockIdx.x - a.nrb);
         return;
     }
-    float *W = (float *)smem + wave * 384;  // Pl[64] Vl[64] Rl[64] T[64] S[64] Q[64]
-    float *Pl = W, *Vl = W + 64, *Rl = W + 128, *T = W + 192, *S = W + 256, *Q = W + 320;
+    constexpr int CW = 64 * J;
+    float *W = (float *)smem + wave * 6 * CW;  // Pl Vl Rl T S Q, CW floats each
+    float *Pl = W, *Vl = W + CW, *Rl = W + 2 * CW, *T = W + 3 * CW, *S = W + 4 * CW, *Q = W + 5 * CW;
     const int r = blockIdx.x * 4 + wave;
     const bool valid = r < a.R;
     const int L = a.L, K = a.K, RG = a.Rpad >> 4;
     const MidSide &ss = a.side[0], &sd = a.side[1];
-    const int c = lane, ns = ss.n;
-    const bool cs = c < ns, cd = c < L;
-    const int k = cs ? c / L : 0, l = cs ? c - k * L : 0;
+    const int ns = ss.n;
+    int c[J], kk[J], ll[J];
+    bool cs[J], cd[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        c[j] = lane + 64 * j;
+        cs[j] = c[j] < ns;
+        cd[j] = c[j] < L;
+        kk[j] = cs[j] ? c[j] / L : 0;
+        ll[j] = cs[j] ? c[j] - kk[j] * L : 0;
+    }
 
-    // ---- slice sums + head epilogue (one column per lane) -------------------------
+    // ---- slice sums + head epilogue (J columns per lane) ---------------------------
     // all slice loads of both sides are independent and in flight together (summed in
     // slice order afterwards)
-    float ts[16], td[16];
-    const float *srcs = ss.ypart + (size_t)r * ss.npad + (c < ss.npad ? c : 0);
-    const float *srcd = sd.ypart + (size_t)r * sd.npad + (c < sd.npad ? c : 0);
+    float ys[J], yd[J];
+    {
+        float ts[J][16], td[J][16];
 #pragma unroll
-    for (int s = 0; s < 16; ++s) {
-        ts[s] = s < a.S ? srcs[(size_t)s * ss.sstride] : 0.f;
-        td[s] = s < a.S ? srcd[(size_t)s * sd.sstride] : 0.f;
-    }
-    float ys = 0.f, yd = 0.f;
+        for (int j = 0; j < J; ++j) {
+            const float *srcs = ss.ypart + (size_t)r * ss.npad + (c[j] < ss.npad ? c[j] : 0);
+            const float *srcd = sd.ypart + (size_t)r * sd.npad + (c[j] < sd.npad ? c[j] : 0);
 #pragma unroll
-    for (int s = 0; s < 16; ++s) { ys += ts[s]; yd += td[s]; }
-    float scs = 1.f, scd = 1.f, bs = 0.f, bd = 0.f;
-    if (cs) {
-        if (a.weight_norm) scs = ss.g[c] * __builtin_amdgcn_rsqf(ss.n2[c]);
-        if (ss.b) bs = ss.b[c];
-    }
-    if (cd) {
-        if (a.weight_norm) scd = sd.g[c] * __builtin_amdgcn_rsqf(sd.n2[c]);
-        if (sd.b) bd = sd.b[c];
+            for (int s = 0; s < 16; ++s) {
+                ts[j][s] = s < a.S ? srcs[(size_t)s * ss.sstride] : 0.f;
+                td[j][s] = s < a.S ? srcd[(size_t)s * sd.sstride] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            ys[j] = 0.f;
+            yd[j] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 16; ++s) { ys[j] += ts[j][s]; yd[j] += td[j][s]; }
+        }
     }
     const float thr_raw = *a.thr;
-    const float xvs = (valid && cs) ? ys * a.in_mul : 0.f;
-    const float xvd = (valid && cd) ? yd * a.in_mul : 0.f;
-    const float P = (valid && cs) ? act_fn(xvs * scs + bs, a.act) : 0.f;
-    const float v = (valid && cd) ? act_fn(xvd * scd + bd, a.act) : 0.f;
-    Pl[c] = P;
-    Vl[c] = v;
-    const float vl = Vl[l];           // destination coordinate l of this source column
-    const float diff = cs ? vl - P : 0.f;
+    float xvs[J], xvd[J], P[J], v[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        float scs = 1.f, scd = 1.f, bs = 0.f, bd = 0.f;
+        if (cs[j]) {
+            if (a.weight_norm) scs = ss.g[c[j]] * __builtin_amdgcn_rsqf(ss.n2[c[j]]);
+            if (ss.b) bs = ss.b[c[j]];
+        }
+        if (cd[j]) {
+            if (a.weight_norm) scd = sd.g[c[j]] * __builtin_amdgcn_rsqf(sd.n2[c[j]]);
+            if (sd.b) bd = sd.b[c[j]];
+        }
+        xvs[j] = (valid && cs[j]) ? ys[j] * a.in_mul : 0.f;
+        xvd[j] = (valid && cd[j]) ? yd[j] * a.in_mul : 0.f;
+        P[j] = (valid && cs[j]) ? act_fn(xvs[j] * scs + bs, a.act) : 0.f;
+        v[j] = (valid && cd[j]) ? act_fn(xvd[j] * scd + bd, a.act) : 0.f;
+        Pl[c[j]] = P[j];
+        Vl[c[j]] = v[j];
+    }
+    float diff[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) diff[j] = cs[j] ? Vl[ll[j]] - P[j] : 0.f;   // destination coordinate l of this column
 
     // ---- distance ----------------------------------------------------------------
-    float d, sk = 1.f, rl = 0.f, dlk = 0.f;
+    float d, sk[J], rl[J], dlk[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) { sk[j] = 1.f; rl[j] = 0.f; dlk[j] = 0.f; }
     if (K > 1) {
-        T[c] = diff * diff;
+#pragma unroll
+        for (int j = 0; j < J; ++j) T[c[j]] = diff[j] * diff[j];
         float e = 0.f;
-        if (c < K)
-            for (int i = 0; i < L; ++i) e += T[c * L + i];
-        S[c] = -e;                    // logits (lanes >= K: unused)
+        if (lane < K)
+            for (int i = 0; i < L; ++i) e += T[lane * L + i];
+        S[lane] = -e;                 // logits (lanes >= K: unused)
         float mx = -INFINITY;
         for (int i = 0; i < K; ++i) mx = fmaxf(mx, S[i]);
         float den = 0.f;
         for (int i = 0; i < K; ++i) den += fexp(S[i] - mx);
         const float inv = frcp(den);
-        const float sme = c < K ? fexp(-e - mx) * inv : 0.f;   // s_c for lanes < K
-        Q[c] = sme;
-        sk = Q[k];                    // softmax weight of this column's prototype
-        float m = 0.f;
-        if (cd)
-            for (int i = 0; i < K; ++i) m = fmaf(Q[i], Pl[i * L + c], m);
-        rl = cd ? v - m : 0.f;
-        Rl[c] = rl;
-        d = wave_sum(rl * rl);
-        T[c] = cs ? Rl[l] * P : 0.f;
+        const float sme = lane < K ? fexp(-e - mx) * inv : 0.f;   // s_k for lanes < K
+        Q[lane] = sme;
+        float dsum = 0.f;
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            sk[j] = Q[kk[j]];         // softmax weight of this column's prototype
+            float m = 0.f;
+            if (cd[j])
+                for (int i = 0; i < K; ++i) m = fmaf(Q[i], Pl[i * L + c[j]], m);
+            rl[j] = cd[j] ? v[j] - m : 0.f;
+            Rl[c[j]] = rl[j];
+            dsum = fmaf(rl[j], rl[j], dsum);
+        }
+        d = wave_sum(dsum);
+#pragma unroll
+        for (int j = 0; j < J; ++j) T[c[j]] = cs[j] ? Rl[ll[j]] * P[j] : 0.f;
         float q = 0.f;
-        if (c < K)
-            for (int i = 0; i < L; ++i) q += T[c * L + i];
+        if (lane < K)
+            for (int i = 0; i < L; ++i) q += T[lane * L + i];
         q *= -2.f;
-        S[c] = q;                     // q_k (lanes < K)
+        S[lane] = q;                  // q_k (lanes < K)
         float qbar = 0.f;
         for (int i = 0; i < K; ++i) qbar = fmaf(Q[i], S[i], qbar);
-        const float dl_me = c < K ? sme * (q - qbar) : 0.f;
-        T[c] = dl_me;                 // dl_k (lanes < K)
-        dlk = T[k];
+        const float dl_me = lane < K ? sme * (q - qbar) : 0.f;
+        T[lane] = dl_me;              // dl_k (lanes < K); T is free again, q has been reduced
+#pragma unroll
+        for (int j = 0; j < J; ++j) dlk[j] = T[kk[j]];
     } else {
-        d = wave_sum(diff * diff);
+        float dsum = 0.f;
+#pragma unroll
+        for (int j = 0; j < J; ++j) dsum = fmaf(diff[j], diff[j], dsum);
+        d = wave_sum(dsum);
     }
 
     // ---- threshold, loss, dL/dd ------------------------------------------------------
@@ -1550,29 +1588,32 @@ __global__ __launch_bounds__(256) void cfl_mid_row_kernel(MidArgs a) {
         a.rowqf[frag_off(r, lane, RG)] = qv;
     }
 
-    // ---- backward: one source column and (lanes < L) one destination column per lane --
-    float dP, dv;
-    if (K > 1) {
-        const float rls = Rl[l];
-        dP = -2.f * sk * rls + 2.f * dlk * diff;
-        dv = 2.f * rl;
-        if (cd)
-            for (int i = 0; i < K; ++i) dv = fmaf(-2.f * T[i], v - Pl[i * L + c], dv);
-    } else {
-        dP = -2.f * diff;
-        dv = 2.f * (v - Pl[c]);
-    }
-    if (c < ss.npad) {
-        const float dy = cs ? dP * dd * act_grad(P, a.act) : 0.f;
-        const size_t o_ = frag_off(r, c, RG);
-        ss.dyf[o_] = dy;
-        if (ss.cwf) ss.cwf[o_] = dy * xvs;
-    }
-    if (c < sd.npad) {
-        const float dy = cd ? dv * dd * act_grad(v, a.act) : 0.f;
-        const size_t o_ = frag_off(r, c, RG);
-        sd.dyf[o_] = dy;
-        if (sd.cwf) sd.cwf[o_] = dy * xvd;
+    // ---- backward: J source columns and (columns < L) J destination columns per lane ----
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        float dP, dv;
+        if (K > 1) {
+            const float rls = Rl[ll[j]];
+            dP = -2.f * sk[j] * rls + 2.f * dlk[j] * diff[j];
+            dv = 2.f * rl[j];
+            if (cd[j])
+                for (int i = 0; i < K; ++i) dv = fmaf(-2.f * T[i], v[j] - Pl[i * L + c[j]], dv);
+        } else {
+            dP = -2.f * diff[j];
+            dv = 2.f * (v[j] - Pl[c[j]]);
+        }
+        if (c[j] < ss.npad) {
+            const float dy = cs[j] ? dP * dd * act_grad(P[j], a.act) : 0.f;
+            const size_t o_ = frag_off(r, c[j], RG);
+            ss.dyf[o_] = dy;
+            if (ss.cwf) ss.cwf[o_] = dy * xvs[j];
+        }
+        if (c[j] < sd.npad) {
+            const float dy = cd[j] ? dv * dd * act_grad(v[j], a.act) : 0.f;
+            const size_t o_ = frag_off(r, c[j], RG);
+            sd.dyf[o_] = dy;
+            if (sd.cwf) sd.cwf[o_] = dy * xvd[j];
+        }
     }
 }
 
@@ -2281,10 +2322,17 @@ static int run_pairs(const CflShape *s, const CflNorm *norm, const CflLossCfg *l
         ProfScope ps(st, CFL_K_MID);
         const dim3 mgrid(ma.nrb + nreg_blocks), mblk(64);
         const bool generic_only = debug_env("CFL_DEBUG_MID_GENERIC") > 0;
-        const bool row_ok = s->dist_type == CFL_DIST_PCD && side[0].head->npad <= 64 &&
-                            side[1].head->npad <= 64 && debug_env("CFL_DEBUG_MID_NOROW") == 0;
-        if (!generic_only && row_ok)
-            hipLaunchKernelGGL(cfl_mid_row_kernel, dim3(ma.nrb + nreg_blocks), dim3(256), 4 * 384 * sizeof(float), st, ma);
+        // one wave per row: pcd (any K <= 64) and siamese with up to 256 padded columns per side
+        const int wide = side[0].head->npad > side[1].head->npad ? side[0].head->npad : side[1].head->npad;
+        const bool row_ok = (s->dist_type == CFL_DIST_PCD || s->dist_type == CFL_DIST_SIAMESE) && wide <= 256 &&
+                            s->K <= 64 && debug_env("CFL_DEBUG_MID_NOROW") == 0;
+        const dim3 rgrid(ma.nrb + nreg_blocks);
+        if (!generic_only && row_ok && wide <= 64)
+            hipLaunchKernelGGL((cfl_mid_row_kernel<1>), rgrid, dim3(256), 4 * 6 * 64 * sizeof(float), st, ma);
+        else if (!generic_only && row_ok && wide <= 128)
+            hipLaunchKernelGGL((cfl_mid_row_kernel<2>), rgrid, dim3(256), 4 * 6 * 128 * sizeof(float), st, ma);
+        else if (!generic_only && row_ok)
+            hipLaunchKernelGGL((cfl_mid_row_kernel<4>), rgrid, dim3(256), 4 * 6 * 256 * sizeof(float), st, ma);
         else if (!generic_only && s->K <= 4 && pl.Lq <= 2)
             hipLaunchKernelGGL((cfl_mid_kernel<4, 2>), mgrid, mblk, pl.mid_lds, st, ma);
         else if (!generic_only && s->K <= 8 && pl.Lq <= 2)

@@ -23,11 +23,16 @@ ap.add_argument('--input-size', type=int, default=4096)
 ap.add_argument('--num-components', type=int, default=3)
 ap.add_argument('--latent-size', type=int, default=20)
 ap.add_argument('--tag', default='')
+ap.add_argument('--dist-type', default='pcd')
+ap.add_argument('--weight-norm', action='store_true')
+ap.add_argument('--caffe-margin', type=float, default=None)
 a = ap.parse_args()
 B, D, K, L = a.batch_size, a.input_size, a.num_components, a.latent_size
-cfg = O.EncoderCfg(D=D, L=L, K=K)
+cfg = O.EncoderCfg(D=D, L=L, K=K, dist_type=a.dist_type, style='cfl' if a.weight_norm else 'dist')
 params = O.init_encoder_params(cfg, np.random.RandomState(0), np.float32)
-eng = PairEngine(D, L, K, norm=H.make_norm(1 / 58.388599), params=params, batch_size=B)
+eng = PairEngine(D, L, K, a.dist_type, weight_norm=a.weight_norm, has_bias=cfg.has_bias,
+                 norm=H.make_norm(1 / 58.388599), loss=H.make_loss(caffe_margin=a.caffe_margin,
+                 use_threshold=a.dist_type != 'siamese' or not a.caffe_margin), params=params, batch_size=B)
 g = torch.Generator(device='cuda'); g.manual_seed(1)
 nb = max(2, (384 << 20) // (16 * B * D))
 pool = [tuple(torch.randn(B, D, generator=g, device='cuda').abs_() * 13 for _ in range(4)) for _ in range(nb)]
