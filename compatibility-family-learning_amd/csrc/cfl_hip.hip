@@ -575,7 +575,9 @@ extern "C" __global__ __launch_bounds__(256) void cfl_grad_kernel(GradArgs a) {
 // significand bits, by truncation: h = v & 0xffff0000, m = (v - h) & 0xffff0000, l = v - h - m;
 // both subtractions are exact), and a product a*b is accumulated in fp32 from the six partial
 // products whose weight is >= 2^-16 of it: ah*bh, ah*bm, am*bh, ah*bl, al*bh, am*bm.  The dropped
-// terms (am*bl, al*bm, al*bl) are <= 2^-23 |a*b|, the size of one fp32 rounding.
+// terms (am*bl, al*bm, al*bl) are <= 2^-21 |a*b| in the worst case and 2^-24 |a*b| rms
+// (tests/test_bf16x3_split.py), the size of an fp32 rounding; against the fp64 oracle the gradient error
+// equals that of the fp32 kernel (tests/test_hip_parity.py).
 // v_mfma_f32_16x16x32_bf16 runs 16x the fp32 MFMA rate, so six of them over K = 32 cost 96
 // cycles against 256 for the eight v_mfma_f32_16x16x4_f32 they replace; the splits are VALU work
 // that co-issues in the MFMA shadows.  Data layouts (row-major x, fragment-major dYf, Wf slabs)
