@@ -23,6 +23,9 @@ import os
 import sys
 import time
 
+# must be in the environment before the HIP runtime starts (multi-process RCCL needs dmabuf IPC on this pool)
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.join(ROOT, 'compatibility-family-learning_amd')
 for _p in (ROOT, PKG):
@@ -152,7 +155,6 @@ def main():
     device = torch.device('cuda', dev_index)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         if backend == 'nccl':
             dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
         else:
