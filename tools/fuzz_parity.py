@@ -1,0 +1,52 @@
+#!/usr/bin/env python
+"""Randomised parity sweep of the pair step and the scoring path against the oracle: random
+(D, L, K, dist type, model style, activation, batch, directed, loss options) through the assertions of
+tests/test_hip_parity.py.  Usage: python tools/fuzz_parity.py [N] [seed]"""
+import os, sys, traceback
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, 'compatibility-family-learning_amd')]
+import numpy as np
+import tests.test_hip_parity as T
+import __graft_entry__ as g
+g.build()
+from cfl import hipabi
+T.H = hipabi
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+fails = 0
+for it in range(N):
+    style = rng.choice(['dist', 'cfl'])
+    dist = 'pcd' if style == 'dist' else rng.choice(['pcd', 'monomer', 'siamese'], p=[0.5, 0.2, 0.3])
+    D = int(rng.choice([64, 128, 192, 256, 512, 1024, 2048]))
+    if dist == 'siamese':
+        L, K = int(rng.randint(1, 300)), 1
+    else:
+        K = int(rng.randint(1, 9))
+        L = int(rng.randint(1, max(2, min(80, 600 // K))))
+    act = None if style == 'dist' else rng.choice([None, 'tanh', 'sigmoid', 'relu'], p=[0.55, 0.15, 0.15, 0.15])
+    B = int(rng.choice([1, 2, 3, 7, 16, 31, 64, 100, 129, 200, 257]))
+    nv = float(rng.choice([1.0, 16.0, 58.388599]))
+    directed = bool(style == 'cfl' and rng.rand() < 0.25)
+    lkw = {}
+    if rng.rand() < 0.4:
+        lkw['reg_const'] = float(rng.choice([1e-4, 1e-3, 1e-2]))
+    if style == 'cfl':
+        if rng.rand() < 0.4:
+            lkw['pos_weight'] = float(rng.choice([0.0625, 0.5, 2.0]))
+        if dist == 'siamese' and rng.rand() < 0.5:
+            lkw['caffe_margin'] = float(rng.choice([5.0, 100.0]))
+            lkw['use_threshold'] = bool(rng.rand() < 0.5)
+        elif rng.rand() < 0.4:
+            lkw['lambda_m'] = float(rng.choice([0.1, 0.5]))
+            if dist == 'siamese':
+                lkw['use_threshold'] = bool(rng.rand() < 0.5)
+    desc = (style, dist, D, L, K, act, B, nv, lkw, directed)
+    try:
+        T.test_step_fwd_bwd(*desc)
+        T.test_pair_scores(style, dist, D, L, K, act, max(1, B // 2 + 1), nv)
+    except Exception as e:          # noqa
+        fails += 1
+        print('FAIL', desc, '->', repr(e)[:300], flush=True)
+print('fuzz: %d cases, %d failures' % (N, fails))
+sys.exit(1 if fails else 0)
