@@ -47,7 +47,7 @@ def conv2d_weight_norm(x, V, g, b, stride, activation=None):
     _, pl, pr = same_pads(x.shape[2], KW, stride)
     W = wn_filter(V, g)
     xn = F.pad(x.permute(0, 3, 1, 2), (pl, pr, pt, pb))
-    y = F.conv2d(xn, W.permute(3, 2, 0, 1), stride=stride).permute(0, 2, 3, 1)
+    y = F.conv2d(xn, W.permute(3, 2, 0, 1).contiguous(), stride=stride).permute(0, 2, 3, 1)
     if b is not None:
         y = y + b
     if activation == 'lrelu':
