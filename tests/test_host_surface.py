@@ -137,3 +137,30 @@ def test_incremental_average():
     for v in (1.0, 2.0, 6.0):
         a.add(v)
     assert a.average == pytest.approx(3.0) and a.count == 3
+
+
+def test_checkpoint_converter_npz_round_trip(tmp_path):
+    """cfl.bin.convert_checkpoint: .pt <-> .npz keyed by the TensorFlow variable names (Adam slots as
+    <name>/Adam, <name>/Adam_1); the TensorFlow directions fail loudly without TensorFlow."""
+    import torch
+    from cfl.bin import convert_checkpoint as C
+    rng = np.random.RandomState(0)
+    names = ['CFL/DistEncoder/outputs/fully_connected/V', 'CFL/DistEncoder/outputs/fully_connected/g',
+             'CFL/Thresholder/threshold/threshold']
+    state = {'variables': {n: rng.randn(3, 2).astype(np.float32) for n in names},
+             'adam_m': {n: rng.randn(3, 2).astype(np.float32) for n in names},
+             'adam_v': {n: np.abs(rng.randn(3, 2)).astype(np.float32) for n in names},
+             'beta1_power': 0.81, 'beta2_power': 0.998, 'global_step': 7, 'name': 'x'}
+    pt, npz, back = tmp_path / 'model-7.pt', tmp_path / 'm.npz', tmp_path / 'back.pt'
+    torch.save(state, str(pt))
+    assert C.main(['--to-npz', str(pt), str(npz)]) == 0
+    with np.load(str(npz)) as z:
+        assert names[0] + '/Adam_1' in z.files and int(z['global_step']) == 7
+    assert C.main(['--from-npz', str(npz), str(back)]) == 0
+    got = torch.load(str(back), weights_only=False)
+    for key in ('variables', 'adam_m', 'adam_v'):
+        for n in names:
+            assert np.array_equal(got[key][n], state[key][n])
+    assert got['global_step'] == 7 and abs(got['beta1_power'] - 0.81) < 1e-6
+    with pytest.raises(SystemExit):
+        C.main(['--from-tf', str(tmp_path / 'nope'), str(back)])
