@@ -12,7 +12,7 @@ EXPORTS = ('cfl_conv_transpose_workspace_bytes', 'cfl_conv2d_transpose_wn_fwd', 
            'cfl_ew_act_fwd', 'cfl_ew_act_bwd', 'cfl_ew_add_act', 'cfl_ew_axpy', 'cfl_ew_affine_clip', 'cfl_subpixel2x_fwd',
            'cfl_subpixel2x_bwd', 'cfl_concat_cols', 'cfl_gather_prototype', 'cfl_bce_logits',
            'cfl_rowdist_loss', 'cfl_perturb_workspace_bytes', 'cfl_perturb', 'cfl_grad_penalty', 'cfl_copy_cols',
-           'cfl_tile_concat_channels', 'cfl_tile_concat_channels_bwd')
+           'cfl_tile_concat_channels', 'cfl_tile_concat_channels_bwd', 'cfl_auc_workspace_bytes', 'cfl_auc')
 
 EW = {None: 0, 'linear': 0, 'lrelu': 1, 'relu': 2, 'tanh': 3, 'sigmoid': 4}
 
@@ -47,8 +47,11 @@ def lib():
     L.cfl_perturb_workspace_bytes.restype = sz
     L.cfl_perturb.argtypes = [vp, vp, i64, i64, f32, vp, vp, sz, vp]
     L.cfl_grad_penalty.argtypes = [vp, i64, i64, f32, vp, vp, vp, vp]
+    L.cfl_auc_workspace_bytes.argtypes = [i64, i64]
+    L.cfl_auc_workspace_bytes.restype = sz
+    L.cfl_auc.argtypes = [vp, i64, vp, i64, vp, vp, sz, vp]
     for n in EXPORTS:
-        if n not in ('cfl_conv_transpose_workspace_bytes', 'cfl_perturb_workspace_bytes'):
+        if n not in ('cfl_conv_transpose_workspace_bytes', 'cfl_perturb_workspace_bytes', 'cfl_auc_workspace_bytes'):
             getattr(L, n).restype = C.c_int
     _ready = True
     return L
@@ -195,3 +198,16 @@ def grad_penalty(u, lambda_gp, loss, need_v=True):
     rowloss = torch.empty(B, dtype=torch.float32, device=u.device)
     _check(lib().cfl_grad_penalty(_dev(u), B, N, float(lambda_gp), _dev(loss), _opt(v), _dev(rowloss), _stream()))
     return v
+
+
+def auc(scores_pos, scores_neg):
+    """(auc, accuracy) of device score vectors (include/cfl_hip.h cfl_auc); one host read-back of 16 bytes."""
+    n = lib().cfl_auc_workspace_bytes(scores_pos.numel(), scores_neg.numel())
+    if n == 0:
+        raise H.CflHipError('cfl_auc: bad sizes')
+    ws = torch.empty((n + 7) // 8, dtype=torch.float64, device=scores_pos.device)
+    out = torch.empty(2, dtype=torch.float64, device=scores_pos.device)
+    _check(lib().cfl_auc(_dev(scores_pos), scores_pos.numel(), _dev(scores_neg), scores_neg.numel(),
+                         out.data_ptr(), ws.data_ptr(), ws.numel() * 8, _stream()))
+    a, acc = out.cpu().tolist()
+    return a, acc

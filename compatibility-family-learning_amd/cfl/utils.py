@@ -195,7 +195,7 @@ def _scores(model, data, batch_size, negative):
 RESIDENT_EVAL_ROWS = 8192   # pairs per scoring launch when the split's features live in HBM
 
 
-def _resident_scores(model, data, negative):
+def _resident_scores(model, data, negative, device_result=False):
     """Vector datasets with a linear encoder: the split's features.b is uploaded once (cached on the dataset
     object), pair rows are gathered on the GPU by index (cfl_gather_rows) and scored in large chunks -- the
     same scores as the per-batch path, without one host-to-device copy of 2 x [batch, D] floats per batch.
@@ -218,12 +218,21 @@ def _resident_scores(model, data, negative):
     out = []
     for i in range(0, pairs.shape[0], RESIDENT_EVAL_ROWS):
         chunk = pairs[i:i + RESIDENT_EVAL_ROWS]
-        out.append(model.engine.scores(res.gather(chunk[:, 0]), res.gather(chunk[:, 1])).cpu().numpy())
-    return np.concatenate(out).astype(np.float32) if out else np.zeros(0, np.float32)
+        out.append(model.engine.scores(res.gather(chunk[:, 0]), res.gather(chunk[:, 1])))
+    if device_result:
+        return torch.cat(out).contiguous() if out else None
+    return torch.cat(out).cpu().numpy().astype(np.float32) if out else np.zeros(0, np.float32)
 
 
 def dist_eval(sess, model, batch_size, data):
-    """cfl/utils.py:227-274: accuracy by the sign of the score, AUC, ROC."""
+    """cfl/utils.py:227-274: accuracy by the sign of the score, AUC, ROC.  With HBM-resident features the scores
+    never leave the GPU: AUC and accuracy come from cfl_auc (sort-based, ties = half credit, equal to
+    sklearn's roc_auc_score) and `roc` is not materialised (no caller reads it)."""
+    dp, dn = (_resident_scores(model, data, False, True), _resident_scores(model, data, True, True))
+    if dp is not None and dn is not None and dp.numel() and dn.numel():
+        from . import hipgan
+        auc, acc = hipgan.auc(dp, dn)
+        return Namespace(error=1.0 - acc, accuracy=acc, auc=auc, roc=None)
     from sklearn.metrics import roc_auc_score, roc_curve
     pos = _scores(model, data, batch_size, False)
     neg = _scores(model, data, batch_size, True)

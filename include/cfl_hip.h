@@ -304,6 +304,14 @@ int cfl_perturb(const float *x, const float *eps, int64_t B, int64_t N, float la
 int cfl_grad_penalty(const float *u, int64_t B, int64_t N, float lambda_gp, float *loss, float *v,
                      float *rowloss, cfl_stream_t stream);
 
+/* ROC AUC (ties get half credit, = sklearn.metrics.roc_auc_score) and sign accuracy of a split's scores:
+ * the `roc_auc_score` / accuracy of dist_eval, cfl/utils.py:227-274, cfl/bin/evaluate_total.py:100-118.
+ *   scores_pos [n_pos], scores_neg [n_neg] : dev fp32;  out : dev double[2] = {auc, accuracy}
+ *   accuracy = (#(pos > 0) + #(neg <= 0)) / (n_pos + n_neg)                                            */
+size_t cfl_auc_workspace_bytes(int64_t n_pos, int64_t n_neg);
+int cfl_auc(const float *scores_pos, int64_t n_pos, const float *scores_neg, int64_t n_neg, double *out,
+            void *workspace, size_t workspace_bytes, cfl_stream_t stream);
+
 /* Optional per-kernel timing (bench.py's roofline object).  While enabled,
  * every kernel the library launches is bracketed by two HIP events recorded on
  * the caller's stream.  cfl_profile_read() synchronises those events, adds the

@@ -286,3 +286,22 @@ def test_cgan_step_matches_oracle(t_dim):
         for k, v in ref.items():
             diff = np.abs(got[pre + k] - v.numpy())
             assert (diff <= 2e-4).mean() >= 0.97, (k, diff.max())
+
+
+@pytest.mark.parametrize('n_pos,n_neg,ties', [(1, 1, False), (37, 91, False), (5000, 3000, True), (70000, 90001, True)])
+def test_gpu_auc_matches_sklearn(n_pos, n_neg, ties):
+    from sklearn.metrics import roc_auc_score
+    G, _, _, _, _ = _mods()
+    rng = np.random.RandomState(n_pos)
+    sp = (rng.randn(n_pos) + 0.5).astype(np.float32)
+    sn = (rng.randn(n_neg) - 0.5).astype(np.float32)
+    if ties:                      # heavy ties, incl. exact zeros and values shared between the classes
+        sp = np.round(sp * 4) / 4
+        sn = np.round(sn * 4) / 4
+    if n_pos == 1:
+        sp[:] = 0.25
+        sn[:] = 0.25
+    a, acc = G.auc(torch.as_tensor(sp).cuda(), torch.as_tensor(sn).cuda())
+    want = roc_auc_score(np.r_[np.ones(n_pos), np.zeros(n_neg)], np.r_[sp, sn])
+    assert abs(a - want) <= 1e-12, (a, want)
+    assert abs(acc - ((sp > 0).sum() + (sn <= 0).sum()) / (n_pos + n_neg)) <= 1e-12
