@@ -6,7 +6,7 @@ import os
 
 from ..input_data import load_data_sets
 from ..models.cfl import construct_model
-from ..ops import dist_normalizer
+from ..ops import dist_ae_transformer, dist_normalizer, dist_transformer
 from ..utils import dist_check_args, dist_parser, dist_predict, load_model, reduce_product
 
 logger = logging.getLogger(__name__)
@@ -26,7 +26,10 @@ def main(predict_root, data_name, data_root, checkpoint_root, log_root, seed, da
         input_shape=a['input_shape'], ae_shape=a['ae_shape'], data_scale=data_scale,
         data_mean=data_mean, data_norm=a['data_norm'], latent_norm=latent_norm, data_type=a['data_type'])
     batch_size = a['batch_size']
+    train_tr, val_tr = dist_transformer(a['source_shape'], a['input_shape'], data_random_crop, data_mirror)
     model, _ = construct_model(
+        train_data_transformer=train_tr, val_data_transformer=val_tr,
+        ae_transformer=dist_ae_transformer(a['input_shape'], a['ae_shape']),
         is_double=a.pop('data_is_double'), disable_double=a.pop('data_disable_double'), data=data,
         data_normalizer=data_normalizer, data_unnormalizer=data_unnormalizer,
         ae_normalizer=ae_normalizer, ae_unnormalizer=ae_unnormalizer,

@@ -3,14 +3,14 @@ with ``--gan``, by the MrCGAN post epochs.
 
 Drop-in for the reference's cfl/bin/train.py flag surface and directory layout
 (checkpoints/<data>/<model.get_name()>/{model-*, best_model/, best_acc_model/}).
-The random-crop / mirror input transformers are not built and fail loudly."""
+Random crop / mirror / resize input transformers run on the GPU (cfl_image_transform)."""
 import logging
 import os
 import shutil
 
 from ..input_data import load_data_sets
 from ..models.cfl import construct_model
-from ..ops import dist_normalizer
+from ..ops import dist_ae_transformer, dist_normalizer, dist_transformer
 from ..utils import Saver, ScalarWriter, dist_check_args, dist_parser, load_model, reduce_product
 from .train_dist import setup_logging
 
@@ -22,9 +22,6 @@ def train_dist(load_pre_weights, data_switch, epochs, post_epochs, eval_epochs, 
                data_mirror, data_random_crop, data_is_image, raw_latent, data_scale, data_mean,
                latent_norm, **model_args):
     a = model_args
-    if data_mirror or data_random_crop:
-        raise NotImplementedError('random crop / mirror input transformers (cfl/ops.py:38-63,262-299) '
-                                  'are not built')
     input_size = reduce_product(a['input_shape'])
     source_size = reduce_product(a['source_shape']) if a['source_shape'] else input_size
     data = load_data_sets(os.path.join(data_root, data_name), source_size, is_image=data_is_image,
@@ -34,7 +31,10 @@ def train_dist(load_pre_weights, data_switch, epochs, post_epochs, eval_epochs, 
      latent_normalizer) = dist_normalizer(
         input_shape=a['input_shape'], ae_shape=a['ae_shape'], data_scale=data_scale,
         data_mean=data_mean, data_norm=a['data_norm'], latent_norm=latent_norm, data_type=a['data_type'])
+    train_tr, val_tr = dist_transformer(a['source_shape'], a['input_shape'], data_random_crop, data_mirror)
     model, aux = construct_model(
+        train_data_transformer=train_tr, val_data_transformer=val_tr,
+        ae_transformer=dist_ae_transformer(a['input_shape'], a['ae_shape']),
         is_double=a.pop('data_is_double'), disable_double=a.pop('data_disable_double'), data=data,
         data_normalizer=data_normalizer, data_unnormalizer=data_unnormalizer,
         ae_normalizer=ae_normalizer, ae_unnormalizer=ae_unnormalizer,

@@ -12,7 +12,7 @@ EXPORTS = ('cfl_conv_transpose_workspace_bytes', 'cfl_conv2d_transpose_wn_fwd', 
            'cfl_ew_act_fwd', 'cfl_ew_act_bwd', 'cfl_ew_add_act', 'cfl_ew_axpy', 'cfl_ew_affine_clip', 'cfl_subpixel2x_fwd',
            'cfl_subpixel2x_bwd', 'cfl_concat_cols', 'cfl_gather_prototype', 'cfl_bce_logits',
            'cfl_rowdist_loss', 'cfl_perturb_workspace_bytes', 'cfl_perturb', 'cfl_grad_penalty', 'cfl_copy_cols',
-           'cfl_tile_concat_channels', 'cfl_tile_concat_channels_bwd', 'cfl_auc_workspace_bytes', 'cfl_auc')
+           'cfl_tile_concat_channels', 'cfl_tile_concat_channels_bwd', 'cfl_auc_workspace_bytes', 'cfl_auc', 'cfl_image_transform')
 
 EW = {None: 0, 'linear': 0, 'lrelu': 1, 'relu': 2, 'tanh': 3, 'sigmoid': 4}
 
@@ -47,6 +47,7 @@ def lib():
     L.cfl_perturb_workspace_bytes.restype = sz
     L.cfl_perturb.argtypes = [vp, vp, i64, i64, f32, vp, vp, sz, vp]
     L.cfl_grad_penalty.argtypes = [vp, i64, i64, f32, vp, vp, vp, vp]
+    L.cfl_image_transform.argtypes = [vp, i64, i32, i32, i32, vp, i32, i32, vp, vp, i32, vp]
     L.cfl_auc_workspace_bytes.argtypes = [i64, i64]
     L.cfl_auc_workspace_bytes.restype = sz
     L.cfl_auc.argtypes = [vp, i64, vp, i64, vp, vp, sz, vp]
@@ -211,3 +212,15 @@ def auc(scores_pos, scores_neg):
                          out.data_ptr(), ws.data_ptr(), ws.numel() * 8, _stream()))
     a, acc = out.cpu().tolist()
     return a, acc
+
+
+def image_transform(x, out_hw, offsets=None, flip=None, resize=False):
+    """x [B,H,W,C] -> [B,h,w,C]: crop / pad window (offsets int32 [B,2] or central) or bilinear resize, then
+    optional per-sample left-right flip (flip int32 [B])."""
+    B, Hh, W, Cc = x.shape
+    y = torch.empty(B, out_hw[0], out_hw[1], Cc, dtype=torch.float32, device=x.device)
+    _check(lib().cfl_image_transform(_dev(x), B, Hh, W, Cc, _dev(y), out_hw[0], out_hw[1],
+                                     _dev(offsets, torch.int32) if offsets is not None else None,
+                                     _dev(flip, torch.int32) if flip is not None else None, int(bool(resize)),
+                                     _stream()))
+    return y

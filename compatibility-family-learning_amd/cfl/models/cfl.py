@@ -84,6 +84,7 @@ class CFL(PairModel):
             directed=directed, norm=norm, loss=loss, lr=lr, beta1=beta1, beta2=beta2,
             batch_size=batch_size, seed=seed, device=device)
         self._ema = {}
+        self._np_rng = np.random.RandomState(int(seed) + 4)    # random crops / mirrors
         self.gan_phase = None
         if gan:
             from .mrcgan import GanPhase
@@ -128,8 +129,8 @@ class CFL(PairModel):
         """What the encoder heads read for raw input rows x: the padded rows themselves (linear model) or the
         flattened ConvPCD trunk features of the normalised pixels (conv model; frozen in the post epochs)."""
         if self.trunk is None:
-            return self.to_device(x)
-        return self.trunk.forward(self._pixels(x)).clone()   # the trunk reuses its activation buffers per row count
+            return self.to_device(self._prep(x, True))
+        return self.trunk.forward(self._pixels(x, True)).clone()   # the trunk reuses its activation buffers per row count
 
     def gan_inputs(self, labeled, unl_src, unl_dst):
         """Device inputs of GanPhase.step from one labeled batch and the unlabeled source / target item
@@ -143,11 +144,9 @@ class CFL(PairModel):
         hd, B = self._heads, self.batch_size
         o = 1 if self.uses_latent else 0
         enc_in = lambda parts: self._enc_rows(parts[o] if len(parts) > 1 else parts[0])
-        img = lambda parts: self._dev(parts[0])
         lab = self.select_batch(labeled)
         dst_side = 1 if self.directed else 0
-        real = G.affine_clip(img(unl_dst), self.ae_normalizer.to_cfl_norm()) if self.ae_normalizer is not None \
-            else img(unl_dst)
+        real = self._ae_image(unl_dst[0])
         c = torch.randint(0, self.num_components, (B,), generator=self._gen, device=self.device, dtype=torch.int32)
         enc_act = hd.activations(enc_in(unl_dst), dst_side)
         prj_c = G.gather_prototype(hd.prototype_activations(enc_in(unl_src), 0), c)
@@ -169,9 +168,7 @@ class CFL(PairModel):
         hd, B = self._heads, self.batch_size
         lab = self.select_batch(labeled)
         per = 2 if len(labeled) == 8 else 1
-        an = self.ae_normalizer.to_cfl_norm() if self.ae_normalizer is not None else None
-        img = lambda a: G.affine_clip(self._dev(a), an) if an is not None else self._dev(a)
-        real_pos, real_neg = img(labeled[1 * per]), img(labeled[3 * per])
+        real_pos, real_neg = self._ae_image(labeled[1 * per]), self._ae_image(labeled[3 * per])
         cond = self._cgan_condition
         z = torch.randn(B, self.z_dim, generator=self._gen, device=self.device) * float(self.z_stddev)
         eps = torch.rand(B, 1, generator=self._gen, device=self.device)
@@ -184,8 +181,8 @@ class CFL(PairModel):
         if not self.t_dim:
             return hd.activations(self._enc_rows(a), 0)
         if self.trunk is not None:
-            return self._pixels(a)
-        return hd.normalize(self.to_device(a))[:, :self.input_size].contiguous()
+            return self._pixels(a, True)
+        return hd.normalize(self.to_device(self._prep(a, True)))[:, :self.input_size].contiguous()
 
     def post_step(self, labeled, unl_src=None, unl_dst=None):
         if self.cgan:
@@ -240,22 +237,44 @@ class CFL(PairModel):
         acts = self.gan_phase.generate(self._sample_z(x.shape[0]), hd.activations(x, 1 if self.directed else 0))
         return acts.cpu().numpy()
 
+    # -- input transformers (cfl/models/cfl.py:136-147, 309-320; cfl/ops.py:262-299) ------------------------
+    def _prep(self, x, train):
+        """Raw dataset rows -> the rows the encoder / normaliser sees: the train (random crop / mirror) or val
+        (central crop / resize) transformer on image-shaped inputs; latents and untransformed data pass through."""
+        tr = self.train_data_transformer if train else self.val_data_transformer
+        if tr is None or self.uses_latent:
+            return x
+        t = self._dev(x)
+        if t.shape[1] != int(np.prod(tr.source_shape)):
+            return x                      # already transformed (or not an image row)
+        return tr.apply(t, self._np_rng)
+
+    def _ae_image(self, x):
+        """ae-normalised image rows for the generator / discriminator: transformer, optional resize to ae_shape
+        (dist_ae_transformer), ae_normalizer."""
+        from .. import hipgan as G
+        t = self._dev(self._prep(x, True))
+        if self.ae_transformer is not None:
+            t = self.ae_transformer.apply(t, self._np_rng)
+        return G.affine_clip(t, self.ae_normalizer.to_cfl_norm()) if self.ae_normalizer is not None else t
+
     # -- ConvPCD: trunk + heads ---------------------------------------------------
-    def _pixels(self, x):
+    def _pixels(self, x, train=False):
         import torch
+        x = self._prep(x, train)
         t = x if isinstance(x, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(x, np.float32))
         return self.trunk.normalize(t.to(self.device, torch.float32))
 
     def train_step(self, batch):
         batch = self.select_batch(batch)
         if self.trunk is None:
-            return PairModel.train_step(self, batch)
+            return PairModel.train_step(self, [self._prep(b, True) for b in batch])
         import torch
         eng = self.engine
         B = batch[0].shape[0]
         # rows ordered [pos_src, neg_src, pos_dst, neg_dst]: each side's 2B rows contiguous
-        x = torch.cat([self._pixels(batch[0]), self._pixels(batch[2]),
-                       self._pixels(batch[1]), self._pixels(batch[3])])
+        x = torch.cat([self._pixels(batch[0], True), self._pixels(batch[2], True),
+                       self._pixels(batch[1], True), self._pixels(batch[3], True)])
         F = self.trunk.forward(x)
         rows = (F[0:B], F[2 * B:3 * B], F[B:2 * B], F[3 * B:4 * B])
         eng.fwd_bwd(rows)
@@ -274,7 +293,7 @@ class CFL(PairModel):
 
     def predict(self, src, dst):
         if self.trunk is None:
-            return PairModel.predict(self, src, dst)
+            return PairModel.predict(self, self._prep(src, False), self._prep(dst, False))
         import torch
         n = src.shape[0]
         F = self.trunk.forward(torch.cat([self._pixels(src), self._pixels(dst)]))
@@ -283,7 +302,7 @@ class CFL(PairModel):
     def batch_accuracy(self, batch):
         batch = self.select_batch(batch)
         if self.trunk is None:
-            return PairModel.batch_accuracy(self, batch)
+            return PairModel.batch_accuracy(self, [self._prep(b, False) for b in batch])
         sp, sn = self.predict(batch[0], batch[1]), self.predict(batch[2], batch[3])
         return 0.5 * float((sp > 0).mean() + (sn <= 0).mean())
 
@@ -402,7 +421,8 @@ class CFL(PairModel):
         from .. import engine as dp
         from ..input_data import ResidentFeatures
         resident = None
-        if not data.train.is_image and self.trunk is None:
+        if not data.train.is_image and self.trunk is None and self.train_data_transformer is None \
+                and self.val_data_transformer is None:
             resident = (ResidentFeatures(data.train, self.device), ResidentFeatures(data.val, self.device))
         shard = dp.shard_rows(self.batch_size) if dp.world_size() > 1 else None
         if shard is not None and resident is None:

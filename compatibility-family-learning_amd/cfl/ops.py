@@ -124,3 +124,92 @@ def dist_normalizer(input_shape, ae_shape, data_scale, data_mean, data_norm, lat
     else:
         ae_n, ae_u = data_n, data_u
     return data_n, data_u, ae_n, ae_u, latent_n
+
+
+# ---------------------------------------------------------------------------
+# input transformers (cfl/ops.py:28-63, 262-299): crop / random crop / resize / random mirror
+# ---------------------------------------------------------------------------
+class ImageTransform(object):
+    """source_shape -> out_shape on flattened NHWC rows.  kind: 'crop' (central window of
+    resize_image_with_crop_or_pad), 'random_crop' (tf.random_crop, one offset per sample), 'resize'
+    (tf.image.resize_images, bilinear, align_corners=False), 'reshape' (shapes equal); `mirror` adds the
+    per-sample tf.image.random_flip_left_right.  `apply` runs on the GPU (cfl_image_transform); calling the
+    object on a NumPy array applies the deterministic part on the host (tests)."""
+
+    def __init__(self, source_shape, out_shape, kind, mirror=False):
+        self.source_shape = tuple(source_shape) if len(source_shape) == 3 else tuple(source_shape) + (1,)
+        self.out_shape = tuple(out_shape) if len(out_shape) == 3 else tuple(out_shape) + (1,)
+        self.kind, self.mirror = kind, bool(mirror)
+        self.out_size = int(np.prod(self.out_shape))
+
+    @property
+    def is_identity(self):
+        return self.kind == 'reshape' and not self.mirror
+
+    def draw(self, n, rng):
+        """(offsets [n,2] or None, flips [n] or None) from a NumPy RandomState."""
+        off = flip = None
+        if self.kind == 'random_crop':
+            off = np.stack([rng.randint(0, self.source_shape[0] - self.out_shape[0] + 1, size=n),
+                            rng.randint(0, self.source_shape[1] - self.out_shape[1] + 1, size=n)], 1).astype(np.int32)
+        if self.mirror:
+            flip = (rng.rand(n) < 0.5).astype(np.int32)
+        return off, flip
+
+    def apply(self, t, rng):
+        """t: device tensor [n, prod(source_shape)] -> [n, prod(out_shape)]."""
+        import torch
+        from . import hipgan
+        n = t.shape[0]
+        x = t.contiguous().view((n,) + self.source_shape)
+        off, flip = self.draw(n, rng)
+        dev = lambda a: torch.from_numpy(a).to(t.device) if a is not None else None
+        y = hipgan.image_transform(x, self.out_shape[:2], dev(off), dev(flip), resize=self.kind == 'resize')
+        return y.view(n, self.out_size)
+
+    def __call__(self, x, offsets=None, flips=None):
+        x = np.asarray(x, np.float32).reshape((-1,) + self.source_shape)
+        n, (H, W, C), (h, w, _) = x.shape[0], self.source_shape, self.out_shape
+        y = np.zeros((n, h, w, C), np.float32)
+        for b in range(n):
+            if self.kind == 'resize':
+                fy, fx = np.arange(h) * (np.float32(H) / np.float32(h)), np.arange(w) * (np.float32(W) / np.float32(w))
+                y0, x0 = np.floor(fy).astype(int), np.floor(fx).astype(int)
+                y1, x1 = np.minimum(y0 + 1, H - 1), np.minimum(x0 + 1, W - 1)
+                ly, lx = (fy - y0).astype(np.float32)[:, None, None], (fx - x0).astype(np.float32)[None, :, None]
+                top = x[b][y0][:, x0] + (x[b][y0][:, x1] - x[b][y0][:, x0]) * lx
+                bot = x[b][y1][:, x0] + (x[b][y1][:, x1] - x[b][y1][:, x0]) * lx
+                img = top + (bot - top) * ly
+            else:
+                oy = offsets[b][0] if offsets is not None else ((H - h) // 2 if H >= h else -((h - H) // 2))
+                ox = offsets[b][1] if offsets is not None else ((W - w) // 2 if W >= w else -((w - W) // 2))
+                img = np.zeros((h, w, C), np.float32)
+                ys, xs = np.arange(h) + oy, np.arange(w) + ox
+                vy, vx = (ys >= 0) & (ys < H), (xs >= 0) & (xs < W)
+                img[np.ix_(vy, vx)] = x[b][np.ix_(ys[vy], xs[vx])]
+            if flips is not None and flips[b]:
+                img = img[:, ::-1]
+            y[b] = img
+        return y.reshape(n, -1)
+
+
+def dist_transformer(source_shape, input_shape, data_random_crop, data_mirror):
+    """(train_transformer, val_transformer) of cfl/ops.py:262-289; None stands for the plain reshape."""
+    if source_shape is not None and tuple(input_shape) != tuple(source_shape):
+        if source_shape[0] > input_shape[0]:
+            train = ImageTransform(source_shape, input_shape, 'random_crop' if data_random_crop else 'crop', data_mirror)
+            val = ImageTransform(source_shape, input_shape, 'crop')
+        else:
+            train = ImageTransform(source_shape, input_shape, 'resize', data_mirror)
+            val = ImageTransform(source_shape, input_shape, 'resize')
+        return train, val
+    if data_mirror:
+        return ImageTransform(input_shape, input_shape, 'reshape', True), None
+    return None, None
+
+
+def dist_ae_transformer(input_shape, ae_shape):
+    """cfl/ops.py:292-299: resize to the generator / discriminator resolution when it differs."""
+    if ae_shape is not None and tuple(input_shape) != tuple(ae_shape):
+        return ImageTransform(input_shape, ae_shape, 'resize')
+    return None

@@ -69,6 +69,43 @@ __global__ __launch_bounds__(EW_THREADS) void ew_affine_clip_kernel(const float 
     }
 }
 
+// input transformers of cfl/ops.py:38-63 on NHWC image batches:
+//   mode 0: crop / zero-pad window (tf.random_crop with per-sample offsets, or resize_image_with_crop_or_pad when
+//           off == NULL: central), then optional per-sample left-right flip (tf.image.random_flip_left_right)
+//   mode 1: tf.image.resize_images bilinear, align_corners = False (TF-1: src = dst * in / out), then flip
+__global__ __launch_bounds__(EW_THREADS) void image_transform_kernel(const float *x, int H, int W, int C, float *y,
+                                                                     int h, int w, int64_t n, const int32_t *off,
+                                                                     const int32_t *flip, int mode) {
+    for (int64_t o = blockIdx.x * (int64_t)EW_THREADS + threadIdx.x; o < n; o += (int64_t)gridDim.x * EW_THREADS) {
+        const int c = (int)(o % C);
+        int64_t t = o / C;
+        int j = (int)(t % w);
+        t /= w;
+        const int i = (int)(t % h);
+        const int64_t b = t / h;
+        if (flip && flip[b]) j = w - 1 - j;
+        const float *xb = x + b * (int64_t)H * W * C;
+        float v;
+        if (mode == 0) {
+            // central window: crop offset (H - h) / 2 when larger, pad offset (h - H) / 2 when smaller
+            const int oy = off ? off[2 * b] : (H >= h ? (H - h) / 2 : -((h - H) / 2));
+            const int ox = off ? off[2 * b + 1] : (W >= w ? (W - w) / 2 : -((w - W) / 2));
+            const int sy = i + oy, sx = j + ox;
+            v = (sy >= 0 && sy < H && sx >= 0 && sx < W) ? xb[((int64_t)sy * W + sx) * C + c] : 0.f;
+        } else {
+            const float fy = i * ((float)H / (float)h), fx = j * ((float)W / (float)w);
+            const int y0 = (int)floorf(fy), x0 = (int)floorf(fx);
+            const int y1 = y0 + 1 < H ? y0 + 1 : H - 1, x1 = x0 + 1 < W ? x0 + 1 : W - 1;
+            const float ly = fy - y0, lx = fx - x0;
+            const float a0 = xb[((int64_t)y0 * W + x0) * C + c], a1 = xb[((int64_t)y0 * W + x1) * C + c];
+            const float b0 = xb[((int64_t)y1 * W + x0) * C + c], b1 = xb[((int64_t)y1 * W + x1) * C + c];
+            const float top = a0 + (a1 - a0) * lx, bot = b0 + (b1 - b0) * lx;
+            v = top + (bot - top) * ly;
+        }
+        y[o] = v;
+    }
+}
+
 // sub-pixel shuffle (cfl/layers.py:212-250): out[b,2h+i,2w+j,c] = in[b,h,w,(2i+j)*Cq+c], Cq = C/4
 __global__ __launch_bounds__(EW_THREADS) void subpixel_fwd_kernel(const float *x, float *y, int64_t n, int H,
                                                                   int W, int C, int act) {
@@ -343,6 +380,16 @@ extern "C" int cfl_ew_affine_clip(const float *x, float *y, int64_t n, const Cfl
     hipLaunchKernelGGL(ew_affine_clip_kernel, dim3(ew_blocks(n)), dim3(EW_THREADS), 0, (hipStream_t)stream, x, y, n,
                        norm->mul, norm->add, norm->lo, norm->hi, norm->has_lo, norm->has_hi);
     return done("ew_affine_clip");
+}
+
+extern "C" int cfl_image_transform(const float *x, int64_t B, int H, int W, int C, float *y, int h, int w,
+                                   const int32_t *offsets, const int32_t *flip, int mode, cfl_stream_t stream) {
+    if (!x || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0 || h <= 0 || w <= 0 || mode < 0 || mode > 1)
+        return cfl_set_err(CFL_E_SHAPE, "cfl_image_transform: bad argument");
+    const int64_t n = B * h * w * C;
+    hipLaunchKernelGGL(image_transform_kernel, dim3(ew_blocks(n)), dim3(EW_THREADS), 0, (hipStream_t)stream, x, H, W, C,
+                       y, h, w, n, offsets, flip, mode);
+    return done("image_transform");
 }
 
 extern "C" int cfl_subpixel2x_fwd(const float *x, float *y, int64_t B, int H, int W, int C, int act,

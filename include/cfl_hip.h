@@ -266,6 +266,12 @@ int cfl_ew_axpy(float alpha, const float *x, float *y, int64_t n, cfl_stream_t s
 /* y = clip(x * mul + add, lo, hi): data / ae / latent normaliser (cfl/ops.py:66-143, 302-349) applied
  * to a batch that does not enter the fused pair kernels (images for the conv stacks, GAN inputs). */
 int cfl_ew_affine_clip(const float *x, float *y, int64_t n, const CflNorm *norm, cfl_stream_t stream);
+/* Input transformers of cfl/ops.py:38-63, 262-299 on NHWC batches x [B,H,W,C] -> y [B,h,w,C]:
+ * mode 0 = crop / zero-pad window (offsets [B,2] = (row, col) of tf.random_crop, NULL = the central window of
+ * resize_image_with_crop_or_pad); mode 1 = tf.image.resize_images bilinear (align_corners = False).
+ * flip [B] (nullable) = per-sample left-right flip applied to the result (tf.image.random_flip_left_right). */
+int cfl_image_transform(const float *x, int64_t B, int H, int W, int C, float *y, int h, int w,
+                        const int32_t *offsets, const int32_t *flip, int mode, cfl_stream_t stream);
 /* conv2d_subpixel scale 2 (cfl/layers.py:212-250): x [B,H,W,C] -> y [B,2H,2W,C/4],
  * y[b,2h+i,2w+j,c] = act(x[b,h,w,(2i+j)*C/4+c]); bwd scatters dy * act'(y) back (y may be NULL
  * when act == CFL_EW_NONE).                                                                  */

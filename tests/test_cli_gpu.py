@@ -87,10 +87,10 @@ def test_cfl_train_predict_linear(dataset, tmp_path):
         assert (pdir / f).exists()
 
 
-def test_unbuilt_parts_fail_loudly(dataset, tmp_path):
+def test_bad_flag_combinations_fail_loudly(dataset, tmp_path):
     from cfl.bin import train
-    with pytest.raises(NotImplementedError, match='mirror'):
-        train.main(_common(dataset, tmp_path) + ['--model-type', 'linear', '--use-threshold', '--data-mirror',
+    with pytest.raises(AssertionError):      # cfl/utils.py:70-71: the CD loss is for siamese only
+        train.main(_common(dataset, tmp_path) + ['--model-type', 'linear', '--use-threshold', '--caffe-margin', '5',
                                                  '--input-shape', '200'])
 
 
@@ -284,3 +284,23 @@ def test_cfl_conv_encoder_then_gan(tmp_path):
     assert v['CFL/Discriminator/conv2/Conv/V'].shape == (5, 5, 64, 128)
     m = st['adam_m']['CFL/Generator/fc1/fully_connected/V']
     assert np.isfinite(m).all() and np.abs(m).max() > 0
+
+
+def test_cfl_random_crop_mirror_transformers(tmp_path):
+    """--source-shape / --input-shape / --data-random-crop / --data-mirror: 20x20 source pixels, random 16x16 crops
+    (central crop for validation and prediction), ConvPCD encoder."""
+    from cfl.bin import predict, train
+    from cfl.synthetic import make_dataset
+    root = tmp_path / 'data'
+    make_dataset(str(root / 'px'), D=400, n_items=200, n_pos=200, n_neg=200, k=2, latent=6, seed=3, scale=0.3)
+    base = ['--data-name', 'px', '--data-root', str(root), '--checkpoint-root', str(tmp_path / 'ck'),
+            '--log-root', str(tmp_path / 'logs'), '--model-type', 'conv', '--data-type', 'sigmoid', '--source-shape',
+            '20', '20', '1', '--input-shape', '16', '16', '1', '--data-random-crop', '--data-mirror', '--dist-type',
+            'pcd', '--use-threshold', '--num-components', '2', '--latent-size', '8', '--batch-size', '20', '--seed', '6']
+    train.main(base + ['--epochs', '2', '--reset'])
+    ck = tmp_path / 'ck' / 'px' / 'cfl_pcd_conv_sigmoid_ls_8_nc_2_ut'
+    assert (ck / 'best_model' / 'best_accuracy').exists()
+    v = torch.load(str(ck / 'model-20.pt'), weights_only=False)['variables']
+    assert v['CFL/DistEncoder/conv1/Conv/V'].shape == (5, 5, 1, 64)
+    predict.start(base + ['--predict-root', str(tmp_path / 'pred')])
+    assert (tmp_path / 'pred' / 'px' / 'cfl_pcd_conv_sigmoid_ls_8_nc_2_ut' / 'predict.txt').exists()

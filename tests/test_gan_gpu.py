@@ -305,3 +305,25 @@ def test_gpu_auc_matches_sklearn(n_pos, n_neg, ties):
     want = roc_auc_score(np.r_[np.ones(n_pos), np.zeros(n_neg)], np.r_[sp, sn])
     assert abs(a - want) <= 1e-12, (a, want)
     assert abs(acc - ((sp > 0).sum() + (sn <= 0).sum()) / (n_pos + n_neg)) <= 1e-12
+
+
+def test_image_transform_kernel_matches_host_restatement():
+    """cfl_image_transform (crop / pad window with per-sample offsets, central window, bilinear resize, per-sample
+    mirror) against the NumPy restatement in cfl.ops.ImageTransform."""
+    from cfl import ops
+    G, _, _, _, _ = _mods()
+    rng = np.random.RandomState(9)
+    x = rng.rand(5, 12 * 10 * 3).astype(np.float32)
+    cases = [ops.ImageTransform((12, 10, 3), (8, 6, 3), 'random_crop', True),
+             ops.ImageTransform((12, 10, 3), (8, 6, 3), 'crop'),
+             ops.ImageTransform((12, 10, 3), (16, 14, 3), 'crop'),          # zero padding
+             ops.ImageTransform((12, 10, 3), (7, 15, 3), 'resize', True),
+             ops.ImageTransform((12, 10, 3), (24, 20, 3), 'resize'),
+             ops.ImageTransform((12, 10, 3), (12, 10, 3), 'reshape', True)]
+    for tr in cases:
+        r1, r2 = np.random.RandomState(3), np.random.RandomState(3)
+        got = tr.apply(torch.as_tensor(x).cuda(), r1).cpu().numpy()
+        off, flip = tr.draw(5, r2)
+        want = tr(x, off, flip)
+        assert got.shape == want.shape
+        assert np.abs(got - want).max() <= (1e-6 if tr.kind == 'resize' else 0.0), tr.kind
