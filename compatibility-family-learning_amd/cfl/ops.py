@@ -79,8 +79,8 @@ def _scalar(v, what):
     if isinstance(v, (list, tuple)):
         if len(v) != 1:
             raise NotImplementedError(
-                'per-channel %s (cfl/ops.py:84-106) belongs to the image path, which is '
-                'outside the linear hot path' % what)
+                'per-channel %s (cfl/ops.py:84-106) is not built: no shipped experiment uses it; '
+                'scalar --data-mean / --data-norm are' % what)
         return float(v[0])
     return float(v)
 
