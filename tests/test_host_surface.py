@@ -164,3 +164,38 @@ def test_checkpoint_converter_npz_round_trip(tmp_path):
     assert got['global_step'] == 7 and abs(got['beta1_power'] - 0.81) < 1e-6
     with pytest.raises(SystemExit):
         C.main(['--from-tf', str(tmp_path / 'nope'), str(back)])
+
+
+def test_input_transformer_descriptors():
+    """cfl.ops.dist_transformer / dist_ae_transformer (cfl/ops.py:262-299) and the NumPy restatement of the
+    window / resize / mirror arithmetic the GPU kernel is checked against."""
+    assert ops.dist_transformer(None, (28, 28, 1), False, False) == (None, None)
+    tr, va = ops.dist_transformer((20, 20, 1), (16, 16, 1), True, True)
+    assert (tr.kind, tr.mirror, va.kind, va.mirror) == ('random_crop', True, 'crop', False)
+    tr, va = ops.dist_transformer((20, 20, 1), (16, 16, 1), False, False)
+    assert tr.kind == 'crop' and va.kind == 'crop'
+    tr, va = ops.dist_transformer((8, 8, 3), (16, 16, 3), False, True)
+    assert tr.kind == 'resize' and tr.mirror and va.kind == 'resize' and not va.mirror
+    tr, va = ops.dist_transformer(None, (8, 8, 3), False, True)
+    assert tr.kind == 'reshape' and tr.mirror and va is None
+    assert ops.dist_ae_transformer((28, 28, 1), None) is None
+    assert ops.dist_ae_transformer((28, 28, 1), (32, 32, 1)).kind == 'resize'
+    rng = np.random.RandomState(0)
+    x = rng.rand(3, 6 * 5 * 2).astype(np.float32)
+    img = x.reshape(3, 6, 5, 2)
+    crop = ops.ImageTransform((6, 5, 2), (4, 3, 2), 'crop')
+    assert np.array_equal(crop(x).reshape(3, 4, 3, 2), img[:, 1:5, 1:4])          # central window
+    off = np.array([[0, 0], [2, 2], [1, 0]], np.int32)
+    got = ops.ImageTransform((6, 5, 2), (4, 3, 2), 'random_crop')(x, off).reshape(3, 4, 3, 2)
+    assert np.array_equal(got[1], img[1, 2:6, 2:5]) and np.array_equal(got[2], img[2, 1:5, 0:3])
+    pad = ops.ImageTransform((6, 5, 2), (8, 7, 2), 'crop')(x).reshape(3, 8, 7, 2)
+    assert np.array_equal(pad[:, 1:7, 1:6], img) and pad[:, 0].sum() == 0 and pad[:, :, 0].sum() == 0
+    same = ops.ImageTransform((6, 5, 2), (6, 5, 2), 'resize')(x)
+    assert np.allclose(same, x)
+    up = ops.ImageTransform((6, 5, 2), (12, 10, 2), 'resize')(x).reshape(3, 12, 10, 2)
+    assert np.allclose(up[:, ::2, ::2], img)                                       # src = dst / 2: even pixels exact
+    flip = ops.ImageTransform((6, 5, 2), (6, 5, 2), 'reshape', True)
+    once = flip(x, None, np.ones(3, np.int32))
+    assert np.array_equal(once.reshape(3, 6, 5, 2), img[:, :, ::-1]) and np.array_equal(flip(once, None, np.ones(3, np.int32)), x)
+    o, f = ops.ImageTransform((20, 20, 1), (16, 16, 1), 'random_crop', True).draw(1000, np.random.RandomState(1))
+    assert o.min() == 0 and o.max() == 4 and 0.4 < f.mean() < 0.6
