@@ -319,7 +319,9 @@ __device__ __forceinline__ void proj_body(const ProjJob &jb, const ProjArgs &a, 
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                 for (int gg = 0; gg < 2; ++gg) af[mt][gg] = tile[(mt * 16 + r16) * 8 + ((4 * gg + q4) ^ (r16 & 7))];
+#ifdef CFL_STAMPS
             if (qq == 0) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); STAMP(1); }
+#endif
 #ifndef ABL_PROJ_NOMFMA
 #pragma unroll
             for (int gg = 0; gg < 2; ++gg)
