@@ -12,7 +12,8 @@ EXPORTS = ('cfl_conv_transpose_workspace_bytes', 'cfl_conv2d_transpose_wn_fwd', 
            'cfl_ew_act_fwd', 'cfl_ew_act_bwd', 'cfl_ew_add_act', 'cfl_ew_axpy', 'cfl_ew_affine_clip', 'cfl_subpixel2x_fwd',
            'cfl_subpixel2x_bwd', 'cfl_concat_cols', 'cfl_gather_prototype', 'cfl_bce_logits',
            'cfl_rowdist_loss', 'cfl_perturb_workspace_bytes', 'cfl_perturb', 'cfl_grad_penalty', 'cfl_copy_cols',
-           'cfl_tile_concat_channels', 'cfl_tile_concat_channels_bwd', 'cfl_auc_workspace_bytes', 'cfl_auc', 'cfl_image_transform')
+           'cfl_tile_concat_channels', 'cfl_tile_concat_channels_bwd', 'cfl_auc_workspace_bytes', 'cfl_auc', 'cfl_image_transform',
+           'cfl_ew_affine_clip_channels')
 
 EW = {None: 0, 'linear': 0, 'lrelu': 1, 'relu': 2, 'tanh': 3, 'sigmoid': 4}
 
@@ -47,6 +48,8 @@ def lib():
     L.cfl_perturb_workspace_bytes.restype = sz
     L.cfl_perturb.argtypes = [vp, vp, i64, i64, f32, vp, vp, sz, vp]
     L.cfl_grad_penalty.argtypes = [vp, i64, i64, f32, vp, vp, vp, vp]
+    L.cfl_ew_affine_clip_channels.argtypes = [vp, vp, i64, i32, C.POINTER(C.c_float), C.POINTER(C.c_float),
+                                              C.POINTER(H.CflNorm), vp]
     L.cfl_image_transform.argtypes = [vp, i64, i32, i32, i32, vp, i32, i32, vp, vp, i32, vp]
     L.cfl_auc_workspace_bytes.argtypes = [i64, i64]
     L.cfl_auc_workspace_bytes.restype = sz
@@ -114,6 +117,16 @@ def affine_clip(x, norm, out=None):
     """norm: hipabi.CflNorm (Normalizer.to_cfl_norm())."""
     out = torch.empty_like(x) if out is None else out
     _check(lib().cfl_ew_affine_clip(_dev(x), _dev(out), x.numel(), C.byref(norm), _stream()))
+    return out
+
+
+def affine_clip_channels(x, mul, add, clip, out=None):
+    """per-channel y = clip(x * mul[c] + add[c]) for NHWC rows (c = element index mod len(mul) <= 4)."""
+    out = torch.empty_like(x) if out is None else out
+    n = len(mul)
+    m = (C.c_float * n)(*[float(v) for v in mul])
+    a = (C.c_float * n)(*[float(v) for v in add])
+    _check(lib().cfl_ew_affine_clip_channels(_dev(x), _dev(out), x.numel(), n, m, a, C.byref(clip), _stream()))
     return out
 
 

@@ -64,7 +64,10 @@ class CFL(PairModel):
             enc_norm = latent_normalizer
         else:
             enc_norm = data_normalizer
-        norm = enc_norm.to_cfl_norm() if enc_norm is not None else H.make_norm()
+        # a per-channel normaliser cannot ride in the pair kernels' scalar affine map: it is applied as an explicit
+        # pass on the rows (after the transformer) and the kernels see the identity
+        self._explicit_norm = enc_norm if (enc_norm is not None and enc_norm.per_channel) else None
+        norm = H.make_norm() if (enc_norm is None or self._explicit_norm is not None) else enc_norm.to_cfl_norm()
         loss = H.make_loss(use_threshold=use_threshold, pos_weight=pos_weight,
                            caffe_margin=caffe_margin, lambda_m=lambda_m, reg_const=reg_const)
         self.trunk = None
@@ -75,8 +78,9 @@ class CFL(PairModel):
             import torch
             dev = torch.device(device if device is not None else 'cuda')
             shape3 = self.input_shape if len(self.input_shape) == 3 else self.input_shape + (1,)
-            self.trunk = ConvTrunk(shape3, 4 * batch_size, norm, reg_const, lr, beta1, beta2, 1e-8,
+            self.trunk = ConvTrunk(shape3, 4 * batch_size, enc_norm, reg_const, lr, beta1, beta2, 1e-8,
                                    np.random.RandomState(seed + 1), dev)
+            self._explicit_norm = None     # the trunk applies the data normaliser itself
             head_inputs, norm = self.trunk.feature_size, H.make_norm()
         self._setup_engine(
             head_inputs, latent_size, num_components, dist_type,
@@ -242,21 +246,26 @@ class CFL(PairModel):
         """Raw dataset rows -> the rows the encoder / normaliser sees: the train (random crop / mirror) or val
         (central crop / resize) transformer on image-shaped inputs; latents and untransformed data pass through."""
         tr = self.train_data_transformer if train else self.val_data_transformer
-        if tr is None or self.uses_latent:
+        if self.uses_latent or (tr is None and self._explicit_norm is None):
             return x
         t = self._dev(x)
-        if t.shape[1] != int(np.prod(tr.source_shape)):
-            return x                      # already transformed (or not an image row)
-        return tr.apply(t, self._np_rng)
+        if tr is not None and t.shape[1] == int(np.prod(tr.source_shape)):
+            t = tr.apply(t, self._np_rng)
+        if self._explicit_norm is not None:
+            t = self._explicit_norm.apply(t)
+        return t
 
     def _ae_image(self, x):
         """ae-normalised image rows for the generator / discriminator: transformer, optional resize to ae_shape
         (dist_ae_transformer), ae_normalizer."""
         from .. import hipgan as G
-        t = self._dev(self._prep(x, True))
+        tr = self.train_data_transformer
+        t = self._dev(x)
+        if tr is not None and t.shape[1] == int(np.prod(tr.source_shape)):
+            t = tr.apply(t, self._np_rng)
         if self.ae_transformer is not None:
             t = self.ae_transformer.apply(t, self._np_rng)
-        return G.affine_clip(t, self.ae_normalizer.to_cfl_norm()) if self.ae_normalizer is not None else t
+        return self.ae_normalizer.apply(t) if self.ae_normalizer is not None else t
 
     # -- ConvPCD: trunk + heads ---------------------------------------------------
     def _pixels(self, x, train=False):
@@ -422,7 +431,7 @@ class CFL(PairModel):
         from ..input_data import ResidentFeatures
         resident = None
         if not data.train.is_image and self.trunk is None and self.train_data_transformer is None \
-                and self.val_data_transformer is None:
+                and self.val_data_transformer is None and self._explicit_norm is None:
             resident = (ResidentFeatures(data.train, self.device), ResidentFeatures(data.val, self.device))
         shard = dp.shard_rows(self.batch_size) if dp.world_size() > 1 else None
         if shard is not None and resident is None:

@@ -76,13 +76,8 @@ class ConvTrunk(object):
         return plan
 
     def normalize(self, x):
-        """data_normalizer (cfl/ops.py:66-124) on the raw [rows, prod(shape)] pixels (cfl_ew_affine_clip)."""
-        from .. import hipgan
-        n = self.norm
-        x = x.contiguous()
-        if n.mul == 1.0 and n.add == 0.0 and not (n.has_lo or n.has_hi):
-            return x
-        return hipgan.affine_clip(x, n)
+        """data_normalizer (cfl/ops.py:66-124, scalar or per-channel) on the raw [rows, prod(shape)] pixels."""
+        return self.norm.apply(x) if self.norm is not None else x.contiguous()
 
     def forward(self, x_rows):
         """x_rows: [rows, H*W*C] device tensor (already normalised) -> features [rows, F]."""

@@ -20,13 +20,24 @@ class Normalizer(object):
     """x_hat = clip(x * mul + add, lo, hi), optionally reshaped to (-1, prod(shape))."""
 
     def __init__(self, mul=1.0, add=0.0, lo=None, hi=None, input_shape=None, spec=None):
-        self.mul, self.add, self.lo, self.hi = float(mul), float(add), lo, hi
+        # per-channel (cfl/ops.py:84-106): mul / add are sequences over the last (channel) axis of input_shape
+        self.per_channel = isinstance(mul, (list, tuple, np.ndarray))
+        if self.per_channel:
+            self.mul = [float(v) for v in mul]
+            self.add = [float(v) for v in add]
+        else:
+            self.mul, self.add = float(mul), float(add)
+        self.lo, self.hi = lo, hi
         self.input_shape = tuple(input_shape) if input_shape else None
         self.spec = spec or {}
 
     def __call__(self, x):
         x = np.asarray(x)
-        y = x * x.dtype.type(self.mul) + x.dtype.type(self.add)
+        if self.per_channel:
+            c = len(self.mul)
+            y = (x.reshape(-1, c) * np.asarray(self.mul, x.dtype) + np.asarray(self.add, x.dtype)).reshape(x.shape)
+        else:
+            y = x * x.dtype.type(self.mul) + x.dtype.type(self.add)
         if self.lo is not None or self.hi is not None:
             y = np.clip(y, self.lo, self.hi)
         if self.input_shape:
@@ -35,7 +46,18 @@ class Normalizer(object):
 
     def to_cfl_norm(self):
         from . import hipabi
+        if self.per_channel:
+            raise ValueError('a per-channel normaliser cannot be folded into the pair kernels; use apply()')
         return hipabi.make_norm(self.mul, self.add, self.lo, self.hi)
+
+    def apply(self, t):
+        """The normaliser as an explicit pass over a device tensor (images of the conv stacks, GAN inputs)."""
+        from . import hipabi, hipgan
+        if self.per_channel:
+            return hipgan.affine_clip_channels(t.contiguous(), self.mul, self.add, hipabi.make_norm(1.0, 0.0, self.lo, self.hi))
+        if self.mul == 1.0 and self.add == 0.0 and self.lo is None and self.hi is None:
+            return t.contiguous()
+        return hipgan.affine_clip(t.contiguous(), self.to_cfl_norm())
 
     def inverse(self):
         return Unnormalizer(self.mul, self.add, self.input_shape)
@@ -43,11 +65,18 @@ class Normalizer(object):
 
 class Unnormalizer(object):
     def __init__(self, mul, add, input_shape=None):
-        self.mul, self.add, self.input_shape = float(mul), float(add), input_shape
+        self.per_channel = isinstance(mul, (list, tuple, np.ndarray))
+        self.mul = [float(v) for v in mul] if self.per_channel else float(mul)
+        self.add = [float(v) for v in add] if self.per_channel else float(add)
+        self.input_shape = input_shape
 
     def __call__(self, y):
         y = np.asarray(y)
-        x = (y - y.dtype.type(self.add)) / y.dtype.type(self.mul)
+        if self.per_channel:
+            c = len(self.mul)
+            x = ((y.reshape(-1, c) - np.asarray(self.add, y.dtype)) / np.asarray(self.mul, y.dtype)).reshape(y.shape)
+        else:
+            x = (y - y.dtype.type(self.add)) / y.dtype.type(self.mul)
         if self.input_shape:
             x = x.reshape((-1,) + tuple(self.input_shape))
         return x
@@ -73,25 +102,35 @@ def unnormalizer(scale, shift):
     return Unnormalizer(1.0 / scale, shift)
 
 
-def _scalar(v, what):
+def _channels(v, what, input_shape):
+    """None, a scalar, a 1-list (scalar) or one value per channel of input_shape (cfl/ops.py:84-106)."""
     if v is None:
         return None
-    if isinstance(v, (list, tuple)):
-        if len(v) != 1:
-            raise NotImplementedError(
-                'per-channel %s (cfl/ops.py:84-106) is not built: no shipped experiment uses it; '
-                'scalar --data-mean / --data-norm are' % what)
-        return float(v[0])
+    if isinstance(v, (list, tuple, np.ndarray)):
+        if len(v) == 1:
+            return float(v[0])
+        if input_shape is None or len(v) != tuple(input_shape)[-1]:
+            raise ValueError('%s has %d values but the data has %r channels' % (what, len(v), input_shape))
+        if len(v) > 4:
+            raise NotImplementedError('per-channel %s for more than 4 channels' % what)
+        return [float(t) for t in v]
     return float(v)
 
 
 def normalizer_v2(input_shape, scale=None, mean=None, norm=None, clip_value_min=None,
                   clip_value_max=None):
-    """cfl/ops.py:66-143, scalar mean / norm: ((x * scale) - mean) / norm, clip,
-    reshape(-1, prod(input_shape))."""
+    """cfl/ops.py:66-143: ((x * scale) - mean) / norm, clip, reshape(-1, prod(input_shape)); mean / norm scalar or
+    one value per channel."""
     scale = 1.0 if scale is None else float(scale)
-    mean = _scalar(mean, 'mean') or 0.0
-    norm = _scalar(norm, 'norm') or 1.0
+    mean = _channels(mean, 'mean', input_shape)
+    norm = _channels(norm, 'norm', input_shape)
+    if isinstance(mean, list) or isinstance(norm, list):
+        c = tuple(input_shape)[-1]
+        mean_c = mean if isinstance(mean, list) else [mean or 0.0] * c
+        norm_c = norm if isinstance(norm, list) else [norm or 1.0] * c
+        return Normalizer([scale / n for n in norm_c], [-m / n for m, n in zip(mean_c, norm_c)], clip_value_min,
+                          clip_value_max, input_shape, spec=dict(scale=scale, mean=mean_c, norm=norm_c))
+    mean, norm = mean or 0.0, norm or 1.0
     return Normalizer(scale / norm, -mean / norm, clip_value_min, clip_value_max, input_shape,
                       spec=dict(scale=scale, mean=mean, norm=norm))
 
@@ -103,9 +142,8 @@ def normalize_v2(tensor, input_shape, scale=None, mean=None, norm=None, clip_val
 
 def unnormalizer_v2(input_shape, scale=None, mean=None, norm=None):
     """cfl/ops.py:146-195, scalar case: (y * norm + mean) / scale."""
-    return normalizer_v2(None, scale, mean, norm).inverse() if input_shape is None else \
-        Unnormalizer((1.0 if scale is None else float(scale)) / (_scalar(norm, 'norm') or 1.0),
-                     -(_scalar(mean, 'mean') or 0.0) / (_scalar(norm, 'norm') or 1.0), input_shape)
+    n = normalizer_v2(input_shape, scale, mean, norm)
+    return Unnormalizer(n.mul, n.add, input_shape)
 
 
 CLIP_VALUES = {'sigmoid': (0., 1.), 'tanh': (-1., 1.), 'relu': (0., None), 'linear': (None, None)}

@@ -202,7 +202,7 @@ def _resident_scores(model, data, negative, device_result=False):
     Returns None when the fast path does not apply (image data, conv encoder, models without an engine)."""
     if getattr(data, 'is_image', True) or getattr(model, 'trunk', None) is not None or not hasattr(model, 'engine'):
         return None
-    if getattr(model, 'val_data_transformer', None) is not None:
+    if getattr(model, 'val_data_transformer', None) is not None or getattr(model, '_explicit_norm', None) is not None:
         return None
     try:
         import torch

@@ -69,6 +69,20 @@ __global__ __launch_bounds__(EW_THREADS) void ew_affine_clip_kernel(const float 
     }
 }
 
+// per-channel variant for NHWC images (element i belongs to channel i % C, C <= 4): cfl/ops.py:84-106
+struct ChanAffine { float mul[4], add[4]; };
+__global__ __launch_bounds__(EW_THREADS) void ew_affine_clip_chan_kernel(const float *x, float *y, int64_t n, int C,
+                                                                         ChanAffine p, float lo, float hi,
+                                                                         int has_lo, int has_hi) {
+    for (int64_t i = blockIdx.x * (int64_t)EW_THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * EW_THREADS) {
+        const int c = (int)(i % C);
+        float v = fmaf(x[i], p.mul[c], p.add[c]);
+        if (has_lo) v = fmaxf(v, lo);
+        if (has_hi) v = fminf(v, hi);
+        y[i] = v;
+    }
+}
+
 // input transformers of cfl/ops.py:38-63 on NHWC image batches:
 //   mode 0: crop / zero-pad window (tf.random_crop with per-sample offsets, or resize_image_with_crop_or_pad when
 //           off == NULL: central), then optional per-sample left-right flip (tf.image.random_flip_left_right)
@@ -380,6 +394,18 @@ extern "C" int cfl_ew_affine_clip(const float *x, float *y, int64_t n, const Cfl
     hipLaunchKernelGGL(ew_affine_clip_kernel, dim3(ew_blocks(n)), dim3(EW_THREADS), 0, (hipStream_t)stream, x, y, n,
                        norm->mul, norm->add, norm->lo, norm->hi, norm->has_lo, norm->has_hi);
     return done("ew_affine_clip");
+}
+
+extern "C" int cfl_ew_affine_clip_channels(const float *x, float *y, int64_t n, int C, const float *mul,
+                                           const float *add, const CflNorm *clip, cfl_stream_t stream) {
+    if (!x || !y || !mul || !add || !clip || n < 0 || C < 1 || C > 4 || n % C)
+        return cfl_set_err(CFL_E_SHAPE, "cfl_ew_affine_clip_channels: bad argument (1 <= C <= 4)");
+    if (n == 0) return CFL_OK;
+    ChanAffine p;
+    for (int c = 0; c < 4; ++c) { p.mul[c] = c < C ? mul[c] : 1.f; p.add[c] = c < C ? add[c] : 0.f; }
+    hipLaunchKernelGGL(ew_affine_clip_chan_kernel, dim3(ew_blocks(n)), dim3(EW_THREADS), 0, (hipStream_t)stream, x, y, n,
+                       C, p, clip->lo, clip->hi, clip->has_lo, clip->has_hi);
+    return done("ew_affine_clip_channels");
 }
 
 extern "C" int cfl_image_transform(const float *x, int64_t B, int H, int W, int C, float *y, int h, int w,

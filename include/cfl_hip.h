@@ -266,6 +266,10 @@ int cfl_ew_axpy(float alpha, const float *x, float *y, int64_t n, cfl_stream_t s
 /* y = clip(x * mul + add, lo, hi): data / ae / latent normaliser (cfl/ops.py:66-143, 302-349) applied
  * to a batch that does not enter the fused pair kernels (images for the conv stacks, GAN inputs). */
 int cfl_ew_affine_clip(const float *x, float *y, int64_t n, const CflNorm *norm, cfl_stream_t stream);
+/* per-channel mean / norm of NHWC images (cfl/ops.py:84-106): y[i] = clip(x[i] * mul[i % C] + add[i % C]);
+ * mul / add are HOST arrays of C <= 4 floats, lo / hi / has_* are taken from `clip`.                    */
+int cfl_ew_affine_clip_channels(const float *x, float *y, int64_t n, int C, const float *mul, const float *add,
+                                const CflNorm *clip, cfl_stream_t stream);
 /* Input transformers of cfl/ops.py:38-63, 262-299 on NHWC batches x [B,H,W,C] -> y [B,h,w,C]:
  * mode 0 = crop / zero-pad window (offsets [B,2] = (row, col) of tf.random_crop, NULL = the central window of
  * resize_image_with_crop_or_pad); mode 1 = tf.image.resize_images bilinear (align_corners = False).

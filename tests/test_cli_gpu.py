@@ -304,3 +304,26 @@ def test_cfl_random_crop_mirror_transformers(tmp_path):
     assert v['CFL/DistEncoder/conv1/Conv/V'].shape == (5, 5, 1, 64)
     predict.start(base + ['--predict-root', str(tmp_path / 'pred')])
     assert (tmp_path / 'pred' / 'px' / 'cfl_pcd_conv_sigmoid_ls_8_nc_2_ut' / 'predict.txt').exists()
+
+
+def test_cfl_per_channel_normaliser_linear_and_conv(tmp_path):
+    """--data-mean / --data-norm with one value per channel on RGB images: explicit normalisation pass in front of
+    the linear heads (the pair kernels fold only scalar maps) and inside the conv trunk."""
+    from cfl.bin import predict, train
+    from cfl.synthetic import make_double_dataset
+    root = tmp_path / 'data'
+    make_double_dataset(str(root / 'rgb'), image_shape=(8, 8, 3), n_items=120, n_pos=160, n_neg=160, k=2, seed=8,
+                        double=False)
+    for mt, name in (('linear', 'cfl_pcd_linear_tanh_ls_8_nc_2_ut_norm_0.25_0.3_0.35'),
+                     ('conv', 'cfl_pcd_conv_tanh_ls_8_nc_2_ut_norm_0.25_0.3_0.35')):
+        base = ['--data-name', 'rgb', '--data-root', str(root), '--checkpoint-root', str(tmp_path / 'ck'),
+                '--log-root', str(tmp_path / 'logs'), '--model-type', mt, '--data-type', 'tanh', '--data-mean', '0.5',
+                '0.45', '0.4', '--data-norm', '0.25', '0.3', '0.35', '--data-is-image', '--input-shape', '8', '8', '3',
+                '--dist-type', 'pcd', '--use-threshold', '--num-components', '2', '--latent-size', '8', '--batch-size',
+                '16', '--lr', '0.01', '--seed', '9']
+        train.main(base + ['--epochs', '2', '--reset'])
+        ck = tmp_path / 'ck' / 'rgb' / name
+        epoch, acc, auc = (ck / 'best_model' / 'best_accuracy').read_text().split('\t')
+        assert np.isfinite(float(auc)) and float(auc) > 0.4
+        predict.start(base + ['--predict-root', str(tmp_path / 'pred')])
+        assert (tmp_path / 'pred' / 'rgb' / name / 'predict.txt').exists()

@@ -327,3 +327,15 @@ def test_image_transform_kernel_matches_host_restatement():
         want = tr(x, off, flip)
         assert got.shape == want.shape
         assert np.abs(got - want).max() <= (1e-6 if tr.kind == 'resize' else 0.0), tr.kind
+
+
+def test_per_channel_normalizer_on_gpu():
+    from cfl import ops
+    rng = np.random.RandomState(10)
+    x = rng.rand(7, 4 * 5 * 3).astype(np.float32)
+    n = ops.normalizer_v2((4, 5, 3), scale=None, mean=(0.485, 0.456, 0.406), norm=(0.229, 0.224, 0.225),
+                          clip_value_min=-1.0, clip_value_max=1.0)
+    got = n.apply(torch.as_tensor(x).cuda()).cpu().numpy()
+    assert np.abs(got - n(x)).max() <= 1e-6
+    s = ops.normalizer_v2((4, 5, 3), scale=2.0, mean=0.5, norm=0.5)
+    assert np.abs(s.apply(torch.as_tensor(x).cuda()).cpu().numpy() - s(x)).max() <= 1e-6

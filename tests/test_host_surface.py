@@ -92,8 +92,16 @@ def test_normalizers():
     c = dn.to_cfl_norm()
     assert (c.mul, c.add, c.lo, c.hi, c.has_lo, c.has_hi) == (2.0, -1.0, -1.0, 1.0, 1, 1)
     assert ops.dist_normalizer((4,), None, None, None, None, None, 'relu')[0].to_cfl_norm().has_hi == 0
-    with pytest.raises(NotImplementedError):
-        ops.normalizer_v2((4,), mean=(0.1, 0.2, 0.3))
+    with pytest.raises(ValueError):
+        ops.normalizer_v2((4,), mean=(0.1, 0.2, 0.3))                 # 3 values for 4 "channels"
+    pc = ops.normalizer_v2((2, 2, 3), scale=2.0, mean=(0.1, 0.2, 0.3), norm=(0.5, 1.0, 2.0), clip_value_min=-1.0)
+    xs = np.arange(24, dtype=np.float32).reshape(2, 12) / 10
+    want = np.clip((xs.reshape(-1, 3) * 2.0 - [0.1, 0.2, 0.3]) / [0.5, 1.0, 2.0], -1.0, None).reshape(2, 12)
+    assert pc.per_channel and np.allclose(pc(xs), want, atol=1e-6)
+    assert np.allclose(ops.unnormalizer_v2((2, 2, 3), 2.0, (0.1, 0.2, 0.3), (0.5, 1.0, 2.0))(
+        ((xs.reshape(-1, 3) * 2.0 - [0.1, 0.2, 0.3]) / [0.5, 1.0, 2.0]).reshape(2, 12).astype(np.float32)).reshape(2, 12), xs, atol=1e-5)
+    with pytest.raises(ValueError):
+        pc.to_cfl_norm()
     assert np.allclose(ops.lrelu(np.array([-1., 2.])), [-0.2, 2.])
 
 
