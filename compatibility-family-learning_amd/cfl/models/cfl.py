@@ -51,8 +51,6 @@ class CFL(PairModel):
         self.source_shape = tuple(source_shape) if source_shape else self.input_shape
         if model_type not in ('linear', 'conv'):
             raise ValueError(model_type)
-        if model_type == 'conv' and directed:
-            raise NotImplementedError('directed conv encoders are not built yet')
         self.ENCODER_SCOPES = ('DistEncoderSrc', 'DistEncoderDst') if directed else ('DistEncoder',)
         # double data: the encoder reads the pre-computed latents unless --data-disable-double
         # (cfl/models/cfl.py:176-193, 578)
@@ -70,7 +68,7 @@ class CFL(PairModel):
         norm = H.make_norm() if (enc_norm is None or self._explicit_norm is not None) else enc_norm.to_cfl_norm()
         loss = H.make_loss(use_threshold=use_threshold, pos_weight=pos_weight,
                            caffe_margin=caffe_margin, lambda_m=lambda_m, reg_const=reg_const)
-        self.trunk = None
+        self.trunk = self.trunk_dst = None
         head_inputs = reduce_product(self.latent_shape if self.uses_latent else self.input_shape)
         if model_type == 'conv':
             # ConvPCD: the normaliser applies to the pixels; the heads see the flattened trunk
@@ -80,6 +78,9 @@ class CFL(PairModel):
             shape3 = self.input_shape if len(self.input_shape) == 3 else self.input_shape + (1,)
             self.trunk = ConvTrunk(shape3, 4 * batch_size, enc_norm, reg_const, lr, beta1, beta2, 1e-8,
                                    np.random.RandomState(seed + 1), dev)
+            # --directed: a second trunk for the target encoder (DistEncoderDst, cfl/models/cfl.py:676-681)
+            self.trunk_dst = ConvTrunk(shape3, 4 * batch_size, enc_norm, reg_const, lr, beta1, beta2, 1e-8,
+                                       np.random.RandomState(seed + 5), dev) if directed else self.trunk
             self._explicit_norm = None     # the trunk applies the data normaliser itself
             head_inputs, norm = self.trunk.feature_size, H.make_norm()
         self._setup_engine(
@@ -129,12 +130,14 @@ class CFL(PairModel):
         t = x if isinstance(x, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(x, np.float32))
         return t.to(self.device, torch.float32).contiguous()
 
-    def _enc_rows(self, x):
+    def _enc_rows(self, x, side=0):
         """What the encoder heads read for raw input rows x: the padded rows themselves (linear model) or the
-        flattened ConvPCD trunk features of the normalised pixels (conv model; frozen in the post epochs)."""
+        flattened ConvPCD trunk features of the normalised pixels (conv model; frozen in the post epochs).
+        side 1 = the target encoder's trunk when --directed."""
         if self.trunk is None:
             return self.to_device(self._prep(x, True))
-        return self.trunk.forward(self._pixels(x, True)).clone()   # the trunk reuses its activation buffers per row count
+        tr = self.trunk_dst if side else self.trunk
+        return tr.forward(self._pixels(x, True)).clone()   # a trunk reuses its activation buffers per row count
 
     def gan_inputs(self, labeled, unl_src, unl_dst):
         """Device inputs of GanPhase.step from one labeled batch and the unlabeled source / target item
@@ -147,15 +150,15 @@ class CFL(PairModel):
             self._heads = FrozenHeads(self.engine, self.act_type)
         hd, B = self._heads, self.batch_size
         o = 1 if self.uses_latent else 0
-        enc_in = lambda parts: self._enc_rows(parts[o] if len(parts) > 1 else parts[0])
+        enc_in = lambda parts, side=0: self._enc_rows(parts[o] if len(parts) > 1 else parts[0], side)
         lab = self.select_batch(labeled)
         dst_side = 1 if self.directed else 0
         real = self._ae_image(unl_dst[0])
         c = torch.randint(0, self.num_components, (B,), generator=self._gen, device=self.device, dtype=torch.int32)
-        enc_act = hd.activations(enc_in(unl_dst), dst_side)
+        enc_act = hd.activations(enc_in(unl_dst, dst_side), dst_side)
         prj_c = G.gather_prototype(hd.prototype_activations(enc_in(unl_src), 0), c)
         neg_c = G.gather_prototype(hd.prototype_activations(self._enc_rows(lab[2]), 0), c)
-        neg_tgt_act = hd.activations(self._enc_rows(lab[3]), dst_side)
+        neg_tgt_act = hd.activations(self._enc_rows(lab[3], dst_side), dst_side)
         z = torch.randn(B, self.z_dim, generator=self._gen, device=self.device) * float(self.z_stddev)
         eps = torch.rand(B, 1, generator=self._gen, device=self.device)
         return real, enc_act, prj_c, neg_c, neg_tgt_act, z.contiguous(), eps
@@ -237,7 +240,7 @@ class CFL(PairModel):
     def generate_target(self, dst_rows):
         """G(z, activations of the target encoder) (self.g_target)."""
         hd = self._sample_heads()
-        x = self._enc_rows(dst_rows)
+        x = self._enc_rows(dst_rows, 1 if self.directed else 0)
         acts = self.gan_phase.generate(self._sample_z(x.shape[0]), hd.activations(x, 1 if self.directed else 0))
         return acts.cpu().numpy()
 
@@ -282,22 +285,35 @@ class CFL(PairModel):
         eng = self.engine
         B = batch[0].shape[0]
         # rows ordered [pos_src, neg_src, pos_dst, neg_dst]: each side's 2B rows contiguous
-        x = torch.cat([self._pixels(batch[0], True), self._pixels(batch[2], True),
-                       self._pixels(batch[1], True), self._pixels(batch[3], True)])
-        F = self.trunk.forward(x)
-        rows = (F[0:B], F[2 * B:3 * B], F[B:2 * B], F[3 * B:4 * B])
-        eng.fwd_bwd(rows)
-        dF = torch.empty_like(F)
+        xs = torch.cat([self._pixels(batch[0], True), self._pixels(batch[2], True)])
+        xd = torch.cat([self._pixels(batch[1], True), self._pixels(batch[3], True)])
+        two = self.trunk_dst is not self.trunk
+        if two:
+            Fs, Fd = self.trunk.forward(xs), self.trunk_dst.forward(xd)
+        else:
+            F = self.trunk.forward(torch.cat([xs, xd]))
+            Fs, Fd = F[0:2 * B], F[2 * B:4 * B]
+        eng.fwd_bwd((Fs[0:B], Fd[0:B], Fs[B:2 * B], Fd[B:2 * B]))
         ws = eng._workspace(B, 2)
-        H.pair_input_grad(eng.shape, eng.norm, B, eng.theta, ws, dF[0:2 * B], dF[2 * B:4 * B])
-        self.trunk.backward(dF)
+        if two:
+            dFs, dFd = torch.empty_like(Fs), torch.empty_like(Fd)
+            H.pair_input_grad(eng.shape, eng.norm, B, eng.theta, ws, dFs, dFd)
+            self.trunk.backward(dFs)
+            self.trunk_dst.backward(dFd)
+        else:
+            dF = torch.empty_like(F)
+            H.pair_input_grad(eng.shape, eng.norm, B, eng.theta, ws, dF[0:2 * B], dF[2 * B:4 * B])
+            self.trunk.backward(dF)
         lr_t = eng.lr_t()
         scale = 1.0
+        trunks = [self.trunk, self.trunk_dst] if two else [self.trunk]
         if eng.world_size > 1:
             from ..engine import reduce_gradients
             scale = reduce_gradients(eng.grad)
-            reduce_gradients(self.trunk.grad)
-        self.trunk.apply_adam(lr_t, scale)
+            for tr in trunks:
+                reduce_gradients(tr.grad)
+        for tr in trunks:
+            tr.apply_adam(lr_t, scale)
         eng.apply_adam(scale)
 
     def predict(self, src, dst):
@@ -305,6 +321,9 @@ class CFL(PairModel):
             return PairModel.predict(self, self._prep(src, False), self._prep(dst, False))
         import torch
         n = src.shape[0]
+        if self.trunk_dst is not self.trunk:
+            Fs, Fd = self.trunk.forward(self._pixels(src)), self.trunk_dst.forward(self._pixels(dst))
+            return self.engine.scores(Fs, Fd).cpu().numpy().reshape(-1, 1)
         F = self.trunk.forward(torch.cat([self._pixels(src), self._pixels(dst)]))
         return self.engine.scores(F[:n], F[n:]).cpu().numpy().reshape(-1, 1)
 
@@ -315,20 +334,34 @@ class CFL(PairModel):
         sp, sn = self.predict(batch[0], batch[1]), self.predict(batch[2], batch[3])
         return 0.5 * float((sp > 0).mean() + (sn <= 0).mean())
 
+    def assign_trainable(self, state, ignore_missing=True):
+        """--load-pre-weights (cfl/utils.py:480-494): encoder variables of the no-gan run, incl. the conv trunks."""
+        PairModel.assign_trainable(self, state, ignore_missing)
+        for i, tr in enumerate(self._trunks()):
+            pre = 'CFL/' + self.ENCODER_SCOPES[i] + '/'
+            tr.load_named({k[len(pre):]: v for k, v in state['variables'].items() if k.startswith(pre + 'conv')})
+
+    def _trunks(self):
+        if self.trunk is None:
+            return []
+        return [self.trunk, self.trunk_dst] if self.trunk_dst is not self.trunk else [self.trunk]
+
     def scalars(self):
         s = PairModel.scalars(self)
         if self.trunk is not None and self.reg_const:
             extra = self.trunk.reg_loss()     # conv V regulariser (cfl/models/blocks.py:585)
+            if self.trunk_dst is not self.trunk:
+                extra += self.trunk_dst.reg_loss()
             s['reg'] += extra
             s['total'] += extra
         return s
 
     def checkpoint_state(self):
         st = PairModel.checkpoint_state(self)
-        if self.trunk is not None:
-            pre = 'CFL/' + self.ENCODER_SCOPES[0] + '/'
-            for key, base in (('variables', None), ('adam_m', self.trunk.m), ('adam_v', self.trunk.v)):
-                st[key].update({pre + k: v for k, v in self.trunk.named(base).items()})
+        for i, tr in enumerate(self._trunks()):
+            pre = 'CFL/' + self.ENCODER_SCOPES[i] + '/'
+            for key, base in (('variables', None), ('adam_m', tr.m), ('adam_v', tr.v)):
+                st[key].update({pre + k: v for k, v in tr.named(base).items()})
         if self.gan_phase is not None:
             for net in (self.gan_phase.gen, self.gan_phase.disc):
                 ns = net.state()
@@ -340,11 +373,10 @@ class CFL(PairModel):
 
     def load_checkpoint_state(self, state):
         PairModel.load_checkpoint_state(self, state)
-        if self.trunk is not None:
-            pre = 'CFL/' + self.ENCODER_SCOPES[0] + '/'
-            for key, base in (('variables', None), ('adam_m', self.trunk.m), ('adam_v', self.trunk.v)):
-                self.trunk.load_named({k[len(pre):]: v for k, v in state[key].items()
-                                       if k.startswith(pre + 'conv')}, base)
+        for i, tr in enumerate(self._trunks()):
+            pre = 'CFL/' + self.ENCODER_SCOPES[i] + '/'
+            for key, base in (('variables', None), ('adam_m', tr.m), ('adam_v', tr.v)):
+                tr.load_named({k[len(pre):]: v for k, v in state[key].items() if k.startswith(pre + 'conv')}, base)
         if self.gan_phase is not None and 'gan_powers' in state:
             for n, net in (('g', self.gan_phase.gen), ('d', self.gan_phase.disc)):
                 strip = lambda d: {k[4:]: v for k, v in d.items() if k.startswith('CFL/')}

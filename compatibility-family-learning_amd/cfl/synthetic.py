@@ -38,6 +38,11 @@ def make_split(path, n_items, D, n_pos, n_neg, rng, teacher, scale, noise=0.15, 
         with open(os.path.join(path, name), 'w') as f:
             for a, b in pairs:
                 f.write('{} {} {}\n'.format(ids[a], relation, ids[b]))
+    # --directed / --data-directed read the two item roles (cfl/input_data.py:403-428)
+    with open(os.path.join(path, 'source.txt'), 'w') as f:
+        f.writelines(a + '\n' for a in ids[:half])
+    with open(os.path.join(path, 'target.txt'), 'w') as f:
+        f.writelines(a + '\n' for a in ids[half:])
     return feats, pos, neg
 
 

@@ -275,11 +275,18 @@ def test_cfl_conv_encoder_then_gan(tmp_path):
     train.main(base + ['--epochs', '1', '--reset', '--disable-eval'])
     gan = ['--m-prj', '0.5', '--m-enc', '0.1', '--d-lr', '0.001', '--d-beta1', '0.9', '--g-lr', '0.001', '--g-beta1',
            '0.9', '--gan', '--z-dim', '6']
-    train.main(base + gan + ['--epochs', '0', '--post-epochs', '1', '--disable-eval'])
+    train.main(base + ['--epochs', '1', '--reset'])       # with evaluation: leaves a best_model to warm-start from
+    train.main(base + gan + ['--load-pre-weights', '--epochs', '1', '--post-epochs', '1', '--disable-eval'])
     gck = tmp_path / 'ck' / 'px' / 'cfl_pcd_conv_sigmoid_ls_8_nc_2_ut_lm_0.5_gan_z_6_m_prj_0.5_m_enc_0.1'
-    st = torch.load(str(gck / 'model-10.pt'), weights_only=False)
+    st = torch.load(str(gck / 'model-20.pt'), weights_only=False)
     v = st['variables']
     assert v['CFL/DistEncoder/conv1/Conv/V'].shape == (5, 5, 1, 64)
+    # the conv trunk was warm-started from the no-gan run's best model and stays frozen in the post epoch
+    from cfl.utils import latest_checkpoint
+    best = torch.load(latest_checkpoint(str(tmp_path / 'ck' / 'px' / 'cfl_pcd_conv_sigmoid_ls_8_nc_2_ut_lm_0.5' /
+                                            'best_model')) + '.pt', weights_only=False)['variables']
+    for k in ('CFL/DistEncoder/conv1/Conv/V', 'CFL/DistEncoder/conv2/Conv/g', 'CFL/DistEncoder/outputs/fully_connected/V'):
+        assert np.array_equal(v[k], best[k]), k
     assert v['CFL/Generator/conv_t1/Conv2d_transpose/V'].shape == (5, 5, 128, 128)
     assert v['CFL/Discriminator/conv2/Conv/V'].shape == (5, 5, 64, 128)
     m = st['adam_m']['CFL/Generator/fc1/fully_connected/V']
@@ -327,3 +334,23 @@ def test_cfl_per_channel_normaliser_linear_and_conv(tmp_path):
         assert np.isfinite(float(auc)) and float(auc) > 0.4
         predict.start(base + ['--predict-root', str(tmp_path / 'pred')])
         assert (tmp_path / 'pred' / 'rgb' / name / 'predict.txt').exists()
+
+
+def test_cfl_directed_conv_encoders(tmp_path):
+    """--directed with --model-type conv: separate source / target trunks (DistEncoderSrc / DistEncoderDst)."""
+    from cfl.bin import predict, train
+    from cfl.synthetic import make_dataset
+    root = tmp_path / 'data'
+    make_dataset(str(root / 'px'), D=256, n_items=200, n_pos=200, n_neg=200, k=2, latent=6, seed=4, scale=0.3)
+    base = ['--data-name', 'px', '--data-root', str(root), '--checkpoint-root', str(tmp_path / 'ck'),
+            '--log-root', str(tmp_path / 'logs'), '--model-type', 'conv', '--data-type', 'sigmoid', '--input-shape',
+            '16', '16', '1', '--dist-type', 'pcd', '--use-threshold', '--directed', '--num-components', '2',
+            '--latent-size', '8', '--batch-size', '20', '--seed', '7']
+    train.main(base + ['--epochs', '2', '--reset'])
+    ck = tmp_path / 'ck' / 'px' / 'cfl_pcd_conv_di_sigmoid_ls_8_nc_2_ut'
+    v = torch.load(str(ck / 'model-20.pt'), weights_only=False)['variables']
+    a, b = v['CFL/DistEncoderSrc/conv1/Conv/V'], v['CFL/DistEncoderDst/conv1/Conv/V']
+    assert a.shape == b.shape == (5, 5, 1, 64) and not np.array_equal(a, b)
+    assert 'CFL/DistEncoderDst/outputs/fully_connected/V' in v
+    predict.start(base + ['--predict-root', str(tmp_path / 'pred')])
+    assert (tmp_path / 'pred' / 'px' / 'cfl_pcd_conv_di_sigmoid_ls_8_nc_2_ut' / 'predict_acc.txt').exists()
