@@ -164,7 +164,9 @@ def init_sr_discriminator(ae_shape, latent_size, rng, dim=32, c_dim=None, t_dim=
         extra = _cond(p, s, rng, c_dim, t_dim) if (c_dim and i == 3) else 0
         _conv_p(p, s + _cname(4), rng, 4, 4, dim + extra, dim * 2)
         dim *= 2
-    side_h, side_w = ae_shape[0] >> (nb + 1), ae_shape[1] >> (nb + 1)
+    side_h, side_w = ae_shape[0], ae_shape[1]
+    for _ in range(nb + 1):                      # every stride-2 'SAME' conv: ceil(n / 2)
+        side_h, side_w = -(-side_h // 2), -(-side_w // 2)
     feat = side_h * side_w * dim
     _fc_p(p, 'disc_outputs/fully_connected', rng, feat, 1)
     _fc_p(p, 'latent_outputs/fully_connected', rng, feat, latent_size)
