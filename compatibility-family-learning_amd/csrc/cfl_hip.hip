@@ -235,6 +235,7 @@ struct ProjJob {
 struct ProjArgs {
     ProjJob job[CFL_MAX_JOBS];
     int B, R, Rpad, D, S;
+    int xcd;  // 1: blockIdx.x enumerates the d slices (see cfl_xcd_aligned)
     NormDev norm;
 };
 
@@ -244,8 +245,11 @@ __device__ __forceinline__ void proj_body(const ProjJob &jb, const ProjArgs &a, 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // provably uniform
     const int r16 = lane & 15, q4 = lane >> 4;  // MFMA: row / k index
     const int rr8 = lane >> 3, ch8 = lane & 7;  // load: row within 8-row group / 16-B chunk
-    const int row0 = blockIdx.x * 32;
-    const int s = blockIdx.y;
+    // Workgroups are dealt to the 8 XCDs round-robin by linear id.  With the d slices fastest an XCD
+    // only ever touches 1/8 of the weights (one slice of every column tile) and one d band of x --
+    // the same band the weight-gradient launch assigns to it, so part of x is still in that XCD's L2.
+    const int row0 = (a.xcd ? blockIdx.y : blockIdx.x) * 32;
+    const int s = a.xcd ? blockIdx.x : blockIdx.y;
     const int G = a.D >> 4;           // 16-d groups
     const int NC = (G + 7) >> 3;      // 128-d chunks
     const int nw = a.S * 4, wg = s * 4 + wave;
@@ -412,18 +416,27 @@ struct RedRange {
 struct GradArgs {
     GradJob job[CFL_MAX_JOBS];
     int B, R, Rpad, D, P;
+    int tps;  // > 0: 64-d tiles per projection slice, tiles are dealt to XCDs by slice (cfl_xcd_aligned)
     NormDev norm;
     RedRange red[CFL_MAX_RED];
     int nred, red_total;
     float *colsum;
 };
 
+// d tile of this workgroup.  XCD = blockIdx.x mod 8 (gridDim.x is a multiple of 8 when tps > 0); tile dt
+// belongs to projection slice dt / tps, which the projection launch ran on XCD (dt / tps) mod 8.
+__device__ __forceinline__ int grad_dtile(int tps) {
+    if (tps <= 0) return blockIdx.x;
+    const int k = blockIdx.x & 7, j = blockIdx.x >> 3;
+    return ((j / tps) * 8 + k) * tps + j % tps;
+}
+
 template <int NT>
 __device__ __forceinline__ void grad_body(const GradJob &jb, const GradArgs &a, f32x4 *lds) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // provably uniform
     const int i16 = lane & 15, kq = lane >> 4;
-    const int dbase = blockIdx.x * 64;
+    const int dbase = grad_dtile(a.tps) * 64;
     const int p = blockIdx.y;
     const int RG = a.Rpad >> 4, G = a.D >> 4;
     const int rows_wg = a.Rpad / a.P, rows_w = rows_wg >> 2;  // multiple of 64
@@ -591,7 +604,7 @@ __device__ __forceinline__ void grad_body_x3(const GradJob &jb, const GradArgs &
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i16 = lane & 15, kq = lane >> 4;
-    const int dbase = blockIdx.x * 64;
+    const int dbase = grad_dtile(a.tps) * 64;
     const int p = blockIdx.y;
     const int RG = a.Rpad >> 4, G = a.D >> 4;
     const int rows_wg = a.Rpad / a.P, rows_w = rows_wg >> 2;
@@ -1978,6 +1991,12 @@ struct Plan {
 };
 
 static inline int pow2_floor(int x) { int p = 1; while (p * 2 <= x) p *= 2; return p; }
+// XCD-aligned launch order of proj and grad: with S a multiple of 8 the d slices can be dealt one per XCD
+// (S fastest in proj), and grad deals its 64-d tiles to the XCD that projected their slice.
+static int debug_env(const char *name);
+static inline bool cfl_xcd_aligned(int S, int dtiles) {
+    return S % 8 == 0 && dtiles % S == 0 && debug_env("CFL_DEBUG_NOXCD") <= 0;
+}
 
 // tuning overrides for experiments (tools/kernel_probe.py): CFL_DEBUG_S / CFL_DEBUG_P
 static int debug_env(const char *name) {
@@ -2203,7 +2222,9 @@ static int run_pairs(const CflShape *s, const CflNorm *norm, const CflLossCfg *l
             }
         }
         pa.B = (int)rows; pa.R = pl.R; pa.Rpad = pl.Rpad; pa.D = s->D; pa.S = pl.S; pa.norm = nd;
+        pa.xcd = cfl_xcd_aligned(pl.S, s->D / 64);
         dim3 grid((pl.R + 31) / 32, pl.S, nj);
+        if (pa.xcd) grid = dim3(pl.S, (pl.R + 31) / 32, nj);
         ProfScope ps(st, CFL_K_PROJ);
         hipLaunchKernelGGL(cfl_proj_kernel, grid, dim3(256), 4 * 8 * 64 * sizeof(f32x4), st, pa);  // 32 KiB: cross-wave sum (the 4 KiB/wave transpose tiles alias it)
     }
@@ -2391,6 +2412,7 @@ static int run_pairs(const CflShape *s, const CflNorm *norm, const CflLossCfg *l
             }
         }
         ga.nred = nr; ga.red_total = tot; ga.colsum = ws + pl.colsum;
+        ga.tps = cfl_xcd_aligned(pl.S, s->D / 64) ? (s->D / 64) / pl.S : 0;
         dim3 grid(s->D / 64, pl.P, nj + 1);
         ProfScope ps(st, CFL_K_GRAD);
         if (pl.x3)
