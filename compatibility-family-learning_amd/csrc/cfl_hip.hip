@@ -1772,6 +1772,13 @@ extern "C" __global__ __launch_bounds__(256) void cfl_finalize_kernel(FinArgs a)
     for (; k < a.nregions; ++k)
         if (base >= a.reg[k].off && base < a.reg[k].off + a.reg[k].cnt) break;
     const f32x4 th = *(const f32x4 *)(a.theta + base);
+    // the Adam slots are requested together with theta and the slabs (one memory round trip, not two:
+    // behind the gradient store the compiler could not hoist them)
+    f32x4 mm = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
+    if (a.adam_m) {
+        mm = *(const f32x4 *)(a.adam_m + base);
+        vv = *(const f32x4 *)(a.adam_v + base);
+    }
     f32x4 gr = {0.f, 0.f, 0.f, 0.f};
     if (k < a.nregions) {
         const Region &rg = a.reg[k];
@@ -1871,7 +1878,6 @@ extern "C" __global__ __launch_bounds__(256) void cfl_finalize_kernel(FinArgs a)
     }
     *(f32x4 *)(a.grad + base) = gr;
     if (a.adam_m) {  // fused TF-Adam apply (single-GPU step)
-        f32x4 mm = *(const f32x4 *)(a.adam_m + base), vv = *(const f32x4 *)(a.adam_v + base);
         mm = a.b1 * mm + (1.f - a.b1) * gr;
         vv = a.b2 * vv + (1.f - a.b2) * gr * gr;
         f32x4 tn = th;

@@ -156,12 +156,15 @@ def test_step_fwd_bwd(style, dist, D, L, K, act, B, nv, lkw, directed):
     gp, gpd, gthr = H.unpack_theta(sh, grad)
     want_thr = dthr if lcfg.use_threshold else dthr_aux
     assert abs(gthr - want_thr) <= 1e-5 * max(1.0, abs(want_thr)), (gthr, want_thr)
+    # per-tensor relative bound; a tensor whose whole gradient is a cancellation residue (>1000x below the
+    # largest gradient of the step) is held to that absolute floor instead
+    gmax = max([float(np.abs(np.asarray(v)).max()) for ref in (g, gd) if ref is not None for v in ref.values()] + [0.0])
     for got, ref in ((gp, g), (gpd, gd)):
         if ref is None:
             continue
         for k in got:
             r = np.asarray(ref.get(k, np.zeros_like(got[k])), dtype=np.float64)
-            scale = max(np.abs(r).max(), 1e-6)
+            scale = max(np.abs(r).max(), 1e-3 * gmax, 1e-6)
             err = np.abs(got[k] - r).max()
             assert err <= 2e-4 * scale, (k, err, scale)
 
