@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 
 #include "../../include/cfl_hip.h"
 #include "gemm_gather.h"
@@ -252,6 +253,53 @@ struct StoreSlab {
 // ---- finalize: dV = s*dW - (s/n^2)(dW.V) V + reg*V ; dg = (dW.V)/n ; db = slab row `rows` ----------
 // one block per output channel (measured: blocking 16 / 64 channels per block for coalescing leaves
 // too few blocks on the narrow layers and is 10x slower)
+// Split-K slabs -> few slabs, coalesced.  The per-channel kernels below walk a filter column (stride Co floats),
+// which is fine for one or a few slabs but not for the ~10^2 slabs of a small-filter layer (tens of MB).  This pass
+// sums slab groups element-wise -- every load a full line, up to 16 independent loads in flight per thread, slabs added
+// in index order -- into the first slab of each group; the per-channel kernel then sees `groups` slabs `gsz * stride`
+// apart.  n = floats of a slab that carry data.
+template <int VEC>
+__global__ __launch_bounds__(256) void slab_sum_kernel(float *slab, int splits, size_t stride, size_t n, int gsz) {
+    const size_t e = ((size_t)blockIdx.x * 256 + threadIdx.x) * VEC;
+    if (e >= n) return;
+    const int z0 = blockIdx.y * gsz, z1 = z0 + gsz < splits ? z0 + gsz : splits;
+    typedef float vec_t __attribute__((ext_vector_type(VEC)));
+    float *base = slab + e;
+    vec_t acc = *(const vec_t *)(base + (size_t)z0 * stride);
+    for (int z = z0 + 1; z < z1; z += 16) {
+        vec_t v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+            if (z + u < z1) v[u] = *(const vec_t *)(base + (size_t)(z + u) * stride);
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+            if (z + u < z1) acc += v[u];
+    }
+    *(vec_t *)(base + (size_t)z0 * stride) = acc;
+}
+
+// returns the number of slab groups left (their first slabs are gsz * stride apart: *gstride)
+static int slab_presum(float *slab, int splits, size_t stride, size_t n, size_t *gstride, hipStream_t st) {
+    *gstride = stride;
+    if (splits <= 4) return splits;
+    const bool v4 = stride % 4 == 0 && n % 4 == 0 && ((uintptr_t)slab & 15) == 0;
+    const size_t threads = v4 ? n / 4 : n;
+    // enough groups for ~16 k threads, at least 8 slabs per group
+    int groups = (int)((16384 + threads - 1) / threads);
+    if (groups > splits / 8) groups = splits / 8;
+    if (groups > 16) groups = 16;
+    if (groups < 1) groups = 1;
+    const int gsz = (splits + groups - 1) / groups;
+    groups = (splits + gsz - 1) / gsz;
+    const dim3 grid((unsigned)((threads + 255) / 256), groups);
+    if (v4)
+        hipLaunchKernelGGL(slab_sum_kernel<4>, grid, dim3(256), 0, st, slab, splits, stride, n, gsz);
+    else
+        hipLaunchKernelGGL(slab_sum_kernel<1>, grid, dim3(256), 0, st, slab, splits, stride, n, gsz);
+    *gstride = (size_t)gsz * stride;
+    return groups;
+}
+
 __global__ __launch_bounds__(256) void conv_wfinal_kernel(const float *slab, int splits, size_t stride,
                                                           const float *V, const float *scale,
                                                           const float *n2, int rows, int Co, float reg,
@@ -306,12 +354,12 @@ __global__ __launch_bounds__(256) void conv_bgrad_kernel(const float *dy, const 
 }
 
 // ---- C ABI --------------------------------------------------------------------------------
-// split-K of the weight-gradient GEMM (M = taps*Ci + 4, N = Co, K = pixels): enough splits for ~2048
+// split-K of the weight-gradient GEMM (M = taps*Ci + 4, N = Co, K = pixels): enough splits for ~3072
 // workgroups given the output tile the GEMM will pick for this N, at least 512 pixels per split, <= 256 slabs
 static int wgrad_split_count(long long K, long long M, int N) {
     const int tm = N <= 16 ? 256 : (N <= 32 ? 128 : 64), tn = 64 * 64 / tm;
     const long long tiles = ((M + tm - 1) / tm) * ((N + tn - 1) / tn);
-    long long s = (2048 + tiles - 1) / tiles;
+    long long s = (3072 + tiles - 1) / tiles;
     if (s > K / 512) s = K / 512;
     if (s > 256) s = 256;
     if (s < 1) s = 1;
@@ -407,7 +455,9 @@ extern "C" int cfl_conv2d_wn_bwd(const CflConv *c, const float *x, const float *
         else
             gemm_gather(rows + 4, g.Co, npix, wgrad_klen(g), Im2colXT{Im2colX{x, g}, rows}, DyPre{dy, y, g.Co, g.act},
                         StoreSlab{slab, sstride, g.Co}, st);
-        hipLaunchKernelGGL(conv_wfinal_kernel, dim3(g.Co), dim3(256), 0, st, slab, splits, sstride, V, scale, n2, rows,
+        size_t gstride;
+        const int groups = slab_presum(slab, splits, sstride, (size_t)(rows + 1) * g.Co, &gstride, st);
+        hipLaunchKernelGGL(conv_wfinal_kernel, dim3(g.Co), dim3(256), 0, st, slab, groups, gstride, V, scale, n2, rows,
                            g.Co, reg_const, dV, gain ? dg : nullptr, db);
     } else if (db) {
         hipLaunchKernelGGL(conv_bgrad_kernel, dim3(g.Co), dim3(256), 0, st, dy, y, npix, g.Co, g.act, db);
@@ -638,7 +688,9 @@ extern "C" int cfl_conv2d_transpose_wn_bwd(const CflConv *c, const float *x, con
         else
             gemm_gather(taps * Co, Ci, npix_in, klen, TIm2colDyT{TIm2colDy{dy, y, nullptr, g}}, PlainKN{x, Ci},
                         StoreSlab{slab, welems, Ci}, st);
-        hipLaunchKernelGGL(convt_wfinal_kernel, dim3(Co), dim3(256), 0, st, slab, splits, welems, V, scale, n2,
+        size_t gstride;
+        const int groups = slab_presum(slab, splits, welems, welems, &gstride, st);
+        hipLaunchKernelGGL(convt_wfinal_kernel, dim3(Co), dim3(256), 0, st, slab, groups, gstride, V, scale, n2,
                            taps, Co, Ci, reg_const, dV, gain ? dg : nullptr);
     }
     if (db) hipLaunchKernelGGL(conv_bgrad_kernel, dim3(Co), dim3(256), 0, st, dy, y, g.B * g.H * g.W, Co, g.act, db);

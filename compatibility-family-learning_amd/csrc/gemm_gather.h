@@ -9,6 +9,7 @@
 // are staged with one index computation and one 16-byte load per 4 elements (modes below).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 
 typedef float gg_f32x4 __attribute__((ext_vector_type(4)));
 
@@ -154,6 +155,156 @@ __global__ __launch_bounds__(256) void gemm_gather_kernel(int M, int N, int K, i
             }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// bf16x3 variant (vector staging modes only): the same GEMM on v_mfma_f32_16x16x32_bf16 at fp32-level
+// accuracy.  Every staged fp32 value is split exactly into three bf16 values v = h + m + l (truncation:
+// h = v & 0xffff0000, m = (v - h) & 0xffff0000, l = v - h - m; both subtractions exact) ONCE, at staging
+// time, and parked in LDS as three bf16 planes; a product is accumulated in fp32 from the six partial
+// products of weight >= 2^-16 (hh, hm, mh, hl, lh, mm; dropped terms <= 2^-21 |ab| worst case, 2^-24 rms --
+// see cfl_hip.hip / tests/test_bf16x3_split.py).  Six bf16 MFMAs over K = 32 cost 96 cycles against 256
+// for the eight fp32 MFMAs they replace.  K step 32; tile shapes, split-K and Store functors as above.
+//   LDS plane row = 32 bf16 + 8 pad (80 bytes: the b128 fragment reads stay conflict-free).
+//   MFMA operand: lane (r = l & 15, q = l >> 4) holds k = 8q .. 8q+7 of row / column r.
+// ---------------------------------------------------------------------------------------------------
+typedef __bf16 gg_bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int gg_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int gg_u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void gg_split3(float v, float &h, float &m, float &l) {
+    h = __uint_as_float(__float_as_uint(v) & 0xffff0000u);
+    const float r = v - h;
+    m = __uint_as_float(__float_as_uint(r) & 0xffff0000u);
+    l = r - m;
+}
+// {bf16(e1) : bf16(e0)} by truncation = the high halves of the two floats
+__device__ __forceinline__ unsigned gg_pack(float e0, float e1) {
+    return __builtin_amdgcn_perm(__float_as_uint(e1), __float_as_uint(e0), 0x07060302u);
+}
+
+template <int MT, int AMODE, int BMODE, class LoadA, class LoadB, class Store>
+__global__ __launch_bounds__(256) void gemm_gather_x3_kernel(int M, int N, int K, int klen, LoadA la,
+                                                             LoadB lb, Store st) {
+    static_assert(AMODE != GG_SCALAR && BMODE != GG_SCALAR, "bf16x3 path: vector staging modes only");
+    constexpr int NT = 4 / MT, TM = 64 * MT, TN = 64 / MT, RS = 40;   // RS: plane row stride in bf16
+    __shared__ __attribute__((aligned(16))) unsigned short As[3][TM][RS];
+    __shared__ __attribute__((aligned(16))) unsigned short Bs[3][TN][RS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r16 = lane & 15, q = lane >> 4;
+    const int m0 = blockIdx.x * TM, n0 = blockIdx.y * TN;
+    const int kbeg = blockIdx.z * klen, kend = min(K, kbeg + klen);
+    // staging work items (8 values each):
+    //   VEC_K : one row / column, 8 consecutive k  (two 16-byte gathers)      -> one b128 store per plane
+    //   VEC_MN: 4 consecutive rows / columns at k and k+1 (two 16-byte gathers) -> four b32 stores per plane
+    const int lm = tid >> 2, lk = (tid & 3) * 8;
+    const int tk = (tid >> 4) * 2, tm = (tid & 15) * 4;
+    const int bk = (tid / (TN / 4)) * 2, bn = (tid % (TN / 4)) * 4;
+    const bool bact = tid < 4 * TN;
+    gg_f32x4 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (gg_f32x4){0.f, 0.f, 0.f, 0.f};
+    const gg_f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    auto gather = [&](int k0, gg_f32x4 (&av)[MT][2], gg_f32x4 (&bv)[2]) {
+#pragma unroll
+        for (int p = 0; p < MT; ++p) {
+            if constexpr (AMODE == GG_VEC_K) {
+                const int m = m0 + p * 64 + lm;
+                av[p][0] = (m < M && k0 + lk < kend) ? la.v4(m, k0 + lk) : zero;
+                av[p][1] = (m < M && k0 + lk + 4 < kend) ? la.v4(m, k0 + lk + 4) : zero;
+            } else {
+                const int m = m0 + p * 64 + tm;
+                av[p][0] = (m < M && k0 + tk < kend) ? la.v4(m, k0 + tk) : zero;
+                av[p][1] = (m < M && k0 + tk + 1 < kend) ? la.v4(m, k0 + tk + 1) : zero;
+            }
+        }
+        bv[0] = zero; bv[1] = zero;
+        if (bact) {
+            if constexpr (BMODE == GG_VEC_K) {
+                if (n0 + lm < N && k0 + lk < kend) bv[0] = lb.v4(k0 + lk, n0 + lm);
+                if (n0 + lm < N && k0 + lk + 4 < kend) bv[1] = lb.v4(k0 + lk + 4, n0 + lm);
+            } else {
+                if (n0 + bn < N && k0 + bk < kend) bv[0] = lb.v4(k0 + bk, n0 + bn);
+                if (n0 + bn < N && k0 + bk + 1 < kend) bv[1] = lb.v4(k0 + bk + 1, n0 + bn);
+            }
+        }
+    };
+    // split the 8 staged values and park the three planes
+    auto park_k = [&](unsigned short (*pl)[RS], int planes_stride, int row, int k, const gg_f32x4 (&v)[2]) {
+        float h[8], m[8], l[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) gg_split3(v[i >> 2][i & 3], h[i], m[i], l[i]);
+        gg_u32x4 ph, pm, pq;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            ph[i] = gg_pack(h[2 * i], h[2 * i + 1]);
+            pm[i] = gg_pack(m[2 * i], m[2 * i + 1]);
+            pq[i] = gg_pack(l[2 * i], l[2 * i + 1]);
+        }
+        *(gg_u32x4 *)&pl[row][k] = ph;
+        *(gg_u32x4 *)&pl[planes_stride + row][k] = pm;
+        *(gg_u32x4 *)&pl[2 * planes_stride + row][k] = pq;
+    };
+    auto park_mn = [&](unsigned short (*pl)[RS], int planes_stride, int row, int k, const gg_f32x4 (&v)[2]) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float h0, m0_, l0, h1, m1, l1;
+            gg_split3(v[0][e], h0, m0_, l0);
+            gg_split3(v[1][e], h1, m1, l1);
+            *(unsigned *)&pl[row + e][k] = gg_pack(h0, h1);
+            *(unsigned *)&pl[planes_stride + row + e][k] = gg_pack(m0_, m1);
+            *(unsigned *)&pl[2 * planes_stride + row + e][k] = gg_pack(l0, l1);
+        }
+    };
+    gg_f32x4 av[MT][2], bv[2];
+    if (kbeg < kend) gather(kbeg, av, bv);
+    for (int k0 = kbeg; k0 < kend; k0 += 32) {
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < MT; ++p) {
+            if constexpr (AMODE == GG_VEC_K) park_k(As[0], TM, p * 64 + lm, lk, av[p]);
+            else park_mn(As[0], TM, p * 64 + tm, tk, av[p]);
+        }
+        if (bact) {
+            if constexpr (BMODE == GG_VEC_K) park_k(Bs[0], TN, lm, lk, bv);
+            else park_mn(Bs[0], TN, bn, bk, bv);
+        }
+        __syncthreads();
+        if (k0 + 32 < kend) gather(k0 + 32, av, bv);
+        gg_bf16x8 a[3][MT], b[3][NT];
+#pragma unroll
+        for (int lv = 0; lv < 3; ++lv) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+                a[lv][mt] = *(const gg_bf16x8 *)&As[lv][(wave * MT + mt) * 16 + r16][8 * q];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) b[lv][nt] = *(const gg_bf16x8 *)&Bs[lv][nt * 16 + r16][8 * q];
+        }
+        // small terms first; consecutive MFMAs hit different accumulators
+#define GG_X3(LA, LB)                                                                                   \
+    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) \
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[LA][mt], b[LB][nt], acc[mt][nt], 0, 0, 0);
+        GG_X3(1, 1) GG_X3(2, 0) GG_X3(0, 2) GG_X3(1, 0) GG_X3(0, 1) GG_X3(0, 0)
+#undef GG_X3
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int m = m0 + (wave * MT + mt) * 16 + 4 * q + e, n = n0 + nt * 16 + r16;
+                if (m < M && n < N) st(m, n, acc[mt][nt][e], (int)blockIdx.z);
+            }
+}
+
+// 1: bf16x3 matrix-core arithmetic for the vector-staged GEMMs (default); 0 with CFL_EXACT_FP32=1 in the
+// environment (k-ordered fp32 FMA chains of v_mfma_f32_16x16x4_f32, as for the pair step)
+static inline bool gg_use_x3() {
+    static const int v = [] { const char *e = getenv("CFL_EXACT_FP32"); return (e && atoi(e) > 0) ? 0 : 1; }();
+    return v != 0;
+}
+
 // K-range per split (multiple of 16) for about `want` splits; the split count is ceil(K / klen)
 static inline int gg_klen(long long K, int want) {
     if (want < 1) want = 1;
@@ -165,6 +316,24 @@ template <int AMODE, int BMODE, class LoadA, class LoadB, class Store>
 static inline void gemm_gather_modes(int M, int N, int K, int klen, LoadA la, LoadB lb, Store st,
                                      hipStream_t stream) {
     const int splits = gg_splits(K, klen);
+    if constexpr (AMODE != GG_SCALAR && BMODE != GG_SCALAR) {
+        if (gg_use_x3()) {
+            if (N <= 16) {
+                dim3 grid((M + 255) / 256, (N + 15) / 16, splits);
+                hipLaunchKernelGGL((gemm_gather_x3_kernel<4, AMODE, BMODE, LoadA, LoadB, Store>), grid, dim3(256), 0,
+                                   stream, M, N, K, klen, la, lb, st);
+            } else if (N <= 32) {
+                dim3 grid((M + 127) / 128, (N + 31) / 32, splits);
+                hipLaunchKernelGGL((gemm_gather_x3_kernel<2, AMODE, BMODE, LoadA, LoadB, Store>), grid, dim3(256), 0,
+                                   stream, M, N, K, klen, la, lb, st);
+            } else {
+                dim3 grid((M + 63) / 64, (N + 63) / 64, splits);
+                hipLaunchKernelGGL((gemm_gather_x3_kernel<1, AMODE, BMODE, LoadA, LoadB, Store>), grid, dim3(256), 0,
+                                   stream, M, N, K, klen, la, lb, st);
+            }
+            return;
+        }
+    }
     if (N <= 16) {
         dim3 grid((M + 255) / 256, (N + 15) / 16, splits);
         hipLaunchKernelGGL((gemm_gather_kernel<4, AMODE, BMODE, LoadA, LoadB, Store>), grid, dim3(256), 0, stream,
