@@ -181,20 +181,39 @@ __device__ __forceinline__ unsigned gg_pack(float e0, float e1) {
     return __builtin_amdgcn_perm(__float_as_uint(e1), __float_as_uint(e0), 0x07060302u);
 }
 
+// Row stride (bf16 elements) of a [k][m] image with `cols` columns: the smallest stride >= cols whose 32-bit word
+// count is 16 mod 32.  Together with the chunk swizzle below (16-column chunk index XOR bit 3 of k) the eight
+// 4-row x 32-byte blocks that one 32-lane half fetches with ds_read_b64_tr_b16 fall on 64 distinct banks.
+constexpr int gg_tr_stride(int cols) {
+    int w = cols / 2 < 16 ? 16 : cols / 2;
+    while (w % 32 != 16) w += 2;
+    return 2 * w;
+}
+typedef short gg_s16x4 __attribute__((ext_vector_type(4)));
+typedef short gg_s16x8 __attribute__((ext_vector_type(8)));
+
 template <int MT, int AMODE, int BMODE, class LoadA, class LoadB, class Store>
 __global__ __launch_bounds__(256) void gemm_gather_x3_kernel(int M, int N, int K, int klen, LoadA la,
                                                              LoadB lb, Store st) {
     static_assert(AMODE != GG_SCALAR && BMODE != GG_SCALAR, "bf16x3 path: vector staging modes only");
-    constexpr int NT = 4 / MT, TM = 64 * MT, TN = 64 / MT, RS = 40;   // RS: plane row stride in bf16
-    __shared__ __attribute__((aligned(16))) unsigned short As[3][TM][RS];
-    __shared__ __attribute__((aligned(16))) unsigned short Bs[3][TN][RS];
+    constexpr int NT = 4 / MT, TM = 64 * MT, TN = 64 / MT;
+    // LDS images, three bf16 planes each.
+    //   VEC_K  operand: [row][k], rows of 32 k + 8 pad (80 bytes); fragment = one ds_read_b128.
+    //   VEC_MN operand: [k][row] as it arrives (no transposing stores), 16-column chunks swizzled by bit 3 of k;
+    //                   fragment = two ds_read_b64_tr_b16 (hardware transpose: lane i of a 16-lane group receives
+    //                   column i of a 4-row block; tools/microbench/trread.hip pins the lane map).
+    constexpr bool AT = AMODE == GG_VEC_MN, BT = BMODE == GG_VEC_MN;
+    constexpr int RS = 40, SA = gg_tr_stride(TM), SB = gg_tr_stride(TN);
+    constexpr int APL = AT ? 32 * SA : TM * RS, BPL = BT ? 32 * SB : TN * RS;   // bf16 per plane
+    __shared__ __attribute__((aligned(16))) unsigned short As[3 * APL];
+    __shared__ __attribute__((aligned(16))) unsigned short Bs[3 * BPL];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r16 = lane & 15, q = lane >> 4;
     const int m0 = blockIdx.x * TM, n0 = blockIdx.y * TN;
     const int kbeg = blockIdx.z * klen, kend = min(K, kbeg + klen);
     // staging work items (8 values each):
-    //   VEC_K : one row / column, 8 consecutive k  (two 16-byte gathers)      -> one b128 store per plane
-    //   VEC_MN: 4 consecutive rows / columns at k and k+1 (two 16-byte gathers) -> four b32 stores per plane
+    //   VEC_K : one row / column, 8 consecutive k (two 16-byte gathers)          -> one b128 store per plane
+    //   VEC_MN: 4 consecutive rows / columns at k and at k+1 (two 16-byte gathers) -> two b64 stores per plane
     const int lm = tid >> 2, lk = (tid & 3) * 8;
     const int tk = (tid >> 4) * 2, tm = (tid & 15) * 4;
     const int bk = (tid / (TN / 4)) * 2, bn = (tid % (TN / 4)) * 4;
@@ -229,8 +248,8 @@ __global__ __launch_bounds__(256) void gemm_gather_x3_kernel(int M, int N, int K
             }
         }
     };
-    // split the 8 staged values and park the three planes
-    auto park_k = [&](unsigned short (*pl)[RS], int planes_stride, int row, int k, const gg_f32x4 (&v)[2]) {
+    // split the staged values and park the three planes
+    auto park_k = [&](unsigned short *img, int plane, int row, int k, const gg_f32x4 (&v)[2]) {
         float h[8], m[8], l[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) gg_split3(v[i >> 2][i & 3], h[i], m[i], l[i]);
@@ -241,20 +260,37 @@ __global__ __launch_bounds__(256) void gemm_gather_x3_kernel(int M, int N, int K
             pm[i] = gg_pack(m[2 * i], m[2 * i + 1]);
             pq[i] = gg_pack(l[2 * i], l[2 * i + 1]);
         }
-        *(gg_u32x4 *)&pl[row][k] = ph;
-        *(gg_u32x4 *)&pl[planes_stride + row][k] = pm;
-        *(gg_u32x4 *)&pl[2 * planes_stride + row][k] = pq;
+        unsigned short *d = img + row * RS + k;
+        *(gg_u32x4 *)d = ph;
+        *(gg_u32x4 *)(d + plane) = pm;
+        *(gg_u32x4 *)(d + 2 * plane) = pq;
     };
-    auto park_mn = [&](unsigned short (*pl)[RS], int planes_stride, int row, int k, const gg_f32x4 (&v)[2]) {
+    auto park_mn = [&](unsigned short *img, int plane, int stride, int col, int k, const gg_f32x4 (&v)[2]) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            float h0, m0_, l0, h1, m1, l1;
-            gg_split3(v[0][e], h0, m0_, l0);
-            gg_split3(v[1][e], h1, m1, l1);
-            *(unsigned *)&pl[row + e][k] = gg_pack(h0, h1);
-            *(unsigned *)&pl[planes_stride + row + e][k] = gg_pack(m0_, m1);
-            *(unsigned *)&pl[2 * planes_stride + row + e][k] = gg_pack(l0, l1);
+        for (int i = 0; i < 2; ++i) {   // rows k and k+1 of the [k][col] image
+            float h[4], m[4], l[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) gg_split3(v[i][e], h[e], m[e], l[e]);
+            const int kk = k + i;
+            unsigned short *d = img + kk * stride + ((((col >> 4) ^ ((kk >> 3) & 1)) << 4) | (col & 15));
+            *(gg_u32x2 *)d = (gg_u32x2){gg_pack(h[0], h[1]), gg_pack(h[2], h[3])};
+            *(gg_u32x2 *)(d + plane) = (gg_u32x2){gg_pack(m[0], m[1]), gg_pack(m[2], m[3])};
+            *(gg_u32x2 *)(d + 2 * plane) = (gg_u32x2){gg_pack(l[0], l[1]), gg_pack(l[2], l[3])};
         }
+    };
+    // fragment (k = 8q .. 8q+7 of row / column c0 + r16) of plane `lv`
+    auto frag_k = [&](const unsigned short *img, int plane, int lv, int c0) -> gg_bf16x8 {
+        return *(const gg_bf16x8 *)(img + lv * plane + (c0 + r16) * RS + 8 * q);
+    };
+    auto frag_mn = [&](const unsigned short *img, int plane, int stride, int lv, int c0) -> gg_bf16x8 {
+        // lane 4a+p of the 16-lane group supplies row 8q + a, columns 4p .. 4p+3 of the 16-column block at c0
+        const int a = r16 >> 2, p = r16 & 3;
+        const unsigned short *s0 = img + lv * plane + (8 * q + a) * stride + ((((c0 >> 4) ^ (q & 1)) << 4) | (4 * p));
+        typedef __attribute__((address_space(3))) gg_s16x4 *lds_p;
+        const gg_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)s0);
+        const gg_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(s0 + 4 * stride));
+        const gg_s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return __builtin_bit_cast(gg_bf16x8, v);
     };
     gg_f32x4 av[MT][2], bv[2];
     if (kbeg < kend) gather(kbeg, av, bv);
@@ -262,12 +298,12 @@ __global__ __launch_bounds__(256) void gemm_gather_x3_kernel(int M, int N, int K
         __syncthreads();
 #pragma unroll
         for (int p = 0; p < MT; ++p) {
-            if constexpr (AMODE == GG_VEC_K) park_k(As[0], TM, p * 64 + lm, lk, av[p]);
-            else park_mn(As[0], TM, p * 64 + tm, tk, av[p]);
+            if constexpr (AT) park_mn(As, APL, SA, p * 64 + tm, tk, av[p]);
+            else park_k(As, APL, p * 64 + lm, lk, av[p]);
         }
         if (bact) {
-            if constexpr (BMODE == GG_VEC_K) park_k(Bs[0], TN, lm, lk, bv);
-            else park_mn(Bs[0], TN, bn, bk, bv);
+            if constexpr (BT) park_mn(Bs, BPL, SB, bn, bk, bv);
+            else park_k(Bs, BPL, lm, lk, bv);
         }
         __syncthreads();
         if (k0 + 32 < kend) gather(k0 + 32, av, bv);
@@ -275,10 +311,15 @@ __global__ __launch_bounds__(256) void gemm_gather_x3_kernel(int M, int N, int K
 #pragma unroll
         for (int lv = 0; lv < 3; ++lv) {
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-                a[lv][mt] = *(const gg_bf16x8 *)&As[lv][(wave * MT + mt) * 16 + r16][8 * q];
+            for (int mt = 0; mt < MT; ++mt) {
+                if constexpr (AT) a[lv][mt] = frag_mn(As, APL, SA, lv, (wave * MT + mt) * 16);
+                else a[lv][mt] = frag_k(As, APL, lv, (wave * MT + mt) * 16);
+            }
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) b[lv][nt] = *(const gg_bf16x8 *)&Bs[lv][nt * 16 + r16][8 * q];
+            for (int nt = 0; nt < NT; ++nt) {
+                if constexpr (BT) b[lv][nt] = frag_mn(Bs, BPL, SB, lv, nt * 16);
+                else b[lv][nt] = frag_k(Bs, BPL, lv, nt * 16);
+            }
         }
         // small terms first; consecutive MFMAs hit different accumulators
 #define GG_X3(LA, LB)                                                                                   \
