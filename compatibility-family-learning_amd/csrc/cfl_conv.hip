@@ -98,11 +98,34 @@ struct Im2colX {   // A(m = (b,oh,ow), k = (kh,kw,ci)) = x[b, oh*S+kh-pt, ow*S+k
         if (ih < 0 || ih >= g.H || iw < 0 || iw >= g.W) return (gg_f32x4){0.f, 0.f, 0.f, 0.f};
         return *(const gg_f32x4 *)(x + (((size_t)b * g.H + ih) * g.W + iw) * g.Ci + ci);
     }
+    // two-phase form (gemm_gather.h): pixel index decomposed once, tap index once per K step
+    struct Fix { int bH, ih0, iw0; };
+    struct Str { int kh, kw, ci; };
+    __device__ Fix fix(int m) const {
+        int ow, t, oh, b;
+        gg_divmod(m, g.dOW, t, ow); gg_divmod(t, g.dOH, b, oh);
+        return Fix{b * g.H, oh * g.S - g.pt, ow * g.S - g.pl};
+    }
+    __device__ Str stream(int k) const {
+        int ci, t2, kw, kh;
+        gg_divmod(k, g.dCi, t2, ci); gg_divmod(t2, g.dKW, kh, kw);
+        return Str{kh, kw, ci};
+    }
+    __device__ gg_f32x4 get(const Fix &a, const Str &s) const {
+        const int ih = a.ih0 + s.kh, iw = a.iw0 + s.kw;
+        if ((unsigned)ih >= (unsigned)g.H || (unsigned)iw >= (unsigned)g.W) return (gg_f32x4){0.f, 0.f, 0.f, 0.f};
+        return *(const gg_f32x4 *)(x + ((size_t)(a.bH + ih) * g.W + iw) * g.Ci + s.ci);
+    }
 };
 struct FilterKN {  // B(k, n = co) = V[k][co]
     const float *V; int Co;
     __device__ float operator()(int k, int n) const { return V[(size_t)k * Co + n]; }
     __device__ gg_f32x4 v4(int k, int n) const { return *(const gg_f32x4 *)(V + (size_t)k * Co + n); }  // n .. n+3
+    struct Fix { int n; };
+    struct Str { size_t o; };
+    __device__ Fix fix(int n) const { return Fix{n}; }
+    __device__ Str stream(int k) const { return Str{(size_t)k * Co}; }
+    __device__ gg_f32x4 get(const Fix &a, const Str &s) const { return *(const gg_f32x4 *)(V + s.o + a.n); }
 };
 struct StoreFwd {
     float *y; const float *scale, *bias; int Co, act;
@@ -142,6 +165,34 @@ struct DyGather {  // A(m = (b,ih,iw), k = (kh,kw,co)) = dy_pre[b,(ih+pt-kh)/S,(
         for (int e = 0; e < 4; ++e) r[e] = d[e] * act_slope(yy[e], g.act) * sc[e];
         return r;
     }
+    struct Fix { int bOH, ihp, iwp; };
+    struct Str { int kh, kw, co; };
+    __device__ Fix fix(int m) const {
+        int iw, t, ih, b;
+        gg_divmod(m, g.dW, t, iw); gg_divmod(t, g.dH, b, ih);
+        return Fix{b * g.OH, ih + g.pt, iw + g.pl};
+    }
+    __device__ Str stream(int k) const {
+        int co, t2, kw, kh;
+        gg_divmod(k, g.dCo, t2, co); gg_divmod(t2, g.dKW, kh, kw);
+        return Str{kh, kw, co};
+    }
+    __device__ gg_f32x4 get(const Fix &a, const Str &s) const {
+        const gg_f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        const int nh = a.ihp - s.kh, nw = a.iwp - s.kw;
+        if (nh < 0 || nw < 0) return zero;
+        int oh, ow, rh, rw;
+        gg_divmod(nh, g.dS, oh, rh); gg_divmod(nw, g.dS, ow, rw);
+        if (rh || rw) return zero;
+        if (oh >= g.OH || ow >= g.OW) return zero;
+        const size_t o = ((size_t)(a.bOH + oh) * g.OW + ow) * g.Co + s.co;
+        const gg_f32x4 d = *(const gg_f32x4 *)(dy + o), yy = *(const gg_f32x4 *)(y + o),
+                       sc = *(const gg_f32x4 *)(scale + s.co);
+        gg_f32x4 r;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) r[e] = d[e] * act_slope(yy[e], g.act) * sc[e];
+        return r;
+    }
 };
 struct FilterT {   // B(k = (kh,kw,co), n = ci) = V[kh,kw,ci,co]
     const float *V; ConvGeom g;
@@ -155,6 +206,15 @@ struct FilterT {   // B(k = (kh,kw,co), n = ci) = V[kh,kw,ci,co]
         gg_divmod(k, g.dCo, t, co);
         return *(const gg_f32x4 *)(V + ((size_t)t * g.Ci + n) * g.Co + co);
     }
+    struct Fix { int nCo; };
+    struct Str { size_t o; };
+    __device__ Fix fix(int n) const { return Fix{n * g.Co}; }
+    __device__ Str stream(int k) const {
+        int co, t;
+        gg_divmod(k, g.dCo, t, co);
+        return Str{(size_t)t * g.Ci * g.Co + co};
+    }
+    __device__ gg_f32x4 get(const Fix &a, const Str &s) const { return *(const gg_f32x4 *)(V + s.o + a.nCo); }
 };
 // ---- stride-2 input gradient by output-pixel parity ------------------------------------------
 // With stride 2 an input pixel (ih, iw) only meets the taps kh == (ih + pt) mod 2, kw == (iw + pl) mod 2,
@@ -229,6 +289,15 @@ struct Im2colXT {  // A(m = (kh,kw,ci), k = (b,oh,ow)) : the same gather with th
         if (m >= rows) return (gg_f32x4){m == rows ? 1.f : 0.f, 0.f, 0.f, 0.f};
         return f.v4(k, m);
     }
+    // roles swapped: the tap index (kh,kw,ci) is the fixed one here, the pixel streams
+    struct Fix { Im2colX::Str s; int m; };
+    typedef Im2colX::Fix Str;
+    __device__ Fix fix(int m) const { return Fix{f.stream(m), m}; }
+    __device__ Str stream(int k) const { return f.fix(k); }
+    __device__ gg_f32x4 get(const Fix &a, const Str &s) const {
+        if (a.m >= rows) return (gg_f32x4){a.m == rows ? 1.f : 0.f, 0.f, 0.f, 0.f};
+        return f.get(s, a.s);
+    }
 };
 struct DyPre {     // B(k = (b,oh,ow), n = co) = dy * act'(y)
     const float *dy, *y; int Co, act;
@@ -244,6 +313,11 @@ struct DyPre {     // B(k = (b,oh,ow), n = co) = dy * act'(y)
         for (int e = 0; e < 4; ++e) r[e] = d[e] * act_slope(yy[e], act);
         return r;
     }
+    struct Fix { int n; };
+    struct Str { int k; };
+    __device__ Fix fix(int n) const { return Fix{n}; }
+    __device__ Str stream(int k) const { return Str{k}; }
+    __device__ gg_f32x4 get(const Fix &a, const Str &s) const { return v4(s.k, a.n); }
 };
 struct StoreSlab {
     float *slab; size_t stride; int ld;

@@ -10,6 +10,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdlib>
+#include <type_traits>
+#include <utility>
 
 typedef float gg_f32x4 __attribute__((ext_vector_type(4)));
 
@@ -181,6 +183,31 @@ __device__ __forceinline__ unsigned gg_pack(float e0, float e1) {
     return __builtin_amdgcn_perm(__float_as_uint(e1), __float_as_uint(e0), 0x07060302u);
 }
 
+// Optional two-phase functor interface (used by the bf16x3 kernel): the index a thread keeps for the whole K loop
+// (its row m of A / column n of B) is decomposed once by fix(), the streaming index k once per K step by stream(),
+// and get(fix, stream) does what is left (bounds, address, load) -- instead of v4(m, k) redoing all divisions on every call.
+// Functors without fix() are driven through v4().
+template <class F, class = void> struct gg_has_fix : std::false_type {};
+template <class F> struct gg_has_fix<F, std::void_t<decltype(std::declval<const F &>().fix(0))>> : std::true_type {};
+template <class F, bool IS_A, bool H = gg_has_fix<F>::value> struct gg_two_phase;
+template <class F, bool IS_A> struct gg_two_phase<F, IS_A, true> {
+    using Fix = decltype(std::declval<const F &>().fix(0));
+    using Str = decltype(std::declval<const F &>().stream(0));
+    static __device__ __forceinline__ Fix fix(const F &f, int i) { return f.fix(i); }
+    static __device__ __forceinline__ Str stream(const F &f, int k) { return f.stream(k); }
+    static __device__ __forceinline__ gg_f32x4 get(const F &f, const Fix &a, const Str &b) { return f.get(a, b); }
+};
+template <class F, bool IS_A> struct gg_two_phase<F, IS_A, false> {
+    struct Fix { int i; };
+    struct Str { int k; };
+    static __device__ __forceinline__ Fix fix(const F &, int i) { return Fix{i}; }
+    static __device__ __forceinline__ Str stream(const F &, int k) { return Str{k}; }
+    static __device__ __forceinline__ gg_f32x4 get(const F &f, const Fix &a, const Str &b) {
+        if constexpr (IS_A) return f.v4(a.i, b.k);
+        else return f.v4(b.k, a.i);
+    }
+};
+
 // Row stride (bf16 elements) of a [k][m] image with `cols` columns: the smallest stride >= cols whose 32-bit word
 // count is 16 mod 32.  Together with the chunk swizzle below (16-column chunk index XOR bit 3 of k) the eight
 // 4-row x 32-byte blocks that one 32-lane half fetches with ds_read_b64_tr_b16 fall on 64 distinct banks.
@@ -192,11 +219,11 @@ constexpr int gg_tr_stride(int cols) {
 typedef short gg_s16x4 __attribute__((ext_vector_type(4)));
 typedef short gg_s16x8 __attribute__((ext_vector_type(8)));
 
-template <int MT, int AMODE, int BMODE, class LoadA, class LoadB, class Store>
+template <int MT, int NT, int AMODE, int BMODE, class LoadA, class LoadB, class Store>
 __global__ __launch_bounds__(256) void gemm_gather_x3_kernel(int M, int N, int K, int klen, LoadA la,
                                                              LoadB lb, Store st) {
     static_assert(AMODE != GG_SCALAR && BMODE != GG_SCALAR, "bf16x3 path: vector staging modes only");
-    constexpr int NT = 4 / MT, TM = 64 * MT, TN = 64 / MT;
+    constexpr int TM = 64 * MT, TN = 16 * NT;   // workgroup tile; each wave owns MT x NT 16x16 tiles
     // LDS images, three bf16 planes each.
     //   VEC_K  operand: [row][k], rows of 32 k + 8 pad (80 bytes); fragment = one ds_read_b128.
     //   VEC_MN operand: [k][row] as it arrives (no transposing stores), 16-column chunks swizzled by bit 3 of k;
@@ -224,28 +251,28 @@ __global__ __launch_bounds__(256) void gemm_gather_x3_kernel(int M, int N, int K
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (gg_f32x4){0.f, 0.f, 0.f, 0.f};
     const gg_f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    using PA = gg_two_phase<LoadA, true>;
+    using PB = gg_two_phase<LoadB, false>;
+    // loop-invariant halves of the gather indices
+    typename PA::Fix fa[MT];
+#pragma unroll
+    for (int p = 0; p < MT; ++p) fa[p] = PA::fix(la, m0 + p * 64 + (AT ? tm : lm));
+    const typename PB::Fix fb = PB::fix(lb, n0 + (BT ? bn : lm));
     auto gather = [&](int k0, gg_f32x4 (&av)[MT][2], gg_f32x4 (&bv)[2]) {
+        const int ka0 = k0 + (AT ? tk : lk), ka1 = ka0 + (AT ? 1 : 4);
+        const typename PA::Str sa0 = PA::stream(la, ka0), sa1 = PA::stream(la, ka1);
 #pragma unroll
         for (int p = 0; p < MT; ++p) {
-            if constexpr (AMODE == GG_VEC_K) {
-                const int m = m0 + p * 64 + lm;
-                av[p][0] = (m < M && k0 + lk < kend) ? la.v4(m, k0 + lk) : zero;
-                av[p][1] = (m < M && k0 + lk + 4 < kend) ? la.v4(m, k0 + lk + 4) : zero;
-            } else {
-                const int m = m0 + p * 64 + tm;
-                av[p][0] = (m < M && k0 + tk < kend) ? la.v4(m, k0 + tk) : zero;
-                av[p][1] = (m < M && k0 + tk + 1 < kend) ? la.v4(m, k0 + tk + 1) : zero;
-            }
+            const int m = m0 + p * 64 + (AT ? tm : lm);
+            av[p][0] = (m < M && ka0 < kend) ? PA::get(la, fa[p], sa0) : zero;
+            av[p][1] = (m < M && ka1 < kend) ? PA::get(la, fa[p], sa1) : zero;
         }
         bv[0] = zero; bv[1] = zero;
         if (bact) {
-            if constexpr (BMODE == GG_VEC_K) {
-                if (n0 + lm < N && k0 + lk < kend) bv[0] = lb.v4(k0 + lk, n0 + lm);
-                if (n0 + lm < N && k0 + lk + 4 < kend) bv[1] = lb.v4(k0 + lk + 4, n0 + lm);
-            } else {
-                if (n0 + bn < N && k0 + bk < kend) bv[0] = lb.v4(k0 + bk, n0 + bn);
-                if (n0 + bn < N && k0 + bk + 1 < kend) bv[1] = lb.v4(k0 + bk + 1, n0 + bn);
-            }
+            const int kb0 = k0 + (BT ? bk : lk), kb1 = kb0 + (BT ? 1 : 4);
+            const int n = n0 + (BT ? bn : lm);
+            if (n < N && kb0 < kend) bv[0] = PB::get(lb, fb, PB::stream(lb, kb0));
+            if (n < N && kb1 < kend) bv[1] = PB::get(lb, fb, PB::stream(lb, kb1));
         }
     };
     // split the staged values and park the three planes
@@ -361,15 +388,15 @@ static inline void gemm_gather_modes(int M, int N, int K, int klen, LoadA la, Lo
         if (gg_use_x3()) {
             if (N <= 16) {
                 dim3 grid((M + 255) / 256, (N + 15) / 16, splits);
-                hipLaunchKernelGGL((gemm_gather_x3_kernel<4, AMODE, BMODE, LoadA, LoadB, Store>), grid, dim3(256), 0,
+                hipLaunchKernelGGL((gemm_gather_x3_kernel<4, 1, AMODE, BMODE, LoadA, LoadB, Store>), grid, dim3(256), 0,
                                    stream, M, N, K, klen, la, lb, st);
             } else if (N <= 32) {
                 dim3 grid((M + 127) / 128, (N + 31) / 32, splits);
-                hipLaunchKernelGGL((gemm_gather_x3_kernel<2, AMODE, BMODE, LoadA, LoadB, Store>), grid, dim3(256), 0,
+                hipLaunchKernelGGL((gemm_gather_x3_kernel<2, 2, AMODE, BMODE, LoadA, LoadB, Store>), grid, dim3(256), 0,
                                    stream, M, N, K, klen, la, lb, st);
             } else {
                 dim3 grid((M + 63) / 64, (N + 63) / 64, splits);
-                hipLaunchKernelGGL((gemm_gather_x3_kernel<1, AMODE, BMODE, LoadA, LoadB, Store>), grid, dim3(256), 0,
+                hipLaunchKernelGGL((gemm_gather_x3_kernel<1, 4, AMODE, BMODE, LoadA, LoadB, Store>), grid, dim3(256), 0,
                                    stream, M, N, K, klen, la, lb, st);
             }
             return;
