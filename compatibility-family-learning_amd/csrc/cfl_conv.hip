@@ -56,6 +56,15 @@ __device__ __forceinline__ float act_slope(float y, int act) {
     return 1.f;
 }
 
+// the same slope from uniform constants (no branch on `act` per element): y > 0 ? 1 : (y < 0 ? neg : zer)
+struct ActSlope {
+    float neg, zer;
+    __device__ __forceinline__ float operator()(float y) const { return y > 0.f ? 1.f : (y < 0.f ? neg : zer); }
+};
+__device__ __forceinline__ ActSlope act_slope_consts(int act) {
+    return act == 1 ? ActSlope{0.2f, 0.f} : (act == 2 ? ActSlope{0.f, 0.f} : ActSlope{1.f, 1.f});
+}
+
 // ---- per-output-channel weight-norm scale: g / sqrt(max(sum V^2, 1e-12)) ----------------
 __global__ __launch_bounds__(256) void conv_scale_kernel(const float *V, const float *g, int rows, int Co,
                                                          float *scale, float *n2out) {
@@ -111,10 +120,12 @@ struct Im2colX {   // A(m = (b,oh,ow), k = (kh,kw,ci)) = x[b, oh*S+kh-pt, ow*S+k
         gg_divmod(k, g.dCi, t2, ci); gg_divmod(t2, g.dKW, kh, kw);
         return Str{kh, kw, ci};
     }
-    __device__ gg_f32x4 get(const Fix &a, const Str &s) const {
+    __device__ gg_f32x4 get(const Fix &a, const Str &s, bool ok) const {
         const int ih = a.ih0 + s.kh, iw = a.iw0 + s.kw;
-        if ((unsigned)ih >= (unsigned)g.H || (unsigned)iw >= (unsigned)g.W) return (gg_f32x4){0.f, 0.f, 0.f, 0.f};
-        return *(const gg_f32x4 *)(x + ((size_t)(a.bH + ih) * g.W + iw) * g.Ci + s.ci);
+        ok = ok && (unsigned)ih < (unsigned)g.H && (unsigned)iw < (unsigned)g.W;
+        const size_t o = ok ? ((size_t)(a.bH + ih) * g.W + iw) * g.Ci + s.ci : (size_t)s.ci;   // safe address
+        const gg_f32x4 v = *(const gg_f32x4 *)(x + o);
+        return ok ? v : (gg_f32x4){0.f, 0.f, 0.f, 0.f};
     }
 };
 struct FilterKN {  // B(k, n = co) = V[k][co]
@@ -125,7 +136,10 @@ struct FilterKN {  // B(k, n = co) = V[k][co]
     struct Str { size_t o; };
     __device__ Fix fix(int n) const { return Fix{n}; }
     __device__ Str stream(int k) const { return Str{(size_t)k * Co}; }
-    __device__ gg_f32x4 get(const Fix &a, const Str &s) const { return *(const gg_f32x4 *)(V + s.o + a.n); }
+    __device__ gg_f32x4 get(const Fix &a, const Str &s, bool ok) const {
+        const gg_f32x4 v = *(const gg_f32x4 *)(V + (ok ? s.o + a.n : (size_t)0));
+        return ok ? v : (gg_f32x4){0.f, 0.f, 0.f, 0.f};
+    }
 };
 struct StoreFwd {
     float *y; const float *scale, *bias; int Co, act;
@@ -177,20 +191,18 @@ struct DyGather {  // A(m = (b,ih,iw), k = (kh,kw,co)) = dy_pre[b,(ih+pt-kh)/S,(
         gg_divmod(k, g.dCo, t2, co); gg_divmod(t2, g.dKW, kh, kw);
         return Str{kh, kw, co};
     }
-    __device__ gg_f32x4 get(const Fix &a, const Str &s) const {
-        const gg_f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    __device__ gg_f32x4 get(const Fix &a, const Str &s, bool ok) const {
         const int nh = a.ihp - s.kh, nw = a.iwp - s.kw;
-        if (nh < 0 || nw < 0) return zero;
         int oh, ow, rh, rw;
-        gg_divmod(nh, g.dS, oh, rh); gg_divmod(nw, g.dS, ow, rw);
-        if (rh || rw) return zero;
-        if (oh >= g.OH || ow >= g.OW) return zero;
-        const size_t o = ((size_t)(a.bOH + oh) * g.OW + ow) * g.Co + s.co;
+        gg_divmod(nh < 0 ? 0 : nh, g.dS, oh, rh); gg_divmod(nw < 0 ? 0 : nw, g.dS, ow, rw);
+        ok = ok && nh >= 0 && nw >= 0 && (rh | rw) == 0 && oh < g.OH && ow < g.OW;
+        const size_t o = ok ? ((size_t)(a.bOH + oh) * g.OW + ow) * g.Co + s.co : (size_t)s.co;   // safe address
         const gg_f32x4 d = *(const gg_f32x4 *)(dy + o), yy = *(const gg_f32x4 *)(y + o),
                        sc = *(const gg_f32x4 *)(scale + s.co);
+        const ActSlope sl = act_slope_consts(g.act);
         gg_f32x4 r;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) r[e] = d[e] * act_slope(yy[e], g.act) * sc[e];
+        for (int e = 0; e < 4; ++e) r[e] = ok ? d[e] * sl(yy[e]) * sc[e] : 0.f;
         return r;
     }
 };
@@ -214,7 +226,10 @@ struct FilterT {   // B(k = (kh,kw,co), n = ci) = V[kh,kw,ci,co]
         gg_divmod(k, g.dCo, t, co);
         return Str{(size_t)t * g.Ci * g.Co + co};
     }
-    __device__ gg_f32x4 get(const Fix &a, const Str &s) const { return *(const gg_f32x4 *)(V + s.o + a.nCo); }
+    __device__ gg_f32x4 get(const Fix &a, const Str &s, bool ok) const {
+        const gg_f32x4 v = *(const gg_f32x4 *)(V + (ok ? s.o + a.nCo : (size_t)0));
+        return ok ? v : (gg_f32x4){0.f, 0.f, 0.f, 0.f};
+    }
 };
 // ---- stride-2 input gradient by output-pixel parity ------------------------------------------
 // With stride 2 an input pixel (ih, iw) only meets the taps kh == (ih + pt) mod 2, kw == (iw + pl) mod 2,
@@ -294,9 +309,9 @@ struct Im2colXT {  // A(m = (kh,kw,ci), k = (b,oh,ow)) : the same gather with th
     typedef Im2colX::Fix Str;
     __device__ Fix fix(int m) const { return Fix{f.stream(m), m}; }
     __device__ Str stream(int k) const { return f.fix(k); }
-    __device__ gg_f32x4 get(const Fix &a, const Str &s) const {
-        if (a.m >= rows) return (gg_f32x4){a.m == rows ? 1.f : 0.f, 0.f, 0.f, 0.f};
-        return f.get(s, a.s);
+    __device__ gg_f32x4 get(const Fix &a, const Str &s, bool ok) const {
+        const gg_f32x4 v = f.get(s, a.s, ok && a.m < rows);
+        return (ok && a.m == rows) ? (gg_f32x4){1.f, 0.f, 0.f, 0.f} : v;
     }
 };
 struct DyPre {     // B(k = (b,oh,ow), n = co) = dy * act'(y)
@@ -317,7 +332,15 @@ struct DyPre {     // B(k = (b,oh,ow), n = co) = dy * act'(y)
     struct Str { int k; };
     __device__ Fix fix(int n) const { return Fix{n}; }
     __device__ Str stream(int k) const { return Str{k}; }
-    __device__ gg_f32x4 get(const Fix &a, const Str &s) const { return v4(s.k, a.n); }
+    __device__ gg_f32x4 get(const Fix &a, const Str &s, bool ok) const {
+        const size_t o = ok ? (size_t)s.k * Co + a.n : (size_t)0;
+        const gg_f32x4 d = *(const gg_f32x4 *)(dy + o), yy = *(const gg_f32x4 *)(y + o);
+        const ActSlope sl = act_slope_consts(act);
+        gg_f32x4 r;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) r[e] = ok ? d[e] * sl(yy[e]) : 0.f;
+        return r;
+    }
 };
 struct StoreSlab {
     float *slab; size_t stride; int ld;

@@ -185,7 +185,8 @@ __device__ __forceinline__ unsigned gg_pack(float e0, float e1) {
 
 // Optional two-phase functor interface (used by the bf16x3 kernel): the index a thread keeps for the whole K loop
 // (its row m of A / column n of B) is decomposed once by fix(), the streaming index k once per K step by stream(),
-// and get(fix, stream) does what is left (bounds, address, load) -- instead of v4(m, k) redoing all divisions on every call.
+// and get(fix, stream, ok) does what is left (bounds, address, load; `ok` false -> zeros, branch-free: the load goes to a
+// safe address and the result is selected) -- instead of v4(m, k) redoing all divisions on every call.
 // Functors without fix() are driven through v4().
 template <class F, class = void> struct gg_has_fix : std::false_type {};
 template <class F> struct gg_has_fix<F, std::void_t<decltype(std::declval<const F &>().fix(0))>> : std::true_type {};
@@ -195,14 +196,17 @@ template <class F, bool IS_A> struct gg_two_phase<F, IS_A, true> {
     using Str = decltype(std::declval<const F &>().stream(0));
     static __device__ __forceinline__ Fix fix(const F &f, int i) { return f.fix(i); }
     static __device__ __forceinline__ Str stream(const F &f, int k) { return f.stream(k); }
-    static __device__ __forceinline__ gg_f32x4 get(const F &f, const Fix &a, const Str &b) { return f.get(a, b); }
+    static __device__ __forceinline__ gg_f32x4 get(const F &f, const Fix &a, const Str &b, bool ok) {
+        return f.get(a, b, ok);
+    }
 };
 template <class F, bool IS_A> struct gg_two_phase<F, IS_A, false> {
     struct Fix { int i; };
     struct Str { int k; };
     static __device__ __forceinline__ Fix fix(const F &, int i) { return Fix{i}; }
     static __device__ __forceinline__ Str stream(const F &, int k) { return Str{k}; }
-    static __device__ __forceinline__ gg_f32x4 get(const F &f, const Fix &a, const Str &b) {
+    static __device__ __forceinline__ gg_f32x4 get(const F &f, const Fix &a, const Str &b, bool ok) {
+        if (!ok) return (gg_f32x4){0.f, 0.f, 0.f, 0.f};
         if constexpr (IS_A) return f.v4(a.i, b.k);
         else return f.v4(b.k, a.i);
     }
@@ -264,15 +268,15 @@ __global__ __launch_bounds__(256) void gemm_gather_x3_kernel(int M, int N, int K
 #pragma unroll
         for (int p = 0; p < MT; ++p) {
             const int m = m0 + p * 64 + (AT ? tm : lm);
-            av[p][0] = (m < M && ka0 < kend) ? PA::get(la, fa[p], sa0) : zero;
-            av[p][1] = (m < M && ka1 < kend) ? PA::get(la, fa[p], sa1) : zero;
+            av[p][0] = PA::get(la, fa[p], sa0, m < M && ka0 < kend);
+            av[p][1] = PA::get(la, fa[p], sa1, m < M && ka1 < kend);
         }
         bv[0] = zero; bv[1] = zero;
         if (bact) {
             const int kb0 = k0 + (BT ? bk : lk), kb1 = kb0 + (BT ? 1 : 4);
             const int n = n0 + (BT ? bn : lm);
-            if (n < N && kb0 < kend) bv[0] = PB::get(lb, fb, PB::stream(lb, kb0));
-            if (n < N && kb1 < kend) bv[1] = PB::get(lb, fb, PB::stream(lb, kb1));
+            bv[0] = PB::get(lb, fb, PB::stream(lb, kb0), n < N && kb0 < kend);
+            bv[1] = PB::get(lb, fb, PB::stream(lb, kb1), n < N && kb1 < kend);
         }
     };
     // split the staged values and park the three planes
