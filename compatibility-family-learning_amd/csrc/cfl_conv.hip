@@ -265,6 +265,32 @@ struct DyGatherS2 {   // A(m = (b, i, j), k = (kh', kw', co)), input pixel (2i +
         for (int e = 0; e < 4; ++e) r[e] = d[e] * act_slope(yy[e], g.act) * sc[e];
         return r;
     }
+    struct Fix { int bOH, nh0, nw0; };
+    struct Str { int kh, kw, co; };   // kh < 0: tap outside the filter
+    __device__ Fix fix(int m) const {
+        int j, t, i, b;
+        gg_divmod(m, dW2, t, j); gg_divmod(t, dH2, b, i);
+        return Fix{b * g.OH, 2 * i + ph + g.pt, 2 * j + pw + g.pl};
+    }
+    __device__ Str stream(int k) const {
+        int co, t2, a0, a1;
+        gg_divmod(k, g.dCo, t2, co); gg_divmod(t2, dKW2, a1, a0);
+        const int kw = 2 * a0 + ow0, kh = 2 * a1 + oh0;
+        return Str{(kh >= g.KH || kw >= g.KW) ? -1 : kh, kw, co};
+    }
+    __device__ gg_f32x4 get(const Fix &a, const Str &s, bool ok) const {
+        const int nh = a.nh0 - s.kh, nw = a.nw0 - s.kw;   // even by construction
+        const int oh = nh >> 1, ow = nw >> 1;
+        ok = ok && s.kh >= 0 && nh >= 0 && nw >= 0 && oh < g.OH && ow < g.OW;
+        const size_t o = ok ? ((size_t)(a.bOH + oh) * g.OW + ow) * g.Co + s.co : (size_t)s.co;   // safe address
+        const gg_f32x4 d = *(const gg_f32x4 *)(dy + o), yy = *(const gg_f32x4 *)(y + o),
+                       sc = *(const gg_f32x4 *)(scale + s.co);
+        const ActSlope sl = act_slope_consts(g.act);
+        gg_f32x4 r;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) r[e] = ok ? d[e] * sl(yy[e]) * sc[e] : 0.f;
+        return r;
+    }
 };
 struct FilterTS2 {    // B(k = (kh', kw', co), n = ci) = V[2kh'+oh0, 2kw'+ow0, ci, co]
     const float *V; ConvGeom g; int oh0, ow0, KW2; gg_div dKW2;
@@ -281,6 +307,20 @@ struct FilterTS2 {    // B(k = (kh', kw', co), n = ci) = V[2kh'+oh0, 2kw'+ow0, c
         const int kw = 2 * a0 + ow0, kh = 2 * a1 + oh0;
         if (kh >= g.KH || kw >= g.KW) return (gg_f32x4){0.f, 0.f, 0.f, 0.f};
         return *(const gg_f32x4 *)(V + ((size_t)(kh * g.KW + kw) * g.Ci + n) * g.Co + co);
+    }
+    struct Fix { int nCo; };
+    struct Str { size_t o; bool ok; };
+    __device__ Fix fix(int n) const { return Fix{n * g.Co}; }
+    __device__ Str stream(int k) const {
+        int co, t2, a0, a1;
+        gg_divmod(k, g.dCo, t2, co); gg_divmod(t2, dKW2, a1, a0);
+        const int kw = 2 * a0 + ow0, kh = 2 * a1 + oh0;
+        return Str{(size_t)(kh * g.KW + kw) * g.Ci * g.Co + co, kh < g.KH && kw < g.KW};
+    }
+    __device__ gg_f32x4 get(const Fix &a, const Str &s, bool ok) const {
+        ok = ok && s.ok;
+        const gg_f32x4 v = *(const gg_f32x4 *)(V + (ok ? s.o + a.nCo : (size_t)0));
+        return ok ? v : (gg_f32x4){0.f, 0.f, 0.f, 0.f};
     }
 };
 struct StoreS2 {      // class-local pixel m = (b, i, j) -> dx[b, 2i+ph, 2j+pw, n]
