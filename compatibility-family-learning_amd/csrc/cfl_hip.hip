@@ -2037,6 +2037,9 @@ static int make_plan(const CflShape *s, int64_t rows, int groups, bool train, Pl
         const int dtiles = s->D / 64;
         int want = (256 + dtiles * njobs - 1) / (dtiles * njobs);
         P = pow2_floor(want < 1 ? 1 : want);
+        // ... and no more than two 64-row chunks per wave (measured: B = 1024 rows per side, P 2 -> 4: -4 us on grad)
+        const int by_rows = pow2_floor(pl->R / 512 < 1 ? 1 : pl->R / 512);
+        if (P < by_rows) P = by_rows;
         if (P > 8) P = 8;
         while (P > 1 && pl->R / P < 64) P /= 2;
         if (debug_env("CFL_DEBUG_P") > 0) P = debug_env("CFL_DEBUG_P");
