@@ -188,3 +188,19 @@ def test_convpcd_model_matches_oracle():
     st = model.checkpoint_state()['variables']
     assert st['CFL/DistEncoder/conv2/Conv/V'].shape == (5, 5, 64, 128)
     assert st['CFL/DistEncoder/outputs/fully_connected/V'].shape == (6272, 30)
+
+
+def test_exact_fp32_gemm_path_in_a_fresh_process():
+    """The conv GEMMs default to the bf16x3 matrix-core arithmetic; CFL_EXACT_FP32=1 (read once per process)
+    selects the fp32-MFMA kernel.  Run two layer cases under it so that both cores stay covered."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, CFL_EXACT_FP32='1')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, '-m', 'pytest', '-q', '-x', '-m', 'gpu',
+                        os.path.join(root, 'tests', 'test_conv_gpu.py'), '-k',
+                        'test_conv2d_wn_fwd_bwd and (6-14-14-64-128 or 2-8-8-6-70)'],
+                       env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert ' passed' in r.stdout and 'deselected' in r.stdout, r.stdout[-500:]
