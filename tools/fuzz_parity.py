@@ -18,7 +18,7 @@ fails = 0
 for it in range(N):
     style = rng.choice(['dist', 'cfl'])
     dist = 'pcd' if style == 'dist' else rng.choice(['pcd', 'monomer', 'siamese'], p=[0.5, 0.2, 0.3])
-    D = int(rng.choice([64, 128, 192, 256, 512, 1024, 2048]))
+    D = int(rng.choice([64, 128, 192, 256, 512, 1024, 2048, 4096, 8192]))   # >= 4096: XCD-aligned launch order (S = 8 / 16)
     if dist == 'siamese':
         L, K = int(rng.randint(1, 300)), 1
     else:
