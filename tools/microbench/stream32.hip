@@ -2,6 +2,7 @@
 // access patterns?  (experiment helper; not part of the product)
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
@@ -63,11 +64,53 @@ __global__ __launch_bounds__(256) void k_rows1k(const float *x, float *out, int 
     for (int i = 1; i < 16; ++i) s += v[i];
     if (s[0] + s[1] + s[2] + s[3] == 12345.678f) out[0] = s[0];
 }
+// pattern 4: wave instr = 2 rows x 512 B ; wave covers 32 rows x 128 d (16 loads)
+__global__ __launch_bounds__(256) void k_rows512(const float *x, float *out, int R, int D) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int rr = lane >> 5, ch = lane & 31;
+    const int row0 = blockIdx.x * 32, d0 = (blockIdx.y * 4 + wave) * 128;
+    f32x4 v[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = *(const f32x4 *)(x + (size_t)(row0 + 2 * i + rr) * D + d0 + 4 * ch);
+    f32x4 s = v[0];
+#pragma unroll
+    for (int i = 1; i < 16; ++i) s += v[i];
+    if (s[0] + s[1] + s[2] + s[3] == 12345.678f) out[0] = s[0];
+}
+// pattern 5: wave instr = 8 rows x 128 B ; wave covers 32 rows x 128 d (the shipped proj kernel)
+__global__ __launch_bounds__(256) void k_rows128(const float *x, float *out, int R, int D) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int rr = lane >> 3, ch = lane & 7;
+    const int row0 = blockIdx.x * 32, d0 = (blockIdx.y * 4 + wave) * 128;
+    f32x4 v[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            v[q * 4 + i] = *(const f32x4 *)(x + (size_t)(row0 + 8 * i + rr) * D + d0 + q * 32 + 4 * ch);
+    f32x4 s = v[0];
+#pragma unroll
+    for (int i = 1; i < 16; ++i) s += v[i];
+    if (s[0] + s[1] + s[2] + s[3] == 12345.678f) out[0] = s[0];
+}
+// pattern 6: wave instr = 1 row x 1 KiB ; wave covers 32 rows x 256 d (32 loads), 2-wave workgroups (512 d)
+__global__ __launch_bounds__(128) void k_rows1k32(const float *x, float *out, int R, int D) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row0 = blockIdx.x * 32, d0 = (blockIdx.y * 2 + wave) * 256;
+    f32x4 v[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) v[i] = *(const f32x4 *)(x + (size_t)(row0 + i) * D + d0 + 4 * lane);
+    f32x4 s = v[0];
+#pragma unroll
+    for (int i = 1; i < 32; ++i) s += v[i];
+    if (s[0] + s[1] + s[2] + s[3] == 12345.678f) out[0] = s[0];
+}
 __global__ void k_empty(float *out) { if (threadIdx.x == 9999) out[0] = 1.f; }
 
-int main() {
+int main(int argc, char **argv) {
     const int R = 2048, D = 4096;            // one "batch" = 2048 x 4096 f32 = 32 MiB
-    const size_t nb = 12, bytes = (size_t)R * D * 4;
+    // pool of nb batches: 12 (384 MiB) defeats the 256 MiB Infinity Cache, 1 re-reads the same 32 MiB
+    const size_t nb = argc > 1 ? (size_t)atoi(argv[1]) : 12, bytes = (size_t)R * D * 4;
     float *pool, *out;
     CK(hipMalloc(&pool, nb * bytes));
     CK(hipMalloc(&out, 64));
@@ -93,5 +136,8 @@ int main() {
     run("rows 4x256B/instr (proj v2)", [&](float *p) { hipLaunchKernelGGL(k_rows256, dim3(R / 32, D / 512), dim3(256), 0, 0, p, out, R, D); });
     run("rows 16x64B/instr (proj v1)", [&](float *p) { hipLaunchKernelGGL(k_rows64, dim3(R / 32, D / 512), dim3(512), 0, 0, p, out, R, D); });
     run("rows 1x1KiB/instr", [&](float *p) { hipLaunchKernelGGL(k_rows1k, dim3(R / 16, D / 1024), dim3(256), 0, 0, p, out, R, D); });
+    run("rows 2x512B/instr, 32x128 tile", [&](float *p) { hipLaunchKernelGGL(k_rows512, dim3(R / 32, D / 512), dim3(256), 0, 0, p, out, R, D); });
+    run("rows 8x128B/instr (proj shipped)", [&](float *p) { hipLaunchKernelGGL(k_rows128, dim3(R / 32, D / 512), dim3(256), 0, 0, p, out, R, D); });
+    run("rows 1x1KiB/instr, 32x256 tile", [&](float *p) { hipLaunchKernelGGL(k_rows1k32, dim3(R / 32, D / 512), dim3(128), 0, 0, p, out, R, D); });
     return 0;
 }
