@@ -1696,6 +1696,8 @@ struct Region {
 };
 
 struct FinArgs {
+    // compact copy of the region bounds (floats): the region search reads these with three wide scalar loads
+    int rbeg[CFL_MAX_REGIONS], rend[CFL_MAX_REGIONS];
     Region reg[CFL_MAX_REGIONS];
     int nregions;
     long long total;           // floats in theta
@@ -1717,6 +1719,105 @@ struct FinArgs {
     float lr_t, b1, b2, eps;
     const float *thr_copy;     // max(thr,1e-6) as seen by the mid kernel of this step
 };
+
+// gradient of the 4 parameters at `base`, which lie in region `rg`
+__device__ __forceinline__ f32x4 fin_region_grad(const FinArgs &a, const Region &rg, long long base, const f32x4 th) {
+    f32x4 gr = {0.f, 0.f, 0.f, 0.f};
+    const long long rel = base - rg.off;
+    switch (rg.kind) {
+        case RK_W: {
+            // Wf layout: block = rel/256 -> nt = block / G ; c16 = ((rel%256)/4) % 16
+            const int G = a.D >> 4;
+            const int c = (int)((rel >> 8) / G) * 16 + (int)((rel >> 2) & 15);
+            const long long ps = (long long)rg.npad * a.D;
+            f32x4 t[2][8];
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int pp = 0; pp < 8; ++pp)
+                    t[s][pp] = (rg.slab[s] && pp < a.P) ? *(const f32x4 *)(rg.slab[s] + rel + pp * ps)
+                                                        : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int pp = 0; pp < 8; ++pp) gr += t[s][pp];
+            // the slabs hold X^T dy with unscaled dy: apply the input / weight-norm scale
+            if (a.weight_norm) {
+                if (c < rg.n) {
+                    const float n2 = rg.n2[c], n = sqrtf(n2);
+                    gr *= n2 > 0.f ? a.in_mul * rg.g[c] / n : 0.f;
+                    float cw = 0.f;
+                    for (int s = 0; s < 2; ++s)
+                        if (rg.cs_cw[s] >= 0) cw += a.colsum[rg.cs_cw[s] + c];
+                    if (n2 > 0.f) gr -= (rg.g[c] * cw / (n2 * n)) * th;
+                } else {
+                    gr *= 0.f;
+                }
+            } else {
+                gr *= a.in_mul;
+            }
+            break;
+        }
+        case RK_BIAS: {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int c = (int)rel + e;
+                if (c < rg.n)
+                    for (int s = 0; s < 2; ++s)
+                        if (rg.cs_dy[s] >= 0) gr[e] += a.colsum[rg.cs_dy[s] + c];
+            }
+            break;
+        }
+        case RK_GAIN: {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int c = (int)rel + e;
+                if (c < rg.n) {
+                    float cw = 0.f;
+                    for (int s = 0; s < 2; ++s)
+                        if (rg.cs_cw[s] >= 0) cw += a.colsum[rg.cs_cw[s] + c];
+                    const float n2 = rg.n2[c];
+                    gr[e] = n2 > 0.f ? cw / sqrtf(n2) : 0.f;
+                }
+            }
+            break;
+        }
+        case RK_THR: {
+            if (rel == 0) gr[0] = th[0] >= CFL_THR_FLOOR ? a.colsum[a.cs_rowq + P_DTHR] : 0.f;
+            break;
+        }
+        case RK_MONO_W: {  // V[L][kpad]; cs_dy[0] >= 0 marks the encoder whose gate is used
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int l = (int)((rel + e) / a.kpad), kk = (int)((rel + e) % a.kpad);
+                if (l < a.L && kk < rg.n && rg.cs_dy[0] >= 0) {
+                    float g1 = a.colsum[a.cs_mono + l * a.kpad + kk];
+                    if (a.weight_norm) {
+                        const float cw = a.colsum[a.cs_duc + kk];
+                        const float n2 = rg.n2[kk], n = sqrtf(n2);
+                        if (n2 > 0.f) g1 -= rg.g[kk] * cw / (n2 * n) * th[e];
+                    }
+                    gr[e] = g1;
+                }
+            }
+            break;
+        }
+        case RK_MONO_G: {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int kk = (int)rel + e;
+                if (rg.cs_dy[0] >= 0 && kk < rg.n) {
+                    const float n2 = rg.n2[kk];
+                    gr[e] = n2 > 0.f ? a.colsum[a.cs_duc + kk] / sqrtf(n2) : 0.f;
+                }
+            }
+            break;
+        }
+        default: break;
+    }
+    if (rg.reg) gr += a.reg_const * th;
+    return gr;
+}
 
 extern "C" __global__ __launch_bounds__(256) void cfl_finalize_kernel(FinArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1768,9 +1869,13 @@ extern "C" __global__ __launch_bounds__(256) void cfl_finalize_kernel(FinArgs a)
     // loads of a thread are independent and issued together.
     const long long base = ((long long)blockIdx.x * 256 + tid) * 4;
     if (base >= a.total) return;
-    int k = 0;
-    for (; k < a.nregions; ++k)
-        if (base >= a.reg[k].off && base < a.reg[k].off + a.reg[k].cnt) break;
+    // region of this float4: all descriptors' bounds are fetched at once (a search loop with an early
+    // exit made every iteration a dependent kernel-argument load)
+    int k = a.nregions;
+    const int b32 = (int)base;   // theta has < 2^31 floats (make_plan)
+#pragma unroll
+    for (int i = CFL_MAX_REGIONS - 1; i >= 0; --i)
+        k = ((b32 >= a.rbeg[i]) & (b32 < a.rend[i])) ? i : k;   // unused slots are empty ranges (0, 0)
     const f32x4 th = *(const f32x4 *)(a.theta + base);
     // the Adam slots are requested together with theta and the slabs (one memory round trip, not two:
     // behind the gradient store the compiler could not hoist them)
@@ -1781,100 +1886,14 @@ extern "C" __global__ __launch_bounds__(256) void cfl_finalize_kernel(FinArgs a)
     }
     f32x4 gr = {0.f, 0.f, 0.f, 0.f};
     if (k < a.nregions) {
-        const Region &rg = a.reg[k];
-        const long long rel = base - rg.off;
-        switch (rg.kind) {
-            case RK_W: {
-                // Wf layout: block = rel/256 -> nt = block / G ; c16 = ((rel%256)/4) % 16
-                const int G = a.D >> 4;
-                const int c = (int)((rel >> 8) / G) * 16 + (int)((rel >> 2) & 15);
-                const long long ps = (long long)rg.npad * a.D;
-                f32x4 t[2][8];
-#pragma unroll
-                for (int s = 0; s < 2; ++s)
-#pragma unroll
-                    for (int pp = 0; pp < 8; ++pp)
-                        t[s][pp] = (rg.slab[s] && pp < a.P) ? *(const f32x4 *)(rg.slab[s] + rel + pp * ps)
-                                                            : (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int s = 0; s < 2; ++s)
-#pragma unroll
-                    for (int pp = 0; pp < 8; ++pp) gr += t[s][pp];
-                // the slabs hold X^T dy with unscaled dy: apply the input / weight-norm scale
-                if (a.weight_norm) {
-                    if (c < rg.n) {
-                        const float n2 = rg.n2[c], n = sqrtf(n2);
-                        gr *= n2 > 0.f ? a.in_mul * rg.g[c] / n : 0.f;
-                        float cw = 0.f;
-                        for (int s = 0; s < 2; ++s)
-                            if (rg.cs_cw[s] >= 0) cw += a.colsum[rg.cs_cw[s] + c];
-                        if (n2 > 0.f) gr -= (rg.g[c] * cw / (n2 * n)) * th;
-                    } else {
-                        gr *= 0.f;
-                    }
-                } else {
-                    gr *= a.in_mul;
-                }
-                break;
-            }
-            case RK_BIAS: {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int c = (int)rel + e;
-                    if (c < rg.n)
-                        for (int s = 0; s < 2; ++s)
-                            if (rg.cs_dy[s] >= 0) gr[e] += a.colsum[rg.cs_dy[s] + c];
-                }
-                break;
-            }
-            case RK_GAIN: {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int c = (int)rel + e;
-                    if (c < rg.n) {
-                        float cw = 0.f;
-                        for (int s = 0; s < 2; ++s)
-                            if (rg.cs_cw[s] >= 0) cw += a.colsum[rg.cs_cw[s] + c];
-                        const float n2 = rg.n2[c];
-                        gr[e] = n2 > 0.f ? cw / sqrtf(n2) : 0.f;
-                    }
-                }
-                break;
-            }
-            case RK_THR: {
-                if (rel == 0) gr[0] = th[0] >= CFL_THR_FLOOR ? a.colsum[a.cs_rowq + P_DTHR] : 0.f;
-                break;
-            }
-            case RK_MONO_W: {  // V[L][kpad]; cs_dy[0] >= 0 marks the encoder whose gate is used
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int l = (int)((rel + e) / a.kpad), kk = (int)((rel + e) % a.kpad);
-                    if (l < a.L && kk < rg.n && rg.cs_dy[0] >= 0) {
-                        float g1 = a.colsum[a.cs_mono + l * a.kpad + kk];
-                        if (a.weight_norm) {
-                            const float cw = a.colsum[a.cs_duc + kk];
-                            const float n2 = rg.n2[kk], n = sqrtf(n2);
-                            if (n2 > 0.f) g1 -= rg.g[kk] * cw / (n2 * n) * th[e];
-                        }
-                        gr[e] = g1;
-                    }
-                }
-                break;
-            }
-            case RK_MONO_G: {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int kk = (int)rel + e;
-                    if (rg.cs_dy[0] >= 0 && kk < rg.n) {
-                        const float n2 = rg.n2[kk];
-                        gr[e] = n2 > 0.f ? a.colsum[a.cs_duc + kk] / sqrtf(n2) : 0.f;
-                    }
-                }
-                break;
-            }
-            default: break;
-        }
-        if (rg.reg) gr += a.reg_const * th;
+        // Almost every wave lies inside one region (regions are 64-float aligned, a wave covers 256 floats): its
+        // descriptor is then fetched with scalar loads.  Per-lane descriptors (vector loads from the kernel
+        // arguments, one more dependent round trip before the slab loads can be issued) only at region boundaries.
+        const int ku = __builtin_amdgcn_readfirstlane(k);
+        if (__builtin_amdgcn_ballot_w64(k != ku) == 0)
+            gr = fin_region_grad(a, a.reg[ku], base, th);
+        else
+            gr = fin_region_grad(a, a.reg[k], base, th);
     }
     *(f32x4 *)(a.grad + base) = gr;
     if (a.adam_m) {  // fused TF-Adam apply (single-GPU step)
@@ -2027,6 +2046,7 @@ static int make_plan(const CflShape *s, int64_t rows, int groups, bool train, Pl
     const CflHead *hs, *hd;
     side_heads(s, pl->lay, &hs, &hd);
     if (hs->npad > 1024 || hd->npad > 1024) return set_err(CFL_E_UNSUPPORTED, "more than 1024 head columns");
+    if (pl->lay.total >= (1ll << 31)) return set_err(CFL_E_UNSUPPORTED, "more than 2^31 parameters");
     pl->R = (int)(rows * groups);
     const int njobs = (hs->npad / 16 + 3) / 4 + (hd->npad / 16 + 3) / 4;
     if (njobs > CFL_MAX_JOBS) return set_err(CFL_E_UNSUPPORTED, "too many column chunks");
@@ -2445,6 +2465,10 @@ static int run_pairs(const CflShape *s, const CflNorm *norm, const CflLossCfg *l
     if (adam) {
         fa.adam_m = adam->m; fa.adam_v = adam->v; fa.theta_out = adam->theta;
         fa.lr_t = adam->lr_t; fa.b1 = adam->b1; fa.b2 = adam->b2; fa.eps = adam->eps;
+    }
+    for (int i = 0; i < fa.nregions; ++i) {
+        fa.rbeg[i] = (int)fa.reg[i].off;
+        fa.rend[i] = (int)(fa.reg[i].off + fa.reg[i].cnt);
     }
     {
         ProfScope ps(st, CFL_K_FINALIZE);
