@@ -1454,11 +1454,26 @@ __global__ __launch_bounds__(256) void cfl_mid_row_kernel(MidArgs a) {
         ll[j] = cs[j] ? c[j] - kk[j] * L : 0;
     }
 
+    // ---- head parameters: requested before the slice loads, so that this one-wave-per-row kernel (whose
+    // latency chain IS its duration) pays one memory round trip for everything it reads, not two ------------
+    const float thr_raw = *a.thr;
+    float scs[J], scd[J], bs[J], bd[J], ys[J], yd[J];
+    {
+        float gs[J], ns[J], gd[J], nd[J];
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            const int ks = cs[j] ? c[j] : 0, kd = cd[j] ? c[j] : 0;   // clamped: unconditional loads
+            gs[j] = a.weight_norm ? ss.g[ks] : 1.f;
+            ns[j] = a.weight_norm ? ss.n2[ks] : 1.f;
+            gd[j] = a.weight_norm ? sd.g[kd] : 1.f;
+            nd[j] = a.weight_norm ? sd.n2[kd] : 1.f;
+            bs[j] = ss.b ? ss.b[ks] : 0.f;
+            bd[j] = sd.b ? sd.b[kd] : 0.f;
+        }
+        __builtin_amdgcn_sched_barrier(0);
     // ---- slice sums + head epilogue (J columns per lane) ---------------------------
     // all slice loads of both sides are independent and in flight together (summed in
     // slice order afterwards)
-    float ys[J], yd[J];
-    {
         float ts[J][16], td[J][16];
 #pragma unroll
         for (int j = 0; j < J; ++j) {
@@ -1472,29 +1487,26 @@ __global__ __launch_bounds__(256) void cfl_mid_row_kernel(MidArgs a) {
         }
 #pragma unroll
         for (int j = 0; j < J; ++j) {
+            scs[j] = (a.weight_norm && cs[j]) ? gs[j] * __builtin_amdgcn_rsqf(ns[j]) : 1.f;
+            scd[j] = (a.weight_norm && cd[j]) ? gd[j] * __builtin_amdgcn_rsqf(nd[j]) : 1.f;
+            if (!cs[j]) bs[j] = 0.f;
+            if (!cd[j]) bd[j] = 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
             ys[j] = 0.f;
             yd[j] = 0.f;
 #pragma unroll
             for (int s = 0; s < 16; ++s) { ys[j] += ts[j][s]; yd[j] += td[j][s]; }
         }
     }
-    const float thr_raw = *a.thr;
     float xvs[J], xvd[J], P[J], v[J];
 #pragma unroll
     for (int j = 0; j < J; ++j) {
-        float scs = 1.f, scd = 1.f, bs = 0.f, bd = 0.f;
-        if (cs[j]) {
-            if (a.weight_norm) scs = ss.g[c[j]] * __builtin_amdgcn_rsqf(ss.n2[c[j]]);
-            if (ss.b) bs = ss.b[c[j]];
-        }
-        if (cd[j]) {
-            if (a.weight_norm) scd = sd.g[c[j]] * __builtin_amdgcn_rsqf(sd.n2[c[j]]);
-            if (sd.b) bd = sd.b[c[j]];
-        }
         xvs[j] = (valid && cs[j]) ? ys[j] * a.in_mul : 0.f;
         xvd[j] = (valid && cd[j]) ? yd[j] * a.in_mul : 0.f;
-        P[j] = (valid && cs[j]) ? act_fn(xvs[j] * scs + bs, a.act) : 0.f;
-        v[j] = (valid && cd[j]) ? act_fn(xvd[j] * scd + bd, a.act) : 0.f;
+        P[j] = (valid && cs[j]) ? act_fn(xvs[j] * scs[j] + bs[j], a.act) : 0.f;
+        v[j] = (valid && cd[j]) ? act_fn(xvd[j] * scd[j] + bd[j], a.act) : 0.f;
         Pl[c[j]] = P[j];
         Vl[c[j]] = v[j];
     }
