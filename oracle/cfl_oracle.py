@@ -4,16 +4,26 @@ TEST INFRASTRUCTURE ONLY.  Nothing under ``oracle/`` is part of the product:
 only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline``
 leg may import it, and only as the checker / the timed CPU baseline.
 
-PARITY UNPINNED (arithmetic).  The reference (appier/compatibility-family-
-learning) executes this arithmetic inside TensorFlow 1.x, which is not
-installable in the build container, and the reference ships no tests, golden
-vectors or fixtures for it.  This file is therefore a plain
-NumPy restatement that follows the cited reference lines; it is pinned only by
-(i) the analytic known-answer tests of SURVEY.md App. A.7, (ii) float64
-finite-difference checks of every analytic gradient and (iii) an independent
-torch-autograd float64 cross-check (tests/test_oracle.py).  The data / eval side
-(oracle/data_oracle.py) IS pinned against vectors captured by importing the
-reference (tests/golden/).
+PARITY: COMPOSITION PINNED, TENSORFLOW KERNELS UNPINNED ("parity unpinned" for
+the TF primitives).  The reference (appier/compatibility-family-learning) runs
+this arithmetic inside TensorFlow 1.x, which is not installable in the build
+container, and ships no tests or golden vectors for it.
+What IS pinned: tests/golden/make_arith_goldens.py imports the reference's own
+``cfl.models.dist.Dist`` / ``cfl.models.cfl.CFL`` classes (with ``cfl.layers``,
+``cfl.ops``, ``cfl.models.base``, ``cfl.models.blocks`` behind them) and runs
+their constructors over an eager float64 stand-in for the TF primitives
+(tests/golden/tf_standin.py); tests/test_arith_goldens.py requires this file to
+reproduce every distance, score, loss part, gradient (by TF variable name) and
+every variable after 1-3 Adam steps of 11 linear cases to float64 round-off.
+So which head feeds which side, reshape orders, softmax axes, loss / pos_weight
+/ regulariser placement, optimiser ownership and the maximum / relu tie rules
+follow the reference's lines; only the primitives themselves (matmul, softmax,
+sigmoid_cross_entropy_with_logits, Adam, ... restated from TF's documentation)
+were never compared with a real TensorFlow run.  Further pins: the analytic
+known-answer tests of SURVEY.md App. A.7, float64 finite differences of every
+analytic gradient and a torch-autograd cross-check (tests/test_oracle.py).  The
+data / eval side (oracle/data_oracle.py) is pinned against vectors captured by
+importing the reference unmodified (tests/golden/).
 
 All citations are ``path:line`` relative to the reference tree.
 

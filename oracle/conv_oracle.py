@@ -9,11 +9,12 @@ convolution layers and of the ConvPCD encoder, following
     lrelu                         cfl/ops.py:10-12
     ConvPCD                       cfl/models/blocks.py:530-590
 
-PARITY UNPINNED: like oracle/cfl_oracle.py this restates TensorFlow-1 arithmetic that
-cannot be executed here (no TensorFlow) and for which the reference holds no tests; it
-relies on the documented TF semantics of SURVEY.md App. E ('SAME' padding puts the extra
-pixel on the bottom / right, l2_normalize(x, dims, eps=1e-12) = x * rsqrt(max(sum x^2, eps)),
-HWIO filters, NHWC activations).  Only tests/ and smoke() may import it.
+PARITY: composition pinned, TensorFlow kernels unpinned (see oracle/cfl_oracle.py): the ConvPCD trunk + heads
++ losses + Adam reproduce, to float64 round-off, golden vectors produced by the reference's own CFL / ConvPCD
+classes running over a TF stand-in (tests/golden/make_arith_goldens.py, tests/test_arith_goldens.py).  The
+primitives follow the documented TF semantics of SURVEY.md App. E ('SAME' padding puts the extra pixel on the
+bottom / right, l2_normalize(x, dims, eps=1e-12) = x * rsqrt(max(sum x^2, eps)), HWIO filters, NHWC
+activations).  Only tests/ and smoke() may import it.
 """
 import math
 

@@ -10,10 +10,14 @@ torch (CPU, float64, autograd incl. double backward) restatement of
     GAN losses                cfl/models/cfl.py:951-1063
     the two Adams             cfl/models/cfl.py:1087-1096, run together at cfl/models/cfl.py:1491-1497
 
-PARITY UNPINNED (see oracle/cfl_oracle.py): TensorFlow cannot run here and the reference has no
-tests for this arithmetic.  Assumed TF-1 semantics: conv2d_transpose with
-'SAME' padding is the exact adjoint of the 'SAME' strided convolution with the same filter;
-relu'(0) = 0; tf.nn.moments = population variance.  Only tests/ and smoke() may import this file.
+PARITY: composition pinned, TensorFlow kernels unpinned (see oracle/cfl_oracle.py).  The whole post-epoch
+step -- generator / discriminator stacks, the GAN wiring of CFL._build_model, every loss part, the gradient
+penalty's double backward, the two Adams, for srgan / conv, cgan / non-cgan, with and without --t-dim -- is
+checked to float64 round-off against golden vectors produced by the reference's own classes running over a
+TF stand-in (tests/golden/make_arith_goldens.py, tests/test_arith_goldens.py).  TF-1 semantics the stand-in
+and this file both take from TF's documentation: conv2d_transpose with 'SAME' padding is
+the exact adjoint of the 'SAME' strided convolution with the same filter; relu'(0) = 0; tf.nn.moments =
+population variance.  Only tests/ and smoke() may import this file.
 """
 import math
 
@@ -373,7 +377,9 @@ class AdamTF:
         self.b1p, self.b2p = np.float32(beta1), np.float32(beta2)
 
     def lr_t(self):
-        return float(np.float32(self.lr) * np.sqrt(np.float32(1) - self.b2p) / (np.float32(1) - self.b1p))
+        # the power accumulators are float32 variables in TF; the expression is evaluated in the dtype of the
+        # trained variables (float64 here), like oracle/cfl_oracle.py AdamState.lr_t
+        return float(np.float64(self.lr) * np.sqrt(1.0 - np.float64(self.b2p)) / (1.0 - np.float64(self.b1p)))
 
     def apply(self, params, grads):
         lr_t = self.lr_t()
