@@ -16,12 +16,14 @@ import sys
 
 import numpy as np
 
+from ..utils import Saver
+
 ADAM_SUFFIX = ('/Adam', '/Adam_1')      # TF-1 slot names of tf.train.AdamOptimizer (m, v)
 
 
 def _load_pt(path):
-    import torch
-    return torch.load(path, weights_only=False)
+    from ..utils import load_checkpoint_file
+    return load_checkpoint_file(path)
 
 
 def state_to_arrays(state):
@@ -95,12 +97,12 @@ def main(argv=None):
     elif a.from_npz:
         import torch
         with np.load(a.src) as z:
-            torch.save(arrays_to_state({k: z[k] for k in z.files}, a.step), a.dst)
+            torch.save(Saver._plain(arrays_to_state({k: z[k] for k in z.files}, a.step)), a.dst)
     elif a.to_tf:
         to_tf(state_to_arrays(_load_pt(a.src)), a.dst)
     else:
         import torch
-        torch.save(arrays_to_state(from_tf(a.src), a.step), a.dst)
+        torch.save(Saver._plain(arrays_to_state(from_tf(a.src), a.step)), a.dst)
     return 0
 
 

@@ -6,8 +6,8 @@ Drop-in for the reference's cfl/bin/train.py flag surface and directory layout
 Random crop / mirror / resize input transformers run on the GPU (cfl_image_transform)."""
 import logging
 import os
-import shutil
 
+from .. import engine as dp
 from ..input_data import load_data_sets
 from ..models.cfl import construct_model
 from ..ops import dist_ae_transformer, dist_normalizer, dist_transformer
@@ -22,6 +22,8 @@ def train_dist(load_pre_weights, data_switch, epochs, post_epochs, eval_epochs, 
                data_mirror, data_random_crop, data_is_image, raw_latent, data_scale, data_mean,
                latent_norm, **model_args):
     a = model_args
+    dp.init_from_env()
+    chief = dp.rank() == 0
     input_size = reduce_product(a['input_shape'])
     source_size = reduce_product(a['source_shape']) if a['source_shape'] else input_size
     data = load_data_sets(os.path.join(data_root, data_name), source_size, is_image=data_is_image,
@@ -44,10 +46,7 @@ def train_dist(load_pre_weights, data_switch, epochs, post_epochs, eval_epochs, 
     no_gan_checkpoint_dir = os.path.join(root, model.get_name(no_gan=True)) if load_pre_weights else None
     checkpoint_dir = os.path.join(root, model.get_name())
     log_dir = os.path.join(log_root, data_name, model.get_name())
-    for path in (checkpoint_dir, log_dir):
-        if reset and os.path.exists(path):
-            shutil.rmtree(path)
-        os.makedirs(path, exist_ok=True)
+    dp.prepare_run_dirs((checkpoint_dir, log_dir), reset)
     setup_logging(log_dir)
     logger.warning('run with %s', model.get_name())
 
@@ -56,14 +55,15 @@ def train_dist(load_pre_weights, data_switch, epochs, post_epochs, eval_epochs, 
     best_acc_dir = os.path.join(checkpoint_dir, 'best_acc_model')
     os.makedirs(best_dir, exist_ok=True)
     os.makedirs(best_acc_dir, exist_ok=True)
-    writer = ScalarWriter(log_dir)
+    writer = ScalarWriter(log_dir) if chief else None      # checkpoints, scalars and evaluation: rank 0 only
     try:
         model.train(sess=None, data=data, start_iter=start_iter, epochs=epochs, post_epochs=post_epochs,
                     best_dir=best_dir, best_acc_dir=best_acc_dir, checkpoint_dir=checkpoint_dir,
                     eval_epochs=eval_epochs, disable_eval=disable_eval, saver=saver, best_saver=Saver(),
                     best_acc_saver=Saver(), save_iters=save_iters, writer=writer)
     finally:
-        writer.close()
+        if writer is not None:
+            writer.close()
 
 
 def parse_args(argv=None):

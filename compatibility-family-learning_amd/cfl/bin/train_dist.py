@@ -3,13 +3,13 @@
 Drop-in for the reference's cfl/bin/train_dist.py (same flags, checkpoint / log
 layout and best_acc_model bookkeeping, cfl/bin/train_dist.py:37-124).  The
 TensorFlow queues + enqueue threads are replaced by HBM-resident feature tables
-gathered on the GPU by pair index (cfl.input_data.ResidentFeatures), and the
-per-iteration ``sess.run`` by one fused HIP training step.
+(cfl.input_data.ResidentFeatures) that the fused HIP training step reads in place
+by pair index (cfl_pair_train_step_idx: no gather pass, no batch copy), and the
+per-iteration ``sess.run`` by that one step.
 """
 import gc
 import logging
 import os
-import shutil
 
 from tqdm import trange
 
@@ -23,6 +23,17 @@ from ..utils import (IncrementalAverage, Saver, dist_eval, load_best_stats, load
 logger = logging.getLogger(__name__)
 
 SCALAR_EVERY = 25  # host read-back cadence of the display scalars (steps)
+
+
+def train_steps(model, train_src, val_src, batch_size, shard, n_steps, on_scalars=None, progress=None):
+    """The per-iteration body of the training loop (cfl/bin/train_dist.py:77-87 of the reference: one
+    ``sess.run([summary, [s_optim], s_accuracy, val_s_accuracy])`` per iteration): the next labeled batch of the
+    seeded index stream -- as positions into the resident feature table -- goes through one fused training step;
+    the display scalars (train / validation accuracy) are read back every SCALAR_EVERY iterations."""
+    for i in (progress if progress is not None else range(n_steps)):
+        model.engine.step(train_src.next_indexed(batch_size, shard))
+        if on_scalars is not None and (i % SCALAR_EVERY == 0 or i == n_steps - 1):
+            on_scalars(i, model.scalars(), model.batch_accuracy(val_src.next_indexed(batch_size)))
 
 
 def train_loop(model, data, aux, batch_size, start_epoch, epochs, log_dir, checkpoint_dir, saver):
@@ -39,26 +50,27 @@ def train_loop(model, data, aux, batch_size, start_epoch, epochs, log_dir, check
     os.makedirs(best_dir, exist_ok=True)
     best_accuracy_path = os.path.join(best_dir, 'best_accuracy')
     stats = load_best_stats(best_accuracy_path)
-    scalar_log = open(os.path.join(log_dir, 'scalars.tsv'), 'a')
-
     # data parallel (torchrun): every rank walks the same seeded index stream and
     # trains on its contiguous slice of each global batch; rank 0 evaluates and saves
     shard = dp.shard_rows(batch_size) if dp.world_size() > 1 else None
     chief = dp.rank() == 0
+    # the scalars are global-batch values on every rank (they travel in the gradient all-reduce): one writer
+    scalar_log = open(os.path.join(log_dir, 'scalars.tsv'), 'a') if chief else None
     for e in range(start_epoch, epochs):
         t = trange(nb_batch, disable=not chief)
         t.set_description('epoch {}'.format(e))
         train_avg, val_avg = IncrementalAverage(), IncrementalAverage()
-        for i in t:
-            model.engine.step(train_src.next_batch(batch_size, shard))
-            if i % SCALAR_EVERY == 0 or i == nb_batch - 1:
-                s = model.scalars()
-                train_avg.add(s['accuracy'])
-                val_avg.add(model.batch_accuracy(val_src.next_batch(batch_size)))
-                t.set_postfix(train_acc=train_avg.average, val_acc=val_avg.average)
+
+        def on_scalars(i, s, val_acc, e=e, t=t, train_avg=train_avg, val_avg=val_avg):
+            train_avg.add(s['accuracy'])
+            val_avg.add(val_acc)
+            t.set_postfix(train_acc=train_avg.average, val_acc=val_avg.average)
+            if scalar_log is not None:
                 scalar_log.write('{}\t{}\t{}\t{}\n'.format(nb_batch * e + i, s['total'], s['accuracy'],
                                                            s['threshold']))
-        scalar_log.flush()
+        train_steps(model, train_src, val_src, batch_size, shard, nb_batch, on_scalars, progress=t)
+        if scalar_log is not None:
+            scalar_log.flush()
         gc.collect()
         if not chief:
             continue
@@ -76,12 +88,14 @@ def train_loop(model, data, aux, batch_size, start_epoch, epochs, log_dir, check
         else:
             logger.warning('epoch %d: avg error = train: %f val: %f', e, 1. - train_avg.average,
                            1. - val_avg.average)
-    scalar_log.close()
+    if scalar_log is not None:
+        scalar_log.close()
 
 
 def setup_logging(log_dir):
     log_format = '%(asctime)s [%(levelname)-5.5s] [%(name)s]  %(message)s'
-    logging.basicConfig(filename=os.path.join(log_dir, 'log.log'), format=log_format,
+    # one writer of log.log: rank 0 (the other ranks log to the console only)
+    logging.basicConfig(filename=os.path.join(log_dir, 'log.log') if dp.rank() == 0 else None, format=log_format,
                         level=logging.WARNING)
     console = logging.StreamHandler()
     console.setLevel(logging.INFO)
@@ -92,12 +106,7 @@ def setup_logging(log_dir):
 def train_monomer(data_name, data_root, checkpoint_root, log_root, run_tag, seed, normalize_value,
                   input_shape, batch_size, num_components, latent_size, lr, beta1, beta2, epochs,
                   reg_const, reset):
-    if int(os.environ.get('WORLD_SIZE', '1')) > 1 and not dp.dist.is_initialized():
-        import torch
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
-        dp.dist.init_process_group('nccl')
+    dp.init_from_env()
     input_shape = tuple(input_shape)
     input_size = reduce_product(input_shape)
     data = load_data_sets(os.path.join(data_root, data_name), input_size, seed=seed)
@@ -109,12 +118,7 @@ def train_monomer(data_name, data_root, checkpoint_root, log_root, run_tag, seed
 
     checkpoint_dir = os.path.join(checkpoint_root, data_name, model.get_name())
     log_dir = os.path.join(log_root, data_name, model.get_name())
-    for path in (checkpoint_dir, log_dir):
-        if reset and os.path.exists(path) and dp.rank() == 0:
-            shutil.rmtree(path)
-        os.makedirs(path, exist_ok=True)
-    if dp.world_size() > 1:
-        dp.dist.barrier()
+    dp.prepare_run_dirs((checkpoint_dir, log_dir), reset)
     setup_logging(log_dir)
     saver, start_epoch = load_model(model, checkpoint_dir)
     train_loop(model=model, aux=aux, data=data, batch_size=batch_size, start_epoch=start_epoch,

@@ -26,10 +26,37 @@ def rank():
     return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
 
 
+def init_from_env():
+    """Under torchrun (WORLD_SIZE > 1 in the environment): bind this process to its GPU and join the RCCL
+    process group.  One process per GPU; called by the CLI entry points before any model is built."""
+    import os
+    if int(os.environ.get('WORLD_SIZE', '1')) > 1 and not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        backend = os.environ.get('CFL_DIST_BACKEND', 'nccl')
+        local = int(os.environ.get('LOCAL_RANK', '0'))
+        torch.cuda.set_device(local if backend == 'nccl' else local % max(torch.cuda.device_count(), 1))
+        dist.init_process_group(backend)
+    return world_size()
+
+
+def prepare_run_dirs(paths, reset):
+    """--reset and directory creation with several ranks: rank 0 clears and creates, the others wait."""
+    import os
+    import shutil
+    if rank() == 0:
+        for path in paths:
+            if reset and os.path.exists(path):
+                shutil.rmtree(path)
+            os.makedirs(path, exist_ok=True)
+    if world_size() > 1:
+        dist.barrier()
+
+
 def reduce_gradients(flat_grad):
     """The ONE exchange of a data-parallel step: sum the flat fp32
-    gradient (same layout on every rank) over all ranks; returns the factor that turns
-    the sum into the gradient of the global-batch mean loss.  Backend "nccl" is RCCL
+    buffer [gradient | loss / accuracy scalars] (same layout on every rank) over all ranks;
+    returns the factor that turns the sums into the global-batch means.  Backend "nccl" is RCCL
     over xGMI on MI355X; the CPU tests run the same code over gloo."""
     n = world_size()
     if n > 1:
@@ -65,8 +92,13 @@ class PairEngine(object):
         self.theta = H.pack_theta(self.shape, params, params_dst, thr, self.device)
         self.m = torch.zeros_like(self.theta)
         self.v = torch.zeros_like(self.theta)
-        self.grad = torch.zeros_like(self.theta)
-        self.scalars = torch.zeros(H.S_COUNT, dtype=torch.float32, device=self.device)
+        # ONE flat buffer [gradient (layout of theta) | the step's loss / accuracy scalars | pad]: the kernels
+        # write both parts, and the data-parallel exchange is a single all-reduce of it
+        n = self.theta.numel()
+        self.gradbuf = torch.zeros(n + 64, dtype=torch.float32, device=self.device)
+        self.grad = self.gradbuf[:n]
+        self.scalars = self.gradbuf[n:n + H.S_COUNT]
+        self._scalar_scale = 1.0
         # TF keeps beta1_power / beta2_power as float32 variables
         self.beta1_power = np.float32(beta1)
         self.beta2_power = np.float32(beta2)
@@ -101,6 +133,7 @@ class PairEngine(object):
         ws = self._workspace(batch[0].shape[0], 2)
         H.pair_step_fwd_bwd(self.shape, self.norm, self.loss, batch, self.theta,
                             self.grad, self.scalars, ws)
+        self._scalar_scale = 1.0
 
     def apply_adam(self, grad_scale=1.0):
         H.adam_tf(self.theta, self.m, self.v, self.grad, self.lr_t(), self.beta1,
@@ -113,28 +146,50 @@ class PairEngine(object):
         self.global_step += 1
 
     def step(self, batch):
-        """One training step on this rank's shard of the row batch."""
+        """One training step on this rank's shard of the row batch: `batch` is either the 4 dense device
+        tensors (pos_src, pos_dst, neg_src, neg_dst) or a (table, IndexStreams) pair -- rows picked from a
+        resident feature table by index (cfl.input_data.ResidentFeatures.next_indexed)."""
         n = self.world_size
+        indexed = isinstance(batch[1], H.IndexStreams)
+        rows = batch[1].n if indexed else batch[0].shape[0]
+        ws = self._workspace(rows, 2)
         if n == 1:
             # single GPU: Adam fused into the last kernel of the step
-            ws = self._workspace(batch[0].shape[0], 2)
-            H.pair_train_step(self.shape, self.norm, self.loss, batch, self.theta, self.m,
-                              self.v, self.grad, self.scalars, ws, self.lr_t(), self.beta1,
-                              self.beta2, self.eps)
+            if indexed:
+                H.pair_train_step_idx(self.shape, self.norm, self.loss, batch[0], batch[1], self.theta, self.m,
+                                      self.v, self.grad, self.scalars, ws, self.lr_t(), self.beta1, self.beta2,
+                                      self.eps)
+            else:
+                H.pair_train_step(self.shape, self.norm, self.loss, batch, self.theta, self.m,
+                                  self.v, self.grad, self.scalars, ws, self.lr_t(), self.beta1,
+                                  self.beta2, self.eps)
+            self._scalar_scale = 1.0
             self._advance()
             return
-        self.fwd_bwd(batch)
-        # one exchange per step: sum of the flat fp32 gradient over xGMI
-        self.apply_adam(reduce_gradients(self.grad))
+        if indexed:
+            H.pair_step_fwd_bwd_idx(self.shape, self.norm, self.loss, batch[0], batch[1], self.theta, self.grad,
+                                    self.scalars, ws)
+        else:
+            H.pair_step_fwd_bwd(self.shape, self.norm, self.loss, batch, self.theta, self.grad, self.scalars, ws)
+        # one exchange per step: sum of [flat fp32 gradient | scalars] over xGMI
+        scale = reduce_gradients(self.gradbuf)
+        self._scalar_scale = scale
+        self.apply_adam(scale)
 
     def read_scalars(self):
-        """Host copy of the last step's scalars (synchronises the stream)."""
-        vals = self.scalars.cpu().numpy()
+        """Host copy of the last step's scalars (synchronises the stream).  Under data parallelism they are the
+        global-batch values: every scalar is a mean over this rank's rows, the shards are equal-sized, and the
+        sums travelled in the gradient all-reduce."""
+        vals = self.scalars.cpu().numpy() * np.float32(self._scalar_scale)
         return dict(zip(H.SCALAR_NAMES, (float(x) for x in vals)))
 
     def scores(self, xs, xt):
         """max(thr,1e-6) - dist(src, dst), the value the reference fetches as
-        ``val_s_pos_predicts.outputs`` (cfl/utils.py:245)."""
+        ``val_s_pos_predicts.outputs`` (cfl/utils.py:245).  (xs, xt) dense device rows, or
+        (table, IndexStreams of 2 streams)."""
+        if isinstance(xt, H.IndexStreams):
+            ws = self._workspace(xt.n, 1)
+            return H.pair_scores_idx(self.shape, self.norm, xs, xt, self.theta, ws)
         ws = self._workspace(xs.shape[0], 1)
         return H.pair_scores(self.shape, self.norm, xs, xt, self.theta, ws)
 

@@ -46,7 +46,7 @@ class CflLayout(C.Structure):
 
 class CflNorm(C.Structure):
     _fields_ = [('mul', C.c_float), ('add', C.c_float), ('lo', C.c_float),
-                ('hi', C.c_float), ('has_lo', C.c_int32), ('has_hi', C.c_int32)]
+                ('hi', C.c_float), ('has_lo', C.c_int32), ('has_hi', C.c_int32), ('valid_cols', C.c_int32)]
 
 
 class CflLossCfg(C.Structure):
@@ -64,7 +64,8 @@ CONV_ACTS = {None: 0, 'linear': 0, 'lrelu': 1, 'relu': 2}
 EXPORTS = ('cfl_version', 'cfl_last_error', 'cfl_layout', 'cfl_workspace_bytes',
            'cfl_pair_scores', 'cfl_pair_step_fwd_bwd', 'cfl_pair_train_step', 'cfl_adam_tf',
            'cfl_gather_rows', 'cfl_profile_enable', 'cfl_profile_read', 'cfl_pair_input_grad',
-           'cfl_conv_workspace_bytes', 'cfl_conv2d_wn_fwd', 'cfl_conv2d_wn_bwd')
+           'cfl_conv_workspace_bytes', 'cfl_conv2d_wn_fwd', 'cfl_conv2d_wn_bwd',
+           'cfl_pair_scores_idx', 'cfl_pair_step_fwd_bwd_idx', 'cfl_pair_train_step_idx', 'cfl_reload_env')
 
 KERNEL_NAMES = ('colnorm', 'proj', 'mid', 'grad', 'finalize', 'adam', 'gather')
 K_COUNT = 8
@@ -107,6 +108,21 @@ def lib():
         C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_size_t,
         C.c_void_p]
     L.cfl_pair_train_step.restype = C.c_int
+    L.cfl_pair_scores_idx.argtypes = [
+        C.POINTER(CflShape), C.POINTER(CflNorm), C.c_void_p, C.c_int64, C.POINTER(C.c_void_p), C.c_int64,
+        C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    L.cfl_pair_scores_idx.restype = C.c_int
+    L.cfl_pair_step_fwd_bwd_idx.argtypes = [
+        C.POINTER(CflShape), C.POINTER(CflNorm), C.POINTER(CflLossCfg), C.c_void_p, C.c_int64,
+        C.POINTER(C.c_void_p), C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+        C.c_void_p]
+    L.cfl_pair_step_fwd_bwd_idx.restype = C.c_int
+    L.cfl_pair_train_step_idx.argtypes = [
+        C.POINTER(CflShape), C.POINTER(CflNorm), C.POINTER(CflLossCfg), C.c_void_p, C.c_int64,
+        C.POINTER(C.c_void_p), C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+        C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_size_t, C.c_void_p]
+    L.cfl_pair_train_step_idx.restype = C.c_int
+    L.cfl_reload_env.restype = C.c_int
     L.cfl_adam_tf.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                               C.c_int64, C.c_float, C.c_float, C.c_float,
                               C.c_float, C.c_float, C.c_void_p]
@@ -126,7 +142,7 @@ def lib():
     L.cfl_conv2d_wn_bwd.restype = C.c_int
     L.cfl_profile_enable.argtypes = [C.c_int]
     L.cfl_profile_read.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_int64)]
-    if L.cfl_version() != 1:
+    if L.cfl_version() != 2:
         raise CflHipError('libcfl_hip.so ABI version mismatch')
     _lib = L
     return L
@@ -145,10 +161,11 @@ def make_shape(D, L, K, dist_type='pcd', weight_norm=False, has_bias=True,
                     ACT_TYPES[act_type], int(bool(directed)))
 
 
-def make_norm(mul=1.0, add=0.0, lo=None, hi=None):
+def make_norm(mul=1.0, add=0.0, lo=None, hi=None, valid_cols=0):
+    """valid_cols: true feature width when the rows are zero-padded to a multiple of 64 (0 = no padding)."""
     return CflNorm(float(mul), float(add), float(lo if lo is not None else 0.0),
                    float(hi if hi is not None else 0.0), int(lo is not None),
-                   int(hi is not None))
+                   int(hi is not None), int(valid_cols))
 
 
 def make_loss(use_threshold=True, pos_weight=None, caffe_margin=None,
@@ -211,6 +228,66 @@ def pair_train_step(shape, norm, loss, x4, theta, m, v, grad, scalars, workspace
         C.byref(shape), C.byref(norm), C.byref(loss), arr, B, _dev(theta), _dev(m), _dev(v),
         _dev(grad), _dev(scalars), float(lr_t), float(beta1), float(beta2), float(eps),
         workspace.data_ptr(), workspace.numel() * workspace.element_size(), _stream()))
+
+
+class IndexStreams(object):
+    """The index side of an indexed call: `ptrs` = device addresses of the 2 (scoring) or 4 (training) int32 index
+    streams, `stride` in elements (2 walks one column of an [n, 2] pair array in place), `n` rows per stream.
+    `keep` holds the tensors the addresses point into."""
+
+    def __init__(self, ptrs, stride, n, keep=None):
+        self.arr = (C.c_void_p * len(ptrs))(*[int(p) for p in ptrs])
+        self.stride, self.n, self.keep = int(stride), int(n), keep
+
+    def pair(self, k):
+        """the 2 streams (src, dst) of pair group k of a 4-stream training batch (0 = positive, 1 = negative)"""
+        return IndexStreams([self.arr[2 * k], self.arr[2 * k + 1]], self.stride, self.n, keep=self.keep)
+
+    @classmethod
+    def from_tensors(cls, tensors):
+        """dense int32 device vectors, one per stream"""
+        for t in tensors:
+            _dev(t, torch.int32)
+        return cls([t.data_ptr() for t in tensors], 1, tensors[0].shape[0], keep=list(tensors))
+
+
+def _table(table):
+    _dev(table)
+    return table.data_ptr(), table.shape[0]
+
+
+def pair_scores_idx(shape, norm, table, streams, theta, workspace, scores=None, dists=None):
+    """pair_scores with rows src = table[idx0], dst = table[idx1] (cfl_pair_scores_idx)."""
+    if scores is None:
+        scores = torch.empty(streams.n, dtype=torch.float32, device=table.device)
+    tp, rows = _table(table)
+    _check(lib().cfl_pair_scores_idx(
+        C.byref(shape), C.byref(norm), tp, rows, streams.arr, streams.stride, streams.n, _dev(theta),
+        _dev(scores), _dev(dists) if dists is not None else None, workspace.data_ptr(),
+        workspace.numel() * workspace.element_size(), _stream()))
+    return scores
+
+
+def pair_step_fwd_bwd_idx(shape, norm, loss, table, streams, theta, grad, scalars, workspace):
+    tp, rows = _table(table)
+    _check(lib().cfl_pair_step_fwd_bwd_idx(
+        C.byref(shape), C.byref(norm), C.byref(loss), tp, rows, streams.arr, streams.stride, streams.n,
+        _dev(theta), _dev(grad), _dev(scalars), workspace.data_ptr(),
+        workspace.numel() * workspace.element_size(), _stream()))
+
+
+def pair_train_step_idx(shape, norm, loss, table, streams, theta, m, v, grad, scalars, workspace, lr_t, beta1,
+                        beta2, eps=1e-8):
+    tp, rows = _table(table)
+    _check(lib().cfl_pair_train_step_idx(
+        C.byref(shape), C.byref(norm), C.byref(loss), tp, rows, streams.arr, streams.stride, streams.n,
+        _dev(theta), _dev(m), _dev(v), _dev(grad), _dev(scalars), float(lr_t), float(beta1), float(beta2),
+        float(eps), workspace.data_ptr(), workspace.numel() * workspace.element_size(), _stream()))
+
+
+def reload_env():
+    """Re-read CFL_EXACT_FP32 / CFL_DEBUG_* (the launch plans are cached per process otherwise)."""
+    return lib().cfl_reload_env()
 
 
 def adam_tf(theta, m, v, grad, lr_t, beta1, beta2, eps=1e-8, grad_scale=1.0):

@@ -433,10 +433,16 @@ class SemiDataSet(object):
 
 
 class ResidentFeatures(object):
-    """The whole ``features.b`` of a split kept in HBM; batches are assembled on
-    the GPU with cfl_gather_rows from the index arrays of
-    ``SemiDataSet.next_batch_indices``.  The feature dimension
-    is zero-padded to a multiple of 64 for the kernels."""
+    """The whole ``features.b`` of a split kept in HBM, and the labeled pair lists beside it.
+
+    Replaces the reference's batch assembly (cfl/input_data.py:542-589: index pairs -> cfl/input_data.py:212-228: one
+    seek + read per vector) without materialising a batch at all: ``next_indexed`` advances the dataset's own seeded
+    index stream (``SemiDataSet.next_batch_indices``: the reference's RandomState call sequence, bit-exact) and
+    hands the training step the *positions* of the batch -- a window of the device copy of the (shuffled) pair
+    list, walked in place with stride 2 -- and the fused pair kernels read each feature row where it lies in the
+    table (cfl_pair_train_step_idx).  The pair lists are re-uploaded only when the dataset reshuffles them (once
+    per epoch).  ``next_batch`` still assembles dense batches with cfl_gather_rows for consumers that want them.
+    The feature dimension is zero-padded to a multiple of 64 for the kernels."""
 
     def __init__(self, dataset, device='cuda'):
         import torch
@@ -452,6 +458,9 @@ class ResidentFeatures(object):
         self.table = t.contiguous().to(device)
         self.device = self.table.device
         self.dataset = dataset
+        if self.table.shape[0] >= 2 ** 31:
+            raise ValueError('feature table too large for int32 row indices')
+        self._pairs = {}      # 'pos' / 'neg' -> (host array object that was uploaded, device int32 [n, 2])
 
     def gather(self, positions, out=None):
         import torch
@@ -469,3 +478,49 @@ class ResidentFeatures(object):
         c = (1, 0) if switched else (0, 1)
         return (self.gather(pos[:, c[0]]), self.gather(pos[:, c[1]]),
                 self.gather(neg[:, c[0]]), self.gather(neg[:, c[1]]))
+
+    def _device_pairs(self, which):
+        """int32 device copy of dataset.pairs_<which> in its CURRENT order (the dataset replaces the array object
+        when it reshuffles: cfl/input_data.py:543-551)."""
+        import torch
+        host = getattr(self.dataset, 'pairs_' + which)
+        cached = self._pairs.get(which)
+        if cached is None or cached[0] is not host:
+            dev = torch.from_numpy(np.ascontiguousarray(host, dtype=np.int32)).to(self.device)
+            cached = self._pairs[which] = (host, dev)
+        return cached[1]
+
+    def next_indexed(self, batch_size, shard=None):
+        """(table, IndexStreams) of the next labeled batch for PairEngine.step: no row is copied.  Same rows, same
+        order as ``next_batch``; ``shard`` as there."""
+        ds = self.dataset
+        pos, neg, switched = ds.next_batch_indices(batch_size)
+        lo, hi = shard if shard is not None else (0, batch_size)
+        c = (1, 0) if switched else (0, 1)
+        ptrs, keep = [], []
+        for which, rows in (('pos', pos), ('neg', neg)):
+            host = getattr(ds, 'pairs_' + which)
+            head = getattr(ds, 'head_labeled_' + which) - batch_size      # next_batch_indices has advanced it
+            if np.may_share_memory(rows, host):
+                dev = self._device_pairs(which)                         # window [head, head + B) of the pair list
+                base = dev.data_ptr() + 8 * (head + lo)
+            else:
+                # B > number of pairs: the reference oversamples with RandomState.choice (cfl/input_data.py:558-566);
+                # such a batch is not a window of the list -- upload its positions
+                import torch
+                dev = torch.from_numpy(np.ascontiguousarray(rows[lo:hi], dtype=np.int32)).to(self.device)
+                base = dev.data_ptr()
+            keep.append(dev)
+            ptrs += [base + 4 * c[0], base + 4 * c[1]]
+        return self.table, self._h.IndexStreams(ptrs, 2, hi - lo, keep=keep)
+
+    def whole_indexed(self, which, batch_size):
+        """(table, IndexStreams of (src, dst)) chunks over all pairs of pairs_<which> in file order, for scoring
+        (the whole_pos_batches / whole_neg_batches of cfl/utils.py:233-266)."""
+        import torch
+        host = getattr(self.dataset, 'pairs_' + which)
+        dev = torch.from_numpy(np.ascontiguousarray(host, dtype=np.int32)).to(self.device)
+        for i in range(0, host.shape[0], batch_size):
+            n = min(batch_size, host.shape[0] - i)
+            base = dev.data_ptr() + 8 * i
+            yield self.table, self._h.IndexStreams([base, base + 4], 2, n, keep=[dev])

@@ -32,6 +32,10 @@ class PairModel(object):
         self.input_size = int(input_size)
         self.padded_size = (self.input_size + 63) // 64 * 64
         self.device = torch.device(device if device is not None else 'cuda')
+        if norm is not None and self.padded_size != self.input_size:
+            # zero-padded feature columns must stay zero through a normaliser with a shift / lower clip
+            norm = H.make_norm(norm.mul, norm.add, norm.lo if norm.has_lo else None,
+                               norm.hi if norm.has_hi else None, valid_cols=self.input_size)
         rng = np.random.RandomState(seed)
         n_enc = 2 if directed else 1
         params = [self._init_params(rng, dist_type, weight_norm, has_bias, latent_size,
@@ -79,8 +83,17 @@ class PairModel(object):
         return t.contiguous()
 
     # -- the two entry points of the hot path ----------------------------------
+    @staticmethod
+    def is_indexed(batch):
+        """a (feature table, IndexStreams) batch of ResidentFeatures.next_indexed"""
+        return len(batch) == 2 and isinstance(batch[1], H.IndexStreams)
+
     def train_step(self, batch):
-        """One optimisation step on (pos_src, pos_dst, neg_src, neg_dst)."""
+        """One optimisation step on (pos_src, pos_dst, neg_src, neg_dst) -- dense rows, or the positions of the
+        rows in a resident feature table."""
+        if self.is_indexed(batch):
+            self.engine.step(batch)
+            return
         self.engine.step([self.to_device(b) for b in batch])
 
     def predict(self, src, dst):
@@ -90,6 +103,10 @@ class PairModel(object):
 
     def batch_accuracy(self, batch):
         """s_accuracy of a batch without training on it (the val_s_accuracy fetch)."""
+        if self.is_indexed(batch):
+            sp = self.engine.scores(batch[0], batch[1].pair(0))
+            sn = self.engine.scores(batch[0], batch[1].pair(1))
+            return 0.5 * float((sp > 0).float().mean() + (sn <= 0).float().mean())
         sp = self.engine.scores(self.to_device(batch[0]), self.to_device(batch[1]))
         sn = self.engine.scores(self.to_device(batch[2]), self.to_device(batch[3]))
         return 0.5 * float((sp > 0).float().mean() + (sn <= 0).float().mean())

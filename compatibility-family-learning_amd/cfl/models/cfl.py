@@ -139,10 +139,24 @@ class CFL(PairModel):
         tr = self.trunk_dst if side else self.trunk
         return tr.forward(self._pixels(x, True)).clone()   # a trunk reuses its activation buffers per row count
 
-    def gan_inputs(self, labeled, unl_src, unl_dst):
+    def _draws(self, draws):
+        """(z, eps, c) of one post-epoch iteration: z ~ N(0, z_stddev), eps ~ U[0,1), gate c ~ U{0..K-1}
+        (cfl/models/cfl.py:70-100, 535-546), or the caller's values (feeding the reference's z / eps / c
+        placeholders_with_default)."""
+        import torch
+        B = self.batch_size
+        if draws is not None:
+            z, eps, c = draws
+            return (self._dev(np.asarray(z, np.float32)), self._dev(np.asarray(eps, np.float32).reshape(B, 1)),
+                    torch.as_tensor(np.asarray(c), dtype=torch.int32, device=self.device))
+        c = torch.randint(0, self.num_components, (B,), generator=self._gen, device=self.device, dtype=torch.int32)
+        z = torch.randn(B, self.z_dim, generator=self._gen, device=self.device) * float(self.z_stddev)
+        eps = torch.rand(B, 1, generator=self._gen, device=self.device)
+        return z.contiguous(), eps, c
+
+    def gan_inputs(self, labeled, unl_src, unl_dst, draws=None):
         """Device inputs of GanPhase.step from one labeled batch and the unlabeled source / target item
-        batches (lists [x] or [image, latent]).  Draws z ~ N(0, z_stddev), eps ~ U[0,1), gate c ~ U{0..K-1}
-        (cfl/models/cfl.py:70-100, 535-546)."""
+        batches (lists [x] or [image, latent])."""
         import torch
         from .. import hipgan as G
         from .encoder_heads import FrozenHeads
@@ -154,16 +168,14 @@ class CFL(PairModel):
         lab = self.select_batch(labeled)
         dst_side = 1 if self.directed else 0
         real = self._ae_image(unl_dst[0])
-        c = torch.randint(0, self.num_components, (B,), generator=self._gen, device=self.device, dtype=torch.int32)
+        z, eps, c = self._draws(draws)
         enc_act = hd.activations(enc_in(unl_dst, dst_side), dst_side)
         prj_c = G.gather_prototype(hd.prototype_activations(enc_in(unl_src), 0), c)
         neg_c = G.gather_prototype(hd.prototype_activations(self._enc_rows(lab[2]), 0), c)
         neg_tgt_act = hd.activations(self._enc_rows(lab[3], dst_side), dst_side)
-        z = torch.randn(B, self.z_dim, generator=self._gen, device=self.device) * float(self.z_stddev)
-        eps = torch.rand(B, 1, generator=self._gen, device=self.device)
-        return real, enc_act, prj_c, neg_c, neg_tgt_act, z.contiguous(), eps
+        return real, enc_act, prj_c, neg_c, neg_tgt_act, z, eps
 
-    def cgan_inputs(self, labeled):
+    def cgan_inputs(self, labeled, draws=None):
         """Device inputs of GanPhase.step_cgan (cfl/models/cfl.py:747-782): positive / negative TARGET images
         and the source-side conditions -- the source encoder's activations, or with --t-dim the (normalised)
         source inputs themselves."""
@@ -177,9 +189,8 @@ class CFL(PairModel):
         per = 2 if len(labeled) == 8 else 1
         real_pos, real_neg = self._ae_image(labeled[1 * per]), self._ae_image(labeled[3 * per])
         cond = self._cgan_condition
-        z = torch.randn(B, self.z_dim, generator=self._gen, device=self.device) * float(self.z_stddev)
-        eps = torch.rand(B, 1, generator=self._gen, device=self.device)
-        return real_pos, real_neg, cond(lab[0]), cond(lab[2]), z.contiguous(), eps
+        z, eps, _ = self._draws(draws)
+        return real_pos, real_neg, cond(lab[0]), cond(lab[2]), z, eps
 
     def _cgan_condition(self, a):
         """pos_src / neg_src of cfl/models/cfl.py:748-749: the source encoder's activations, or with --t-dim the
@@ -191,11 +202,11 @@ class CFL(PairModel):
             return self._pixels(a, True)
         return hd.normalize(self.to_device(self._prep(a, True)))[:, :self.input_size].contiguous()
 
-    def post_step(self, labeled, unl_src=None, unl_dst=None):
+    def post_step(self, labeled, unl_src=None, unl_dst=None, draws=None):
         if self.cgan:
-            self.gan_phase.step_cgan(*self.cgan_inputs(labeled))
+            self.gan_phase.step_cgan(*self.cgan_inputs(labeled, draws))
         else:
-            self.gan_phase.step(*self.gan_inputs(labeled, unl_src, unl_dst))
+            self.gan_phase.step(*self.gan_inputs(labeled, unl_src, unl_dst, draws))
 
     # -- sampling (cfl/models/cfl.py:808-860: s_encoder_sample, g_target, g_prototypes, d_prototypes) --------
     def _sample_heads(self):
@@ -278,6 +289,8 @@ class CFL(PairModel):
         return self.trunk.normalize(t.to(self.device, torch.float32))
 
     def train_step(self, batch):
+        if self.is_indexed(batch):
+            return PairModel.train_step(self, batch)
         batch = self.select_batch(batch)
         if self.trunk is None:
             return PairModel.train_step(self, [self._prep(b, True) for b in batch])
@@ -309,7 +322,7 @@ class CFL(PairModel):
         trunks = [self.trunk, self.trunk_dst] if two else [self.trunk]
         if eng.world_size > 1:
             from ..engine import reduce_gradients
-            scale = reduce_gradients(eng.grad)
+            scale = eng._scalar_scale = reduce_gradients(eng.gradbuf)     # gradient + the step's scalars
             for tr in trunks:
                 reduce_gradients(tr.grad)
         for tr in trunks:
@@ -328,6 +341,8 @@ class CFL(PairModel):
         return self.engine.scores(F[:n], F[n:]).cpu().numpy().reshape(-1, 1)
 
     def batch_accuracy(self, batch):
+        if self.is_indexed(batch):
+            return PairModel.batch_accuracy(self, batch)
         batch = self.select_batch(batch)
         if self.trunk is None:
             return PairModel.batch_accuracy(self, [self._prep(b, False) for b in batch])
@@ -471,15 +486,15 @@ class CFL(PairModel):
         chief = dp.rank() == 0
 
         def next_train():
-            return resident[0].next_batch(self.batch_size, shard) if resident else data.train.next_batch(self.batch_size)
+            return resident[0].next_indexed(self.batch_size, shard) if resident else data.train.next_batch(self.batch_size)
 
         def next_val():
-            return resident[1].next_batch(self.batch_size) if resident else data.val.next_batch(self.batch_size)
+            return resident[1].next_indexed(self.batch_size) if resident else data.val.next_batch(self.batch_size)
         for e in range(start_epoch, total_epochs):
             t = trange(start_iter % nb_batch if e == start_epoch else 0, nb_batch, disable=not chief)
             if e >= epochs:
-                self._post_epoch(e, t, data, nb_batch, save_iters, saver, checkpoint_dir, writer)
-                if e % save_epochs == 0 and saver is not None:
+                self._post_epoch(e, t, data, nb_batch, save_iters, saver if chief else None, checkpoint_dir, writer)
+                if e % save_epochs == 0 and saver is not None and chief:
                     saver.save(self, os.path.join(checkpoint_dir, 'model'), global_step=(e + 1) * nb_batch)
                 continue
             t.set_description('epoch {}'.format(e))

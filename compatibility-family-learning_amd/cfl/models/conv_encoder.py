@@ -109,11 +109,18 @@ class ConvTrunk(object):
             dy = dx
 
     def apply_adam(self, lr_t, grad_scale=1.0):
+        if self.reg_const:
+            # s_loss_reg belongs to the weights the step was evaluated at: keep sum(V^2) of the pre-update filters
+            # on the device (no host sync here)
+            self._reg_sum = sum((self._view(seg, 'V') ** 2).sum() for seg in self.slices)
         H.adam_tf(self.theta, self.m, self.v, self.grad, lr_t, self.beta1, self.beta2, self.eps, grad_scale)
 
     def reg_loss(self):
         if not self.reg_const:
             return 0.0
+        cached = getattr(self, '_reg_sum', None)
+        if cached is not None:
+            return 0.5 * self.reg_const * float(cached)
         tot = 0.0
         for seg in self.slices:
             tot += float((self._view(seg, 'V') ** 2).sum())
@@ -129,6 +136,8 @@ class ConvTrunk(object):
         return out
 
     def load_named(self, named, base=None):
+        if base is None:
+            self._reg_sum = None
         for i, seg in enumerate(self.slices):
             scope = 'conv%d/Conv/' % (i + 1)
             for leaf, key in (('V', 'V'), ('g', 'g'), ('biases', 'b')):

@@ -54,6 +54,10 @@ class GanPhase(object):
             self.disc = Discriminator(gan_type, ae_shape, latent_size, rng, device, d_lr, d_beta1, d_beta2)
         self.scalars = torch.zeros(16, dtype=torch.float32, device=device)
         self.ae_size = int(np.prod(self.ae_shape))
+        # diagnostics: keep the (generator, discriminator) tapes of the last step alive (tests read the activation
+        # signs from them); off by default so that a step's activations are released when it returns
+        self.keep_tapes = False
+        self.last_tapes = None
 
     def generate(self, z, c):
         """Generator activations for display / sampling (cfl.bin.sample)."""
@@ -110,6 +114,8 @@ class GanPhase(object):
                            gl[2 * B:3 * B])
         d_img = disc.backward(d_tape, B, 4 * B, gd, gl, need_dx=True, need_dw=False)
         gen.backward(g_tape, d_img.contiguous())
+        if self.keep_tapes:
+            self.last_tapes = (g_tape, d_tape)
 
         if apply:
             disc.adam()

@@ -197,8 +197,8 @@ RESIDENT_EVAL_ROWS = 8192   # pairs per scoring launch when the split's features
 
 def _resident_scores(model, data, negative, device_result=False):
     """Vector datasets with a linear encoder: the split's features.b is uploaded once (cached on the dataset
-    object), pair rows are gathered on the GPU by index (cfl_gather_rows) and scored in large chunks -- the
-    same scores as the per-batch path, without one host-to-device copy of 2 x [batch, D] floats per batch.
+    object) and the scoring kernels read the pair rows in place by index (cfl_pair_scores_idx) in large chunks --
+    the same scores as the per-batch path, without one host-to-device copy of 2 x [batch, D] floats per batch.
     Returns None when the fast path does not apply (image data, conv encoder, models without an engine)."""
     if getattr(data, 'is_image', True) or getattr(model, 'trunk', None) is not None or not hasattr(model, 'engine'):
         return None
@@ -216,11 +216,8 @@ def _resident_scores(model, data, negative, device_result=False):
         res = data._resident = ResidentFeatures(data, model.device)
     if res.padded_size != model.padded_size:
         return None
-    pairs = data.pairs_neg if negative else data.pairs_pos
-    out = []
-    for i in range(0, pairs.shape[0], RESIDENT_EVAL_ROWS):
-        chunk = pairs[i:i + RESIDENT_EVAL_ROWS]
-        out.append(model.engine.scores(res.gather(chunk[:, 0]), res.gather(chunk[:, 1])))
+    out = [model.engine.scores(table, streams)
+           for table, streams in res.whole_indexed('neg' if negative else 'pos', RESIDENT_EVAL_ROWS)]
     if device_result:
         return torch.cat(out).contiguous() if out else None
     return torch.cat(out).cpu().numpy().astype(np.float32) if out else np.zeros(0, np.float32)
@@ -398,11 +395,38 @@ class Saver(object):
         self.max_to_keep = max_to_keep
         self._kept = []
 
+    @staticmethod
+    def _plain(obj):
+        """numpy arrays / scalars -> torch tensors / python numbers, so that the file holds nothing torch.load
+        needs to unpickle (it is read back with weights_only=True)"""
+        import torch
+        if isinstance(obj, dict):
+            return {k: Saver._plain(v) for k, v in obj.items()}
+        if isinstance(obj, (list, tuple)):
+            return [Saver._plain(v) for v in obj]
+        if isinstance(obj, np.ndarray):
+            return torch.from_numpy(np.ascontiguousarray(obj))
+        if isinstance(obj, np.generic):
+            return obj.item()
+        return obj
+
+    def _seed_kept(self, dirname):
+        """a saver created for a resumed run continues the directory's `checkpoint` list (tf.train.Saver recovers
+        it from the state file), so that old model-* files keep being pruned"""
+        state = os.path.join(dirname, 'checkpoint')
+        if self._kept or not os.path.exists(state):
+            return
+        with open(state) as f:
+            names = re.findall(r'all_model_checkpoint_paths:\s*"([^"]+)"', f.read())
+        self._kept = [os.path.join(dirname, os.path.basename(n)) for n in names
+                      if os.path.exists(os.path.join(dirname, os.path.basename(n)) + '.pt')]
+
     def save(self, model, save_path, global_step):
         import torch
         path = '{}-{}'.format(save_path, global_step)
         os.makedirs(os.path.dirname(path), exist_ok=True)
-        torch.save(model.checkpoint_state(), path + '.pt')
+        self._seed_kept(os.path.dirname(path))
+        torch.save(self._plain(model.checkpoint_state()), path + '.pt')
         self._kept = [p for p in self._kept if p != path] + [path]
         while len(self._kept) > self.max_to_keep:
             old = self._kept.pop(0)
@@ -417,7 +441,13 @@ class Saver(object):
 
     def restore(self, model, path):
         import torch
-        model.load_checkpoint_state(torch.load(path + '.pt', weights_only=False))
+        model.load_checkpoint_state(load_checkpoint_file(path + '.pt'))
+
+
+def load_checkpoint_file(path):
+    """A checkpoint as {'variables': {TF name: array}, 'adam_m', 'adam_v', ...}: tensors only, no pickled code."""
+    import torch
+    return torch.load(path, map_location='cpu', weights_only=True)
 
 
 def latest_checkpoint(checkpoint_dir):
@@ -453,8 +483,7 @@ def load_model(model, checkpoint_dir, load_pre_weights=None):
         last = latest_checkpoint(load_pre_weights)
         if not (best and last):
             raise Exception('must have best model! %s' % os.path.join(load_pre_weights, 'best_model'))
-        import torch
-        model.assign_trainable(torch.load(best + '.pt', weights_only=False), ignore_missing=True)
+        model.assign_trainable(load_checkpoint_file(best + '.pt'), ignore_missing=True)
         start_step = _step_of(last)
         logger.info('%s loaded', best)
     return saver, start_step

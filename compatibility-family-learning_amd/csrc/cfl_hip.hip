@@ -35,6 +35,7 @@
 //   Adam       tf.train.AdamOptimizer (TF-1.x), cfl/models/cfl.py:1077-1085
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -157,22 +158,41 @@ extern "C" int cfl_debug_clear_stamps(void) {
 struct NormDev {
     float mul, add, lo, hi;
     int elementwise;  // 1: x_hat = clip(x*mul+add) at load; 0: mul folded into the epilogue
+    int valid;        // feature columns >= valid are the zero padding up to a multiple of 64: they stay zero
 };
 
-__device__ __forceinline__ f32x4 norm_apply(f32x4 v, const NormDev &n) {
+// v = the four features of columns col .. col+3 of a row
+__device__ __forceinline__ f32x4 norm_apply(f32x4 v, const NormDev &n, int col) {
     if (n.elementwise) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = fminf(fmaxf(fmaf(v[i], n.mul, n.add), n.lo), n.hi);
+        for (int i = 0; i < 4; ++i)
+            v[i] = col + i < n.valid ? fminf(fmaxf(fmaf(v[i], n.mul, n.add), n.lo), n.hi) : 0.f;
     }
     return v;
 }
 
-__device__ __forceinline__ const float *row_ptr(const float *x0, const float *x1, int r, int B,
-                                                int R, int D) {
-    // rows [0,B) live in x0, rows [B,2B) in x1; rows >= R are clamped to a valid
-    // row (their products are never stored / are multiplied by zero dY).
+// Where the input rows of one side (src or dst) of a launch come from: two dense row blocks (rows [0,B) in x0,
+// rows [B,2B) in x1), or -- ix0 != nullptr -- rows of a resident feature table picked by two index streams
+// (ix0[r * istride] for r < B, ix1[(r-B) * istride] above; x0 == x1 == table).  The indexed form is what lets the
+// training loop feed the step straight from the HBM-resident features.b (no gather pass, no batch copy); a row is
+// 4*D contiguous bytes either way, so every access pattern of the kernels is unchanged.
+struct RowSrc {
+    const float *x0, *x1;
+    const int *ix0, *ix1;
+    int istride;
+    unsigned last_row;   // table rows - 1: indices are clamped (memory safety; valid indices are never changed)
+};
+
+__device__ __forceinline__ const float *row_ptr(const RowSrc &s, int r, int B, int R, int D) {
+    // rows >= R are clamped to a valid row (their products are never stored / are multiplied by zero dY).
     int rc = r < R ? r : R - 1;
-    return rc < B ? x0 + (size_t)rc * D : x1 + (size_t)(rc - B) * D;
+    if (s.ix0) {   // uniform
+        const int *ip = rc < B ? s.ix0 + (size_t)rc * s.istride : s.ix1 + (size_t)(rc - B) * s.istride;
+        unsigned t = (unsigned)*ip;
+        t = t < s.last_row ? t : s.last_row;
+        return s.x0 + (size_t)t * D;
+    }
+    return rc < B ? s.x0 + (size_t)rc * D : s.x1 + (size_t)(rc - B) * D;
 }
 
 __device__ __forceinline__ float wave_sum(float x) {
@@ -225,7 +245,7 @@ __device__ __forceinline__ void split_frag(const float (&v)[8], bf16x8 (&f)[3]) 
 //   The 4 partial tiles are summed through LDS in a fixed order.
 // ---------------------------------------------------------------------------
 struct ProjJob {
-    const float *x0, *x1;  // pair-group row blocks
+    int side;              // 0 = src rows, 1 = dst rows (ProjArgs::rows)
     const float *wf;       // Wf tile base: blocks [(nt)*G + g]
     float *ypart;          // chunk base (column offset applied) inside [S][Rpad][npad]
     long long sstride;     // floats between slices (Rpad * npad)
@@ -234,6 +254,7 @@ struct ProjJob {
 
 struct ProjArgs {
     ProjJob job[CFL_MAX_JOBS];
+    RowSrc rows[2];
     int B, R, Rpad, D, S;
     int xcd;  // 1: blockIdx.x enumerates the d slices (see cfl_xcd_aligned)
     NormDev norm;
@@ -263,7 +284,7 @@ __device__ __forceinline__ void proj_body(const ProjJob &jb, const ProjArgs &a, 
 
     const float *xrow[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) xrow[i] = row_ptr(jb.x0, jb.x1, row0 + 8 * i + rr8, a.B, a.R, a.D) + 4 * ch8;
+    for (int i = 0; i < 4; ++i) xrow[i] = row_ptr(a.rows[jb.side], row0 + 8 * i + rr8, a.B, a.R, a.D) + 4 * ch8;
     const float *wfl = jb.wf + lane * 4;
     f32x4 *tile = lds + wave * 256;  // 32 rows x 8 chunks of 16 B = 4 KiB per wave
     STAMP(0);
@@ -316,7 +337,7 @@ __device__ __forceinline__ void proj_body(const ProjJob &jb, const ProjArgs &a, 
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int row = 8 * i + rr8;
-                tile[row * 8 + (ch8 ^ (row & 7))] = norm_apply(araw[qq][i], a.norm);
+                tile[row * 8 + (ch8 ^ (row & 7))] = norm_apply(araw[qq][i], a.norm, g0 * 16 + qq * 32 + 4 * ch8);
             }
             f32x4 af[2][2];
 #pragma unroll
@@ -396,7 +417,7 @@ extern "C" __global__ __launch_bounds__(256) void cfl_proj_kernel(ProjArgs a) {
 //   z-slice 0 of the launch: row reductions (column sums of dYf etc.).
 // ---------------------------------------------------------------------------
 struct GradJob {
-    const float *x0, *x1;
+    int side;              // 0 = src rows, 1 = dst rows (GradArgs::rows)
     const float *dyf;      // dYf tile base: blocks [(nt)*RG + rg]
     float *wpart;          // Wf tile base inside slab 0; slabs are pstride apart
     long long pstride;     // floats between row-range slabs (npad * D)
@@ -415,6 +436,7 @@ struct RedRange {
 
 struct GradArgs {
     GradJob job[CFL_MAX_JOBS];
+    RowSrc rows[2];
     int B, R, Rpad, D, P;
     int tps;  // > 0: 64-d tiles per projection slice, tiles are dealt to XCDs by slice (cfl_xcd_aligned)
     NormDev norm;
@@ -466,14 +488,14 @@ __device__ __forceinline__ void grad_body(const GradJob &jb, const GradArgs &a, 
         for (int rg = 0; rg < 4; ++rg) {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                xa[rg][j] = *(const f32x4 *)(row_ptr(jb.x0, jb.x1, p0 + 16 * rg + 4 * kq + j, a.B, a.R, a.D) +
+                xa[rg][j] = *(const f32x4 *)(row_ptr(a.rows[jb.side], p0 + 16 * rg + 4 * kq + j, a.B, a.R, a.D) +
                                              dbase + 4 * i16);
             __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) xa[rg][j] = norm_apply(xa[rg][j], a.norm);
+            for (int j = 0; j < 4; ++j) xa[rg][j] = norm_apply(xa[rg][j], a.norm, dbase + 4 * i16);
 #ifndef ABL_GRAD_NOMFMA
 #pragma unroll
             for (int j = 0; j < 4; ++j)
@@ -624,6 +646,14 @@ __device__ __forceinline__ void grad_body_x3(const GradJob &jb, const GradArgs &
     const float *dyl = jb.dyf + ((size_t)(kq >> 1) * 256 + (2 * (kq & 1) * 16 + i16) * 4);
     for (int p0 = rbeg; p0 < rstop; p0 += 64) {
         f32x4 dyr[2][NT][2], xr[2][8];
+        // row addresses first: with an indexed source they start with a (cached, 4-byte) index load each, which
+        // is in flight together with the dY fragments instead of in front of the x loads
+        const float *xrow[2][8];
+#pragma unroll
+        for (int r2 = 0; r2 < 2; ++r2)
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj)
+                xrow[r2][jj] = row_ptr(a.rows[jb.side], p0 + 32 * r2 + 8 * kq + jj, a.B, a.R, a.D);
 #pragma unroll
         for (int r2 = 0; r2 < 2; ++r2)
 #pragma unroll
@@ -637,8 +667,7 @@ __device__ __forceinline__ void grad_body_x3(const GradJob &jb, const GradArgs &
         for (int r2 = 0; r2 < 2; ++r2) {
 #pragma unroll
             for (int jj = 0; jj < 8; ++jj)
-                xr[r2][jj] = *(const f32x4 *)(row_ptr(jb.x0, jb.x1, p0 + 32 * r2 + 8 * kq + jj, a.B, a.R, a.D) +
-                                              dbase + 4 * i16);
+                xr[r2][jj] = *(const f32x4 *)(xrow[r2][jj] + dbase + 4 * i16);
             __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
@@ -652,7 +681,7 @@ __device__ __forceinline__ void grad_body_x3(const GradJob &jb, const GradArgs &
                 split_frag(v, bf[nt]);
             }
 #pragma unroll
-            for (int jj = 0; jj < 8; ++jj) xr[r2][jj] = norm_apply(xr[r2][jj], a.norm);
+            for (int jj = 0; jj < 8; ++jj) xr[r2][jj] = norm_apply(xr[r2][jj], a.norm, dbase + 4 * i16);
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 float v[8];
@@ -2022,6 +2051,8 @@ struct Plan {
     // workspace offsets (floats)
     size_t ypart[2], dyf[2], cwf[2], wpart[2];
     bool x3;   // bf16x3 matrix-core path for the weight gradient
+    bool xcd;  // XCD-aligned launch order of proj / grad (cfl_xcd_aligned)
+    int mid_generic, mid_norow;   // debug overrides of the mid kernel choice
     size_t mono_ya, mono_du, mono_duc, rowqf, thr_copy, colsum, regpart, n2, total_floats;
     size_t mid_lds;
     int ys;
@@ -2093,6 +2124,9 @@ static int make_plan(const CflShape *s, int64_t rows, int groups, bool train, Pl
     if (S > 16) S = 16;
     if (debug_env("CFL_DEBUG_S") > 0) S = debug_env("CFL_DEBUG_S");
     pl->S = S;
+    pl->xcd = cfl_xcd_aligned(S, s->D / 64);
+    pl->mid_generic = debug_env("CFL_DEBUG_MID_GENERIC") > 0;
+    pl->mid_norow = debug_env("CFL_DEBUG_MID_NOROW") != 0;
     pl->nrb = pl->Rpad / MID_RB;
     pl->kpad = pl->lay.enc[0].mono.npad;
     pl->lpad = (int)round_up(s->L, 16);
@@ -2155,6 +2189,7 @@ static NormDev make_norm(const CflNorm *n, float *in_mul) {
     d.lo = (n && n->has_lo) ? n->lo : -INFINITY;
     d.hi = (n && n->has_hi) ? n->hi : INFINITY;
     d.elementwise = n && (n->add != 0.f || n->has_lo || n->has_hi);
+    d.valid = (n && n->valid_cols > 0) ? n->valid_cols : 0x7fffffff;
     *in_mul = d.elementwise ? 1.f : d.mul;
     return d;
 }
@@ -2204,13 +2239,43 @@ struct SideRt {
 
 struct AdamFuse { float *theta, *m, *v; float lr_t, b1, b2, eps; };
 
+// Indexed row source of a call (cfl_pair_*_idx): rows of `table` picked by 2 * groups index streams.
+struct IndexSrc { const float *table; int64_t table_rows; const int32_t *const *idx; int64_t stride; };
+
+// The plan of a (shape, rows, groups, train) combination never changes within a process (the tuning overrides
+// are read from the environment once per combination): a training loop re-plans nothing per step.
+static std::atomic<int> g_env_generation{0};
+extern "C" int cfl_reload_env(void) { return ++g_env_generation; }
+
+static int cached_plan(const CflShape *s, int64_t rows, int groups, bool train, Plan *out) {
+    struct Entry { CflShape s; int64_t rows; int groups; bool train; Plan pl; };
+    static thread_local std::vector<Entry> cache;
+    static thread_local int seen_generation = 0;
+    if (seen_generation != g_env_generation.load()) {
+        cache.clear();
+        seen_generation = g_env_generation.load();
+    }
+    for (const Entry &e : cache)
+        if (e.rows == rows && e.groups == groups && e.train == train && memcmp(&e.s, s, sizeof(CflShape)) == 0) {
+            *out = e.pl;
+            return CFL_OK;
+        }
+    if (!s) return set_err(CFL_E_SHAPE, "shape is NULL");
+    int rc = make_plan(s, rows, groups, train, out);
+    if (rc) return rc;
+    if (cache.size() >= 64) cache.erase(cache.begin());
+    cache.push_back({*s, rows, groups, train, *out});
+    return CFL_OK;
+}
+
 static int run_pairs(const CflShape *s, const CflNorm *norm, const CflLossCfg *loss,
                      const float *const *x, int groups, int64_t rows, const float *theta,
                      float *grad, float *scalars, float *scores, float *dists, void *workspace,
-                     size_t workspace_bytes, hipStream_t st, const AdamFuse *adam = nullptr) {
+                     size_t workspace_bytes, hipStream_t st, const AdamFuse *adam = nullptr,
+                     const IndexSrc *isrc = nullptr) {
     const bool train = grad != nullptr;
     Plan pl;
-    int rc = make_plan(s, rows, groups, train, &pl);
+    int rc = cached_plan(s, rows, groups, train, &pl);
     if (rc) return rc;
     if (!theta || !workspace) return set_err(CFL_E_SHAPE, "NULL theta/workspace");
     if (workspace_bytes < pl.total_floats * sizeof(float))
@@ -2218,8 +2283,19 @@ static int run_pairs(const CflShape *s, const CflNorm *norm, const CflLossCfg *l
                        pl.total_floats * sizeof(float));
     if (((uintptr_t)workspace & 15) || ((uintptr_t)theta & 15))
         return set_err(CFL_E_SHAPE, "theta / workspace must be 16-byte aligned");
-    for (int i = 0; i < 2 * groups; ++i)
-        if (!x[i] || ((uintptr_t)x[i] & 15)) return set_err(CFL_E_SHAPE, "input %d NULL or misaligned", i);
+    if (isrc) {
+        if (!isrc->table || ((uintptr_t)isrc->table & 15) || isrc->table_rows <= 0 || isrc->table_rows >= (1ll << 31))
+            return set_err(CFL_E_SHAPE, "feature table NULL / misaligned / row count %lld out of range",
+                           (long long)isrc->table_rows);
+        if (!isrc->idx || isrc->stride <= 0 || isrc->stride > (1 << 20))
+            return set_err(CFL_E_SHAPE, "index streams NULL or stride %lld out of range", (long long)isrc->stride);
+        for (int i = 0; i < 2 * groups; ++i)
+            if (!isrc->idx[i] || ((uintptr_t)isrc->idx[i] & 3))
+                return set_err(CFL_E_SHAPE, "index stream %d NULL or misaligned", i);
+    } else {
+        for (int i = 0; i < 2 * groups; ++i)
+            if (!x[i] || ((uintptr_t)x[i] & 15)) return set_err(CFL_E_SHAPE, "input %d NULL or misaligned", i);
+    }
     float *ws = (float *)workspace;
     float in_mul;
     NormDev nd = make_norm(norm, &in_mul);
@@ -2233,10 +2309,20 @@ static int run_pairs(const CflShape *s, const CflNorm *norm, const CflLossCfg *l
         default: side[0] = {&pl.lay.enc[0].outputs, 0, 0}; side[1] = {&pl.lay.enc[1].outputs, 1, 0}; break;
     }
     // x layout: train: pos_src,pos_dst,neg_src,neg_dst ; score: src,dst
-    const float *xs[2][2];
+    RowSrc rsrc[2];
     for (int sd = 0; sd < 2; ++sd) {
-        xs[sd][0] = x[sd];
-        xs[sd][1] = groups == 2 ? x[2 + sd] : x[sd];
+        RowSrc &r = rsrc[sd];
+        memset(&r, 0, sizeof(r));
+        if (isrc) {
+            r.x0 = r.x1 = isrc->table;
+            r.ix0 = isrc->idx[sd];
+            r.ix1 = groups == 2 ? isrc->idx[2 + sd] : isrc->idx[sd];
+            r.istride = (int)isrc->stride;
+            r.last_row = (unsigned)(isrc->table_rows - 1);
+        } else {
+            r.x0 = x[sd];
+            r.x1 = groups == 2 ? x[2 + sd] : x[sd];
+        }
     }
 
     int n2_off[2][3] = {{-1, -1, -1}, {-1, -1, -1}};
@@ -2254,7 +2340,7 @@ static int run_pairs(const CflShape *s, const CflNorm *norm, const CflLossCfg *l
             const int tiles = h->npad / 16;
             for (int c0 = 0; c0 < tiles; c0 += 4) {
                 ProjJob &j = pa.job[nj++];
-                j.x0 = xs[sd][0]; j.x1 = xs[sd][1];
+                j.side = sd;
                 j.wf = theta + h->w + (size_t)c0 * G * 256;
                 j.ypart = ws + pl.ypart[sd] + (size_t)c0 * 16;
                 j.sstride = (long long)h->npad * rp;
@@ -2262,8 +2348,9 @@ static int run_pairs(const CflShape *s, const CflNorm *norm, const CflLossCfg *l
                 j.npad = h->npad;
             }
         }
+        pa.rows[0] = rsrc[0]; pa.rows[1] = rsrc[1];
         pa.B = (int)rows; pa.R = pl.R; pa.Rpad = pl.Rpad; pa.D = s->D; pa.S = pl.S; pa.norm = nd;
-        pa.xcd = cfl_xcd_aligned(pl.S, s->D / 64);
+        pa.xcd = pl.xcd;
         dim3 grid((pl.R + 31) / 32, pl.S, nj);
         if (pa.xcd) grid = dim3(pl.S, (pl.R + 31) / 32, nj);
         ProfScope ps(st, CFL_K_PROJ);
@@ -2387,11 +2474,11 @@ static int run_pairs(const CflShape *s, const CflNorm *norm, const CflLossCfg *l
     {
         ProfScope ps(st, CFL_K_MID);
         const dim3 mgrid(ma.nrb + nreg_blocks), mblk(64);
-        const bool generic_only = debug_env("CFL_DEBUG_MID_GENERIC") > 0;
+        const bool generic_only = pl.mid_generic != 0;
         // one wave per row: pcd (any K <= 64) and siamese with up to 256 padded columns per side
         const int wide = side[0].head->npad > side[1].head->npad ? side[0].head->npad : side[1].head->npad;
         const bool row_ok = (s->dist_type == CFL_DIST_PCD || s->dist_type == CFL_DIST_SIAMESE) && wide <= 256 &&
-                            s->K <= 64 && debug_env("CFL_DEBUG_MID_NOROW") == 0;
+                            s->K <= 64 && !pl.mid_norow;
         const dim3 rgrid(ma.nrb + nreg_blocks);
         if (!generic_only && row_ok && wide <= 64)
             hipLaunchKernelGGL((cfl_mid_row_kernel<1>), rgrid, dim3(256), 4 * 6 * 64 * sizeof(float), st, ma);
@@ -2423,13 +2510,14 @@ static int run_pairs(const CflShape *s, const CflNorm *norm, const CflLossCfg *l
             const int tiles = h->npad / 16;
             for (int c0 = 0; c0 < tiles; c0 += 4) {
                 GradJob &j = ga.job[nj++];
-                j.x0 = xs[sd][0]; j.x1 = xs[sd][1];
+                j.side = sd;
                 j.dyf = ws + pl.dyf[sd] + (size_t)c0 * RG * 256;
                 j.wpart = ws + pl.wpart[sd] + (size_t)c0 * G * 256;
                 j.pstride = (long long)h->npad * s->D;
                 j.nt = tiles - c0 < 4 ? tiles - c0 : 4;
             }
         }
+        ga.rows[0] = rsrc[0]; ga.rows[1] = rsrc[1];
         ga.B = (int)rows; ga.R = pl.R; ga.Rpad = pl.Rpad; ga.D = s->D; ga.P = pl.P; ga.norm = nd;
         int nr = 0, tot = 0;
         auto red = [&](int kind, const float *A, const float *B, int count, int out) -> RedRange & {
@@ -2453,7 +2541,7 @@ static int run_pairs(const CflShape *s, const CflNorm *norm, const CflLossCfg *l
             }
         }
         ga.nred = nr; ga.red_total = tot; ga.colsum = ws + pl.colsum;
-        ga.tps = cfl_xcd_aligned(pl.S, s->D / 64) ? (s->D / 64) / pl.S : 0;
+        ga.tps = pl.xcd ? (s->D / 64) / pl.S : 0;
         dim3 grid(s->D / 64, pl.P, nj + 1);
         ProfScope ps(st, CFL_K_GRAD);
         if (pl.x3)
@@ -2522,6 +2610,49 @@ extern "C" int cfl_pair_train_step(const CflShape *shape, const CflNorm *norm,
     AdamFuse af = {theta, m, v, lr_t, beta1, beta2, eps};
     return run_pairs(shape, norm, loss, x4, 2, B, theta, grad, scalars, nullptr, nullptr, workspace,
                      workspace_bytes, (hipStream_t)stream, &af);
+}
+
+static int check_train_args(const CflLossCfg *loss, const void *grad, const void *scalars) {
+    if (!loss || !grad || !scalars) return set_err(CFL_E_SHAPE, "NULL loss/grad/scalars");
+    if (loss->caffe_margin != 0.f && loss->lambda_m != 0.f)
+        return set_err(CFL_E_SHAPE, "caffe_margin and lambda_m are exclusive (cfl/utils.py:72-73)");
+    return CFL_OK;
+}
+
+extern "C" int cfl_pair_scores_idx(const CflShape *shape, const CflNorm *norm, const float *table,
+                                   int64_t table_rows, const int32_t *const idx2[2], int64_t idx_stride, int64_t n,
+                                   const float *theta, float *scores, float *dists, void *workspace,
+                                   size_t workspace_bytes, cfl_stream_t stream) {
+    if (!scores) return set_err(CFL_E_SHAPE, "scores is NULL");
+    IndexSrc is = {table, table_rows, idx2, idx_stride};
+    return run_pairs(shape, norm, nullptr, nullptr, 1, n, theta, nullptr, nullptr, scores, dists, workspace,
+                     workspace_bytes, (hipStream_t)stream, nullptr, &is);
+}
+
+extern "C" int cfl_pair_step_fwd_bwd_idx(const CflShape *shape, const CflNorm *norm, const CflLossCfg *loss,
+                                         const float *table, int64_t table_rows, const int32_t *const idx4[4],
+                                         int64_t idx_stride, int64_t B, const float *theta, float *grad,
+                                         float *scalars, void *workspace, size_t workspace_bytes,
+                                         cfl_stream_t stream) {
+    int rc = check_train_args(loss, grad, scalars);
+    if (rc) return rc;
+    IndexSrc is = {table, table_rows, idx4, idx_stride};
+    return run_pairs(shape, norm, loss, nullptr, 2, B, theta, grad, scalars, nullptr, nullptr, workspace,
+                     workspace_bytes, (hipStream_t)stream, nullptr, &is);
+}
+
+extern "C" int cfl_pair_train_step_idx(const CflShape *shape, const CflNorm *norm, const CflLossCfg *loss,
+                                       const float *table, int64_t table_rows, const int32_t *const idx4[4],
+                                       int64_t idx_stride, int64_t B, float *theta, float *m, float *v,
+                                       float *grad, float *scalars, float lr_t, float beta1, float beta2,
+                                       float eps, void *workspace, size_t workspace_bytes, cfl_stream_t stream) {
+    int rc = check_train_args(loss, grad, scalars);
+    if (rc) return rc;
+    if (!m || !v) return set_err(CFL_E_SHAPE, "NULL Adam slots");
+    AdamFuse af = {theta, m, v, lr_t, beta1, beta2, eps};
+    IndexSrc is = {table, table_rows, idx4, idx_stride};
+    return run_pairs(shape, norm, loss, nullptr, 2, B, theta, grad, scalars, nullptr, nullptr, workspace,
+                     workspace_bytes, (hipStream_t)stream, &af, &is);
 }
 
 // ---- input gradient of the two heads (needed when the pair rows are not leaves: ConvPCD) --

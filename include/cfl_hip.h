@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define CFL_ABI_VERSION 1
+#define CFL_ABI_VERSION 2
 
 /* error codes */
 #define CFL_OK 0
@@ -116,6 +116,9 @@ typedef struct {
     float hi;        /* used iff has_hi */
     int32_t has_lo;
     int32_t has_hi;
+    int32_t valid_cols; /* > 0: the input rows carry only this many features, zero-padded to CflShape.D (a multiple
+                         * of 64); the pad columns stay zero after the map (they must not pick up `add` or a positive
+                         * `lo`, or the zero weight rows under them would start to train).  0 = every column is data */
 } CflNorm;
 
 /* Loss of cfl/models/cfl.py:868-949 / cfl/models/dist.py:253-284.             */
@@ -190,6 +193,31 @@ int cfl_pair_train_step(const CflShape *shape, const CflNorm *norm,
                         float *theta, float *m, float *v, float *grad, float *scalars,
                         float lr_t, float beta1, float beta2, float eps,
                         void *workspace, size_t workspace_bytes, cfl_stream_t stream);
+
+/* The same three entry points fed from a RESIDENT FEATURE TABLE instead of dense batches: row r of input stream k
+ * is table[idx[k][r * idx_stride], :].  Replaces the batch assembly of cfl/input_data.py:542-589 + 212-228 (index
+ * pairs -> one seek + read per vector) together with the step: features.b stays in HBM, the training loop hands
+ * over the index pairs only (idx_stride = 2 walks one column of an int32 [n, 2] pair array in place), and the
+ * kernels read each 4*D-byte row where it lies -- no gather pass, no batch copy.
+ *   table  : dev [table_rows, D] row-major fp32, 16-byte aligned;  idx[k] : dev int32, 4-byte aligned, entries in
+ *            [0, table_rows) (larger values are clamped to the last row);  stream order as x4 / (xs, xt).      */
+int cfl_pair_scores_idx(const CflShape *shape, const CflNorm *norm, const float *table, int64_t table_rows,
+                        const int32_t *const idx2[2], int64_t idx_stride, int64_t n, const float *theta,
+                        float *scores, float *dists, void *workspace, size_t workspace_bytes,
+                        cfl_stream_t stream);
+int cfl_pair_step_fwd_bwd_idx(const CflShape *shape, const CflNorm *norm, const CflLossCfg *loss,
+                              const float *table, int64_t table_rows, const int32_t *const idx4[4],
+                              int64_t idx_stride, int64_t B, const float *theta, float *grad, float *scalars,
+                              void *workspace, size_t workspace_bytes, cfl_stream_t stream);
+int cfl_pair_train_step_idx(const CflShape *shape, const CflNorm *norm, const CflLossCfg *loss,
+                            const float *table, int64_t table_rows, const int32_t *const idx4[4],
+                            int64_t idx_stride, int64_t B, float *theta, float *m, float *v, float *grad,
+                            float *scalars, float lr_t, float beta1, float beta2, float eps, void *workspace,
+                            size_t workspace_bytes, cfl_stream_t stream);
+
+/* The launch plan of a (shape, rows, groups) combination is computed once per process and thread; the tuning /
+ * diagnostic overrides it reads from the environment (CFL_EXACT_FP32, CFL_DEBUG_*) are re-read after this call. */
+int cfl_reload_env(void);
 
 /* TF-1.x AdamOptimizer apply over a flat array:
  *   m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ; theta -= lr_t m / (sqrt(v)+eps)

@@ -23,8 +23,24 @@ import torch
 import torch.nn.functional as F
 
 
+# Test hook: when set, every kinked activation of the oracles is evaluated as `x * slope` with the slope
+# pattern supplied by the hook (called as MASK_HOOK(kind, x) -> bool mask of x's shape, in call order) instead of
+# the sign of the oracle's own float64 pre-activation.  tests/test_activation_masks_gpu.py feeds the masks of the
+# fp32 HIP run, which makes oracle and HIP the SAME locally-linear function.
+MASK_HOOK = None
+
+
 def lrelu(x, leak=0.2):
+    if MASK_HOOK is not None:
+        m = MASK_HOOK('lrelu', x)
+        return x * torch.where(m, torch.ones_like(x), torch.full_like(x, leak))
     return torch.relu(x) - leak * torch.relu(-x)
+
+
+def relu(x):
+    if MASK_HOOK is not None:
+        return x * MASK_HOOK('relu', x).to(x.dtype)
+    return torch.relu(x)
 
 
 def same_pads(n, k, s):
@@ -54,7 +70,7 @@ def conv2d_weight_norm(x, V, g, b, stride, activation=None):
     if activation == 'lrelu':
         y = lrelu(y)
     elif activation == 'relu':
-        y = torch.relu(y)
+        y = relu(y)
     return y
 
 
@@ -63,7 +79,7 @@ def conv2d_subpixel(x, scale=2, activation=None):
     B, H, W, C = x.shape
     co = C // (scale * scale)
     y = x.reshape(B, H, W, scale, scale, co).permute(0, 1, 3, 2, 4, 5).reshape(B, H * scale, W * scale, co)
-    return torch.relu(y) if activation == 'relu' else y
+    return relu(y) if activation == 'relu' else y
 
 
 def xavier(rng, shape, fan_in, fan_out):

@@ -45,7 +45,7 @@ def fc_wn(x, V, g, b, act=None):
     if act == 'lrelu':
         y = CO.lrelu(y)
     elif act == 'relu':
-        y = torch.relu(y)
+        y = CO.relu(y)
     return y
 
 
@@ -66,7 +66,7 @@ def conv2d_transpose_weight_norm(x, V, g, b, stride, activation=None):
     if b is not None:
         y = y + b
     if activation == 'relu':
-        y = torch.relu(y)
+        y = CO.relu(y)
     return y
 
 

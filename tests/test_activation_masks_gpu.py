@@ -1,0 +1,161 @@
+"""Why the conv / GAN trajectories are held to looser tolerances than the pair step -- shown, not asserted.
+
+The conv stacks contain kinked activations (lrelu, relu).  An fp32 run and the float64 oracle evaluate the
+same pre-activations to ~1e-7 relative, so every step a handful of near-zero pre-activations end up on
+different sides of the kink; from then on the two runs are (slightly) different piecewise-linear functions and
+Adam's lr-sized first steps amplify that.  Here the oracle is forced onto the fp32 run's side of every kink
+(oracle/conv_oracle.py MASK_HOOK: slope patterns taken from the HIP activations): with the masks held equal the
+SAME kernels and the SAME Adam hold the north star's 1e-5 over the steps where the free-running comparison needs
+5e-4 (tests/test_conv_gpu.py) / 2e-3 (tests/test_gan_gpu.py).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import cfl_oracle as O
+from oracle import conv_oracle as CO
+from oracle import gan_oracle as GO
+
+pytestmark = pytest.mark.gpu
+
+
+class MaskFeeder(object):
+    """hands the oracle the HIP run's slope patterns, in the oracle's call order"""
+
+    def __init__(self):
+        self.queue = []
+
+    def push(self, kind, act):
+        self.queue.append((kind, (act > 0).cpu()))
+
+    def __call__(self, kind, x):
+        assert self.queue, 'oracle evaluated more kinked activations than the HIP tape holds'
+        k, m = self.queue.pop(0)
+        assert k == kind and m.numel() == x.numel(), (k, kind, tuple(m.shape), tuple(x.shape))
+        return m.reshape(x.shape)
+
+    def __enter__(self):
+        CO.MASK_HOOK = self
+        return self
+
+    def __exit__(self, *a):
+        CO.MASK_HOOK = None
+        left = len(self.queue)
+        self.queue = []
+        if a[0] is None:
+            assert left == 0, '%d masks were not consumed' % left
+
+
+def test_convpcd_trajectory_holds_1e5_with_equal_masks():
+    """BASELINE config 0 shape (28x28x1 conv encoder, PCD K=1, latent 30, sigmoid data, reg 5e-4), 8 steps."""
+    import tests.test_oracle as TO
+    from cfl import ops
+    from cfl.models.cfl import construct_model
+    rng = np.random.RandomState(4)
+    B, shape, L, K, reg, steps = 12, (28, 28, 1), 30, 1, 5e-4, 8
+    dn = ops.dist_normalizer(shape, None, None, None, None, None, 'sigmoid')
+    kw = dict(is_double=False, disable_double=False, latent_shape=None, source_shape=None, input_shape=shape,
+              ae_shape=None, batch_size=B, data_norm=None, data_type='sigmoid', model_type='conv',
+              gan_type='conv', num_components=K, latent_size=L, pos_weight=None, caffe_margin=None, gan=False,
+              cgan=False, t_dim=None, dist_type='pcd', act_type=None, use_threshold=True, lr=1e-3, beta1=0.9,
+              beta2=0.999, z_dim=20, z_stddev=1., g_dim=64, g_lr=2e-4, g_beta1=.5, g_beta2=.999, m_prj=None,
+              m_enc=None, d_dim=64, d_lr=2e-4, d_beta1=.5, d_beta2=.999, lambda_dra=.5, lambda_gp=None,
+              lambda_m=0.0, directed=False, data_directed=False, reg_const=reg, data_normalizer=dn[0],
+              data_unnormalizer=dn[1], seed=2)
+    model, _ = construct_model(**kw)
+    model.engine.theta[model.engine.layout.thr] = 0.3
+    hp, _, thr = model.engine.named_variables()
+    cfg = O.EncoderCfg(D=6272, L=L, K=K, dist_type='pcd', style='cfl')
+    params = {'head/' + k: v.astype(np.float64) for k, v in hp.items()}
+    for k, v in model.trunk.named().items():
+        params['conv/' + k] = v.astype(np.float64)
+    params['thr'] = np.float64(thr)
+    adam = O.AdamState(1e-3)
+    lcfg = O.LossCfg(reg_const=reg)
+    series = []
+    for step in range(steps):
+        batch = tuple(rng.rand(B, 784).astype(np.float32) * 1.2 - 0.1 for _ in range(4))
+        model.train_step(batch)
+        got = model.scalars()['total']
+        acts = model.trunk._inputs[1:]                       # post-lrelu, rows [pos_src | neg_src | pos_dst | neg_dst]
+        with MaskFeeder() as mf:
+            for part in (0, 2, 1, 3):                        # oracle order: pos_src, pos_dst, neg_src, neg_dst
+                for a in acts:
+                    mf.push('lrelu', a[part * B:(part + 1) * B])
+            tp = {k: torch.tensor(v, requires_grad=True) for k, v in params.items()}
+            cp = {k.split('/', 1)[1].replace('/Conv/', '/').replace('biases', 'b'): v
+                  for k, v in tp.items() if k.startswith('conv/')}
+            feats = [CO.convpcd_features(torch.clamp(torch.tensor(b, dtype=torch.float64), 0., 1.), shape, cp)
+                     for b in batch]
+            head = {k.split('/', 1)[1]: v for k, v in tp.items() if k.startswith('head/')}
+            total, _, _ = TO._torch_forward(cfg, lcfg, head, tp['thr'], tuple(feats))
+            total = total + sum(0.5 * reg * (v * v).sum() for k, v in cp.items() if k.endswith('/V'))
+            total.backward()
+        ref = float(total.detach())
+        series.append(abs(got - ref) / max(1.0, abs(ref)))
+        adam.apply(params, {k: (v.grad.numpy() if v.grad is not None else np.zeros_like(params[k]))
+                            for k, v in tp.items()})
+    assert max(series) <= 1e-5, ['%.1e' % e for e in series]
+    # and the weights: Adam moves every entry by ~lr per step whatever the size of its gradient, so entries whose
+    # gradient is at the fp32 noise level are excluded by a fraction, not by a loose bound
+    hp, _, thr = model.engine.named_variables()
+    for got, ref, k in [(v, params['head/' + k], k) for k, v in hp.items()] + \
+                       [(v, params['conv/' + k], k) for k, v in model.trunk.named().items()]:
+        d = np.abs(got - ref)
+        assert (d <= 2e-5 * max(1.0, np.abs(ref).max())).mean() >= 0.99, (k, float(d.max()))
+
+
+def _gan_masks(mf, ph, B, gan_type, lambda_gp):
+    """queue the masks of one recorded GanPhase.step in the order oracle/gan_oracle.py gan_losses evaluates them:
+    G(enc), G(neg), G(prj) -- HIP rows [g | g_prj | g_neg] -- then D(real), D(g), D(g_prj), D(g_neg)[, D(X_hat)]"""
+    g_tape, (d_tape, _) = ph.last_tapes
+    for blk in (0, 2, 1):
+        rows = slice(blk * B, (blk + 1) * B)
+        for item in g_tape:
+            if item[0] == 'layer' and item[1].act == 'relu':
+                mf.push('relu', item[3][rows])
+            elif item[0] == 'subpixel' and item[1] == 'relu':
+                mf.push('relu', item[2][rows])
+    for blk in range(5 if lambda_gp else 4):
+        rows = slice(blk * B, (blk + 1) * B)
+        for item in d_tape:
+            if item[0] == 'conv':
+                if item[1].act == 'lrelu':
+                    mf.push('lrelu', item[3][rows])
+            elif item[0] == 'res':
+                mf.push('lrelu', item[4][rows])              # r1 = lrelu(conv a)
+                mf.push('lrelu', item[6][rows])              # out = lrelu(r2 + h)
+
+
+@pytest.mark.parametrize('gan_type,shape,m_enc,m_prj,lambda_gp', [
+    ('srgan', (16, 16, 3), 0.05, 0.2, 0.5),
+    ('conv', (16, 16, 1), None, None, 0.5),
+])
+def test_gan_step_trajectory_holds_with_equal_masks(gan_type, shape, m_enc, m_prj, lambda_gp):
+    """the shapes / seeds of tests/test_gan_gpu.py::test_post_epoch_step_matches_oracle (which needs 2e-3 after
+    step 0): with equal masks every loss part of every step is within 2e-5"""
+    from cfl.models import mrcgan as M
+    B, Ld, zd, steps = 4, 6, 5, 4
+    o = GO.GanOracle(gan_type, shape, 'tanh', zd, Ld, seed=1, m_enc=m_enc, m_prj=m_prj, lambda_gp=lambda_gp)
+    ph = M.GanPhase(gan_type, shape, 'tanh', zd, Ld, B, torch.device('cuda'), np.random.RandomState(0),
+                    lambda_gp=lambda_gp, lambda_dra=0.5, m_enc=m_enc, m_prj=m_prj)
+    ph.keep_tapes = True
+    for net, ref, pre in ((ph.gen, o.gp, 'Generator/'), (ph.disc, o.dp, 'Discriminator/')):
+        net.pool.load({pre + k: v.numpy() for k, v in ref.items()})
+    rng = np.random.RandomState(5)
+    N = int(np.prod(shape))
+    dev = lambda a: torch.tensor(np.asarray(a, np.float32), device='cuda')
+    worst = {}
+    for it in range(steps):
+        batch = [np.tanh(rng.randn(B, N)), 0.3 * rng.randn(B, Ld), 0.3 * rng.randn(B, Ld), 0.3 * rng.randn(B, Ld),
+                 0.3 * rng.randn(B, Ld), rng.randn(B, zd), rng.rand(B, 1)]
+        ph.step(*[dev(b) for b in batch])
+        s = ph.read_scalars()
+        with MaskFeeder() as mf:
+            _gan_masks(mf, ph, B, gan_type, lambda_gp)
+            d_total, g_total, parts = o.step(*[torch.tensor(b) for b in batch])
+        ref = dict(d_total_loss=float(d_total), g_total_loss=float(g_total))
+        ref.update({k: float(v) for k, v in parts.items() if k in s})
+        for k, r in ref.items():
+            worst[k] = max(worst.get(k, 0.0), abs(s[k] - r) / max(1.0, abs(r)))
+    assert max(worst.values()) <= 2e-5, worst

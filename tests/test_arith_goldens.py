@@ -306,3 +306,219 @@ def test_gan_step_matches_reference_graph(name):
             chk('after/CFL/Discriminator/' + k, v.numpy())
         for k, v in go.gp.items():
             chk('after/CFL/Generator/' + k, v.numpy())
+
+
+# ---------------------------------------------------------------------------------------------------------
+# the HIP path against the same goldens (-m gpu): the product's host classes (cfl.models.dist.Dist,
+# cfl.models.cfl.CFL), loaded with the recipe's initial variables through their TensorFlow-named checkpoint
+# state, fed the recipe's batches; every call goes through the C ABI of libcfl_hip.so.
+# ---------------------------------------------------------------------------------------------------------
+ALL_CASES = [c['name'] for c in R.CASES]
+F32_TOL = 2e-5          # fp32 kernels against the float64 goldens, relative to max(1, |golden|)
+
+
+def build_product_model(case):
+    from cfl import ops
+    if case['model'] == 'dist':
+        from cfl.models.dist import construct_model
+        nv = case['normalize_value']
+        model, _ = construct_model(tuple(case['input_shape']), case['latent_size'], case['num_components'], 1e-3, 0.9,
+                                   0.999, case['batch_size'], nv, reg_const=case['reg_const'],
+                                   data_normalizer=ops.normalizer(nv, 0.), data_unnormalizer=ops.unnormalizer(nv, 0.))
+        return model
+    from cfl.models.cfl import construct_model
+    kw = R.cfl_kwargs(case)
+    tr, vtr = ops.dist_transformer(source_shape=None, input_shape=kw['input_shape'], data_random_crop=False,
+                                   data_mirror=False)
+    dn, dun, aen, aeun, ln = ops.dist_normalizer(**R.norm_kwargs(case))
+    model, _ = construct_model(train_data_transformer=tr, val_data_transformer=vtr,
+                               ae_transformer=ops.dist_ae_transformer(kw['input_shape'], kw['ae_shape']),
+                               data_normalizer=dn, data_unnormalizer=dun, ae_normalizer=aen, ae_unnormalizer=aeun,
+                               latent_normalizer=ln, seed=0, **kw)
+    return model
+
+
+def load_initial(model, case):
+    st = model.checkpoint_state()
+    init = G.initial_variables(case)
+    assert set(st['variables']) == set(init), sorted(set(st['variables']) ^ set(init))
+    for n, v in init.items():
+        assert tuple(np.shape(st['variables'][n])) == tuple(np.shape(v)), n
+        st['variables'][n] = np.asarray(v, np.float32)
+        st['adam_m'][n] = np.zeros_like(st['variables'][n])
+        st['adam_v'][n] = np.zeros_like(st['variables'][n])
+    model.load_checkpoint_state(st)
+    assert model.get_name() == G.meta(case['name'])['model_name']
+
+
+def labeled(case, items):
+    """a labeled batch in cfl/input_data.py:581-589 order (image and latent interleaved for double data)"""
+    if case.get('is_double'):
+        out = []
+        for img, lat in items:
+            out += [img.astype(np.float32), lat.astype(np.float32)]
+        return out
+    return [x.astype(np.float32) for x in items]
+
+
+def unl(case, item):
+    return [a.astype(np.float32) for a in item] if case.get('is_double') else [item.astype(np.float32)]
+
+
+class _Diffs(object):
+    def __init__(self, case):
+        self.case, self.bad, self.worst = case, [], {}
+
+    def scalar(self, step, key, got, tol=F32_TOL):
+        if not G.has(self.case, step, key):
+            return
+        ref = float(G.expected(self.case, step, key))
+        err = abs(float(got) - ref) / max(1.0, abs(ref))
+        self.worst[key] = max(self.worst.get(key, 0.0), err)
+        if not err <= tol:
+            self.bad.append('step %d %s: got %.8g want %.8g (rel %.2e > %.1e)' % (step, key, got, ref, err, tol))
+
+    def array(self, step, key, got, tol=F32_TOL, frac=1.0, digest_tol=3e-4):
+        """small tensors element-wise (a fraction `frac` of the entries within tol of the tensor's scale), large
+        ones through their seeded projections"""
+        full = '%s/step%d/%s' % (self.case['name'], step, key)
+        got = np.asarray(got, dtype=np.float64)
+        if full in G.npz().files:
+            ref = G.npz()[full]
+            if got.shape != ref.shape:
+                self.bad.append('%s: shape %r vs %r' % (full, got.shape, ref.shape))
+                return
+            scale = max(float(np.abs(ref).max()), 1e-3)
+            d = np.abs(got - ref) / scale
+            ok = float((d <= tol).mean()) if d.size else 1.0
+            self.worst[key] = max(self.worst.get(key, 0.0), float(d.max()) if d.size else 0.0)
+            if ok < frac:
+                self.bad.append('%s: %.4f of entries within %.1e (max %.2e)' % (full, ok, tol, d.max()))
+            return
+        for k, mine in R.digest(full, got).items():
+            ref = G.npz()[k]
+            # [sum, sumsq, 4 probes, 32 leading entries]: relative to the size of the probe projections
+            scale = max(float(np.abs(ref[2:6]).max()), 1e-6)
+            err = float(np.abs(mine[2:] - ref[2:]).max()) / scale
+            self.worst[key] = max(self.worst.get(key, 0.0), err)
+            if not err <= digest_tol:
+                self.bad.append('%s: digest differs by %.2e of its scale' % (k, err))
+
+    def finish(self):
+        assert not self.bad, '\n'.join(self.bad[:40]) + '\nworst: %r' % (sorted(self.worst.items(), key=lambda kv: -kv[1])[:8],)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', ALL_CASES)
+def test_hip_matches_reference_graph(name):
+    """HIP (fp32) against the float64 goldens of the reference's own graph code: step 0 is a pure function of the
+    inputs (held to 2e-5); later steps follow the fp32 trajectory (losses 1e-5 for the pair step; conv / GAN stacks
+    are held to the tolerance their kinked activations allow, see tests/test_activation_masks_gpu.py)."""
+    import torch
+    from cfl import hipabi as H
+    case = R.case_by_name(name)
+    model = build_product_model(case)
+    load_initial(model, case)
+    m = G.meta(name)
+    df = _Diffs(case)
+    kinked = case.get('model_type') == 'conv' or case.get('gan')
+    for step in range(case['steps']):
+        inp = R.inputs(case, step)
+        later = step > 0
+        if not case.get('gan_step'):
+            val = labeled(case, inp['val'])
+            vsel = model.select_batch(val) if hasattr(model, 'select_batch') else val
+            df.array(step, 'val_pos_scores', model.predict(vsel[0], vsel[1]), tol=5e-5 if kinked and later else F32_TOL)
+            df.array(step, 'val_neg_scores', model.predict(vsel[2], vsel[3]), tol=5e-5 if kinked and later else F32_TOL)
+            model.train_step(labeled(case, inp['batch']))
+            s = model.scalars()
+            tol = (5e-4 if kinked else 1e-5) if later else F32_TOL
+            df.scalar(step, 's_total_loss', s['total'], tol)
+            df.scalar(step, 's_loss_reg', s['reg'], tol)
+            df.scalar(step, 'thres_loss' if case['model'] == 'dist' else 's_thres_loss', s['thres'], tol)
+            df.scalar(step, 's_p_loss_pos', s['loss_pos'], tol)
+            df.scalar(step, 's_p_loss_neg', s['loss_neg'], tol)
+            df.scalar(step, 's_cd_loss', s['cd'], tol)
+            df.scalar(step, 's_accuracy', s['accuracy'], 1e-6 if not later else 0.5 / case['batch_size'] + 1e-6)
+            df.scalar(step, 's_margins', s['mean_d_pos'] - s['mean_d_neg'], tol)
+            df.scalar(step, 'threshold', s['threshold'], tol)
+            df.scalar(step, 's_pos_dists_adapt', s['dist_adapt_pos'], tol)
+            df.scalar(step, 's_neg_dists_adapt', s['dist_adapt_neg'], tol)
+            # gradients of the fused pair step by TensorFlow variable name
+            if step == 0:
+                owner = {v: t for t, vs in m['optimizers'].items() for v in vs}
+                nograd = {v for vs in m.get('no_gradient', {}).values() for v in vs}
+                named_grad = model._named(model.engine.grad)
+                for n, g in named_grad.items():
+                    if n in nograd or n not in owner:
+                        continue
+                    df.array(step, 'grad/%s/%s' % (owner[n], n), g, tol=3e-5)
+                if getattr(model, 'trunk', None) is not None:
+                    for n, g in model.trunk.named(model.trunk.grad).items():
+                        df.array(step, 'grad/s_optim/CFL/DistEncoder/' + n, g, tol=1e-4, frac=0.999, digest_tol=1e-3)
+        else:
+            lab = labeled(case, inp['batch'])
+            draws = (inp['z'], inp['eps'], inp['c'])
+            if case.get('cgan'):
+                model.post_step(lab, draws=draws)
+            else:
+                model.post_step(lab, unl(case, inp['unlabeled'][0]), unl(case, inp['unlabeled'][1]), draws=draws)
+            s = model.gan_phase.read_scalars()
+            tol = 2e-3 if later else 5e-5
+            for k in ('d_total_loss', 'g_total_loss', 'd_loss_real', 'd_loss_fake', 'd_loss_neg', 'd_grad_loss',
+                      'd_loss_d', 'g_loss', 'g_loss_d', 'g_loss_d_neg', 'g_loss_int'):
+                if k in s:
+                    df.scalar(step, k, s[k], tol)
+            if step == 0:
+                for k in ('d_real_accuracy', 'd_fake_accuracy', 'g_accuracy'):
+                    df.scalar(step, k, s[k], 1e-6)
+                ph = model.gan_phase
+                nograd = {v for vs in m.get('no_gradient', {}).values() for v in vs}
+                for tag, net in (('post_d_optim', ph.disc), ('post_g_optim', ph.gen)):
+                    for n, g in net.pool.named(net.pool.grad).items():
+                        if 'CFL/' + n not in nograd:
+                            df.array(step, 'grad/%s/CFL/%s' % (tag, n), g, tol=3e-4, frac=0.995, digest_tol=1e-3)
+        # variables after the step (Adam's first steps move every entry by about lr whatever the size of its
+        # gradient, so entries whose gradient is at the fp32 noise level may go the other way: a fraction, not all)
+        vars_now = model.checkpoint_state()['variables']
+        lr = max(case.get('d_lr', 2e-4), case.get('g_lr', 2e-4)) if case.get('gan_step') else 1e-3
+        for n, v in vars_now.items():
+            key = 'after/' + n
+            full = '%s/step%d/%s' % (name, step, key)
+            if full in G.npz().files:
+                ref = G.npz()[full]
+                d = np.abs(np.asarray(v, np.float64) - ref)
+                if d.size and not (float((d <= 1e-5 + 0.05 * lr).mean()) >= 0.97 and d.max() <= 2.5 * (step + 1) * lr):
+                    df.bad.append('%s: %.4f within tol, max %.2e' % (full, float((d <= 1e-5 + 0.05 * lr).mean()), d.max()))
+            else:
+                df.array(step, key, v, digest_tol=2e-3)
+    df.finish()
+
+
+@pytest.mark.gpu
+def test_padded_width_with_shift_normaliser_roundtrip():
+    """A feature width that is not a multiple of 64 together with a normaliser that maps 0 to a non-zero value
+    (--data-type tanh --data-mean .5 --data-norm .5: add = -1): the zero padding must stay out of the model.  The
+    padded weight rows never train, so a checkpoint (which stores the true [D, N] variables) restores the very
+    model that was trained.  (The multi-step parity of this configuration is the golden case cfl_pcd_tanh_data.)"""
+    import torch
+    from cfl import hipabi as H
+    case = dict(R.case_by_name('cfl_pcd_tanh_data'), input_shape=(200,), batch_size=32, latent_size=8)
+    model = build_product_model(case)
+    rng = np.random.RandomState(3)
+    mk = lambda: [rng.rand(32, 200).astype(np.float32) * 1.2 - 0.1 for _ in range(4)]
+    for _ in range(4):
+        model.train_step(mk())
+    p, _, _ = H.unpack_theta(model.engine.shape, model.engine.theta)
+    for k in ('outputs/W', 'proto/W'):
+        assert not p[k][200:].any(), k              # rows under the zero padding received no update
+        assert np.abs(p[k][:200]).max() > 0
+    twin = build_product_model(case)
+    twin.load_checkpoint_state(model.checkpoint_state())
+    assert torch.equal(twin.engine.theta, model.engine.theta)
+    probe = mk()
+    assert np.array_equal(twin.predict(probe[0], probe[1]), model.predict(probe[0], probe[1]))
+    nxt = mk()
+    model.train_step(nxt)
+    twin.train_step(nxt)
+    assert torch.equal(twin.engine.theta, model.engine.theta)

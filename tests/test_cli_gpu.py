@@ -145,6 +145,54 @@ def test_resident_gather_equals_host_batches(dataset):
     assert np.array_equal(sh[1].cpu().numpy()[:, :200], full[1][10:20])
 
 
+def test_indexed_batches_train_like_dense_batches(dataset):
+    """ResidentFeatures.next_indexed hands the step the POSITIONS of the batch (a window of the device copy of the
+    shuffled pair list); the fused kernels read the rows in place.  Same index stream (epoch wraps, data_switch
+    coin flips, the B > N oversampling branch), and bit-identical training to dense gathered batches."""
+    from cfl import hipabi as H
+    from cfl import input_data
+    from cfl.engine import PairEngine
+    path = os.path.join(dataset, 'syn/toy', 'train')
+    a = input_data.SemiDataSet(path, input_size=200, data_switch=True, seed=9)
+    b = input_data.SemiDataSet(path, input_size=200, data_switch=True, seed=9)
+    ra, rb = input_data.ResidentFeatures(a), input_data.ResidentFeatures(b)
+    rng = np.random.RandomState(0)
+    mk = lambda: PairEngine(256, 6, 3, 'pcd', weight_norm=True, has_bias=True, norm=H.make_norm(1.0 / 16.0),
+                            loss=H.make_loss(pos_weight=0.25, lambda_m=0.5), lr=1e-3, device='cuda',
+                            params={'outputs/W': rng_w(0, 256, 6), 'outputs/b': np.zeros(6, np.float32),
+                                    'outputs/g': np.ones(6, np.float32), 'proto/W': rng_w(1, 256, 18),
+                                    'proto/b': np.zeros(18, np.float32), 'proto/g': np.ones(18, np.float32)})
+    rng_w = lambda s, d, n: (np.random.RandomState(s).randn(d, n) * 0.05).astype(np.float32)
+    ea, eb = mk(), mk()
+    n_pairs = a.pairs_pos.shape[0]
+    for B in [37] * 6 + [n_pairs // 2 + 1] * 4 + [37] * 2:          # the long batches force epoch wraps
+        table, streams = ra.next_indexed(B)
+        dense = rb.next_batch(B)
+        ea.step((table, streams))
+        eb.step(dense)
+        assert torch.equal(ea.theta, eb.theta) and torch.equal(ea.grad, eb.grad)
+        assert torch.equal(ea.scalars, eb.scalars)
+        sa = ea.scores(table, streams.pair(1))
+        sb = eb.scores(dense[2], dense[3])
+        assert torch.equal(sa, sb)
+    assert a.head_labeled_pos == b.head_labeled_pos and np.array_equal(a.pairs_pos, b.pairs_pos)
+    # shards: rows [lo, hi) of the global batch
+    t, st = ra.next_indexed(40, (10, 20))
+    full = rb.next_batch(40)
+    assert st.n == 10
+    assert torch.equal(ea.scores(t, st.pair(0)), eb.scores(full[0][10:20].contiguous(), full[1][10:20].contiguous()))
+    # B > number of pairs: the reference's RandomState.choice oversampling (cfl/input_data.py:558-566)
+    t, st = ra.next_indexed(n_pairs + 5)
+    full = rb.next_batch(n_pairs + 5)
+    assert torch.equal(ea.scores(t, st.pair(0)), eb.scores(full[0], full[1]))
+    # out-of-range positions are clamped to the last table row, never read out of bounds
+    bad = torch.tensor([0, 10 ** 9, -1, 3], dtype=torch.int32, device='cuda')
+    ok = torch.tensor([0, ra.table.shape[0] - 1, ra.table.shape[0] - 1, 3], dtype=torch.int32, device='cuda')
+    s_bad = ea.scores(ra.table, H.IndexStreams.from_tensors([bad, bad]))
+    s_ok = ea.scores(ra.table, H.IndexStreams.from_tensors([ok, ok]))
+    assert torch.equal(s_bad, s_ok)
+
+
 def test_cfl_train_conv_model(tmp_path):
     """--model-type conv end to end on an MNIST-shaped synthetic pair set (8x8x1 images so
     the trunk is one 5x5 stride-2 layer), the command line of experiments/fashion_30/run.sh."""

@@ -1,0 +1,111 @@
+"""The N > 1 path on the GPU (-m gpu; the box has ONE GPU, so the two ranks share it and talk over gloo --
+functional coverage of exactly the code the RCCL ranks run, not a measurement):
+
+* PairEngine.step on the two row shards of a global batch == the single-GPU step on the whole batch
+  (gradient, scalars, Adam result), for dense and for indexed batches;
+* `python bench.py --gpus 2` starts its own two ranks, trains shards of one seeded global pool, and prints one
+  JSON line with n_gpus == ranks_seen == 2.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, out):
+    for p in (ROOT, os.path.join(ROOT, 'compatibility-family-learning_amd')):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from cfl import engine, hipabi as H
+        from cfl.engine import PairEngine
+        rng = np.random.RandomState(0)                       # identical on every rank
+        D, L, K, B = 256, 6, 3, 64
+        params = {'outputs/W': (rng.randn(D, L) * 0.05).astype(np.float32), 'outputs/b': np.zeros(L, np.float32),
+                  'outputs/g': np.ones(L, np.float32), 'proto/W': (rng.randn(D, L * K) * 0.05).astype(np.float32),
+                  'proto/b': np.zeros(L * K, np.float32), 'proto/g': np.ones(L * K, np.float32)}
+        mk = lambda: PairEngine(D, L, K, 'pcd', weight_norm=True, has_bias=True, norm=H.make_norm(0.25),
+                                loss=H.make_loss(pos_weight=0.25, lambda_m=0.5, reg_const=1e-3), lr=1e-3,
+                                device='cuda', params=params)
+        eng = mk()
+        table = torch.tensor(np.abs(rng.randn(500, D)).astype(np.float32), device='cuda')
+        lo, hi = engine.shard_rows(B)
+        worst = 0.0
+        ref = mk() if rank == 0 else None
+        for it in range(4):
+            idx = [torch.tensor(rng.randint(0, 500, size=B).astype(np.int32), device='cuda') for _ in range(4)]
+            full = [table[i.long()].contiguous() for i in idx]
+            if it % 2 == 0:
+                eng.step([x[lo:hi].contiguous() for x in full])                      # dense shard
+            else:
+                eng.step((table, H.IndexStreams.from_tensors([i[lo:hi].contiguous() for i in idx])))
+            assert eng.world_size == world
+            s = eng.read_scalars()
+            if rank == 0:
+                # the single-GPU step on the whole global batch (no collective: fwd_bwd + Adam by hand)
+                ref.fwd_bwd(full)
+                rs = ref.read_scalars()
+                g_dp = eng.grad * (1.0 / world)
+                worst = max(worst, float((g_dp - ref.grad).abs().max() / ref.grad.abs().max()))
+                ref.apply_adam(1.0)
+                worst = max(worst, float((eng.theta - ref.theta).abs().max()))
+                for k in ('total', 'thres', 'loss_pos', 'loss_neg', 'cd', 'accuracy', 'mean_d_pos', 'threshold'):
+                    worst = max(worst, abs(s[k] - rs[k]) / max(1.0, abs(rs[k])))
+        # every rank holds the same weights
+        th = eng.theta.clone()
+        dist.all_reduce(th, op=dist.ReduceOp.MAX)
+        same = bool(torch.equal(th, eng.theta))
+        if rank == 0:
+            out.put((worst, same))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_steps_equal_the_single_gpu_step():
+    ctx = mp.get_context('spawn')
+    out = ctx.SimpleQueue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    worst, same = out.get()
+    assert same
+    assert worst < 2e-6, worst        # summation order differs from one rank: 1e-5 bar of SURVEY 8(e)
+
+
+def test_bench_starts_its_own_ranks():
+    env = dict(os.environ, CFL_DIST_BACKEND='gloo')
+    env.pop('WORLD_SIZE', None)
+    env.pop('RANK', None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '5', '--warmup', '2',
+                        '--repeats', '3', '--pool-mib', '64', '--no-cpu-baseline', '--no-kernel-profile',
+                        '--no-cli-loop'], env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['ranks_seen'] == 2 and out['config']['global_batch_rows'] == 1024
+    assert out['config']['parallelism'] == 'dp2' and out['scaling'] == 'weak' and out['value'] > 0
+    assert np.isfinite(out['config']['final_loss'])
+    # a mismatching launcher is an error, not a silent single-GPU run
+    env2 = dict(env, WORLD_SIZE='1', RANK='0')
+    r2 = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup',
+                         '1'], env=env2, cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert r2.returncode != 0 and '--gpus 2 but WORLD_SIZE 1' in r2.stderr

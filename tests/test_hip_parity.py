@@ -344,6 +344,7 @@ def test_bf16x3_matrix_core_path_is_fp32_equivalent(monkeypatch):
     errs = {}
     for mode, env in (('x3', '0'), ('fp32', '1')):
         monkeypatch.setenv('CFL_EXACT_FP32', env)
+        H.reload_env()            # launch plans (incl. this switch) are cached per process
         eng = PairEngine(D, L, K, norm=H.make_norm(1 / 58.388599), params=params, batch_size=B)
         eng.fwd_bwd(dev)
         g, _, _ = H.unpack_theta(eng.shape, eng.grad)
@@ -355,3 +356,5 @@ def test_bf16x3_matrix_core_path_is_fp32_equivalent(monkeypatch):
         assert errs['x3'][k] < 2e-6 and errs['fp32'][k] < 2e-6, errs
         assert errs['x3'][k] <= 2.0 * errs['fp32'][k] + 1e-7, errs
     assert errs['x3']['loss'] <= 1e-6 and errs['fp32']['loss'] <= 1e-6, errs
+    monkeypatch.undo()
+    H.reload_env()

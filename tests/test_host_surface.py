@@ -160,7 +160,8 @@ def test_checkpoint_converter_npz_round_trip(tmp_path):
              'adam_v': {n: np.abs(rng.randn(3, 2)).astype(np.float32) for n in names},
              'beta1_power': 0.81, 'beta2_power': 0.998, 'global_step': 7, 'name': 'x'}
     pt, npz, back = tmp_path / 'model-7.pt', tmp_path / 'm.npz', tmp_path / 'back.pt'
-    torch.save(state, str(pt))
+    from cfl.utils import Saver
+    torch.save(Saver._plain(state), str(pt))
     assert C.main(['--to-npz', str(pt), str(npz)]) == 0
     with np.load(str(npz)) as z:
         assert names[0] + '/Adam_1' in z.files and int(z['global_step']) == 7

@@ -20,6 +20,7 @@ dev = [torch.from_numpy(b).cuda() for b in batch]
 out = {}
 for mode in ('x3', 'fp32'):
     os.environ['CFL_EXACT_FP32'] = '0' if mode == 'x3' else '1'
+    H.reload_env()
     eng = PairEngine(D, L, K, norm=H.make_norm(1 / 58.388599), params=params, batch_size=B)
     eng.fwd_bwd(dev)
     torch.cuda.synchronize()
