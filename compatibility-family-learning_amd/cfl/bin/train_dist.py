@@ -25,15 +25,72 @@ logger = logging.getLogger(__name__)
 SCALAR_EVERY = 25  # host read-back cadence of the display scalars (steps)
 
 
+class DeferredScalars(object):
+    """Read-backs that do not stall the stream: at a read-back point the step's scalars and the validation accuracy
+    (computed on the device) are copied into pinned host memory behind an event; they are handed to the callback
+    when the event has completed -- normally one cadence later -- and all of them at `flush()`.  The host can thus
+    stay hundreds of launches ahead of the GPU, which is what hides the per-epoch reshuffle of the pair lists
+    (a serial MT19937 permutation, cfl/input_data.py:543-551) behind queued training steps."""
+
+    def __init__(self, model, on_scalars):
+        self.model, self.on_scalars, self.pending = model, on_scalars, []
+
+    def record(self, step, val_batch):
+        import torch
+        from .. import hipabi as H
+        eng = self.model.engine
+        host = torch.empty(H.S_COUNT + 1, dtype=torch.float32).pin_memory()
+        host[:H.S_COUNT].copy_(eng.scalars, non_blocking=True)
+        sp = eng.scores(val_batch[0], val_batch[1].pair(0))
+        sn = eng.scores(val_batch[0], val_batch[1].pair(1))
+        acc = 0.5 * ((sp > 0).float().mean() + (sn <= 0).float().mean())
+        host[H.S_COUNT:].copy_(acc.reshape(1), non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self.pending.append((step, host, ev, eng._scalar_scale))
+        self.poll()
+
+    def poll(self, wait=False):
+        from .. import hipabi as H
+        while self.pending and (wait or self.pending[0][2].query()):
+            step, host, ev, scale = self.pending.pop(0)
+            ev.synchronize()
+            vals = host.numpy()
+            s = dict(zip(H.SCALAR_NAMES, (float(x) * scale for x in vals[:H.S_COUNT])))
+            self.on_scalars(step, s, float(vals[H.S_COUNT]))
+
+    def flush(self):
+        self.poll(wait=True)
+
+
 def train_steps(model, train_src, val_src, batch_size, shard, n_steps, on_scalars=None, progress=None):
-    """The per-iteration body of the training loop (cfl/bin/train_dist.py:77-87 of the reference: one
-    ``sess.run([summary, [s_optim], s_accuracy, val_s_accuracy])`` per iteration): the next labeled batch of the
-    seeded index stream -- as positions into the resident feature table -- goes through one fused training step;
-    the display scalars (train / validation accuracy) are read back every SCALAR_EVERY iterations."""
-    for i in (progress if progress is not None else range(n_steps)):
-        model.engine.step(train_src.next_indexed(batch_size, shard))
-        if on_scalars is not None and (i % SCALAR_EVERY == 0 or i == n_steps - 1):
-            on_scalars(i, model.scalars(), model.batch_accuracy(val_src.next_indexed(batch_size)))
+    """The iterations of the training loop (cfl/bin/train_dist.py:77-87 of the reference: one
+    ``sess.run([summary, [s_optim], s_accuracy, val_s_accuracy])`` per iteration): the labeled batches of the
+    seeded index stream -- as positions into the resident feature table -- go through the fused training step;
+    the display scalars (train / validation accuracy) are read back every SCALAR_EVERY iterations, without stalling
+    the stream (DeferredScalars).  On one GPU the iterations between two read-backs are one library call (windows of
+    the device pair lists); data-parallel ranks step batch by batch (each step contains the gradient all-reduce)."""
+    i = 0
+    single = dp.world_size() == 1
+    deferred = DeferredScalars(model, on_scalars) if on_scalars is not None else None
+    while i < n_steps:
+        # the chunk ends with the next iteration whose scalars are read back (0, 25, 50, ..., and the last one)
+        stop = min((i + SCALAR_EVERY - 1) // SCALAR_EVERY * SCALAR_EVERY, n_steps - 1) + 1
+        win = train_src.next_windows(batch_size, stop - i, shard) if single else None
+        if win is not None:
+            model.engine.step_windows(win)
+            done = win.nsteps
+        else:
+            model.engine.step(train_src.next_indexed(batch_size, shard))
+            done = 1
+        last = i + done - 1
+        i += done
+        if progress is not None:
+            progress.update(done)
+        if deferred is not None and (last % SCALAR_EVERY == 0 or last == n_steps - 1):
+            deferred.record(last, val_src.next_indexed(batch_size))
+    if deferred is not None:
+        deferred.flush()
 
 
 def train_loop(model, data, aux, batch_size, start_epoch, epochs, log_dir, checkpoint_dir, saver):
@@ -69,6 +126,7 @@ def train_loop(model, data, aux, batch_size, start_epoch, epochs, log_dir, check
                 scalar_log.write('{}\t{}\t{}\t{}\n'.format(nb_batch * e + i, s['total'], s['accuracy'],
                                                            s['threshold']))
         train_steps(model, train_src, val_src, batch_size, shard, nb_batch, on_scalars, progress=t)
+        t.close()
         if scalar_log is not None:
             scalar_log.flush()
         gc.collect()

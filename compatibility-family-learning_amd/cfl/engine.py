@@ -176,6 +176,22 @@ class PairEngine(object):
         self._scalar_scale = scale
         self.apply_adam(scale)
 
+    def step_windows(self, win):
+        """`win.nsteps` consecutive single-GPU training steps over windows of the device pair lists
+        (cfl.input_data.ResidentFeatures.next_windows): one library call, the launches of all steps are enqueued
+        back to back."""
+        if self.world_size != 1:
+            raise H.CflHipError('step_windows is the single-GPU loop; data-parallel ranks step batch by batch')
+        ws = self._workspace(win.rows, 2)
+        b1p, b2p = H.pair_train_steps_idx(
+            self.shape, self.norm, self.loss, win.table, win.pos_pairs, win.neg_pairs, win.pos_head, win.neg_head,
+            win.batch_rows, win.shard_lo, win.rows, win.switched, win.nsteps, self.theta, self.m, self.v, self.grad,
+            self.scalars, ws, np.float32(self.lr), self.beta1, self.beta2, self.eps, self.beta1_power,
+            self.beta2_power)
+        self.beta1_power, self.beta2_power = np.float32(b1p), np.float32(b2p)
+        self.global_step += win.nsteps
+        self._scalar_scale = 1.0
+
     def read_scalars(self):
         """Host copy of the last step's scalars (synchronises the stream).  Under data parallelism they are the
         global-batch values: every scalar is a mean over this rank's rows, the shards are equal-sized, and the

@@ -65,7 +65,8 @@ EXPORTS = ('cfl_version', 'cfl_last_error', 'cfl_layout', 'cfl_workspace_bytes',
            'cfl_pair_scores', 'cfl_pair_step_fwd_bwd', 'cfl_pair_train_step', 'cfl_adam_tf',
            'cfl_gather_rows', 'cfl_profile_enable', 'cfl_profile_read', 'cfl_pair_input_grad',
            'cfl_conv_workspace_bytes', 'cfl_conv2d_wn_fwd', 'cfl_conv2d_wn_bwd',
-           'cfl_pair_scores_idx', 'cfl_pair_step_fwd_bwd_idx', 'cfl_pair_train_step_idx', 'cfl_reload_env')
+           'cfl_pair_scores_idx', 'cfl_pair_step_fwd_bwd_idx', 'cfl_pair_train_step_idx', 'cfl_reload_env',
+           'cfl_pair_train_steps_idx')
 
 KERNEL_NAMES = ('colnorm', 'proj', 'mid', 'grad', 'finalize', 'adam', 'gather')
 K_COUNT = 8
@@ -122,6 +123,12 @@ def lib():
         C.POINTER(C.c_void_p), C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
         C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_size_t, C.c_void_p]
     L.cfl_pair_train_step_idx.restype = C.c_int
+    L.cfl_pair_train_steps_idx.argtypes = [
+        C.POINTER(CflShape), C.POINTER(CflNorm), C.POINTER(CflLossCfg), C.c_void_p, C.c_int64, C.c_void_p,
+        C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_char_p, C.c_int64, C.c_void_p,
+        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float,
+        C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_void_p, C.c_size_t, C.c_void_p]
+    L.cfl_pair_train_steps_idx.restype = C.c_int
     L.cfl_reload_env.restype = C.c_int
     L.cfl_adam_tf.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                               C.c_int64, C.c_float, C.c_float, C.c_float,
@@ -283,6 +290,23 @@ def pair_train_step_idx(shape, norm, loss, table, streams, theta, m, v, grad, sc
         C.byref(shape), C.byref(norm), C.byref(loss), tp, rows, streams.arr, streams.stride, streams.n,
         _dev(theta), _dev(m), _dev(v), _dev(grad), _dev(scalars), float(lr_t), float(beta1), float(beta2),
         float(eps), workspace.data_ptr(), workspace.numel() * workspace.element_size(), _stream()))
+
+
+def pair_train_steps_idx(shape, norm, loss, table, pos_pairs, neg_pairs, pos_head, neg_head, batch_rows, shard_lo,
+                         rows, switched, nsteps, theta, m, v, grad, scalars, workspace, lr, beta1, beta2, eps,
+                         beta1_power, beta2_power):
+    """nsteps consecutive training steps over windows of the device pair lists (cfl_pair_train_steps_idx).
+    Returns the advanced (beta1_power, beta2_power) as python floats holding float32 values."""
+    tp, trows = _table(table)
+    b1p, b2p = C.c_float(beta1_power), C.c_float(beta2_power)
+    sw = bytes(bytearray(int(bool(x)) for x in switched)) if switched is not None else None
+    _check(lib().cfl_pair_train_steps_idx(
+        C.byref(shape), C.byref(norm), C.byref(loss), tp, trows, _dev(pos_pairs, torch.int32),
+        _dev(neg_pairs, torch.int32), int(pos_head), int(neg_head), int(batch_rows), int(shard_lo), int(rows), sw,
+        int(nsteps), _dev(theta), _dev(m), _dev(v), _dev(grad), _dev(scalars), float(lr), float(beta1),
+        float(beta2), float(eps), C.byref(b1p), C.byref(b2p), workspace.data_ptr(),
+        workspace.numel() * workspace.element_size(), _stream()))
+    return b1p.value, b2p.value
 
 
 def reload_env():

@@ -486,8 +486,12 @@ class ResidentFeatures(object):
         host = getattr(self.dataset, 'pairs_' + which)
         cached = self._pairs.get(which)
         if cached is None or cached[0] is not host:
-            dev = torch.from_numpy(np.ascontiguousarray(host, dtype=np.int32)).to(self.device)
-            cached = self._pairs[which] = (host, dev)
+            # pinned staging + stream-ordered copy: the upload neither waits for the queued training steps (which
+            # still read the previous device copy -- kept alive by `cached` until this assignment, and by the
+            # stream order afterwards) nor stalls the host
+            staged = torch.from_numpy(np.ascontiguousarray(host, dtype=np.int32)).pin_memory()
+            dev = staged.to(self.device, non_blocking=True)
+            cached = self._pairs[which] = (host, dev, staged)
         return cached[1]
 
     def next_indexed(self, batch_size, shard=None):
@@ -513,6 +517,28 @@ class ResidentFeatures(object):
             keep.append(dev)
             ptrs += [base + 4 * c[0], base + 4 * c[1]]
         return self.table, self._h.IndexStreams(ptrs, 2, hi - lo, keep=keep)
+
+    def next_windows(self, batch_size, max_steps, shard=None):
+        """Up to `max_steps` consecutive labeled batches as ONE window descriptor for PairEngine.step_windows, or
+        None when the very next batch is not a plain window of both pair lists (an epoch wrap reshuffles, or the
+        batch is larger than a list) -- the caller then takes that batch through next_indexed.  The dataset's
+        stream is advanced exactly as `nsteps` calls of next_batch_indices would: between reshuffles a batch only
+        moves the two heads and, with data_switch, draws one coin flip (cfl/input_data.py:542-577)."""
+        from argparse import Namespace
+        ds = self.dataset
+        npos, nneg = ds.pairs_pos.shape[0], ds.pairs_neg.shape[0]
+        k = min(int(max_steps), (npos - ds.head_labeled_pos) // batch_size, (nneg - ds.head_labeled_neg) // batch_size)
+        if k <= 0 or batch_size > npos or batch_size > nneg:
+            return None
+        lo, hi = shard if shard is not None else (0, batch_size)
+        win = Namespace(table=self.table, pos_pairs=self._device_pairs('pos'), neg_pairs=self._device_pairs('neg'),
+                        pos_head=ds.head_labeled_pos, neg_head=ds.head_labeled_neg, batch_rows=batch_size,
+                        shard_lo=lo, rows=hi - lo, nsteps=k, switched=None)
+        if ds.data_switch:
+            win.switched = [bool(ds._rng.rand() > 0.5) for _ in range(k)]
+        ds.head_labeled_pos += k * batch_size
+        ds.head_labeled_neg += k * batch_size
+        return win
 
     def whole_indexed(self, which, batch_size):
         """(table, IndexStreams of (src, dst)) chunks over all pairs of pairs_<which> in file order, for scoring

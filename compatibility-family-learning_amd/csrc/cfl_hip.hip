@@ -424,6 +424,12 @@ struct GradJob {
     int nt;
 };
 
+// columns of the per-row loss-quantity tile written by mid and summed over rows by grad_red_block
+enum {
+    P_BCE_POS = 0, P_BCE_NEG, P_OK_POS, P_OK_NEG, P_D_POS, P_D_NEG, P_O_POS, P_O_NEG,
+    P_DTHR, P_HINGE_NEG, P_SQRT_POS, P_SQRT_NEG, P_NROWQ = 12
+};
+
 // Row reductions that ride in the grad launch (z-slice 0).
 //   kind 0: column sums of a fragment-major buffer: one job per 16-column tile
 //   kind 1: gate head  dVm[l][k] = sum_r ya[r][l] * du[r][k]  (row-major buffers), one job per l
@@ -434,6 +440,40 @@ struct RedRange {
 };
 #define CFL_MAX_RED 8
 
+// Fused tail of the weight-gradient launch (plan.fused: plain heads, pcd, one encoder, P <= 2): the launch itself
+// turns the per-range partial gradients into the flat gradient and applies TF-Adam, so the step needs no finalize
+// launch and no round trip of P gradient slabs through HBM.
+//   * a (64-d tile, column job) is produced by P workgroups (row ranges).  They take a ticket; the first P-1
+//     publish their partial tile into their slab -- `sc1` (write-through) stores, every storing wave drains with
+//     s_waitcnt vmcnt(0), workgroup barrier, then ONE lane adds 1 to the tile's arrival counter (agent-scope
+//     atomic) -- and leave; the last one polls that counter with `sc1` loads (one lane), barrier, reads the
+//     published tiles with `sc1` loads and runs the epilogue.  This is the last-arriver hand-off of
+//     MI355X_MICROARCH.md ("hand-offs measured with sc1 loads in place of the acquire", first row): no
+//     agent-scope fence on either side.  The tiles are summed in the fixed order of the row ranges, so the result
+//     does not depend on who arrives last (bit-reproducible, and bit-identical to the finalize kernel).
+//   * the row-reduction blocks (z-slice 0) own whole columns, so they finish the bias / threshold entries and the
+//     step's scalars themselves.
+// Tickets and flags live in the workspace and are zeroed by the mid launch of the same step.
+struct GradFuse {
+    int on;
+    int *ticket, *flag;          // [jobs * d tiles]
+    const float *theta;
+    float *grad;                 // flat gradient, layout of theta
+    float *theta_out, *m, *v;    // fused TF-Adam (m == nullptr: gradient only)
+    float lr_t, b1, b2, eps, in_mul, reg_const;
+    long long w_off[CFL_MAX_JOBS];   // theta offset of the job's Wf tile base
+    // row-reduction side: red range k (kind 0) feeds the bias array at red_b[k] (npad red_npad[k], n red_n[k])
+    long long red_b[CFL_MAX_RED];
+    int red_n[CFL_MAX_RED], red_npad[CFL_MAX_RED];
+    long long thr_off;
+    // scalars
+    const float *regpart;
+    int nregblocks, B, use_threshold;
+    float pos_weight, caffe_margin, lambda_m;
+    float *scalars;
+    const float *thr_copy;
+};
+
 struct GradArgs {
     GradJob job[CFL_MAX_JOBS];
     RowSrc rows[2];
@@ -443,6 +483,7 @@ struct GradArgs {
     RedRange red[CFL_MAX_RED];
     int nred, red_total;
     float *colsum;
+    GradFuse fuse;
 };
 
 // d tile of this workgroup.  XCD = blockIdx.x mod 8 (gridDim.x is a multiple of 8 when tps > 0); tile dt
@@ -452,6 +493,141 @@ __device__ __forceinline__ int grad_dtile(int tps) {
     const int k = blockIdx.x & 7, j = blockIdx.x >> 3;
     return ((j / tps) * 8 + k) * tps + j % tps;
 }
+
+// 16-byte write-through store / L1-bypassing load (the `sc1` forms of the hand-off table)
+__device__ __forceinline__ void store_sc1(float *p, f32x4 v) {
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ f32x4 load_sc1(const float *p) {
+    f32x4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+
+// TF-1.x Adam on one parameter (tensorflow/core/kernels/training_ops: the hyper-parameters are
+// float32 scalars and (1 - beta) is formed in float32):  m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ;
+// theta -= lr_t m / (sqrt(v) + eps).  Explicit fma's: every kernel that applies Adam (finalize, the fused tail of
+// the weight-gradient launch, cfl_adam_kernel) rounds identically, whatever the compiler contracts around it.
+__device__ __forceinline__ void adam1(float &th, float &mm, float &vv, float g, float lr_t, float b1, float b2,
+                                      float eps) {
+    mm = fmaf(b1, mm, (1.f - b1) * g);
+    vv = fmaf(b2, vv, ((1.f - b2) * g) * g);
+    th -= lr_t * mm / (sqrtf(vv) + eps);
+}
+__device__ __forceinline__ void adam4(f32x4 &th, f32x4 &mm, f32x4 &vv, const f32x4 g, float lr_t, float b1, float b2,
+                                      float eps) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float t = th[e], m = mm[e], v = vv[e];
+        adam1(t, m, v, g[e], lr_t, b1, b2, eps);
+        th[e] = t; mm[e] = m; vv[e] = v;
+    }
+}
+
+// gradient entry -> flat gradient (+ L2 term) -> optional TF-Adam, 4 consecutive parameters at `off`
+__device__ __forceinline__ void fuse_apply(const GradFuse &f, long long off, f32x4 gr, f32x4 th, f32x4 mm, f32x4 vv) {
+    if (f.reg_const != 0.f) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) gr[e] = fmaf(f.reg_const, th[e], gr[e]);
+    }
+    *(f32x4 *)(f.grad + off) = gr;
+    if (f.m) {
+        adam4(th, mm, vv, gr, f.lr_t, f.b1, f.b2, f.eps);
+        *(f32x4 *)(f.m + off) = mm;
+        *(f32x4 *)(f.v + off) = vv;
+        *(f32x4 *)(f.theta_out + off) = th;
+    }
+}
+
+// Tail of a weight-gradient workgroup in fused mode.  `sum` = this workgroup's partial tile in the C/D mapping of
+// the bodies below (valid in waves < NT; wave = nt); tile_off = float offset of the lane's first float4 inside the
+// head's Wf array (the other three are 64 floats apart).
+template <int NT>
+__device__ __forceinline__ void grad_fused_tail(const GradArgs &a, int job, int P, int p, int wave,
+                                                f32x4 (&sum)[4], size_t tile_off, float *slab0, long long pstride,
+                                                int *lds_i) {
+    const GradFuse &f = a.fuse;
+    const int slot = job * gridDim.x + blockIdx.x;
+    int ticket = P - 1;
+    if (P > 1) {
+        if (threadIdx.x == 0) *lds_i = atomicAdd(f.ticket + slot, 1);      // agent scope
+        __syncthreads();
+        ticket = *lds_i;
+    }
+    if (ticket < P - 1) {
+        // not the last of the P row ranges: publish the partial tile into slab p and leave
+        if (wave < NT) {
+            float *dst = slab0 + (size_t)p * pstride + tile_off;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const f32x4 v = {sum[0][e], sum[1][e], sum[2][e], sum[3][e]};
+                store_sc1(dst + e * 64, v);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) atomicAdd(f.flag + slot, 1);                 // agent-scope arrival count
+        return;
+    }
+    // the last arriver: parameters first (they do not depend on the partners), then the published tiles
+    const long long base = f.w_off[job] + (long long)tile_off;
+    f32x4 th[4], mm[4], vv[4];
+    if (wave < NT) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            th[e] = *(const f32x4 *)(f.theta + base + e * 64);
+            if (f.m) {
+                mm[e] = *(const f32x4 *)(f.m + base + e * 64);
+                vv[e] = *(const f32x4 *)(f.v + base + e * 64);
+            }
+        }
+    }
+    if (P > 1) {
+        if (threadIdx.x == 0)
+            while (__hip_atomic_load(f.flag + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < P - 1)
+                __builtin_amdgcn_s_sleep(1);
+        __syncthreads();
+    }
+    if (wave < NT) {
+        // sum over the row ranges in the fixed order 0 .. P-1 (own registers at position p): the result does not
+        // depend on which workgroup arrived last, and equals the finalize kernel's slab sum bit for bit
+        f32x4 g[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) g[e] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int q = 0; q < P; ++q) {
+            if (q == p) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) g[e] += (f32x4){sum[0][e], sum[1][e], sum[2][e], sum[3][e]};
+            } else {
+                f32x4 part[4];
+                const float *src = slab0 + (size_t)q * pstride + tile_off;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) part[e] = load_sc1(src + e * 64);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int e = 0; e < 4; ++e) g[e] += part[e];
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) fuse_apply(f, base + e * 64, g[e] * f.in_mul, th[e], mm[e], vv[e]);
+    }
+}
+
+// the same reduction, handing the tile to the fused tail instead of storing a slab
+#define CFL_GRAD_FUSED_EPILOGUE()                                                                     \
+    if (a.fuse.on) {                                                                                  \
+        f32x4 sum[4];                                                                                 \
+        const int ntw = wave < NT ? wave : 0;                                                         \
+        _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                               \
+            sum[t] = lds[((0 * NT + ntw) * 4 + t) * 64 + lane];                                       \
+            _Pragma("unroll") for (int w = 1; w < 4; ++w) sum[t] += lds[((w * NT + ntw) * 4 + t) * 64 + lane]; \
+        }                                                                                             \
+        __syncthreads();                                                                              \
+        grad_fused_tail<NT>(a, (int)blockIdx.z - 1, a.P, p, wave, sum,                                \
+                            ((size_t)ntw * G + (dbase >> 4) + kq) * 256 + i16 * 4, jb.wpart, jb.pstride,  \
+                            (int *)lds);                                                              \
+        return;                                                                                       \
+    }
 
 template <int NT>
 __device__ __forceinline__ void grad_body(const GradJob &jb, const GradArgs &a, f32x4 *lds) {
@@ -520,6 +696,7 @@ __device__ __forceinline__ void grad_body(const GradJob &jb, const GradArgs &a, 
 #pragma unroll
         for (int t = 0; t < 4; ++t) lds[((wave * NT + nt) * 4 + t) * 64 + lane] = acc[t][nt];
     __syncthreads();
+    CFL_GRAD_FUSED_EPILOGUE()
     if (wave < NT) {
         const int nt = wave;
         f32x4 sum[4];
@@ -538,6 +715,54 @@ __device__ __forceinline__ void grad_body(const GradJob &jb, const GradArgs &a, 
             f32x4 v = {sum[0][e], sum[1][e], sum[2][e], sum[3][e]};
             *(f32x4 *)(dst + e * 64) = v;
         }
+    }
+}
+
+
+
+// the step's scalars (cfl/models/cfl.py:868-949) from the row sums `sc` of the per-row loss quantities
+__device__ __forceinline__ void write_scalars(float *o, const float *sc, float regsum, int B, int use_threshold,
+                                              float pos_weight, float caffe_margin, float lambda_m, float thr) {
+    const float invB = 1.f / (float)B;
+    const float pw = pos_weight != 0.f ? pos_weight : 1.f;
+    const float lpos = sc[P_BCE_POS] * invB, lneg = sc[P_BCE_NEG] * invB;
+    const float thres = lpos * pw + lneg;
+    float cd = 0.f;
+    if (caffe_margin != 0.f)
+        cd = 0.5f * (sc[P_D_POS] * invB * pw + sc[P_HINGE_NEG] * invB);
+    else if (lambda_m != 0.f)
+        cd = sc[P_D_POS] * invB * lambda_m * pw;
+    float total = regsum + cd;
+    if (use_threshold) total += thres;
+    o[CFL_S_TOTAL] = total;
+    o[CFL_S_REG] = regsum;
+    o[CFL_S_THRES] = thres;
+    o[CFL_S_LOSS_POS] = lpos;
+    o[CFL_S_LOSS_NEG] = lneg;
+    o[CFL_S_CD] = cd;
+    o[CFL_S_ACCURACY] = 0.5f * (sc[P_OK_POS] * invB + sc[P_OK_NEG] * invB);
+    o[CFL_S_MEAN_D_POS] = sc[P_D_POS] * invB;
+    o[CFL_S_MEAN_D_NEG] = sc[P_D_NEG] * invB;
+    o[CFL_S_MEAN_O_POS] = sc[P_O_POS] * invB;
+    o[CFL_S_MEAN_O_NEG] = sc[P_O_NEG] * invB;
+    o[CFL_S_THRESHOLD] = thr;
+    o[CFL_S_DIST_ADAPT_POS] = sc[P_SQRT_POS] * invB;
+    o[CFL_S_DIST_ADAPT_NEG] = sc[P_SQRT_NEG] * invB;
+    o[14] = 0.f;
+    o[15] = 0.f;
+}
+
+// one parameter: flat gradient (+ L2 term) and optional TF-Adam (fused mode, bias / threshold entries)
+__device__ __forceinline__ void fuse_apply1(const GradFuse &f, long long off, float gr, bool reg) {
+    float th = f.theta[off];
+    if (reg && f.reg_const != 0.f) gr = fmaf(f.reg_const, th, gr);
+    f.grad[off] = gr;
+    if (f.m) {
+        float mm = f.m[off], vv = f.v[off];
+        adam1(th, mm, vv, gr, f.lr_t, f.b1, f.b2, f.eps);
+        f.m[off] = mm;
+        f.v[off] = vv;
+        f.theta_out[off] = th;
     }
 }
 
@@ -568,9 +793,44 @@ __device__ void grad_red_block(const GradArgs &a, float *lds) {
             __syncthreads();
             if (lane < 16) lds[wave * 16 + lane] = acc;
             __syncthreads();
-            if (wave == 0 && lane < 16)
-                a.colsum[rr.out_off + idx * 16 + lane] =
-                    (lds[lane] + lds[16 + lane]) + (lds[32 + lane] + lds[48 + lane]);
+            float csum = 0.f;
+            if (wave == 0 && lane < 16) {
+                csum = (lds[lane] + lds[16 + lane]) + (lds[32 + lane] + lds[48 + lane]);
+                a.colsum[rr.out_off + idx * 16 + lane] = csum;
+            }
+            if (a.fuse.on) {
+                // this block owns the whole column: finish the entries that depend on it
+                const GradFuse &f = a.fuse;
+                if (k == 0) {
+                    // row sums of the loss quantities: threshold gradient and the step's scalars
+                    __syncthreads();
+                    if (wave == 0 && lane < 16) lds[64 + lane] = csum;
+                    __syncthreads();
+                    if (wave == 0) {
+                        if (lane == 0) {
+                            const float th = f.theta[f.thr_off];
+                            fuse_apply1(f, f.thr_off, th >= CFL_THR_FLOOR ? lds[64 + P_DTHR] : 0.f, false);
+                        } else {
+                            fuse_apply1(f, f.thr_off + lane, 0.f, false);   // rest of the 64-float threshold slot
+                        }
+                        float rs = 0.f;
+                        for (int b = lane; b < f.nregblocks; b += 64) rs += f.regpart[b];
+                        rs = wave_sum(rs);
+                        if (lane == 0)
+                            write_scalars(f.scalars, lds + 64, 0.5f * f.reg_const * rs, f.B, f.use_threshold,
+                                          f.pos_weight, f.caffe_margin, f.lambda_m, f.thr_copy[0]);
+                    }
+                } else if (f.red_b[k] >= 0 && wave == 0) {
+                    const int c = idx * 16 + lane;
+                    if (lane < 16) {
+                        fuse_apply1(f, f.red_b[k] + c, c < f.red_n[k] ? csum : 0.f, true);
+                    } else if (idx == 0) {
+                        // pad of the bias array up to its 64-float slot: zero gradient
+                        const int cp = f.red_npad[k] + lane - 16;
+                        if (cp < ((f.red_npad[k] + 63) & ~63)) fuse_apply1(f, f.red_b[k] + cp, 0.f, true);
+                    }
+                }
+            }
         } else {
             // kind 1: gate head, l = idx, dVm[l][k] for all k ; kind 2: plain column sums
             for (int kk = 0; kk < rr.K; ++kk) {
@@ -705,6 +965,7 @@ __device__ __forceinline__ void grad_body_x3(const GradJob &jb, const GradArgs &
 #pragma unroll
         for (int t = 0; t < 4; ++t) lds[((wave * NT + nt) * 4 + t) * 64 + lane] = acc[t][nt];
     __syncthreads();
+    CFL_GRAD_FUSED_EPILOGUE()
     if (wave < NT) {
         const int nt = wave;
         f32x4 sum[4];
@@ -756,10 +1017,6 @@ extern "C" __global__ __launch_bounds__(256) void cfl_grad_x3_kernel(GradArgs a)
 //   grad launch (grad_red_block).
 // ---------------------------------------------------------------------------
 #define MID_RB 4
-enum {
-    P_BCE_POS = 0, P_BCE_NEG, P_OK_POS, P_OK_NEG, P_D_POS, P_D_NEG, P_O_POS, P_O_NEG,
-    P_DTHR, P_HINGE_NEG, P_SQRT_POS, P_SQRT_NEG, P_NROWQ = 12
-};
 
 struct MidSide {
     const float *ypart;   // [S][Rpad][npad]
@@ -788,6 +1045,8 @@ struct MidArgs {
     float *scores, *dists;
     float *rowqf;         // fragment-major tile of the per-row loss quantities
     float *thr_copy;      // max(thr, 1e-6) of this step (read by finalize's scalar block)
+    int *zero_i;          // hand-off tickets / flags of the fused weight-gradient launch: cleared here, every step
+    int nzero;
     int nrb, ys;          // row blocks; LDS row stride of Y (floats)
     // regulariser blocks
     const float *theta;
@@ -1029,6 +1288,8 @@ __device__ __forceinline__ void mid_math_reg(const MidArgs &a, const float *Y, c
     }
     if (!valid) dd = 0.f;
     if (blockIdx.x == 0 && tid == 0) a.thr_copy[0] = thr;
+    if (blockIdx.x == 0 && a.zero_i)
+        for (int i = tid; i < a.nzero; i += blockDim.x) a.zero_i[i] = 0;
     {
         const bool pos = valid && is_pos, neg = valid && !is_pos;
         float qv = 0.f;
@@ -1338,6 +1599,8 @@ __global__ __launch_bounds__(64) void cfl_mid_kernel(MidArgs a) {
     if (a.train) { if (tid == 0) a.rowqf[blockIdx.x] = dd; return; }
 #endif
     if (blockIdx.x == 0 && tid == 0) a.thr_copy[0] = thr;
+    if (blockIdx.x == 0 && a.zero_i)
+        for (int i = tid; i < a.nzero; i += blockDim.x) a.zero_i[i] = 0;
     // per-row loss quantities: lane p writes quantity #p of its row (one fragment tile,
     // summed over rows by grad_red_block)
     {
@@ -1625,6 +1888,8 @@ __global__ __launch_bounds__(256) void cfl_mid_row_kernel(MidArgs a) {
     }
     if (!valid) dd = 0.f;
     if (blockIdx.x == 0 && threadIdx.x == 0) a.thr_copy[0] = thr;
+    if (blockIdx.x == 0 && a.zero_i)
+        for (int i = threadIdx.x; i < a.nzero; i += blockDim.x) a.zero_i[i] = 0;
     if (lane < 16) {
         const bool pos = valid && is_pos, neg = valid && !is_pos;
         float qv = 0.f;
@@ -1856,7 +2121,10 @@ __device__ __forceinline__ f32x4 fin_region_grad(const FinArgs &a, const Region 
         }
         default: break;
     }
-    if (rg.reg) gr += a.reg_const * th;
+    if (rg.reg) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) gr[e] = fmaf(a.reg_const, th[e], gr[e]);
+    }
     return gr;
 }
 
@@ -1872,38 +2140,9 @@ extern "C" __global__ __launch_bounds__(256) void cfl_finalize_kernel(FinArgs a)
             if (lane == 0) regsum_s = 0.5f * a.reg_const * s;
         }
         __syncthreads();
-        if (tid == 0) {
-            const float *sc = a.colsum + a.cs_rowq;
-            const float regsum = regsum_s;
-            const float invB = 1.f / (float)a.B;
-            const float pw = a.pos_weight != 0.f ? a.pos_weight : 1.f;
-            const float lpos = sc[P_BCE_POS] * invB, lneg = sc[P_BCE_NEG] * invB;
-            const float thres = lpos * pw + lneg;
-            float cd = 0.f;
-            if (a.caffe_margin != 0.f)
-                cd = 0.5f * (sc[P_D_POS] * invB * pw + sc[P_HINGE_NEG] * invB);
-            else if (a.lambda_m != 0.f)
-                cd = sc[P_D_POS] * invB * a.lambda_m * pw;
-            float total = regsum + cd;
-            if (a.use_threshold) total += thres;
-            float *o = a.scalars;
-            o[CFL_S_TOTAL] = total;
-            o[CFL_S_REG] = regsum;
-            o[CFL_S_THRES] = thres;
-            o[CFL_S_LOSS_POS] = lpos;
-            o[CFL_S_LOSS_NEG] = lneg;
-            o[CFL_S_CD] = cd;
-            o[CFL_S_ACCURACY] = 0.5f * (sc[P_OK_POS] * invB + sc[P_OK_NEG] * invB);
-            o[CFL_S_MEAN_D_POS] = sc[P_D_POS] * invB;
-            o[CFL_S_MEAN_D_NEG] = sc[P_D_NEG] * invB;
-            o[CFL_S_MEAN_O_POS] = sc[P_O_POS] * invB;
-            o[CFL_S_MEAN_O_NEG] = sc[P_O_NEG] * invB;
-            o[CFL_S_THRESHOLD] = a.thr_copy[0];
-            o[CFL_S_DIST_ADAPT_POS] = sc[P_SQRT_POS] * invB;
-            o[CFL_S_DIST_ADAPT_NEG] = sc[P_SQRT_NEG] * invB;
-            o[14] = 0.f;
-            o[15] = 0.f;
-        }
+        if (tid == 0)
+            write_scalars(a.scalars, a.colsum + a.cs_rowq, regsum_s, a.B, a.use_threshold, a.pos_weight,
+                          a.caffe_margin, a.lambda_m, a.thr_copy[0]);
         return;
     }
     // main blocks: one float4 (4 consecutive parameters, same region) per thread; all
@@ -1938,11 +2177,8 @@ extern "C" __global__ __launch_bounds__(256) void cfl_finalize_kernel(FinArgs a)
     }
     *(f32x4 *)(a.grad + base) = gr;
     if (a.adam_m) {  // fused TF-Adam apply (single-GPU step)
-        mm = a.b1 * mm + (1.f - a.b1) * gr;
-        vv = a.b2 * vv + (1.f - a.b2) * gr * gr;
         f32x4 tn = th;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) tn[e] -= a.lr_t * mm[e] / (sqrtf(vv[e]) + a.eps);
+        adam4(tn, mm, vv, gr, a.lr_t, a.b1, a.b2, a.eps);
         *(f32x4 *)(a.adam_m + base) = mm;
         *(f32x4 *)(a.adam_v + base) = vv;
         *(f32x4 *)(a.theta_out + base) = tn;
@@ -1961,10 +2197,7 @@ extern "C" __global__ __launch_bounds__(256) void cfl_adam_kernel(float *theta, 
     for (; i < n4; i += stride) {
         f32x4 g = ((const f32x4 *)grad)[i] * gscale;
         f32x4 mm = ((f32x4 *)m)[i], vv = ((f32x4 *)v)[i], th = ((f32x4 *)theta)[i];
-        mm = b1 * mm + (1.f - b1) * g;
-        vv = b2 * vv + (1.f - b2) * g * g;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) th[k] -= lr_t * mm[k] / (sqrtf(vv[k]) + eps);
+        adam4(th, mm, vv, g, lr_t, b1, b2, eps);
         ((f32x4 *)m)[i] = mm;
         ((f32x4 *)v)[i] = vv;
         ((f32x4 *)theta)[i] = th;
@@ -2052,6 +2285,9 @@ struct Plan {
     size_t ypart[2], dyf[2], cwf[2], wpart[2];
     bool x3;   // bf16x3 matrix-core path for the weight gradient
     bool xcd;  // XCD-aligned launch order of proj / grad (cfl_xcd_aligned)
+    bool fused;       // gradient + Adam finished inside the weight-gradient launch (GradFuse)
+    size_t handoff;   // workspace offset of the hand-off tickets + flags (ints), nhandoff of each
+    int nhandoff;
     int mid_generic, mid_norow;   // debug overrides of the mid kernel choice
     size_t mono_ya, mono_du, mono_duc, rowqf, thr_copy, colsum, regpart, n2, total_floats;
     size_t mid_lds;
@@ -2112,6 +2348,10 @@ static int make_plan(const CflShape *s, int64_t rows, int groups, bool train, Pl
     // (the forward projection always uses the latter: measured, bf16x3 buys nothing there because each
     // W fragment is shared by only two row tiles, so the splits cost what the MFMAs save)
     pl->x3 = debug_env("CFL_EXACT_FP32") <= 0;
+    // fused tail: every gradient entry must be complete inside one (pair of) workgroup(s) -- plain heads (the
+    // weight-norm correction couples a column over all of d), pcd (each side feeds its own head), one encoder
+    pl->fused = train && !s->weight_norm && s->dist_type == CFL_DIST_PCD && !s->directed &&
+                debug_env("CFL_DEBUG_NOFUSE") <= 0;
     pl->P = P;
     pl->Rpad = (int)round_up(pl->R, 256 * P);  // grad: 64-row chunks x 4 waves x P ranges
     // proj d split: one 128-d chunk per wave when that yields enough workgroups
@@ -2163,6 +2403,8 @@ static int make_plan(const CflShape *s, int64_t rows, int groups, bool train, Pl
         pl->wpart[0] = take((size_t)P * hs->npad * s->D);
         pl->wpart[1] = take((size_t)P * hd->npad * s->D);
         pl->regpart = take((size_t)pl->nregblocks);
+        pl->nhandoff = njobs * (s->D / 64);
+        pl->handoff = take(2 * (size_t)pl->nhandoff);
     }
     pl->n2 = take(2 * 6 * 1024);  // squared column norms + gain snapshot of up to 6 heads
     pl->total_floats = off;
@@ -2395,6 +2637,10 @@ static int run_pairs(const CflShape *s, const CflNorm *norm, const CflLossCfg *l
         ma.thr_copy = ws + pl.thr_copy;
         ma.regpart = ws + pl.regpart;
         ma.theta = theta;
+        if (pl.fused && pl.P > 1) {
+            ma.zero_i = (int *)(ws + pl.handoff);
+            ma.nzero = 2 * pl.nhandoff;
+        }
     }
     ma.scores = scores; ma.dists = dists;
     ma.nrb = train ? pl.nrb : (pl.R + MID_RB - 1) / MID_RB;
@@ -2541,6 +2787,36 @@ static int run_pairs(const CflShape *s, const CflNorm *norm, const CflLossCfg *l
             }
         }
         ga.nred = nr; ga.red_total = tot; ga.colsum = ws + pl.colsum;
+        if (pl.fused) {
+            GradFuse &f = ga.fuse;
+            f.on = 1;
+            f.ticket = (int *)(ws + pl.handoff);
+            f.flag = f.ticket + pl.nhandoff;
+            f.theta = theta; f.grad = grad;
+            if (adam) {
+                f.theta_out = adam->theta; f.m = adam->m; f.v = adam->v;
+                f.lr_t = adam->lr_t; f.b1 = adam->b1; f.b2 = adam->b2; f.eps = adam->eps;
+            }
+            f.in_mul = in_mul; f.reg_const = loss->reg_const;
+            int jn = 0;
+            for (int sd = 0; sd < 2; ++sd) {
+                const CflHead *h = side[sd].head;
+                for (int c0 = 0; c0 < h->npad / 16; c0 += 4) f.w_off[jn++] = h->w + (long long)c0 * G * 256;
+            }
+            for (int k = 0; k < CFL_MAX_RED; ++k) f.red_b[k] = -1;
+            // red ranges: 0 = row quantities, 1 + sd = dY of side sd (no weight-norm ranges in fused mode)
+            for (int sd = 0; sd < 2; ++sd) {
+                const CflHead *h = side[sd].head;
+                f.red_b[1 + sd] = h->b;
+                f.red_n[1 + sd] = h->n;
+                f.red_npad[1 + sd] = h->npad;
+            }
+            f.thr_off = pl.lay.thr;
+            f.regpart = ws + pl.regpart; f.nregblocks = nreg_blocks;
+            f.B = (int)rows; f.use_threshold = loss->use_threshold;
+            f.pos_weight = loss->pos_weight; f.caffe_margin = loss->caffe_margin; f.lambda_m = loss->lambda_m;
+            f.scalars = scalars; f.thr_copy = ws + pl.thr_copy;
+        }
         ga.tps = pl.xcd ? (s->D / 64) / pl.S : 0;
         dim3 grid(s->D / 64, pl.P, nj + 1);
         ProfScope ps(st, CFL_K_GRAD);
@@ -2550,6 +2826,10 @@ static int run_pairs(const CflShape *s, const CflNorm *norm, const CflLossCfg *l
             hipLaunchKernelGGL(cfl_grad_kernel, grid, dim3(256), 4 * 4 * 4 * 64 * sizeof(f32x4), st, ga);
     }
 
+    if (pl.fused) {
+        HIP_TRY(hipGetLastError());
+        return CFL_OK;
+    }
     // ---- finalize -----------------------------------------------------------
     fa.total = pl.lay.total; fa.theta = theta; fa.grad = grad;
     fa.colsum = ws + pl.colsum; fa.cs_rowq = pl.cs_rowq; fa.cs_mono = pl.cs_mono; fa.cs_duc = pl.cs_duc;
@@ -2653,6 +2933,48 @@ extern "C" int cfl_pair_train_step_idx(const CflShape *shape, const CflNorm *nor
     IndexSrc is = {table, table_rows, idx4, idx_stride};
     return run_pairs(shape, norm, loss, nullptr, 2, B, theta, grad, scalars, nullptr, nullptr, workspace,
                      workspace_bytes, (hipStream_t)stream, &af, &is);
+}
+
+// A train of consecutive training steps on windows of the (shuffled) pair lists: step i trains rows
+// [head + i*B + lo, head + i*B + lo + rows) of both lists.  This is the inner loop of cfl/bin/train_dist.py:77-87
+// (`for i in t: sess.run([s_optim, ...])`) between two read-backs of the display scalars: the host enqueues the
+// launches of all steps back to back, so the loop is bound by the GPU, not by per-step interpreter work.  TF-Adam's
+// float32 power accumulators (beta1_power / beta2_power) are advanced here; `scalars` / `grad` hold
+// the values of the LAST step.  switched[i] != 0 swaps source and target of step i (data_switch,
+// cfl/input_data.py:575-577); NULL = never.
+extern "C" int cfl_pair_train_steps_idx(const CflShape *shape, const CflNorm *norm, const CflLossCfg *loss,
+                                        const float *table, int64_t table_rows, const int32_t *pos_pairs,
+                                        const int32_t *neg_pairs, int64_t pos_head, int64_t neg_head,
+                                        int64_t batch_rows, int64_t shard_lo, int64_t rows,
+                                        const uint8_t *switched, int64_t nsteps, float *theta, float *m, float *v,
+                                        float *grad, float *scalars, float lr, float beta1, float beta2, float eps,
+                                        float *beta1_power, float *beta2_power, void *workspace,
+                                        size_t workspace_bytes, cfl_stream_t stream) {
+    int rc = check_train_args(loss, grad, scalars);
+    if (rc) return rc;
+    if (!m || !v || !pos_pairs || !neg_pairs || !beta1_power || !beta2_power)
+        return set_err(CFL_E_SHAPE, "NULL pointer");
+    if (nsteps <= 0 || batch_rows <= 0 || rows <= 0 || shard_lo < 0 || shard_lo + rows > batch_rows ||
+        pos_head < 0 || neg_head < 0)
+        return set_err(CFL_E_SHAPE, "bad step window");
+    float b1p = *beta1_power, b2p = *beta2_power;
+    for (int64_t i = 0; i < nsteps; ++i) {
+        const int32_t *ps = pos_pairs + 2 * (pos_head + i * batch_rows + shard_lo);
+        const int32_t *ng = neg_pairs + 2 * (neg_head + i * batch_rows + shard_lo);
+        const int c0 = (switched && switched[i]) ? 1 : 0;
+        const int32_t *idx4[4] = {ps + c0, ps + (1 - c0), ng + c0, ng + (1 - c0)};
+        const float lr_t = lr * sqrtf(1.f - b2p) / (1.f - b1p);
+        AdamFuse af = {theta, m, v, lr_t, beta1, beta2, eps};
+        IndexSrc is = {table, table_rows, idx4, 2};
+        rc = run_pairs(shape, norm, loss, nullptr, 2, rows, theta, grad, scalars, nullptr, nullptr, workspace,
+                       workspace_bytes, (hipStream_t)stream, &af, &is);
+        if (rc) return rc;
+        b1p *= beta1;
+        b2p *= beta2;
+    }
+    *beta1_power = b1p;
+    *beta2_power = b2p;
+    return CFL_OK;
 }
 
 // ---- input gradient of the two heads (needed when the pair rows are not leaves: ConvPCD) --

@@ -215,6 +215,22 @@ int cfl_pair_train_step_idx(const CflShape *shape, const CflNorm *norm, const Cf
                             float *scalars, float lr_t, float beta1, float beta2, float eps, void *workspace,
                             size_t workspace_bytes, cfl_stream_t stream);
 
+/* A train of `nsteps` consecutive training steps over windows of the device copies of the (shuffled) pair lists
+ * pos_pairs / neg_pairs (int32 [n, 2] = (source, target) positions): step i trains rows
+ * [head + i*batch_rows + shard_lo, ... + rows) of both lists (shard_lo / rows select this rank's slice of the global
+ * batch; single GPU: 0 / batch_rows).  Replaces the loop `for i in t: sess.run([summary, [s_optim], ...])` of
+ * cfl/bin/train_dist.py:77-87 between two read-backs of the display scalars.  lr_t is derived per step from the float32
+ * power accumulators *beta1_power / *beta2_power (HOST floats, TF's beta1_power / beta2_power variables), which are
+ * advanced by nsteps.  switched: HOST bytes [nsteps] (data_switch coin flips, cfl/input_data.py:575-577) or NULL.
+ * grad / scalars hold the last step's values.                                                                   */
+int cfl_pair_train_steps_idx(const CflShape *shape, const CflNorm *norm, const CflLossCfg *loss,
+                             const float *table, int64_t table_rows, const int32_t *pos_pairs,
+                             const int32_t *neg_pairs, int64_t pos_head, int64_t neg_head, int64_t batch_rows,
+                             int64_t shard_lo, int64_t rows, const uint8_t *switched, int64_t nsteps, float *theta,
+                             float *m, float *v, float *grad, float *scalars, float lr, float beta1, float beta2,
+                             float eps, float *beta1_power, float *beta2_power, void *workspace,
+                             size_t workspace_bytes, cfl_stream_t stream);
+
 /* The launch plan of a (shape, rows, groups) combination is computed once per process and thread; the tuning /
  * diagnostic overrides it reads from the environment (CFL_EXACT_FP32, CFL_DEBUG_*) are re-read after this call. */
 int cfl_reload_env(void);

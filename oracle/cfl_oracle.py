@@ -510,10 +510,21 @@ class AdamState:
             self.beta1_power = np.float32(self.beta1)
             self.beta2_power = np.float32(self.beta2)
 
+    def hyper(self, dtype):
+        """(lr, beta1, beta2, eps) as the reference's graph holds them: python floats converted to float32 tensors
+        (the variables are float32), THEN taken to the evaluation dtype.  beta2 = 0.999 is not a float32 number
+        (fl32(0.999) = 0.99900001287...), and TensorFlow's Adam kernel forms (1 - beta2) from that tensor, so the
+        v update weighs g^2 by 0.00099998713, not by 0.001: a 1.3e-5 relative difference that a float64
+        evaluation of the same graph must carry too, or Adam's first (sign-like, lr-sized) steps of a
+        high-dimensional batch separate the trajectories at the 1e-5 level."""
+        t = np.dtype(dtype).type
+        return tuple(t(np.float32(x)) for x in (self.lr, self.beta1, self.beta2, self.eps))
+
     def lr_t(self, dtype=np.float32):
         """lr * sqrt(1 - beta2^t) / (1 - beta1^t), evaluated in ``dtype``."""
         t = np.dtype(dtype).type
-        return t(self.lr) * np.sqrt(t(1) - t(self.beta2_power)) / (
+        lr = self.hyper(dtype)[0]
+        return lr * np.sqrt(t(1) - t(self.beta2_power)) / (
             t(1) - t(self.beta1_power))
 
     def apply(self, params: Dict[str, np.ndarray], grads: Dict[str, np.ndarray]):
@@ -523,12 +534,13 @@ class AdamState:
             t = th.dtype.type
             if lr_t is None:
                 lr_t = self.lr_t(th.dtype)
+                _, b1, b2, eps = self.hyper(th.dtype)
             g = np.asarray(g, dtype=th.dtype)
             m = self.m.setdefault(k, np.zeros_like(th))
             v = self.v.setdefault(k, np.zeros_like(th))
-            m[...] = t(self.beta1) * m + t(1 - self.beta1) * g
-            v[...] = t(self.beta2) * v + t(1 - self.beta2) * g * g
-            params[k] = th - lr_t * m / (np.sqrt(v) + t(self.eps))
+            m[...] = b1 * m + (t(1) - b1) * g
+            v[...] = b2 * v + (t(1) - b2) * g * g
+            params[k] = th - lr_t * m / (np.sqrt(v) + eps)
         self.beta1_power = np.float32(self.beta1_power * np.float32(self.beta1))
         self.beta2_power = np.float32(self.beta2_power * np.float32(self.beta2))
 
@@ -536,9 +548,10 @@ class AdamState:
 def adam_tf_flat(theta, m, v, g, lr_t, beta1, beta2, eps):
     """Flat-array form used to check the HIP multi-tensor Adam kernel."""
     t = theta.dtype.type
-    m_new = t(beta1) * m + t(1 - beta1) * g
-    v_new = t(beta2) * v + t(1 - beta2) * g * g
-    theta_new = theta - t(lr_t) * m_new / (np.sqrt(v_new) + t(eps))
+    b1, b2, eps = (t(np.float32(x)) for x in (beta1, beta2, eps))     # float32 tensors in the reference's graph
+    m_new = b1 * m + (t(1) - b1) * g
+    v_new = b2 * v + (t(1) - b2) * g * g
+    theta_new = theta - t(lr_t) * m_new / (np.sqrt(v_new) + eps)
     return theta_new, m_new, v_new
 
 

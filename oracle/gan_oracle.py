@@ -371,7 +371,8 @@ class AdamTF:
     """TF-1 AdamOptimizer over a dict of tensors (cfl/models/cfl.py:1090-1096)."""
 
     def __init__(self, params, lr, beta1, beta2=0.999, eps=1e-8):
-        self.lr, self.b1, self.b2, self.eps = lr, beta1, beta2, eps
+        # the hyper-parameters are float32 tensors in the reference's graph (see oracle/cfl_oracle.py AdamState.hyper)
+        self.lr, self.b1, self.b2, self.eps = (float(np.float32(x)) for x in (lr, beta1, beta2, eps))
         self.m = {k: torch.zeros_like(v) for k, v in params.items()}
         self.v = {k: torch.zeros_like(v) for k, v in params.items()}
         self.b1p, self.b2p = np.float32(beta1), np.float32(beta2)

@@ -23,7 +23,8 @@ Semantics restated (TF 1.x docs):
   conv2d 'SAME'      total pad max((ceil(n/s)-1) s + k - n, 0), the extra one at the bottom / right
   conv2d_transpose   the gradient of that conv2d with respect to its input
   maximum / relu     subgradient at ties: maximum -> first argument gets it (x >= y); relu'(0) = 0
-  AdamOptimizer      lr_t = lr sqrt(1-b2^t)/(1-b1^t); m,v EMA; theta -= lr_t m / (sqrt(v) + eps)
+  AdamOptimizer      lr_t = lr sqrt(1-b2^t)/(1-b1^t); m,v EMA; theta -= lr_t m / (sqrt(v) + eps); lr, b1, b2, eps
+                     carry their float32 values (they are float32 tensors in the reference's graph)
   ExponentialMovingAverage(d)   zero-initialised shadow, shadow -= (1-d)(shadow - value), no debias
 
 A "session run" is modelled by `run_train_ops(ops)`: all gradients are taken first (at the same
@@ -680,7 +681,10 @@ class _MinimizeOp(object):
 
 class AdamOptimizer(object):
     def __init__(self, learning_rate=0.001, beta1=0.9, beta2=0.999, epsilon=1e-8, use_locking=False, name='Adam'):
-        self.lr, self.b1, self.b2, self.eps = learning_rate, beta1, beta2, epsilon
+        # _prepare(): the python floats become tensors and are cast to the variables' dtype -- float32 in the
+        # reference.  This float64 evaluation keeps those float32 VALUES (beta2 = fl32(0.999) = 0.99900001287...),
+        # so that (1 - beta2) is what the reference's fp32 kernel multiplies g^2 with.
+        self.lr, self.b1, self.b2, self.eps = (float(np.float32(x)) for x in (learning_rate, beta1, beta2, epsilon))
         self.index = _S.n_optimizers
         _S.n_optimizers += 1
 

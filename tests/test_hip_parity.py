@@ -358,3 +358,85 @@ def test_bf16x3_matrix_core_path_is_fp32_equivalent(monkeypatch):
     assert errs['x3']['loss'] <= 1e-6 and errs['fp32']['loss'] <= 1e-6, errs
     monkeypatch.undo()
     H.reload_env()
+
+
+@pytest.mark.parametrize('B,D,K,L,reg', [(512, 4096, 3, 20, 0.0), (128, 1024, 5, 12, 1e-3), (16, 256, 1, 7, 1e-3),
+                                          (1024, 2048, 3, 20, 0.0)])
+def test_fused_gradient_tail_equals_finalize_kernel(B, D, K, L, reg, monkeypatch):
+    """The `Dist` step finishes gradient + Adam inside the weight-gradient launch (pairs of row-range workgroups
+    hand their partial tile over with sc1 stores / loads, the row-reduction blocks finish biases, threshold and
+    scalars): 3 launches.  CFL_DEBUG_NOFUSE=1 keeps the 4-launch form with the finalize kernel.  Same arithmetic in
+    the same order => bit-identical weights, Adam slots, gradient and scalars, step after step (300 steps: the
+    hand-off is exercised ~40 000 times per configuration, under the uneven load of a running training loop)."""
+    from cfl import hipabi as H
+    from cfl.engine import PairEngine
+    rng = np.random.RandomState(5)
+    cfg = O.EncoderCfg(D=D, L=L, K=K)
+    params = O.init_encoder_params(cfg, rng, np.float32)
+    pool = [[torch.from_numpy(np.abs(rng.randn(B, D)).astype(np.float32) * 3).cuda() for _ in range(4)]
+            for _ in range(3)]
+    res = {}
+    for mode in ('fused', 'finalize'):
+        monkeypatch.setenv('CFL_DEBUG_NOFUSE', '0' if mode == 'fused' else '1')
+        H.reload_env()
+        eng = PairEngine(D, L, K, norm=H.make_norm(1 / 8.0), loss=H.make_loss(reg_const=reg), params=params,
+                         batch_size=B)
+        H.profile_enable(True)
+        eng.step(pool[0])
+        torch.cuda.synchronize()
+        H.profile_enable(False)
+        kinds = set(H.profile_read())
+        assert ('finalize' in kinds) == (mode == 'finalize'), kinds
+        snaps = []
+        for it in range(300):
+            eng.step(pool[it % 3])
+            if it in (0, 1, 7, 299):
+                snaps.append([t.clone() for t in (eng.theta, eng.m, eng.v, eng.grad, eng.scalars)])
+        # the forward/backward-only entry point (data-parallel path): gradient without Adam
+        eng.fwd_bwd(pool[1])
+        snaps.append([eng.grad.clone(), eng.scalars.clone(), eng.theta.clone()])
+        res[mode] = snaps
+    monkeypatch.undo()
+    H.reload_env()
+    for a, b in zip(res['fused'], res['finalize']):
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
+    assert np.isfinite(res['fused'][-1][1].cpu().numpy()).all()
+
+
+def test_step_windows_equal_single_indexed_steps(tmp_path):
+    """PairEngine.step_windows (one library call for the iterations between two scalar read-backs) == the same
+    iterations as single indexed steps: identical index stream (heads, data_switch coin flips, epoch wraps handled
+    by the caller) and bit-identical training, including TF-Adam's float32 power accumulators."""
+    from cfl import hipabi as H
+    from cfl import input_data
+    from cfl.engine import PairEngine
+    from cfl.synthetic import make_dataset
+    root = make_dataset(str(tmp_path / 'toy'), D=256, n_items=300, n_pos=900, n_neg=700, k=2, latent=6, seed=1)
+    path = str(tmp_path / 'toy' / 'train')
+    a = input_data.SemiDataSet(path, input_size=256, data_switch=True, seed=9)
+    b = input_data.SemiDataSet(path, input_size=256, data_switch=True, seed=9)
+    ra, rb = input_data.ResidentFeatures(a), input_data.ResidentFeatures(b)
+    rng = np.random.RandomState(0)
+    cfg = O.EncoderCfg(D=256, L=6, K=3)
+    params = O.init_encoder_params(cfg, rng, np.float32)
+    mk = lambda: PairEngine(256, 6, 3, norm=H.make_norm(1 / 16.0), loss=H.make_loss(), params=params, lr=2e-3)
+    ea, eb = mk(), mk()
+    B, total, done = 64, 60, 0                       # 700 // 64 = 10 batches per epoch of the shorter list: wraps
+    while done < total:
+        win = ra.next_windows(B, min(7, total - done))
+        if win is None:
+            ea.step(ra.next_indexed(B))
+            n = 1
+        else:
+            ea.step_windows(win)
+            n = win.nsteps
+        for _ in range(n):
+            eb.step(rb.next_indexed(B))
+        done += n
+        assert torch.equal(ea.theta, eb.theta) and torch.equal(ea.scalars, eb.scalars)
+        assert ea.beta1_power == eb.beta1_power and ea.beta2_power == eb.beta2_power
+        assert ea.global_step == eb.global_step
+    assert a.head_labeled_pos == b.head_labeled_pos and a.head_labeled_neg == b.head_labeled_neg
+    assert np.array_equal(a.pairs_pos, b.pairs_pos) and np.array_equal(a.pairs_neg, b.pairs_neg)
+    assert a._rng.rand() == b._rng.rand()
