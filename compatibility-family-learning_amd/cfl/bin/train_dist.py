@@ -32,14 +32,25 @@ class DeferredScalars(object):
     stay hundreds of launches ahead of the GPU, which is what hides the per-epoch reshuffle of the pair lists
     (a serial MT19937 permutation, cfl/input_data.py:543-551) behind queued training steps."""
 
+    SLOTS = 64      # pinned host slots (allocated once per model: hipHostMalloc is slow); more than enough run-ahead
+
     def __init__(self, model, on_scalars):
+        import torch
+        from .. import hipabi as H
         self.model, self.on_scalars, self.pending = model, on_scalars, []
+        pool = getattr(model, '_deferred_pool', None)
+        if pool is None:
+            pool = model._deferred_pool = torch.empty(self.SLOTS, H.S_COUNT + 1, dtype=torch.float32).pin_memory()
+        self.pool, self.next_slot = pool, 0
 
     def record(self, step, val_batch):
         import torch
         from .. import hipabi as H
         eng = self.model.engine
-        host = torch.empty(H.S_COUNT + 1, dtype=torch.float32).pin_memory()
+        while len(self.pending) >= self.SLOTS:
+            self.poll(wait=True, at_most=1)
+        host = self.pool[self.next_slot]
+        self.next_slot = (self.next_slot + 1) % self.SLOTS
         host[:H.S_COUNT].copy_(eng.scalars, non_blocking=True)
         sp = eng.scores(val_batch[0], val_batch[1].pair(0))
         sn = eng.scores(val_batch[0], val_batch[1].pair(1))
@@ -50,9 +61,11 @@ class DeferredScalars(object):
         self.pending.append((step, host, ev, eng._scalar_scale))
         self.poll()
 
-    def poll(self, wait=False):
+    def poll(self, wait=False, at_most=None):
         from .. import hipabi as H
-        while self.pending and (wait or self.pending[0][2].query()):
+        n = 0
+        while self.pending and (wait or self.pending[0][2].query()) and (at_most is None or n < at_most):
+            n += 1
             step, host, ev, scale = self.pending.pop(0)
             ev.synchronize()
             vals = host.numpy()

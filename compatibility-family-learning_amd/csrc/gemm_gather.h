@@ -223,11 +223,20 @@ constexpr int gg_tr_stride(int cols) {
 typedef short gg_s16x4 __attribute__((ext_vector_type(4)));
 typedef short gg_s16x8 __attribute__((ext_vector_type(8)));
 
-template <int MT, int NT, int AMODE, int BMODE, class LoadA, class LoadB, class Store>
+// WM x WN = 4 waves: wave (wm, wn) owns the MT x NT 16x16 tiles at rows (wm MT + mt) 16, columns (wn NT + nt) 16.
+// 4 x 1 (the narrow-output shapes) re-reads every B fragment in all four waves; 2 x 2 with MT = NT = 4 is the
+// 128 x 128 tile of the wide layers: 96 MFMAs per K step and wave against 24 fragment reads (0.25 LDS reads per
+// MFMA instead of 0.625 with the 64 x 64 tile) and every staged / split value feeds 128 outputs instead of 64 --
+// the 64 x 64 tile is bound by the LDS pipe and the staging VALU work, not by the matrix cores.
+template <int WM, int WN, int MT, int NT, int AMODE, int BMODE, class LoadA, class LoadB, class Store>
 __global__ __launch_bounds__(256) void gemm_gather_x3_kernel(int M, int N, int K, int klen, LoadA la,
                                                              LoadB lb, Store st) {
     static_assert(AMODE != GG_SCALAR && BMODE != GG_SCALAR, "bf16x3 path: vector staging modes only");
-    constexpr int TM = 64 * MT, TN = 16 * NT;   // workgroup tile; each wave owns MT x NT 16x16 tiles
+    static_assert(WM * WN == 4, "four waves");
+    constexpr int TM = 16 * WM * MT, TN = 16 * WN * NT;   // workgroup tile
+    constexpr int NPA = TM / 64;                           // 64-row staging passes of A
+    constexpr int NPB = TN >= 64 ? TN / 64 : 1;            // 64-column staging passes of B (narrow B: one partial pass)
+    static_assert(TM % 64 == 0 && (TN < 64 || TN % 64 == 0), "tile shape");
     // LDS images, three bf16 planes each.
     //   VEC_K  operand: [row][k], rows of 32 k + 8 pad (80 bytes); fragment = one ds_read_b128.
     //   VEC_MN operand: [k][row] as it arrives (no transposing stores), 16-column chunks swizzled by bit 3 of k;
@@ -239,16 +248,18 @@ __global__ __launch_bounds__(256) void gemm_gather_x3_kernel(int M, int N, int K
     __shared__ __attribute__((aligned(16))) unsigned short As[3 * APL];
     __shared__ __attribute__((aligned(16))) unsigned short Bs[3 * BPL];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
     const int r16 = lane & 15, q = lane >> 4;
     const int m0 = blockIdx.x * TM, n0 = blockIdx.y * TN;
     const int kbeg = blockIdx.z * klen, kend = min(K, kbeg + klen);
-    // staging work items (8 values each):
+    // staging work items (8 values each), 64 rows / columns x 32 k per pass:
     //   VEC_K : one row / column, 8 consecutive k (two 16-byte gathers)          -> one b128 store per plane
     //   VEC_MN: 4 consecutive rows / columns at k and at k+1 (two 16-byte gathers) -> two b64 stores per plane
     const int lm = tid >> 2, lk = (tid & 3) * 8;
     const int tk = (tid >> 4) * 2, tm = (tid & 15) * 4;
-    const int bk = (tid / (TN / 4)) * 2, bn = (tid % (TN / 4)) * 4;
-    const bool bact = tid < 4 * TN;
+    // B narrower than 64 columns: the threads that exist for it cover all 32 k in one pass
+    const int bk = TN >= 64 ? tk : (tid / (TN / 4)) * 2, bn = TN >= 64 ? tm : (tid % (TN / 4)) * 4;
+    const bool bact = TN >= 64 || tid < 4 * TN;
     gg_f32x4 acc[MT][NT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -258,25 +269,31 @@ __global__ __launch_bounds__(256) void gemm_gather_x3_kernel(int M, int N, int K
     using PA = gg_two_phase<LoadA, true>;
     using PB = gg_two_phase<LoadB, false>;
     // loop-invariant halves of the gather indices
-    typename PA::Fix fa[MT];
+    typename PA::Fix fa[NPA];
 #pragma unroll
-    for (int p = 0; p < MT; ++p) fa[p] = PA::fix(la, m0 + p * 64 + (AT ? tm : lm));
-    const typename PB::Fix fb = PB::fix(lb, n0 + (BT ? bn : lm));
-    auto gather = [&](int k0, gg_f32x4 (&av)[MT][2], gg_f32x4 (&bv)[2]) {
+    for (int p = 0; p < NPA; ++p) fa[p] = PA::fix(la, m0 + p * 64 + (AT ? tm : lm));
+    typename PB::Fix fb[NPB];
+#pragma unroll
+    for (int p = 0; p < NPB; ++p) fb[p] = PB::fix(lb, n0 + p * 64 + (BT ? bn : lm));
+    auto gather = [&](int k0, gg_f32x4 (&av)[NPA][2], gg_f32x4 (&bv)[NPB][2]) {
         const int ka0 = k0 + (AT ? tk : lk), ka1 = ka0 + (AT ? 1 : 4);
         const typename PA::Str sa0 = PA::stream(la, ka0), sa1 = PA::stream(la, ka1);
 #pragma unroll
-        for (int p = 0; p < MT; ++p) {
+        for (int p = 0; p < NPA; ++p) {
             const int m = m0 + p * 64 + (AT ? tm : lm);
             av[p][0] = PA::get(la, fa[p], sa0, m < M && ka0 < kend);
             av[p][1] = PA::get(la, fa[p], sa1, m < M && ka1 < kend);
         }
-        bv[0] = zero; bv[1] = zero;
-        if (bact) {
-            const int kb0 = k0 + (BT ? bk : lk), kb1 = kb0 + (BT ? 1 : 4);
-            const int n = n0 + (BT ? bn : lm);
-            bv[0] = PB::get(lb, fb, PB::stream(lb, kb0), n < N && kb0 < kend);
-            bv[1] = PB::get(lb, fb, PB::stream(lb, kb1), n < N && kb1 < kend);
+        const int kb0 = k0 + (BT ? bk : lk), kb1 = kb0 + (BT ? 1 : 4);
+        const typename PB::Str sb0 = PB::stream(lb, kb0), sb1 = PB::stream(lb, kb1);
+#pragma unroll
+        for (int p = 0; p < NPB; ++p) {
+            bv[p][0] = zero; bv[p][1] = zero;
+            if (bact) {
+                const int n = n0 + p * 64 + (BT ? bn : lm);
+                bv[p][0] = PB::get(lb, fb[p], sb0, n < N && kb0 < kend);
+                bv[p][1] = PB::get(lb, fb[p], sb1, n < N && kb1 < kend);
+            }
         }
     };
     // split the staged values and park the three planes
@@ -323,18 +340,21 @@ __global__ __launch_bounds__(256) void gemm_gather_x3_kernel(int M, int N, int K
         const gg_s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         return __builtin_bit_cast(gg_bf16x8, v);
     };
-    gg_f32x4 av[MT][2], bv[2];
+    gg_f32x4 av[NPA][2], bv[NPB][2];
     if (kbeg < kend) gather(kbeg, av, bv);
     for (int k0 = kbeg; k0 < kend; k0 += 32) {
         __syncthreads();
 #pragma unroll
-        for (int p = 0; p < MT; ++p) {
+        for (int p = 0; p < NPA; ++p) {
             if constexpr (AT) park_mn(As, APL, SA, p * 64 + tm, tk, av[p]);
             else park_k(As, APL, p * 64 + lm, lk, av[p]);
         }
         if (bact) {
-            if constexpr (BT) park_mn(Bs, BPL, SB, bn, bk, bv);
-            else park_k(Bs, BPL, lm, lk, bv);
+#pragma unroll
+            for (int p = 0; p < NPB; ++p) {
+                if constexpr (BT) park_mn(Bs, BPL, SB, p * 64 + bn, bk, bv[p]);
+                else park_k(Bs, BPL, p * 64 + lm, lk, bv[p]);
+            }
         }
         __syncthreads();
         if (k0 + 32 < kend) gather(k0 + 32, av, bv);
@@ -343,13 +363,13 @@ __global__ __launch_bounds__(256) void gemm_gather_x3_kernel(int M, int N, int K
         for (int lv = 0; lv < 3; ++lv) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
-                if constexpr (AT) a[lv][mt] = frag_mn(As, APL, SA, lv, (wave * MT + mt) * 16);
-                else a[lv][mt] = frag_k(As, APL, lv, (wave * MT + mt) * 16);
+                if constexpr (AT) a[lv][mt] = frag_mn(As, APL, SA, lv, (wm * MT + mt) * 16);
+                else a[lv][mt] = frag_k(As, APL, lv, (wm * MT + mt) * 16);
             }
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                if constexpr (BT) b[lv][nt] = frag_mn(Bs, BPL, SB, lv, nt * 16);
-                else b[lv][nt] = frag_k(Bs, BPL, lv, nt * 16);
+                if constexpr (BT) b[lv][nt] = frag_mn(Bs, BPL, SB, lv, (wn * NT + nt) * 16);
+                else b[lv][nt] = frag_k(Bs, BPL, lv, (wn * NT + nt) * 16);
             }
         }
         // small terms first; consecutive MFMAs hit different accumulators
@@ -365,7 +385,7 @@ __global__ __launch_bounds__(256) void gemm_gather_x3_kernel(int M, int N, int K
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const int m = m0 + (wave * MT + mt) * 16 + 4 * q + e, n = n0 + nt * 16 + r16;
+                const int m = m0 + (wm * MT + mt) * 16 + 4 * q + e, n = n0 + (wn * NT + nt) * 16 + r16;
                 if (m < M && n < N) st(m, n, acc[mt][nt][e], (int)blockIdx.z);
             }
 }
@@ -375,6 +395,15 @@ __global__ __launch_bounds__(256) void gemm_gather_x3_kernel(int M, int N, int K
 static inline bool gg_use_x3() {
     static const int v = [] { const char *e = getenv("CFL_EXACT_FP32"); return (e && atoi(e) > 0) ? 0 : 1; }();
     return v != 0;
+}
+
+// 128 x 128 tile (2 x 2 waves of 64 x 64): when both output dimensions fill it and the launch still has enough
+// workgroups for the chip (CFL_DEBUG_NOBIGTILE=1 keeps the 64 x 64 tile)
+static inline bool gg_big_tile(long long M, long long N, int splits) {
+    static const int off = [] { const char *e = getenv("CFL_DEBUG_NOBIGTILE"); return (e && atoi(e) > 0) ? 1 : 0; }();
+    if (off || N < 128 || M < 128) return false;
+    const long long wgs = ((M + 127) / 128) * ((N + 127) / 128) * splits;
+    return wgs >= 512;
 }
 
 // K-range per split (multiple of 16) for about `want` splits; the split count is ceil(K / klen)
@@ -392,16 +421,20 @@ static inline void gemm_gather_modes(int M, int N, int K, int klen, LoadA la, Lo
         if (gg_use_x3()) {
             if (N <= 16) {
                 dim3 grid((M + 255) / 256, (N + 15) / 16, splits);
-                hipLaunchKernelGGL((gemm_gather_x3_kernel<4, 1, AMODE, BMODE, LoadA, LoadB, Store>), grid, dim3(256), 0,
-                                   stream, M, N, K, klen, la, lb, st);
+                hipLaunchKernelGGL((gemm_gather_x3_kernel<4, 1, 4, 1, AMODE, BMODE, LoadA, LoadB, Store>), grid, dim3(256),
+                                   0, stream, M, N, K, klen, la, lb, st);
             } else if (N <= 32) {
                 dim3 grid((M + 127) / 128, (N + 31) / 32, splits);
-                hipLaunchKernelGGL((gemm_gather_x3_kernel<2, 2, AMODE, BMODE, LoadA, LoadB, Store>), grid, dim3(256), 0,
-                                   stream, M, N, K, klen, la, lb, st);
+                hipLaunchKernelGGL((gemm_gather_x3_kernel<4, 1, 2, 2, AMODE, BMODE, LoadA, LoadB, Store>), grid, dim3(256),
+                                   0, stream, M, N, K, klen, la, lb, st);
+            } else if (gg_big_tile(M, N, splits)) {
+                dim3 grid((M + 127) / 128, (N + 127) / 128, splits);
+                hipLaunchKernelGGL((gemm_gather_x3_kernel<2, 2, 4, 4, AMODE, BMODE, LoadA, LoadB, Store>), grid, dim3(256),
+                                   0, stream, M, N, K, klen, la, lb, st);
             } else {
                 dim3 grid((M + 63) / 64, (N + 63) / 64, splits);
-                hipLaunchKernelGGL((gemm_gather_x3_kernel<1, 4, AMODE, BMODE, LoadA, LoadB, Store>), grid, dim3(256), 0,
-                                   stream, M, N, K, klen, la, lb, st);
+                hipLaunchKernelGGL((gemm_gather_x3_kernel<4, 1, 1, 4, AMODE, BMODE, LoadA, LoadB, Store>), grid, dim3(256),
+                                   0, stream, M, N, K, klen, la, lb, st);
             }
             return;
         }
