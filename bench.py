@@ -240,9 +240,11 @@ def cli_loop(args, device):
     from cfl.models.dist import construct_model
     from cfl.ops import normalizer, unnormalizer
     from cfl.synthetic import make_dataset
+    from cfl.engine import quiet_host_threads
     B, D = args.batch_size, args.input_size
     root = tempfile.mkdtemp(prefix='cfl_bench_')
     try:
+        quiet_host_threads()            # what the command-line entry point does first (engine.init_from_env)
         t0 = time.perf_counter()
         make_dataset(os.path.join(root, 'syn'), D=D, n_items=args.cli_items, n_pos=args.cli_pairs,
                      n_neg=args.cli_pairs, splits=(('train', 1.0), ('val', 0.1), ('test', 0.02)))

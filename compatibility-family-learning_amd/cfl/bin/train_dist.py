@@ -11,6 +11,8 @@ import gc
 import logging
 import os
 
+import numpy as np
+
 from tqdm import trange
 
 from .. import engine as dp
@@ -35,13 +37,21 @@ class DeferredScalars(object):
     SLOTS = 64      # pinned host slots (allocated once per model: hipHostMalloc is slow); more than enough run-ahead
 
     def __init__(self, model, on_scalars):
-        import torch
-        from .. import hipabi as H
         self.model, self.on_scalars, self.pending = model, on_scalars, []
-        pool = getattr(model, '_deferred_pool', None)
-        if pool is None:
-            pool = model._deferred_pool = torch.empty(self.SLOTS, H.S_COUNT + 1, dtype=torch.float32).pin_memory()
-        self.pool, self.next_slot = pool, 0
+        self.pool, self.next_slot = None, 0
+
+    def _slot(self, width):
+        """Pinned row [scalars | validation scores of the positive pairs | ... of the negative pairs]."""
+        import torch
+        pool = getattr(self.model, '_deferred_pool', None)
+        if pool is None or pool.shape[1] != width:
+            if self.pending:
+                self.poll(wait=True)
+            pool = self.model._deferred_pool = torch.empty(self.SLOTS, width, dtype=torch.float32).pin_memory()
+        self.pool = pool
+        host = pool[self.next_slot]
+        self.next_slot = (self.next_slot + 1) % self.SLOTS
+        return host
 
     def record(self, step, val_batch):
         import torch
@@ -49,28 +59,32 @@ class DeferredScalars(object):
         eng = self.model.engine
         while len(self.pending) >= self.SLOTS:
             self.poll(wait=True, at_most=1)
-        host = self.pool[self.next_slot]
-        self.next_slot = (self.next_slot + 1) % self.SLOTS
+        table, streams = val_batch
+        n = streams.n
+        host = self._slot(H.S_COUNT + 2 * n)
         host[:H.S_COUNT].copy_(eng.scalars, non_blocking=True)
-        sp = eng.scores(val_batch[0], val_batch[1].pair(0))
-        sn = eng.scores(val_batch[0], val_batch[1].pair(1))
-        acc = 0.5 * ((sp > 0).float().mean() + (sn <= 0).float().mean())
-        host[H.S_COUNT:].copy_(acc.reshape(1), non_blocking=True)
+        # the validation scores travel as they are (2 x n floats); the accuracy is counted on the host when the
+        # slot is read -- no elementwise / reduction launches on the training stream
+        host[H.S_COUNT:H.S_COUNT + n].copy_(eng.scores(table, streams.pair(0)), non_blocking=True)
+        host[H.S_COUNT + n:].copy_(eng.scores(table, streams.pair(1)), non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
-        self.pending.append((step, host, ev, eng._scalar_scale))
+        self.pending.append((step, host, ev, eng._scalar_scale, n))
         self.poll()
 
     def poll(self, wait=False, at_most=None):
         from .. import hipabi as H
-        n = 0
-        while self.pending and (wait or self.pending[0][2].query()) and (at_most is None or n < at_most):
-            n += 1
-            step, host, ev, scale = self.pending.pop(0)
+        k = 0
+        while self.pending and (wait or self.pending[0][2].query()) and (at_most is None or k < at_most):
+            k += 1
+            step, host, ev, scale, n = self.pending.pop(0)
             ev.synchronize()
             vals = host.numpy()
             s = dict(zip(H.SCALAR_NAMES, (float(x) * scale for x in vals[:H.S_COUNT])))
-            self.on_scalars(step, s, float(vals[H.S_COUNT]))
+            # batch_accuracy (cfl/bin/train_dist.py:52-56 of the reference: mean of [s_pos > 0] and [s_neg <= 0])
+            sp, sn = vals[H.S_COUNT:H.S_COUNT + n], vals[H.S_COUNT + n:]
+            acc = 0.5 * (float(np.count_nonzero(sp > 0)) / n + float(np.count_nonzero(sn <= 0)) / n)
+            self.on_scalars(step, s, acc)
 
     def flush(self):
         self.poll(wait=True)
@@ -143,10 +157,11 @@ def train_loop(model, data, aux, batch_size, start_epoch, epochs, log_dir, check
         if scalar_log is not None:
             scalar_log.flush()
         gc.collect()
-        if not chief:
-            continue
-        saver.save(model, os.path.join(checkpoint_dir, 'model'), global_step=e)
+        if chief:
+            saver.save(model, os.path.join(checkpoint_dir, 'model'), global_step=e)
 
+        # evaluation is collective under data parallelism (every rank scores a shard, rank 0 gathers); the two
+        # numbers come back to every rank, so all ranks take the same decisions and only rank 0 writes files
         val_stats = dist_eval(None, model, batch_size, data.val)
         if val_stats.accuracy > stats.best_accuracy:
             test_stats = dist_eval(None, model, batch_size, data.test)
@@ -154,8 +169,9 @@ def train_loop(model, data, aux, batch_size, start_epoch, epochs, log_dir, check
                            e, 1. - train_avg.average, 1. - val_stats.accuracy,
                            1. - test_stats.accuracy, val_stats.auc, test_stats.auc)
             stats.best_accuracy, stats.best_auc, stats.best_epoch = val_stats.accuracy, val_stats.auc, e
-            best_saver.save(model, os.path.join(best_dir, 'model'), global_step=stats.best_epoch)
-            save_best_stats(best_accuracy_path, stats.best_epoch, stats.best_accuracy, stats.best_auc)
+            if chief:
+                best_saver.save(model, os.path.join(best_dir, 'model'), global_step=stats.best_epoch)
+                save_best_stats(best_accuracy_path, stats.best_epoch, stats.best_accuracy, stats.best_auc)
         else:
             logger.warning('epoch %d: avg error = train: %f val: %f', e, 1. - train_avg.average,
                            1. - val_avg.average)

@@ -27,9 +27,11 @@ def rank():
 
 
 def init_from_env():
-    """Under torchrun (WORLD_SIZE > 1 in the environment): bind this process to its GPU and join the RCCL
-    process group.  One process per GPU; called by the CLI entry points before any model is built."""
+    """Called by the CLI entry points before any model is built: caps the host thread pool (quiet_host_threads) and,
+    under torchrun (WORLD_SIZE > 1 in the environment), binds this process to its GPU and joins the RCCL process
+    group.  One process per GPU."""
     import os
+    quiet_host_threads()
     if int(os.environ.get('WORLD_SIZE', '1')) > 1 and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
@@ -62,6 +64,20 @@ def reduce_gradients(flat_grad):
     if n > 1:
         dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM)
     return 1.0 / n
+
+
+def quiet_host_threads(n=4):
+    """The training loop's host side is one launching thread plus the reshuffle worker; torch's intra-op OpenMP pool
+    defaults to one thread per core and its idle threads SPIN after every parallel region (a host-side tensor copy
+    of a few hundred KB is enough).  On a many-core box inside a CPU-quota'd container that spinning alone exhausts
+    the quota and the kernel then freezes every thread of the process -- including the one launching kernels -- for
+    the rest of each 100 ms period (measured: 60 ms stalls, GPU idle).  The command-line entry points cap the pool
+    unless the user chose a size (OMP_NUM_THREADS)."""
+    import os
+    if os.environ.get('OMP_NUM_THREADS'):
+        return
+    if torch.get_num_threads() > n:
+        torch.set_num_threads(n)
 
 
 def shard_rows(n_rows, rank_=None, world=None):

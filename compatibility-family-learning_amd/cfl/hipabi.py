@@ -66,7 +66,7 @@ EXPORTS = ('cfl_version', 'cfl_last_error', 'cfl_layout', 'cfl_workspace_bytes',
            'cfl_gather_rows', 'cfl_profile_enable', 'cfl_profile_read', 'cfl_pair_input_grad',
            'cfl_conv_workspace_bytes', 'cfl_conv2d_wn_fwd', 'cfl_conv2d_wn_bwd',
            'cfl_pair_scores_idx', 'cfl_pair_step_fwd_bwd_idx', 'cfl_pair_train_step_idx', 'cfl_reload_env',
-           'cfl_pair_train_steps_idx')
+           'cfl_pair_train_steps_idx', 'cfl_mt19937_reshuffle')
 
 KERNEL_NAMES = ('colnorm', 'proj', 'mid', 'grad', 'finalize', 'adam', 'gather')
 K_COUNT = 8
@@ -129,6 +129,9 @@ def lib():
         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float,
         C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_void_p, C.c_size_t, C.c_void_p]
     L.cfl_pair_train_steps_idx.restype = C.c_int
+    L.cfl_mt19937_reshuffle.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_int64, C.c_void_p, C.c_int64,
+                                        C.c_void_p, C.c_void_p, C.c_void_p]
+    L.cfl_mt19937_reshuffle.restype = C.c_int
     L.cfl_reload_env.restype = C.c_int
     L.cfl_adam_tf.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                               C.c_int64, C.c_float, C.c_float, C.c_float,
@@ -307,6 +310,23 @@ def pair_train_steps_idx(shape, norm, loss, table, pos_pairs, neg_pairs, pos_hea
         float(beta2), float(eps), C.byref(b1p), C.byref(b2p), workspace.data_ptr(),
         workspace.numel() * workspace.element_size(), _stream()))
     return b1p.value, b2p.value
+
+
+def mt19937_reshuffle(state, rows, want32=False):
+    """(rows[perm], new_state[, int32 copy]) with perm = RandomState.permutation(len(rows)) drawn from the legacy
+    generator `state` (the tuple of RandomState.get_state()); host-only, runs without the interpreter lock."""
+    key = np.array(state[1], dtype=np.uint32)
+    pos = C.c_int32(int(state[2]))
+    rows = np.ascontiguousarray(rows, dtype=np.int64)
+    flat = rows.reshape(rows.shape[0], -1)
+    out = np.empty_like(flat)
+    out32 = np.empty(flat.shape, dtype=np.int32) if want32 else None
+    _check(lib().cfl_mt19937_reshuffle(key.ctypes.data, C.byref(pos), flat.shape[0], flat.ctypes.data, flat.shape[1],
+                                       out.ctypes.data, None, out32.ctypes.data if want32 else None))
+    new_state = (state[0], key, int(pos.value), state[3], state[4])
+    if want32:
+        return out.reshape(rows.shape), new_state, out32.reshape(rows.shape)
+    return out.reshape(rows.shape), new_state
 
 
 def reload_env():

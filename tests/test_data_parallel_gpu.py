@@ -3,6 +3,8 @@ functional coverage of exactly the code the RCCL ranks run, not a measurement):
 
 * PairEngine.step on the two row shards of a global batch == the single-GPU step on the whole batch
   (gradient, scalars, Adam result), for dense and for indexed batches;
+* dist_eval under two ranks (every rank scores a shard of each pair list, rank 0 gathers and computes AUC /
+  accuracy, both ranks get the numbers) == the single-GPU evaluation, bit for bit;
 * `python bench.py --gpus 2` starts its own two ranks, trains shards of one seeded global pool, and prints one
   JSON line with n_gpus == ranks_seen == 2.
 """
@@ -88,6 +90,51 @@ def test_sharded_steps_equal_the_single_gpu_step():
     worst, same = out.get()
     assert same
     assert worst < 2e-6, worst        # summation order differs from one rank: 1e-5 bar of SURVEY 8(e)
+
+
+def _eval_worker(rank, world, port, path, out):
+    for p in (ROOT, os.path.join(ROOT, 'compatibility-family-learning_amd')):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from cfl import engine, hipgan, input_data, ops, utils
+        from cfl.models.dist import construct_model
+        data = input_data.load_data_sets(path, 200, seed=5)
+        model, _ = construct_model(input_shape=(200,), latent_size=6, num_components=2, lr=2e-3, beta1=0.9,
+                                   beta2=0.999, batch_size=50, normalize_value=16.0, reg_const=1e-3,
+                                   data_normalizer=ops.normalizer(16.0, 0.), data=data, seed=3)
+        res = input_data.ResidentFeatures(data.train, model.device)
+        for _ in range(5):
+            model.engine.step(res.next_indexed(50, engine.shard_rows(50)))
+        ev = utils.dist_eval(None, model, 64, data.val)                 # collective: 175 + 174 pairs, ragged shards
+        one = hipgan.auc(utils._resident_scores(model, data.val, False, True),
+                         utils._resident_scores(model, data.val, True, True))
+        out.put((rank, ev.auc, ev.accuracy, one[0], one[1]))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_evaluation_equals_the_single_gpu_evaluation(tmp_path):
+    from cfl.synthetic import make_dataset
+    path = str(tmp_path / 'toy')
+    make_dataset(path, D=200, n_items=300, n_pos=701, n_neg=699, k=2, latent=6, seed=1, scale=4.0)
+    ctx = mp.get_context('spawn')
+    out = ctx.SimpleQueue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_eval_worker, args=(r, 2, port, path, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    got = sorted(out.get() for _ in range(2))
+    for rank, auc, acc, auc1, acc1 in got:
+        assert (auc, acc) == (auc1, acc1), got          # same scores, same sort: the same two numbers
+    assert got[0][1:] == got[1][1:] and 0.0 < got[0][1] < 1.0
 
 
 def test_bench_starts_its_own_ranks():

@@ -133,3 +133,49 @@ def test_bad_feature_file(tmp_path):
     (tmp_path / 'features.b').write_bytes(b'x' * 31)
     with pytest.raises(ValueError):
         D.FeatureFile(str(tmp_path / 'features.b'), DIM)
+
+
+def test_prefetched_reshuffle_is_the_same_stream(tmp_path):
+    """SemiDataSet.prefetch_reshuffle computes the next epoch wrap's `pairs[rng.permutation(n)]` ahead of time on
+    a copy of the generator (worker thread) and adopts it only if nobody drew from the generator in between: the
+    index stream, the shuffled lists and the generator state stay bit-identical to the plain stream -- with equal
+    and unequal list lengths (both lists wrapping in the same batch), data_switch coin flips and foreign draws."""
+    from cfl import input_data
+    from cfl.synthetic import make_dataset
+    for n_pos, n_neg in ((900, 700), (640, 640)):
+        root = str(tmp_path / ('toy%d' % n_neg))
+        make_dataset(root, D=64, n_items=300, n_pos=n_pos, n_neg=n_neg, k=2, latent=6, seed=1)
+        path = os.path.join(root, 'train')
+        for sw in (False, True):
+            a = input_data.SemiDataSet(path, input_size=64, data_switch=sw, seed=9)
+            b = input_data.SemiDataSet(path, input_size=64, data_switch=sw, seed=9)
+            for it in range(200):
+                B = [64, 33, 100][it % 3]
+                pa = a.next_batch_indices(B)
+                a.prefetch_reshuffle(B)
+                pb = b.next_batch_indices(B)
+                assert np.array_equal(pa[0], pb[0]) and np.array_equal(pa[1], pb[1]) and pa[2] == pb[2], (sw, it)
+                if it % 7 == 0:                                  # a foreign draw invalidates the prefetch
+                    assert a._rng.rand() == b._rng.rand()
+            assert np.array_equal(a.pairs_pos, b.pairs_pos) and np.array_equal(a.pairs_neg, b.pairs_neg)
+            assert a._rng.rand() == b._rng.rand()
+
+
+def test_library_reshuffle_equals_numpy_legacy_stream():
+    """cfl_mt19937_reshuffle (host-only C: MT19937 + Fisher-Yates with masked-rejection intervals) against
+    numpy.random.RandomState.permutation, bit for bit, from mid-stream generator states; the generator state after the
+    call equals numpy's (the next draw agrees)."""
+    import __graft_entry__ as g
+    g.build()
+    from cfl import hipabi as H
+    from numpy.random import RandomState
+    for seed, n in ((0, 10), (633, 200000), (9, 1), (77, 65537), (11, 2), (5, 1000)):
+        a, b = RandomState(seed), RandomState(seed)
+        a.rand(seed % 7)
+        b.rand(seed % 7)
+        rows = np.arange(2 * n, dtype=np.int64).reshape(n, 2) * 3 + 1
+        ref = rows[a.permutation(n)]
+        out, st = H.mt19937_reshuffle(b.get_state(), rows)
+        b.set_state(st)
+        assert np.array_equal(out, ref), (seed, n)
+        assert a.randint(0, 10 ** 9) == b.randint(0, 10 ** 9), (seed, n)
