@@ -145,10 +145,15 @@ class PairEngine(object):
 
     # -- the hot path ------------------------------------------------------
     def fwd_bwd(self, batch):
-        """batch = (pos_src, pos_dst, neg_src, neg_dst) device tensors [B, D]."""
-        ws = self._workspace(batch[0].shape[0], 2)
-        H.pair_step_fwd_bwd(self.shape, self.norm, self.loss, batch, self.theta,
-                            self.grad, self.scalars, ws)
+        """batch = (pos_src, pos_dst, neg_src, neg_dst) device tensors [B, D], or (table, IndexStreams)."""
+        if isinstance(batch[1], H.IndexStreams):
+            ws = self._workspace(batch[1].n, 2)
+            H.pair_step_fwd_bwd_idx(self.shape, self.norm, self.loss, batch[0], batch[1], self.theta, self.grad,
+                                    self.scalars, ws)
+        else:
+            ws = self._workspace(batch[0].shape[0], 2)
+            H.pair_step_fwd_bwd(self.shape, self.norm, self.loss, batch, self.theta,
+                                self.grad, self.scalars, ws)
         self._scalar_scale = 1.0
 
     def apply_adam(self, grad_scale=1.0):

@@ -195,6 +195,14 @@ __device__ __forceinline__ const float *row_ptr(const RowSrc &s, int r, int B, i
     return rc < B ? s.x0 + (size_t)rc * D : s.x1 + (size_t)(rc - B) * D;
 }
 
+// table row of batch row r of an indexed source (same clamps as row_ptr)
+__device__ __forceinline__ unsigned row_index(const RowSrc &s, int r, int B, int R) {
+    const int rc = r < R ? r : R - 1;
+    const int *ip = rc < B ? s.ix0 + (size_t)rc * s.istride : s.ix1 + (size_t)(rc - B) * s.istride;
+    const unsigned t = (unsigned)*ip;
+    return t < s.last_row ? t : s.last_row;
+}
+
 __device__ __forceinline__ float wave_sum(float x) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
@@ -494,14 +502,30 @@ __device__ __forceinline__ int grad_dtile(int tps) {
     return ((j / tps) * 8 + k) * tps + j % tps;
 }
 
-// 16-byte write-through store / L1-bypassing load (the `sc1` forms of the hand-off table)
-__device__ __forceinline__ void store_sc1(float *p, f32x4 v) {
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+// A lane's four float4 of a tile (64 floats apart) as write-through stores / L1-bypassing loads -- the `sc1` forms of
+// the hand-off table.  Each direction is ONE asm statement that ends with its own s_waitcnt: the compiler neither
+// tracks the completion of memory instructions inside inline asm nor applies its hazard rules to them (a VALU write
+// to the data registers of a > 64-bit store needs wait states after the store; a register filled by an asm load
+// may be copied or consumed by compiler-scheduled code before a separate wait statement).  With separate statements
+// both happened: the first two dwords of a published float4 were overwritten by the address arithmetic of the next
+// store (found with forced row splits P = 4, 8 at small batches; tests/test_hip_parity.py).
+__device__ __forceinline__ void store4_sc1_wait(float *p, f32x4 v0, f32x4 v1, f32x4 v2, f32x4 v3) {
+    asm volatile(
+        "global_store_dwordx4 %0, %1, off sc1\n\t"
+        "global_store_dwordx4 %0, %2, off offset:256 sc1\n\t"
+        "global_store_dwordx4 %0, %3, off offset:512 sc1\n\t"
+        "global_store_dwordx4 %0, %4, off offset:768 sc1\n\t"
+        "s_waitcnt vmcnt(0)"
+        :: "v"(p), "v"(v0), "v"(v1), "v"(v2), "v"(v3) : "memory");
 }
-__device__ __forceinline__ f32x4 load_sc1(const float *p) {
-    f32x4 v;
-    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
-    return v;
+__device__ __forceinline__ void load4_sc1_wait(const float *p, f32x4 (&o)[4]) {
+    asm volatile(
+        "global_load_dwordx4 %0, %4, off sc1\n\t"
+        "global_load_dwordx4 %1, %4, off offset:256 sc1\n\t"
+        "global_load_dwordx4 %2, %4, off offset:512 sc1\n\t"
+        "global_load_dwordx4 %3, %4, off offset:768 sc1\n\t"
+        "s_waitcnt vmcnt(0)"
+        : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]) : "v"(p) : "memory");
 }
 
 // TF-1.x Adam on one parameter (tensorflow/core/kernels/training_ops: the hyper-parameters are
@@ -557,14 +581,11 @@ __device__ __forceinline__ void grad_fused_tail(const GradArgs &a, int job, int 
     if (ticket < P - 1) {
         // not the last of the P row ranges: publish the partial tile into slab p and leave
         if (wave < NT) {
-            float *dst = slab0 + (size_t)p * pstride + tile_off;
+            f32x4 v[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const f32x4 v = {sum[0][e], sum[1][e], sum[2][e], sum[3][e]};
-                store_sc1(dst + e * 64, v);
-            }
+            for (int e = 0; e < 4; ++e) v[e] = (f32x4){sum[0][e], sum[1][e], sum[2][e], sum[3][e]};
+            store4_sc1_wait(slab0 + (size_t)p * pstride + tile_off, v[0], v[1], v[2], v[3]);   // written through
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (threadIdx.x == 0) atomicAdd(f.flag + slot, 1);                 // agent-scope arrival count
         return;
@@ -600,10 +621,7 @@ __device__ __forceinline__ void grad_fused_tail(const GradArgs &a, int job, int 
                 for (int e = 0; e < 4; ++e) g[e] += (f32x4){sum[0][e], sum[1][e], sum[2][e], sum[3][e]};
             } else {
                 f32x4 part[4];
-                const float *src = slab0 + (size_t)q * pstride + tile_off;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) part[e] = load_sc1(src + e * 64);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                load4_sc1_wait(slab0 + (size_t)q * pstride + tile_off, part);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) g[e] += part[e];
             }
@@ -881,7 +899,7 @@ extern "C" __global__ __launch_bounds__(256) void cfl_grad_kernel(GradArgs a) {
 // and the C/D mapping are those of the fp32 kernel; only the k <-> row assignment inside a
 // 32-row group differs (k = 8*kq + jj <-> row 32*R2 + 8*kq + jj).
 // ---------------------------------------------------------------------------
-template <int NT>
+template <int NT, bool STAGED>
 __device__ __forceinline__ void grad_body_x3(const GradJob &jb, const GradArgs &a, f32x4 *lds) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -904,16 +922,24 @@ __device__ __forceinline__ void grad_body_x3(const GradJob &jb, const GradArgs &
     // 32*R2 + 8*kq + jj: rg = 2*R2 + (kq >> 1), kq' = 2*(kq & 1) + (jj >> 2), j = jj & 3.  The dY
     // fragments are L2 hits that land long before x does, so splitting them costs no wall time.
     const float *dyl = jb.dyf + ((size_t)(kq >> 1) * 256 + (2 * (kq & 1) * 16 + i16) * 4);
+    // The addresses of the workgroup's whole row range are staged in LDS once (the region is reused by the
+    // cross-wave sum below, behind a barrier): with an indexed source each address starts with an index load, and
+    // those loads in front of every 64-row group's x loads -- a dependent global round trip per group -- cost
+    // 2.6 us per launch at the headline shape (tools/idx_probe.py); this way one coalesced round trip is paid, at
+    // the start.  Dense sources take the same route: 16 addresses per lane and group out of two ds_read_b128s
+    // instead of 16 clamp / select / multiply chains in front of the loads.
+    const RowSrc rs = jb.side ? a.rows[1] : a.rows[0];   // (a reference to a.rows[runtime index] would put `a` on the stack)
+    // STAGED <=> rows_wg <= 8192 (64 KiB of LDS); otherwise row_ptr per group.
+    // (staged as element offsets from x0, not as pointers: a pointer loaded from LDS has no known address space and
+    // would turn the x loads into flat loads)
+    const long long *lrow = (const long long *)lds;
+    if (STAGED) {
+        long long *w = (long long *)lds;
+        for (int r = threadIdx.x; r < rows_wg; r += 256) w[r] = row_ptr(rs, p * rows_wg + r, a.B, a.R, a.D) - rs.x0;
+        __syncthreads();
+    }
     for (int p0 = rbeg; p0 < rstop; p0 += 64) {
         f32x4 dyr[2][NT][2], xr[2][8];
-        // row addresses first: with an indexed source they start with a (cached, 4-byte) index load each, which
-        // is in flight together with the dY fragments instead of in front of the x loads
-        const float *xrow[2][8];
-#pragma unroll
-        for (int r2 = 0; r2 < 2; ++r2)
-#pragma unroll
-            for (int jj = 0; jj < 8; ++jj)
-                xrow[r2][jj] = row_ptr(a.rows[jb.side], p0 + 32 * r2 + 8 * kq + jj, a.B, a.R, a.D);
 #pragma unroll
         for (int r2 = 0; r2 < 2; ++r2)
 #pragma unroll
@@ -925,9 +951,14 @@ __device__ __forceinline__ void grad_body_x3(const GradJob &jb, const GradArgs &
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int r2 = 0; r2 < 2; ++r2) {
+            const float *xrow[8];
 #pragma unroll
             for (int jj = 0; jj < 8; ++jj)
-                xr[r2][jj] = *(const f32x4 *)(xrow[r2][jj] + dbase + 4 * i16);
+                xrow[jj] = STAGED ? rs.x0 + lrow[(p0 - p * rows_wg) + 32 * r2 + 8 * kq + jj]
+                                  : row_ptr(rs, p0 + 32 * r2 + 8 * kq + jj, a.B, a.R, a.D);
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj)
+                xr[r2][jj] = *(const f32x4 *)(xrow[jj] + dbase + 4 * i16);
             __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
@@ -960,6 +991,7 @@ __device__ __forceinline__ void grad_body_x3(const GradJob &jb, const GradArgs &
     }
 
     // cross-wave sum and slab store: identical to the fp32 body (same C/D mapping)
+    if (STAGED) __syncthreads();   // every wave is done with the staged addresses
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -985,17 +1017,29 @@ __device__ __forceinline__ void grad_body_x3(const GradJob &jb, const GradArgs &
     }
 }
 
-extern "C" __global__ __launch_bounds__(256) void cfl_grad_x3_kernel(GradArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+// Two kernels rather than one with both bodies: eight inlined instantiations make the compiler keep `a` on the
+// stack (1.5 KiB of scratch per lane, occupancy 1).
+template <bool STAGED>
+__device__ __forceinline__ void grad_x3_kernel_body(const GradArgs &a, char *smem) {
     f32x4 *lds = (f32x4 *)smem;
     if (blockIdx.z == 0) { grad_red_block(a, (float *)smem); return; }
     const GradJob &jb = a.job[blockIdx.z - 1];
     switch (jb.nt) {
-        case 1: grad_body_x3<1>(jb, a, lds); break;
-        case 2: grad_body_x3<2>(jb, a, lds); break;
-        case 3: grad_body_x3<3>(jb, a, lds); break;
-        default: grad_body_x3<4>(jb, a, lds); break;
+        case 1: grad_body_x3<1, STAGED>(jb, a, lds); break;
+        case 2: grad_body_x3<2, STAGED>(jb, a, lds); break;
+        case 3: grad_body_x3<3, STAGED>(jb, a, lds); break;
+        default: grad_body_x3<4, STAGED>(jb, a, lds); break;
     }
+}
+
+extern "C" __global__ __launch_bounds__(256) void cfl_grad_x3_kernel(GradArgs a) {   // Rpad / P <= 8192
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    grad_x3_kernel_body<true>(a, smem);
+}
+
+extern "C" __global__ __launch_bounds__(256) void cfl_grad_x3_longrange_kernel(GradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    grad_x3_kernel_body<false>(a, smem);
 }
 
 // ---------------------------------------------------------------------------
@@ -2820,8 +2864,10 @@ static int run_pairs(const CflShape *s, const CflNorm *norm, const CflLossCfg *l
         ga.tps = pl.xcd ? (s->D / 64) / pl.S : 0;
         dim3 grid(s->D / 64, pl.P, nj + 1);
         ProfScope ps(st, CFL_K_GRAD);
-        if (pl.x3)
+        if (pl.x3 && pl.Rpad / pl.P <= 8192)
             hipLaunchKernelGGL(cfl_grad_x3_kernel, grid, dim3(256), 4 * 4 * 4 * 64 * sizeof(f32x4), st, ga);
+        else if (pl.x3)
+            hipLaunchKernelGGL(cfl_grad_x3_longrange_kernel, grid, dim3(256), 4 * 4 * 4 * 64 * sizeof(f32x4), st, ga);
         else
             hipLaunchKernelGGL(cfl_grad_kernel, grid, dim3(256), 4 * 4 * 4 * 64 * sizeof(f32x4), st, ga);
     }

@@ -360,9 +360,53 @@ def test_bf16x3_matrix_core_path_is_fp32_equivalent(monkeypatch):
     H.reload_env()
 
 
-@pytest.mark.parametrize('B,D,K,L,reg', [(512, 4096, 3, 20, 0.0), (128, 1024, 5, 12, 1e-3), (16, 256, 1, 7, 1e-3),
-                                          (1024, 2048, 3, 20, 0.0)])
-def test_fused_gradient_tail_equals_finalize_kernel(B, D, K, L, reg, monkeypatch):
+def test_long_row_ranges_take_the_unstaged_gradient_kernel(monkeypatch):
+    """The weight-gradient kernel stages the addresses of a workgroup's row range in LDS when the range has at most
+    8192 rows, and computes them per 64-row group otherwise (cfl_grad_x3_longrange_kernel).  One row range over
+    2 x 4700 rows (CFL_DEBUG_P=1) takes the second kernel: gradient against the fp64 oracle, and dense == indexed
+    bit for bit in both kernels."""
+    from cfl import hipabi as H
+    from cfl.engine import PairEngine
+    B, D, K, L = 4700, 128, 2, 6
+    cfg = O.EncoderCfg(D=D, L=L, K=K)
+    rng = np.random.RandomState(11)
+    params = O.init_encoder_params(cfg, rng, np.float32)
+    table = np.abs(rng.randn(3000, D)).astype(np.float32)
+    idx = [rng.randint(0, 3000, size=B).astype(np.int32) for _ in range(4)]
+    batch = [table[i] for i in idx]
+    p64 = {k: v.astype(np.float64) for k, v in params.items()}
+    sc, grads, _, _, _ = O.train_step_loss_and_grads(cfg, O.LossCfg(), p64, 1e-6,
+                                                     tuple(b.astype(np.float64) / 4.0 for b in batch))
+    tdev = torch.from_numpy(table).cuda()
+    streams = H.IndexStreams.from_tensors([torch.from_numpy(i).cuda() for i in idx])
+    dev = [torch.from_numpy(b).cuda() for b in batch]
+    got = {}
+    for mode, env in (('staged', '0'), ('long', '1')):
+        monkeypatch.setenv('CFL_DEBUG_P', env)
+        H.reload_env()
+        e1 = PairEngine(D, L, K, norm=H.make_norm(0.25), params=params, batch_size=B)
+        e2 = PairEngine(D, L, K, norm=H.make_norm(0.25), params=params, batch_size=B)
+        e1.fwd_bwd(dev)
+        e2.fwd_bwd((tdev, streams))
+        assert torch.equal(e1.grad, e2.grad) and torch.equal(e1.scalars, e2.scalars), mode
+        g, _, _ = H.unpack_theta(e1.shape, e1.grad)
+        for k in ('outputs/W', 'proto/W'):
+            err = np.abs(g[k].astype(np.float64) - grads[k]).max() / np.abs(grads[k]).max()
+            # P = 1 accumulates all 9400 rows in one fp32 chain per wave: a few 1e-6 of rounding
+            assert err < 1e-5, (mode, k, err)
+        got[mode] = e1.grad.clone()
+    assert float((got['staged'] - got['long']).abs().max()) <= 1e-5 * float(got['long'].abs().max())
+    monkeypatch.undo()
+    H.reload_env()
+
+
+@pytest.mark.parametrize('B,D,K,L,reg,P', [(512, 4096, 3, 20, 0.0, 0), (128, 1024, 5, 12, 1e-3, 0),
+                                            (16, 256, 1, 7, 1e-3, 0), (1024, 2048, 3, 20, 0.0, 0),
+                                            # forced row splits: short row ranges, many publishers per tile (this is
+                                            # where separate inline-asm store / wait statements lost half a float4)
+                                            (512, 4096, 3, 20, 0.0, 4), (512, 4096, 3, 20, 0.0, 8),
+                                            (1024, 2048, 3, 20, 0.0, 8), (2048, 1024, 3, 20, 1e-3, 0)])
+def test_fused_gradient_tail_equals_finalize_kernel(B, D, K, L, reg, P, monkeypatch):
     """The `Dist` step finishes gradient + Adam inside the weight-gradient launch (pairs of row-range workgroups
     hand their partial tile over with sc1 stores / loads, the row-reduction blocks finish biases, threshold and
     scalars): 3 launches.  CFL_DEBUG_NOFUSE=1 keeps the 4-launch form with the finalize kernel.  Same arithmetic in
@@ -376,6 +420,8 @@ def test_fused_gradient_tail_equals_finalize_kernel(B, D, K, L, reg, monkeypatch
     pool = [[torch.from_numpy(np.abs(rng.randn(B, D)).astype(np.float32) * 3).cuda() for _ in range(4)]
             for _ in range(3)]
     res = {}
+    if P:
+        monkeypatch.setenv('CFL_DEBUG_P', str(P))
     for mode in ('fused', 'finalize'):
         monkeypatch.setenv('CFL_DEBUG_NOFUSE', '0' if mode == 'fused' else '1')
         H.reload_env()
