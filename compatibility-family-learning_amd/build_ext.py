@@ -12,7 +12,7 @@ HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 
 def build(force=False, verbose=False):
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
-    deps = SRCS + [os.path.join(HERE, 'csrc', 'gemm_gather.h'),
+    deps = SRCS + [os.path.join(HERE, 'csrc', 'gemm_gather.h'), os.path.join(HERE, 'csrc', 'conv_halo.h'),
                    os.path.join(os.path.dirname(HERE), 'include', 'cfl_hip.h')]
     if (not force and os.path.exists(OUT)
             and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in deps)):

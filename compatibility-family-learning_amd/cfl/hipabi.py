@@ -64,7 +64,7 @@ CONV_ACTS = {None: 0, 'linear': 0, 'lrelu': 1, 'relu': 2}
 EXPORTS = ('cfl_version', 'cfl_last_error', 'cfl_layout', 'cfl_workspace_bytes',
            'cfl_pair_scores', 'cfl_pair_step_fwd_bwd', 'cfl_pair_train_step', 'cfl_adam_tf',
            'cfl_gather_rows', 'cfl_profile_enable', 'cfl_profile_read', 'cfl_pair_input_grad',
-           'cfl_conv_workspace_bytes', 'cfl_conv2d_wn_fwd', 'cfl_conv2d_wn_bwd',
+           'cfl_conv_workspace_bytes', 'cfl_conv_uses_direct_kernel', 'cfl_conv2d_wn_fwd', 'cfl_conv2d_wn_bwd',
            'cfl_pair_scores_idx', 'cfl_pair_step_fwd_bwd_idx', 'cfl_pair_train_step_idx', 'cfl_reload_env',
            'cfl_pair_train_steps_idx', 'cfl_mt19937_reshuffle')
 
@@ -145,6 +145,7 @@ def lib():
     L.cfl_pair_input_grad.restype = C.c_int
     L.cfl_conv_workspace_bytes.argtypes = [C.POINTER(CflConv)]
     L.cfl_conv_workspace_bytes.restype = C.c_size_t
+    L.cfl_conv_uses_direct_kernel.argtypes = [C.POINTER(CflConv), C.c_int]
     L.cfl_conv2d_wn_fwd.argtypes = [C.POINTER(CflConv)] + [C.c_void_p] * 6 + [C.c_size_t, C.c_void_p]
     L.cfl_conv2d_wn_fwd.restype = C.c_int
     L.cfl_conv2d_wn_bwd.argtypes = ([C.POINTER(CflConv)] + [C.c_void_p] * 5 + [C.c_float] +
@@ -360,6 +361,11 @@ def make_conv(B, H, W, Ci, Co, KH, KW, stride, act=None):
 
 def conv_out_hw(conv):
     return -(-conv.H // conv.stride), -(-conv.W // conv.stride)
+
+
+def conv_uses_direct_kernel(conv, product):
+    """product 'fwd' / 'dx': does this shape run on the 3x3 halo-tile kernel (csrc/conv_halo.h)?"""
+    return lib().cfl_conv_uses_direct_kernel(C.byref(conv), {'fwd': 0, 'dx': 1}[product]) == 1
 
 
 def conv_workspace(conv, device):

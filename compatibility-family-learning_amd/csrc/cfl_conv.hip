@@ -11,6 +11,7 @@
 
 #include "../../include/cfl_hip.h"
 #include "gemm_gather.h"
+#include "conv_halo.h"
 
 extern int cfl_set_err(int code, const char *fmt, ...);
 
@@ -508,11 +509,33 @@ static int wgrad_klen(const ConvGeom &g) {
 }
 static int wgrad_splits(const ConvGeom &g) { return gg_splits((long long)g.B * g.OH * g.OW, wgrad_klen(g)); }
 
+// workspace = [scale Co | n2 Co | pad] + one scratch region shared by the products of a call (they run one after the
+// other on the stream): the split-K slabs of the weight gradient, or the prepared filter planes + split slabs of
+// the halo kernel (conv_halo.h) for the forward pass / the input gradient
+static size_t conv_ws_header_floats(const ConvGeom &g) { return (2 * (size_t)g.Co + 64 + 3) / 4 * 4; }
+static bool halo_shape(const ConvGeom &g) { return g.KH == 3 && g.KW == 3 && g.S == 1; }
+static HaloPlan halo_fwd_plan(const ConvGeom &g) {
+    return halo_shape(g) ? halo_plan(g.B, g.H, g.W, g.Ci, g.Co) : HaloPlan{};
+}
+static HaloPlan halo_dx_plan(const ConvGeom &g) {
+    return halo_shape(g) ? halo_plan(g.B, g.H, g.W, g.Co, g.Ci) : HaloPlan{};
+}
+
 extern "C" size_t cfl_conv_workspace_bytes(const CflConv *c) {
     ConvGeom g;
     if (make_geom(c, &g)) return 0;
     const size_t rows = (size_t)g.KH * g.KW * g.Ci;
-    return (2 * (size_t)g.Co + 64 + (size_t)wgrad_splits(g) * (rows + 4) * g.Co) * sizeof(float);
+    size_t region = (size_t)wgrad_splits(g) * (rows + 4) * g.Co * sizeof(float);
+    const size_t hf = halo_scratch_bytes(halo_fwd_plan(g)), hd = halo_scratch_bytes(halo_dx_plan(g));
+    if (hf > region) region = hf;
+    if (hd > region) region = hd;
+    return conv_ws_header_floats(g) * sizeof(float) + region;
+}
+
+extern "C" int cfl_conv_uses_direct_kernel(const CflConv *c, int product) {
+    ConvGeom g;
+    if (make_geom(c, &g)) return -1;
+    return (product == 0 ? halo_fwd_plan(g) : halo_dx_plan(g)).ok ? 1 : 0;
 }
 
 extern "C" int cfl_conv2d_wn_fwd(const CflConv *c, const float *x, const float *V, const float *gain,
@@ -528,7 +551,11 @@ extern "C" int cfl_conv2d_wn_fwd(const CflConv *c, const float *x, const float *
     const int rows = g.KH * g.KW * g.Ci;
     hipLaunchKernelGGL(conv_scale_kernel, dim3(g.Co), dim3(256), 0, st, V, gain, rows, g.Co, scale, n2);
     const bool vec = (g.Ci % 4 == 0) && (g.Co % 4 == 0);   // 16-byte gathers along the channel dimension
-    if (vec)
+    const HaloPlan hp = halo_fwd_plan(g);
+    if (hp.ok)   // 3x3 stride 1: direct halo-tile kernel (weight-norm scale folded into the prepared filters)
+        halo_conv(hp, g.B, g.H, g.W, g.Ci, g.Co, x, nullptr, 0, V, scale, g.Ci, g.Co, 0, bias, g.act, y,
+                  (float *)workspace + conv_ws_header_floats(g), st);
+    else if (vec)
         gemm_gather_modes<GG_VEC_K, GG_VEC_MN>(g.B * g.OH * g.OW, g.Co, rows, gg_klen(rows, 1), Im2colX{x, g},
                                                FilterKN{V, g.Co}, StoreFwd{y, scale, bias, g.Co, g.act}, st);
     else
@@ -552,13 +579,18 @@ extern "C" int cfl_conv2d_wn_bwd(const CflConv *c, const float *x, const float *
     if (workspace_bytes < cfl_conv_workspace_bytes(c)) return cfl_set_err(CFL_E_WORKSPACE, "conv workspace too small");
     hipStream_t st = (hipStream_t)stream;
     float *scale = (float *)workspace, *n2 = scale + g.Co;
-    float *slab = (float *)workspace + 2 * (size_t)g.Co + 64;
+    float *slab = (float *)workspace + conv_ws_header_floats(g);
     const int rows = g.KH * g.KW * g.Ci;
     const int npix = g.B * g.OH * g.OW;
     hipLaunchKernelGGL(conv_scale_kernel, dim3(g.Co), dim3(256), 0, st, V, gain, rows, g.Co, scale, n2);
     const bool vec = (g.Ci % 4 == 0) && (g.Co % 4 == 0);
     if (dx) {
-        if (g.S == 2 && g.H % 2 == 0 && g.W % 2 == 0) {
+        const HaloPlan hp = halo_dx_plan(g);
+        if (hp.ok) {
+            // 3x3 stride 1: the input gradient is the same direct convolution over dy * act'(y) with the flipped,
+            // scale-weighted filter (conv_halo.h)
+            halo_conv(hp, g.B, g.H, g.W, g.Co, g.Ci, dy, y, g.act, V, scale, g.Ci, g.Co, 1, nullptr, 0, dx, slab, st);
+        } else if (g.S == 2 && g.H % 2 == 0 && g.W % 2 == 0) {
             // four dense sub-problems, one per parity class of the input pixel
             const int KH2 = (g.KH + 1) / 2, KW2 = (g.KW + 1) / 2, H2 = g.H / 2, W2 = g.W / 2;
             const int K2 = KH2 * KW2 * g.Co;

@@ -1,0 +1,459 @@
+// conv_halo.h -- 3x3 stride-1 'SAME' convolution as a direct (halo-tile) bf16x3 matrix-core kernel.
+//
+//   out[b, y, x, n] = sum_{kh, kw, k}  A[b, y + kh - 1, x + kw - 1, k] * Wt[kh*3 + kw][k][n]
+//
+// used for the forward pass of the 3x3 layers (A = x, Wt = g/||V|| * V) and for their input gradient
+// (A = dy * act'(y), Wt[t][co][ci] = scale[co] * V[8 - t][ci][co]: the flipped filter), i.e. the layers of
+// cfl/layers.py:100-187 that the SR generator / discriminator stacks of cfl/models/blocks.py are made of.
+//
+// Why not the gathered GEMM of gemm_gather.h: there every K step of every workgroup re-gathers its A tile from
+// global memory with per-element index arithmetic and splits it into bf16 planes again -- ~700 VALU instructions
+// against 24 MFMAs, and each input value is fetched and split 9 x (N / tile) times.  Here
+//   * a workgroup owns 128 output pixels (8 x 16 of one image, or whole 8 x 8 / 4 x 4 images) x TN channels;
+//   * per 32-channel chunk of the contraction the input HALO tile (10 x 18 pixels ...) is loaded once with plain
+//     16-byte row loads, split once into the three bf16 planes, and parked in LDS; the nine taps then read their
+//     A fragments from it at LDS offsets that differ by a per-tap constant -- no address arithmetic in the loop;
+//   * the filters are prepared once per call (conv_halo_prep_kernel: weight-norm scale folded in, transposed /
+//     flipped, split into planes, [tap][chunk][plane][n][32 k]) so that a tap's B tile is copied global -> LDS as it
+//     is, double-buffered: one barrier per tap step;
+//   * the next chunk's halo is requested three taps ahead into registers, so the global latency is hidden
+//     behind the remaining taps' MFMAs.
+// The inner step is then 6 MT NT MFMAs per wave against (MT + NT) x 3 fragment reads and a 16-byte copy or two.
+// Arithmetic: the same exact three-way bf16 split and six partial products as gemm_gather_x3_kernel (fp32-level).
+// Split-K over channel chunks (gridDim.z) for launches with few output tiles: partial sums go to slabs and
+// conv_halo_reduce_kernel applies the epilogue.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+
+#include "gemm_gather.h"
+
+struct HaloArgs {
+    const float *a;        // [B, H, W, K] fp32 activations (x, or dy)
+    const float *ya;       // dgrad with an activation: y of the layer (slope source), else nullptr
+    float slope_neg, slope_zero;   // act'(pre) from the sign of y: y > 0 ? 1 : (y < 0 ? neg : zero)
+    const unsigned short *wp;      // prepared filter planes
+    float *out;            // [B, H, W, N], or slabs [splits][B*H*W][N] when splits > 1
+    const float *bias;     // epilogue (splits == 1): out = act(acc + bias[n]); nullptr = no bias
+    int act;               // epilogue activation (0 none, 1 lrelu, 2 relu)
+    int B, H, W, K, N, Npad;
+    int tiles_x, tiles_y;  // 128-pixel tiles per image (both 1 for the whole-image tiles)
+    int nchunks;           // K / 32
+    int chunks_per_split;  // gridDim.z = ceil(nchunks / chunks_per_split)
+    size_t slab_stride;    // B*H*W*N when splits > 1
+};
+
+__device__ __forceinline__ float halo_act(float v, int act) {
+    if (act == 1) return v > 0.f ? v : 0.2f * v;
+    if (act == 2) return fmaxf(v, 0.f);
+    return v;
+}
+
+// filters -> planes.  dgrad == 0: value(t, k = ci, n = co) = V[t][ci][co] * scale[co];
+//                     dgrad == 1: value(t, k = co, n = ci) = V[8 - t][ci][co] * scale[co].
+// One thread per (t, chunk, n, octet of k): 8 values -> three 16-byte stores.
+__global__ __launch_bounds__(256) void conv_halo_prep_kernel(const float *V, const float *scale, int Ci, int Co,
+                                                             int dgrad, int K, int N, int Npad,
+                                                             unsigned short *wp) {
+    const int nchunks = K >> 5;
+    const long long total = 9ll * nchunks * Npad * 4;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int oct = (int)(i & 3);
+    long long r = i >> 2;
+    const int n = (int)(r % Npad); r /= Npad;
+    const int kc = (int)(r % nchunks);
+    const int t = (int)(r / nchunks);
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int k = kc * 32 + oct * 8 + e;
+        float x = 0.f;
+        if (n < N) {
+            if (dgrad) x = V[((size_t)(8 - t) * Ci + n) * Co + k] * scale[k];
+            else x = V[((size_t)t * Ci + k) * Co + n] * scale[n];
+        }
+        v[e] = x;
+    }
+    float h[8], m[8], l[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) gg_split3(v[e], h[e], m[e], l[e]);
+    gg_u32x4 ph, pm, pl;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        ph[e] = gg_pack(h[2 * e], h[2 * e + 1]);
+        pm[e] = gg_pack(m[2 * e], m[2 * e + 1]);
+        pl[e] = gg_pack(l[2 * e], l[2 * e + 1]);
+    }
+    const size_t blk = (size_t)(t * nchunks + kc) * 3;
+    unsigned short *d = wp + ((blk * Npad + n) * 32 + oct * 8);
+    const size_t plane = (size_t)Npad * 32;
+    *(gg_u32x4 *)d = ph;
+    *(gg_u32x4 *)(d + plane) = pm;
+    *(gg_u32x4 *)(d + 2 * plane) = pl;
+}
+
+// TW = tile width in pixels: 16 (8 rows of one image), 8 (two 8x8 images) or 4 (eight 4x4 images).
+template <int TN, int WM, int WN, int MT, int NT, int TW, bool SLOPE>
+__global__ __launch_bounds__(256) void conv_halo_x3_kernel(HaloArgs p) {
+    static_assert(WM * WN == 4 && WM * MT * 16 == 128 && WN * NT * 16 == TN, "tile shape");
+    constexpr int TH = TW == 16 ? 8 : TW, IMGS = 128 / (TW * TH);
+    constexpr int HW = TW + 2, HH = TH + 2, HPI = HH * HW, HP = IMGS * HPI;   // halo pixels
+    constexpr int RS = 40;                                    // bf16 per LDS row: 32 k + 8 pad (80 bytes)
+    constexpr int APL = HP * RS, BPL = TN * RS;              // bf16 per plane
+    constexpr int AIT = (HP * 4 + 255) / 256;                // staging items (8 channels of one halo pixel) per thread
+    constexpr int BIT = (TN * 12 + 255) / 256;               // 16-byte pieces of a tap's B tile per thread
+    extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
+    unsigned short *As = smem;                               // [3][HP][RS]
+    unsigned short *Bs = smem + 3 * APL;                     // [2][3][TN][RS]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int r16 = lane & 15, q = lane >> 4;
+
+    // ---- which pixels ----
+    int b0, oy0, ox0;
+    if (IMGS == 1) {
+        const int per = p.tiles_x * p.tiles_y;
+        b0 = blockIdx.x / per;
+        const int r = blockIdx.x - b0 * per;
+        const int ty = r / p.tiles_x;
+        oy0 = ty * TH; ox0 = (r - ty * p.tiles_x) * TW;
+    } else {
+        b0 = blockIdx.x * IMGS; oy0 = 0; ox0 = 0;
+    }
+    const int n0 = blockIdx.y * TN;
+    const int c_beg = blockIdx.z * p.chunks_per_split;
+    const int c_end = min(p.nchunks, c_beg + p.chunks_per_split);
+
+    // ---- loop-invariant halves of the staging addresses ----
+    unsigned aoff[AIT];     // element offset of the item's 8 channels at chunk 0; 0xffffffff = padding / outside
+    int arow[AIT];          // LDS row (halo pixel) of the item, -1 = no item
+#pragma unroll
+    for (int u = 0; u < AIT; ++u) {
+        const int i = tid + 256 * u;
+        const int hp = i >> 2, c8 = (i & 3) * 8;
+        arow[u] = hp < HP ? hp : -1;
+        const int img = hp / HPI, r = hp - img * HPI, hy = r / HW, hx = r - hy * HW;
+        const int b = b0 + img, iy = oy0 + hy - 1, ix = ox0 + hx - 1;
+        const bool ok = hp < HP && b < p.B && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+        aoff[u] = ok ? (unsigned)((((size_t)b * p.H + iy) * p.W + ix) * p.K + c8) : 0xffffffffu;
+    }
+    gg_f32x4 areg[AIT][2], yreg[SLOPE ? AIT : 1][2];
+    auto a_request = [&](int kc) {
+#pragma unroll
+        for (int u = 0; u < AIT; ++u) {
+            const bool ok = aoff[u] != 0xffffffffu;
+            const size_t o = ok ? (size_t)aoff[u] + (size_t)kc * 32 : (size_t)0;   // safe address, selected below
+            areg[u][0] = *(const gg_f32x4 *)(p.a + o);
+            areg[u][1] = *(const gg_f32x4 *)(p.a + o + 4);
+            if (SLOPE) {
+                yreg[u][0] = *(const gg_f32x4 *)(p.ya + o);
+                yreg[u][1] = *(const gg_f32x4 *)(p.ya + o + 4);
+            }
+        }
+    };
+    auto a_park = [&]() {
+#pragma unroll
+        for (int u = 0; u < AIT; ++u) {
+            if (arow[u] < 0) continue;
+            const bool ok = aoff[u] != 0xffffffffu;
+            float h[8], m[8], l[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float v = areg[u][e >> 2][e & 3];
+                if (SLOPE) {
+                    const float yy = yreg[u][e >> 2][e & 3];
+                    v *= yy > 0.f ? 1.f : (yy < 0.f ? p.slope_neg : p.slope_zero);
+                }
+                v = ok ? v : 0.f;
+                gg_split3(v, h[e], m[e], l[e]);
+            }
+            gg_u32x4 ph, pm, pl;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                ph[e] = gg_pack(h[2 * e], h[2 * e + 1]);
+                pm[e] = gg_pack(m[2 * e], m[2 * e + 1]);
+                pl[e] = gg_pack(l[2 * e], l[2 * e + 1]);
+            }
+            unsigned short *d = As + arow[u] * RS + ((tid + 256 * u) & 3) * 8;
+            *(gg_u32x4 *)d = ph;
+            *(gg_u32x4 *)(d + APL) = pm;
+            *(gg_u32x4 *)(d + 2 * APL) = pl;
+        }
+    };
+    // B tile of one (tap, chunk): three planes of TN rows x 64 bytes, contiguous per plane in wp
+    gg_u32x4 breg[BIT];
+    auto b_request = [&](int t, int kc) {
+        const unsigned short *src = p.wp + (size_t)(t * p.nchunks + kc) * 3 * p.Npad * 32;
+#pragma unroll
+        for (int u = 0; u < BIT; ++u) {
+            const int j = tid + 256 * u;
+            const int pl = j / (TN * 4), r = j - pl * (TN * 4);      // plane, 16-byte piece within the plane's tile
+            if ((TN * 12) % 256 == 0 || j < TN * 12)
+                breg[u] = *(const gg_u32x4 *)(src + ((size_t)pl * p.Npad + n0) * 32 + r * 8);
+        }
+    };
+    auto b_park = [&](int buf) {
+        unsigned short *dst = Bs + buf * 3 * BPL;
+#pragma unroll
+        for (int u = 0; u < BIT; ++u) {
+            const int j = tid + 256 * u;
+            const int pl = j / (TN * 4), r = j - pl * (TN * 4);
+            if ((TN * 12) % 256 == 0 || j < TN * 12) *(gg_u32x4 *)(dst + pl * BPL + (r >> 2) * RS + (r & 3) * 8) = breg[u];
+        }
+    };
+
+    // ---- fragment addresses ----
+    int hb[MT];            // halo row of this lane's output pixel in m-tile mt, at tap (0, 0)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int pix = (wm * MT + mt) * 16 + r16;
+        const int img = pix / (TW * TH), r = pix - img * (TW * TH), py = r / TW, px = r - py * TW;
+        hb[mt] = img * HPI + py * HW + px;
+    }
+    gg_f32x4 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (gg_f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // ---- main loop: one step = one tap of one 32-channel chunk.  The fragments of step s+1 are read from LDS into a
+    // second register set WHILE the MFMAs of step s run (a wave's MFMAs only overlap with its own LDS traffic if that
+    // traffic is issued in front of them: with one wave per SIMD nothing else fills the matrix-core time), so
+    //   LDS at the start of step s:  halo of chunk(s) [replaced at the start of the chunk's last tap, below],
+    //                                B[s+1] in buffer (s+1)&1 (parked during step s-1),
+    //   registers:                   F[s] (read during step s-1), breg = B[s+2] (requested during step s-1).
+    const int nsteps = (c_end - c_beg) * 9;
+    gg_bf16x8 fa0[3][MT], fb0[3][NT], fa1[3][MT], fb1[3][NT];
+    auto load_frags = [&](gg_bf16x8 (&fa)[3][MT], gg_bf16x8 (&fb)[3][NT], int tapoff, int buf) {
+        // in the order the products consume them
+        const int order_a[3] = {1, 2, 0}, order_b[3] = {1, 0, 2};
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int la = order_a[i], lb = order_b[i];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+                fa[la][mt] = *(const gg_bf16x8 *)(As + la * APL + (hb[mt] + tapoff) * RS + 8 * q);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                fb[lb][nt] = *(const gg_bf16x8 *)(Bs + (buf * 3 + lb) * BPL + ((wn * NT + nt) * 16 + r16) * RS + 8 * q);
+        }
+    };
+    auto products = [&](const gg_bf16x8 (&fa)[3][MT], const gg_bf16x8 (&fb)[3][NT]) {
+#define HALO_X3(LA, LB)                                                                                 \
+    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) \
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[LA][mt], fb[LB][nt], acc[mt][nt], 0, 0, 0);
+        // small terms first; consecutive MFMAs hit different accumulators
+        HALO_X3(1, 1) HALO_X3(2, 0) HALO_X3(0, 2) HALO_X3(1, 0) HALO_X3(0, 1) HALO_X3(0, 0)
+#undef HALO_X3
+    };
+    // (tap, chunk) of the running step and of the filter request stream (three steps ahead)
+    int t = 0, kc = c_beg, tr = 0, kcr = c_beg;
+    auto tapoff_of = [&](int tt) { const int kh = tt / 3; return kh * HW + (tt - 3 * kh); };
+    auto request_next_b = [&]() {
+        b_request(tr, kcr);
+        if (kcr + 1 < c_end || tr < 8) {         // stays on the last tile once the stream is exhausted
+            if (++tr == 9) { tr = 0; ++kcr; }
+        }
+    };
+    // PF: prefetch the next step's fragments.  The reads are spread between the MFMAs (one ds_read_b128 per group of
+    // MFMAs): issued in one burst after the barrier, the four waves' 96 reads queue up in front of the LDS and every
+    // wave waits at issue until its own are accepted -- measured, the reads then cost their full LDS time on top of
+    // the MFMAs although they are not consumed until the next step.
+    auto step = [&](auto PF, int s, gg_bf16x8 (&fa)[3][MT], gg_bf16x8 (&fb)[3][NT], gg_bf16x8 (&na)[3][MT],
+                    gg_bf16x8 (&nb)[3][NT]) {
+        constexpr bool pf = decltype(PF)::value;
+        if (pf && t == 8) {
+            // the next step opens the next chunk: its halo (requested at tap 5) replaces this one.  Every wave
+            // holds this step's fragments in registers already (waited for before the last barrier).
+            a_park();
+            __syncthreads();
+        }
+        if (t == 5 && kc + 1 < c_end) a_request(kc + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (pf) load_frags(na, nb, tapoff_of(t == 8 ? 0 : t + 1), (s + 1) & 1);
+        // B[s+2] over B[s] (whose fragments are in registers), then the request of B[s+3] into the same registers.
+        // Unconditional, so that they sit in the MFMAs' basic block and can be spread between them: in the last two
+        // steps the park hits a buffer nobody reads again and the request re-reads the last tile.
+        b_park(s & 1);
+        request_next_b();
+        products(fa, fb);
+        {
+            // schedule: the fragment reads over the first 3/4 of the MFMAs, the filter stores (which the compiler
+            // keeps behind the reads: same LDS array) and loads over the last quarter
+            constexpr int reads = pf ? 3 * (MT + NT) : 0, mfmas = 6 * MT * NT;
+            constexpr int head = reads > 0 ? mfmas * 3 / 4 : 0, per_r = head / (reads > 0 ? reads : 1);
+            constexpr int per_w = (mfmas - per_r * reads) / BIT;
+#pragma unroll
+            for (int i = 0; i < reads; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, per_r, 0);   // MFMAs
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);       // one LDS read
+            }
+#pragma unroll
+            for (int i = 0; i < BIT; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, per_w, 0);
+                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);       // one LDS store
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);       // one global load
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // own reads landed, own stores done: safe to let others overwrite
+        __syncthreads();
+        if (++t == 9) { t = 0; ++kc; }
+    };
+    const std::true_type PF1;
+    const std::false_type PF0;
+    if (nsteps > 0) {
+        // prologue: halo of the first chunk, B[0] and B[1] in LDS, B[2] requested, F[0] in registers
+        a_request(c_beg);
+        request_next_b();
+        a_park();
+        b_park(0);
+        request_next_b();                      // nsteps >= 9
+        __syncthreads();
+        load_frags(fa0, fb0, tapoff_of(0), 0);
+        b_park(1);
+        request_next_b();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __syncthreads();
+        // nsteps is a multiple of 9: odd counts end on (fa0, fb0), even counts on (fa1, fb1)
+        int s = 0;
+        for (; s + 2 < nsteps; s += 2) {
+            step(PF1, s, fa0, fb0, fa1, fb1);
+            step(PF1, s + 1, fa1, fb1, fa0, fb0);
+        }
+        if (s + 1 < nsteps) {
+            step(PF1, s, fa0, fb0, fa1, fb1);
+            step(PF0, s + 1, fa1, fb1, fa0, fb0);
+        } else {
+            step(PF0, s, fa0, fb0, fa1, fb1);
+        }
+    }
+
+    // ---- epilogue: C layout col = lane & 15 (channel), rows 4q + e (pixel) ----
+    const bool raw = gridDim.z > 1;
+    float *out = p.out + (raw ? (size_t)blockIdx.z * p.slab_stride : (size_t)0);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int pix = (wm * MT + mt) * 16 + 4 * q + e;
+            const int img = pix / (TW * TH), r = pix - img * (TW * TH), py = r / TW, px = r - py * TW;
+            const int b = b0 + img, oy = oy0 + py, ox = ox0 + px;
+            if (b >= p.B || oy >= p.H || ox >= p.W) continue;
+            float *row = out + (((size_t)b * p.H + oy) * p.W + ox) * p.N;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int n = n0 + (wn * NT + nt) * 16 + r16;
+                if (n >= p.N) continue;
+                float v = acc[mt][nt][e];
+                if (!raw) v = halo_act(v + (p.bias ? p.bias[n] : 0.f), p.act);
+                row[n] = v;
+            }
+        }
+}
+
+// out[i] = act(sum_z slab[z][i] + bias[n]),  4 elements per thread (N % 4 == 0)
+__global__ __launch_bounds__(256) void conv_halo_reduce_kernel(const float *slab, int splits, size_t stride, size_t n4,
+                                                               int N, const float *bias, int act, float *out) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    gg_f32x4 s = *(const gg_f32x4 *)(slab + 4 * i);
+    for (int z = 1; z < splits; ++z) s += *(const gg_f32x4 *)(slab + (size_t)z * stride + 4 * i);
+    const int n = (int)((4 * i) % (size_t)N);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) s[e] = halo_act(s[e] + (bias ? bias[n + e] : 0.f), act);
+    *(gg_f32x4 *)(out + 4 * i) = s;
+}
+
+// ---- host side ----------------------------------------------------------------------------------------------
+struct HaloPlan {
+    bool ok;
+    int tw, tiles_x, tiles_y, ptiles, tn, ntiles, Npad, nchunks, splits, chunks_per_split;
+    size_t wp_bytes, slab_floats;
+};
+
+static inline bool halo_off() {
+    static const int off = [] { const char *e = getenv("CFL_DEBUG_NOHALO"); return (e && atoi(e) > 0) ? 1 : 0; }();
+    return off != 0;
+}
+
+// B images of H x W, contraction over K channels, N output channels
+static inline HaloPlan halo_plan(int B, int H, int W, int K, int N) {
+    HaloPlan pl;
+    memset(&pl, 0, sizeof(pl));
+    if (halo_off() || !gg_use_x3()) return pl;
+    if (K % 32 != 0 || N % 4 != 0 || N < 32) return pl;
+    if (W % 16 == 0 && H % 8 == 0) { pl.tw = 16; pl.tiles_x = W / 16; pl.tiles_y = H / 8; pl.ptiles = B * pl.tiles_x * pl.tiles_y; }
+    else if (W == 8 && H == 8) { pl.tw = 8; pl.tiles_x = pl.tiles_y = 1; pl.ptiles = (B + 1) / 2; }
+    else if (W == 4 && H == 4) { pl.tw = 4; pl.tiles_x = pl.tiles_y = 1; pl.ptiles = (B + 7) / 8; }
+    else return pl;
+    if ((size_t)B * H * W * (size_t)K >= 0xffffffffull) return pl;     // 32-bit element offsets of A
+    pl.tn = N >= 128 ? 128 : (N >= 64 ? 64 : 32);
+    pl.ntiles = (N + pl.tn - 1) / pl.tn;
+    pl.Npad = pl.ntiles * pl.tn;
+    pl.nchunks = K / 32;
+    const long long tiles = (long long)pl.ptiles * pl.ntiles;
+    int want = (int)((512 + tiles - 1) / tiles);
+    if (want > pl.nchunks) want = pl.nchunks;
+    if (want > 32) want = 32;
+    if (want < 1) want = 1;
+    pl.chunks_per_split = (pl.nchunks + want - 1) / want;
+    pl.splits = (pl.nchunks + pl.chunks_per_split - 1) / pl.chunks_per_split;
+    pl.wp_bytes = (size_t)9 * pl.nchunks * 3 * pl.Npad * 32 * sizeof(unsigned short);
+    pl.slab_floats = pl.splits > 1 ? (size_t)pl.splits * B * H * W * N : 0;
+    pl.ok = true;
+    return pl;
+}
+static inline size_t halo_scratch_bytes(const HaloPlan &pl) {
+    return pl.ok ? ((pl.wp_bytes + 15) / 16 * 16 + pl.slab_floats * sizeof(float)) : 0;
+}
+
+template <int TN, int WM, int WN, int MT, int NT, int TW, bool SLOPE>
+static inline void halo_launch_one(const HaloArgs &a, dim3 grid, hipStream_t st) {
+    constexpr int TH = TW == 16 ? 8 : TW, IMGS = 128 / (TW * TH), HP = IMGS * (TH + 2) * (TW + 2);
+    constexpr size_t lds = (size_t)(3 * HP * 40 + 2 * 3 * TN * 40) * sizeof(unsigned short);
+    auto kern = conv_halo_x3_kernel<TN, WM, WN, MT, NT, TW, SLOPE>;
+    static bool attr = false;   // > 64 KiB of dynamic LDS needs the opt-in, once per instantiation
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = true;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, a);
+}
+template <int TW, bool SLOPE>
+static inline void halo_launch_tw(const HaloArgs &a, int tn, dim3 grid, hipStream_t st) {
+    if (tn == 128) halo_launch_one<128, 2, 2, 4, 4, TW, SLOPE>(a, grid, st);
+    else if (tn == 64) halo_launch_one<64, 2, 2, 4, 2, TW, SLOPE>(a, grid, st);
+    else halo_launch_one<32, 4, 1, 2, 2, TW, SLOPE>(a, grid, st);
+}
+
+// scratch: [wp planes | slabs].  V: HWIO filter of the LAYER (Ci, Co = the layer's channels).
+static inline void halo_conv(const HaloPlan &pl, int B, int H, int W, int K, int N, const float *a, const float *ya,
+                             int slope_act, const float *V, const float *scale, int Ci, int Co, int dgrad,
+                             const float *bias, int act, float *out, void *scratch, hipStream_t st) {
+    unsigned short *wp = (unsigned short *)scratch;
+    float *slab = (float *)((char *)scratch + (pl.wp_bytes + 15) / 16 * 16);
+    const long long prep = 9ll * pl.nchunks * pl.Npad * 4;
+    hipLaunchKernelGGL(conv_halo_prep_kernel, dim3((unsigned)((prep + 255) / 256)), dim3(256), 0, st, V, scale, Ci, Co,
+                       dgrad, K, N, pl.Npad, wp);
+    HaloArgs h;
+    memset(&h, 0, sizeof(h));
+    h.a = a; h.ya = (ya && slope_act != 0) ? ya : nullptr;
+    h.slope_neg = slope_act == 1 ? 0.2f : 0.f; h.slope_zero = 0.f;
+    h.wp = wp; h.out = pl.splits > 1 ? slab : out; h.bias = bias; h.act = act;
+    h.B = B; h.H = H; h.W = W; h.K = K; h.N = N; h.Npad = pl.Npad;
+    h.tiles_x = pl.tiles_x; h.tiles_y = pl.tiles_y; h.nchunks = pl.nchunks;
+    h.chunks_per_split = pl.chunks_per_split; h.slab_stride = (size_t)B * H * W * N;
+    const dim3 grid(pl.ptiles, pl.ntiles, pl.splits);
+    const bool slope = h.ya != nullptr;
+    if (pl.tw == 16) { if (slope) halo_launch_tw<16, true>(h, pl.tn, grid, st); else halo_launch_tw<16, false>(h, pl.tn, grid, st); }
+    else if (pl.tw == 8) { if (slope) halo_launch_tw<8, true>(h, pl.tn, grid, st); else halo_launch_tw<8, false>(h, pl.tn, grid, st); }
+    else { if (slope) halo_launch_tw<4, true>(h, pl.tn, grid, st); else halo_launch_tw<4, false>(h, pl.tn, grid, st); }
+    if (pl.splits > 1) {
+        const size_t n4 = h.slab_stride / 4;
+        hipLaunchKernelGGL(conv_halo_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, slab, pl.splits,
+                           h.slab_stride, n4, N, bias, act, out);
+    }
+}

@@ -30,6 +30,19 @@ CONV_CASES = [
     (2, 5, 5, 3, 12, 3, 2, 'lrelu', True),         # odd input with stride 2
     (48, 14, 14, 64, 128, 5, 2, 'lrelu', True),    # training-size conv2: split-K weight gradient
     (48, 28, 28, 1, 64, 5, 2, 'lrelu', True),      # training-size conv1
+    # 3x3 stride 1 with 32-channel multiples: the direct halo-tile kernel (csrc/conv_halo.h) for the forward pass
+    # and the input gradient.  Tile variants: 8x16 pixels of one image / two 8x8 images / eight 4x4 images;
+    # 128 / 64 / 32 output channels per workgroup; with and without the activation slope; split-K over channel
+    # chunks (few output tiles); batch sizes that leave the last multi-image tile partly empty; channel counts
+    # that are not a multiple of the channel tile.
+    (3, 16, 16, 64, 128, 3, 1, 'lrelu', True),     # one image per tile, 128-channel tile both ways
+    (2, 32, 32, 32, 32, 3, 1, 'lrelu', True),      # discriminator stage 1: 32 -> 32, 8 tiles per image
+    (2, 16, 32, 64, 64, 3, 1, None, True),         # 64-channel tile, no slope, non-square image
+    (5, 8, 8, 128, 128, 3, 1, 'lrelu', True),      # two images per tile, odd batch
+    (11, 4, 4, 256, 256, 3, 1, 'relu', True),      # eight images per tile, partial last tile, split-K
+    (3, 4, 4, 64, 512, 3, 1, None, False),         # generator block 1 shape: dx has N = 64, K = 512 (split-K)
+    (2, 8, 8, 96, 160, 3, 1, 'lrelu', True),       # channels not multiples of the tiles (160 -> 2 x 128, 96 -> 128)
+    (2, 16, 16, 32, 36, 3, 1, None, True),         # Co % 32 != 0: forward on the halo kernel, dx on the gathered GEMM
 ]
 
 
@@ -48,6 +61,9 @@ def test_conv2d_wn_fwd_bwd(B, Hh, Ww, Ci, Co, K, S, act, bias):
     ((y * dy).sum() + 0.5 * reg * (tV * tV).sum()).backward()
 
     conv = H.make_conv(B, Hh, Ww, Ci, Co, K, K, S, act)
+    direct = K == 3 and S == 1 and (Hh, Ww) in ((4, 4), (8, 8), (16, 16), (16, 32), (32, 32))
+    assert H.conv_uses_direct_kernel(conv, 'fwd') == (direct and Ci % 32 == 0 and Co % 4 == 0 and Co >= 32)
+    assert H.conv_uses_direct_kernel(conv, 'dx') == (direct and Co % 32 == 0 and Ci % 4 == 0 and Ci >= 32)
     ws = H.conv_workspace(conv, 'cuda')
     f = lambda a: torch.tensor(a, dtype=torch.float32, device='cuda').contiguous()
     dx_, dV_, dg_, db_ = None, None, None, None
