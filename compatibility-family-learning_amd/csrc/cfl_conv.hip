@@ -388,6 +388,35 @@ struct StoreSlab {
     __device__ void operator()(int m, int n, float v, int z) const { slab[z * stride + (size_t)m * ld + n] = v; }
 };
 
+// split-K partial sums of an input-gradient GEMM -> the Store functor of the unsplit launch (4 columns per thread)
+template <class Store>
+__global__ __launch_bounds__(256) void slab_reduce_store_kernel(const float *slab, int splits, size_t stride, int M,
+                                                                int N, Store st) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int n4 = N / 4;
+    if (i >= (size_t)M * n4) return;
+    const int m = (int)(i / n4), n = (int)(i - (size_t)m * n4) * 4;
+    const float *p = slab + (size_t)m * N + n;
+    gg_f32x4 acc = *(const gg_f32x4 *)p;
+    for (int z = 1; z < splits; ++z) acc += *(const gg_f32x4 *)(p + (size_t)z * stride);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) st(m, n + e, acc[e], 0);
+}
+// The stride-2 input gradient of the small feature maps (4x4 ... 16x16 images, 256 ... 64 channels) has a long
+// contraction (taps/4 x Co) and few output tiles: unsplit, a few dozen workgroups walk hundreds of K steps (measured:
+// 0.47 ms for 1.7 GF at the 4x4 stage of config 5).  Splits over K for ~768 workgroups, >= 128 k per split.
+static int dx_s2_splits(const ConvGeom &g) {
+    if (g.Ci % 4 != 0 || g.Co % 4 != 0) return 1;
+    const long long M = (long long)g.B * (g.H / 2) * (g.W / 2), N = g.Ci;
+    const int K2 = ((g.KH + 1) / 2) * ((g.KW + 1) / 2) * g.Co;
+    const long long tiles = ((M + 63) / 64) * ((N + 63) / 64);
+    long long s = (768 + tiles - 1) / tiles;
+    if (s > K2 / 128) s = K2 / 128;
+    if (s > 32) s = 32;
+    if (s < 1) s = 1;
+    return (int)s;
+}
+
 // ---- finalize: dV = s*dW - (s/n^2)(dW.V) V + reg*V ; dg = (dW.V)/n ; db = slab row `rows` ----------
 // one block per output channel (measured: blocking 16 / 64 channels per block for coalescing leaves
 // too few blocks on the narrow layers and is 10x slower)
@@ -529,7 +558,28 @@ extern "C" size_t cfl_conv_workspace_bytes(const CflConv *c) {
     const size_t hf = halo_scratch_bytes(halo_fwd_plan(g)), hd = halo_scratch_bytes(halo_dx_plan(g));
     if (hf > region) region = hf;
     if (hd > region) region = hd;
+    if (g.S == 2 && g.H % 2 == 0 && g.W % 2 == 0) {
+        const int sp = dx_s2_splits(g);
+        const size_t s2 = sp > 1 ? (size_t)sp * g.B * (g.H / 2) * (g.W / 2) * g.Ci * sizeof(float) : 0;
+        if (s2 > region) region = s2;
+    }
     return conv_ws_header_floats(g) * sizeof(float) + region;
+}
+
+// 1x1 layer on a 1x1 image with one or two outputs (the discriminator's real/fake logit): a matrix-vector product.
+// One wave per row; the generic GEMM would put all of K = 2048 on the two workgroups that cover 500 rows.
+__global__ __launch_bounds__(256) void fc_narrow_fwd_kernel(const float *x, const float *V, const float *scale,
+                                                            const float *bias, int M, int K, int N, int act, float *y) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= M) return;
+    const float *xr = x + (size_t)row * K;
+    for (int n = 0; n < N; ++n) {
+        float acc = 0.f;
+        for (int k = lane; k < K; k += 64) acc = fmaf(xr[k], V[(size_t)k * N + n], acc);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+        if (lane == 0) y[(size_t)row * N + n] = act_apply(acc * scale[n] + (bias ? bias[n] : 0.f), act);
+    }
 }
 
 extern "C" int cfl_conv_uses_direct_kernel(const CflConv *c, int product) {
@@ -552,7 +602,10 @@ extern "C" int cfl_conv2d_wn_fwd(const CflConv *c, const float *x, const float *
     hipLaunchKernelGGL(conv_scale_kernel, dim3(g.Co), dim3(256), 0, st, V, gain, rows, g.Co, scale, n2);
     const bool vec = (g.Ci % 4 == 0) && (g.Co % 4 == 0);   // 16-byte gathers along the channel dimension
     const HaloPlan hp = halo_fwd_plan(g);
-    if (hp.ok)   // 3x3 stride 1: direct halo-tile kernel (weight-norm scale folded into the prepared filters)
+    if (g.KH == 1 && g.KW == 1 && g.H == 1 && g.W == 1 && g.S == 1 && g.Co <= 2)
+        hipLaunchKernelGGL(fc_narrow_fwd_kernel, dim3((g.B + 3) / 4), dim3(256), 0, st, x, V, scale, bias, g.B, g.Ci,
+                           g.Co, g.act, y);
+    else if (hp.ok)   // 3x3 stride 1: direct halo-tile kernel (weight-norm scale folded into the prepared filters)
         halo_conv(hp, g.B, g.H, g.W, g.Ci, g.Co, x, nullptr, 0, V, scale, g.Ci, g.Co, 0, bias, g.act, y,
                   (float *)workspace + conv_ws_header_floats(g), st);
     else if (vec)
@@ -601,7 +654,15 @@ extern "C" int cfl_conv2d_wn_bwd(const CflConv *c, const float *x, const float *
                     DyGatherS2 fa{dy, y, scale, g, ph, pw, oh0, ow0, KH2, KW2, H2, W2, dKW2, dH2, dW2};
                     FilterTS2 fb{V, g, oh0, ow0, KW2, dKW2};
                     StoreS2 fs{dx, g.Ci, g.H, g.W, H2, W2, ph, pw, dH2, dW2};
-                    if (g.Co % 4 == 0)
+                    const int sp = dx_s2_splits(g);
+                    if (g.Co % 4 == 0 && sp > 1) {
+                        const int M2 = g.B * H2 * W2, klen = gg_klen(K2, sp), nsp = gg_splits(K2, klen);
+                        const size_t sstride = (size_t)M2 * g.Ci;
+                        gemm_gather_modes<GG_VEC_K, GG_VEC_K>(M2, g.Ci, K2, klen, fa, fb, StoreSlab{slab, sstride, g.Ci}, st);
+                        const size_t items = (size_t)M2 * (g.Ci / 4);
+                        hipLaunchKernelGGL(slab_reduce_store_kernel<StoreS2>, dim3((unsigned)((items + 255) / 256)),
+                                           dim3(256), 0, st, slab, nsp, sstride, M2, g.Ci, fs);
+                    } else if (g.Co % 4 == 0)
                         gemm_gather_modes<GG_VEC_K, GG_VEC_K>(g.B * H2 * W2, g.Ci, K2, gg_klen(K2, 1), fa, fb, fs, st);
                     else
                         gemm_gather(g.B * H2 * W2, g.Ci, K2, gg_klen(K2, 1), fa, fb, fs, st);
