@@ -520,6 +520,97 @@ __global__ __launch_bounds__(256) void conv_bgrad_kernel(const float *dy, const 
     if (threadIdx.x == 0) db[co] = red[0];
 }
 
+// ---- coalesced forms for the large filters ---------------------------------------------------------------------
+// The per-channel kernels above walk a filter column (stride Co floats: one 4-byte element per 64-byte sector); fine
+// for a 288 x 32 filter, 43 us per call for the generator's 4608 x 1024 one, three calls per layer and step.  These
+// read rows: a block owns 64 channels x a chunk of rows (4 row lanes x 64 consecutive channels per pass), per-chunk
+// partial sums go through `part` [chunks][Co] and a per-channel pass finishes.  Fixed summation order.
+#define CFL_COL_CHUNKS 16
+__global__ __launch_bounds__(256) void conv_sumsq_partial_kernel(const float *V, int rows, int Co, int rpc, float *part) {
+    __shared__ float red[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+    const int r0 = blockIdx.y * rpc, r1 = min(rows, r0 + rpc);
+    float acc = 0.f;
+    if (c < Co)
+        for (int r = r0 + rl; r < r1; r += 4) { const float v = V[(size_t)r * Co + c]; acc = fmaf(v, v, acc); }
+    red[rl][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (rl == 0 && c < Co) part[(size_t)blockIdx.y * Co + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+__global__ __launch_bounds__(256) void conv_scale_final_kernel(const float *part, int chunks, const float *g, int Co,
+                                                               float *scale, float *n2out) {
+    const int co = blockIdx.x * 256 + threadIdx.x;
+    if (co >= Co) return;
+    float t = 0.f;
+    for (int z = 0; z < chunks; ++z) t += part[(size_t)z * Co + co];
+    const float n2 = fmaxf(t, 1e-12f);
+    n2out[co] = n2;
+    scale[co] = (g ? g[co] : 1.f) * rsqrtf(n2);
+}
+// dV := sum of the slab groups (parked), part[chunk][co] = sum_r dW V over the chunk's rows
+__global__ __launch_bounds__(256) void conv_wdot_partial_kernel(const float *slab, int splits, size_t stride,
+                                                                const float *V, int rows, int Co, int rpc, float *dV,
+                                                                float *part) {
+    __shared__ float red[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+    const int r0 = blockIdx.y * rpc, r1 = min(rows, r0 + rpc);
+    float acc = 0.f;
+    if (c < Co)
+        for (int r = r0 + rl; r < r1; r += 4) {
+            const size_t o = (size_t)r * Co + c;
+            float dw = 0.f;
+            for (int z = 0; z < splits; ++z) dw += slab[z * stride + o];
+            dV[o] = dw;
+            acc = fmaf(dw, V[o], acc);
+        }
+    red[rl][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (rl == 0 && c < Co) part[(size_t)blockIdx.y * Co + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+// c = sum of the partials: dg, db (slab row `rows`), and the factor of V in dV, left in part[0][co]
+__global__ __launch_bounds__(256) void conv_wdot_final_kernel(float *part, int chunks, const float *slab, int splits,
+                                                              size_t stride, const float *scale, const float *n2,
+                                                              int rows, int Co, float reg, float *dg, float *db) {
+    const int co = blockIdx.x * 256 + threadIdx.x;
+    if (co >= Co) return;
+    float c = 0.f;
+    for (int z = 0; z < chunks; ++z) c += part[(size_t)z * Co + co];
+    const float s = scale[co], nn = n2[co];
+    if (dg) dg[co] = c * rsqrtf(nn);
+    if (db) {
+        float t = 0.f;
+        for (int z = 0; z < splits; ++z) t += slab[z * stride + (size_t)rows * Co + co];
+        db[co] = t;
+    }
+    part[co] = reg - (s / nn) * c;
+}
+// dV = s dW + (reg - (s/n^2) c) V, 4 elements per thread (Co % 4 == 0)
+__global__ __launch_bounds__(256) void conv_wapply_kernel(const float *V, const float *scale, const float *vfac,
+                                                          size_t n4, int Co, float *dV) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const int co = (int)((4 * i) % (size_t)Co);
+    const gg_f32x4 dw = *(const gg_f32x4 *)(dV + 4 * i), v = *(const gg_f32x4 *)(V + 4 * i);
+    const gg_f32x4 s = *(const gg_f32x4 *)(scale + co), f = *(const gg_f32x4 *)(vfac + co);
+    gg_f32x4 r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r[e] = s[e] * dw[e] + f[e] * v[e];
+    *(gg_f32x4 *)(dV + 4 * i) = r;
+}
+// (measured with rocprofv3 on the config-5 step: below ~10^6 elements the one-launch per-channel kernels win)
+static bool conv_big_filter(int rows, int Co) { return (long long)rows * Co >= (1 << 20) && Co % 4 == 0; }
+static int conv_col_rpc(int rows) { return (rows + CFL_COL_CHUNKS - 1) / CFL_COL_CHUNKS; }
+static void conv_scale(const float *V, const float *gain, int rows, int Co, float *scale, float *n2, float *part,
+                       hipStream_t st) {
+    if (!conv_big_filter(rows, Co)) {
+        hipLaunchKernelGGL(conv_scale_kernel, dim3(Co), dim3(256), 0, st, V, gain, rows, Co, scale, n2);
+        return;
+    }
+    const int rpc = conv_col_rpc(rows), chunks = (rows + rpc - 1) / rpc;
+    hipLaunchKernelGGL(conv_sumsq_partial_kernel, dim3((Co + 63) / 64, chunks), dim3(256), 0, st, V, rows, Co, rpc, part);
+    hipLaunchKernelGGL(conv_scale_final_kernel, dim3((Co + 255) / 256), dim3(256), 0, st, part, chunks, gain, Co, scale, n2);
+}
+
 // ---- C ABI --------------------------------------------------------------------------------
 // split-K of the weight-gradient GEMM (M = taps*Ci + 4, N = Co, K = pixels): enough splits for ~3072
 // workgroups given the output tile the GEMM will pick for this N, at least 512 pixels per split, <= 256 slabs
@@ -541,7 +632,7 @@ static int wgrad_splits(const ConvGeom &g) { return gg_splits((long long)g.B * g
 // workspace = [scale Co | n2 Co | pad] + one scratch region shared by the products of a call (they run one after the
 // other on the stream): the split-K slabs of the weight gradient, or the prepared filter planes + split slabs of
 // the halo kernel (conv_halo.h) for the forward pass / the input gradient
-static size_t conv_ws_header_floats(const ConvGeom &g) { return (2 * (size_t)g.Co + 64 + 3) / 4 * 4; }
+static size_t conv_ws_header_floats(const ConvGeom &g) { return ((2 + CFL_COL_CHUNKS) * (size_t)g.Co + 64 + 3) / 4 * 4; }
 static bool halo_shape(const ConvGeom &g) { return g.KH == 3 && g.KW == 3 && g.S == 1; }
 static HaloPlan halo_fwd_plan(const ConvGeom &g) {
     return halo_shape(g) ? halo_plan(g.B, g.H, g.W, g.Ci, g.Co) : HaloPlan{};
@@ -599,7 +690,7 @@ extern "C" int cfl_conv2d_wn_fwd(const CflConv *c, const float *x, const float *
     hipStream_t st = (hipStream_t)stream;
     float *scale = (float *)workspace, *n2 = scale + g.Co;
     const int rows = g.KH * g.KW * g.Ci;
-    hipLaunchKernelGGL(conv_scale_kernel, dim3(g.Co), dim3(256), 0, st, V, gain, rows, g.Co, scale, n2);
+    conv_scale(V, gain, rows, g.Co, scale, n2, n2 + g.Co, st);
     const bool vec = (g.Ci % 4 == 0) && (g.Co % 4 == 0);   // 16-byte gathers along the channel dimension
     const HaloPlan hp = halo_fwd_plan(g);
     if (g.KH == 1 && g.KW == 1 && g.H == 1 && g.W == 1 && g.S == 1 && g.Co <= 2)
@@ -635,7 +726,7 @@ extern "C" int cfl_conv2d_wn_bwd(const CflConv *c, const float *x, const float *
     float *slab = (float *)workspace + conv_ws_header_floats(g);
     const int rows = g.KH * g.KW * g.Ci;
     const int npix = g.B * g.OH * g.OW;
-    hipLaunchKernelGGL(conv_scale_kernel, dim3(g.Co), dim3(256), 0, st, V, gain, rows, g.Co, scale, n2);
+    conv_scale(V, gain, rows, g.Co, scale, n2, n2 + g.Co, st);
     const bool vec = (g.Ci % 4 == 0) && (g.Co % 4 == 0);
     if (dx) {
         const HaloPlan hp = halo_dx_plan(g);
@@ -687,8 +778,19 @@ extern "C" int cfl_conv2d_wn_bwd(const CflConv *c, const float *x, const float *
                         StoreSlab{slab, sstride, g.Co}, st);
         size_t gstride;
         const int groups = slab_presum(slab, splits, sstride, (size_t)(rows + 1) * g.Co, &gstride, st);
-        hipLaunchKernelGGL(conv_wfinal_kernel, dim3(g.Co), dim3(256), 0, st, slab, groups, gstride, V, scale, n2, rows,
-                           g.Co, reg_const, dV, gain ? dg : nullptr, db);
+        if (conv_big_filter(rows, g.Co)) {
+            float *part = n2 + g.Co;
+            const int rpc = conv_col_rpc(rows), chunks = (rows + rpc - 1) / rpc;
+            hipLaunchKernelGGL(conv_wdot_partial_kernel, dim3((g.Co + 63) / 64, chunks), dim3(256), 0, st, slab, groups,
+                               gstride, V, rows, g.Co, rpc, dV, part);
+            hipLaunchKernelGGL(conv_wdot_final_kernel, dim3((g.Co + 255) / 256), dim3(256), 0, st, part, chunks, slab,
+                               groups, gstride, scale, n2, rows, g.Co, reg_const, gain ? dg : nullptr, db);
+            const size_t n4 = (size_t)rows * g.Co / 4;
+            hipLaunchKernelGGL(conv_wapply_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, V, scale, part, n4,
+                               g.Co, dV);
+        } else
+            hipLaunchKernelGGL(conv_wfinal_kernel, dim3(g.Co), dim3(256), 0, st, slab, groups, gstride, V, scale, n2, rows,
+                               g.Co, reg_const, dV, gain ? dg : nullptr, db);
     } else if (db) {
         hipLaunchKernelGGL(conv_bgrad_kernel, dim3(g.Co), dim3(256), 0, st, dy, y, npix, g.Co, g.act, db);
     }

@@ -43,6 +43,7 @@ CONV_CASES = [
     (3, 4, 4, 64, 512, 3, 1, None, False),         # generator block 1 shape: dx has N = 64, K = 512 (split-K)
     (2, 8, 8, 96, 160, 3, 1, 'lrelu', True),       # channels not multiples of the tiles (160 -> 2 x 128, 96 -> 128)
     (2, 16, 16, 32, 36, 3, 1, None, True),         # Co % 32 != 0: forward on the halo kernel, dx on the gathered GEMM
+    (2, 4, 4, 256, 512, 3, 1, None, True),         # > 2^20 filter elements: row-wise (coalesced) scale / weight-norm finalisation
 ]
 
 

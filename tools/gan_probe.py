@@ -22,3 +22,9 @@ n = int(os.environ.get('N', 5))
 for _ in range(n): ph.step(*batch)
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
 print('MrCGAN step B=%d: %.1f ms -> %.1f images/s' % (B, dt * 1e3, B / dt), ph.read_scalars())
+# host side alone: how long does the python loop take to ENQUEUE a step (the stream is left to drain afterwards)
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(n): ph.step(*batch)
+host = (time.perf_counter() - t0) / n
+torch.cuda.synchronize(); both = (time.perf_counter() - t0) / n
+print('host enqueue %.1f ms/step, with drain %.1f ms/step' % (host * 1e3, both * 1e3))
