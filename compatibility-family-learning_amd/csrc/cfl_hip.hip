@@ -451,14 +451,14 @@ struct RedRange {
 // Fused tail of the weight-gradient launch (plan.fused: plain heads, pcd, one encoder, P <= 2): the launch itself
 // turns the per-range partial gradients into the flat gradient and applies TF-Adam, so the step needs no finalize
 // launch and no round trip of P gradient slabs through HBM.
-//   * a (64-d tile, column job) is produced by P workgroups (row ranges).  They take a ticket; the first P-1
+//   * a (64-d tile, column job) is produced by P workgroups (row ranges).  The first P-1 row ranges
 //     publish their partial tile into their slab -- `sc1` (write-through) stores, every storing wave drains with
 //     s_waitcnt vmcnt(0), workgroup barrier, then ONE lane adds 1 to the tile's arrival counter (agent-scope
-//     atomic) -- and leave; the last one polls that counter with `sc1` loads (one lane), barrier, reads the
-//     published tiles with `sc1` loads and runs the epilogue.  This is the last-arriver hand-off of
+//     atomic) -- and leave; the workgroup of the last row range polls that counter with `sc1` loads (one lane),
+//     barrier, reads the published tiles with `sc1` loads and runs the epilogue.  The memory side is the last-arriver hand-off of
 //     MI355X_MICROARCH.md ("hand-offs measured with sc1 loads in place of the acquire", first row): no
 //     agent-scope fence on either side.  The tiles are summed in the fixed order of the row ranges, so the result
-//     does not depend on who arrives last (bit-reproducible, and bit-identical to the finalize kernel).
+//     is bit-reproducible, and bit-identical to the finalize kernel).
 //   * the row-reduction blocks (z-slice 0) own whole columns, so they finish the bias / threshold entries and the
 //     step's scalars themselves.
 // Tickets and flags live in the workspace and are zeroed by the mid launch of the same step.
@@ -572,13 +572,11 @@ __device__ __forceinline__ void grad_fused_tail(const GradArgs &a, int job, int 
                                                 int *lds_i) {
     const GradFuse &f = a.fuse;
     const int slot = job * gridDim.x + blockIdx.x;
-    int ticket = P - 1;
-    if (P > 1) {
-        if (threadIdx.x == 0) *lds_i = atomicAdd(f.ticket + slot, 1);      // agent scope
-        __syncthreads();
-        ticket = *lds_i;
-    }
-    if (ticket < P - 1) {
+    // Roles are static: the workgroup of the LAST row range finishes the tile, the others publish.  (A ticket --
+    // "whoever arrives last finishes" -- costs an atomic round trip on every workgroup's critical path, ~1 us, and buys
+    // nothing: the finisher waits for the publishers' data either way.  No deadlock: a finisher only waits for
+    // workgroups with a smaller linear id, which were dispatched before it and run to completion on their own.)
+    if (p < P - 1) {
         // not the last of the P row ranges: publish the partial tile into slab p and leave
         if (wave < NT) {
             f32x4 v[4];
@@ -590,7 +588,7 @@ __device__ __forceinline__ void grad_fused_tail(const GradArgs &a, int job, int 
         if (threadIdx.x == 0) atomicAdd(f.flag + slot, 1);                 // agent-scope arrival count
         return;
     }
-    // the last arriver: parameters first (they do not depend on the partners), then the published tiles
+    // the finisher: parameters first (they do not depend on the partners), then the published tiles
     const long long base = f.w_off[job] + (long long)tile_off;
     f32x4 th[4], mm[4], vv[4];
     if (wave < NT) {
