@@ -405,7 +405,10 @@ def test_long_row_ranges_take_the_unstaged_gradient_kernel(monkeypatch):
                                             # forced row splits: short row ranges, many publishers per tile (this is
                                             # where separate inline-asm store / wait statements lost half a float4)
                                             (512, 4096, 3, 20, 0.0, 4), (512, 4096, 3, 20, 0.0, 8),
-                                            (1024, 2048, 3, 20, 0.0, 8), (2048, 1024, 3, 20, 1e-3, 0)])
+                                            (1024, 2048, 3, 20, 0.0, 8), (2048, 1024, 3, 20, 1e-3, 0),
+                                            # d-tile counts that are not multiples of 8: the row ranges of a tile run on
+                                            # DIFFERENT XCDs (separate L2s), the hand-off crosses them
+                                            (512, 576, 3, 20, 0.0, 0), (1024, 320, 2, 12, 1e-3, 4), (512, 4160, 3, 20, 0.0, 0)])
 def test_fused_gradient_tail_equals_finalize_kernel(B, D, K, L, reg, P, monkeypatch):
     """The `Dist` step finishes gradient + Adam inside the weight-gradient launch (pairs of row-range workgroups
     hand their partial tile over with sc1 stores / loads, the row-reduction blocks finish biases, threshold and
