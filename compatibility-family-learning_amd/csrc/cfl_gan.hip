@@ -258,16 +258,21 @@ __global__ __launch_bounds__(EW_THREADS) void bce_kernel(const float *x, int64_t
 __global__ __launch_bounds__(EW_THREADS) void rowdist_kernel(const float *a, const float *b, int64_t B, int L,
                                                              int mode, float margin, float weight, float *loss,
                                                              float *da, int accumulate) {
-    __shared__ float red[EW_THREADS];
+    // one block; wave w owns rows w, w + nwaves, ... (wave-level reductions: no block barrier per row -- the rows are
+    // short, L = the latent size, and a barrier per row made this a 120 us kernel); the per-wave totals are added in
+    // wave order at the end, so the result does not depend on timing
+    __shared__ float tot[EW_THREADS / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = EW_THREADS / 64;
     float total = 0.f;
     const float invB = 1.f / (float)B;
-    for (int64_t r = 0; r < B; ++r) {
+    for (int64_t r = wave; r < B; r += nw) {
         float d = 0.f;
-        for (int j = threadIdx.x; j < L; j += EW_THREADS) {
+        for (int j = lane; j < L; j += 64) {
             const float t = a[r * L + j] - b[r * L + j];
             d = fmaf(t, t, d);
         }
-        d = block_sum(d, red);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) d += __shfl_xor(d, o);
         float li, coef;   // coef = d loss_i / d d
         if (mode == 0) {
             li = d;
@@ -280,13 +285,19 @@ __global__ __launch_bounds__(EW_THREADS) void rowdist_kernel(const float *a, con
         }
         total += li;
         if (da)
-            for (int j = threadIdx.x; j < L; j += EW_THREADS) {
+            for (int j = lane; j < L; j += 64) {
                 const float t = a[r * L + j] - b[r * L + j];
                 const float gval = weight * invB * coef * 2.f * t;
                 da[r * L + j] = accumulate ? da[r * L + j] + gval : gval;
             }
     }
-    if (threadIdx.x == 0 && loss) *loss = weight * total * invB;
+    if (lane == 0) tot[wave] = total;
+    __syncthreads();
+    if (threadIdx.x == 0 && loss) {
+        float t = 0.f;
+        for (int w = 0; w < nw; ++w) t += tot[w];
+        *loss = weight * t * invB;
+    }
 }
 
 // population mean / variance of all elements, two stages in fixed order
