@@ -241,6 +241,53 @@ __device__ __forceinline__ void split_frag(const float (&v)[8], bf16x8 (&f)[3]) 
 }
 
 // ---------------------------------------------------------------------------
+// colnorm (weight-norm): n2[c] = sum_d V[d][c]^2   (cfl/layers.py:81) + gain snapshot.
+// The blocks ride in the projection launch as an extra z-slice (the projection uses the raw V; `mid`, the next
+// launch, is the first consumer of the norms), like the row reductions ride in the weight-gradient launch: one
+// launch less per step of a weight-normalised model (a stand-alone colnorm launch measured 6.9 us, all dispatch).
+// ---------------------------------------------------------------------------
+struct ColnormArgs {
+    const float *theta;
+    float *n2;            // [ncols_total]
+    float *gcopy;         // [ncols_total] snapshot of the gains (finalize may update theta in place)
+    long long g_off[8];
+    int nheads, ncols;
+    long long w_off[8];
+    int npad[8], n2_off[8], rowlen[8], strided[8];
+    int D;
+};
+
+__device__ __forceinline__ void colnorm_column(const ColnormArgs &a, int col, float *red) {
+    int c = col, h = 0;
+    while (h < a.nheads && c >= a.npad[h]) { c -= a.npad[h]; ++h; }
+    if (h >= a.nheads) return;   // uniform per block
+    float acc = 0.f;
+    if (!a.strided[h]) {
+        // Wf layout: column c = 16nt + c16 lives at ((nt*G + g)*64 + q*16 + c16) float4s
+        const int G = a.D >> 4, nt = c >> 4, c16 = c & 15;
+        const f32x4 *w = (const f32x4 *)(a.theta + a.w_off[h]) + (size_t)nt * G * 64 + c16;
+        for (int i = threadIdx.x; i < G * 4; i += 256) {
+            const f32x4 v = w[(size_t)(i >> 2) * 64 + (i & 3) * 16];
+            acc += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+        }
+    } else {  // mono head V[L][kpad]: column c strided by kpad
+        const float *w = a.theta + a.w_off[h];
+        for (int l = threadIdx.x; l < a.rowlen[h]; l += 256) {
+            float v = w[l * a.npad[h] + c];
+            acc = fmaf(v, v, acc);
+        }
+    }
+    acc = wave_sum(acc);
+    __syncthreads();             // red[] of the previous column has been read
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        a.n2[a.n2_off[h] + c] = (red[0] + red[1]) + (red[2] + red[3]);
+        a.gcopy[a.n2_off[h] + c] = a.g_off[h] >= 0 ? a.theta[a.g_off[h] + c] : 1.f;
+    }
+}
+
+// ---------------------------------------------------------------------------
 // proj: Ypart[s][r][c] = sum_{d in slice s} X[r][d] * W[d][c]
 //   workgroup = 4 waves, one 32-row tile; wave w owns chunks of 128 d (8 groups of
 //   16) and computes the whole [32 x NT*16] tile for them with v_mfma_f32_16x16x4_f32.
@@ -266,6 +313,8 @@ struct ProjArgs {
     int B, R, Rpad, D, S;
     int xcd;  // 1: blockIdx.x enumerates the d slices (see cfl_xcd_aligned)
     NormDev norm;
+    int njobs;            // z-slices [0, njobs) project; slice njobs (weight-norm only) computes the column norms
+    ColnormArgs cn;
 };
 
 template <int NT>
@@ -404,6 +453,11 @@ __device__ __forceinline__ void proj_body(const ProjJob &jb, const ProjArgs &a, 
 extern "C" __global__ __launch_bounds__(256) void cfl_proj_kernel(ProjArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     f32x4 *lds = (f32x4 *)smem;
+    if ((int)blockIdx.z == a.njobs) {
+        const int nb = gridDim.x * gridDim.y;
+        for (int col = blockIdx.y * gridDim.x + blockIdx.x; col < a.cn.ncols; col += nb) colnorm_column(a.cn, col, (float *)smem);
+        return;
+    }
     const ProjJob &jb = a.job[blockIdx.z];
     switch (jb.nt) {
         case 1: proj_body<1>(jb, a, lds); break;
@@ -1983,51 +2037,6 @@ __global__ __launch_bounds__(256) void cfl_mid_row_kernel(MidArgs a) {
 }
 
 // ---------------------------------------------------------------------------
-// colnorm (weight-norm): n2[c] = sum_d V[d][c]^2   (cfl/layers.py:81) + gain snapshot
-// ---------------------------------------------------------------------------
-struct ColnormArgs {
-    const float *theta;
-    float *n2;            // [ncols_total]
-    float *gcopy;         // [ncols_total] snapshot of the gains (finalize may update theta in place)
-    long long g_off[8];
-    int nheads;
-    long long w_off[8];
-    int npad[8], n2_off[8], rowlen[8], strided[8];
-    int D;
-};
-
-extern "C" __global__ __launch_bounds__(256) void cfl_colnorm_kernel(ColnormArgs a) {
-    // blockIdx.x enumerates columns over all heads
-    int c = blockIdx.x, h = 0;
-    while (h < a.nheads && c >= a.npad[h]) { c -= a.npad[h]; ++h; }
-    if (h >= a.nheads) return;
-    float acc = 0.f;
-    if (!a.strided[h]) {
-        // Wf layout: column c = 16nt + c16 lives at ((nt*G + g)*64 + q*16 + c16) float4s
-        const int G = a.D >> 4, nt = c >> 4, c16 = c & 15;
-        const f32x4 *w = (const f32x4 *)(a.theta + a.w_off[h]) + (size_t)nt * G * 64 + c16;
-        for (int i = threadIdx.x; i < G * 4; i += 256) {
-            const f32x4 v = w[(size_t)(i >> 2) * 64 + (i & 3) * 16];
-            acc += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
-        }
-    } else {  // mono head V[L][kpad]: column c strided by kpad
-        const float *w = a.theta + a.w_off[h];
-        for (int l = threadIdx.x; l < a.rowlen[h]; l += 256) {
-            float v = w[l * a.npad[h] + c];
-            acc = fmaf(v, v, acc);
-        }
-    }
-    __shared__ float red[4];
-    acc = wave_sum(acc);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        a.n2[a.n2_off[h] + c] = (red[0] + red[1]) + (red[2] + red[3]);
-        a.gcopy[a.n2_off[h] + c] = a.g_off[h] >= 0 ? a.theta[a.g_off[h] + c] : 1.f;
-    }
-}
-
-// ---------------------------------------------------------------------------
 // finalize: weight-gradient slabs + row-reduced column sums -> flat gradient ;
 //           last block -> scalars.  Purely element-wise: every reduction over rows
 //           was done by grad_red_block, every reduction over theta by mid_reg_block.
@@ -2478,10 +2487,10 @@ static NormDev make_norm(const CflNorm *n, float *in_mul) {
     return d;
 }
 
-// weight-norm squared column norms for every head of both encoders
-static int launch_colnorm(const CflShape *s, const Plan &pl, const float *theta, float *ws,
-                          int n2_off[2][3], hipStream_t st) {
-    ColnormArgs ca;
+// weight-norm squared column norms for every head of both encoders: arguments of the colnorm slice of the projection launch
+static int fill_colnorm(const CflShape *s, const Plan &pl, const float *theta, float *ws,
+                        int n2_off[2][3], ColnormArgs *out) {
+    ColnormArgs &ca = *out;
     memset(&ca, 0, sizeof(ca));
     ca.theta = theta;
     ca.n2 = ws + pl.n2;
@@ -2508,10 +2517,7 @@ static int launch_colnorm(const CflShape *s, const Plan &pl, const float *theta,
         }
     }
     ca.nheads = nh;
-    if (s->weight_norm && ncols > 0) {
-        ProfScope ps(st, CFL_K_COLNORM);
-        hipLaunchKernelGGL(cfl_colnorm_kernel, dim3(ncols), dim3(256), 0, st, ca);
-    }
+    ca.ncols = (s->weight_norm && ncols > 0) ? ncols : 0;   // 0: no colnorm slice in the projection launch
     return CFL_OK;
 }
 
@@ -2610,7 +2616,8 @@ static int run_pairs(const CflShape *s, const CflNorm *norm, const CflLossCfg *l
     }
 
     int n2_off[2][3] = {{-1, -1, -1}, {-1, -1, -1}};
-    launch_colnorm(s, pl, theta, ws, n2_off, st);
+    ColnormArgs cna;
+    fill_colnorm(s, pl, theta, ws, n2_off, &cna);
     const float *n2base = ws + pl.n2;
     const float *gbase = ws + pl.n2 + 6 * 1024;
 
@@ -2635,8 +2642,10 @@ static int run_pairs(const CflShape *s, const CflNorm *norm, const CflLossCfg *l
         pa.rows[0] = rsrc[0]; pa.rows[1] = rsrc[1];
         pa.B = (int)rows; pa.R = pl.R; pa.Rpad = pl.Rpad; pa.D = s->D; pa.S = pl.S; pa.norm = nd;
         pa.xcd = pl.xcd;
-        dim3 grid((pl.R + 31) / 32, pl.S, nj);
-        if (pa.xcd) grid = dim3(pl.S, (pl.R + 31) / 32, nj);
+        pa.njobs = nj; pa.cn = cna;
+        const int nz = nj + (cna.ncols > 0 ? 1 : 0);
+        dim3 grid((pl.R + 31) / 32, pl.S, nz);
+        if (pa.xcd) grid = dim3(pl.S, (pl.R + 31) / 32, nz);
         ProfScope ps(st, CFL_K_PROJ);
         hipLaunchKernelGGL(cfl_proj_kernel, grid, dim3(256), 4 * 8 * 64 * sizeof(f32x4), st, pa);  // 32 KiB: cross-wave sum (the 4 KiB/wave transpose tiles alias it)
     }
