@@ -527,6 +527,14 @@ struct GradFuse {
     // row-reduction side: red range k (kind 0) feeds the bias array at red_b[k] (npad red_npad[k], n red_n[k])
     long long red_b[CFL_MAX_RED];
     int red_n[CFL_MAX_RED], red_npad[CFL_MAX_RED];
+    // weight-normalised heads: red range k (column sums of dy * xv: c_j = sum_d V_dj (x^T dy)_dj) feeds the gain array
+    // at red_g[k]; the W tiles need c_j too: the range's blocks publish it (sc1) and bump red_done
+    int wn;
+    long long red_g[CFL_MAX_RED];
+    const float *red_n2[CFL_MAX_RED];
+    int *red_done, red_expect;
+    const float *wn_g[CFL_MAX_JOBS], *wn_n2[CFL_MAX_JOBS], *wn_cw[CFL_MAX_JOBS];   // at the job's first column
+    int wn_n[CFL_MAX_JOBS];                                                        // valid columns from there
     long long thr_off;
     // scalars
     const float *regpart;
@@ -655,10 +663,19 @@ __device__ __forceinline__ void grad_fused_tail(const GradArgs &a, int job, int 
             }
         }
     }
-    if (P > 1) {
-        if (threadIdx.x == 0)
-            while (__hip_atomic_load(f.flag + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < P - 1)
-                __builtin_amdgcn_s_sleep(1);
+    // weight-norm: per-column gain snapshot and squared norm (workspace, written by the projection launch)
+    const int wcol = (wave < NT ? wave : 0) * 16 + (threadIdx.x & 15);
+    float wg = 1.f, wn2 = 1.f;
+    if (f.wn) { wg = f.wn_g[job][wcol]; wn2 = f.wn_n2[job][wcol]; }
+    if (P > 1 || f.wn) {
+        if (threadIdx.x == 0) {
+            if (P > 1)
+                while (__hip_atomic_load(f.flag + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < P - 1)
+                    __builtin_amdgcn_s_sleep(1);
+            if (f.wn)   // the c_j column sums of this launch's reduction blocks (dispatched first, short)
+                while (__hip_atomic_load(f.red_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < f.red_expect)
+                    __builtin_amdgcn_s_sleep(1);
+        }
         __syncthreads();
     }
     if (wave < NT) {
@@ -678,8 +695,25 @@ __device__ __forceinline__ void grad_fused_tail(const GradArgs &a, int job, int 
                 for (int e = 0; e < 4; ++e) g[e] += part[e];
             }
         }
+        if (f.wn) {
+            // dV = (g/n) in_mul X^T dy - (g c / n^3) V   (cfl/layers.py:80-90 differentiated; same operations in the
+            // same order as the RK_W branch of the finalize kernel)
+            const float cw = __hip_atomic_load(f.wn_cw[job] + wcol, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const bool colok = wcol < f.wn_n[job];
+            const float n = sqrtf(wn2);
+            const float s1 = (colok && wn2 > 0.f) ? f.in_mul * wg / n : 0.f;
+            const float s2 = (colok && wn2 > 0.f) ? wg * cw / (wn2 * n) : 0.f;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) fuse_apply(f, base + e * 64, g[e] * f.in_mul, th[e], mm[e], vv[e]);
+            for (int e = 0; e < 4; ++e) {
+                f32x4 gr = g[e] * s1;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) gr[i] = fmaf(-s2, th[e][i], gr[i]);
+                fuse_apply(f, base + e * 64, gr, th[e], mm[e], vv[e]);
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) fuse_apply(f, base + e * 64, g[e] * f.in_mul, th[e], mm[e], vv[e]);
+        }
     }
 }
 
@@ -864,9 +898,17 @@ __device__ void grad_red_block(const GradArgs &a, float *lds) {
             if (lane < 16) lds[wave * 16 + lane] = acc;
             __syncthreads();
             float csum = 0.f;
+            const bool publish = a.fuse.on && a.fuse.wn && a.fuse.red_g[k] >= 0;   // c_j sums the W tiles wait for
             if (wave == 0 && lane < 16) {
                 csum = (lds[lane] + lds[16 + lane]) + (lds[32 + lane] + lds[48 + lane]);
-                a.colsum[rr.out_off + idx * 16 + lane] = csum;
+                if (publish)   // written through (agent scope): read by tile finishers of this launch, on any XCD
+                    __hip_atomic_store(a.colsum + rr.out_off + idx * 16 + lane, csum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else
+                    a.colsum[rr.out_off + idx * 16 + lane] = csum;
+            }
+            if (publish && wave == 0) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (lane == 0) atomicAdd(a.fuse.red_done, 1);
             }
             if (a.fuse.on) {
                 // this block owns the whole column: finish the entries that depend on it
@@ -898,6 +940,20 @@ __device__ void grad_red_block(const GradArgs &a, float *lds) {
                         // pad of the bias array up to its 64-float slot: zero gradient
                         const int cp = f.red_npad[k] + lane - 16;
                         if (cp < ((f.red_npad[k] + 63) & ~63)) fuse_apply1(f, f.red_b[k] + cp, 0.f, true);
+                    }
+                } else if (f.wn && f.red_g[k] >= 0 && wave == 0) {
+                    // gain entries: dg_j = c_j / n_j (the RK_GAIN branch of the finalize kernel; no L2 term)
+                    const int c = idx * 16 + lane;
+                    if (lane < 16) {
+                        float gr = 0.f;
+                        if (c < f.red_n[k]) {
+                            const float n2 = f.red_n2[k][c];
+                            gr = n2 > 0.f ? csum / sqrtf(n2) : 0.f;
+                        }
+                        fuse_apply1(f, f.red_g[k] + c, gr, false);
+                    } else if (idx == 0) {
+                        const int cp = f.red_npad[k] + lane - 16;
+                        if (cp < ((f.red_npad[k] + 63) & ~63)) fuse_apply1(f, f.red_g[k] + cp, 0.f, false);
                     }
                 }
             }
@@ -2106,7 +2162,10 @@ __device__ __forceinline__ f32x4 fin_region_grad(const FinArgs &a, const Region 
                     float cw = 0.f;
                     for (int s = 0; s < 2; ++s)
                         if (rg.cs_cw[s] >= 0) cw += a.colsum[rg.cs_cw[s] + c];
-                    if (n2 > 0.f) gr -= (rg.g[c] * cw / (n2 * n)) * th;
+                    // (explicit fma: the fused tail of the weight-gradient launch performs the same operations)
+                    const float s2 = n2 > 0.f ? rg.g[c] * cw / (n2 * n) : 0.f;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) gr[e] = fmaf(-s2, th[e], gr[e]);
                 } else {
                     gr *= 0.f;
                 }
@@ -2401,7 +2460,7 @@ static int make_plan(const CflShape *s, int64_t rows, int groups, bool train, Pl
     pl->x3 = debug_env("CFL_EXACT_FP32") <= 0;
     // fused tail: every gradient entry must be complete inside one (pair of) workgroup(s) -- plain heads (the
     // weight-norm correction couples a column over all of d), pcd (each side feeds its own head), one encoder
-    pl->fused = train && !s->weight_norm && s->dist_type == CFL_DIST_PCD && !s->directed &&
+    pl->fused = train && s->dist_type == CFL_DIST_PCD && !s->directed &&
                 debug_env("CFL_DEBUG_NOFUSE") <= 0;
     pl->P = P;
     pl->Rpad = (int)round_up(pl->R, 256 * P);  // grad: 64-row chunks x 4 waves x P ranges
@@ -2455,7 +2514,7 @@ static int make_plan(const CflShape *s, int64_t rows, int groups, bool train, Pl
         pl->wpart[1] = take((size_t)P * hd->npad * s->D);
         pl->regpart = take((size_t)pl->nregblocks);
         pl->nhandoff = njobs * (s->D / 64);
-        pl->handoff = take(2 * (size_t)pl->nhandoff);
+        pl->handoff = take(2 * (size_t)pl->nhandoff + 64);   // tickets, flags, + the reduction blocks' counter
     }
     pl->n2 = take(2 * 6 * 1024);  // squared column norms + gain snapshot of up to 6 heads
     pl->total_floats = off;
@@ -2688,9 +2747,9 @@ static int run_pairs(const CflShape *s, const CflNorm *norm, const CflLossCfg *l
         ma.thr_copy = ws + pl.thr_copy;
         ma.regpart = ws + pl.regpart;
         ma.theta = theta;
-        if (pl.fused && pl.P > 1) {
+        if (pl.fused && (pl.P > 1 || s->weight_norm)) {
             ma.zero_i = (int *)(ws + pl.handoff);
-            ma.nzero = 2 * pl.nhandoff;
+            ma.nzero = 2 * pl.nhandoff + 1;
         }
     }
     ma.scores = scores; ma.dists = dists;
@@ -2854,13 +2913,34 @@ static int run_pairs(const CflShape *s, const CflNorm *norm, const CflLossCfg *l
                 const CflHead *h = side[sd].head;
                 for (int c0 = 0; c0 < h->npad / 16; c0 += 4) f.w_off[jn++] = h->w + (long long)c0 * G * 256;
             }
-            for (int k = 0; k < CFL_MAX_RED; ++k) f.red_b[k] = -1;
-            // red ranges: 0 = row quantities, 1 + sd = dY of side sd (no weight-norm ranges in fused mode)
+            for (int k = 0; k < CFL_MAX_RED; ++k) { f.red_b[k] = -1; f.red_g[k] = -1; }
+            // red ranges: 0 = row quantities, then per side: dY (-> bias) and, with weight norm, dy * xv (-> gain, c_j)
+            f.wn = s->weight_norm ? 1 : 0;
+            f.red_done = f.flag + pl.nhandoff;
+            f.red_expect = 0;
+            const int per_side = 1 + (pl.has_cw ? 1 : 0);
+            jn = 0;
             for (int sd = 0; sd < 2; ++sd) {
                 const CflHead *h = side[sd].head;
-                f.red_b[1 + sd] = h->b;
-                f.red_n[1 + sd] = h->n;
-                f.red_npad[1 + sd] = h->npad;
+                const int kd = 1 + sd * per_side;
+                f.red_b[kd] = h->b;
+                f.red_n[kd] = h->n;
+                f.red_npad[kd] = h->npad;
+                if (f.wn) {
+                    const float *n2p = n2base + n2_off[side[sd].enc][side[sd].which];
+                    const float *gp = gbase + n2_off[side[sd].enc][side[sd].which];
+                    f.red_g[kd + 1] = h->g;
+                    f.red_n[kd + 1] = h->n;
+                    f.red_npad[kd + 1] = h->npad;
+                    f.red_n2[kd + 1] = n2p;
+                    f.red_expect += h->npad / 16;
+                    for (int c0 = 0; c0 < h->npad / 16; c0 += 4, ++jn) {
+                        f.wn_g[jn] = gp + c0 * 16;
+                        f.wn_n2[jn] = n2p + c0 * 16;
+                        f.wn_cw[jn] = ws + pl.colsum + pl.cs_cw[sd] + c0 * 16;
+                        f.wn_n[jn] = h->n - c0 * 16;
+                    }
+                }
             }
             f.thr_off = pl.lay.thr;
             f.regpart = ws + pl.regpart; f.nregblocks = nreg_blocks;

@@ -401,6 +401,10 @@ def test_long_row_ranges_take_the_unstaged_gradient_kernel(monkeypatch):
 
 
 @pytest.mark.parametrize('B,D,K,L,reg,P', [(512, 4096, 3, 20, 0.0, 0), (128, 1024, 5, 12, 1e-3, 0),
+                                            # weight-normalised heads (P < 0 marks them; |P| - 1 = forced split): the tail
+                                            # also waits for the c_j column sums of the launch's reduction blocks
+                                            (1024, 2048, 5, 20, 1e-3, -1), (128, 1024, 3, 12, 1e-3, -1), (512, 576, 2, 7, 0.0, -1),
+                                            (512, 1024, 3, 20, 0.0, -5), (16, 256, 1, 7, 1e-3, -1),
                                             (16, 256, 1, 7, 1e-3, 0), (1024, 2048, 3, 20, 0.0, 0),
                                             # forced row splits: short row ranges, many publishers per tile (this is
                                             # where separate inline-asm store / wait statements lost half a float4)
@@ -418,8 +422,14 @@ def test_fused_gradient_tail_equals_finalize_kernel(B, D, K, L, reg, P, monkeypa
     from cfl import hipabi as H
     from cfl.engine import PairEngine
     rng = np.random.RandomState(5)
-    cfg = O.EncoderCfg(D=D, L=L, K=K)
+    wn = P < 0
+    if wn:
+        P = -P - 1
+    cfg = O.EncoderCfg(D=D, L=L, K=K, style='cfl' if wn else 'dist')
     params = O.init_encoder_params(cfg, rng, np.float32)
+    if wn:   # gains away from 1 so that the correction term is exercised
+        params = {k: (v * (1.0 + 0.3 * rng.rand(*v.shape)).astype(np.float32) if k.endswith('/g') else v)
+                  for k, v in params.items()}
     pool = [[torch.from_numpy(np.abs(rng.randn(B, D)).astype(np.float32) * 3).cuda() for _ in range(4)]
             for _ in range(3)]
     res = {}
@@ -428,8 +438,8 @@ def test_fused_gradient_tail_equals_finalize_kernel(B, D, K, L, reg, P, monkeypa
     for mode in ('fused', 'finalize'):
         monkeypatch.setenv('CFL_DEBUG_NOFUSE', '0' if mode == 'fused' else '1')
         H.reload_env()
-        eng = PairEngine(D, L, K, norm=H.make_norm(1 / 8.0), loss=H.make_loss(reg_const=reg), params=params,
-                         batch_size=B)
+        eng = PairEngine(D, L, K, weight_norm=cfg.weight_norm, has_bias=cfg.has_bias, norm=H.make_norm(1 / 8.0),
+                         loss=H.make_loss(reg_const=reg), params=params, batch_size=B)
         H.profile_enable(True)
         eng.step(pool[0])
         torch.cuda.synchronize()
