@@ -208,3 +208,24 @@ def test_input_transformer_descriptors():
     assert np.array_equal(once.reshape(3, 6, 5, 2), img[:, :, ::-1]) and np.array_equal(flip(once, None, np.ones(3, np.int32)), x)
     o, f = ops.ImageTransform((20, 20, 1), (16, 16, 1), 'random_crop', True).draw(1000, np.random.RandomState(1))
     assert o.min() == 0 and o.max() == 4 and 0.4 < f.mean() < 0.6
+
+
+def test_cli_entry_points_cap_the_host_thread_pool(monkeypatch):
+    """engine.quiet_host_threads (called by init_from_env of every CLI entry point): torch's intra-op pool is capped
+    unless the user chose a size with OMP_NUM_THREADS (idle OpenMP threads spinning at a barrier
+    exhaust a container's CPU quota and the kernel then freezes the launching thread)."""
+    import torch
+    from cfl import engine
+    before = torch.get_num_threads()
+    try:
+        torch.set_num_threads(max(before, 6))
+        monkeypatch.setenv('OMP_NUM_THREADS', '6')
+        engine.quiet_host_threads()
+        assert torch.get_num_threads() == max(before, 6)          # the user's choice stands
+        monkeypatch.delenv('OMP_NUM_THREADS')
+        engine.quiet_host_threads()
+        assert torch.get_num_threads() <= 4
+        engine.quiet_host_threads(2)
+        assert torch.get_num_threads() <= 2
+    finally:
+        torch.set_num_threads(before)
