@@ -453,13 +453,13 @@ __device__ __forceinline__ void proj_body(const ProjJob &jb, const ProjArgs &a, 
 extern "C" __global__ __launch_bounds__(256) void cfl_proj_kernel(ProjArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     f32x4 *lds = (f32x4 *)smem;
-    if ((int)blockIdx.z == a.njobs) {
-        const int nb = gridDim.x * gridDim.y;
-        for (int col = blockIdx.y * gridDim.x + blockIdx.x; col < a.cn.ncols; col += nb) colnorm_column(a.cn, col, (float *)smem);
-        return;
-    }
     const ProjJob &jb = a.job[blockIdx.z];
     switch (jb.nt) {
+        case 0: {   // the colnorm slice (marked by nt == 0: no kernel-argument load of its own in front of the dispatch)
+            const int nb = gridDim.x * gridDim.y;
+            for (int col = blockIdx.y * gridDim.x + blockIdx.x; col < a.cn.ncols; col += nb) colnorm_column(a.cn, col, (float *)smem);
+            break;
+        }
         case 1: proj_body<1>(jb, a, lds); break;
         case 2: proj_body<2>(jb, a, lds); break;
         case 3: proj_body<3>(jb, a, lds); break;
@@ -2702,7 +2702,10 @@ static int run_pairs(const CflShape *s, const CflNorm *norm, const CflLossCfg *l
         pa.B = (int)rows; pa.R = pl.R; pa.Rpad = pl.Rpad; pa.D = s->D; pa.S = pl.S; pa.norm = nd;
         pa.xcd = pl.xcd;
         pa.njobs = nj; pa.cn = cna;
-        const int nz = nj + (cna.ncols > 0 ? 1 : 0);
+        const bool cn_slice = cna.ncols > 0;
+        if (cn_slice && nj >= CFL_MAX_JOBS) return set_err(CFL_E_UNSUPPORTED, "too many column chunks");
+        if (cn_slice) pa.job[nj].nt = 0;      // marks the colnorm slice
+        const int nz = nj + (cn_slice ? 1 : 0);
         dim3 grid((pl.R + 31) / 32, pl.S, nz);
         if (pa.xcd) grid = dim3(pl.S, (pl.R + 31) / 32, nz);
         ProfScope ps(st, CFL_K_PROJ);
