@@ -222,26 +222,32 @@ def roofline_eval(args, eng, pool, device):
     n_calls = reps * len(calls)
     per_call_s = e0.elapsed_time(e1) * 1e-3 / n_calls
     alg = 8.0 * D * B
-    # the same path at the call size dist_eval / dist_predict use (cfl.utils.RESIDENT_EVAL_ROWS = 8192 pairs per call)
+    # the same path at the call size dist_eval / dist_predict use (cfl.utils.RESIDENT_EVAL_ROWS pairs per call): two
+    # sets of fresh rows (2 x 1.07 GB at the headline shape: far past the 256 MiB Infinity Cache), alternated
+    from cfl.utils import RESIDENT_EVAL_ROWS
     big = None
-    nb = 8192 // B
-    if nb >= 2:
-        npool = len(pool)      # two 8192-pair sets of fresh copies (2 x 268 MB at the headline shape: past the Infinity Cache)
-        sets = [(torch.cat([pool[(g * nb + i) % npool][0] for i in range(nb)]),
-                 torch.cat([pool[(g * nb + i) % npool][1] for i in range(nb)])) for g in range(2)]
+    nbig = RESIDENT_EVAL_ROWS
+    if nbig > B:
+        g = torch.Generator(device=device)
+        g.manual_seed(77)
+        mk = lambda: torch.randn(nbig, D, generator=g, device=device).abs_().mul_(NORMALIZE_VALUE / 4.5)
+        sets = [(mk(), mk()) for _ in range(2)]
         for xs, xt in sets:
             eng.scores(xs, xt)
         torch.cuda.synchronize()
         f0, f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ncalls = 100
         f0.record(st)
-        for i in range(200):
+        for i in range(ncalls):
             eng.scores(*sets[i & 1])
         f1.record(st)
         torch.cuda.synchronize()
-        t = f0.elapsed_time(f1) * 1e-3 / 200
-        big = {'pairs_per_call': nb * B, 'avg_call_us': round(t * 1e6, 3), 'pairs_per_s': round(nb * B / t, 1),
-               'achieved': round(8.0 * D * nb * B / t / 1e9, 1), 'frac': round(8.0 * D * nb * B / t / 1e9 / HBM_PEAK_GBS, 4)}
+        t = f0.elapsed_time(f1) * 1e-3 / ncalls
+        big = {'pairs_per_call': nbig, 'avg_call_us': round(t * 1e6, 3), 'pairs_per_s': round(nbig / t, 1),
+               'achieved': round(8.0 * D * nbig / t / 1e9, 1), 'frac': round(8.0 * D * nbig / t / 1e9 / HBM_PEAK_GBS, 4)}
         del sets
+        eng._ws = {k: v for k, v in eng._ws.items() if k[1] != 1}
+        torch.cuda.empty_cache()
     return {'kernels': 'cfl_proj_kernel + cfl_mid_row_kernel (one cfl_pair_scores call)', 'bound': 'hbm', 'dist_eval_call': big,
             'achieved': round(alg / per_call_s / 1e9, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
             'frac': round(alg / per_call_s / 1e9 / HBM_PEAK_GBS, 4), 'traffic': None,

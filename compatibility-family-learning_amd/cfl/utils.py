@@ -192,14 +192,14 @@ def _scores(model, data, batch_size, negative):
     return np.concatenate(out) if out else np.zeros(0, np.float32)
 
 
-RESIDENT_EVAL_ROWS = 8192   # pairs per scoring launch when the split's features live in HBM
+RESIDENT_EVAL_ROWS = 32768   # pairs per scoring launch when the split's features live in HBM (measured on one MI355X:
+#                              8192 pairs per call reach 0.35 of the HBM roof, 32768 reach 0.43-0.45: profiles/r03_*)
 
 
-def _resident_scores(model, data, negative, device_result=False, rows=None):
-    """Vector datasets with a linear encoder: the split's features.b is uploaded once (cached on the dataset
-    object) and the scoring kernels read the pair rows in place by index (cfl_pair_scores_idx) in large chunks --
-    the same scores as the per-batch path, without one host-to-device copy of 2 x [batch, D] floats per batch.
-    Returns None when the fast path does not apply (image data, conv encoder, models without an engine)."""
+def _resident_ready(model, data):
+    """The split's resident feature table when the in-place scoring path applies (vector dataset, linear encoder, no
+    per-batch transformer, matching padded width), else None.  Cheap and side-effect free apart from the one-time
+    upload, so that every rank of a data-parallel run can decide -- identically -- BEFORE the first collective."""
     if getattr(data, 'is_image', True) or getattr(model, 'trunk', None) is not None or not hasattr(model, 'engine'):
         return None
     if getattr(model, 'val_data_transformer', None) is not None or getattr(model, '_explicit_norm', None) is not None:
@@ -216,6 +216,18 @@ def _resident_scores(model, data, negative, device_result=False, rows=None):
         res = data._resident = ResidentFeatures(data, model.device)
     if res.padded_size != model.padded_size:
         return None
+    return res
+
+
+def _resident_scores(model, data, negative, device_result=False, rows=None):
+    """Vector datasets with a linear encoder: the split's features.b is uploaded once (cached on the dataset
+    object) and the scoring kernels read the pair rows in place by index (cfl_pair_scores_idx) in large chunks --
+    the same scores as the per-batch path, without one host-to-device copy of 2 x [batch, D] floats per batch.
+    Returns None when the fast path does not apply (image data, conv encoder, models without an engine)."""
+    res = _resident_ready(model, data)
+    if res is None:
+        return None
+    import torch
     out = [model.engine.scores(table, streams)
            for table, streams in res.whole_indexed('neg' if negative else 'pos', RESIDENT_EVAL_ROWS, rows)]
     if rows is not None and not out:
@@ -225,12 +237,15 @@ def _resident_scores(model, data, negative, device_result=False, rows=None):
     return torch.cat(out).cpu().numpy().astype(np.float32) if out else np.zeros(0, np.float32)
 
 
-def _sharded_eval(model, data):
-    """Data-parallel evaluation (new functionality, the reference is single-device): every rank scores
-    a contiguous shard of the positive and of the negative pair list, the scores are gathered on rank 0, which
-    computes AUC / accuracy (cfl_auc) and broadcasts the two numbers so that every rank takes the same
-    best-model decisions.  Collective: EVERY rank must call dist_eval.  None when there is one rank or the
-    resident fast path does not apply."""
+def _sharded_eval(model, data, batch_size):
+    """Data-parallel evaluation (new functionality, the reference is single-device).  Collective: EVERY
+    rank must call dist_eval.  Returns None when there is one rank.
+      * resident fast path (vector dataset, linear encoder): every rank scores a contiguous shard of the positive and
+        of the negative pair list, the scores are gathered on rank 0, which computes AUC / accuracy (cfl_auc);
+      * otherwise (image data, conv encoder, per-batch transformers, padded-width mismatch): rank 0 evaluates the
+        whole split the single-GPU way.
+    Either way rank 0 broadcasts (auc, accuracy), so that every rank takes the same best-model decisions.  Which
+    branch runs is decided from properties every rank shares (_resident_ready), before any collective."""
     from . import engine as dpar
     world = dpar.world_size()
     if world <= 1:
@@ -238,37 +253,35 @@ def _sharded_eval(model, data):
     import torch
     import torch.distributed as dist
     rank = dpar.rank()
-    parts = []
-    for negative, pairs in ((False, data.pairs_pos), (True, data.pairs_neg)):
-        n = pairs.shape[0]
-        per = (n + world - 1) // world
-        lo, hi = min(rank * per, n), min((rank + 1) * per, n)
-        mine = _resident_scores(model, data, negative, True, rows=(lo, hi))
-        if mine is None:
-            raise NotImplementedError('data-parallel evaluation needs a vector dataset with a linear encoder')
-        padded = torch.zeros(per, dtype=torch.float32, device=model.device)
-        padded[:hi - lo] = mine
-        gathered = [torch.empty_like(padded) for _ in range(world)] if rank == 0 else None
-        dist.gather(padded, gathered, dst=0)
-        if rank == 0:
-            parts.append(torch.cat([g[:min((r + 1) * per, n) - min(r * per, n)] for r, g in enumerate(gathered)]))
     result = torch.zeros(2, dtype=torch.float64, device=model.device)
-    if rank == 0:
-        from . import hipgan
-        auc, acc = hipgan.auc(parts[0].contiguous(), parts[1].contiguous())
-        result[0], result[1] = auc, acc
+    if _resident_ready(model, data) is None:
+        if rank == 0:
+            r = _local_eval(model, batch_size, data)
+            result[0], result[1] = r.auc, r.accuracy
+    else:
+        parts = []
+        for negative, pairs in ((False, data.pairs_pos), (True, data.pairs_neg)):
+            n = pairs.shape[0]
+            per = (n + world - 1) // world
+            lo, hi = min(rank * per, n), min((rank + 1) * per, n)
+            mine = _resident_scores(model, data, negative, True, rows=(lo, hi))
+            padded = torch.zeros(per, dtype=torch.float32, device=model.device)
+            padded[:hi - lo] = mine
+            gathered = [torch.empty_like(padded) for _ in range(world)] if rank == 0 else None
+            dist.gather(padded, gathered, dst=0)
+            if rank == 0:
+                parts.append(torch.cat([g[:min((r + 1) * per, n) - min(r * per, n)] for r, g in enumerate(gathered)]))
+        if rank == 0:
+            from . import hipgan
+            auc, acc = hipgan.auc(parts[0].contiguous(), parts[1].contiguous())
+            result[0], result[1] = auc, acc
     dist.broadcast(result, 0)
     auc, acc = float(result[0]), float(result[1])
     return Namespace(error=1.0 - acc, accuracy=acc, auc=auc, roc=None)
 
 
-def dist_eval(sess, model, batch_size, data):
-    """cfl/utils.py:227-274: accuracy by the sign of the score, AUC, ROC.  With HBM-resident features the scores
-    never leave the GPU: AUC and accuracy come from cfl_auc (sort-based, ties = half credit, equal to
-    sklearn's roc_auc_score) and `roc` is not materialised (no caller reads it)."""
-    sharded = _sharded_eval(model, data)
-    if sharded is not None:
-        return sharded
+def _local_eval(model, batch_size, data):
+    """dist_eval of one process over the whole split."""
     dp, dn = (_resident_scores(model, data, False, True), _resident_scores(model, data, True, True))
     if dp is not None and dn is not None and dp.numel() and dn.numel():
         from . import hipgan
@@ -283,6 +296,16 @@ def dist_eval(sess, model, batch_size, data):
     y_score = np.concatenate([pos, neg])
     return Namespace(error=(total - correct) / total, accuracy=correct / total,
                      auc=roc_auc_score(y_true, y_score), roc=roc_curve(y_true, y_score))
+
+
+def dist_eval(sess, model, batch_size, data):
+    """cfl/utils.py:227-274: accuracy by the sign of the score, AUC, ROC.  With HBM-resident features the scores
+    never leave the GPU: AUC and accuracy come from cfl_auc (sort-based, ties = half credit, equal to
+    sklearn's roc_auc_score) and `roc` is not materialised (no caller reads it)."""
+    sharded = _sharded_eval(model, data, batch_size)
+    if sharded is not None:
+        return sharded
+    return _local_eval(model, batch_size, data)
 
 
 def dist_predict(sess, model, data, batch_size, predict_dir, output_name):

@@ -148,8 +148,16 @@ extern "C" int cfl_debug_clear_stamps(void) {
     if (hipGetSymbolAddress(&p, HIP_SYMBOL(cfl_stamps)) != hipSuccess) return -2;
     return hipMemset(p, 0, sizeof(unsigned long long) * 16384 * 8) == hipSuccess ? 0 : -2;
 }
+#define RSTAMP(slot)                                                                         \
+    do {                                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+        unsigned long long _t = __builtin_readcyclecounter();                                \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+        if ((threadIdx.x & 63) == 0) cfl_stamps[(blockIdx.x * 8 + (threadIdx.x >> 6)) * 8 + (slot)] = _t; \
+    } while (0)
 #else
 #define STAMP(slot) do {} while (0)
+#define RSTAMP(slot) do {} while (0)
 #endif
 
 // ---------------------------------------------------------------------------
@@ -312,6 +320,7 @@ struct ProjArgs {
     RowSrc rows[2];
     int B, R, Rpad, D, S;
     int xcd;  // 1: blockIdx.x enumerates the d slices (see cfl_xcd_aligned)
+    int mix, mixjobs, mixtiles;   // streaming form, S == 1: 1-d grid, jobs dealt in groups of 8 (proj_stream_kernel_body)
     NormDev norm;
     int njobs;            // z-slices [0, njobs) project; slice njobs (weight-norm only) computes the column norms
     ColnormArgs cn;
@@ -448,6 +457,460 @@ __device__ __forceinline__ void proj_body(const ProjJob &jb, const ProjArgs &a, 
         for (int e = 0; e < 4; ++e) dst[(size_t)e * jb.npad] = sum[e];
     }
     STAMP(7);
+}
+
+// ---------------------------------------------------------------------------
+// proj, streaming form: the same contraction for waves that own SEVERAL 128-d chunks (S <= 2: 2048 rows per
+// side and more, and every dist_eval / dist_predict call).  proj_body above issues the 16 x loads of a chunk,
+// waits for them and multiplies, chunk after chunk: with one chunk per wave (the training step at B = 512) that
+// is all there is to overlap, with eight it leaves the matrix pipe idle for a memory latency per chunk (B = 8192:
+// 162 us for 13 GF = 51 % of the fp32-MFMA roof).  Here the x registers of a quarter (32 d) are refilled with the
+// same quarter of the NEXT chunk the moment they have been parked in LDS, i.e. before that quarter's MFMAs, so
+// there are always 3-4 quarters (12-16 KiB per wave) of x in flight behind the one being multiplied; the W
+// fragments of quarter t+2 are requested after the MFMAs of quarter t (two register sets, as before).
+// The steady-state body is BRANCH-FREE (prefetch indices are clamped to the last quarter of the row instead of
+// being guarded): with the loads inside uniform branches the compiler's waitcnt pass has to assume the path on
+// which nothing was issued and drains the queue (s_waitcnt vmcnt(0)) in front of every quarter -- measured: no
+// gain at all over proj_body.  Arithmetic, accumulation order and output are those of proj_body bit for bit
+// (k-ordered fp32 FMA chains per wave, waves summed in wave order).
+//   MIX: workgroups of all column jobs are dealt in groups of 8 (one per XCD) over ONE grid dimension, so that the
+//   co-resident workgroups of a CU are a mix of wide (64-column) and narrow jobs.
+// ---------------------------------------------------------------------------
+template <int NT>
+__device__ __forceinline__ void proj_stream_body(const ProjJob &jb, const ProjArgs &a, f32x4 *lds, int rowtile) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r16 = lane & 15, q4 = lane >> 4;
+    const int rr8 = lane >> 3, ch8 = lane & 7;
+    const int row0 = rowtile * 32;
+    const int s = a.mix ? 0 : (a.xcd ? blockIdx.x : blockIdx.y);
+    const int G = a.D >> 4;
+    const int NC = (G + 7) >> 3;
+    const int nw = a.S * 4, wg = s * 4 + wave;
+    const int cbeg = wg * NC / nw, cend = (wg + 1) * NC / nw;
+    const int qlast = (G >> 1) - 1;   // last 32-d quarter of a row (D % 64 == 0)
+
+    f32x4 acc[2][NT];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const float *xrow[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) xrow[i] = row_ptr(a.rows[jb.side], row0 + 8 * i + rr8, a.B, a.R, a.D) + 4 * ch8;
+    const float *wfl = jb.wf + lane * 4;
+    f32x4 *tile = lds + wave * 256;
+
+    f32x4 bq[2][2][NT] = {}, araw[4][4] = {}, af[2][2];
+    auto loadB = [&](int tq, f32x4 (*dst)[NT]) {   // tq clamped: a prefetch past the row re-reads its last quarter
+#ifndef ABL_PROJ_NOB
+        tq = tq < qlast ? tq : qlast;
+#pragma unroll
+        for (int gg = 0; gg < 2; ++gg)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                dst[gg][nt] = *(const f32x4 *)(wfl + ((size_t)nt * G + 2 * tq + gg) * 256);
+#endif
+    };
+    auto loadA = [&](int tq, f32x4 *dst) {
+#ifndef ABL_PROJ_NOA
+        tq = tq < qlast ? tq : qlast;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dst[i] = *(const f32x4 *)(xrow[i] + tq * 32);
+#endif
+    };
+    auto park = [&](int tq, const f32x4 *src) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = 8 * i + rr8;
+            tile[row * 8 + (ch8 ^ (row & 7))] = norm_apply(src[i], a.norm, tq * 32 + 4 * ch8);
+        }
+    };
+    auto frags = [&]() {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int gg = 0; gg < 2; ++gg) af[mt][gg] = tile[(mt * 16 + r16) * 8 + ((4 * gg + q4) ^ (r16 & 7))];
+    };
+    auto mfmas = [&](const f32x4 (*fb)[NT]) {
+#ifdef ABL_PROJ_NOMFMA
+        asm volatile("" ::"v"(af[0][0]), "v"(af[0][1]), "v"(af[1][0]), "v"(af[1][1]));
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) asm volatile("" ::"v"(fb[0][nt]), "v"(fb[1][nt]));
+        return;
+#endif
+#pragma unroll
+        for (int gg = 0; gg < 2; ++gg)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mt][gg][e], fb[gg][nt][e], acc[mt][nt], 0, 0, 0);
+    };
+
+    if (cbeg < cend) {   // (a wave without a chunk only takes part in the sum below)
+        // prologue: first chunk, in consumption order
+        const int t0 = cbeg * 4;
+        loadB(t0, bq[0]);        __builtin_amdgcn_sched_barrier(0);
+        loadA(t0, araw[0]);      __builtin_amdgcn_sched_barrier(0);
+        loadB(t0 + 1, bq[1]);    __builtin_amdgcn_sched_barrier(0);
+        loadA(t0 + 1, araw[1]);  __builtin_amdgcn_sched_barrier(0);
+        loadA(t0 + 2, araw[2]);  __builtin_amdgcn_sched_barrier(0);
+        loadA(t0 + 3, araw[3]);  __builtin_amdgcn_sched_barrier(0);
+        const int clast = cend - 1;
+        for (int c = cbeg; c < clast; ++c) {   // every chunk but the last: 4 full quarters, next chunk prefetched
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) {
+                const int tq = 4 * c + qq;
+                park(tq, araw[qq]);
+                loadA(tq + 4, araw[qq]);
+                __builtin_amdgcn_sched_barrier(0);
+                frags();
+                mfmas(bq[qq & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+                loadB(tq + 2, bq[qq & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // last chunk: 4 quarters, or 2 when D % 128 == 64 and it is the row's last
+        const int tl = 4 * clast;
+        const bool full = qlast - tl >= 3;   // uniform
+#pragma unroll
+        for (int qq = 0; qq < 2; ++qq) {
+            park(tl + qq, araw[qq]);
+            frags();
+            mfmas(bq[qq & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            loadB(tl + qq + 2, bq[qq & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (full) {
+#pragma unroll
+            for (int qq = 2; qq < 4; ++qq) {
+                park(tl + qq, araw[qq]);
+                frags();
+                mfmas(bq[qq & 1]);
+            }
+        }
+    }
+
+    // cross-wave sum and store: identical to proj_body
+    __syncthreads();
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) lds[(wave * 2 * NT + mt * NT + nt) * 64 + lane] = acc[mt][nt];
+    __syncthreads();
+    for (int t = wave; t < 2 * NT; t += 4) {
+        const int mt = t / NT, nt = t % NT;
+        f32x4 sum = lds[(0 * 2 * NT + t) * 64 + lane];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) sum += lds[(w * 2 * NT + t) * 64 + lane];
+        float *dst = jb.ypart + (size_t)s * jb.sstride + (size_t)(row0 + mt * 16 + 4 * q4) * jb.npad +
+                     nt * 16 + r16;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dst[(size_t)e * jb.npad] = sum[e];
+    }
+}
+
+extern "C" __global__ __launch_bounds__(256) void cfl_proj_stream_kernel(ProjArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    f32x4 *lds = (f32x4 *)smem;
+    int z = blockIdx.z, rowtile = a.xcd ? blockIdx.y : blockIdx.x;
+    if (a.mix) {
+        // linear id -> (job, row tile): groups of 8 consecutive workgroups (one per XCD) share a job
+        const int id = blockIdx.x, nz = a.mixjobs;
+        z = (id >> 3) % nz;
+        rowtile = (id / (8 * nz)) * 8 + (id & 7);
+        if (rowtile * 32 >= a.R && a.job[z].nt != 0) return;
+    }
+    const ProjJob &jb = a.job[z];
+    switch (jb.nt) {
+        case 0: {
+            const int nb = a.mix ? a.mixtiles : gridDim.x * gridDim.y;
+            const int b0 = a.mix ? rowtile : blockIdx.y * gridDim.x + blockIdx.x;
+            for (int col = b0; col < a.cn.ncols; col += nb) colnorm_column(a.cn, col, (float *)smem);
+            break;
+        }
+        case 1: proj_stream_body<1>(jb, a, lds, rowtile); break;
+        case 2: proj_stream_body<2>(jb, a, lds, rowtile); break;
+        case 3: proj_stream_body<3>(jb, a, lds, rowtile); break;
+        default: proj_stream_body<4>(jb, a, lds, rowtile); break;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// proj, ring form (large row counts: rows per side >= 2048, every dist_eval / dist_predict call).
+// Counters of the streaming form above on a dist_eval call (profiles/r03_a_*): the matrix pipe is busy 40 % of
+// the launch while the waves spend 77 % of their cycles stalled AT ISSUE (SQ_WAIT_INST_ANY) -- not in s_waitcnt.
+// A wave that both loads and multiplies is in-order: when the vector-memory path is backed up (16 KiB of x in
+// flight per wave, and every wave fetching its own W fragments from L2: 2 bytes of W per byte of x) its next
+// load sits at issue and the MFMAs behind it cannot start.  Ablations say the same: loads alone 62 us, MFMAs +
+// W alone 58 us, together 82 us.  So loading and multiplying are separated:
+//   workgroup = 8 waves: 4 LOADER waves + 4 CONSUMER waves (one of each per SIMD), one workgroup per CU;
+//   work unit  = (column job, 128-row tile, d slice): consumer j owns rows 32j .. 32j+31 of the tile for the whole
+//                slice (no cross-wave sum), the 4 consumers share the W fragments of a step through LDS (a
+//                quarter of the L2 -> CU traffic of the per-wave fetches);
+//   step       = 64 d (two 32-d quarters).  A ring of RING_SLOTS slots in LDS, slot = [2 x 4 x (32 rows x 32 d) |
+//                4*NT W blocks]; everything arrives by LDS-DMA (global_load_lds_dwordx4: no VGPRs, no ds_write):
+//                x in 8-row x 128-B pieces whose per-lane SOURCE address is pre-swizzled so that the lane-linear
+//                LDS image is the XOR-swizzled A-fragment tile of proj_body; W blocks are already fragment-major
+//                (1 KiB = one piece, read back lane-linear);
+//   protocol   = per step: loaders issue the pieces of step t + 2 into the slot the consumers left at the previous
+//                barrier, wait (counted vmcnt) until step t + 1 has landed, barrier; consumers read the fragments
+//                of step t (ds_read_b128, all requested up front, consumed progressively), multiply, barrier.
+//                One step (48 KiB per CU) stays in flight across every barrier; a consumer never issues a
+//                vector-memory instruction in the loop.  A loader issues 8 + NT pieces per step.
+//   A workgroup walks up to RING_UNITS units as ONE stream of steps (the ring runs across the seams); units are
+//   dealt heavy-to-light in snake order, so every workgroup gets the same mix of wide and narrow jobs.
+// Arithmetic per output element: the same k-ordered fp32 FMA chain as proj_body over the wave's d range; a d slice
+// is summed by one wave here (by four in proj_body), so results differ from the other forms by fp32 rounding of
+// the slice sums only.
+// ---------------------------------------------------------------------------
+#define RING_SLOTS 3
+#define RING_UNITS 4
+#define RING_SLOT_FLOATS (12 * 1024)           // 32 KiB of x + 16 KiB of W
+#define RING_LDS_BYTES (RING_SLOTS * RING_SLOT_FLOATS * 4)
+
+struct RingArgs {
+    ProjJob job[CFL_MAX_JOBS];
+    int order[CFL_MAX_JOBS];   // job indices, widest first
+    RowSrc rows[2];
+    int B, R, D, S, njobs;
+    int tiles, nunits, nwg, Kh;   // 128-row tiles per side, units = njobs * tiles * S, workgroups, 64-d steps per slice
+    int dbg;                      // CFL_DEBUG_RING_ABL (timing experiments only): 1 no x pieces, 2 no W pieces, 4 no MFMAs
+    NormDev norm;
+};
+
+// one 1 KiB LDS-DMA piece: lane l's 16 bytes at gsrc land at lds_dst + 16 l (lds_dst wave-uniform byte address)
+__device__ __forceinline__ void glds16(const float *gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+// wait until at most `pieces` (9 .. 12: the pieces of ONE step) of this wave's DMA pieces are outstanding
+__device__ __forceinline__ void ring_wait_all_but(int pieces) {
+    switch (pieces) {
+        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+        case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+        case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+        case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+}
+
+__device__ __forceinline__ void ring_unit_of(const RingArgs &a, int uid, int &job, int &tile, int &slice) {
+    const int per_job = a.tiles * a.S;
+    job = a.order[uid / per_job];
+    const int rem = uid % per_job;
+    tile = rem / a.S;
+    slice = rem % a.S;
+}
+// the i-th unit of workgroup w (snake order over the heavy-to-light list); -1: none
+__device__ __forceinline__ int ring_uid(const RingArgs &a, int w, int i) {
+    const int base = (i >> 1) * 2 * a.nwg;
+    const int uid = (i & 1) ? base + 2 * a.nwg - 1 - w : base + w;
+    return uid < a.nunits ? uid : -1;
+}
+
+template <int NT>
+__device__ __forceinline__ void ring_consume_unit(const RingArgs &a, const ProjJob &jb, int tile, int slice, int t0,
+                                                  const float *lds, int cj) {
+    const int lane = threadIdx.x & 63;
+    const int r16 = lane & 15, q4 = lane >> 4;
+    f32x4 acc[2][NT];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int d0 = slice * a.Kh * 64;
+    // Two fragment sets, one per 32-d half of a step: the reads of a half are in flight while the other half is
+    // multiplied, and the step's barrier sits between its two MFMA groups -- when it is reached both halves of the
+    // slot are in registers (the slot is free), and the first half of the NEXT step is requested right behind it.
+    f32x4 af[2][2][2], bq[2][2][NT];   // [set = half][..]
+    auto readh = [&](int slot, int h) {
+        const f32x4 *xs = (const f32x4 *)(lds + slot * RING_SLOT_FLOATS + (h * 4 + cj) * 1024);
+        const f32x4 *wsl = (const f32x4 *)(lds + slot * RING_SLOT_FLOATS + 8192 + h * 2 * NT * 256) + lane;
+#pragma unroll
+        for (int gg = 0; gg < 2; ++gg) {
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) af[h][mt][gg] = xs[(mt * 16 + r16) * 8 + ((4 * gg + q4) ^ (r16 & 7))];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) bq[h][gg][nt] = wsl[(gg * NT + nt) * 64];
+        }
+    };
+    auto mult = [&](int q, int h) {
+        if (a.norm.elementwise) {
+#pragma unroll
+            for (int gg = 0; gg < 2; ++gg)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+                    af[h][mt][gg] = norm_apply(af[h][mt][gg], a.norm, d0 + q * 64 + h * 32 + 4 * (4 * gg + q4));
+        }
+        if (a.dbg & 4) {   // timing experiments: fragments consumed, nothing multiplied
+#pragma unroll
+            for (int gg = 0; gg < 2; ++gg) {
+                asm volatile("" ::"v"(af[h][0][gg]), "v"(af[h][1][gg]));
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) asm volatile("" ::"v"(bq[h][gg][nt]));
+            }
+            return;
+        }
+#pragma unroll
+        for (int gg = 0; gg < 2; ++gg)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[h][mt][gg][e], bq[h][gg][nt][e], acc[mt][nt], 0, 0, 0);
+    };
+    readh(t0 % RING_SLOTS, 0);
+    for (int q = 0; q < a.Kh; ++q) {
+        const int slot = (t0 + q) % RING_SLOTS;
+        readh(slot, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mult(q, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // both halves of the slot are in registers: it may be refilled
+        if (t0 == 0 && q == 0) RSTAMP(2);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (q + 1 < a.Kh) readh((t0 + q + 1) % RING_SLOTS, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        mult(q, 1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (t0 == 0) RSTAMP(3);
+    // C layout: col = lane & 15, rows 4 (lane >> 4) .. + 3  ->  Ypart[slice][row][npad]
+    const int row0 = tile * 128 + cj * 32;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            float *dst = jb.ypart + (size_t)slice * jb.sstride + (size_t)(row0 + mt * 16 + 4 * q4) * jb.npad + nt * 16 + r16;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dst[(size_t)e * jb.npad] = acc[mt][nt][e];
+        }
+}
+
+extern "C" __global__ __launch_bounds__(512) void cfl_proj_ring_kernel(RingArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const float *lds = (const float *)smem;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int w = blockIdx.x;
+    const int G = a.D >> 4;
+    int nu = 0;
+#pragma unroll
+    for (int i = 0; i < RING_UNITS; ++i) nu += ring_uid(a, w, i) >= 0 ? 1 : 0;   // units are a prefix (uid grows with i)
+    const int T = nu * a.Kh;
+
+    if (wave >= 4) {
+        // ---------------- loader wave lj: x rows 32 lj .. 32 lj + 31 of every unit's tile, W blocks lj + 4k ------------
+        const int lj = wave - 4;
+        const float *xp[RING_UNITS][4];
+        const float *wp[RING_UNITS][4];
+        int unt[RING_UNITS];
+        typedef __attribute__((address_space(3))) char lds_char;
+        const unsigned lds0 = (unsigned)(uintptr_t)(lds_char *)smem;   // LDS byte address of the ring
+#pragma unroll
+        for (int u = 0; u < RING_UNITS; ++u) {
+            int job = 0, tile = 0, slice = 0;
+            const int uid = ring_uid(a, w, u);
+            ring_unit_of(a, uid >= 0 ? uid : 0, job, tile, slice);
+            const ProjJob &jb = a.job[job];
+            const RowSrc rs = jb.side ? a.rows[1] : a.rows[0];
+            const int rr = lane >> 3, ch = (lane & 7) ^ (rr & 7);   // LDS position l <-> (row l >> 3, chunk (l & 7) ^ row)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                xp[u][i] = row_ptr(rs, tile * 128 + lj * 32 + 8 * i + rr, a.B, a.R, a.D) + slice * a.Kh * 64 + 4 * ch;
+            unt[u] = jb.nt;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int b = lj + 4 * k;                 // block b = (h * 2 + gg) * NT + nt of the step's W tile, b < 4 NT
+                const int hg = b / jb.nt, nt = b - hg * jb.nt;   // hg = 2 h + gg = the 16-d group inside the step
+                wp[u][k] = jb.wf + ((size_t)nt * G + 4 * slice * a.Kh + (hg & 3)) * 256 + lane * 4;
+            }
+        }
+        // the row pointers of an indexed source come from index loads: every ordinary load has returned before the
+        // first DMA piece is issued (none is issued after this point)
+        RSTAMP(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        RSTAMP(1);
+        auto issue = [&](int t) -> int {   // returns the pieces issued
+            const int u = t / a.Kh, q = t - u * a.Kh;
+            const unsigned sb = lds0 + (unsigned)((t % RING_SLOTS) * RING_SLOT_FLOATS) * 4;
+            int n = 0;
+#pragma unroll
+            for (int uu = 0; uu < RING_UNITS; ++uu)
+                if (uu == u) {   // (static register indexing)
+                    if (!(a.dbg & 1)) {
+#pragma unroll
+                        for (int h = 0; h < 2; ++h)
+#pragma unroll
+                            for (int i = 0; i < 4; ++i)
+                                glds16(xp[uu][i] + q * 64 + h * 32, sb + ((h * 4 + lj) * 1024 + i * 256) * 4);
+                        n += 8;
+                    }
+                    if (!(a.dbg & 2)) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            if (k < unt[uu]) glds16(wp[uu][k] + (size_t)q * 1024, sb + (8192 + (lj + 4 * k) * 256) * 4);
+                        n += unt[uu];
+                    }
+                }
+            return n;
+        };
+        int pend = 0;                       // pieces of the newest step issued
+        if (T > 0) pend = issue(0);
+        if (T > 1) pend = issue(1);
+        RSTAMP(2);
+        ring_wait_all_but(T > 1 ? pend : 0);   // step 0 has landed
+        RSTAMP(3);
+        __builtin_amdgcn_s_barrier();
+        for (int t = 0; t < T; ++t) {
+            // step t + 2 goes into the slot of step t - 1, which the consumers left at the last barrier
+            if (t + 2 < T) { pend = issue(t + 2); ring_wait_all_but(pend); }   // step t + 1 has landed
+            else ring_wait_all_but(0);
+            if (t == 0) RSTAMP(4);
+            if (t == a.Kh - 1) RSTAMP(5);
+            __builtin_amdgcn_s_barrier();
+            if (t == a.Kh - 1) RSTAMP(6);
+        }
+        RSTAMP(7);
+        return;
+    }
+
+    // ---------------- consumer wave cj ------------------------------------------------------------------------------
+    RSTAMP(0);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    RSTAMP(1);
+    int t0 = 0;
+    for (int u = 0; u < nu; ++u) {
+        int job, tile, slice;
+        ring_unit_of(a, ring_uid(a, w, u), job, tile, slice);
+        const ProjJob &jb = a.job[job];
+        switch (jb.nt) {
+            case 1: ring_consume_unit<1>(a, jb, tile, slice, t0, lds, wave); break;
+            case 2: ring_consume_unit<2>(a, jb, tile, slice, t0, lds, wave); break;
+            case 3: ring_consume_unit<3>(a, jb, tile, slice, t0, lds, wave); break;
+            default: ring_consume_unit<4>(a, jb, tile, slice, t0, lds, wave); break;
+        }
+        t0 += a.Kh;
+        if (u == 0) RSTAMP(4);
+    }
+    RSTAMP(5);
 }
 
 extern "C" __global__ __launch_bounds__(256) void cfl_proj_kernel(ProjArgs a) {
@@ -2395,6 +2858,10 @@ struct Plan {
     size_t ypart[2], dyf[2], cwf[2], wpart[2];
     bool x3;   // bf16x3 matrix-core path for the weight gradient
     bool xcd;  // XCD-aligned launch order of proj / grad (cfl_xcd_aligned)
+    int proj_stream;  // 0: one wait per 128-d chunk (proj_body); 1: streaming form (proj_stream_body)
+    bool proj_mix;    // streaming form at S == 1: column jobs interleaved in launch order
+    bool proj_ring;   // loader / consumer ring form (cfl_proj_ring_kernel); S is then the ring's d split
+    int ring_tiles, ring_units, ring_nwg;
     bool fused;       // gradient + Adam finished inside the weight-gradient launch (GradFuse)
     size_t handoff;   // workspace offset of the hand-off tickets + flags (ints), nhandoff of each
     int nhandoff;
@@ -2473,8 +2940,35 @@ static int make_plan(const CflShape *s, int64_t rows, int groups, bool train, Pl
     if (S > maxS) S = pow2_floor(maxS);
     if (S > 16) S = 16;
     if (debug_env("CFL_DEBUG_S") > 0) S = debug_env("CFL_DEBUG_S");
+    // ring form: >= 2048 rows per side; d split so that every workgroup (one per CU) gets two work units
+    pl->proj_ring = false;
+    {
+        const int ov = debug_env("CFL_DEBUG_PROJ_RING");
+        const int tiles = (pl->R + 127) / 128;
+        int rs = 1;
+        while (rs < 16 && njobs * tiles * rs < 512 && s->D / (2 * rs) >= 256 && (s->D / 64) % (2 * rs) == 0) rs *= 2;
+        const int units = njobs * tiles * rs;
+        const bool ok = (s->D / 64) % rs == 0 && s->D / 64 / rs >= 2 && units <= RING_UNITS * 256 && units >= 192;
+        if (ok && ov > 0) {   // opt-in (CFL_DEBUG_PROJ_RING=1): measured within +-6 % of the streaming form, see DESIGN.md
+            pl->proj_ring = true;
+            pl->ring_tiles = tiles;
+            pl->ring_units = units;
+            int nwg = (units + 1) / 2;
+            if (nwg > 256) nwg = 256;
+            pl->ring_nwg = nwg;
+            S = rs;
+        }
+    }
     pl->S = S;
-    pl->xcd = cfl_xcd_aligned(S, s->D / 64);
+    pl->xcd = !pl->proj_ring && cfl_xcd_aligned(S, s->D / 64);
+    // streaming projection when a wave owns at least four 128-d chunks (measured: equal to the chunk-at-a-time form at
+    // two, -11 % at eight; CFL_DEBUG_PROJ_STREAM: -1 never, 1 always)
+    {
+        const int per_wave = nchunks / (4 * S);
+        const int ov = debug_env("CFL_DEBUG_PROJ_STREAM");
+        pl->proj_stream = ov < 0 ? 0 : ov > 0 ? 1 : (per_wave >= 4 ? 1 : 0);
+        pl->proj_mix = debug_env("CFL_DEBUG_PROJ_MIX") > 0;   // opt-in: measured +15 % (slower) on dist_eval calls
+    }
     pl->mid_generic = debug_env("CFL_DEBUG_MID_GENERIC") > 0;
     pl->mid_norow = debug_env("CFL_DEBUG_MID_NOROW") != 0;
     pl->nrb = pl->Rpad / MID_RB;
@@ -2706,10 +3200,49 @@ static int run_pairs(const CflShape *s, const CflNorm *norm, const CflLossCfg *l
         if (cn_slice && nj >= CFL_MAX_JOBS) return set_err(CFL_E_UNSUPPORTED, "too many column chunks");
         if (cn_slice) pa.job[nj].nt = 0;      // marks the colnorm slice
         const int nz = nj + (cn_slice ? 1 : 0);
-        dim3 grid((pl.R + 31) / 32, pl.S, nz);
-        if (pa.xcd) grid = dim3(pl.S, (pl.R + 31) / 32, nz);
+        if (pl.proj_ring) {
+            RingArgs ra;
+            memset(&ra, 0, sizeof(ra));
+            for (int i = 0; i < nj; ++i) ra.job[i] = pa.job[i];
+            // widest jobs first (stable)
+            int k = 0;
+            for (int nt = 4; nt >= 1; --nt)
+                for (int i = 0; i < nj; ++i)
+                    if (pa.job[i].nt == nt) ra.order[k++] = i;
+            ra.rows[0] = rsrc[0]; ra.rows[1] = rsrc[1];
+            ra.B = (int)rows; ra.R = pl.R; ra.D = s->D; ra.S = pl.S; ra.njobs = nj;
+            ra.tiles = pl.ring_tiles; ra.nunits = pl.ring_units; ra.nwg = pl.ring_nwg; ra.Kh = s->D / 64 / pl.S;
+            ra.norm = nd;
+            ra.dbg = debug_env("CFL_DEBUG_RING_ABL");
+            static std::atomic<bool> attr{false};   // > 64 KiB of dynamic LDS needs the opt-in
+            if (!attr.load()) {
+                HIP_TRY(hipFuncSetAttribute((const void *)cfl_proj_ring_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            RING_LDS_BYTES));
+                attr.store(true);
+            }
+            ProfScope ps(st, CFL_K_PROJ);
+            hipLaunchKernelGGL(cfl_proj_ring_kernel, dim3(pl.ring_nwg), dim3(512), RING_LDS_BYTES, st, ra);
+            if (cn_slice) {   // weight-norm column norms: the colnorm slice alone, in the chunk-at-a-time kernel
+                ProjArgs pc = pa;
+                pc.job[0].nt = 0;
+                pc.xcd = 0; pc.mix = 0;
+                hipLaunchKernelGGL(cfl_proj_kernel, dim3(64, 1, 1), dim3(256), 4 * 8 * 64 * sizeof(f32x4), st, pc);
+            }
+        } else {
+        const int rtiles = (pl.R + 31) / 32;
+        dim3 grid(rtiles, pl.S, nz);
+        if (pa.xcd) grid = dim3(pl.S, rtiles, nz);
+        if (pl.proj_stream && pl.proj_mix && pl.S == 1 && nz > 1) {
+            pa.mix = 1; pa.mixjobs = nz; pa.mixtiles = (int)round_up(rtiles, 8);
+            grid = dim3(pa.mixtiles * nz, 1, 1);
+        }
         ProfScope ps(st, CFL_K_PROJ);
-        hipLaunchKernelGGL(cfl_proj_kernel, grid, dim3(256), 4 * 8 * 64 * sizeof(f32x4), st, pa);  // 32 KiB: cross-wave sum (the 4 KiB/wave transpose tiles alias it)
+        // 32 KiB: cross-wave sum (the 4 (8) KiB/wave transpose tiles alias it)
+        if (pl.proj_stream)
+            hipLaunchKernelGGL(cfl_proj_stream_kernel, grid, dim3(256), 4 * 8 * 64 * sizeof(f32x4), st, pa);
+        else
+            hipLaunchKernelGGL(cfl_proj_kernel, grid, dim3(256), 4 * 8 * 64 * sizeof(f32x4), st, pa);
+        }
     }
 
     // ---- mid ----------------------------------------------------------------

@@ -499,3 +499,48 @@ def test_step_windows_equal_single_indexed_steps(tmp_path):
     assert a.head_labeled_pos == b.head_labeled_pos and a.head_labeled_neg == b.head_labeled_neg
     assert np.array_equal(a.pairs_pos, b.pairs_pos) and np.array_equal(a.pairs_neg, b.pairs_neg)
     assert a._rng.rand() == b._rng.rand()
+
+
+@pytest.mark.parametrize('D,L,K,n,act_norm', [(4096, 20, 3, 8192, False), (2048, 20, 5, 4500, False), (1088, 12, 2, 3000, True),
+                                              (4096, 64, 1, 2100, False)])
+def test_projection_forms_agree(D, L, K, n, act_norm, monkeypatch):
+    """The three forms of the forward projection on large scoring calls (a wave owns several 128-d chunks):
+    chunk-at-a-time (proj_body), streaming (proj_stream_body: the default from four chunks per wave) and the
+    loader / consumer ring (cfl_proj_ring_kernel, opt-in).  The streaming form must reproduce the chunk-at-a-time
+    scores BIT FOR BIT (same k-ordered FMA chains, same summation order); the ring form sums a d slice in one
+    wave instead of four, so it is held to fp32 rounding of the scores, and every form to 1e-5 of the fp64
+    oracle.  Shapes: the dist_eval call (two jobs, 4 / 2 column tiles), 7 column tiles on the source side
+    (jobs of 4 + 3 tiles), D % 128 == 64 with an element-wise normaliser, and a one-job-per-side K = 1 model."""
+    rng = np.random.RandomState(99)
+    cfg = O.EncoderCfg(D=D, L=L, K=K)
+    p = _mk(cfg, rng)
+    sh = _shape(cfg)
+    thr, nv = 0.41, 58.388599
+    theta = H.pack_theta(sh, p, None, thr, 'cuda')
+    xs = torch.from_numpy(_inputs(rng, n, D, nv / 4)).cuda()
+    xt = torch.from_numpy(_inputs(rng, n, D, nv / 4)).cuda()
+    norm = H.make_norm(1.0 / nv, -0.05, 0.0, 0.9) if act_norm else H.make_norm(1.0 / nv)
+
+    def run(stream, ring):
+        monkeypatch.setenv('CFL_DEBUG_PROJ_STREAM', str(stream))
+        monkeypatch.setenv('CFL_DEBUG_PROJ_RING', str(ring))
+        H.reload_env()
+        ws = torch.full((H.workspace_bytes(sh, n, 1) // 4,), float('nan'), dtype=torch.float32, device='cuda')
+        out = H.pair_scores(sh, norm, xs, xt, theta, ws).clone()
+        torch.cuda.synchronize()
+        return out
+    try:
+        classic, stream, ring = run(-1, -1), run(1, -1), run(-1, 1)
+    finally:
+        monkeypatch.delenv('CFL_DEBUG_PROJ_STREAM')
+        monkeypatch.delenv('CFL_DEBUG_PROJ_RING')
+        H.reload_env()
+    assert torch.equal(classic, stream)
+    scale = max(1.0, float(classic.abs().max()))
+    assert float((classic - ring).abs().max()) <= 4e-6 * scale
+    f = (lambda x: O.normalize_v2(x.cpu().numpy().astype(np.float64), scale=1.0 / nv, mean=0.05, norm=1.0, clip_min=0.0,
+                                  clip_max=0.9)) if act_norm else (lambda x: x.cpu().numpy().astype(np.float64) / nv)
+    sub = slice(0, 1500)
+    ref = O.pair_scores(cfg, _to64(p), np.float64(thr), f(xs[sub]), f(xt[sub]))
+    for got in (classic, ring):
+        assert np.abs(got[sub].cpu().numpy() - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max())
