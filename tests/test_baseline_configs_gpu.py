@@ -1,9 +1,12 @@
 """BASELINE.json workloads at their own shapes (-m gpu).
 
-* config 1 (headline): 4096-d features, PCD K=3, L=20, batch 512 -- 100 training steps against the float64
-  oracle on identical batches (loss within 1e-5 at every step), then 2 x 100 000 held-out pairs scored by the
-  HIP scoring path and by the oracle on its own trained weights: AUC within 1e-4 (SURVEY 8(d) "AUC check").
-* config 4 shape (2048-d, K=5, L=20, batch 1024, weight-norm heads): 30 steps the same way.
+* config 1 (headline): 4096-d features, PCD K=3, L=20, batch 512 -- 100 training steps beside the oracle in float64
+  AND in float32 on identical batches: three deviation series per step (HIP vs fp64, HIP vs fp32 CPU, fp32 CPU vs fp64)
+  recorded and capped at the values in CAPS (observed series: profiles/r03_trajectory_*.json), then 2 x 100 000
+  held-out pairs scored by the HIP scoring path and by the oracle on its own trained weights: AUC within 1e-4
+  (SURVEY 8(d) "AUC check").
+* config 4 shape (2048-d, K=5, L=20, batch 1024, weight-norm heads) and config 3 (1024-d siamese L=256, hinge margin
+  100, pos_weight 0.0625) plus the dyadic script's pcd run: 30 steps the same way.
 * config 5 (MrCGAN 64x64x3, latent 64, K=2, z=20, srgan, lambda_gp 0.5, m_prj 0.2, m_enc 0.05;
   experiments/dyadic/run_gen.sh:25-53): one full post-epoch step -- every loss part and the D / G gradients --
   against oracle/gan_oracle.py at B=20, and the loss parts at the reference batch size B=100.
@@ -31,27 +34,35 @@ def _planted(gen, B, D, teacher, back, s, noise):
     return [t.contiguous() for t in (ps, pd, ns, nd)]
 
 
-def _trajectory(style, D, K, L, B, steps, lkw, n_eval, nv, min_auc=None):
+def _trajectory(name, style, D, K, L, B, steps, lkw, n_eval, nv, caps, min_auc=None, dist_type='pcd'):
     """HIP beside the NumPy oracle in float64 AND in float32 (the precision of the reference's TensorFlow CPU path) on
-    identical batches.  Bars: the loss of every step within 1e-5 of float64 -- or, where Adam's first lr-sized steps
-    make the trajectory itself ill-conditioned (a 4096-d batch moves every output by ~0.7 per step; the loss jumps by
-    10x between steps), within 4x of what the fp32 CPU evaluation deviates; AUC on the held-out pairs within 1e-4."""
+    identical batches.  Three series are measured per step, recorded (CFL_RECORD_DIR=<dir> writes
+    <dir>/trajectory_<name>.json; the committed copies are profiles/r03_trajectory_*.json) and asserted:
+        hip_vs_fp64    |loss_HIP - loss_fp64| / max(1, |loss_fp64|)
+        hip_vs_fp32    |loss_HIP - loss_fp32cpu| / max(1, ...)        (north_star's reference IS an fp32 CPU path)
+        fp32_vs_fp64   |loss_fp32cpu - loss_fp64| / max(1, ...)       (what fp32 arithmetic itself costs here)
+    `caps` = (cap on hip_vs_fp64, cap on hip_vs_fp32): twice the worst value observed when the bars were set, floored
+    at 1e-6 (the observed series are in the committed JSON); all are below north_star's 1e-5.  Step 0 (before any update: pure forward precision) is held
+    to 1e-6.  AUC on the held-out pairs within 1e-4 of the float64 oracle's."""
+    import json
+    import os
     from cfl import hipabi as H
     from cfl.engine import PairEngine
     rng = np.random.RandomState(0)
-    cfg = O.EncoderCfg(D=D, L=L, K=K, dist_type='pcd', style=style)
+    cfg = O.EncoderCfg(D=D, L=L, K=K, dist_type=dist_type, style=style)
     p = O.init_encoder_params(cfg, rng, np.float32)
     lcfg = O.LossCfg(**lkw)
+    thr0 = 1e-6
     tr = O.OracleTrainer(cfg, lcfg, lr=1e-3, dtype=np.float64, params={k: v.astype(np.float64) for k, v in p.items()})
     tr32 = O.OracleTrainer(cfg, lcfg, lr=1e-3, dtype=np.float32, params={k: v.copy() for k, v in p.items()})
-    eng = PairEngine(D, L, K, 'pcd', weight_norm=cfg.weight_norm, has_bias=cfg.has_bias, norm=H.make_norm(1.0 / nv),
-                     loss=H.make_loss(**lkw), lr=1e-3, device='cuda', params=p, batch_size=B)
+    eng = PairEngine(D, L, K, dist_type, weight_norm=cfg.weight_norm, has_bias=cfg.has_bias, norm=H.make_norm(1.0 / nv),
+                     loss=H.make_loss(**lkw), lr=1e-3, device='cuda', params=p, thr=thr0, batch_size=B)
     gen = torch.Generator(device='cuda')
     gen.manual_seed(633)
     teacher = torch.randn(D, 64, generator=gen, device='cuda') / D ** 0.5
     back = torch.randn(64, D, generator=gen, device='cuda') / 8.0
     s = nv / 4.5
-    hip_err, cpu32_err = [], []
+    hip64, hip32, cpu32 = [], [], []
     for it in range(steps):
         b = _planted(gen, B, D, teacher, back, s, 0.3)
         eng.step(b)
@@ -59,13 +70,15 @@ def _trajectory(style, D, K, L, B, steps, lkw, n_eval, nv, min_auc=None):
         sc = tr.step(tuple(x.astype(np.float64) / nv for x in host))
         sc32 = tr32.step(tuple(x / np.float32(nv) for x in host))
         got = eng.read_scalars()['total']
-        hip_err.append(abs(got - sc['total']) / max(1.0, abs(sc['total'])))
-        cpu32_err.append(abs(float(sc32['total']) - sc['total']) / max(1.0, abs(sc['total'])))
+        den = max(1.0, abs(sc['total']))
+        hip64.append(abs(got - sc['total']) / den)
+        hip32.append(abs(got - float(sc32['total'])) / den)
+        cpu32.append(abs(float(sc32['total']) - sc['total']) / den)
+    record = {'name': name, 'shape': dict(style=style, dist_type=dist_type, D=D, K=K, L=L, B=B, steps=steps, loss=lkw, nv=nv),
+              'hip_vs_fp64': hip64, 'hip_vs_fp32cpu': hip32, 'fp32cpu_vs_fp64': cpu32,
+              'max': dict(hip_vs_fp64=max(hip64), hip_vs_fp32cpu=max(hip32), fp32cpu_vs_fp64=max(cpu32)),
+              'caps_asserted': dict(hip_vs_fp64=caps[0], hip_vs_fp32cpu=caps[1], step0=1e-6)}
     show = lambda e: ['%.1e' % x for x in e[:12]] + ['max %.1e' % max(e)]
-    assert hip_err[0] <= 1e-6, show(hip_err)
-    for t in range(steps):
-        assert hip_err[t] <= max(1e-5, 4.0 * max(cpu32_err[:t + 1])), (t, show(hip_err), show(cpu32_err))
-    assert max(hip_err) <= 2e-4, show(hip_err)
     # held-out pairs, scored in chunks: HIP scores with the HIP-trained weights, the oracles with their own
     sp, sn, rp, rn, qp, qn = [], [], [], [], [], []
     chunk = 8192
@@ -81,33 +94,67 @@ def _trajectory(style, D, K, L, B, steps, lkw, n_eval, nv, min_auc=None):
         qn.append(tr32.scores(g(ns), g(nd)))
     sp, sn, rp, rn, qp, qn = (np.concatenate(a)[:n_eval] for a in (sp, sn, rp, rn, qp, qn))
     ev_h, ev_o = O.dist_eval(sp.astype(np.float64), sn.astype(np.float64)), O.dist_eval(rp, rn)
+    ev_q = O.dist_eval(qp.astype(np.float64), qn.astype(np.float64))
+    scale = max(1.0, float(np.abs(rp).max()))
+    cpu32_dev = max(np.abs(qp - rp).max(), np.abs(qn - rn).max())
+    hip_dev = max(np.abs(sp - rp).max(), np.abs(sn - rn).max())
+    record['eval'] = dict(pairs=int(n_eval), auc_hip=ev_h['auc'], auc_fp64=ev_o['auc'], auc_fp32cpu=ev_q['auc'],
+                          accuracy_hip=ev_h['accuracy'], accuracy_fp64=ev_o['accuracy'],
+                          max_score_dev_hip=float(hip_dev), max_score_dev_fp32cpu=float(cpu32_dev), score_scale=scale)
+    out_dir = os.environ.get('CFL_RECORD_DIR')
+    if out_dir:
+        os.makedirs(out_dir, exist_ok=True)
+        with open(os.path.join(out_dir, 'trajectory_%s.json' % name), 'w') as fh:
+            json.dump(record, fh, indent=1)
+    assert hip64[0] <= 1e-6, show(hip64)
+    assert max(hip64) <= caps[0], (show(hip64), show(cpu32))
+    assert max(hip32) <= caps[1], (show(hip32), show(cpu32))
     if min_auc is not None:
         assert min_auc < ev_o['auc'] < 0.9999, ev_o       # a non-trivial ranking problem
     assert abs(ev_h['auc'] - ev_o['auc']) <= 1e-4, (ev_h, ev_o)
     assert abs(ev_h['accuracy'] - ev_o['accuracy']) <= 1e-3, (ev_h, ev_o)
-    scale = max(1.0, float(np.abs(rp).max()))
-    cpu32_dev = max(np.abs(qp - rp).max(), np.abs(qn - rn).max())
-    hip_dev = max(np.abs(sp - rp).max(), np.abs(sn - rn).max())
     assert hip_dev <= max(1e-4 * scale, 4.0 * cpu32_dev), (hip_dev, cpu32_dev, scale)
-    return max(hip_err), ev_h, ev_o
+    return record
+
+
+# (cap on |HIP - fp64|, cap on |HIP - fp32 CPU|) per workload: 2x the worst value observed on MI355X when the bars
+# were set -- the observed series are committed as profiles/r03_trajectory_<name>.json
+CAPS = {
+    'headline': (4e-6, 2e-6),                 # observed 1.9e-6 / 6.3e-7 (fp32 CPU vs fp64: 1.3e-6)
+    'config4': (1e-6, 1e-6),                  # observed 8.9e-8 / 3.6e-7
+    'config3_pcd': (1e-6, 1e-6),              # observed 1.1e-7 / 1.5e-7
+    'config3_siamese_hinge': (1e-6, 1e-6),    # observed 7.2e-8 / 2.1e-7
+}
 
 
 def test_headline_config_100_steps_and_auc_on_100k_pairs():
     """BASELINE config 1: Monomer-style 4096-d, `Dist` model, K=3, L=20, B=512."""
-    worst, ev_h, ev_o = _trajectory('dist', 4096, 3, 20, 512, 100, dict(), 100000, NV, min_auc=0.52)
-    print('headline: worst rel loss diff %.2e, AUC hip %.6f oracle %.6f' % (worst, ev_h['auc'], ev_o['auc']))
+    r = _trajectory('headline', 'dist', 4096, 3, 20, 512, 100, dict(), 100000, NV, CAPS['headline'], min_auc=0.52)
+    print('headline: worst rel loss diff vs fp64 %.2e, vs fp32 cpu %.2e (fp32 cpu vs fp64 %.2e); AUC hip %.6f fp64 %.6f' % (
+        r['max']['hip_vs_fp64'], r['max']['hip_vs_fp32cpu'], r['max']['fp32cpu_vs_fp64'], r['eval']['auc_hip'],
+        r['eval']['auc_fp64']))
 
 
 def test_config4_shape_trajectory_and_auc():
     """BASELINE config 4 shape: 2048-d latents, PCD K=5, L=20, B=1024, weight-normalised CFL heads with the
     polyvore flags (--pos-weight .25 --use-threshold)."""
-    _trajectory('cfl', 2048, 5, 20, 1024, 30, dict(use_threshold=True, pos_weight=0.25), 32768, 1.0)
+    _trajectory('config4', 'cfl', 2048, 5, 20, 1024, 30, dict(use_threshold=True, pos_weight=0.25), 32768, 1.0, CAPS['config4'])
 
 
-def test_config3_shape_trajectory_and_auc():
-    """BASELINE config 3 shape: 1024-d, hinge ("caffe margin") loss would need siamese; here the pcd run of the same
-    script (experiments/dyadic/run.sh: --num-components 3 --latent-size 64 --pos-weight 0.0625 --use-threshold)."""
-    _trajectory('cfl', 1024, 3, 64, 512, 30, dict(use_threshold=True, pos_weight=0.0625), 32768, 31.9098)
+def test_dyadic_pcd_shape_trajectory_and_auc():
+    """The pcd run of the dyadic script (experiments/dyadic/run.sh: 1024-d, --num-components 3 --latent-size 64
+    --pos-weight 0.0625 --use-threshold) -- NOT BASELINE config 3, which is the siamese / hinge model below."""
+    _trajectory('config3_pcd', 'cfl', 1024, 3, 64, 512, 30, dict(use_threshold=True, pos_weight=0.0625), 32768, 31.9098,
+                CAPS['config3_pcd'])
+
+
+def test_config3_siamese_hinge_trajectory_and_auc():
+    """BASELINE config 3, the model itself (experiments/dyadic/run.sh:40-50): 1024-d GoogLeNet latents, siamese
+    distance, latent_size 256, contrastive hinge --caffe-margin 100, --pos-weight 0.0625, no threshold in the encoder
+    loss (the threshold trains under its own Adam), weight-normalised heads, B=512: 30 steps + AUC on 32768 pairs."""
+    _trajectory('config3_siamese_hinge', 'cfl', 1024, 1, 256, 512, 30,
+                dict(use_threshold=False, caffe_margin=100.0, pos_weight=0.0625), 32768, 31.9098,
+                CAPS['config3_siamese_hinge'], dist_type='siamese')
 
 
 def _close(name, got, want, rtol):
