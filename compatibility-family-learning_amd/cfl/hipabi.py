@@ -318,6 +318,7 @@ def mt19937_reshuffle(state, rows, want32=False):
     generator `state` (the tuple of RandomState.get_state()); host-only, runs without the interpreter lock."""
     key = np.array(state[1], dtype=np.uint32)
     pos = C.c_int32(int(state[2]))
+    in_dtype = np.asarray(rows).dtype
     rows = np.ascontiguousarray(rows, dtype=np.int64)
     flat = rows.reshape(rows.shape[0], -1)
     out = np.empty_like(flat)
@@ -325,9 +326,12 @@ def mt19937_reshuffle(state, rows, want32=False):
     _check(lib().cfl_mt19937_reshuffle(key.ctypes.data, C.byref(pos), flat.shape[0], flat.ctypes.data, flat.shape[1],
                                        out.ctypes.data, None, out32.ctypes.data if want32 else None))
     new_state = (state[0], key, int(pos.value), state[3], state[4])
+    res = out.reshape(rows.shape)
+    if in_dtype != np.int64:            # pairs[perm] keeps the dtype of `pairs`
+        res = res.astype(in_dtype)
     if want32:
-        return out.reshape(rows.shape), new_state, out32.reshape(rows.shape)
-    return out.reshape(rows.shape), new_state
+        return res, new_state, out32.reshape(rows.shape)
+    return res, new_state
 
 
 def reload_env():

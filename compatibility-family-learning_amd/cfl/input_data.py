@@ -352,7 +352,8 @@ class SemiDataSet(object):
         if job is not None:
             job['thread'].join()
             step = job['steps'][0] if job['steps'] else None
-            if (step is not None and step['which'] == which and step['pairs'] is pairs and
+            # ('after' is missing when the worker failed -- library error, out of memory: reshuffle synchronously then)
+            if (step is not None and 'after' in step and step['which'] == which and step['pairs'] is pairs and
                     self._same_state(self._rng.get_state(), step['before'])):
                 self._rng.set_state(step['after'])
                 if len(job['steps']) > 1:          # the other list wraps in the same batch: keep its result
@@ -385,10 +386,13 @@ class SemiDataSet(object):
 
         def work():
             cur = state
-            for st in steps:
-                st['before'] = cur
-                st['result'], cur, st['result32'] = hipabi.mt19937_reshuffle(cur, st['pairs'], want32=True)
-                st['after'] = cur
+            try:
+                for st in steps:
+                    st['before'] = cur
+                    st['result'], cur, st['result32'] = hipabi.mt19937_reshuffle(cur, st['pairs'], want32=True)
+                    st['after'] = cur
+            except Exception as e:          # the wrap falls back to numpy (a step without 'after' is never adopted)
+                steps[0].setdefault('error', repr(e))
         th = threading.Thread(target=work, daemon=True)
         th.start()
         self._prefetch = dict(thread=th, steps=steps)

@@ -511,8 +511,17 @@ class Saver(object):
 
 def load_checkpoint_file(path):
     """A checkpoint as {'variables': {TF name: array}, 'adam_m', 'adam_v', ...}: tensors only, no pickled code."""
+    import pickle
     import torch
-    return torch.load(path, map_location='cpu', weights_only=True)
+    try:
+        return torch.load(path, map_location='cpu', weights_only=True)
+    except pickle.UnpicklingError as e:
+        # files written before the tensors-only format pickled numpy arrays: not loadable with weights_only=True
+        raise RuntimeError(
+            '%s was written by an older build of this package (it pickles numpy objects, which are no longer '
+            'unpickled on load).  Convert it once with\n    python -c "import torch; from cfl.utils import Saver; '
+            "d = torch.load(%r, map_location='cpu', weights_only=False); torch.save(Saver._plain(d), %r)\"\n"
+            'after checking that the file comes from a source you trust.  (%s)' % (path, path, path, e))
 
 
 def latest_checkpoint(checkpoint_dir):

@@ -52,6 +52,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define CFL_MAX_JOBS 16
 #define CFL_MAX_REGIONS 20
 #define CFL_THR_FLOOR 1e-6f
+#define CFL_HANDOFF_SPIN_LIMIT (1 << 22)   // polls (with s_sleep) before an in-launch hand-off is declared lost
 
 // ---------------------------------------------------------------------------
 // error plumbing
@@ -965,7 +966,9 @@ struct RedRange {
 };
 #define CFL_MAX_RED 8
 
-// Fused tail of the weight-gradient launch (plan.fused: plain heads, pcd, one encoder, P <= 2): the launch itself
+// Fused tail of the weight-gradient launch (plan.fused: pcd with one encoder -- plain `Dist` heads and weight-normalised
+// `CFL` heads --, any row split P <= 8; CFL_DEBUG_NOFUSE=1 in the environment restores the separate finalize launch):
+// the launch itself
 // turns the per-range partial gradients into the flat gradient and applies TF-Adam, so the step needs no finalize
 // launch and no round trip of P gradient slabs through HBM.
 //   * a (64-d tile, column job) is produced by P workgroups (row ranges).  The first P-1 row ranges
@@ -1130,16 +1133,31 @@ __device__ __forceinline__ void grad_fused_tail(const GradArgs &a, int job, int 
     const int wcol = (wave < NT ? wave : 0) * 16 + (threadIdx.x & 15);
     float wg = 1.f, wn2 = 1.f;
     if (f.wn) { wg = f.wn_g[job][wcol]; wn2 = f.wn_n2[job][wcol]; }
+    bool lost = false;   // a partner never arrived (bounded spin): poison instead of hanging or using stale tiles
     if (P > 1 || f.wn) {
         if (threadIdx.x == 0) {
-            if (P > 1)
-                while (__hip_atomic_load(f.flag + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < P - 1)
+            // Bounded: ~2^22 polls with s_sleep is > 100 ms, four orders of magnitude beyond any hand-off of a healthy
+            // launch.  The waits are for workgroups dispatched BEFORE this one (smaller linear id), which never wait
+            // themselves, so a time-out means the dispatch-order assumption or the visibility protocol failed.
+            int ok = 1;
+            if (P > 1) {
+                int spins = 0;
+                while (__hip_atomic_load(f.flag + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < P - 1) {
                     __builtin_amdgcn_s_sleep(1);
-            if (f.wn)   // the c_j column sums of this launch's reduction blocks (dispatched first, short)
-                while (__hip_atomic_load(f.red_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < f.red_expect)
+                    if (++spins > CFL_HANDOFF_SPIN_LIMIT) { ok = 0; break; }
+                }
+            }
+            if (f.wn && ok) {   // the c_j column sums of this launch's reduction blocks (dispatched first, short)
+                int spins = 0;
+                while (__hip_atomic_load(f.red_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < f.red_expect) {
                     __builtin_amdgcn_s_sleep(1);
+                    if (++spins > CFL_HANDOFF_SPIN_LIMIT) { ok = 0; break; }
+                }
+            }
+            lds_i[0] = ok;
         }
         __syncthreads();
+        lost = lds_i[0] == 0;
     }
     if (wave < NT) {
         // sum over the row ranges in the fixed order 0 .. P-1 (own registers at position p): the result does not
@@ -1157,6 +1175,10 @@ __device__ __forceinline__ void grad_fused_tail(const GradArgs &a, int job, int 
 #pragma unroll
                 for (int e = 0; e < 4; ++e) g[e] += part[e];
             }
+        }
+        if (lost) {   // loud, not silent: NaN gradient (and parameters) for this tile -> NaN loss at the next read-back
+#pragma unroll
+            for (int e = 0; e < 4; ++e) g[e] = (f32x4){NAN, NAN, NAN, NAN};
         }
         if (f.wn) {
             // dV = (g/n) in_mul X^T dy - (g c / n^3) V   (cfl/layers.py:80-90 differentiated; same operations in the
@@ -2925,8 +2947,9 @@ static int make_plan(const CflShape *s, int64_t rows, int groups, bool train, Pl
     // (the forward projection always uses the latter: measured, bf16x3 buys nothing there because each
     // W fragment is shared by only two row tiles, so the splits cost what the MFMAs save)
     pl->x3 = debug_env("CFL_EXACT_FP32") <= 0;
-    // fused tail: every gradient entry must be complete inside one (pair of) workgroup(s) -- plain heads (the
-    // weight-norm correction couples a column over all of d), pcd (each side feeds its own head), one encoder
+    // fused tail: every gradient entry must be complete inside the P workgroups of one (d tile, column job) -- pcd
+    // (each side feeds its own head), one encoder; weight-normalised heads get their column coupling c_j from the
+    // launch's own reduction blocks.  CFL_DEBUG_NOFUSE=1: the escape hatch (separate finalize launch)
     pl->fused = train && s->dist_type == CFL_DIST_PCD && !s->directed &&
                 debug_env("CFL_DEBUG_NOFUSE") <= 0;
     pl->P = P;
@@ -3098,12 +3121,12 @@ static int cached_plan(const CflShape *s, int64_t rows, int groups, bool train, 
         cache.clear();
         seen_generation = g_env_generation.load();
     }
+    if (!s) return set_err(CFL_E_SHAPE, "shape is NULL");
     for (const Entry &e : cache)
         if (e.rows == rows && e.groups == groups && e.train == train && memcmp(&e.s, s, sizeof(CflShape)) == 0) {
             *out = e.pl;
             return CFL_OK;
         }
-    if (!s) return set_err(CFL_E_SHAPE, "shape is NULL");
     int rc = make_plan(s, rows, groups, train, out);
     if (rc) return rc;
     if (cache.size() >= 64) cache.erase(cache.begin());

@@ -25,9 +25,12 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstring>
 
 #include "gemm_gather.h"
+
+extern int cfl_set_err(int code, const char *fmt, ...);   // cfl_hip.hip
 
 struct HaloArgs {
     const float *a;        // [B, H, W, K] fp32 activations (x, or dy)
@@ -415,10 +418,18 @@ static inline void halo_launch_one(const HaloArgs &a, dim3 grid, hipStream_t st)
     constexpr int TH = TW == 16 ? 8 : TW, IMGS = 128 / (TW * TH), HP = IMGS * (TH + 2) * (TW + 2);
     constexpr size_t lds = (size_t)(3 * HP * 40 + 2 * 3 * TN * 40) * sizeof(unsigned short);
     auto kern = conv_halo_x3_kernel<TN, WM, WN, MT, NT, TW, SLOPE>;
-    static bool attr = false;   // > 64 KiB of dynamic LDS needs the opt-in, once per instantiation
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr = true;
+    // > 64 KiB of dynamic LDS needs the opt-in: once per instantiation and device (one process drives one GPU in the
+    // data-parallel layout, but nothing here relies on it)
+    static std::atomic<unsigned long long> done{0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(done.load() & bit)) {
+        if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            cfl_set_err(CFL_E_HIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize = %zu) failed for the halo kernel", lds);
+            return;
+        }
+        done.fetch_or(bit);
     }
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, a);
 }
