@@ -327,8 +327,10 @@ struct ProjArgs {
     ColnormArgs cn;
 };
 
-template <int NT>
-__device__ __forceinline__ void proj_body(const ProjJob &jb, const ProjArgs &a, f32x4 *lds) {
+// FOLD (cfl_proj_mid_kernel): the partial tile is PUBLISHED -- written through (sc1) as whole 1 KiB C/D fragments into
+// the fold layout (fold_off), the storing wave drains -- instead of stored row-major; (rowtile, s) come from the caller.
+template <int NT, bool FOLD = false>
+__device__ __forceinline__ void proj_body(const ProjJob &jb, const ProjArgs &a, f32x4 *lds, int rowtile = -1, int sl = -1) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // provably uniform
     const int r16 = lane & 15, q4 = lane >> 4;  // MFMA: row / k index
@@ -336,8 +338,8 @@ __device__ __forceinline__ void proj_body(const ProjJob &jb, const ProjArgs &a, 
     // Workgroups are dealt to the 8 XCDs round-robin by linear id.  With the d slices fastest an XCD
     // only ever touches 1/8 of the weights (one slice of every column tile) and one d band of x --
     // the same band the weight-gradient launch assigns to it, so part of x is still in that XCD's L2.
-    const int row0 = (a.xcd ? blockIdx.y : blockIdx.x) * 32;
-    const int s = a.xcd ? blockIdx.x : blockIdx.y;
+    const int row0 = (FOLD ? rowtile : (a.xcd ? blockIdx.y : blockIdx.x)) * 32;
+    const int s = FOLD ? sl : (a.xcd ? blockIdx.x : blockIdx.y);
     const int G = a.D >> 4;           // 16-d groups
     const int NC = (G + 7) >> 3;      // 128-d chunks
     const int nw = a.S * 4, wg = s * 4 + wave;
@@ -445,6 +447,29 @@ __device__ __forceinline__ void proj_body(const ProjJob &jb, const ProjArgs &a, 
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) lds[(wave * 2 * NT + mt * NT + nt) * 64 + lane] = acc[mt][nt];
     __syncthreads();
+    if (FOLD) {
+        // a wave owns tiles t = wave and wave + 4 (< 2 NT <= 8): both published by ONE statement that ends with its
+        // own drain (store4_sc1_wait explains why stores and wait must not be separate asm statements)
+        f32x4 sum[2];
+        float *dst[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int t = wave + 4 * i;
+            const int tt = t < 2 * NT ? t : 0;
+            const int mt = tt / NT, nt = tt % NT;
+            sum[i] = lds[(0 * 2 * NT + tt) * 64 + lane];
+#pragma unroll
+            for (int w = 1; w < 4; ++w) sum[i] += lds[(w * 2 * NT + tt) * 64 + lane];
+            dst[i] = jb.ypart + (size_t)s * jb.sstride +
+                     ((size_t)((row0 >> 5) * 2 + mt) * (jb.npad >> 4) + nt) * 256 + lane * 4;
+        }
+        if (wave + 4 < 2 * NT)
+            asm volatile("global_store_dwordx4 %0, %1, off sc1\n\tglobal_store_dwordx4 %2, %3, off sc1\n\ts_waitcnt vmcnt(0)"
+                         :: "v"(dst[0]), "v"(sum[0]), "v"(dst[1]), "v"(sum[1]) : "memory");
+        else if (wave < 2 * NT)
+            asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" :: "v"(dst[0]), "v"(sum[0]) : "memory");
+        return;
+    }
     for (int t = wave; t < 2 * NT; t += 4) {
         const int mt = t / NT, nt = t % NT;
         f32x4 sum = lds[(0 * 2 * NT + t) * 64 + lane];
@@ -2355,19 +2380,22 @@ __global__ __launch_bounds__(64) void cfl_mid_kernel(MidArgs a) {
 // per slice, every per-column quantity is one VALU op, and the few cross-column sums
 // go through a 1 KiB wave-private LDS scratch.  Same arithmetic, same outputs.
 // ---------------------------------------------------------------------------
-template <int J>   // J = columns per lane: sides of up to 64 * J padded columns
-__global__ __launch_bounds__(256) void cfl_mid_row_kernel(MidArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+// FOLD: the body runs inside the projection launch (cfl_proj_mid_kernel): the partial sums then lie in the published
+// fragment-major tiles (fold_off) instead of the row-major slabs.  `lead`: the one wave of the launch that also
+// clears the hand-off flags of the weight-gradient launch and snapshots the threshold.
+// float offset of (slice s, row r, column c) inside a side's published partial tiles: [s][32-row tile][mt][nt] blocks of
+// 1 KiB in the C/D layout of the 16x16 MFMA (lane = col & 15 + 16 (row & 15) / 4, element row & 3)
+__device__ __forceinline__ size_t fold_off(int s, int r, int c, int tiles_r, int nts) {
+    const int rin = r & 31;
+    const size_t block = ((size_t)(s * tiles_r + (r >> 5)) * 2 + (rin >> 4)) * nts + (c >> 4);
+    return block * 256 + (((c & 15) + 16 * ((rin & 15) >> 2)) << 2) + (rin & 3);
+}
+
+template <int J, int FOLD>   // J = columns per lane: sides of up to 64 * J padded columns; FOLD 2: sc1 loads of the partial tiles
+__device__ __forceinline__ void mid_row_body(const MidArgs &a, int r, bool lead, float *W) {
     const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if ((int)blockIdx.x >= a.nrb) {
-        if (wave == 0) mid_reg_block(a, blockIdx.x - a.nrb);
-        return;
-    }
     constexpr int CW = 64 * J;
-    float *W = (float *)smem + wave * 6 * CW;  // Pl Vl Rl T S Q, CW floats each
     float *Pl = W, *Vl = W + CW, *Rl = W + 2 * CW, *T = W + 3 * CW, *S = W + 4 * CW, *Q = W + 5 * CW;
-    const int r = blockIdx.x * 4 + wave;
     const bool valid = r < a.R;
     const int L = a.L, K = a.K, RG = a.Rpad >> 4;
     const MidSide &ss = a.side[0], &sd = a.side[1];
@@ -2406,12 +2434,20 @@ __global__ __launch_bounds__(256) void cfl_mid_row_kernel(MidArgs a) {
         float ts[J][16], td[J][16];
 #pragma unroll
         for (int j = 0; j < J; ++j) {
-            const float *srcs = ss.ypart + (size_t)r * ss.npad + (c[j] < ss.npad ? c[j] : 0);
-            const float *srcd = sd.ypart + (size_t)r * sd.npad + (c[j] < sd.npad ? c[j] : 0);
+            const int ccs = c[j] < ss.npad ? c[j] : 0, ccd = c[j] < sd.npad ? c[j] : 0;
+            const float *srcs = FOLD ? ss.ypart + fold_off(0, r, ccs, a.Rpad >> 5, ss.npad >> 4)
+                                     : ss.ypart + (size_t)r * ss.npad + ccs;
+            const float *srcd = FOLD ? sd.ypart + fold_off(0, r, ccd, a.Rpad >> 5, sd.npad >> 4)
+                                     : sd.ypart + (size_t)r * sd.npad + ccd;
 #pragma unroll
             for (int s = 0; s < 16; ++s) {
-                ts[j][s] = s < a.S ? srcs[(size_t)s * ss.sstride] : 0.f;
-                td[j][s] = s < a.S ? srcd[(size_t)s * sd.sstride] : 0.f;
+                if (FOLD == 2) {
+                    ts[j][s] = s < a.S ? __hip_atomic_load(srcs + (size_t)s * ss.sstride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+                    td[j][s] = s < a.S ? __hip_atomic_load(srcd + (size_t)s * sd.sstride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+                } else {
+                    ts[j][s] = s < a.S ? srcs[(size_t)s * ss.sstride] : 0.f;
+                    td[j][s] = s < a.S ? srcd[(size_t)s * sd.sstride] : 0.f;
+                }
             }
         }
 #pragma unroll
@@ -2524,9 +2560,9 @@ __global__ __launch_bounds__(256) void cfl_mid_row_kernel(MidArgs a) {
         if (is_pos) dd += pw * a.lambda_m * invB;
     }
     if (!valid) dd = 0.f;
-    if (blockIdx.x == 0 && threadIdx.x == 0) a.thr_copy[0] = thr;
-    if (blockIdx.x == 0 && a.zero_i)
-        for (int i = threadIdx.x; i < a.nzero; i += blockDim.x) a.zero_i[i] = 0;
+    if (lead && lane == 0) a.thr_copy[0] = thr;
+    if (lead && a.zero_i)
+        for (int i = lane; i < a.nzero; i += 64) a.zero_i[i] = 0;
     if (lane < 16) {
         const bool pos = valid && is_pos, neg = valid && !is_pos;
         float qv = 0.f;
@@ -2574,6 +2610,86 @@ __global__ __launch_bounds__(256) void cfl_mid_row_kernel(MidArgs a) {
             sd.dyf[o_] = dy;
             if (sd.cwf) sd.cwf[o_] = dy * xvd[j];
         }
+    }
+}
+
+template <int J>
+__global__ __launch_bounds__(256) void cfl_mid_row_kernel(MidArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if ((int)blockIdx.x >= a.nrb) {
+        if (wave == 0) mid_reg_block(a, blockIdx.x - a.nrb);
+        return;
+    }
+    mid_row_body<J, 0>(a, blockIdx.x * 4 + wave, blockIdx.x == 0 && wave == 0, (float *)smem + wave * 6 * 64 * J);
+}
+
+// ---------------------------------------------------------------------------
+// proj + mid in ONE launch (round-3 experiment, VERDICT item "all-arrive fold"; opt-in: CFL_DEBUG_FOLD=1).
+// The S x jobs = `group` workgroups that produce the partial sums of one 32-row tile have CONSECUTIVE linear ids
+// (id = tile * group + job * S + s: still s = id mod 8, the XCD alignment of the plain launch).  Each
+//   * projects its (job, slice) partial tile and PUBLISHES it: sc1 (write-through) 16-byte stores of whole C/D
+//     fragments, every storing wave drains, workgroup barrier, one lane stores the launch's generation number into the
+//     member's flag word (sc1);
+//   * waits until all `group` flag words of its tile carry this launch's generation (one wave polls them with sc1 loads,
+//     one word per lane; bounded), then ONE agent-scope acquire + drain + barrier (two workgroups share a CU here, which
+//     is outside the configurations the sc1-load-only hand-off is measured for: MI355X_MICROARCH.md, Valid forms);
+//   * runs the distance / loss / dL/dY math of ITS 32 / group rows (wave per row: mid_row_body).
+// No mid launch, no kernel boundary between the partial sums and their consumers.  Flags are never cleared: the
+// generation is a per-process launch counter, so a stale or uninitialised word matches with probability 2^-32.
+// No deadlock under in-order dispatch whatever the residency: a waiting workgroup only waits for members of its own
+// group, which are the next workgroups the dispatcher hands out.
+// ---------------------------------------------------------------------------
+struct FoldArgs {
+    int group, S, ntile_wgs, rows_per_wg;   // workgroups per tile, d slices, tiles * group, 32 / group
+    unsigned gen;
+    int sc1_loads;
+    unsigned *flags;                        // [tiles * group]
+    int nt_of_job[CFL_MAX_JOBS];
+};
+
+extern "C" __global__ __launch_bounds__(256) void cfl_proj_mid_kernel(ProjArgs a, MidArgs ma, FoldArgs fa) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    f32x4 *lds = (f32x4 *)smem;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int id = blockIdx.x;
+    if (id >= fa.ntile_wgs) {   // the L2-regulariser partial sums (mid's extra blocks)
+        if (wave == 0) mid_reg_block(ma, id - fa.ntile_wgs);
+        return;
+    }
+    const int tile = id / fa.group, member = id - tile * fa.group;
+    const int job = member / fa.S, sl = member - job * fa.S;
+    const ProjJob &jb = a.job[job];
+    switch (jb.nt) {
+        case 1: proj_body<1, true>(jb, a, lds, tile, sl); break;
+        case 2: proj_body<2, true>(jb, a, lds, tile, sl); break;
+        case 3: proj_body<3, true>(jb, a, lds, tile, sl); break;
+        default: proj_body<4, true>(jb, a, lds, tile, sl); break;
+    }
+    __syncthreads();   // every storing wave has drained its published fragments
+    unsigned *fl = fa.flags + (size_t)tile * fa.group;
+    if (threadIdx.x == 0) __hip_atomic_store(fl + member, fa.gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (wave == 0) {
+        int spins = 0;
+        for (;;) {
+            const unsigned v = lane < fa.group ? __hip_atomic_load(fl + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : fa.gen;
+            if (__builtin_amdgcn_ballot_w64(v != fa.gen) == 0) break;
+            if (++spins > CFL_HANDOFF_SPIN_LIMIT) break;   // lost hand-off: the rows below read garbage -> NaN loss, no hang
+            __builtin_amdgcn_s_sleep(1);
+        }
+        if (!fa.sc1_loads) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    }
+    __syncthreads();
+    if (wave < fa.rows_per_wg) {
+        const int r = tile * 32 + member * fa.rows_per_wg + wave;
+        // sc1_loads (CFL_DEBUG_FOLD=2, timing experiment): no acquire, every load of a published tile is an sc1 load --
+        // the form the guide measured valid at ONE workgroup per CU only; two share a CU here
+        if (fa.sc1_loads) mid_row_body<1, 2>(ma, r, id == 0 && wave == 0, (float *)smem + wave * 6 * 64);
+        else mid_row_body<1, 1>(ma, r, id == 0 && wave == 0, (float *)smem + wave * 6 * 64);
     }
 }
 
@@ -2882,6 +2998,8 @@ struct Plan {
     bool xcd;  // XCD-aligned launch order of proj / grad (cfl_xcd_aligned)
     int proj_stream;  // 0: one wait per 128-d chunk (proj_body); 1: streaming form (proj_stream_body)
     bool proj_mix;    // streaming form at S == 1: column jobs interleaved in launch order
+    bool fold;        // proj + mid in one launch (cfl_proj_mid_kernel)
+    size_t fold_flags;
     bool proj_ring;   // loader / consumer ring form (cfl_proj_ring_kernel); S is then the ring's d split
     int ring_tiles, ring_units, ring_nwg;
     bool fused;       // gradient + Adam finished inside the weight-gradient launch (GradFuse)
@@ -3032,6 +3150,17 @@ static int make_plan(const CflShape *s, int64_t rows, int groups, bool train, Pl
         pl->regpart = take((size_t)pl->nregblocks);
         pl->nhandoff = njobs * (s->D / 64);
         pl->handoff = take(2 * (size_t)pl->nhandoff + 64);   // tickets, flags, + the reduction blocks' counter
+    }
+    // proj + mid in one launch: pcd, plain heads (weight-norm needs the column norms of the same launch), sides of at
+    // most 64 padded columns (wave-per-row math), S a multiple of 8 (XCD alignment), S * jobs workgroups per 32-row
+    // tile sharing its 32 rows evenly, and -- training -- no padding rows beyond R (mid zero-fills them)
+    {
+        const int group = S * njobs;
+        const int wide = hs->npad > hd->npad ? hs->npad : hd->npad;
+        pl->fold = debug_env("CFL_DEBUG_FOLD") > 0 && s->dist_type == CFL_DIST_PCD && !s->weight_norm && wide <= 64 &&
+                   s->K <= 64 && S % 8 == 0 && group <= 32 && 32 % group == 0 && !pl->proj_ring && !pl->proj_stream &&
+                   pl->R % 32 == 0 && (!train || pl->Rpad == pl->R) && !pl->mid_generic && !pl->mid_norow;
+        pl->fold_flags = take(pl->fold ? (size_t)(pl->R / 32) * group : 0);
     }
     pl->n2 = take(2 * 6 * 1024);  // squared column norms + gain snapshot of up to 6 heads
     pl->total_floats = off;
@@ -3198,8 +3327,8 @@ static int run_pairs(const CflShape *s, const CflNorm *norm, const CflLossCfg *l
     const float *gbase = ws + pl.n2 + 6 * 1024;
 
     // ---- proj ---------------------------------------------------------------
+    ProjArgs pa;
     {
-        ProjArgs pa;
         memset(&pa, 0, sizeof(pa));
         int nj = 0;
         for (int sd = 0; sd < 2; ++sd) {
@@ -3209,7 +3338,7 @@ static int run_pairs(const CflShape *s, const CflNorm *norm, const CflLossCfg *l
                 ProjJob &j = pa.job[nj++];
                 j.side = sd;
                 j.wf = theta + h->w + (size_t)c0 * G * 256;
-                j.ypart = ws + pl.ypart[sd] + (size_t)c0 * 16;
+                j.ypart = ws + pl.ypart[sd] + (size_t)c0 * (pl.fold ? 256 : 16);   // fold: 1 KiB fragment blocks
                 j.sstride = (long long)h->npad * rp;
                 j.nt = tiles - c0 < 4 ? tiles - c0 : 4;
                 j.npad = h->npad;
@@ -3223,7 +3352,9 @@ static int run_pairs(const CflShape *s, const CflNorm *norm, const CflLossCfg *l
         if (cn_slice && nj >= CFL_MAX_JOBS) return set_err(CFL_E_UNSUPPORTED, "too many column chunks");
         if (cn_slice) pa.job[nj].nt = 0;      // marks the colnorm slice
         const int nz = nj + (cn_slice ? 1 : 0);
-        if (pl.proj_ring) {
+        if (pl.fold) {
+            // launched below, together with the row math (cfl_proj_mid_kernel)
+        } else if (pl.proj_ring) {
             RingArgs ra;
             memset(&ra, 0, sizeof(ra));
             for (int i = 0; i < nj; ++i) ra.job[i] = pa.job[i];
@@ -3386,7 +3517,23 @@ static int run_pairs(const CflShape *s, const CflNorm *norm, const CflLossCfg *l
             if (nreg_blocks > pl.nregblocks) return set_err(CFL_E_WORKSPACE, "regpart too small");
         }
     }
-    {
+    if (pl.fold) {
+        static std::atomic<unsigned> fold_gen{1};
+        FoldArgs fo;
+        memset(&fo, 0, sizeof(fo));
+        fo.S = pl.S;
+        fo.group = pl.S * pa.njobs;
+        fo.rows_per_wg = 32 / fo.group;
+        fo.ntile_wgs = (pl.R / 32) * fo.group;
+        unsigned g = fold_gen.fetch_add(1);
+        if (g == 0) g = fold_gen.fetch_add(1);
+        fo.gen = g;
+        fo.flags = (unsigned *)(ws + pl.fold_flags);
+        fo.sc1_loads = debug_env("CFL_DEBUG_FOLD") == 2;
+        ProfScope ps(st, CFL_K_PROJ);
+        hipLaunchKernelGGL(cfl_proj_mid_kernel, dim3(fo.ntile_wgs + nreg_blocks), dim3(256), 4 * 8 * 64 * sizeof(f32x4), st,
+                           pa, ma, fo);
+    } else {
         ProfScope ps(st, CFL_K_MID);
         const dim3 mgrid(ma.nrb + nreg_blocks), mblk(64);
         const bool generic_only = pl.mid_generic != 0;

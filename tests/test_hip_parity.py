@@ -544,3 +544,44 @@ def test_projection_forms_agree(D, L, K, n, act_norm, monkeypatch):
     ref = O.pair_scores(cfg, _to64(p), np.float64(thr), f(xs[sub]), f(xt[sub]))
     for got in (classic, ring):
         assert np.abs(got[sub].cpu().numpy() - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.parametrize('B,D,K,L,reg', [(512, 4096, 3, 20, 0.0), (512, 4096, 4, 10, 1e-3), (256, 2048, 3, 20, 0.0)])
+def test_projection_with_folded_row_math_equals_three_launch_step(B, D, K, L, reg, monkeypatch):
+    """CFL_DEBUG_FOLD=1: distance / loss / dL/dY run inside the projection launch (cfl_proj_mid_kernel: partial tiles
+    published by their S x jobs producers, every producer waits for its tile's group and then does its share of the
+    rows).  Same sums in the same order: parameters, Adam slots, gradient and scalars must equal the three-launch
+    step BIT FOR BIT over 200 steps (~13 000 tile hand-offs per step), and so must the scores of a scoring call."""
+    rng = np.random.RandomState(3)
+    cfg = O.EncoderCfg(D=D, L=L, K=K)
+    p = _mk(cfg, rng)
+    sh = _shape(cfg)
+    norm, loss = H.make_norm(1.0 / 58.388599), H.make_loss(reg_const=reg)
+    pool = [[torch.from_numpy(_inputs(rng, B, D, 13.0)).cuda() for _ in range(4)] for _ in range(5)]
+
+    def run(fold):
+        monkeypatch.setenv('CFL_DEBUG_FOLD', str(fold))
+        H.reload_env()
+        theta = H.pack_theta(sh, p, None, 0.5, 'cuda')
+        m, v = torch.zeros_like(theta), torch.zeros_like(theta)
+        grad = torch.zeros_like(theta)
+        scal = torch.zeros(H.S_COUNT, device='cuda')
+        ws = torch.full((H.workspace_bytes(sh, B, 2) // 4,), float('nan'), dtype=torch.float32, device='cuda')
+        hist = []
+        for i in range(200):
+            H.pair_train_step(sh, norm, loss, pool[i % 5], theta, m, v, grad, scal, ws, 1e-3, 0.9, 0.999)
+            if i % 20 == 0:
+                hist.append(scal.clone())
+        ws1 = torch.full((H.workspace_bytes(sh, B, 1) // 4,), float('nan'), dtype=torch.float32, device='cuda')
+        sc = H.pair_scores(sh, norm, pool[0][0], pool[0][1], theta, ws1).clone()
+        torch.cuda.synchronize()
+        return theta, m, v, grad, torch.stack(hist), sc
+    try:
+        a, b, c = run(0), run(1), run(2)      # 2: the sc1-load variant of the hand-off (timing experiment)
+    finally:
+        monkeypatch.delenv('CFL_DEBUG_FOLD')
+        H.reload_env()
+    assert not torch.isnan(b[0]).any()
+    for other in (b, c):
+        for x, y, name in zip(a, other, ('theta', 'm', 'v', 'grad', 'scalars', 'scores')):
+            assert torch.equal(x, y), name
