@@ -1026,6 +1026,13 @@ struct GradFuse {
     int *red_done, red_expect;
     const float *wn_g[CFL_MAX_JOBS], *wn_n2[CFL_MAX_JOBS], *wn_cw[CFL_MAX_JOBS];   // at the job's first column
     int wn_n[CFL_MAX_JOBS];                                                        // valid columns from there
+    // siamese (both sides project through ONE head): the tile of column job j of side 1 also receives the P row ranges
+    // of job j - pair_jobs of side 0.  pair_jobs > 0: jobs [0, pair_jobs) only publish, job j >= pair_jobs finishes
+    // slot j - pair_jobs after 2P - 1 arrivals, summing side 0's slabs first (the finalize kernel's order).
+    // (scalars only: one more dynamically indexed array in this argument block and hipcc copies the whole block to
+    // scratch -- 2.4 KB per lane, the weight-gradient launch 2.7x slower)
+    int pair_jobs;
+    long long pair_delta;   // floats from side 0's slab array to side 1's (same column chunk, same row range)
     long long thr_off;
     // scalars
     const float *regpart;
@@ -1124,13 +1131,16 @@ __device__ __forceinline__ void grad_fused_tail(const GradArgs &a, int job, int 
                                                 f32x4 (&sum)[4], size_t tile_off, float *slab0, long long pstride,
                                                 int *lds_i) {
     const GradFuse &f = a.fuse;
-    const int slot = job * gridDim.x + blockIdx.x;
+    const bool paired = f.pair_jobs > 0;
+    const bool side0 = paired && job < f.pair_jobs;
+    const int slot = (paired && !side0 ? job - f.pair_jobs : job) * gridDim.x + blockIdx.x;
+    const int expect = paired ? 2 * P - 1 : P - 1;
     // Roles are static: the workgroup of the LAST row range finishes the tile, the others publish.  (A ticket --
     // "whoever arrives last finishes" -- costs an atomic round trip on every workgroup's critical path, ~1 us, and buys
     // nothing: the finisher waits for the publishers' data either way.  No deadlock: a finisher only waits for
     // workgroups with a smaller linear id, which were dispatched before it and run to completion on their own.)
-    if (p < P - 1) {
-        // not the last of the P row ranges: publish the partial tile into slab p and leave
+    if (p < P - 1 || side0) {
+        // not the last of the (2) P row ranges: publish the partial tile into slab p and leave
         if (wave < NT) {
             f32x4 v[4];
 #pragma unroll
@@ -1159,15 +1169,15 @@ __device__ __forceinline__ void grad_fused_tail(const GradArgs &a, int job, int 
     float wg = 1.f, wn2 = 1.f;
     if (f.wn) { wg = f.wn_g[job][wcol]; wn2 = f.wn_n2[job][wcol]; }
     bool lost = false;   // a partner never arrived (bounded spin): poison instead of hanging or using stale tiles
-    if (P > 1 || f.wn) {
+    if (expect > 0 || f.wn) {
         if (threadIdx.x == 0) {
             // Bounded: ~2^22 polls with s_sleep is > 100 ms, four orders of magnitude beyond any hand-off of a healthy
             // launch.  The waits are for workgroups dispatched BEFORE this one (smaller linear id), which never wait
             // themselves, so a time-out means the dispatch-order assumption or the visibility protocol failed.
             int ok = 1;
-            if (P > 1) {
+            if (expect > 0) {
                 int spins = 0;
-                while (__hip_atomic_load(f.flag + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < P - 1) {
+                while (__hip_atomic_load(f.flag + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < expect) {
                     __builtin_amdgcn_s_sleep(1);
                     if (++spins > CFL_HANDOFF_SPIN_LIMIT) { ok = 0; break; }
                 }
@@ -1190,6 +1200,14 @@ __device__ __forceinline__ void grad_fused_tail(const GradArgs &a, int job, int 
         f32x4 g[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) g[e] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (paired) {   // side 0's row ranges first
+            for (int q = 0; q < P; ++q) {
+                f32x4 part[4];
+                load4_sc1_wait(slab0 - f.pair_delta + (size_t)q * pstride + tile_off, part);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) g[e] += part[e];
+            }
+        }
         for (int q = 0; q < P; ++q) {
             if (q == p) {
 #pragma unroll
@@ -1208,6 +1226,7 @@ __device__ __forceinline__ void grad_fused_tail(const GradArgs &a, int job, int 
         if (f.wn) {
             // dV = (g/n) in_mul X^T dy - (g c / n^3) V   (cfl/layers.py:80-90 differentiated; same operations in the
             // same order as the RK_W branch of the finalize kernel)
+            // (siamese: the dual reduction range published c_j over both sides, side 0 first, at side 1's slot)
             const float cw = __hip_atomic_load(f.wn_cw[job] + wcol, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const bool colok = wcol < f.wn_n[job];
             const float n = sqrtf(wn2);
@@ -1380,7 +1399,31 @@ __device__ __forceinline__ void fuse_apply1(const GradFuse &f, long long off, fl
     }
 }
 
-__device__ void grad_red_block(const GradArgs &a, float *lds) {
+// column sums of tile `idx` of a fragment-major buffer (the whole workgroup): lane (kq, c16) adds its 4 rows; the
+// result is valid in lanes 0 .. 15 of wave 0
+__device__ __forceinline__ float tile_colsum(const float *buf, int idx, int RG, int lane, int wave, float *lds) {
+    const f32x4 *pa = (const f32x4 *)(buf + (size_t)idx * RG * 256) + lane;
+    float acc = 0.f;
+    // 8 independent loads in flight per round (a serial load chain here would be the critical path of the launch)
+    for (int rg0 = wave; rg0 < RG; rg0 += 32) {
+        f32x4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            v[u] = rg0 + 4 * u < RG ? pa[(size_t)(rg0 + 4 * u) * 64] : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += (v[u][0] + v[u][1]) + (v[u][2] + v[u][3]);
+    }
+    acc += __shfl_xor(acc, 16);
+    acc += __shfl_xor(acc, 32);
+    __syncthreads();
+    if (lane < 16) lds[wave * 16 + lane] = acc;
+    __syncthreads();
+    float cs = 0.f;
+    if (wave == 0 && lane < 16) cs = (lds[lane] + lds[16 + lane]) + (lds[32 + lane] + lds[48 + lane]);
+    return cs;
+}
+
+__device__ __forceinline__ void grad_red_block(const GradArgs &a, float *lds) {   // (forceinline: an out-of-line call takes the address of the argument block, which then lives in scratch)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nblk = gridDim.x * gridDim.y;
     const int RG = a.Rpad >> 4;
@@ -1390,27 +1433,17 @@ __device__ void grad_red_block(const GradArgs &a, float *lds) {
         const RedRange &rr = a.red[k];
         if (rr.kind == 0) {
             // column sums of tile `idx` of a fragment-major buffer: lane (kq, c16) adds its 4 rows
-            const f32x4 *pa = (const f32x4 *)(rr.A + (size_t)idx * RG * 256) + lane;
-            float acc = 0.f;
-            // 8 independent loads in flight per round (a serial load chain here would be the
-            // critical path of the whole launch)
-            for (int rg0 = wave; rg0 < RG; rg0 += 32) {
-                f32x4 v[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u)
-                    v[u] = rg0 + 4 * u < RG ? pa[(size_t)(rg0 + 4 * u) * 64] : (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int u = 0; u < 8; ++u) acc += (v[u][0] + v[u][1]) + (v[u][2] + v[u][3]);
-            }
-            acc += __shfl_xor(acc, 16);
-            acc += __shfl_xor(acc, 32);
-            __syncthreads();
-            if (lane < 16) lds[wave * 16 + lane] = acc;
-            __syncthreads();
+            // siamese, fused tail: this range also covers side 0's tile of the shared head -- each side summed exactly
+            // as its own range would, then added side 0 first (the finalize kernel's order)
+            const float *second = rr.B;   // (kind 0: B = the second buffer of a dual range, else null)
             float csum = 0.f;
+            if (second) csum = tile_colsum(second, idx, RG, lane, wave, lds);
+            {
+                const float c1 = tile_colsum(rr.A, idx, RG, lane, wave, lds);
+                csum = second ? csum + c1 : c1;
+            }
             const bool publish = a.fuse.on && a.fuse.wn && a.fuse.red_g[k] >= 0;   // c_j sums the W tiles wait for
             if (wave == 0 && lane < 16) {
-                csum = (lds[lane] + lds[16 + lane]) + (lds[32 + lane] + lds[48 + lane]);
                 if (publish)   // written through (agent scope): read by tile finishers of this launch, on any XCD
                     __hip_atomic_store(a.colsum + rr.out_off + idx * 16 + lane, csum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 else
@@ -1489,7 +1522,17 @@ __device__ void grad_red_block(const GradArgs &a, float *lds) {
     }
 }
 
-extern "C" __global__ __launch_bounds__(256) void cfl_grad_kernel(GradArgs a) {
+// The argument block is read IN PLACE from the kernel-argument segment (it is the launch's only explicit argument, at
+// offset 0): clang gives a by-value aggregate parameter a private copy that is only optimised away while the number of
+// accesses stays under an internal limit -- past it the whole block (2.2 KB per lane) lives in scratch and the
+// weight-gradient launch takes 2.7x as long (seen twice: eight inlined bodies in one kernel, and again with the
+// siamese pairing fields).
+#define CFL_KERNARG_IN_PLACE(T, name, param)                                                          \
+    (void)param;                                                                                       \
+    const T &name = *(const T *)__builtin_amdgcn_kernarg_segment_ptr()
+
+extern "C" __global__ __launch_bounds__(256) void cfl_grad_kernel(GradArgs a_) {
+    CFL_KERNARG_IN_PLACE(GradArgs, a, a_);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     f32x4 *lds = (f32x4 *)smem;
     if (blockIdx.z == 0) { grad_red_block(a, (float *)smem); return; }
@@ -1650,12 +1693,14 @@ __device__ __forceinline__ void grad_x3_kernel_body(const GradArgs &a, char *sme
     }
 }
 
-extern "C" __global__ __launch_bounds__(256) void cfl_grad_x3_kernel(GradArgs a) {   // Rpad / P <= 8192
+extern "C" __global__ __launch_bounds__(256) void cfl_grad_x3_kernel(GradArgs a_) {   // Rpad / P <= 8192
+    CFL_KERNARG_IN_PLACE(GradArgs, a, a_);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     grad_x3_kernel_body<true>(a, smem);
 }
 
-extern "C" __global__ __launch_bounds__(256) void cfl_grad_x3_longrange_kernel(GradArgs a) {
+extern "C" __global__ __launch_bounds__(256) void cfl_grad_x3_longrange_kernel(GradArgs a_) {
+    CFL_KERNARG_IN_PLACE(GradArgs, a, a_);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     grad_x3_kernel_body<false>(a, smem);
 }
@@ -3068,7 +3113,7 @@ static int make_plan(const CflShape *s, int64_t rows, int groups, bool train, Pl
     // fused tail: every gradient entry must be complete inside the P workgroups of one (d tile, column job) -- pcd
     // (each side feeds its own head), one encoder; weight-normalised heads get their column coupling c_j from the
     // launch's own reduction blocks.  CFL_DEBUG_NOFUSE=1: the escape hatch (separate finalize launch)
-    pl->fused = train && s->dist_type == CFL_DIST_PCD && !s->directed &&
+    pl->fused = train && (s->dist_type == CFL_DIST_PCD || s->dist_type == CFL_DIST_SIAMESE) && !s->directed &&
                 debug_env("CFL_DEBUG_NOFUSE") <= 0;
     pl->P = P;
     pl->Rpad = (int)round_up(pl->R, 256 * P);  // grad: 64-row chunks x 4 waves x P ranges
@@ -3437,7 +3482,7 @@ static int run_pairs(const CflShape *s, const CflNorm *norm, const CflLossCfg *l
         ma.thr_copy = ws + pl.thr_copy;
         ma.regpart = ws + pl.regpart;
         ma.theta = theta;
-        if (pl.fused && (pl.P > 1 || s->weight_norm)) {
+        if (pl.fused && (pl.P > 1 || s->weight_norm || s->dist_type == CFL_DIST_SIAMESE)) {   // (siamese: 2P contributors per tile)
             ma.zero_i = (int *)(ws + pl.handoff);
             ma.nzero = 2 * pl.nhandoff + 1;
         }
@@ -3589,10 +3634,18 @@ static int run_pairs(const CflShape *s, const CflNorm *norm, const CflLossCfg *l
             tot += count;
             return r;
         };
+        // siamese + fused tail: both sides feed ONE head, so side 1's ranges are dual (they also sum side 0's tile of
+        // the same columns) and side 0 gets none
+        const bool paired = pl.fused && s->dist_type == CFL_DIST_SIAMESE;
+        int red_dy[2] = {-1, -1}, red_cw[2] = {-1, -1};   // range index of a side's dY / dy * xv column sums
         red(0, ws + pl.rowqf, nullptr, 1, pl.cs_rowq);
-        for (int sd = 0; sd < 2; ++sd) {
+        for (int sd = paired ? 1 : 0; sd < 2; ++sd) {
+            red_dy[sd] = nr;
             red(0, ws + pl.dyf[sd], nullptr, side[sd].head->npad / 16, pl.cs_dy[sd]);
-            if (pl.has_cw) red(0, ws + pl.cwf[sd], nullptr, side[sd].head->npad / 16, pl.cs_cw[sd]);
+            if (pl.has_cw) {
+                red_cw[sd] = nr;
+                red(0, ws + pl.cwf[sd], nullptr, side[sd].head->npad / 16, pl.cs_cw[sd]);
+            }
         }
         if (pl.mono) {
             RedRange &r = red(1, ws + pl.mono_ya, ws + pl.mono_du, s->L, pl.cs_mono);
@@ -3624,23 +3677,32 @@ static int run_pairs(const CflShape *s, const CflNorm *norm, const CflLossCfg *l
             f.wn = s->weight_norm ? 1 : 0;
             f.red_done = f.flag + pl.nhandoff;
             f.red_expect = 0;
-            const int per_side = 1 + (pl.has_cw ? 1 : 0);
             jn = 0;
+            if (paired) {
+                f.pair_jobs = (side[0].head->npad / 16 + 3) / 4;
+                f.pair_delta = (long long)pl.wpart[1] - (long long)pl.wpart[0];
+            }
             for (int sd = 0; sd < 2; ++sd) {
                 const CflHead *h = side[sd].head;
-                const int kd = 1 + sd * per_side;
-                f.red_b[kd] = h->b;
-                f.red_n[kd] = h->n;
-                f.red_npad[kd] = h->npad;
-                if (f.wn) {
-                    const float *n2p = n2base + n2_off[side[sd].enc][side[sd].which];
-                    const float *gp = gbase + n2_off[side[sd].enc][side[sd].which];
-                    f.red_g[kd + 1] = h->g;
-                    f.red_n[kd + 1] = h->n;
-                    f.red_npad[kd + 1] = h->npad;
-                    f.red_n2[kd + 1] = n2p;
+                const int kd = red_dy[sd], kc = red_cw[sd];
+                if (kd >= 0) {
+                    f.red_b[kd] = h->b;
+                    f.red_n[kd] = h->n;
+                    f.red_npad[kd] = h->npad;
+                    if (paired) ga.red[kd].B = ws + pl.dyf[0];
+                }
+                const float *n2p = f.wn ? n2base + n2_off[side[sd].enc][side[sd].which] : nullptr;
+                const float *gp = f.wn ? gbase + n2_off[side[sd].enc][side[sd].which] : nullptr;
+                if (f.wn && kc >= 0) {
+                    f.red_g[kc] = h->g;
+                    f.red_n[kc] = h->n;
+                    f.red_npad[kc] = h->npad;
+                    f.red_n2[kc] = n2p;
                     f.red_expect += h->npad / 16;
-                    for (int c0 = 0; c0 < h->npad / 16; c0 += 4, ++jn) {
+                    if (paired) ga.red[kc].B = ws + pl.cwf[0];
+                }
+                for (int c0 = 0; c0 < h->npad / 16; c0 += 4, ++jn) {
+                    if (f.wn) {
                         f.wn_g[jn] = gp + c0 * 16;
                         f.wn_n2[jn] = n2p + c0 * 16;
                         f.wn_cw[jn] = ws + pl.colsum + pl.cs_cw[sd] + c0 * 16;

@@ -71,3 +71,32 @@ def test_bad_shapes_return_error_codes(H):
     with pytest.raises(H.CflHipError, match='no CPU fallback'):
         import torch
         H.adam_tf(*(torch.zeros(64) for _ in range(4)), 1e-3, 0.9, 0.999)
+
+
+def test_hot_kernels_keep_their_argument_block_out_of_scratch():
+    """hipcc gives a by-value aggregate kernel parameter a private copy and removes it only while the number of
+    accesses stays under an internal limit; past it the whole block lives in scratch (2.2 KB per lane) and the launch
+    is several times slower -- silently (it happened twice to the weight-gradient kernels).  The step's kernels must
+    compile without scratch."""
+    import os
+    import re
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = os.path.join(root, 'compatibility-family-learning_amd', 'csrc', 'cfl_hip.hip')
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    if not os.path.exists(hipcc):
+        import pytest
+        pytest.skip('no hipcc')
+    out = subprocess.run([hipcc, '-O3', '--offload-arch=gfx950', '-std=c++17', '-c', src, '-o', os.devnull,
+                          '--cuda-device-only', '-Rpass-analysis=kernel-resource-usage'], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr[-2000:]
+    seen = {}
+    for name, scratch in re.findall(r'Function Name: (\S+).*?ScratchSize \[bytes/lane\]: (\d+)', out.stderr, re.S):
+        seen[name] = int(scratch)
+    hot = ['cfl_proj_kernel', 'cfl_proj_stream_kernel', 'cfl_proj_ring_kernel', 'cfl_grad_kernel', 'cfl_grad_x3_kernel',
+           'cfl_grad_x3_longrange_kernel', 'cfl_finalize_kernel', 'cfl_adam_kernel', 'cfl_proj_mid_kernel']
+    for k in hot:
+        assert k in seen, (k, sorted(seen))
+        assert seen[k] == 0, (k, seen[k])
+    mids = [k for k in seen if 'cfl_mid_row_kernel' in k]
+    assert mids and all(seen[k] == 0 for k in mids), {k: seen[k] for k in mids}

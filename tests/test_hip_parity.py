@@ -585,3 +585,52 @@ def test_projection_with_folded_row_math_equals_three_launch_step(B, D, K, L, re
     for other in (b, c):
         for x, y, name in zip(a, other, ('theta', 'm', 'v', 'grad', 'scalars', 'scores')):
             assert torch.equal(x, y), name
+
+
+@pytest.mark.parametrize('B,D,L,wn,lkw,P', [
+    (512, 1024, 256, True, dict(use_threshold=False, caffe_margin=100.0, pos_weight=0.0625), 0),     # BASELINE config 3
+    (128, 1024, 40, True, dict(reg_const=1e-3), 0), (256, 576, 20, False, dict(lambda_m=0.5), 0),
+    (512, 1024, 64, True, dict(use_threshold=False, caffe_margin=100.0), 4), (16, 256, 7, False, dict(reg_const=1e-3), 0)])
+def test_fused_gradient_tail_siamese_equals_finalize_kernel(B, D, L, wn, lkw, P, monkeypatch):
+    """Siamese models: both sides project through ONE head, so a weight tile receives 2 P row ranges (side 0's
+    workgroups only publish, the last row range of side 1 finishes: 2P - 1 arrivals, side 0's slabs summed first) and
+    the bias / gain / c_j column sums come from dual reduction ranges that cover both sides.  Bit-identical to the
+    four-launch form with the finalize kernel over 300 steps, weight-normalised (config 3: L=256, hinge margin 100,
+    separate threshold Adam) and plain."""
+    from cfl.engine import PairEngine
+    rng = np.random.RandomState(6)
+    cfg = O.EncoderCfg(D=D, L=L, K=1, dist_type='siamese', style='cfl' if wn else 'dist')
+    params = O.init_encoder_params(cfg, rng, np.float32)
+    if wn:
+        params = {k: (v * (1.0 + 0.3 * rng.rand(*v.shape)).astype(np.float32) if k.endswith('/g') else v)
+                  for k, v in params.items()}
+    pool = [[torch.from_numpy(np.abs(rng.randn(B, D)).astype(np.float32) * 3).cuda() for _ in range(4)]
+            for _ in range(3)]
+    res = {}
+    if P:
+        monkeypatch.setenv('CFL_DEBUG_P', str(P))
+    for mode in ('fused', 'finalize'):
+        monkeypatch.setenv('CFL_DEBUG_NOFUSE', '0' if mode == 'fused' else '1')
+        H.reload_env()
+        eng = PairEngine(D, L, 1, 'siamese', weight_norm=cfg.weight_norm, has_bias=cfg.has_bias, norm=H.make_norm(1 / 8.0),
+                         loss=H.make_loss(**lkw), params=params, thr=30.0 if lkw.get('caffe_margin') else 0.5, batch_size=B)
+        H.profile_enable(True)
+        eng.step(pool[0])
+        torch.cuda.synchronize()
+        H.profile_enable(False)
+        kinds = set(H.profile_read())
+        assert ('finalize' in kinds) == (mode == 'finalize'), kinds
+        snaps = []
+        for it in range(300):
+            eng.step(pool[it % 3])
+            if it in (0, 1, 7, 299):
+                snaps.append([t.clone() for t in (eng.theta, eng.m, eng.v, eng.grad, eng.scalars)])
+        eng.fwd_bwd(pool[1])
+        snaps.append([eng.grad.clone(), eng.scalars.clone(), eng.theta.clone()])
+        res[mode] = snaps
+    monkeypatch.undo()
+    H.reload_env()
+    for a, b in zip(res['fused'], res['finalize']):
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
+    assert np.isfinite(res['fused'][-1][1].cpu().numpy()).all()
