@@ -68,6 +68,7 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-profile', action='store_true')
     ap.add_argument('--no-cli-loop', action='store_true')
+    ap.add_argument('--no-other-configs', action='store_true')
     ap.add_argument('--cli-items', type=int, default=40000, help='items of the synthetic features.b of the cli_loop leg')
     ap.add_argument('--cli-pairs', type=int, default=200000)
     return ap.parse_args()
@@ -200,6 +201,14 @@ def eval_auc(args, eng, device, teacher):
             'max_abs_score_diff': float(max(np.abs(sp - op).max(), np.abs(sn - on).max()))}
 
 
+def _eval_traffic():
+    tp = os.path.join(ROOT, 'profiles', 'traffic_eval.json')
+    try:
+        return json.load(open(tp))
+    except Exception:
+        return None
+
+
 def roofline_eval(args, eng, pool, device):
     """The scoring path (dist_eval / dist_predict: cfl_pair_scores, proj + mid): 8*D algorithmic bytes per scored
     pair (two fp32 vectors read once).  Whole-call throughput, HIP events on the launch stream around a train of
@@ -250,9 +259,102 @@ def roofline_eval(args, eng, pool, device):
         torch.cuda.empty_cache()
     return {'kernels': 'cfl_proj_kernel + cfl_mid_row_kernel (one cfl_pair_scores call)', 'bound': 'hbm', 'dist_eval_call': big,
             'achieved': round(alg / per_call_s / 1e9, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-            'frac': round(alg / per_call_s / 1e9 / HBM_PEAK_GBS, 4), 'traffic': None,
+            'frac': round(alg / per_call_s / 1e9 / HBM_PEAK_GBS, 4), 'traffic': _eval_traffic(),
+            'traffic_source': 'profiles/traffic_eval.json: builder box, rocprofv3 --pmc passes of tools/score_loop.py (one dist_eval-sized call: proj + mid); NOT measured in this run',
             'pairs_per_call': B, 'calls': n_calls, 'avg_call_us': round(per_call_s * 1e6, 3),
             'pairs_per_s': round(B / per_call_s, 1), 'algorithmic_bytes_per_call': alg}
+
+
+def other_configs(device):
+    """The other BASELINE.json configurations on the same kernels, measured by THIS run (so that the driver, not a
+    builder-run probe, produces them): event-free step time over a pool larger than the Infinity Cache, median of 5
+    repeats of 100 steps.  Weights are Xavier-uniform (RandomState(0)); inputs |N(0,1)| * 13.
+      config3   experiments/dyadic/run.sh:40-50  1024-d, siamese L=256, weight-norm, hinge margin 100, pos_weight .0625, B=512
+      config4   Polyvore: 2048-d, pcd K=5 L=20, weight-norm, pos_weight .25, B=1024
+      reference experiments/monomer/run.sh:3-11 shape: 4096-d, pcd K=4 L=10, B=100 (the reference's own batch size)
+      config5   MrCGAN post-epoch step, 64x64x3, latent 64, K=2, z=20, srgan, lambda_gp 0.5, B=100 (ms per step)"""
+    import numpy as np
+    import torch
+    from cfl import hipabi as H
+    from cfl.engine import PairEngine
+    from cfl.models.base import xavier_uniform
+    out = {}
+
+    def params_of(D, L, K, dist, wn, rng):
+        p = {'outputs/W': xavier_uniform(rng, D, L)}
+        if dist != 'siamese':
+            p['proto/W'] = xavier_uniform(rng, D, L * K)
+        if wn:
+            for k in list(p):
+                p[k.replace('/W', '/g')] = np.ones(p[k].shape[1], np.float32)
+        if (dist == 'pcd') or not wn:
+            for k in [k for k in p if k.endswith('/W')]:
+                p[k.replace('/W', '/b')] = np.zeros(p[k].shape[1], np.float32)
+        return p
+
+    g = torch.Generator(device=device)
+    g.manual_seed(5)
+    for name, D, L, K, dist, wn, B, lkw, nv in (
+            ('config3_siamese_hinge', 1024, 256, 1, 'siamese', True, 512,
+             dict(use_threshold=False, caffe_margin=100.0, pos_weight=0.0625), 31.9098),
+            ('config4_polyvore_pcd_k5', 2048, 20, 5, 'pcd', True, 1024, dict(pos_weight=0.25), 1.0),
+            ('reference_shape_k4_l10_b100', 4096, 10, 4, 'pcd', False, 100, dict(), NORMALIZE_VALUE)):
+        try:
+            eng = PairEngine(D, L, K, dist, weight_norm=wn, has_bias=(dist == 'pcd') or not wn,
+                             norm=H.make_norm(1.0 / nv), loss=H.make_loss(**lkw), lr=1e-3, device=device,
+                             params=params_of(D, L, K, dist, wn, np.random.RandomState(0)),
+                             thr=30.0 if dist == 'siamese' else 1e-6, batch_size=B)
+            nb = max(2, (320 << 20) // (16 * B * D))
+            pool = [tuple(torch.randn(B, D, generator=g, device=device).abs_() * (nv / 4.5) for _ in range(4))
+                    for _ in range(nb)]
+            for i in range(max(30, nb)):
+                eng.step(pool[i % nb])
+            torch.cuda.synchronize()
+            ts = []
+            for r in range(5):
+                t0 = time.perf_counter()
+                for i in range(100):
+                    eng.step(pool[(r * 100 + i) % nb])
+                torch.cuda.synchronize()
+                ts.append((time.perf_counter() - t0) / 100)
+            t = float(np.median(ts))
+            H.profile_enable(True)
+            for i in range(50):
+                eng.step(pool[i % nb])
+            torch.cuda.synchronize()
+            H.profile_enable(False)
+            prof = H.profile_read()
+            out[name] = {'us_per_step': round(t * 1e6, 2), 'rows_per_s': round(B / t, 1), 'batch_rows': B,
+                         'launches_per_step': len(prof), 'hbm_frac_step': round(16.0 * D * B / t / 1e9 / HBM_PEAK_GBS, 4),
+                         'final_loss': round(eng.read_scalars()['total'], 6)}
+            del pool, eng
+            torch.cuda.empty_cache()
+        except Exception as e:          # a side measurement must not take the headline line down
+            out[name] = {'error': repr(e)}
+    try:
+        from cfl.models.mrcgan import GanPhase
+        B, L, zd, shape = 100, 64, 20, (64, 64, 3)
+        ph = GanPhase('srgan', shape, 'tanh', zd, L, B, device, np.random.RandomState(0), lambda_gp=0.5, lambda_dra=0.5,
+                      m_enc=0.05, m_prj=0.2)
+        N = int(np.prod(shape))
+        batch = [torch.tanh(torch.randn(B, N, device=device, generator=g))] + \
+                [0.3 * torch.randn(B, L, device=device, generator=g) for _ in range(4)] + \
+                [torch.randn(B, zd, device=device, generator=g), torch.rand(B, 1, device=device, generator=g)]
+        for _ in range(3):
+            ph.step(*batch)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n = 10
+        for _ in range(n):
+            ph.step(*batch)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / n
+        out['config5_mrcgan_64x64_b100'] = {'ms_per_step': round(dt * 1e3, 3), 'images_per_s': round(B / dt, 1)}
+        del ph
+        torch.cuda.empty_cache()
+    except Exception as e:
+        out['config5_mrcgan_64x64_b100'] = {'error': repr(e)}
+    return out
 
 
 def cli_loop(args, device):
@@ -468,22 +570,34 @@ def main():
         corr_s = max(raw_s - excess_s, 1e-9)
         alg_bytes = 16.0 * D * B                       # 4 fp32 vectors per row, read once
         alg_flops = 4.0 * D * L * (K + 1) * B          # one of fwd / dW: half of 8*D*L*(K+1)
-        traffic = None
+        traffic, traffic_all = None, {}
         tp = os.path.join(ROOT, 'profiles', 'traffic.json')
         if os.path.exists(tp):
             try:
-                traffic = json.load(open(tp)).get(dom)
+                traffic_all = json.load(open(tp))
+                traffic = traffic_all.get(dom)
             except Exception:
                 traffic = None
+        hbm_frac_dom = alg_bytes / raw_s / 1e9 / HBM_PEAK_GBS
+        mfma_frac_dom = alg_flops / raw_s / 1e12 / FP32_MFMA_PEAK_TF
+        step_traffic = sum(v for k, v in traffic_all.items() if k in ('proj', 'mid', 'grad', 'finalize') and
+                           isinstance(v, (int, float))) or None
+        P_params = D * L * (K + 1) + L * (K + 1) + 1
         out['roofline'] = {
             'kernel': ('cfl_grad_x3_kernel' if dom == 'grad' and os.environ.get('CFL_EXACT_FP32', '0') in ('', '0')
                        else 'cfl_%s_kernel' % dom),
+            # `achieved` / `frac` are on the HBM roof (BASELINE's metric: input bytes); `binding_roof` names the roof
+            # the dominant kernel sits closer to -- at L=20 that is the fp32-equivalent matrix-core roof (`mfma_f32`)
             'bound': 'hbm',
+            'binding_roof': 'mfma_f32' if mfma_frac_dom > hbm_frac_dom else 'hbm',
             'achieved': round(alg_bytes / raw_s / 1e9, 1),
             'peak': HBM_PEAK_GBS,
             'unit': 'GB/s',
-            'frac': round(alg_bytes / raw_s / 1e9 / HBM_PEAK_GBS, 4),
+            'frac': round(hbm_frac_dom, 4),
             'traffic': traffic,
+            'traffic_source': 'profiles/traffic.json: builder box, separate `rocprofv3 --pmc FETCH_SIZE` / `WRITE_SIZE` passes '
+                              'of this command (2 * FETCH_SIZE + WRITE_SIZE, gfx950 half-count correction); NOT measured in '
+                              'this run',
             'avg_launch_us': round(raw_s * 1e6, 3),
             'algorithmic_bytes_per_launch': alg_bytes,
             'event_corrected': {'avg_launch_us': round(corr_s * 1e6, 3),
@@ -494,7 +608,12 @@ def main():
                          'peak_tflops': FP32_MFMA_PEAK_TF,
                          'frac': round(alg_flops / raw_s / 1e12 / FP32_MFMA_PEAK_TF, 4)},
             'step': {'hbm_frac': round(alg_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
-                     'launches_per_step': len(step_kernels)},
+                     'launches_per_step': len(step_kernels),
+                     # x is read twice by design (projection, weight gradient): HBM traffic of a step vs its
+                     # algorithmic bytes 16*D*B + 32*P (inputs once + parameters / Adam slots / gradient)
+                     'traffic_bytes': step_traffic,
+                     'algorithmic_bytes': 16.0 * D * B + 32.0 * P_params,
+                     'traffic_source': 'profiles/traffic.json (builder box)'},
             'kernels': kern,
             'timing': 'hipEvent pairs around every launch on the launch stream, separate pass of %d steps (`kernels` '
                       'lists the raw intervals; `achieved` / `frac` use the raw interval of the dominant kernel).  '
@@ -510,6 +629,10 @@ def main():
             out['cpu_baseline'] = cpu_baseline(args, args.cpu_seconds)
         else:
             out['cpu_baseline'] = None
+        if not args.no_other_configs and not args.no_kernel_profile:
+            pool.clear()
+            torch.cuda.empty_cache()
+            out['other_configs'] = other_configs(device)
         if not args.no_cli_loop:
             pool.clear()
             torch.cuda.empty_cache()
