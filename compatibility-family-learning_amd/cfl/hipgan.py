@@ -2,6 +2,7 @@
 element-wise / permutation / loss kernels).  Same rules as cfl/hipabi.py: tensors must be
 contiguous fp32 on the GPU, no CPU fallback."""
 import ctypes as C
+import os
 
 import torch
 
@@ -13,7 +14,7 @@ EXPORTS = ('cfl_conv_transpose_workspace_bytes', 'cfl_conv2d_transpose_wn_fwd', 
            'cfl_subpixel2x_bwd', 'cfl_concat_cols', 'cfl_gather_prototype', 'cfl_bce_logits',
            'cfl_rowdist_loss', 'cfl_perturb_workspace_bytes', 'cfl_perturb', 'cfl_grad_penalty', 'cfl_copy_cols',
            'cfl_tile_concat_channels', 'cfl_tile_concat_channels_bwd', 'cfl_auc_workspace_bytes', 'cfl_auc', 'cfl_image_transform',
-           'cfl_ew_affine_clip_channels')
+           'cfl_ew_affine_clip_channels', 'cfl_conv_cache_bytes', 'cfl_conv2d_wn_fwd_cached', 'cfl_conv2d_wn_bwd_cached')
 
 EW = {None: 0, 'linear': 0, 'lrelu': 1, 'relu': 2, 'tanh': 3, 'sigmoid': 4}
 
@@ -54,8 +55,14 @@ def lib():
     L.cfl_auc_workspace_bytes.argtypes = [i64, i64]
     L.cfl_auc_workspace_bytes.restype = sz
     L.cfl_auc.argtypes = [vp, i64, vp, i64, vp, vp, sz, vp]
+    L.cfl_conv_cache_bytes.argtypes = [C.POINTER(CflConv)]
+    L.cfl_conv_cache_bytes.restype = sz
+    L.cfl_conv2d_wn_fwd_cached.argtypes = [C.POINTER(CflConv)] + [vp] * 6 + [sz, vp, sz, C.POINTER(C.c_int32), vp]
+    L.cfl_conv2d_wn_bwd_cached.argtypes = ([C.POINTER(CflConv)] + [vp] * 5 + [f32] + [vp] * 5 +
+                                           [sz, vp, sz, C.POINTER(C.c_int32), vp])
     for n in EXPORTS:
-        if n not in ('cfl_conv_transpose_workspace_bytes', 'cfl_perturb_workspace_bytes', 'cfl_auc_workspace_bytes'):
+        if n not in ('cfl_conv_transpose_workspace_bytes', 'cfl_perturb_workspace_bytes', 'cfl_auc_workspace_bytes',
+                     'cfl_conv_cache_bytes'):
             getattr(L, n).restype = C.c_int
     _ready = True
     return L
@@ -74,15 +81,49 @@ def conv_ws_bytes(conv, transposed=False):
     return n
 
 
-def conv_fwd(conv, x, V, g, b, y, ws, transposed=False):
+class ConvCache(object):
+    """Per-layer cache of what depends on the weights only (weight-norm scale, prepared filter planes of the direct 3x3
+    kernel): a device buffer + the host validity bits of include/cfl_hip.h (CFL_CONV_CACHE_*).  `invalidate()` whenever
+    V or g change.  CFL_CONV_CACHE=0 in the environment disables caching (every call recomputes, as the plain ABI)."""
+    enabled = os.environ.get('CFL_CONV_CACHE', '1') not in ('0', '')
+
+    def __init__(self):
+        self.buf = None
+        self.flags = C.c_int32(0)
+
+    def invalidate(self):
+        self.flags.value = 0
+
+    def ensure(self, conv, device):
+        L = lib()
+        n = L.cfl_conv_cache_bytes(C.byref(conv))
+        if self.buf is None or self.buf.numel() * 4 < n:
+            self.buf = torch.empty((n + 3) // 4, dtype=torch.float32, device=device)
+            self.flags.value = 0
+        return self
+
+
+def conv_fwd(conv, x, V, g, b, y, ws, transposed=False, cache=None):
     L = lib()
+    if cache is not None and not transposed and ConvCache.enabled:
+        cache.ensure(conv, x.device)
+        _check(L.cfl_conv2d_wn_fwd_cached(C.byref(conv), _dev(x), _dev(V), _opt(g), _opt(b), _dev(y), ws.data_ptr(),
+                                          ws.numel() * 4, cache.buf.data_ptr(), cache.buf.numel() * 4,
+                                          C.byref(cache.flags), _stream()))
+        return y
     fn = L.cfl_conv2d_transpose_wn_fwd if transposed else L.cfl_conv2d_wn_fwd
     _check(fn(C.byref(conv), _dev(x), _dev(V), _opt(g), _opt(b), _dev(y), ws.data_ptr(), ws.numel() * 4, _stream()))
     return y
 
 
-def conv_bwd(conv, x, V, g, y, dy, ws, dx=None, dV=None, dg=None, db=None, reg_const=0.0, transposed=False):
+def conv_bwd(conv, x, V, g, y, dy, ws, dx=None, dV=None, dg=None, db=None, reg_const=0.0, transposed=False, cache=None):
     L = lib()
+    if cache is not None and not transposed and ConvCache.enabled:
+        cache.ensure(conv, dy.device)
+        _check(L.cfl_conv2d_wn_bwd_cached(C.byref(conv), _opt(x), _dev(V), _opt(g), _opt(y), _dev(dy), float(reg_const),
+                                          _opt(dx), _opt(dV), _opt(dg), _opt(db), ws.data_ptr(), ws.numel() * 4,
+                                          cache.buf.data_ptr(), cache.buf.numel() * 4, C.byref(cache.flags), _stream()))
+        return dx
     fn = L.cfl_conv2d_transpose_wn_bwd if transposed else L.cfl_conv2d_wn_bwd
     _check(fn(C.byref(conv), _opt(x), _dev(V), _opt(g), _opt(y), _dev(dy), float(reg_const), _opt(dx), _opt(dV),
               _opt(dg), _opt(db), ws.data_ptr(), ws.numel() * 4, _stream()))

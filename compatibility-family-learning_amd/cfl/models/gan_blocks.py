@@ -47,6 +47,7 @@ class ParamPool(object):
         self._init = {}
         self.total = 0
         self.theta = None
+        self.version = 0     # bumped whenever theta changes (Adam, load): per-layer weight caches key on it
 
     def add(self, name, value):
         value = np.asarray(value, np.float32)
@@ -75,7 +76,13 @@ class ParamPool(object):
     def named(self, base=None):
         return {n: self.view(n, base).detach().cpu().numpy().copy() for n in self.order}
 
+    def touch(self):
+        """theta was modified: the layers' cached weight-norm scales / prepared filters are stale"""
+        self.version += 1
+
     def load(self, values, base=None):
+        if base is None:
+            self.touch()
         for n in self.order:
             if n in values:
                 self.view(n, base).copy_(torch.as_tensor(np.asarray(values[n], np.float32)).to(self.device))
@@ -98,6 +105,16 @@ class WNLayer(object):
         pool.add(scope + '/g', np.ones(co, np.float32))
         pool.add(scope + '/biases', np.zeros(co, np.float32))
         self._desc = {}
+        # what depends on the weights only (weight-norm scale, prepared filter planes) is kept across the 3-6 calls the
+        # layer sees per step and rebuilt when the pool's version moves (include/cfl_hip.h: cfl_conv2d_wn_*_cached)
+        self._cache = G.ConvCache() if kind != 'convt' else None
+        self._cache_version = -1
+
+    def cache(self):
+        if self._cache is not None and self._cache_version != self.pool.version:
+            self._cache.invalidate()
+            self._cache_version = self.pool.version
+        return self._cache
 
     def p(self, what, base=None):
         return self.pool.view(self.scope + '/' + what, base)
@@ -123,7 +140,7 @@ class WNLayer(object):
         t = self.kind == 'convt'
         oh, ow = self.out_hw(Hh, W)
         y = torch.empty(B, oh, ow, self.co, dtype=torch.float32, device=x.device)
-        G.conv_fwd(d, x, self.p('V'), self.p('g'), self.p('biases') if bias else None, y, ws.get(d, t), t)
+        G.conv_fwd(d, x, self.p('V'), self.p('g'), self.p('biases') if bias else None, y, ws.get(d, t), t, cache=self.cache())
         return y
 
     def bwd(self, x, y, dy, ws, need_dx=True, need_dw=True, grad=None, need_db=True):
@@ -134,7 +151,7 @@ class WNLayer(object):
         dx = torch.empty(B, Hh, W, self.ci, dtype=torch.float32, device=dy.device) if need_dx else None
         G.conv_bwd(d, x, self.p('V'), self.p('g'), y, dy, ws.get(d, t), dx=dx,
                    dV=self.p('V', grad) if need_dw else None, dg=self.p('g', grad) if need_dw else None,
-                   db=self.p('biases', grad) if (need_dw and need_db) else None, transposed=t)
+                   db=self.p('biases', grad) if (need_dw and need_db) else None, transposed=t, cache=self.cache())
         return dx
 
 
@@ -169,6 +186,7 @@ class _Net(object):
     def adam(self):
         p = self.pool
         H.adam_tf(p.theta, p.m, p.v, p.grad, self.lr_t(), self.beta1, self.beta2, self.eps)
+        p.touch()
         self.beta1_power = np.float32(self.beta1_power * np.float32(self.beta1))
         self.beta2_power = np.float32(self.beta2_power * np.float32(self.beta2))
 

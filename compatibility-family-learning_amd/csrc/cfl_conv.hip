@@ -679,26 +679,54 @@ extern "C" int cfl_conv_uses_direct_kernel(const CflConv *c, int product) {
     return (product == 0 ? halo_fwd_plan(g) : halo_dx_plan(g)).ok ? 1 : 0;
 }
 
-extern "C" int cfl_conv2d_wn_fwd(const CflConv *c, const float *x, const float *V, const float *gain,
-                                 const float *bias, float *y, void *workspace, size_t workspace_bytes,
-                                 cfl_stream_t stream) {
+// ---- per-layer cache of what depends on the weights only ----------------------------------------------------
+// [scale Co | n2 Co | column-chunk scratch | pad] [halo planes, forward] [halo planes, input gradient].  The caller owns
+// the buffer and the validity bits (CFL_CONV_CACHE_*): it clears them whenever V or the gains change.
+static size_t conv_cache_planes_off(const ConvGeom &g) { return conv_ws_header_floats(g) * sizeof(float); }
+extern "C" size_t cfl_conv_cache_bytes(const CflConv *c) {
+    ConvGeom g;
+    if (make_geom(c, &g)) return 0;
+    const HaloPlan hf = halo_fwd_plan(g), hd = halo_dx_plan(g);
+    return conv_cache_planes_off(g) + (hf.ok ? (hf.wp_bytes + 15) / 16 * 16 : 0) + (hd.ok ? (hd.wp_bytes + 15) / 16 * 16 : 0);
+}
+// scale / n2 / scratch pointers of a call: in the cache (computed once per weight version) or in the workspace header
+static void conv_scale_of(const ConvGeom &g, const float *V, const float *gain, void *workspace, void *cache,
+                          int32_t *flags, float **scale, float **n2, hipStream_t st) {
+    const int rows = g.KH * g.KW * g.Ci;
+    *scale = cache ? (float *)cache : (float *)workspace;
+    *n2 = *scale + g.Co;
+    if (!cache || !(*flags & CFL_CONV_CACHE_SCALE)) {
+        conv_scale(V, gain, rows, g.Co, *scale, *n2, *n2 + g.Co, st);
+        if (cache) *flags |= CFL_CONV_CACHE_SCALE;
+    }
+}
+
+extern "C" int cfl_conv2d_wn_fwd_cached(const CflConv *c, const float *x, const float *V, const float *gain,
+                                        const float *bias, float *y, void *workspace, size_t workspace_bytes,
+                                        void *cache, size_t cache_bytes, int32_t *cache_flags, cfl_stream_t stream) {
     ConvGeom g;
     int rc = make_geom(c, &g);
     if (rc) return rc;
     if (!x || !V || !y || !workspace) return cfl_set_err(CFL_E_SHAPE, "NULL pointer");
     if (workspace_bytes < cfl_conv_workspace_bytes(c)) return cfl_set_err(CFL_E_WORKSPACE, "conv workspace too small");
+    if (cache && (!cache_flags || cache_bytes < cfl_conv_cache_bytes(c) || ((uintptr_t)cache & 15)))
+        return cfl_set_err(CFL_E_WORKSPACE, "conv cache too small / misaligned / without flags");
     hipStream_t st = (hipStream_t)stream;
-    float *scale = (float *)workspace, *n2 = scale + g.Co;
+    float *scale, *n2;
+    conv_scale_of(g, V, gain, workspace, cache, cache_flags, &scale, &n2, st);
     const int rows = g.KH * g.KW * g.Ci;
-    conv_scale(V, gain, rows, g.Co, scale, n2, n2 + g.Co, st);
     const bool vec = (g.Ci % 4 == 0) && (g.Co % 4 == 0);   // 16-byte gathers along the channel dimension
     const HaloPlan hp = halo_fwd_plan(g);
     if (g.KH == 1 && g.KW == 1 && g.H == 1 && g.W == 1 && g.S == 1 && g.Co <= 2)
         hipLaunchKernelGGL(fc_narrow_fwd_kernel, dim3((g.B + 3) / 4), dim3(256), 0, st, x, V, scale, bias, g.B, g.Ci,
                            g.Co, g.act, y);
-    else if (hp.ok)   // 3x3 stride 1: direct halo-tile kernel (weight-norm scale folded into the prepared filters)
+    else if (hp.ok) {   // 3x3 stride 1: direct halo-tile kernel (weight-norm scale folded into the prepared filters)
+        unsigned short *planes = cache ? (unsigned short *)((char *)cache + conv_cache_planes_off(g)) : nullptr;
+        const bool prep = !cache || !(*cache_flags & CFL_CONV_CACHE_PLANES_FWD);
         halo_conv(hp, g.B, g.H, g.W, g.Ci, g.Co, x, nullptr, 0, V, scale, g.Ci, g.Co, 0, bias, g.act, y,
-                  (float *)workspace + conv_ws_header_floats(g), st);
+                  (float *)workspace + conv_ws_header_floats(g), st, planes, prep);
+        if (cache) *cache_flags |= CFL_CONV_CACHE_PLANES_FWD;
+    }
     else if (vec)
         gemm_gather_modes<GG_VEC_K, GG_VEC_MN>(g.B * g.OH * g.OW, g.Co, rows, gg_klen(rows, 1), Im2colX{x, g},
                                                FilterKN{V, g.Co}, StoreFwd{y, scale, bias, g.Co, g.act}, st);
@@ -708,10 +736,24 @@ extern "C" int cfl_conv2d_wn_fwd(const CflConv *c, const float *x, const float *
     return hipGetLastError() == hipSuccess ? CFL_OK : cfl_set_err(CFL_E_HIP, "conv fwd launch failed");
 }
 
+extern "C" int cfl_conv2d_wn_fwd(const CflConv *c, const float *x, const float *V, const float *gain,
+                                 const float *bias, float *y, void *workspace, size_t workspace_bytes,
+                                 cfl_stream_t stream) {
+    return cfl_conv2d_wn_fwd_cached(c, x, V, gain, bias, y, workspace, workspace_bytes, nullptr, 0, nullptr, stream);
+}
+
 extern "C" int cfl_conv2d_wn_bwd(const CflConv *c, const float *x, const float *V, const float *gain,
                                  const float *y, const float *dy, float reg_const, float *dx, float *dV,
                                  float *dg, float *db, void *workspace, size_t workspace_bytes,
                                  cfl_stream_t stream) {
+    return cfl_conv2d_wn_bwd_cached(c, x, V, gain, y, dy, reg_const, dx, dV, dg, db, workspace, workspace_bytes, nullptr, 0,
+                                    nullptr, stream);
+}
+
+extern "C" int cfl_conv2d_wn_bwd_cached(const CflConv *c, const float *x, const float *V, const float *gain,
+                                        const float *y, const float *dy, float reg_const, float *dx, float *dV,
+                                        float *dg, float *db, void *workspace, size_t workspace_bytes, void *cache,
+                                        size_t cache_bytes, int32_t *cache_flags, cfl_stream_t stream) {
     ConvGeom g;
     int rc = make_geom(c, &g);
     if (rc) return rc;
@@ -721,19 +763,28 @@ extern "C" int cfl_conv2d_wn_bwd(const CflConv *c, const float *x, const float *
         y = dy;  // never dereferenced for act == 0 slopes, but keeps the functors simple
     }
     if (workspace_bytes < cfl_conv_workspace_bytes(c)) return cfl_set_err(CFL_E_WORKSPACE, "conv workspace too small");
+    if (cache && (!cache_flags || cache_bytes < cfl_conv_cache_bytes(c) || ((uintptr_t)cache & 15)))
+        return cfl_set_err(CFL_E_WORKSPACE, "conv cache too small / misaligned / without flags");
     hipStream_t st = (hipStream_t)stream;
-    float *scale = (float *)workspace, *n2 = scale + g.Co;
+    float *scale, *n2;
+    conv_scale_of(g, V, gain, workspace, cache, cache_flags, &scale, &n2, st);
     float *slab = (float *)workspace + conv_ws_header_floats(g);
     const int rows = g.KH * g.KW * g.Ci;
     const int npix = g.B * g.OH * g.OW;
-    conv_scale(V, gain, rows, g.Co, scale, n2, n2 + g.Co, st);
     const bool vec = (g.Ci % 4 == 0) && (g.Co % 4 == 0);
     if (dx) {
         const HaloPlan hp = halo_dx_plan(g);
         if (hp.ok) {
             // 3x3 stride 1: the input gradient is the same direct convolution over dy * act'(y) with the flipped,
             // scale-weighted filter (conv_halo.h)
-            halo_conv(hp, g.B, g.H, g.W, g.Co, g.Ci, dy, y, g.act, V, scale, g.Ci, g.Co, 1, nullptr, 0, dx, slab, st);
+            unsigned short *planes = nullptr;
+            if (cache) {
+                const HaloPlan hf = halo_fwd_plan(g);
+                planes = (unsigned short *)((char *)cache + conv_cache_planes_off(g) + (hf.ok ? (hf.wp_bytes + 15) / 16 * 16 : 0));
+            }
+            const bool prep = !cache || !(*cache_flags & CFL_CONV_CACHE_PLANES_DX);
+            halo_conv(hp, g.B, g.H, g.W, g.Co, g.Ci, dy, y, g.act, V, scale, g.Ci, g.Co, 1, nullptr, 0, dx, slab, st, planes, prep);
+            if (cache) *cache_flags |= CFL_CONV_CACHE_PLANES_DX;
         } else if (g.S == 2 && g.H % 2 == 0 && g.W % 2 == 0) {
             // four dense sub-problems, one per parity class of the input pixel
             const int KH2 = (g.KH + 1) / 2, KW2 = (g.KW + 1) / 2, H2 = g.H / 2, W2 = g.W / 2;

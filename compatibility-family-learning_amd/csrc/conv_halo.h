@@ -441,14 +441,19 @@ static inline void halo_launch_tw(const HaloArgs &a, int tn, dim3 grid, hipStrea
 }
 
 // scratch: [wp planes | slabs].  V: HWIO filter of the LAYER (Ci, Co = the layer's channels).
+// planes_cache (nullable): caller-kept prepared filter planes of THIS layer and direction (cfl_conv_cache_bytes); they
+// are (re)built when need_prep, otherwise reused -- the planes depend on V, the gains and the direction only, and a
+// layer is called 3-6 times per MrCGAN step between two updates of its weights.
 static inline void halo_conv(const HaloPlan &pl, int B, int H, int W, int K, int N, const float *a, const float *ya,
                              int slope_act, const float *V, const float *scale, int Ci, int Co, int dgrad,
-                             const float *bias, int act, float *out, void *scratch, hipStream_t st) {
-    unsigned short *wp = (unsigned short *)scratch;
+                             const float *bias, int act, float *out, void *scratch, hipStream_t st,
+                             unsigned short *planes_cache = nullptr, bool need_prep = true) {
+    unsigned short *wp = planes_cache ? planes_cache : (unsigned short *)scratch;
     float *slab = (float *)((char *)scratch + (pl.wp_bytes + 15) / 16 * 16);
     const long long prep = 9ll * pl.nchunks * pl.Npad * 4;
-    hipLaunchKernelGGL(conv_halo_prep_kernel, dim3((unsigned)((prep + 255) / 256)), dim3(256), 0, st, V, scale, Ci, Co,
-                       dgrad, K, N, pl.Npad, wp);
+    if (need_prep || !planes_cache)
+        hipLaunchKernelGGL(conv_halo_prep_kernel, dim3((unsigned)((prep + 255) / 256)), dim3(256), 0, st, V, scale, Ci, Co,
+                           dgrad, K, N, pl.Npad, wp);
     HaloArgs h;
     memset(&h, 0, sizeof(h));
     h.a = a; h.ya = (ya && slope_act != 0) ? ya : nullptr;

@@ -291,6 +291,28 @@ int cfl_conv2d_wn_bwd(const CflConv *conv, const float *x, const float *V, const
                       float *dg, float *db, void *workspace, size_t workspace_bytes,
                       cfl_stream_t stream);
 
+/* The same two calls with a caller-kept, per-layer cache of everything that depends on the weights only: the
+ * per-channel weight-norm scale g / ||V|| and -- for 3x3 stride-1 layers -- the prepared (scaled, split, re-ordered)
+ * filter planes of the direct kernel, forward and input-gradient direction.  A layer is called 3-6 times per MrCGAN
+ * step between two updates of its weights (batched G / D passes, gradient-penalty double backward); without the cache
+ * each call recomputes them (two to three small launches per call).
+ *   cache        dev buffer of cfl_conv_cache_bytes(conv) bytes, 16-byte aligned, owned by the caller, one per layer
+ *                (it does not depend on B, H, W); NULL = no caching (identical to the plain calls)
+ *   cache_flags  HOST int32: CFL_CONV_CACHE_* bits of what the buffer holds; the library sets bits as it fills the
+ *                buffer, the CALLER clears them (to 0) whenever V or g change.  Results are bit-identical with and
+ *                without the cache.  No reference counterpart (TensorFlow recomputes per op).                       */
+#define CFL_CONV_CACHE_SCALE 1
+#define CFL_CONV_CACHE_PLANES_FWD 2
+#define CFL_CONV_CACHE_PLANES_DX 4
+size_t cfl_conv_cache_bytes(const CflConv *conv);
+int cfl_conv2d_wn_fwd_cached(const CflConv *conv, const float *x, const float *V, const float *g,
+                             const float *b, float *y, void *workspace, size_t workspace_bytes,
+                             void *cache, size_t cache_bytes, int32_t *cache_flags, cfl_stream_t stream);
+int cfl_conv2d_wn_bwd_cached(const CflConv *conv, const float *x, const float *V, const float *g,
+                             const float *y, const float *dy, float reg_const, float *dx, float *dV,
+                             float *dg, float *db, void *workspace, size_t workspace_bytes,
+                             void *cache, size_t cache_bytes, int32_t *cache_flags, cfl_stream_t stream);
+
 /* Weight-normalised TRANSPOSED convolution (conv2d_transpose_weight_norm, cfl/layers.py:253-361):
  * x [B,H,W,Ci], V [KH,KW,Co,Ci] (norm over kh,kw,ci per OUTPUT channel), y [B,H*stride,W*stride,Co],
  * 'SAME'.  `conv` describes the layer in its own terms (H,W,Ci = input; Co = output).  Same

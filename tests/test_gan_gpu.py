@@ -339,3 +339,33 @@ def test_per_channel_normalizer_on_gpu():
     assert np.abs(got - n(x)).max() <= 1e-6
     s = ops.normalizer_v2((4, 5, 3), scale=2.0, mean=0.5, norm=0.5)
     assert np.abs(s.apply(torch.as_tensor(x).cuda()).cpu().numpy() - s(x)).max() <= 1e-6
+
+
+def test_conv_weight_cache_is_bit_identical():
+    """cfl_conv2d_wn_*_cached: the per-layer cache of the weight-norm scale and the prepared filter planes (rebuilt
+    when the parameter pool's version moves: Adam, load) must not change a single bit of a training trajectory --
+    3 srgan steps at 16x16 (every halo tile variant of the small shapes) with the cache on and off."""
+    from cfl import hipgan as G
+    from cfl.models import mrcgan as M
+    shape, Ld, zd, B = (16, 16, 3), 6, 5, 4
+    rng = np.random.RandomState(5)
+    N = int(np.prod(shape))
+    batches = [[np.tanh(rng.randn(B, N)), 0.3 * rng.randn(B, Ld), 0.3 * rng.randn(B, Ld), 0.3 * rng.randn(B, Ld),
+                0.3 * rng.randn(B, Ld), rng.randn(B, zd), rng.rand(B, 1)] for _ in range(3)]
+    dev = lambda a: torch.tensor(np.asarray(a, np.float32), device='cuda')
+    out = {}
+    saved = G.ConvCache.enabled
+    try:
+        for on in (True, False):
+            G.ConvCache.enabled = on
+            ph = M.GanPhase('srgan', shape, 'tanh', zd, Ld, B, torch.device('cuda'), np.random.RandomState(0),
+                            lambda_gp=0.5, lambda_dra=0.5, m_enc=0.05, m_prj=0.2)
+            hist = []
+            for b in batches:
+                ph.step(*[dev(x) for x in b])
+                hist.append(dict(ph.read_scalars()))
+            out[on] = (hist, ph.gen.pool.theta.clone(), ph.disc.pool.theta.clone())
+    finally:
+        G.ConvCache.enabled = saved
+    assert out[True][0] == out[False][0]
+    assert torch.equal(out[True][1], out[False][1]) and torch.equal(out[True][2], out[False][2])
