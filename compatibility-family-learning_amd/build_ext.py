@@ -4,7 +4,7 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SRCS = [os.path.join(HERE, 'csrc', f) for f in ('cfl_hip.hip', 'cfl_conv.hip', 'cfl_gan.hip', 'cfl_eval.hip')]
+SRCS = [os.path.join(HERE, 'csrc', f) for f in ('cfl_hip.hip', 'cfl_conv.hip', 'cfl_gan.hip', 'cfl_eval.hip', 'cfl_dp.hip')]
 SRC = SRCS[0]
 OUT = os.path.join(HERE, 'lib', 'libcfl_hip.so')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')

@@ -95,15 +95,15 @@ def train_steps(model, train_src, val_src, batch_size, shard, n_steps, on_scalar
     ``sess.run([summary, [s_optim], s_accuracy, val_s_accuracy])`` per iteration): the labeled batches of the
     seeded index stream -- as positions into the resident feature table -- go through the fused training step;
     the display scalars (train / validation accuracy) are read back every SCALAR_EVERY iterations, without stalling
-    the stream (DeferredScalars).  On one GPU the iterations between two read-backs are one library call (windows of
-    the device pair lists); data-parallel ranks step batch by batch (each step contains the gradient all-reduce)."""
+    the stream (DeferredScalars).  The iterations between two read-backs are one engine call over windows of the
+    device pair lists (on one GPU one library call; data parallel: the same windows with the gradient exchange inside
+    the loop, PairEngine.step_windows)."""
     i = 0
-    single = dp.world_size() == 1
     deferred = DeferredScalars(model, on_scalars) if on_scalars is not None else None
     while i < n_steps:
         # the chunk ends with the next iteration whose scalars are read back (0, 25, 50, ..., and the last one)
         stop = min((i + SCALAR_EVERY - 1) // SCALAR_EVERY * SCALAR_EVERY, n_steps - 1) + 1
-        win = train_src.next_windows(batch_size, stop - i, shard) if single else None
+        win = train_src.next_windows(batch_size, stop - i, shard)
         if win is not None:
             model.engine.step_windows(win)
             done = win.nsteps

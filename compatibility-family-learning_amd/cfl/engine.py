@@ -122,6 +122,13 @@ class PairEngine(object):
         self._ws = {}
         if batch_size:
             self._workspace(batch_size, 2)
+        # data-parallel exchange: RCCL all-reduce (default) or the library's one-shot push + summing Adam
+        # (CFL_DP_EXCHANGE=oneshot: cfl/dp_exchange.py, csrc/cfl_dp.hip)
+        self._oneshot = None
+        import os
+        if world_size() > 1 and os.environ.get('CFL_DP_EXCHANGE', 'allreduce') == 'oneshot':
+            from .dp_exchange import OneShotExchange
+            self._oneshot = OneShotExchange(self)
 
     # -- plumbing ----------------------------------------------------------
     def _workspace(self, rows, groups):
@@ -192,7 +199,15 @@ class PairEngine(object):
                                     self.scalars, ws)
         else:
             H.pair_step_fwd_bwd(self.shape, self.norm, self.loss, batch, self.theta, self.grad, self.scalars, ws)
-        # one exchange per step: sum of [flat fp32 gradient | scalars] over xGMI
+        self._exchange_and_update()
+
+    def _exchange_and_update(self):
+        """the ONE exchange of a data-parallel step + the replicated Adam apply"""
+        if self._oneshot is not None:
+            self._scalar_scale = self._oneshot.exchange_and_adam(self, self.lr_t())
+            self._advance()
+            return
+        # sum of [flat fp32 gradient | scalars] over xGMI
         scale = reduce_gradients(self.gradbuf)
         self._scalar_scale = scale
         self.apply_adam(scale)
@@ -201,9 +216,23 @@ class PairEngine(object):
         """`win.nsteps` consecutive single-GPU training steps over windows of the device pair lists
         (cfl.input_data.ResidentFeatures.next_windows): one library call, the launches of all steps are enqueued
         back to back."""
-        if self.world_size != 1:
-            raise H.CflHipError('step_windows is the single-GPU loop; data-parallel ranks step batch by batch')
         ws = self._workspace(win.rows, 2)
+        if self.world_size != 1:
+            # data parallel: the same windows, the exchange inside the loop -- every step is forward/backward on this
+            # rank's rows of the window, then the collective + Adam (one host call for the iterations between two
+            # read-backs; with the one-shot exchange nothing in the loop leaves the library's kernels)
+            itemsize = 4
+            pp, npair = win.pos_pairs.data_ptr(), win.neg_pairs.data_ptr()
+            for i in range(win.nsteps):
+                po = pp + 2 * itemsize * (win.pos_head + i * win.batch_rows + win.shard_lo)
+                no = npair + 2 * itemsize * (win.neg_head + i * win.batch_rows + win.shard_lo)
+                c0 = 1 if (win.switched is not None and win.switched[i]) else 0
+                streams = H.IndexStreams([po + 4 * c0, po + 4 * (1 - c0), no + 4 * c0, no + 4 * (1 - c0)], 2, win.rows,
+                                         keep=[win.pos_pairs, win.neg_pairs])
+                H.pair_step_fwd_bwd_idx(self.shape, self.norm, self.loss, win.table, streams, self.theta, self.grad,
+                                        self.scalars, ws)
+                self._exchange_and_update()
+            return
         b1p, b2p = H.pair_train_steps_idx(
             self.shape, self.norm, self.loss, win.table, win.pos_pairs, win.neg_pairs, win.pos_head, win.neg_head,
             win.batch_rows, win.shard_lo, win.rows, win.switched, win.nsteps, self.theta, self.m, self.v, self.grad,

@@ -66,7 +66,7 @@ EXPORTS = ('cfl_version', 'cfl_last_error', 'cfl_layout', 'cfl_workspace_bytes',
            'cfl_gather_rows', 'cfl_profile_enable', 'cfl_profile_read', 'cfl_pair_input_grad',
            'cfl_conv_workspace_bytes', 'cfl_conv_uses_direct_kernel', 'cfl_conv2d_wn_fwd', 'cfl_conv2d_wn_bwd',
            'cfl_pair_scores_idx', 'cfl_pair_step_fwd_bwd_idx', 'cfl_pair_train_step_idx', 'cfl_reload_env',
-           'cfl_pair_train_steps_idx', 'cfl_mt19937_reshuffle')
+           'cfl_pair_train_steps_idx', 'cfl_mt19937_reshuffle', 'cfl_dp_push', 'cfl_dp_wait', 'cfl_dp_adam')
 
 KERNEL_NAMES = ('colnorm', 'proj', 'mid', 'grad', 'finalize', 'adam', 'gather')
 K_COUNT = 8
@@ -151,6 +151,13 @@ def lib():
     L.cfl_conv2d_wn_bwd.argtypes = ([C.POINTER(CflConv)] + [C.c_void_p] * 5 + [C.c_float] +
                                     [C.c_void_p] * 5 + [C.c_size_t, C.c_void_p])
     L.cfl_conv2d_wn_bwd.restype = C.c_int
+    L.cfl_dp_push.argtypes = [C.c_void_p, C.c_int64, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int32, C.c_uint32,
+                              C.c_void_p, C.c_void_p]
+    L.cfl_dp_push.restype = C.c_int
+    L.cfl_dp_wait.argtypes = [C.c_void_p, C.c_int32, C.c_uint32, C.c_void_p, C.c_void_p]
+    L.cfl_dp_wait.restype = C.c_int
+    L.cfl_dp_adam.argtypes = [C.c_void_p] * 4 + [C.c_int32, C.c_int64, C.c_int64, C.c_void_p] + [C.c_float] * 4 + [C.c_void_p, C.c_void_p]
+    L.cfl_dp_adam.restype = C.c_int
     L.cfl_profile_enable.argtypes = [C.c_int]
     L.cfl_profile_read.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     if L.cfl_version() != 2:

@@ -412,6 +412,25 @@ enum {
 int cfl_profile_enable(int on);
 int cfl_profile_read(double *ms_sum, int64_t *launches);
 
+/* One-shot gradient exchange of the data-parallel step (new functionality; the reference is single-device).  An opt-in
+ * alternative to all-reducing [gradient | scalars] with RCCL: every rank pushes its buffer into its slot of every
+ * peer's exchange buffer (peer device memory mapped by the caller, e.g. through hipIpc), and the Adam launch sums the
+ * `world` slots in rank order (deterministic, identical on all ranks).  Host side: cfl/dp_exchange.py.
+ *   cfl_dp_push   src dev [n]; peer_slots / peer_flags: HOST arrays [world] of device pointers -- this rank's slot
+ *                 (n floats, 16-byte aligned) and flag word inside peer r's buffers; ticket: dev uint32, zero before the
+ *                 first call (the kernel leaves it zero); generation: a number unique to this step (e.g. the step count)
+ *   cfl_dp_wait   flags dev [world]: the LOCAL flag words the peers write; returns (on the stream) when all equal
+ *                 `generation`; *lost (dev int32, zero-initialised by the caller) is set when the bounded wait gives up
+ *   cfl_dp_adam   slots dev [world][n] (local); sum_out dev [n] receives the sum over ranks (what an all-reduce leaves);
+ *                 TF-Adam with gradient sum / world on the first n_adam floats (theta, m, v).  *lost != 0 poisons the
+ *                 update with NaN (a lost hand-off must be loud).                                                  */
+int cfl_dp_push(const float *src, int64_t n, float *const *peer_slots, uint32_t *const *peer_flags, int32_t world,
+                uint32_t generation, uint32_t *ticket, cfl_stream_t stream);
+int cfl_dp_wait(const uint32_t *flags, int32_t world, uint32_t generation, int32_t *lost, cfl_stream_t stream);
+int cfl_dp_adam(float *theta, float *m, float *v, const float *slots, int32_t world, int64_t n, int64_t n_adam,
+                float *sum_out, float lr_t, float beta1, float beta2, float eps, const int32_t *lost,
+                cfl_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -156,3 +156,87 @@ def test_bench_starts_its_own_ranks():
     r2 = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup',
                          '1'], env=env2, cwd=ROOT, capture_output=True, text=True, timeout=300)
     assert r2.returncode != 0 and '--gpus 2 but WORLD_SIZE 1' in r2.stderr
+
+
+def _oneshot_worker(rank, world, port, out):
+    for p in (ROOT, os.path.join(ROOT, 'compatibility-family-learning_amd')):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from argparse import Namespace
+        from cfl import engine, hipabi as H
+        from cfl.engine import PairEngine
+        rng = np.random.RandomState(0)                       # identical on every rank
+        D, L, K, B = 256, 6, 3, 64
+        params = {'outputs/W': (rng.randn(D, L) * 0.05).astype(np.float32), 'outputs/b': np.zeros(L, np.float32),
+                  'proto/W': (rng.randn(D, L * K) * 0.05).astype(np.float32), 'proto/b': np.zeros(L * K, np.float32)}
+
+        def mk(exchange):
+            os.environ['CFL_DP_EXCHANGE'] = exchange
+            return PairEngine(D, L, K, 'pcd', weight_norm=False, has_bias=True, norm=H.make_norm(0.25),
+                              loss=H.make_loss(reg_const=1e-3), lr=1e-3, device='cuda', params=params)
+        a, b = mk('allreduce'), mk('oneshot')
+        assert a._oneshot is None and b._oneshot is not None
+        table = torch.tensor(np.abs(rng.randn(500, D)).astype(np.float32), device='cuda')
+        lo, hi = engine.shard_rows(B)
+        worst = 0.0
+        for it in range(6):
+            idx = [torch.tensor(rng.randint(0, 500, size=B).astype(np.int32), device='cuda') for _ in range(4)]
+            batch = (table, H.IndexStreams.from_tensors([i[lo:hi].contiguous() for i in idx]))
+            a.step(batch)
+            b.step(batch)
+            sa, sb = a.read_scalars(), b.read_scalars()
+            worst = max(worst, float((a.theta - b.theta).abs().max()), float((a.grad - b.grad).abs().max() /
+                                                                               a.grad.abs().max()))
+            for k in ('total', 'accuracy', 'mean_d_pos'):
+                worst = max(worst, abs(sa[k] - sb[k]) / max(1.0, abs(sa[k])))
+        # windows of device pair lists through step_windows (K steps per engine call, the exchange inside the loop)
+        # == the same steps taken one by one
+        n = 4 * B
+        pos = torch.tensor(rng.randint(0, 500, size=(n, 2)).astype(np.int32), device='cuda')
+        neg = torch.tensor(rng.randint(0, 500, size=(n, 2)).astype(np.int32), device='cuda')
+        win = Namespace(table=table, pos_pairs=pos, neg_pairs=neg, pos_head=0, neg_head=B, batch_rows=B, shard_lo=lo,
+                        rows=hi - lo, nsteps=3, switched=[False, True, False])
+        c = mk('oneshot')
+        c.load_state_dict(b.state_dict())
+        b.step_windows(win)
+        for i in range(3):
+            ph, nh = i * B + lo, B + i * B + lo
+            cols = (1, 0) if win.switched[i] else (0, 1)
+            streams = H.IndexStreams.from_tensors([pos[ph:ph + hi - lo, cols[0]].contiguous(), pos[ph:ph + hi - lo, cols[1]].contiguous(),
+                                                   neg[nh:nh + hi - lo, cols[0]].contiguous(), neg[nh:nh + hi - lo, cols[1]].contiguous()])
+            c.step((table, streams))
+        windows_equal = bool(torch.equal(b.theta, c.theta)) and b.global_step == c.global_step
+        th = b.theta.clone()
+        dist.all_reduce(th, op=dist.ReduceOp.MAX)
+        same = bool(torch.equal(th, b.theta))                 # every rank holds the same weights, bit for bit
+        lost = int(b._oneshot.lost.item())
+        if rank == 0:
+            out.put((worst, same, windows_equal, lost))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_oneshot_exchange_equals_allreduce_and_windows_equal_single_steps():
+    """CFL_DP_EXCHANGE=oneshot (csrc/cfl_dp.hip, cfl/dp_exchange.py): every rank pushes [gradient | scalars] into its
+    slot of every peer's buffer (mapped through hipIpc), the Adam launch sums the slots in rank order.  Two ranks on
+    the one GPU: parameters / gradient sums / scalars equal the all-reduce path to 1e-6, both ranks hold identical
+    parameters, no hand-off was lost; and PairEngine.step_windows under data parallelism (K steps per call, the exchange
+    inside the loop) equals the same steps taken one at a time, bit for bit."""
+    ctx = mp.get_context('spawn')
+    out = ctx.SimpleQueue()
+    port = 33500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_oneshot_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    worst, same, windows_equal, lost = out.get()
+    assert lost == 0
+    assert same and windows_equal
+    assert worst < 1e-6, worst
