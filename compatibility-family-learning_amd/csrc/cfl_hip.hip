@@ -161,6 +161,15 @@ extern "C" int cfl_debug_clear_stamps(void) {
 #define RSTAMP(slot) do {} while (0)
 #endif
 
+// The argument block is read IN PLACE from the kernel-argument segment (it is the launch's only explicit argument, at
+// offset 0): clang gives a by-value aggregate parameter a private copy that is only optimised away while the number of
+// accesses stays under an internal limit -- past it the whole block (2.2 KB per lane) lives in scratch and the
+// weight-gradient launch takes 2.7x as long (seen twice: eight inlined bodies in one kernel, and again with the
+// siamese pairing fields).
+#define CFL_KERNARG_IN_PLACE(T, name, param)                                                          \
+    (void)param;                                                                                       \
+    const T &name = *(const T *)__builtin_amdgcn_kernarg_segment_ptr()
+
 // ---------------------------------------------------------------------------
 // device helpers
 // ---------------------------------------------------------------------------
@@ -939,6 +948,215 @@ extern "C" __global__ __launch_bounds__(512) void cfl_proj_ring_kernel(RingArgs 
     RSTAMP(5);
 }
 
+// ---------------------------------------------------------------------------
+// proj, bf16x3 form with W planes shared through LDS (large row counts; round 3).
+// The exact-fp32 forms above sit under both of their roofs at once (41-61 us of fp32 matrix-core time and 43-64 us of x
+// arrival per 8192-pair call, profiles/r03_proj_forms.md).  This form halves the matrix time without giving up fp32
+// accuracy: every fp32 operand is split exactly into three bf16 values (split3) and a product is accumulated in fp32 from
+// EIGHT of the nine partial products on v_mfma_f32_16x16x32_bf16 (only a_l * b_l, <= 2^-32 |ab|, is dropped -- the
+// weight gradient drops three; the distances feed exp(), so the forward keeps two more): 8 x 16 cycles per 16x16x32
+// product block against 8 x 32 cycles for the eight v_mfma_f32_16x16x4_f32 it replaces.
+//   * W is split ONCE per call by cfl_wplanes_kernel into bf16 planes in the B-fragment order of the 16x16x32 MFMA
+//     (one 1 KiB block per (column tile, 32-d quarter, plane)): no operand splitting of W inside the loop;
+//   * a workgroup = 4 waves that own 32 rows each of a 128-row tile and walk the SAME d slice, so the W planes of a
+//     step are fetched once per workgroup -- by LDS-DMA (global_load_lds_dwordx4), each wave issuing a share of the
+//     pieces three steps ahead into a 4-slot ring (counted vmcnt + one raw s_barrier per step) -- instead of once per
+//     wave from L2 (2 bytes of W per byte of x in the forms above, 0.75 here);
+//   * x stays on the register path of the streaming form (ring of four quarters, refilled as soon as a quarter has
+//     been parked in the wave-private LDS tile): 16 KiB per wave in flight, more than LDS could hold;
+//   * the A fragments (16 rows x 32 d = whole 128-byte rows) are read back from the tile, split in the VALU slots the
+//     MFMAs leave free, and multiplied.
+// Work units (column job, 128-row tile, d slice) as in the ring form; two workgroups per CU.
+// ---------------------------------------------------------------------------
+#define PX3_SLOTS 4
+#define PX3_AHEAD 3                                  // W planes are requested three steps ahead
+#define PX3_SLOT_USHORTS (4 * 3 * 512)               // up to 4 column tiles x 3 planes x 1 KiB
+#define PX3_LDS_BYTES (PX3_SLOTS * PX3_SLOT_USHORTS * 2 + 4 * 4096)
+
+struct Px3Args {
+    ProjJob job[CFL_MAX_JOBS];                       // wf = the job's PLANES base (ushort units, see cfl_wplanes_kernel)
+    int order[CFL_MAX_JOBS];
+    RowSrc rows[2];
+    int B, R, D, S, njobs;
+    int tiles, nunits, nwg, Kq;                      // Kq = 32-d quarters per slice
+    NormDev norm;
+};
+
+// W (fragment-major fp32, Wf[nt][g][q][c16][e]) -> planes[((nt * Q + tq) * 3 + p) * 512 + lane * 8 + j]:
+// bf16 level p of W[d = 32 tq + 8 (lane >> 4) + j][col = 16 nt + (lane & 15)]  (B operand of v_mfma_f32_16x16x32_bf16)
+struct WPlanesArgs { const float *wf[2]; unsigned short *planes[2]; int ntiles[2]; int G; };
+__global__ __launch_bounds__(256) void cfl_wplanes_kernel(WPlanesArgs w) {   // both sides' heads in one launch
+    const int Q = w.G >> 1;
+    long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long n0 = (long long)w.ntiles[0] * Q * 64;
+    const int sd = i >= n0 ? 1 : 0;
+    if (sd) i -= n0;
+    if (i >= (long long)w.ntiles[sd] * Q * 64) return;
+    const float *wf = sd ? w.wf[1] : w.wf[0];
+    unsigned short *planes = sd ? w.planes[1] : w.planes[0];
+    const int G = w.G;
+    const int lane = (int)(i & 63);
+    const int tq = (int)((i >> 6) % Q), nt = (int)((i >> 6) / Q);
+    const int n = lane & 15, kq = lane >> 4;
+    const int g = 2 * tq + (kq >> 1), q0 = 2 * (kq & 1);
+    const float *src = wf + ((size_t)nt * G + g) * 256 + (q0 * 16 + n) * 4;
+    const f32x4 v0 = *(const f32x4 *)src, v1 = *(const f32x4 *)(src + 64);
+    float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+    bf16x8 f[3];
+    split_frag(v, f);
+    unsigned short *dst = planes + ((size_t)(nt * Q + tq) * 3) * 512 + lane * 8;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) *(bf16x8 *)(dst + p * 512) = f[p];
+}
+
+template <int NT>
+__device__ __forceinline__ void px3_unit(const Px3Args &a, const ProjJob &jb, int tile, int slice, char *smem) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int i16 = lane & 15, kq = lane >> 4;
+    const int rr8 = lane >> 3, ch8 = lane & 7;
+    const int Q = a.D >> 5;                       // quarters per row
+    const int t0 = slice * a.Kq;                  // first quarter of the slice
+    constexpr int NP = NT * 3;                    // W pieces (1 KiB) per step
+    // pieces of a step dealt round-robin to the 4 waves: wave w issues pieces w, w + 4, ... < NP
+    constexpr int PMAX = (NP + 3) / 4;
+    const int mine = (NP - wave + 3) / 4;         // this wave's pieces per step (uniform per wave)
+    typedef __attribute__((address_space(3))) char lds_char;
+    const unsigned lds0 = (unsigned)(uintptr_t)(lds_char *)smem;
+    f32x4 *xt = (f32x4 *)(smem + PX3_SLOTS * PX3_SLOT_USHORTS * 2) + wave * 256;    // wave-private transpose tile
+    const unsigned short *wbase = (const unsigned short *)jb.wf;                    // planes of this job's tiles
+
+    f32x4 acc[2][NT];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int row0 = tile * 128 + wave * 32;
+    const float *xrow[4];
+    {
+        const RowSrc rs = jb.side ? a.rows[1] : a.rows[0];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xrow[i] = row_ptr(rs, row0 + 8 * i + rr8, a.B, a.R, a.D) + t0 * 32 + 4 * ch8;
+    }
+    // piece k of step q: block (nt = k / 3, plane = k % 3) of quarter t0 + q; LDS slot layout = the same block order
+    auto issueW = [&](int q) {
+        const int qq = q < a.Kq ? q : a.Kq - 1;   // past the end: re-fetch the last step (keeps the counted waits exact)
+        const unsigned sb = lds0 + (unsigned)((q % PX3_SLOTS) * PX3_SLOT_USHORTS) * 2;
+#pragma unroll
+        for (int j = 0; j < PMAX; ++j) {
+            const int k = wave + 4 * j;
+            if (k < NP) {
+                const int nt = k / 3, pl = k - 3 * nt;
+                glds16((const float *)(wbase + ((size_t)(nt * Q + t0 + qq) * 3 + pl) * 512 + lane * 8), sb + k * 1024);
+            }
+        }
+    };
+    f32x4 araw[4][4];
+    auto loadA = [&](int q, f32x4 *dst) {
+        const int qq = q < a.Kq ? q : a.Kq - 1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dst[i] = *(const f32x4 *)(xrow[i] + qq * 32);
+    };
+    // prologue: W of steps 0 .. AHEAD-1, x of steps 0 .. 3 (consumption order); own W pieces of step 0 landed, barrier
+#pragma unroll
+    for (int q = 0; q < PX3_AHEAD; ++q) issueW(q);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { loadA(q, araw[q]); __builtin_amdgcn_sched_barrier(0); }
+    // everything issued after this wave's W(0) pieces may stay in flight: W(1), W(2) and the 16 x loads
+    {
+        const int later = 2 * mine + 16;
+        if (later == 18) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+        else if (later == 20) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+        else if (later == 22) asm volatile("s_waitcnt vmcnt(22)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");   // (mine == 0: nothing of its own to wait for)
+    }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+
+    for (int q0 = 0; q0 < a.Kq; q0 += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int q = q0 + u;                 // (Kq is a multiple of 4: whole 128-d chunks per slice)
+            // W planes three steps ahead, then this quarter of x: park, refill the registers with the quarter 4 ahead
+            issueW(q + PX3_AHEAD);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = 8 * i + rr8;
+                xt[row * 8 + (ch8 ^ (row & 7))] = norm_apply(araw[u][i], a.norm, (t0 + q) * 32 + 4 * ch8);
+            }
+            loadA(q + 4, araw[u]);
+            __builtin_amdgcn_sched_barrier(0);
+            // fragments: A = rows 16 mt + i16, d = 8 kq .. 8 kq + 7 (two 16-byte chunks of the parked row), split here;
+            // B = planes from the shared slot (lane-linear 16 bytes per block)
+            bf16x8 af[2][3];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const int row = mt * 16 + i16;
+                const f32x4 c0 = xt[row * 8 + ((2 * kq) ^ (row & 7))], c1 = xt[row * 8 + ((2 * kq + 1) ^ (row & 7))];
+                float v[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
+                split_frag(v, af[mt]);
+            }
+            const bf16x8 *ws = (const bf16x8 *)(smem + (size_t)(q % PX3_SLOTS) * PX3_SLOT_USHORTS * 2) + lane;
+            bf16x8 bf[NT][3];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) bf[nt][pl] = ws[(nt * 3 + pl) * 64];
+            // eight of the nine partial products, small terms first; consecutive MFMAs hit different accumulators
+#define PX3_MM(LA, LB)                                                                                        \
+    _Pragma("unroll") for (int mt = 0; mt < 2; ++mt) _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = \
+        __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mt][LA], bf[nt][LB], acc[mt][nt], 0, 0, 0);
+            PX3_MM(2, 1) PX3_MM(1, 2) PX3_MM(1, 1) PX3_MM(2, 0) PX3_MM(0, 2) PX3_MM(1, 0) PX3_MM(0, 1) PX3_MM(0, 0)
+#undef PX3_MM
+            // own W pieces of step q + 1 have landed (issued at step q - 2: W(q+2), W(q+3) and 4 x quarters are younger)
+            // (younger in the queue: x(q+2), W(q+2), x(q+3), W(q+3), x(q+4) = 12 loads + 2 * mine pieces)
+            {
+                const int later = 2 * mine + 12;
+                if (later == 14) asm volatile("s_waitcnt vmcnt(14) lgkmcnt(0)" ::: "memory");
+                else if (later == 16) asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
+                else if (later == 18) asm volatile("s_waitcnt vmcnt(18) lgkmcnt(0)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the re-fetched tail pieces / quarters: nothing may land after the unit
+    __builtin_amdgcn_s_barrier();
+    // C layout: col = lane & 15, rows 4 (lane >> 4) .. + 3  ->  Ypart[slice][row][npad]
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            float *dst = jb.ypart + (size_t)slice * jb.sstride + (size_t)(row0 + mt * 16 + 4 * kq) * jb.npad + nt * 16 + i16;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dst[(size_t)e * jb.npad] = acc[mt][nt][e];
+        }
+}
+
+extern "C" __global__ __launch_bounds__(256, 2) void cfl_proj_x3_kernel(Px3Args a_) {
+    CFL_KERNARG_IN_PLACE(Px3Args, a, a_);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int w = blockIdx.x;
+    for (int i = 0;; ++i) {
+        // snake order over the heavy-to-light unit list (as the ring form)
+        const int base = (i >> 1) * 2 * a.nwg;
+        const int uid = (i & 1) ? base + 2 * a.nwg - 1 - w : base + w;
+        if (uid >= a.nunits) break;
+        const int per_job = a.tiles * a.S;
+        const int job = a.order[uid / per_job], rem = uid % per_job;
+        const int tile = rem / a.S, slice = rem % a.S;
+        const ProjJob &jb = a.job[job];
+        switch (jb.nt) {
+            case 1: px3_unit<1>(a, jb, tile, slice, smem); break;
+            case 2: px3_unit<2>(a, jb, tile, slice, smem); break;
+            case 3: px3_unit<3>(a, jb, tile, slice, smem); break;
+            default: px3_unit<4>(a, jb, tile, slice, smem); break;
+        }
+    }
+}
+
 extern "C" __global__ __launch_bounds__(256) void cfl_proj_kernel(ProjArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     f32x4 *lds = (f32x4 *)smem;
@@ -1521,15 +1739,6 @@ __device__ __forceinline__ void grad_red_block(const GradArgs &a, float *lds) { 
         }
     }
 }
-
-// The argument block is read IN PLACE from the kernel-argument segment (it is the launch's only explicit argument, at
-// offset 0): clang gives a by-value aggregate parameter a private copy that is only optimised away while the number of
-// accesses stays under an internal limit -- past it the whole block (2.2 KB per lane) lives in scratch and the
-// weight-gradient launch takes 2.7x as long (seen twice: eight inlined bodies in one kernel, and again with the
-// siamese pairing fields).
-#define CFL_KERNARG_IN_PLACE(T, name, param)                                                          \
-    (void)param;                                                                                       \
-    const T &name = *(const T *)__builtin_amdgcn_kernarg_segment_ptr()
 
 extern "C" __global__ __launch_bounds__(256) void cfl_grad_kernel(GradArgs a_) {
     CFL_KERNARG_IN_PLACE(GradArgs, a, a_);
@@ -3043,6 +3252,8 @@ struct Plan {
     bool xcd;  // XCD-aligned launch order of proj / grad (cfl_xcd_aligned)
     int proj_stream;  // 0: one wait per 128-d chunk (proj_body); 1: streaming form (proj_stream_body)
     bool proj_mix;    // streaming form at S == 1: column jobs interleaved in launch order
+    bool proj_x3;     // bf16x3 forward with LDS-shared W planes (cfl_proj_x3_kernel); S is then its d split
+    size_t wplanes[2];
     bool fold;        // proj + mid in one launch (cfl_proj_mid_kernel)
     size_t fold_flags;
     bool proj_ring;   // loader / consumer ring form (cfl_proj_ring_kernel); S is then the ring's d split
@@ -3145,8 +3356,26 @@ static int make_plan(const CflShape *s, int64_t rows, int groups, bool train, Pl
             S = rs;
         }
     }
+    // bf16x3 forward with shared W planes: 128-row tiles, d split so that the 512 resident workgroups (two per CU) get
+    // one or two units each; slices are whole 128-d chunks
+    pl->proj_x3 = false;
+    if (!pl->proj_ring) {
+        const int ov = debug_env("CFL_DEBUG_PROJ_X3");
+        const int tiles = (pl->R + 127) / 128;
+        int rs = 1;
+        while (rs < 16 && njobs * tiles * rs < 512 && (s->D / 128) % (2 * rs) == 0 && s->D / (2 * rs) >= 512) rs *= 2;
+        const int units = njobs * tiles * rs;
+        const bool ok = s->D % 128 == 0 && (s->D / 128) % rs == 0 && units >= 256 && pl->x3;
+        if (ok && ov >= 0 && (ov > 0 || pl->R >= 8192)) {
+            pl->proj_x3 = true;
+            pl->ring_tiles = tiles;
+            pl->ring_units = units;
+            pl->ring_nwg = units < 512 ? units : 512;
+            S = rs;
+        }
+    }
     pl->S = S;
-    pl->xcd = !pl->proj_ring && cfl_xcd_aligned(S, s->D / 64);
+    pl->xcd = !pl->proj_ring && !pl->proj_x3 && cfl_xcd_aligned(S, s->D / 64);
     // streaming projection when a wave owns at least four 128-d chunks (measured: equal to the chunk-at-a-time form at
     // two, -11 % at eight; CFL_DEBUG_PROJ_STREAM: -1 never, 1 always)
     {
@@ -3203,10 +3432,12 @@ static int make_plan(const CflShape *s, int64_t rows, int groups, bool train, Pl
         const int group = S * njobs;
         const int wide = hs->npad > hd->npad ? hs->npad : hd->npad;
         pl->fold = debug_env("CFL_DEBUG_FOLD") > 0 && s->dist_type == CFL_DIST_PCD && !s->weight_norm && wide <= 64 &&
-                   s->K <= 64 && S % 8 == 0 && group <= 32 && 32 % group == 0 && !pl->proj_ring && !pl->proj_stream &&
+                   s->K <= 64 && S % 8 == 0 && group <= 32 && 32 % group == 0 && !pl->proj_ring && !pl->proj_stream && !pl->proj_x3 &&
                    pl->R % 32 == 0 && (!train || pl->Rpad == pl->R) && !pl->mid_generic && !pl->mid_norow;
         pl->fold_flags = take(pl->fold ? (size_t)(pl->R / 32) * group : 0);
     }
+    pl->wplanes[0] = take(pl->proj_x3 ? (size_t)hs->npad * s->D * 3 / 2 : 0);   // bf16 planes: 6 bytes per weight
+    pl->wplanes[1] = take(pl->proj_x3 ? (size_t)hd->npad * s->D * 3 / 2 : 0);
     pl->n2 = take(2 * 6 * 1024);  // squared column norms + gain snapshot of up to 6 heads
     pl->total_floats = off;
     const int ks = s->dist_type == CFL_DIST_PCD ? s->K : 1;
@@ -3399,6 +3630,45 @@ static int run_pairs(const CflShape *s, const CflNorm *norm, const CflLossCfg *l
         const int nz = nj + (cn_slice ? 1 : 0);
         if (pl.fold) {
             // launched below, together with the row math (cfl_proj_mid_kernel)
+        } else if (pl.proj_x3) {
+            Px3Args xa;
+            memset(&xa, 0, sizeof(xa));
+            const int Q = s->D / 32;
+            int jn = 0;
+            {
+                ProfScope psw(st, CFL_K_COLNORM);   // (profile slot reused: the per-call split of W into bf16 planes)
+                WPlanesArgs wa;
+                memset(&wa, 0, sizeof(wa));
+                wa.G = G;
+                long long items = 0;
+                for (int sd = 0; sd < 2; ++sd) {
+                    const CflHead *h = side[sd].head;
+                    unsigned short *planes = (unsigned short *)(ws + pl.wplanes[sd]);
+                    wa.wf[sd] = theta + h->w; wa.planes[sd] = planes; wa.ntiles[sd] = h->npad / 16;
+                    items += (long long)(h->npad / 16) * Q * 64;
+                    for (int c0 = 0; c0 < h->npad / 16; c0 += 4, ++jn) {
+                        xa.job[jn] = pa.job[jn];
+                        xa.job[jn].wf = (const float *)(planes + (size_t)c0 * Q * 3 * 512);
+                    }
+                }
+                hipLaunchKernelGGL(cfl_wplanes_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, wa);
+            }
+            int k = 0;
+            for (int nt = 4; nt >= 1; --nt)
+                for (int i = 0; i < nj; ++i)
+                    if (pa.job[i].nt == nt) xa.order[k++] = i;
+            xa.rows[0] = rsrc[0]; xa.rows[1] = rsrc[1];
+            xa.B = (int)rows; xa.R = pl.R; xa.D = s->D; xa.S = pl.S; xa.njobs = nj;
+            xa.tiles = pl.ring_tiles; xa.nunits = pl.ring_units; xa.nwg = pl.ring_nwg; xa.Kq = Q / pl.S;
+            xa.norm = nd;
+            ProfScope ps(st, CFL_K_PROJ);
+            hipLaunchKernelGGL(cfl_proj_x3_kernel, dim3(pl.ring_nwg), dim3(256), PX3_LDS_BYTES, st, xa);
+            if (cn_slice) {
+                ProjArgs pc = pa;
+                pc.job[0].nt = 0;
+                pc.xcd = 0; pc.mix = 0;
+                hipLaunchKernelGGL(cfl_proj_kernel, dim3(64, 1, 1), dim3(256), 4 * 8 * 64 * sizeof(f32x4), st, pc);
+            }
         } else if (pl.proj_ring) {
             RingArgs ra;
             memset(&ra, 0, sizeof(ra));

@@ -504,13 +504,15 @@ def test_step_windows_equal_single_indexed_steps(tmp_path):
 @pytest.mark.parametrize('D,L,K,n,act_norm', [(4096, 20, 3, 8192, False), (2048, 20, 5, 4500, False), (1088, 12, 2, 3000, True),
                                               (4096, 64, 1, 2100, False)])
 def test_projection_forms_agree(D, L, K, n, act_norm, monkeypatch):
-    """The three forms of the forward projection on large scoring calls (a wave owns several 128-d chunks):
-    chunk-at-a-time (proj_body), streaming (proj_stream_body: the default from four chunks per wave) and the
-    loader / consumer ring (cfl_proj_ring_kernel, opt-in).  The streaming form must reproduce the chunk-at-a-time
-    scores BIT FOR BIT (same k-ordered FMA chains, same summation order); the ring form sums a d slice in one
-    wave instead of four, so it is held to fp32 rounding of the scores, and every form to 1e-5 of the fp64
-    oracle.  Shapes: the dist_eval call (two jobs, 4 / 2 column tiles), 7 column tiles on the source side
-    (jobs of 4 + 3 tiles), D % 128 == 64 with an element-wise normaliser, and a one-job-per-side K = 1 model."""
+    """The forms of the forward projection on large scoring calls (a wave owns several 128-d chunks):
+    chunk-at-a-time (proj_body), streaming (proj_stream_body), the loader / consumer ring (cfl_proj_ring_kernel, opt-in)
+    and the bf16x3 form with LDS-shared W planes (cfl_proj_x3_kernel: the default from 8192 rows per side).  The
+    streaming form must reproduce the chunk-at-a-time scores BIT FOR BIT (same k-ordered FMA chains, same summation
+    order); the ring sums a d slice in one wave and the bf16x3 form accumulates eight exact partial products per
+    32-d block, so both are held to fp32 rounding of the scores -- and the bf16x3 form additionally to an error
+    against the float64 oracle no larger than twice the exact-fp32 form's -- and every form to 1e-5 of the oracle.
+    Shapes: the dist_eval call (two jobs, 4 / 2 column tiles), 7 column tiles on the source side (jobs of 4 + 3
+    tiles), D % 128 == 64 with an element-wise normaliser (the ring / bf16x3 forms decline it), a K = 1 model."""
     rng = np.random.RandomState(99)
     cfg = O.EncoderCfg(D=D, L=L, K=K)
     p = _mk(cfg, rng)
@@ -521,29 +523,34 @@ def test_projection_forms_agree(D, L, K, n, act_norm, monkeypatch):
     xt = torch.from_numpy(_inputs(rng, n, D, nv / 4)).cuda()
     norm = H.make_norm(1.0 / nv, -0.05, 0.0, 0.9) if act_norm else H.make_norm(1.0 / nv)
 
-    def run(stream, ring):
+    def run(stream, ring, x3):
         monkeypatch.setenv('CFL_DEBUG_PROJ_STREAM', str(stream))
         monkeypatch.setenv('CFL_DEBUG_PROJ_RING', str(ring))
+        monkeypatch.setenv('CFL_DEBUG_PROJ_X3', str(x3))
         H.reload_env()
         ws = torch.full((H.workspace_bytes(sh, n, 1) // 4,), float('nan'), dtype=torch.float32, device='cuda')
         out = H.pair_scores(sh, norm, xs, xt, theta, ws).clone()
         torch.cuda.synchronize()
         return out
     try:
-        classic, stream, ring = run(-1, -1), run(1, -1), run(-1, 1)
+        classic, stream, ring, x3 = run(-1, -1, -1), run(1, -1, -1), run(-1, 1, -1), run(-1, -1, 1)
     finally:
-        monkeypatch.delenv('CFL_DEBUG_PROJ_STREAM')
-        monkeypatch.delenv('CFL_DEBUG_PROJ_RING')
+        for k in ('CFL_DEBUG_PROJ_STREAM', 'CFL_DEBUG_PROJ_RING', 'CFL_DEBUG_PROJ_X3'):
+            monkeypatch.delenv(k)
         H.reload_env()
     assert torch.equal(classic, stream)
     scale = max(1.0, float(classic.abs().max()))
     assert float((classic - ring).abs().max()) <= 4e-6 * scale
+    assert float((classic - x3).abs().max()) <= 4e-6 * scale
     f = (lambda x: O.normalize_v2(x.cpu().numpy().astype(np.float64), scale=1.0 / nv, mean=0.05, norm=1.0, clip_min=0.0,
                                   clip_max=0.9)) if act_norm else (lambda x: x.cpu().numpy().astype(np.float64) / nv)
     sub = slice(0, 1500)
     ref = O.pair_scores(cfg, _to64(p), np.float64(thr), f(xs[sub]), f(xt[sub]))
-    for got in (classic, ring):
-        assert np.abs(got[sub].cpu().numpy() - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max())
+    err = {}
+    for name, got in (('classic', classic), ('ring', ring), ('x3', x3)):
+        err[name] = np.abs(got[sub].cpu().numpy() - ref).max()
+        assert err[name] <= 1e-5 * max(1.0, np.abs(ref).max()), (name, err[name])
+    assert err['x3'] <= max(2.0 * err['classic'], 2e-6 * scale), err
 
 
 @pytest.mark.parametrize('B,D,K,L,reg', [(512, 4096, 3, 20, 0.0), (512, 4096, 4, 10, 1e-3), (256, 2048, 3, 20, 0.0)])

@@ -24,7 +24,7 @@ ap.add_argument('--pairs', default='8192,32768')
 ap.add_argument('--input-size', type=int, default=4096)
 ap.add_argument('--num-components', type=int, default=3)
 ap.add_argument('--latent-size', type=int, default=20)
-ap.add_argument('--variants', default='-1:0:-1,1:-1:-1,0:0:1', help='stream:mix:ring overrides, comma separated')
+ap.add_argument('--variants', default='-1:0:-1:-1,1:-1:-1:-1,0:0:-1:1', help='stream:mix:ring:x3 overrides, comma separated')
 a = ap.parse_args()
 D, K, L = a.input_size, a.num_components, a.latent_size
 
@@ -39,10 +39,11 @@ params = {'outputs/W': xavier(rng, D, L), 'outputs/b': np.zeros(L, np.float32),
           'proto/W': xavier(rng, D, L * K), 'proto/b': np.zeros(L * K, np.float32)}
 
 
-def set_variant(stream, mix, ring):
+def set_variant(stream, mix, ring, x3=-1):
     os.environ['CFL_DEBUG_PROJ_STREAM'] = str(stream)
     os.environ['CFL_DEBUG_PROJ_MIX'] = str(mix)
     os.environ['CFL_DEBUG_PROJ_RING'] = str(ring)
+    os.environ['CFL_DEBUG_PROJ_X3'] = str(x3)
     H.reload_env()
 
 
@@ -58,7 +59,7 @@ def events_us(fn, n):
     return e0.elapsed_time(e1) * 1e3 / n
 
 
-variants = [tuple(int(x) for x in v.split(':')) for v in a.variants.split(',')]
+variants = [(tuple(int(x) for x in v.split(':')) + (-1,))[:4] for v in a.variants.split(',')]
 g = torch.Generator(device='cuda')
 g.manual_seed(1)
 
@@ -70,8 +71,8 @@ for n in [int(x) for x in a.pairs.split(',') if x]:
     sets = [(torch.randn(n, D, generator=g, device='cuda').abs_() * 13, torch.randn(n, D, generator=g, device='cuda').abs_() * 13)
             for _ in range(nsets)]
     ref = None
-    for stream, mix, ring in variants:
-        set_variant(stream, mix, ring)
+    for stream, mix, ring, x3 in variants:
+        set_variant(stream, mix, ring, x3)
         eng._ws = {}
         sc = eng.scores(*sets[0]).clone()
         torch.cuda.synchronize()
@@ -88,7 +89,7 @@ for n in [int(x) for x in a.pairs.split(',') if x]:
         torch.cuda.synchronize()
         H.profile_enable(False)
         prof = H.profile_read()
-        print(json.dumps({'what': 'scores', 'pairs': n, 'stream': stream, 'mix': mix, 'ring': ring, 'max_abs_diff_to_first': maxdiff, 'score_scale': float(ref.abs().max()), 'call_us': round(t, 2),
+        print(json.dumps({'what': 'scores', 'pairs': n, 'stream': stream, 'mix': mix, 'ring': ring, 'x3': x3, 'max_abs_diff_to_first': maxdiff, 'score_scale': float(ref.abs().max()), 'call_us': round(t, 2),
                           'hbm_frac': round(8.0 * D * n / t / 1e3 / 8000.0, 4), 'bit_identical_to_first': same,
                           'kernels_us': {k: round(1e3 * ms / c, 2) for k, (ms, c) in prof.items()}}), flush=True)
     del sets, eng
@@ -98,8 +99,8 @@ for n in [int(x) for x in a.pairs.split(',') if x]:
 for B in [int(x) for x in a.train.split(',') if x]:
     nb = max(2, (600 << 20) // (16 * B * D))
     pool = [tuple(torch.randn(B, D, generator=g, device='cuda').abs_() * 13 for _ in range(4)) for _ in range(nb)]
-    for stream, mix, ring in variants:
-        set_variant(stream, mix, ring)
+    for stream, mix, ring, x3 in variants:
+        set_variant(stream, mix, ring, x3)
         eng = PairEngine(D, L, K, 'pcd', weight_norm=False, has_bias=True, norm=H.make_norm(1 / 58.388599),
                          loss=H.make_loss(), params=params, batch_size=B)
         for i in range(10):
@@ -118,7 +119,7 @@ for B in [int(x) for x in a.train.split(',') if x]:
         H.profile_enable(False)
         prof = H.profile_read()
         sc = eng.read_scalars()
-        print(json.dumps({'what': 'train', 'B': B, 'stream': stream, 'mix': mix, 'ring': ring, 'step_us': round(wall, 2),
+        print(json.dumps({'what': 'train', 'B': B, 'stream': stream, 'mix': mix, 'ring': ring, 'x3': x3, 'step_us': round(wall, 2),
                           'loss_after': sc['total'],
                           'kernels_us': {k: round(1e3 * ms / c, 2) for k, (ms, c) in prof.items()}}), flush=True)
         del eng
