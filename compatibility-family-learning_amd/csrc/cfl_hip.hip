@@ -1055,7 +1055,8 @@ __device__ __forceinline__ void px3_unit(const Px3Args &a, const ProjJob &jb, in
     auto loadA = [&](int q, f32x4 *dst) {
         const int qq = q < a.Kq ? q : a.Kq - 1;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) dst[i] = *(const f32x4 *)(xrow[i] + qq * 32);
+        for (int i = 0; i < 4; ++i)   // nt: x is read once by this launch -- keep it from displacing the W planes in L2
+            dst[i] = __builtin_nontemporal_load((const f32x4 *)(xrow[i] + qq * 32));   // (measured: -6 % scoring, -9 % at B = 8192)
     };
     // prologue: W of steps 0 .. AHEAD-1, x of steps 0 .. 3 (consumption order); own W pieces of step 0 landed, barrier
 #pragma unroll

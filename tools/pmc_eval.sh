@@ -8,7 +8,7 @@ cd /tmp
 i=0
 for c in "$@"; do
   i=$((i+1))
-  rocprofv3 --pmc $c --output-format csv -d $O/pmc$i -o run -- python3 $R/tools/score_loop.py --calls 60 > $O/pmc$i.log 2>&1
+  rocprofv3 --pmc $c --output-format csv -d $O/pmc$i -o run -- python3 $R/tools/score_loop.py --calls 40 --pairs ${PAIRS:-8192} > $O/pmc$i.log 2>&1
   f=$(find $O/pmc$i -name "*counter_collection.csv" | head -1)
   if [ -n "$f" ]; then
     python3 - "$f" <<'PY' > $O/pmc$i.summary.txt
