@@ -1252,6 +1252,15 @@ struct GradFuse {
     // scratch -- 2.4 KB per lane, the weight-gradient launch 2.7x slower)
     int pair_jobs;
     long long pair_delta;   // floats from side 0's slab array to side 1's (same column chunk, same row range)
+    // monomer gate head V[L][kpad] (+ gains) of the SOURCE encoder: finished by the kind-1 / kind-2 reduction blocks
+    long long mono_w, mono_g;   // theta offsets (-1: none)
+    const float *mono_n2, *mono_gcopy, *mono_duc;   // weight-norm: squared norms, gain snapshot, [Rpad][kpad] rows of du * u
+    int mono_L, mono_K, mono_kpad, mono_reg;
+    // regions no side projects through (the unused heads of directed encoders): gradient = L2 term only, Adam applied
+    // as the finalize kernel does; handled by element-wise blocks of kind 3
+    int norph;
+    long long orph_off[8], orph_cnt[8];
+    int orph_reg[8];
     long long thr_off;
     // scalars
     const float *regpart;
@@ -1719,8 +1728,35 @@ __device__ __forceinline__ void grad_red_block(const GradArgs &a, float *lds) { 
                     }
                 }
             }
+        } else if (rr.kind == 3) {
+            // fused tail, directed encoders: 1024 floats of the regions nobody projects through.  The finalize kernel
+            // gives them gradient 0 (+ the L2 term) and applies Adam; so does this
+            const GradFuse &f = a.fuse;
+            long long rel = (long long)idx * 1024 + threadIdx.x * 4;
+            for (int o = 0; o < f.norph; ++o) {
+                if (rel < f.orph_cnt[o]) {
+                    const long long off = f.orph_off[o] + rel;
+                    const f32x4 th = *(const f32x4 *)(f.theta + off);
+                    f32x4 gr = {0.f, 0.f, 0.f, 0.f};
+                    if (f.orph_reg[o]) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) gr[e] = fmaf(f.reg_const, th[e], gr[e]);
+                    }
+                    *(f32x4 *)(f.grad + off) = gr;
+                    if (f.m) {
+                        f32x4 mm = *(const f32x4 *)(f.m + off), vv = *(const f32x4 *)(f.v + off), tn = th;
+                        adam4(tn, mm, vv, gr, f.lr_t, f.b1, f.b2, f.eps);
+                        *(f32x4 *)(f.m + off) = mm;
+                        *(f32x4 *)(f.v + off) = vv;
+                        *(f32x4 *)(f.theta_out + off) = tn;
+                    }
+                    break;
+                }
+                rel -= f.orph_cnt[o];
+            }
         } else {
             // kind 1: gate head, l = idx, dVm[l][k] for all k ; kind 2: plain column sums
+            const bool fin = a.fuse.on && a.fuse.mono_w >= 0;
             for (int kk = 0; kk < rr.K; ++kk) {
                 float acc = 0.f;
                 if (rr.kind == 1) {
@@ -1733,9 +1769,47 @@ __device__ __forceinline__ void grad_red_block(const GradArgs &a, float *lds) { 
                 __syncthreads();
                 if (lane == 0) lds[wave] = acc;
                 __syncthreads();
-                if (threadIdx.x == 0)
-                    a.colsum[rr.out_off + (rr.kind == 1 ? idx * rr.kpad : 0) + kk] =
-                        (lds[0] + lds[1]) + (lds[2] + lds[3]);
+                const float tot = (lds[0] + lds[1]) + (lds[2] + lds[3]);
+                if (threadIdx.x == 0) a.colsum[rr.out_off + (rr.kind == 1 ? idx * rr.kpad : 0) + kk] = tot;
+                if (fin) {
+                    // fused tail: this block owns row l = idx of the gate head (kind 1) / the gate gains (kind 2)
+                    const GradFuse &f = a.fuse;
+                    if (rr.kind == 1) {
+                        float g1 = tot;
+                        if (f.mono_duc) {
+                            // weight-norm correction needs c_k = sum_r du_k u_k: the kind-2 sum, recomputed here in the
+                            // same order (256 strided partial sums, wave sums, four waves) -- no cross-block wait
+                            float c = 0.f;
+                            for (int r = threadIdx.x; r < a.Rpad; r += 256) c += f.mono_duc[(size_t)r * rr.kpad + kk];
+                            c = wave_sum(c);
+                            __syncthreads();
+                            if (lane == 0) lds[8 + wave] = c;
+                            __syncthreads();
+                            const float cw = (lds[8] + lds[9]) + (lds[10] + lds[11]);
+                            const float n2 = f.mono_n2[kk], n = sqrtf(n2);
+                            if (threadIdx.x == 0 && n2 > 0.f)
+                                g1 = fmaf(-(f.mono_gcopy[kk] * cw / (n2 * n)), f.theta[f.mono_w + (long long)idx * rr.kpad + kk], g1);
+                        }
+                        if (threadIdx.x == 0) fuse_apply1(f, f.mono_w + (long long)idx * rr.kpad + kk, g1, f.mono_reg != 0);
+                    } else if (threadIdx.x == 0) {
+                        const float n2 = f.mono_n2[kk];
+                        fuse_apply1(f, f.mono_g + kk, n2 > 0.f ? tot / sqrtf(n2) : 0.f, false);
+                    }
+                }
+            }
+            if (fin && wave == 0) {
+                // the padding of the owned entries: columns K .. kpad of the row (kind 1), and -- last row / kind 2 -- the
+                // rest of the region up to its 64-float boundary: zero gradient (+ L2 of a zero weight)
+                const GradFuse &f = a.fuse;
+                if (rr.kind == 1) {
+                    for (int kk = rr.K + lane; kk < rr.kpad; kk += 64) fuse_apply1(f, f.mono_w + (long long)idx * rr.kpad + kk, 0.f, f.mono_reg != 0);
+                    if (idx == f.mono_L - 1) {
+                        const long long used = (long long)f.mono_L * rr.kpad, end = (used + 63) / 64 * 64;
+                        for (long long o = used + lane; o < end; o += 64) fuse_apply1(f, f.mono_w + o, 0.f, f.mono_reg != 0);
+                    }
+                } else {
+                    for (int kk = rr.K + lane; kk < ((rr.kpad + 63) & ~63); kk += 64) fuse_apply1(f, f.mono_g + kk, 0.f, false);
+                }
             }
         }
     }
@@ -3067,7 +3141,7 @@ __device__ __forceinline__ f32x4 fin_region_grad(const FinArgs &a, const Region 
                     if (a.weight_norm) {
                         const float cw = a.colsum[a.cs_duc + kk];
                         const float n2 = rg.n2[kk], n = sqrtf(n2);
-                        if (n2 > 0.f) g1 -= rg.g[kk] * cw / (n2 * n) * th[e];
+                        if (n2 > 0.f) g1 = fmaf(-(rg.g[kk] * cw / (n2 * n)), th[e], g1);   // (explicit: the fused tail performs the same operations)
                     }
                     gr[e] = g1;
                 }
@@ -3325,8 +3399,7 @@ static int make_plan(const CflShape *s, int64_t rows, int groups, bool train, Pl
     // fused tail: every gradient entry must be complete inside the P workgroups of one (d tile, column job) -- pcd
     // (each side feeds its own head), one encoder; weight-normalised heads get their column coupling c_j from the
     // launch's own reduction blocks.  CFL_DEBUG_NOFUSE=1: the escape hatch (separate finalize launch)
-    pl->fused = train && (s->dist_type == CFL_DIST_PCD || s->dist_type == CFL_DIST_SIAMESE) && !s->directed &&
-                debug_env("CFL_DEBUG_NOFUSE") <= 0;
+    pl->fused = train && debug_env("CFL_DEBUG_NOFUSE") <= 0;
     pl->P = P;
     pl->Rpad = (int)round_up(pl->R, 256 * P);  // grad: 64-row chunks x 4 waves x P ranges
     // proj d split: one 128-d chunk per wave when that yields enough workgroups
@@ -3753,7 +3826,7 @@ static int run_pairs(const CflShape *s, const CflNorm *norm, const CflLossCfg *l
         ma.thr_copy = ws + pl.thr_copy;
         ma.regpart = ws + pl.regpart;
         ma.theta = theta;
-        if (pl.fused && (pl.P > 1 || s->weight_norm || s->dist_type == CFL_DIST_SIAMESE)) {   // (siamese: 2P contributors per tile)
+        if (pl.fused) {   // (P > 1, weight-norm c_j hand-off, siamese pairing: the flags are cheap to clear always)
             ma.zero_i = (int *)(ws + pl.handoff);
             ma.nzero = 2 * pl.nhandoff + 1;
         }
@@ -3910,7 +3983,7 @@ static int run_pairs(const CflShape *s, const CflNorm *norm, const CflLossCfg *l
         };
         // siamese + fused tail: both sides feed ONE head, so side 1's ranges are dual (they also sum side 0's tile of
         // the same columns) and side 0 gets none
-        const bool paired = pl.fused && s->dist_type == CFL_DIST_SIAMESE;
+        const bool paired = pl.fused && s->dist_type == CFL_DIST_SIAMESE && !s->directed;
         int red_dy[2] = {-1, -1}, red_cw[2] = {-1, -1};   // range index of a side's dY / dy * xv column sums
         red(0, ws + pl.rowqf, nullptr, 1, pl.cs_rowq);
         for (int sd = paired ? 1 : 0; sd < 2; ++sd) {
@@ -3985,6 +4058,54 @@ static int run_pairs(const CflShape *s, const CflNorm *norm, const CflLossCfg *l
                 }
             }
             f.thr_off = pl.lay.thr;
+            // monomer: the gate head of the source encoder is finished by its own reduction blocks
+            f.mono_w = f.mono_g = -1;
+            if (pl.mono) {
+                const CflHead &mh = pl.lay.enc[0].mono;
+                f.mono_w = mh.w; f.mono_g = mh.g;
+                f.mono_L = s->L; f.mono_K = s->K; f.mono_kpad = pl.kpad; f.mono_reg = loss->reg_const > 0.f;
+                if (s->weight_norm) {
+                    f.mono_n2 = n2base + n2_off[0][2];
+                    f.mono_gcopy = gbase + n2_off[0][2];
+                    f.mono_duc = ws + pl.mono_duc;
+                }
+            }
+            // directed encoders: the heads no side projects through (and the target encoder's gate head)
+            f.norph = 0;
+            long long orph_total = 0;
+            if (s->directed) {
+                auto orphan = [&](long long off, long long cnt, int reg) {
+                    if (off < 0 || cnt <= 0 || f.norph >= 8) return;
+                    f.orph_off[f.norph] = off; f.orph_cnt[f.norph] = round_up(cnt, 64); f.orph_reg[f.norph] = reg;
+                    orph_total += round_up(cnt, 64);
+                    ++f.norph;
+                };
+                const int regon2 = loss->reg_const > 0.f;
+                for (int e = 0; e < 2; ++e) {
+                    const CflHead *hh[2] = {&pl.lay.enc[e].outputs, &pl.lay.enc[e].proto};
+                    for (int k = 0; k < 2; ++k) {
+                        const CflHead *h = hh[k];
+                        if (h->w < 0) continue;
+                        bool used = false;
+                        for (int sd = 0; sd < 2; ++sd) used |= side[sd].enc == e && side[sd].which == k;
+                        if (used) continue;
+                        // W, bias and gain arrays are contiguous in theta (cfl_layout): one region each
+                        orphan(h->w, (long long)h->npad * s->D, regon2);
+                        orphan(h->b, h->b >= 0 ? round_up(h->npad, 64) : 0, regon2);
+                        orphan(h->g, h->g >= 0 ? round_up(h->npad, 64) : 0, 0);
+                    }
+                }
+                if (pl.mono) {
+                    const CflHead &m1 = pl.lay.enc[1].mono;
+                    orphan(m1.w, round_up((long long)s->L * m1.npad, 64), regon2);
+                    orphan(m1.g, m1.g >= 0 ? round_up(m1.npad, 64) : 0, 0);
+                }
+                if (orph_total > 0) {
+                    RedRange &ro = red(3, nullptr, nullptr, (int)((orph_total + 1023) / 1024), 0);
+                    (void)ro;
+                    ga.nred = nr; ga.red_total = tot;
+                }
+            }
             f.regpart = ws + pl.regpart; f.nregblocks = nreg_blocks;
             f.B = (int)rows; f.use_threshold = loss->use_threshold;
             f.pos_weight = loss->pos_weight; f.caffe_margin = loss->caffe_margin; f.lambda_m = loss->lambda_m;

@@ -641,3 +641,51 @@ def test_fused_gradient_tail_siamese_equals_finalize_kernel(B, D, L, wn, lkw, P,
         for x, y in zip(a, b):
             assert torch.equal(x, y)
     assert np.isfinite(res['fused'][-1][1].cpu().numpy()).all()
+
+
+@pytest.mark.parametrize('dist,directed,wn,B,D,L,K,act,lkw', [
+    ('monomer', False, True, 128, 1024, 64, 3, None, dict(pos_weight=0.0625, reg_const=1e-3)),
+    ('monomer', False, False, 64, 512, 12, 2, 'tanh', dict(reg_const=1e-3)),
+    ('monomer', True, True, 96, 512, 20, 4, None, dict(lambda_m=0.5, reg_const=1e-3)),
+    ('pcd', True, True, 128, 1024, 16, 2, None, dict(lambda_m=0.5, reg_const=1e-3)),
+    ('pcd', True, False, 512, 576, 20, 3, None, dict()),
+    ('siamese', True, True, 64, 512, 32, 1, 'sigmoid', dict(reg_const=1e-3)),
+])
+def test_fused_gradient_tail_monomer_and_directed_equal_finalize_kernel(dist, directed, wn, B, D, L, K, act, lkw, monkeypatch):
+    """Every model runs the step in three launches: monomer (the gate head V[L][K] and its gains are finished by the
+    reduction blocks that own their rows / column sums, the weight-norm correction sum recomputed in place) and directed
+    encoders (the heads no side projects through get their L2-only gradient and Adam from element-wise blocks of the
+    same launch).  Bit-identical to the four-launch form with the finalize kernel over 200 steps."""
+    from cfl.engine import PairEngine
+    rng = np.random.RandomState(8)
+    cfg = O.EncoderCfg(D=D, L=L, K=K, dist_type=dist, style='cfl' if wn else 'dist', act_type=act)
+    params = _mk(cfg, rng)
+    params_dst = _mk(cfg, rng) if directed else None
+    pool = [[torch.from_numpy(np.abs(rng.randn(B, D)).astype(np.float32) * 3).cuda() for _ in range(4)] for _ in range(3)]
+    res = {}
+    for mode in ('fused', 'finalize'):
+        monkeypatch.setenv('CFL_DEBUG_NOFUSE', '0' if mode == 'fused' else '1')
+        H.reload_env()
+        eng = PairEngine(D, L, K, dist, weight_norm=cfg.weight_norm, has_bias=cfg.has_bias, act_type=act, directed=directed,
+                         norm=H.make_norm(1 / 8.0), loss=H.make_loss(**lkw), params=params, params_dst=params_dst,
+                         thr=0.7, batch_size=B)
+        H.profile_enable(True)
+        eng.step(pool[0])
+        torch.cuda.synchronize()
+        H.profile_enable(False)
+        kinds = set(H.profile_read())
+        assert ('finalize' in kinds) == (mode == 'finalize'), kinds
+        snaps = []
+        for it in range(200):
+            eng.step(pool[it % 3])
+            if it in (0, 1, 7, 199):
+                snaps.append([t.clone() for t in (eng.theta, eng.m, eng.v, eng.grad, eng.scalars)])
+        eng.fwd_bwd(pool[1])
+        snaps.append([eng.grad.clone(), eng.scalars.clone(), eng.theta.clone()])
+        res[mode] = snaps
+    monkeypatch.undo()
+    H.reload_env()
+    for a, b in zip(res['fused'], res['finalize']):
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
+    assert np.isfinite(res['fused'][-1][1].cpu().numpy()).all()
