@@ -2,15 +2,17 @@
 // training / scoring hot path.  See include/cfl_hip.h for the boundary and
 // DESIGN.md for the data layout and the roofline of every kernel.
 //
-// One training step = 4 launches on the caller's stream (5 with weight-norm):
-//   [colnorm]  (weight-norm only)  n2[c] = sum_d V[d][c]^2, gain snapshot
-//   proj       skinny fp32-MFMA projection partials  Y_s = X[:, slice_s] . W[slice_s, :]
+// One training step = 3 launches on the caller's stream, for every model:
+//   proj       projection partials  Y_s = X[:, slice_s] . W[slice_s, :]  (fp32 MFMA, k-ordered: chunk-at-a-time or
+//              streaming form; bf16x3 with LDS-shared W planes from 8192 rows per side, after a small plane-split
+//              launch; weight-norm: the column norms ride in the launch as an extra slice)
 //   mid        slice-sum + bias/scale/activation, distance, loss, dL/dY
 //              (+ extra blocks: L2-regulariser partial sums)
-//   grad       skinny fp32-MFMA weight-gradient partials  dW_p = X[rows_p, :]^T . dY[rows_p, :]
-//              (+ z-slice 0: row reductions for bias / gain / loss scalars)
-//   finalize   partial slabs -> flat gradient (+bias/gain/threshold grads, +reg), scalars,
-//              optionally the fused TF-Adam apply
+//   grad       weight-gradient partials  dW_p = X[rows_p, :]^T . dY[rows_p, :]  (bf16x3; fp32 MFMA with CFL_EXACT_FP32=1),
+//              row reductions for bias / gain / gate / loss scalars in z-slice 0, and the FUSED TAIL: partial tiles are
+//              handed over inside the launch, summed in a fixed order, turned into the flat gradient and TF-Adam is
+//              applied (GradFuse)
+//   [finalize] only with CFL_DEBUG_NOFUSE=1: partial slabs -> flat gradient, scalars, optional fused TF-Adam
 // cfl_adam_tf is a separate entry point so that a data-parallel caller can
 // all-reduce the flat gradient between cfl_pair_step_fwd_bwd and the update.
 //
