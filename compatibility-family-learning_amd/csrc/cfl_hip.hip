@@ -1905,7 +1905,9 @@ __device__ __forceinline__ void grad_body_x3(const GradJob &jb, const GradArgs &
                                   : row_ptr(rs, p0 + 32 * r2 + 8 * kq + jj, a.B, a.R, a.D);
 #pragma unroll
             for (int jj = 0; jj < 8; ++jj)
-                xr[r2][jj] = *(const f32x4 *)(xrow[jj] + dbase + 4 * i16);
+                // non-temporal: the weight gradient is the step's LAST reader of x (measured: -0.3 us at B = 512, -2.3 us at
+                // B = 2048, -12 % at B = 8192; the projection keeps the default policy so that this re-read hits the Infinity Cache)
+                xr[r2][jj] = __builtin_nontemporal_load((const f32x4 *)(xrow[jj] + dbase + 4 * i16));
             __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
