@@ -3932,11 +3932,13 @@ static int run_pairs(const CflShape *s, const CflNorm *norm, const CflLossCfg *l
         const bool generic_only = pl.mid_generic != 0;
         // one wave per row: pcd (any K <= 64) and siamese with up to 256 padded columns per side
         const int wide = side[0].head->npad > side[1].head->npad ? side[0].head->npad : side[1].head->npad;
-        // scoring calls (no dL/dY to write) of the small-K shapes run the 4-rows-per-wave register form: measured 7 us
-        // less than the wave-per-row form on a 32768-pair call (18 vs 25 us); training keeps wave-per-row (6.4 vs 7+ us)
+        // many rows of the small-K shapes run the 4-rows-per-wave register form instead of wave-per-row.  Measured:
+        // scoring 32768 pairs 13 vs 24 us; training 32768 rows (B = 8192) 14.4 vs 20.4 us -- but 9.7 vs 11.2 us the
+        // other way at B = 512 ... 2048 (the wave-per-row form is the shorter latency chain, the register form the
+        // smaller instruction count)
         const bool small_reg = (s->K <= 8 && pl.Lq <= 2) || (s->K <= 4 && pl.Lq <= 4);
         const bool row_ok = (s->dist_type == CFL_DIST_PCD || s->dist_type == CFL_DIST_SIAMESE) && wide <= 256 &&
-                            s->K <= 64 && !pl.mid_norow && (train || !small_reg || pl.R < 4096);
+                            s->K <= 64 && !pl.mid_norow && !(small_reg && pl.R >= (train ? 16384 : 4096));
         const dim3 rgrid(ma.nrb + nreg_blocks);
         if (!generic_only && row_ok && wide <= 64)
             hipLaunchKernelGGL((cfl_mid_row_kernel<1>), rgrid, dim3(256), 4 * 6 * 64 * sizeof(float), st, ma);
