@@ -118,6 +118,10 @@ STEP_CASES = [
     ('cfl', 'pcd', 2048, 20, 5, None, 1024, 1.0, dict(pos_weight=0.25), False),
     ('cfl', 'siamese', 1024, 256, 1, None, 512, 31.9098,
      dict(use_threshold=False, caffe_margin=100.0, pos_weight=0.0625), False),
+    # large batches: 8192 rows per side take the bf16x3 forward with shared W planes, 16384 also the register row math
+    ('dist', 'pcd', 512, 20, 3, None, 4096, 58.388599, dict(), False),
+    ('dist', 'pcd', 256, 10, 4, None, 8192, 58.388599, dict(reg_const=1e-3), False),
+    ('cfl', 'pcd', 384, 20, 3, None, 4096, 31.9098, dict(pos_weight=0.25), False),
     # edge shapes: single row, odd batch, minimum D, many prototypes (40 column tiles)
     ('dist', 'pcd', 64, 3, 2, None, 1, 1.0, dict(), False),
     ('cfl', 'monomer', 64, 5, 3, None, 3, 1.0, dict(reg_const=1e-3), False),
