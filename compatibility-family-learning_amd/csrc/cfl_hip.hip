@@ -1966,6 +1966,190 @@ __device__ __forceinline__ void grad_body_x3(const GradJob &jb, const GradArgs &
     }
 }
 
+// ---------------------------------------------------------------------------
+// grad, bf16x3, HALF tiles without a row split (round 3): a workgroup owns a 32-d tile and ALL rows (P = 1), so a
+// gradient tile is complete inside ONE workgroup and the fused tail needs no hand-off at all (publish -> drain ->
+// counter -> poll -> sc1 loads cost ~3 us of the 64-d / P = 2 launch at the headline shape, measured with CFL_DEBUG_P).
+// Same number of workgroups (D/32 x jobs), same bytes of x and the same MFMA work per wave; lane i16 holds d =
+// dbase + 2 i16 + t (t = 0, 1: two M blocks instead of four) and fetches 8 bytes per row, 4 rows x 128 bytes per
+// instruction; the dY fragments are read by twice as many workgroups (L2 hits).
+//   acc[t][nt][e]: M row 4 kq + e <-> d = dbase + 8 kq + 2 e + t ; N col = lane & 15
+//   Wf block (nt, g = dbase/16 + (kq >> 1)), float4 h = e >> 1 at ((2 (kq & 1) + h) * 16 + c16) * 4: elements
+//   (e & 1, t) = (0,0) (0,1) (1,0) (1,1)
+// ---------------------------------------------------------------------------
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+template <int NT>
+__device__ __forceinline__ void grad_body_x3_half(const GradJob &jb, const GradArgs &a, f32x4 *lds) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int i16 = lane & 15, kq = lane >> 4;
+    const int dbase = grad_dtile(a.tps) * 32;
+    const int RG = a.Rpad >> 4, G = a.D >> 4;
+    const int rows_w = a.Rpad >> 2;   // multiple of 64
+    const int rbeg = wave * rows_w, rend = rbeg + rows_w;
+    const int r64 = (a.R + 63) & ~63;
+    const int rstop = rend < r64 ? rend : r64;
+
+    f32x4 acc[2][NT];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[t][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const float *dyl = jb.dyf + ((size_t)(kq >> 1) * 256 + (2 * (kq & 1) * 16 + i16) * 4);
+    const RowSrc rs = jb.side ? a.rows[1] : a.rows[0];
+    const long long *lrow = (const long long *)lds;   // row addresses of the whole batch, staged once (grad_body_x3)
+    {
+        long long *w = (long long *)lds;
+        for (int r = threadIdx.x; r < a.Rpad; r += 256) w[r] = row_ptr(rs, r, a.B, a.R, a.D) - rs.x0;
+        __syncthreads();
+    }
+    for (int p0 = rbeg; p0 < rstop; p0 += 64) {
+        f32x4 dyr[2][NT][2];
+        f32x2 xr[2][8];
+#pragma unroll
+        for (int r2 = 0; r2 < 2; ++r2)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const float *q = dyl + ((size_t)nt * RG + (p0 >> 4) + 2 * r2) * 256;
+                dyr[r2][nt][0] = *(const f32x4 *)q;
+                dyr[r2][nt][1] = *(const f32x4 *)(q + 64);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r2 = 0; r2 < 2; ++r2) {
+            const float *xrow[8];
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) xrow[jj] = rs.x0 + lrow[p0 + 32 * r2 + 8 * kq + jj];
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj)   // non-temporal: last reader of x in the step
+                xr[r2][jj] = __builtin_nontemporal_load((const f32x2 *)(xrow[jj] + dbase + 2 * i16));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int r2 = 0; r2 < 2; ++r2) {
+            bf16x8 bf[NT][3];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                float v[8];
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) v[jj] = dyr[r2][nt][jj >> 2][jj & 3];
+                split_frag(v, bf[nt]);
+            }
+            if (a.norm.elementwise) {
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj)
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+                        xr[r2][jj][t] = dbase + 2 * i16 + t < a.norm.valid
+                                            ? fminf(fmaxf(fmaf(xr[r2][jj][t], a.norm.mul, a.norm.add), a.norm.lo), a.norm.hi) : 0.f;
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                float v[8];
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) v[jj] = xr[r2][jj][t];
+                bf16x8 af[3];
+                split_frag(v, af);
+#define CFL_X3(LA, LB)                                                                               \
+    _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) acc[t][nt] =                                   \
+        __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[LA], bf[nt][LB], acc[t][nt], 0, 0, 0);
+                CFL_X3(1, 1) CFL_X3(2, 0) CFL_X3(0, 2) CFL_X3(1, 0) CFL_X3(0, 1) CFL_X3(0, 0)
+#undef CFL_X3
+            }
+        }
+    }
+    __syncthreads();   // every wave is done with the staged addresses
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) lds[((wave * NT + nt) * 2 + t) * 64 + lane] = acc[t][nt];
+    __syncthreads();
+    const int ntw = wave < NT ? wave : 0;
+    f32x4 sum[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        sum[t] = lds[((0 * NT + ntw) * 2 + t) * 64 + lane];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) sum[t] += lds[((w * NT + ntw) * 2 + t) * 64 + lane];
+    }
+    const size_t tile_off = ((size_t)ntw * G + (dbase >> 4) + (kq >> 1)) * 256 + (2 * (kq & 1) * 16 + i16) * 4;
+    const int job = (int)blockIdx.z - 1;
+    if (!a.fuse.on) {
+        if (wave < NT) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+                *(f32x4 *)(jb.wpart + tile_off + h * 64) = (f32x4){sum[0][2 * h], sum[1][2 * h], sum[0][2 * h + 1], sum[1][2 * h + 1]};
+        }
+        return;
+    }
+    // fused tail without a hand-off: the tile is complete here
+    const GradFuse &f = a.fuse;
+    const long long base = f.w_off[job] + (long long)tile_off;
+    f32x4 th[2], mm[2], vv[2];
+    if (wave < NT) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            th[h] = *(const f32x4 *)(f.theta + base + h * 64);
+            if (f.m) {
+                mm[h] = *(const f32x4 *)(f.m + base + h * 64);
+                vv[h] = *(const f32x4 *)(f.v + base + h * 64);
+            }
+        }
+    }
+    const int wcol = ntw * 16 + i16;
+    float wg = 1.f, wn2 = 1.f;
+    bool lost = false;
+    if (f.wn) {
+        wg = f.wn_g[job][wcol]; wn2 = f.wn_n2[job][wcol];
+        if (threadIdx.x == 0) {   // the c_j column sums of this launch's reduction blocks (dispatched first, short)
+            int spins = 0, ok = 1;
+            while (__hip_atomic_load(f.red_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < f.red_expect) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > CFL_HANDOFF_SPIN_LIMIT) { ok = 0; break; }
+            }
+            ((int *)lds)[0] = ok;
+        }
+        __syncthreads();
+        lost = ((int *)lds)[0] == 0;
+    }
+    if (wave < NT) {
+        float s1 = f.in_mul, s2 = 0.f;
+        if (f.wn) {
+            const float cw = __hip_atomic_load(f.wn_cw[job] + wcol, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const bool colok = wcol < f.wn_n[job];
+            const float n = sqrtf(wn2);
+            s1 = (colok && wn2 > 0.f) ? f.in_mul * wg / n : 0.f;
+            s2 = (colok && wn2 > 0.f) ? wg * cw / (wn2 * n) : 0.f;
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            f32x4 g = {sum[0][2 * h], sum[1][2 * h], sum[0][2 * h + 1], sum[1][2 * h + 1]};
+            if (lost) g = (f32x4){NAN, NAN, NAN, NAN};
+            f32x4 gr = g * s1;
+            if (f.wn) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) gr[i] = fmaf(-s2, th[h][i], gr[i]);
+            }
+            fuse_apply(f, base + h * 64, gr, th[h], mm[h], vv[h]);
+        }
+    }
+}
+
+extern "C" __global__ __launch_bounds__(256) void cfl_grad_x3_half_kernel(GradArgs a_) {   // P == 1, Rpad <= 8192
+    CFL_KERNARG_IN_PLACE(GradArgs, a, a_);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    f32x4 *lds = (f32x4 *)smem;
+    if (blockIdx.z == 0) { grad_red_block(a, (float *)smem); return; }
+    const GradJob &jb = a.job[blockIdx.z - 1];
+    switch (jb.nt) {
+        case 1: grad_body_x3_half<1>(jb, a, lds); break;
+        case 2: grad_body_x3_half<2>(jb, a, lds); break;
+        case 3: grad_body_x3_half<3>(jb, a, lds); break;
+        default: grad_body_x3_half<4>(jb, a, lds); break;
+    }
+}
+
 // Two kernels rather than one with both bodies: eight inlined instantiations make the compiler keep `a` on the
 // stack (1.5 KiB of scratch per lane, occupancy 1).
 template <bool STAGED>
@@ -3337,6 +3521,7 @@ struct Plan {
     size_t fold_flags;
     bool proj_ring;   // loader / consumer ring form (cfl_proj_ring_kernel); S is then the ring's d split
     int ring_tiles, ring_units, ring_nwg;
+    bool grad_half;   // 32-d tiles, no row split (cfl_grad_x3_half_kernel)
     bool fused;       // gradient + Adam finished inside the weight-gradient launch (GradFuse)
     size_t handoff;   // workspace offset of the hand-off tickets + flags (ints), nhandoff of each
     int nhandoff;
@@ -3394,6 +3579,18 @@ static int make_plan(const CflShape *s, int64_t rows, int groups, bool train, Pl
         if (P > 8) P = 8;
         while (P > 1 && pl->R / P < 64) P /= 2;
         if (debug_env("CFL_DEBUG_P") > 0) P = debug_env("CFL_DEBUG_P");
+    }
+    // half tiles without a row split (cfl_grad_x3_half_kernel): when 32-d tiles alone fill the chip and the whole batch
+    // is short enough for one workgroup per tile, a gradient tile is complete inside its workgroup and the fused tail
+    // needs no hand-off.  Not for the siamese pairing (two sides per tile) and not with the fp32-MFMA contraction.
+    pl->grad_half = false;
+    if (train && debug_env("CFL_EXACT_FP32") <= 0 && debug_env("CFL_DEBUG_GRAD_HALF") >= 0 && debug_env("CFL_DEBUG_P") <= 0) {
+        const int ht = s->D / 32;
+        const bool paired = s->dist_type == CFL_DIST_SIAMESE && !s->directed;
+        if (!paired && ht * njobs >= 192 && ht * njobs <= 640 && pl->R <= 2048) {
+            pl->grad_half = true;
+            P = 1;
+        }
     }
     // matrix-core arithmetic of the weight-gradient contraction: bf16x3 (fp32-equivalent, default) or,
     // with CFL_EXACT_FP32=1 in the environment, the k-ordered fp32 FMA chains of v_mfma_f32_16x16x4_f32
@@ -4117,10 +4314,12 @@ static int run_pairs(const CflShape *s, const CflNorm *norm, const CflLossCfg *l
             f.pos_weight = loss->pos_weight; f.caffe_margin = loss->caffe_margin; f.lambda_m = loss->lambda_m;
             f.scalars = scalars; f.thr_copy = ws + pl.thr_copy;
         }
-        ga.tps = pl.xcd ? (s->D / 64) / pl.S : 0;
+        ga.tps = pl.xcd ? (s->D / (pl.grad_half ? 32 : 64)) / pl.S : 0;
         dim3 grid(s->D / 64, pl.P, nj + 1);
         ProfScope ps(st, CFL_K_GRAD);
-        if (pl.x3 && pl.Rpad / pl.P <= 8192)
+        if (pl.grad_half)
+            hipLaunchKernelGGL(cfl_grad_x3_half_kernel, dim3(s->D / 32, 1, nj + 1), dim3(256), 4 * 4 * 4 * 64 * sizeof(f32x4), st, ga);
+        else if (pl.x3 && pl.Rpad / pl.P <= 8192)
             hipLaunchKernelGGL(cfl_grad_x3_kernel, grid, dim3(256), 4 * 4 * 4 * 64 * sizeof(f32x4), st, ga);
         else if (pl.x3)
             hipLaunchKernelGGL(cfl_grad_x3_longrange_kernel, grid, dim3(256), 4 * 4 * 4 * 64 * sizeof(f32x4), st, ga);
