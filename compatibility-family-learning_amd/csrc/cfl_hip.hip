@@ -1629,6 +1629,33 @@ __device__ __forceinline__ void fuse_apply1(const GradFuse &f, long long off, fl
     }
 }
 
+// In-launch producers (the row-math blocks of cfl_midgrad_half_kernel): flag words that carry the launch's generation.
+struct MgWait { const unsigned *flags; int n; unsigned gen; int early_x; };
+
+// one wave polls all flags (sc1 loads, bounded), ONE agent-scope acquire, drain, workgroup barrier: plain loads of
+// what the producers wrote through are valid afterwards (MI355X_MICROARCH.md, Valid forms: consumer)
+__device__ __forceinline__ bool mg_wait_all(const MgWait &w, int *lds_i) {
+    if ((threadIdx.x >> 6) == 0) {
+        const int lane = threadIdx.x & 63;
+        int spins = 0, ok = 1;
+        for (;;) {
+            bool all = true;
+            for (int i = lane; i < w.n; i += 64)
+                all = all && __hip_atomic_load(w.flags + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == w.gen;
+            if (__builtin_amdgcn_ballot_w64(!all) == 0) break;
+            if (++spins > CFL_HANDOFF_SPIN_LIMIT) { ok = 0; break; }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) lds_i[0] = ok;
+    }
+    __syncthreads();
+    const bool ok = lds_i[0] != 0;
+    __syncthreads();
+    return ok;
+}
+
 // column sums of tile `idx` of a fragment-major buffer (the whole workgroup): lane (kq, c16) adds its 4 rows; the
 // result is valid in lanes 0 .. 15 of wave 0
 __device__ __forceinline__ float tile_colsum(const float *buf, int idx, int RG, int lane, int wave, float *lds) {
@@ -1653,11 +1680,14 @@ __device__ __forceinline__ float tile_colsum(const float *buf, int idx, int RG, 
     return cs;
 }
 
-__device__ __forceinline__ void grad_red_block(const GradArgs &a, float *lds) {   // (forceinline: an out-of-line call takes the address of the argument block, which then lives in scratch)
+__device__ __forceinline__ void grad_red_block(const GradArgs &a, float *lds, const MgWait *mg = nullptr, int first = -1,
+                                               int nblocks = 0) {   // (forceinline: an out-of-line call takes the address of the argument block, which then lives in scratch)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int nblk = gridDim.x * gridDim.y;
+    // mg: the row math runs in this launch; its outputs are complete once every producer's flag carries the generation
+    const bool mg_ok = mg ? mg_wait_all(*mg, (int *)lds + 512) : true;
+    const int nblk = first >= 0 ? nblocks : gridDim.x * gridDim.y;
     const int RG = a.Rpad >> 4;
-    for (int job = blockIdx.y * gridDim.x + blockIdx.x; job < a.red_total; job += nblk) {
+    for (int job = first >= 0 ? first : blockIdx.y * gridDim.x + blockIdx.x; job < a.red_total; job += nblk) {
         int k = 0, idx = job;
         while (k < a.nred - 1 && idx >= a.red[k].count) { idx -= a.red[k].count; ++k; }
         const RedRange &rr = a.red[k];
@@ -1704,6 +1734,7 @@ __device__ __forceinline__ void grad_red_block(const GradArgs &a, float *lds) { 
                         if (lane == 0)
                             write_scalars(f.scalars, lds + 64, 0.5f * f.reg_const * rs, f.B, f.use_threshold,
                                           f.pos_weight, f.caffe_margin, f.lambda_m, f.thr_copy[0]);
+                        if (lane == 0 && !mg_ok) f.scalars[CFL_S_TOTAL] = NAN;   // lost in-launch hand-off: loud, not silent
                     }
                 } else if (f.red_b[k] >= 0 && wave == 0) {
                     const int c = idx * 16 + lane;
@@ -1980,11 +2011,12 @@ __device__ __forceinline__ void grad_body_x3(const GradJob &jb, const GradArgs &
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 template <int NT>
-__device__ __forceinline__ void grad_body_x3_half(const GradJob &jb, const GradArgs &a, f32x4 *lds) {
+__device__ __forceinline__ void grad_body_x3_half(const GradJob &jb, const GradArgs &a, f32x4 *lds, int job, int dtile,
+                                                  const MgWait *mg = nullptr) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i16 = lane & 15, kq = lane >> 4;
-    const int dbase = grad_dtile(a.tps) * 32;
+    const int dbase = dtile * 32;
     const int RG = a.Rpad >> 4, G = a.D >> 4;
     const int rows_w = a.Rpad >> 2;   // multiple of 64
     const int rbeg = wave * rows_w, rend = rbeg + rows_w;
@@ -2004,6 +2036,27 @@ __device__ __forceinline__ void grad_body_x3_half(const GradJob &jb, const GradA
         for (int r = threadIdx.x; r < a.Rpad; r += 256) w[r] = row_ptr(rs, r, a.B, a.R, a.D) - rs.x0;
         __syncthreads();
     }
+    bool mg_lost = false;
+    f32x2 xfirst[2][8];
+    auto loadx = [&](int p0, f32x2 (*dst)[8]) {
+#pragma unroll
+        for (int r2 = 0; r2 < 2; ++r2) {
+            const float *xrow[8];
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) xrow[jj] = rs.x0 + lrow[p0 + 32 * r2 + 8 * kq + jj];
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj)   // non-temporal: last reader of x in the step
+                dst[r2][jj] = __builtin_nontemporal_load((const f32x2 *)(xrow[jj] + dbase + 2 * i16));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    if (mg) {
+        // the row math runs in this launch (cfl_midgrad_half_kernel): x does not depend on it -- the first chunk's x
+        // is requested BEFORE waiting for dL/dY, so the wait overlaps the arrival of x
+        if (mg->early_x && rbeg < rstop) loadx(rbeg, xfirst);
+        mg_lost = !mg_wait_all(*mg, (int *)lds + 8192);   // (behind the staged addresses: <= 4096 rows x 8 bytes)
+        if (!mg->early_x && rbeg < rstop) loadx(rbeg, xfirst);
+    }
     for (int p0 = rbeg; p0 < rstop; p0 += 64) {
         f32x4 dyr[2][NT][2];
         f32x2 xr[2][8];
@@ -2016,15 +2069,13 @@ __device__ __forceinline__ void grad_body_x3_half(const GradJob &jb, const GradA
                 dyr[r2][nt][1] = *(const f32x4 *)(q + 64);
             }
         __builtin_amdgcn_sched_barrier(0);
+        if (mg && p0 == rbeg) {
 #pragma unroll
-        for (int r2 = 0; r2 < 2; ++r2) {
-            const float *xrow[8];
+            for (int r2 = 0; r2 < 2; ++r2)
 #pragma unroll
-            for (int jj = 0; jj < 8; ++jj) xrow[jj] = rs.x0 + lrow[p0 + 32 * r2 + 8 * kq + jj];
-#pragma unroll
-            for (int jj = 0; jj < 8; ++jj)   // non-temporal: last reader of x in the step
-                xr[r2][jj] = __builtin_nontemporal_load((const f32x2 *)(xrow[jj] + dbase + 2 * i16));
-            __builtin_amdgcn_sched_barrier(0);
+                for (int jj = 0; jj < 8; ++jj) xr[r2][jj] = xfirst[r2][jj];
+        } else {
+            loadx(p0, xr);
         }
 #pragma unroll
         for (int r2 = 0; r2 < 2; ++r2) {
@@ -2074,7 +2125,6 @@ __device__ __forceinline__ void grad_body_x3_half(const GradJob &jb, const GradA
         for (int w = 1; w < 4; ++w) sum[t] += lds[((w * NT + ntw) * 2 + t) * 64 + lane];
     }
     const size_t tile_off = ((size_t)ntw * G + (dbase >> 4) + (kq >> 1)) * 256 + (2 * (kq & 1) * 16 + i16) * 4;
-    const int job = (int)blockIdx.z - 1;
     if (!a.fuse.on) {
         if (wave < NT) {
 #pragma unroll
@@ -2099,7 +2149,7 @@ __device__ __forceinline__ void grad_body_x3_half(const GradJob &jb, const GradA
     }
     const int wcol = ntw * 16 + i16;
     float wg = 1.f, wn2 = 1.f;
-    bool lost = false;
+    bool lost = mg_lost;
     if (f.wn) {
         wg = f.wn_g[job][wcol]; wn2 = f.wn_n2[job][wcol];
         if (threadIdx.x == 0) {   // the c_j column sums of this launch's reduction blocks (dispatched first, short)
@@ -2111,7 +2161,7 @@ __device__ __forceinline__ void grad_body_x3_half(const GradJob &jb, const GradA
             ((int *)lds)[0] = ok;
         }
         __syncthreads();
-        lost = ((int *)lds)[0] == 0;
+        lost = lost || ((int *)lds)[0] == 0;
     }
     if (wave < NT) {
         float s1 = f.in_mul, s2 = 0.f;
@@ -2142,11 +2192,12 @@ extern "C" __global__ __launch_bounds__(256) void cfl_grad_x3_half_kernel(GradAr
     f32x4 *lds = (f32x4 *)smem;
     if (blockIdx.z == 0) { grad_red_block(a, (float *)smem); return; }
     const GradJob &jb = a.job[blockIdx.z - 1];
+    const int job = (int)blockIdx.z - 1, dt = grad_dtile(a.tps);
     switch (jb.nt) {
-        case 1: grad_body_x3_half<1>(jb, a, lds); break;
-        case 2: grad_body_x3_half<2>(jb, a, lds); break;
-        case 3: grad_body_x3_half<3>(jb, a, lds); break;
-        default: grad_body_x3_half<4>(jb, a, lds); break;
+        case 1: grad_body_x3_half<1>(jb, a, lds, job, dt); break;
+        case 2: grad_body_x3_half<2>(jb, a, lds, job, dt); break;
+        case 3: grad_body_x3_half<3>(jb, a, lds, job, dt); break;
+        default: grad_body_x3_half<4>(jb, a, lds, job, dt); break;
     }
 }
 
@@ -2290,7 +2341,8 @@ __device__ void mid_reg_block(const MidArgs &a, int blk) {
         }
     }
     acc = wave_sum(acc);
-    if (tid == 0) a.regpart[blk] = acc;
+    // (written through: in the mid-in-grad launch the consumer is a reduction block of the same launch)
+    if (tid == 0) __hip_atomic_store(a.regpart + blk, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 template <int S>
@@ -2908,7 +2960,8 @@ __device__ __forceinline__ size_t fold_off(int s, int r, int c, int tiles_r, int
     return block * 256 + (((c & 15) + 16 * ((rin & 15) >> 2)) << 2) + (rin & 3);
 }
 
-template <int J, int FOLD>   // J = columns per lane: sides of up to 64 * J padded columns; FOLD 2: sc1 loads of the partial tiles
+template <int J, int FOLD>   // J = columns per lane: sides of up to 64 * J padded columns; FOLD 2: sc1 loads of the partial tiles;
+                              // FOLD 3: row-major slabs in, outputs written through (sc1) for consumers inside the same launch
 __device__ __forceinline__ void mid_row_body(const MidArgs &a, int r, bool lead, float *W) {
     const int lane = threadIdx.x & 63;
     constexpr int CW = 64 * J;
@@ -2952,9 +3005,9 @@ __device__ __forceinline__ void mid_row_body(const MidArgs &a, int r, bool lead,
 #pragma unroll
         for (int j = 0; j < J; ++j) {
             const int ccs = c[j] < ss.npad ? c[j] : 0, ccd = c[j] < sd.npad ? c[j] : 0;
-            const float *srcs = FOLD ? ss.ypart + fold_off(0, r, ccs, a.Rpad >> 5, ss.npad >> 4)
+            const float *srcs = (FOLD == 1 || FOLD == 2) ? ss.ypart + fold_off(0, r, ccs, a.Rpad >> 5, ss.npad >> 4)
                                      : ss.ypart + (size_t)r * ss.npad + ccs;
-            const float *srcd = FOLD ? sd.ypart + fold_off(0, r, ccd, a.Rpad >> 5, sd.npad >> 4)
+            const float *srcd = (FOLD == 1 || FOLD == 2) ? sd.ypart + fold_off(0, r, ccd, a.Rpad >> 5, sd.npad >> 4)
                                      : sd.ypart + (size_t)r * sd.npad + ccd;
 #pragma unroll
             for (int s = 0; s < 16; ++s) {
@@ -3077,9 +3130,16 @@ __device__ __forceinline__ void mid_row_body(const MidArgs &a, int r, bool lead,
         if (is_pos) dd += pw * a.lambda_m * invB;
     }
     if (!valid) dd = 0.f;
-    if (lead && lane == 0) a.thr_copy[0] = thr;
+    auto put = [&](float *q, float val) {   // (FOLD 3: visible to the other workgroups of this launch once drained)
+        if (FOLD == 3) __hip_atomic_store(q, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else *q = val;
+    };
+    if (lead && lane == 0) put(a.thr_copy, thr);
     if (lead && a.zero_i)
-        for (int i = lane; i < a.nzero; i += 64) a.zero_i[i] = 0;
+        for (int i = lane; i < a.nzero; i += 64) {
+            if (FOLD == 3) __hip_atomic_store(a.zero_i + i, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else a.zero_i[i] = 0;
+        }
     if (lane < 16) {
         const bool pos = valid && is_pos, neg = valid && !is_pos;
         float qv = 0.f;
@@ -3098,7 +3158,7 @@ __device__ __forceinline__ void mid_row_body(const MidArgs &a, int r, bool lead,
             case P_SQRT_NEG: qv = neg ? fsqrt(d + 1e-7f) : 0.f; break;
             default: break;
         }
-        a.rowqf[frag_off(r, lane, RG)] = qv;
+        put(a.rowqf + frag_off(r, lane, RG), qv);
     }
 
     // ---- backward: J source columns and (columns < L) J destination columns per lane ----
@@ -3118,14 +3178,14 @@ __device__ __forceinline__ void mid_row_body(const MidArgs &a, int r, bool lead,
         if (c[j] < ss.npad) {
             const float dy = cs[j] ? dP * dd * act_grad(P[j], a.act) : 0.f;
             const size_t o_ = frag_off(r, c[j], RG);
-            ss.dyf[o_] = dy;
-            if (ss.cwf) ss.cwf[o_] = dy * xvs[j];
+            put(ss.dyf + o_, dy);
+            if (ss.cwf) put(ss.cwf + o_, dy * xvs[j]);
         }
         if (c[j] < sd.npad) {
             const float dy = cd[j] ? dv * dd * act_grad(v[j], a.act) : 0.f;
             const size_t o_ = frag_off(r, c[j], RG);
-            sd.dyf[o_] = dy;
-            if (sd.cwf) sd.cwf[o_] = dy * xvd[j];
+            put(sd.dyf + o_, dy);
+            if (sd.cwf) put(sd.cwf + o_, dy * xvd[j]);
         }
     }
 }
@@ -3207,6 +3267,63 @@ extern "C" __global__ __launch_bounds__(256) void cfl_proj_mid_kernel(ProjArgs a
         // the form the guide measured valid at ONE workgroup per CU only; two share a CU here
         if (fa.sc1_loads) mid_row_body<1, 2>(ma, r, id == 0 && wave == 0, (float *)smem + wave * 6 * 64);
         else mid_row_body<1, 1>(ma, r, id == 0 && wave == 0, (float *)smem + wave * 6 * 64);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// mid inside the weight-gradient launch (round 3; the half-tile form only): one launch =
+//   [row-math blocks | L2-regulariser blocks | reduction blocks | (pad to 8) | contraction workgroups (job, 32-d tile)]
+// in linear-id = dispatch order.  The row-math blocks (wave per row, mid_row_body) never wait; they write dL/dY and the
+// per-row loss quantities THROUGH (sc1), drain, barrier, and raise one flag word each that carries the launch's
+// generation.  A contraction workgroup stages its row addresses, REQUESTS THE FIRST CHUNK OF x -- which does not depend on
+// dL/dY -- and only then waits for the flags (one wave polls, one agent acquire, barrier): the latency chain of the row
+// math (~4.5 us) was meant to hide behind the arrival of x instead of occupying a launch of its own (7.1 us + a kernel
+// boundary).  The reduction blocks wait the same way.  No deadlock: producers are dispatched first and never wait.
+// MEASURED (profiles/r03_midgrad_measurement.md): bit-identical, but 4.4 us per step SLOWER than the separate mid launch
+// (with or without the early x request) -- like the proj + mid fold, the in-launch hand-off (written-through 4-byte
+// stores, drain, 260 workgroups polling 256 flags, acquire) costs more than the boundary it removes.  Opt-in only.
+// ---------------------------------------------------------------------------
+struct MidGradArgs {
+    GradArgs g;
+    MidArgs m;
+    unsigned gen;
+    unsigned *flags;     // [nrow + nreg]
+    int nrow, nreg, nred, first_contr, ntile;   // row-math blocks, regulariser blocks, reduction blocks, first contraction id, D / 32
+    int early_x;
+};
+
+extern "C" __global__ __launch_bounds__(256) void cfl_midgrad_half_kernel(MidGradArgs a_) {
+    CFL_KERNARG_IN_PLACE(MidGradArgs, a, a_);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int id = blockIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (id < a.nrow + a.nreg) {
+        if (id < a.nrow) mid_row_body<1, 3>(a.m, id * 4 + wave, id == 0 && wave == 0, (float *)smem + wave * 6 * 64);
+        else if (wave == 0) mid_reg_block(a.m, id - a.nrow);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its written-through outputs
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_store(a.flags + id, a.gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    const MgWait mg = {a.flags, a.nrow + a.nreg, a.gen, a.early_x};
+    if (id < a.nrow + a.nreg + a.nred) {
+        grad_red_block(a.g, (float *)smem, &mg, id - a.nrow - a.nreg, a.nred);
+        return;
+    }
+    if (id < a.first_contr) return;
+    const int c = id - a.first_contr;
+    const int job = c / a.ntile;
+    // XCD-aligned tile order as in the plain launch: first_contr is a multiple of 8, so c mod 8 = blockIdx.x mod 8
+    const int cx = c - job * a.ntile;
+    int dt = cx;
+    if (a.g.tps > 0) { const int k = cx & 7, j = cx >> 3; dt = ((j / a.g.tps) * 8 + k) * a.g.tps + j % a.g.tps; }
+    const GradJob &jb = a.g.job[job];
+    f32x4 *lds = (f32x4 *)smem;
+    switch (jb.nt) {
+        case 1: grad_body_x3_half<1>(jb, a.g, lds, job, dt, &mg); break;
+        case 2: grad_body_x3_half<2>(jb, a.g, lds, job, dt, &mg); break;
+        case 3: grad_body_x3_half<3>(jb, a.g, lds, job, dt, &mg); break;
+        default: grad_body_x3_half<4>(jb, a.g, lds, job, dt, &mg); break;
     }
 }
 
@@ -3522,6 +3639,8 @@ struct Plan {
     bool proj_ring;   // loader / consumer ring form (cfl_proj_ring_kernel); S is then the ring's d split
     int ring_tiles, ring_units, ring_nwg;
     bool grad_half;   // 32-d tiles, no row split (cfl_grad_x3_half_kernel)
+    bool midgrad;     // ... with the row math inside the same launch (cfl_midgrad_half_kernel)
+    size_t mg_flags;
     bool fused;       // gradient + Adam finished inside the weight-gradient launch (GradFuse)
     size_t handoff;   // workspace offset of the hand-off tickets + flags (ints), nhandoff of each
     int nhandoff;
@@ -3712,6 +3831,15 @@ static int make_plan(const CflShape *s, int64_t rows, int groups, bool train, Pl
                    s->K <= 64 && S % 8 == 0 && group <= 32 && 32 % group == 0 && !pl->proj_ring && !pl->proj_stream && !pl->proj_x3 &&
                    pl->R % 32 == 0 && (!train || pl->Rpad == pl->R) && !pl->mid_generic && !pl->mid_norow;
         pl->fold_flags = take(pl->fold ? (size_t)(pl->R / 32) * group : 0);
+    }
+    {
+        // row math inside the weight-gradient launch: half-tile form, wave-per-row math with one column per lane
+        const int wide = hs->npad > hd->npad ? hs->npad : hd->npad;
+        // (opt-in, CFL_DEBUG_MIDGRAD=1 | 2: measured 4.4 us SLOWER per step than the separate mid launch, profiles/r03_midgrad_measurement.md)
+        pl->midgrad = train && pl->grad_half && !pl->fold && debug_env("CFL_DEBUG_MIDGRAD") > 0 &&
+                      (s->dist_type == CFL_DIST_PCD || s->dist_type == CFL_DIST_SIAMESE) && wide <= 64 && s->K <= 64 &&
+                      !pl->mid_generic && !pl->mid_norow && pl->Rpad % 4 == 0 && (pl->lay.total / 4096 + 2) < 4096;
+        pl->mg_flags = take(pl->midgrad ? (size_t)pl->Rpad / 4 + pl->nregblocks + 64 : 0);
     }
     pl->wplanes[0] = take(pl->proj_x3 ? (size_t)hs->npad * s->D * 3 / 2 : 0);   // bf16 planes: 6 bytes per weight
     pl->wplanes[1] = take(pl->proj_x3 ? (size_t)hd->npad * s->D * 3 / 2 : 0);
@@ -4125,6 +4253,8 @@ static int run_pairs(const CflShape *s, const CflNorm *norm, const CflLossCfg *l
         ProfScope ps(st, CFL_K_PROJ);
         hipLaunchKernelGGL(cfl_proj_mid_kernel, dim3(fo.ntile_wgs + nreg_blocks), dim3(256), 4 * 8 * 64 * sizeof(f32x4), st,
                            pa, ma, fo);
+    } else if (pl.midgrad) {
+        // the row math rides in the weight-gradient launch (cfl_midgrad_half_kernel, below)
     } else {
         ProfScope ps(st, CFL_K_MID);
         const dim3 mgrid(ma.nrb + nreg_blocks), mblk(64);
@@ -4319,7 +4449,23 @@ static int run_pairs(const CflShape *s, const CflNorm *norm, const CflLossCfg *l
         ga.tps = pl.xcd ? (s->D / (pl.grad_half ? 32 : 64)) / pl.S : 0;
         dim3 grid(s->D / 64, pl.P, nj + 1);
         ProfScope ps(st, CFL_K_GRAD);
-        if (pl.grad_half)
+        if (pl.midgrad) {
+            static std::atomic<unsigned> mg_gen{1};
+            MidGradArgs mg;
+            memset(&mg, 0, sizeof(mg));
+            mg.g = ga; mg.m = ma;
+            unsigned g = mg_gen.fetch_add(1);
+            if (g == 0) g = mg_gen.fetch_add(1);
+            mg.gen = g;
+            mg.flags = (unsigned *)(ws + pl.mg_flags);
+            mg.nrow = ma.nrb; mg.nreg = nreg_blocks;
+            mg.nred = ga.red_total < 128 ? ga.red_total : 128;
+            mg.first_contr = (int)round_up(mg.nrow + mg.nreg + mg.nred, 8);
+            mg.ntile = s->D / 32;
+            mg.early_x = debug_env("CFL_DEBUG_MIDGRAD") != 2;
+            hipLaunchKernelGGL(cfl_midgrad_half_kernel, dim3(mg.first_contr + nj * mg.ntile), dim3(256),
+                               4 * 4 * 4 * 64 * sizeof(f32x4), st, mg);
+        } else if (pl.grad_half)
             hipLaunchKernelGGL(cfl_grad_x3_half_kernel, dim3(s->D / 32, 1, nj + 1), dim3(256), 4 * 4 * 4 * 64 * sizeof(f32x4), st, ga);
         else if (pl.x3 && pl.Rpad / pl.P <= 8192)
             hipLaunchKernelGGL(cfl_grad_x3_kernel, grid, dim3(256), 4 * 4 * 4 * 64 * sizeof(f32x4), st, ga);

@@ -693,3 +693,44 @@ def test_fused_gradient_tail_monomer_and_directed_equal_finalize_kernel(dist, di
         for x, y in zip(a, b):
             assert torch.equal(x, y)
     assert np.isfinite(res['fused'][-1][1].cpu().numpy()).all()
+
+
+@pytest.mark.parametrize('B,D,K,L,wn,reg', [(512, 4096, 3, 20, False, 0.0), (512, 4096, 4, 10, False, 1e-3),
+                                            (1024, 4096, 3, 20, True, 1e-3), (256, 8192, 2, 12, False, 0.0),
+                                            (100, 4096, 4, 10, False, 0.0)])
+def test_row_math_inside_the_gradient_launch_equals_separate_mid_launch(B, D, K, L, wn, reg, monkeypatch):
+    """cfl_midgrad_half_kernel: the distance / loss / dL/dY math runs as the first blocks of the weight-gradient launch
+    (outputs written through, one generation flag per block), the contraction workgroups request their first chunk of x
+    and then wait for the flags (opt-in CFL_DEBUG_MIDGRAD=1: it measured slower than the separate launch).  Two launches
+    per step instead of three; parameters, Adam slots, gradient and scalars must equal the three-launch step BIT FOR BIT over 300 steps (256+ producer flags x 260 consumers per step)."""
+    from cfl.engine import PairEngine
+    rng = np.random.RandomState(12)
+    cfg = O.EncoderCfg(D=D, L=L, K=K, style='cfl' if wn else 'dist')
+    params = O.init_encoder_params(cfg, rng, np.float32)
+    pool = [[torch.from_numpy(np.abs(rng.randn(B, D)).astype(np.float32) * 3).cuda() for _ in range(4)] for _ in range(3)]
+    res = {}
+    for mode in ('inside', 'separate'):
+        monkeypatch.setenv('CFL_DEBUG_MIDGRAD', '1' if mode == 'inside' else '-1')
+        H.reload_env()
+        eng = PairEngine(D, L, K, weight_norm=cfg.weight_norm, has_bias=cfg.has_bias, norm=H.make_norm(1 / 8.0),
+                         loss=H.make_loss(reg_const=reg), params=params, batch_size=B)
+        H.profile_enable(True)
+        eng.step(pool[0])
+        torch.cuda.synchronize()
+        H.profile_enable(False)
+        kinds = set(H.profile_read())
+        assert ('mid' in kinds) == (mode == 'separate'), kinds
+        snaps = []
+        for it in range(300):
+            eng.step(pool[it % 3])
+            if it in (0, 1, 7, 299):
+                snaps.append([t.clone() for t in (eng.theta, eng.m, eng.v, eng.grad, eng.scalars)])
+        eng.fwd_bwd(pool[1])
+        snaps.append([eng.grad.clone(), eng.scalars.clone(), eng.theta.clone()])
+        res[mode] = snaps
+    monkeypatch.undo()
+    H.reload_env()
+    for a, b in zip(res['inside'], res['separate']):
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
+    assert np.isfinite(res['inside'][-1][1].cpu().numpy()).all()
