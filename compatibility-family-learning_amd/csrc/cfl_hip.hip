@@ -1318,6 +1318,26 @@ __device__ __forceinline__ void load4_sc1_wait(const float *p, f32x4 (&o)[4]) {
         : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]) : "v"(p) : "memory");
 }
 
+__device__ __forceinline__ void load4x3_sc1_wait(const float *p0, const float *p1, const float *p2, f32x4 (&o)[12]) {
+    asm volatile(
+        "global_load_dwordx4 %0, %12, off sc1\n\t"
+        "global_load_dwordx4 %1, %12, off offset:256 sc1\n\t"
+        "global_load_dwordx4 %2, %12, off offset:512 sc1\n\t"
+        "global_load_dwordx4 %3, %12, off offset:768 sc1\n\t"
+        "global_load_dwordx4 %4, %13, off sc1\n\t"
+        "global_load_dwordx4 %5, %13, off offset:256 sc1\n\t"
+        "global_load_dwordx4 %6, %13, off offset:512 sc1\n\t"
+        "global_load_dwordx4 %7, %13, off offset:768 sc1\n\t"
+        "global_load_dwordx4 %8, %14, off sc1\n\t"
+        "global_load_dwordx4 %9, %14, off offset:256 sc1\n\t"
+        "global_load_dwordx4 %10, %14, off offset:512 sc1\n\t"
+        "global_load_dwordx4 %11, %14, off offset:768 sc1\n\t"
+        "s_waitcnt vmcnt(0)"
+        : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7]),
+          "=&v"(o[8]), "=&v"(o[9]), "=&v"(o[10]), "=&v"(o[11])
+        : "v"(p0), "v"(p1), "v"(p2) : "memory");
+}
+
 // TF-1.x Adam on one parameter (tensorflow/core/kernels/training_ops: the hyper-parameters are
 // float32 scalars and (1 - beta) is formed in float32):  m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ;
 // theta -= lr_t m / (sqrt(v) + eps).  Explicit fma's: every kernel that applies Adam (finalize, the fused tail of
@@ -1430,25 +1450,32 @@ __device__ __forceinline__ void grad_fused_tail(const GradArgs &a, int job, int 
         f32x4 g[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) g[e] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (paired) {   // side 0's row ranges first
-            for (int q = 0; q < P; ++q) {
-                f32x4 part[4];
-                load4_sc1_wait(slab0 - f.pair_delta + (size_t)q * pstride + tile_off, part);
+        // published tiles in the finalize kernel's order: side 0's P row ranges first (siamese), then row ranges
+        // 0 .. P-2 of this side; the finisher's own registers (row range P-1) come last.  Three tiles (12 loads) are
+        // in flight per round trip -- one at a time, config 3 (three tiles) and config 4 (P = 4) paid three serial
+        // misses to memory here
+        const int npair = paired ? P : 0, nparts = npair + P - 1;
+        const float *own = slab0 + tile_off;
+        auto part_ptr = [&](int k) {
+            k = k < nparts ? k : nparts - 1;
+            return k < npair ? own - f.pair_delta + (size_t)k * pstride : own + (size_t)(k - npair) * pstride;
+        };
+        for (int k = 0; k < nparts; k += 3) {
+            f32x4 part[12];
+            load4x3_sc1_wait(part_ptr(k), part_ptr(k + 1), part_ptr(k + 2), part);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) g[e] += part[e];
+            for (int e = 0; e < 4; ++e) g[e] += part[e];
+            if (k + 1 < nparts) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) g[e] += part[4 + e];
+            }
+            if (k + 2 < nparts) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) g[e] += part[8 + e];
             }
         }
-        for (int q = 0; q < P; ++q) {
-            if (q == p) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) g[e] += (f32x4){sum[0][e], sum[1][e], sum[2][e], sum[3][e]};
-            } else {
-                f32x4 part[4];
-                load4_sc1_wait(slab0 + (size_t)q * pstride + tile_off, part);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) g[e] += part[e];
-            }
-        }
+        for (int e = 0; e < 4; ++e) g[e] += (f32x4){sum[0][e], sum[1][e], sum[2][e], sum[3][e]};
         if (lost) {   // loud, not silent: NaN gradient (and parameters) for this tile -> NaN loss at the next read-back
 #pragma unroll
             for (int e = 0; e < 4; ++e) g[e] = (f32x4){NAN, NAN, NAN, NAN};
@@ -1657,26 +1684,51 @@ __device__ __forceinline__ bool mg_wait_all(const MgWait &w, int *lds_i) {
 }
 
 // column sums of tile `idx` of a fragment-major buffer (the whole workgroup): lane (kq, c16) adds its 4 rows; the
-// result is valid in lanes 0 .. 15 of wave 0
-__device__ __forceinline__ float tile_colsum(const float *buf, int idx, int RG, int lane, int wave, float *lds) {
+// result is valid in lanes 0 .. 15 of wave 0.  `buf2` (dual ranges: side 0's tile of a shared head) is summed the same
+// way in the same pass and returned in *cs2.
+// The reduction blocks are the critical path of the launch for weight-normalised heads (every tile finisher waits for
+// their c_j) and wherever a block gets more than one job, so a job is ONE round of loads: 16 row groups per wave and
+// buffer in flight at once (both buffers of a dual range together), one LDS exchange for both.  The order of the
+// additions is the one the two-rounds-of-8 form had (row groups wave, wave + 4, ... ascending).
+__device__ __forceinline__ float tile_colsum(const float *buf, int idx, int RG, int lane, int wave, float *lds,
+                                             const float *buf2 = nullptr, float *cs2 = nullptr) {
     const f32x4 *pa = (const f32x4 *)(buf + (size_t)idx * RG * 256) + lane;
-    float acc = 0.f;
-    // 8 independent loads in flight per round (a serial load chain here would be the critical path of the launch)
-    for (int rg0 = wave; rg0 < RG; rg0 += 32) {
-        f32x4 v[8];
+    const f32x4 *pb = (const f32x4 *)((buf2 ? buf2 : buf) + (size_t)idx * RG * 256) + lane;
+    float acc = 0.f, acc2 = 0.f;
+    for (int rg0 = wave; rg0 < RG; rg0 += 64) {
+        f32x4 v[16], w[16];
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
+        for (int u = 0; u < 16; ++u)
             v[u] = rg0 + 4 * u < RG ? pa[(size_t)(rg0 + 4 * u) * 64] : (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (buf2) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) acc += (v[u][0] + v[u][1]) + (v[u][2] + v[u][3]);
+            for (int u = 0; u < 16; ++u)
+                w[u] = rg0 + 4 * u < RG ? pb[(size_t)(rg0 + 4 * u) * 64] : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) acc += (v[u][0] + v[u][1]) + (v[u][2] + v[u][3]);
+        if (buf2) {
+#pragma unroll
+            for (int u = 0; u < 16; ++u) acc2 += (w[u][0] + w[u][1]) + (w[u][2] + w[u][3]);
+        }
     }
     acc += __shfl_xor(acc, 16);
     acc += __shfl_xor(acc, 32);
+    if (buf2) {
+        acc2 += __shfl_xor(acc2, 16);
+        acc2 += __shfl_xor(acc2, 32);
+    }
     __syncthreads();
-    if (lane < 16) lds[wave * 16 + lane] = acc;
+    if (lane < 16) {
+        lds[wave * 16 + lane] = acc;
+        if (buf2) lds[64 + wave * 16 + lane] = acc2;
+    }
     __syncthreads();
     float cs = 0.f;
-    if (wave == 0 && lane < 16) cs = (lds[lane] + lds[16 + lane]) + (lds[32 + lane] + lds[48 + lane]);
+    if (wave == 0 && lane < 16) {
+        cs = (lds[lane] + lds[16 + lane]) + (lds[32 + lane] + lds[48 + lane]);
+        if (buf2) *cs2 = (lds[64 + lane] + lds[80 + lane]) + (lds[96 + lane] + lds[112 + lane]);
+    }
     return cs;
 }
 
@@ -1697,10 +1749,10 @@ __device__ __forceinline__ void grad_red_block(const GradArgs &a, float *lds, co
             // as its own range would, then added side 0 first (the finalize kernel's order)
             const float *second = rr.B;   // (kind 0: B = the second buffer of a dual range, else null)
             float csum = 0.f;
-            if (second) csum = tile_colsum(second, idx, RG, lane, wave, lds);
             {
-                const float c1 = tile_colsum(rr.A, idx, RG, lane, wave, lds);
-                csum = second ? csum + c1 : c1;
+                float c0 = 0.f;
+                const float c1 = tile_colsum(rr.A, idx, RG, lane, wave, lds, second, &c0);
+                csum = second ? c0 + c1 : c1;
             }
             const bool publish = a.fuse.on && a.fuse.wn && a.fuse.red_g[k] >= 0;   // c_j sums the W tiles wait for
             if (wave == 0 && lane < 16) {
