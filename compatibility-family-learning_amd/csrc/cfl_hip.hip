@@ -1338,6 +1338,27 @@ __device__ __forceinline__ void load4x3_sc1_wait(const float *p0, const float *p
         : "v"(p0), "v"(p1), "v"(p2) : "memory");
 }
 
+// half tiles (cfl_grad_x3_half_kernel): two float4 per lane, 64 floats apart
+__device__ __forceinline__ void store2_sc1_wait(float *p, f32x4 v0, f32x4 v1) {
+    asm volatile(
+        "global_store_dwordx4 %0, %1, off sc1\n\t"
+        "global_store_dwordx4 %0, %2, off offset:256 sc1\n\t"
+        "s_waitcnt vmcnt(0)"
+        :: "v"(p), "v"(v0), "v"(v1) : "memory");
+}
+__device__ __forceinline__ void load2x3_sc1_wait(const float *p0, const float *p1, const float *p2, f32x4 (&o)[6]) {
+    asm volatile(
+        "global_load_dwordx4 %0, %6, off sc1\n\t"
+        "global_load_dwordx4 %1, %6, off offset:256 sc1\n\t"
+        "global_load_dwordx4 %2, %7, off sc1\n\t"
+        "global_load_dwordx4 %3, %7, off offset:256 sc1\n\t"
+        "global_load_dwordx4 %4, %8, off sc1\n\t"
+        "global_load_dwordx4 %5, %8, off offset:256 sc1\n\t"
+        "s_waitcnt vmcnt(0)"
+        : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5])
+        : "v"(p0), "v"(p1), "v"(p2) : "memory");
+}
+
 // TF-1.x Adam on one parameter (tensorflow/core/kernels/training_ops: the hyper-parameters are
 // float32 scalars and (1 - beta) is formed in float32):  m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ;
 // theta -= lr_t m / (sqrt(v) + eps).  Explicit fma's: every kernel that applies Adam (finalize, the fused tail of
@@ -2062,16 +2083,26 @@ __device__ __forceinline__ void grad_body_x3(const GradJob &jb, const GradArgs &
 // ---------------------------------------------------------------------------
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-template <int NT>
+template <int NT, bool HO>   // HO: row split and / or siamese pairing (hand-off tail); false: the tile is complete in the workgroup
 __device__ __forceinline__ void grad_body_x3_half(const GradJob &jb, const GradArgs &a, f32x4 *lds, int job, int dtile,
-                                                  const MgWait *mg = nullptr) {
+                                                  int p, const MgWait *mg = nullptr) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i16 = lane & 15, kq = lane >> 4;
     const int dbase = dtile * 32;
     const int RG = a.Rpad >> 4, G = a.D >> 4;
-    const int rows_w = a.Rpad >> 2;   // multiple of 64
-    const int rbeg = wave * rows_w, rend = rbeg + rows_w;
+    // (HO == false keeps every trace of the hand-off out of the headline's kernel: the general tail, although it
+    // takes the same branches there, measured +0.55 us per step)
+    const GradFuse &f = a.fuse;
+    const int P = HO ? a.P : 1;
+    const int pair_jobs = HO ? f.pair_jobs : 0;
+    const long long pair_delta = HO ? f.pair_delta : 0;
+    const bool paired = pair_jobs > 0;
+    const bool side0 = paired && job < pair_jobs;
+    const int slot = (paired && !side0 ? job - pair_jobs : job) * (a.D >> 5) + dtile;
+    const int expect = paired ? 2 * P - 1 : P - 1;
+    const int rows_wg = HO ? a.Rpad / P : a.Rpad, rows_w = rows_wg >> 2;   // multiple of 64
+    const int rbeg = p * rows_wg + wave * rows_w, rend = rbeg + rows_w;
     const int r64 = (a.R + 63) & ~63;
     const int rstop = rend < r64 ? rend : r64;
 
@@ -2181,12 +2212,22 @@ __device__ __forceinline__ void grad_body_x3_half(const GradJob &jb, const GradA
         if (wave < NT) {
 #pragma unroll
             for (int h = 0; h < 2; ++h)
-                *(f32x4 *)(jb.wpart + tile_off + h * 64) = (f32x4){sum[0][2 * h], sum[1][2 * h], sum[0][2 * h + 1], sum[1][2 * h + 1]};
+                *(f32x4 *)(jb.wpart + (size_t)p * jb.pstride + tile_off + h * 64) =
+                    (f32x4){sum[0][2 * h], sum[1][2 * h], sum[0][2 * h + 1], sum[1][2 * h + 1]};
         }
         return;
     }
-    // fused tail without a hand-off: the tile is complete here
-    const GradFuse &f = a.fuse;
+    // fused tail.  P == 1 and one side per head: the tile is complete here, no hand-off at all.  Otherwise the protocol of
+    // grad_fused_tail on half tiles: the first P - 1 row ranges (siamese: and all of side 0) publish their partial tile
+    // (write-through, drained, one arrival count per tile) and leave; the last row range (of side 1) finishes.
+    if (HO && (p < P - 1 || side0)) {
+        if (wave < NT)
+            store2_sc1_wait(jb.wpart + (size_t)p * jb.pstride + tile_off, (f32x4){sum[0][0], sum[1][0], sum[0][1], sum[1][1]},
+                            (f32x4){sum[0][2], sum[1][2], sum[0][3], sum[1][3]});
+        __syncthreads();
+        if (threadIdx.x == 0) atomicAdd(f.flag + slot, 1);
+        return;
+    }
     const long long base = f.w_off[job] + (long long)tile_off;
     f32x4 th[2], mm[2], vv[2];
     if (wave < NT) {
@@ -2202,13 +2243,23 @@ __device__ __forceinline__ void grad_body_x3_half(const GradJob &jb, const GradA
     const int wcol = ntw * 16 + i16;
     float wg = 1.f, wn2 = 1.f;
     bool lost = mg_lost;
-    if (f.wn) {
-        wg = f.wn_g[job][wcol]; wn2 = f.wn_n2[job][wcol];
-        if (threadIdx.x == 0) {   // the c_j column sums of this launch's reduction blocks (dispatched first, short)
-            int spins = 0, ok = 1;
-            while (__hip_atomic_load(f.red_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < f.red_expect) {
-                __builtin_amdgcn_s_sleep(1);
-                if (++spins > CFL_HANDOFF_SPIN_LIMIT) { ok = 0; break; }
+    if (f.wn) { wg = f.wn_g[job][wcol]; wn2 = f.wn_n2[job][wcol]; }
+    if ((HO && expect > 0) || f.wn) {
+        if (threadIdx.x == 0) {   // bounded waits, as in grad_fused_tail
+            int ok = 1;
+            if (expect > 0) {
+                int spins = 0;
+                while (__hip_atomic_load(f.flag + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < expect) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > CFL_HANDOFF_SPIN_LIMIT) { ok = 0; break; }
+                }
+            }
+            if (f.wn && ok) {   // the c_j column sums of this launch's reduction blocks (dispatched first, short)
+                int spins = 0;
+                while (__hip_atomic_load(f.red_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < f.red_expect) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > CFL_HANDOFF_SPIN_LIMIT) { ok = 0; break; }
+                }
             }
             ((int *)lds)[0] = ok;
         }
@@ -2216,6 +2267,29 @@ __device__ __forceinline__ void grad_body_x3_half(const GradJob &jb, const GradA
         lost = lost || ((int *)lds)[0] == 0;
     }
     if (wave < NT) {
+        f32x4 g[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        // published tiles in the finalize kernel's order (side 0's row ranges, then this side's 0 .. P-2), three per
+        // round trip; the finisher's own registers last
+        const int npair = paired ? P : 0, nparts = npair + P - 1;
+        const float *own = jb.wpart + tile_off;
+        auto part_ptr = [&](int k) {
+            k = k < nparts ? k : nparts - 1;
+            return k < npair ? own - pair_delta + (size_t)k * jb.pstride : own + (size_t)(k - npair) * jb.pstride;
+        };
+        for (int k = 0; HO && k < nparts; k += 3) {
+            f32x4 part[6];
+            load2x3_sc1_wait(part_ptr(k), part_ptr(k + 1), part_ptr(k + 2), part);
+            g[0] += part[0]; g[1] += part[1];
+            if (k + 1 < nparts) { g[0] += part[2]; g[1] += part[3]; }
+            if (k + 2 < nparts) { g[0] += part[4]; g[1] += part[5]; }
+        }
+        if (HO && nparts > 0) {
+            g[0] += (f32x4){sum[0][0], sum[1][0], sum[0][1], sum[1][1]};
+            g[1] += (f32x4){sum[0][2], sum[1][2], sum[0][3], sum[1][3]};
+        } else {
+            g[0] = (f32x4){sum[0][0], sum[1][0], sum[0][1], sum[1][1]};
+            g[1] = (f32x4){sum[0][2], sum[1][2], sum[0][3], sum[1][3]};
+        }
         float s1 = f.in_mul, s2 = 0.f;
         if (f.wn) {
             const float cw = __hip_atomic_load(f.wn_cw[job] + wcol, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -2226,9 +2300,9 @@ __device__ __forceinline__ void grad_body_x3_half(const GradJob &jb, const GradA
         }
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            f32x4 g = {sum[0][2 * h], sum[1][2 * h], sum[0][2 * h + 1], sum[1][2 * h + 1]};
-            if (lost) g = (f32x4){NAN, NAN, NAN, NAN};
-            f32x4 gr = g * s1;
+            f32x4 gh = g[h];
+            if (lost) gh = (f32x4){NAN, NAN, NAN, NAN};
+            f32x4 gr = gh * s1;
             if (f.wn) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) gr[i] = fmaf(-s2, th[h][i], gr[i]);
@@ -2238,7 +2312,7 @@ __device__ __forceinline__ void grad_body_x3_half(const GradJob &jb, const GradA
     }
 }
 
-extern "C" __global__ __launch_bounds__(256) void cfl_grad_x3_half_kernel(GradArgs a_) {   // P == 1, Rpad <= 8192
+extern "C" __global__ __launch_bounds__(256) void cfl_grad_x3_half_kernel(GradArgs a_) {   // P == 1, one side per head; Rpad <= 8192 (staged row addresses)
     CFL_KERNARG_IN_PLACE(GradArgs, a, a_);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     f32x4 *lds = (f32x4 *)smem;
@@ -2246,10 +2320,26 @@ extern "C" __global__ __launch_bounds__(256) void cfl_grad_x3_half_kernel(GradAr
     const GradJob &jb = a.job[blockIdx.z - 1];
     const int job = (int)blockIdx.z - 1, dt = grad_dtile(a.tps);
     switch (jb.nt) {
-        case 1: grad_body_x3_half<1>(jb, a, lds, job, dt); break;
-        case 2: grad_body_x3_half<2>(jb, a, lds, job, dt); break;
-        case 3: grad_body_x3_half<3>(jb, a, lds, job, dt); break;
-        default: grad_body_x3_half<4>(jb, a, lds, job, dt); break;
+        case 1: grad_body_x3_half<1, false>(jb, a, lds, job, dt, 0); break;
+        case 2: grad_body_x3_half<2, false>(jb, a, lds, job, dt, 0); break;
+        case 3: grad_body_x3_half<3, false>(jb, a, lds, job, dt, 0); break;
+        default: grad_body_x3_half<4, false>(jb, a, lds, job, dt, 0); break;
+    }
+}
+
+// ... with a row split (grid y = P row ranges) and / or the siamese pairing: hand-off tail
+extern "C" __global__ __launch_bounds__(256) void cfl_grad_x3_half_split_kernel(GradArgs a_) {
+    CFL_KERNARG_IN_PLACE(GradArgs, a, a_);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    f32x4 *lds = (f32x4 *)smem;
+    if (blockIdx.z == 0) { grad_red_block(a, (float *)smem); return; }
+    const GradJob &jb = a.job[blockIdx.z - 1];
+    const int job = (int)blockIdx.z - 1, dt = grad_dtile(a.tps);
+    switch (jb.nt) {
+        case 1: grad_body_x3_half<1, true>(jb, a, lds, job, dt, (int)blockIdx.y); break;
+        case 2: grad_body_x3_half<2, true>(jb, a, lds, job, dt, (int)blockIdx.y); break;
+        case 3: grad_body_x3_half<3, true>(jb, a, lds, job, dt, (int)blockIdx.y); break;
+        default: grad_body_x3_half<4, true>(jb, a, lds, job, dt, (int)blockIdx.y); break;
     }
 }
 
@@ -3372,10 +3462,10 @@ extern "C" __global__ __launch_bounds__(256) void cfl_midgrad_half_kernel(MidGra
     const GradJob &jb = a.g.job[job];
     f32x4 *lds = (f32x4 *)smem;
     switch (jb.nt) {
-        case 1: grad_body_x3_half<1>(jb, a.g, lds, job, dt, &mg); break;
-        case 2: grad_body_x3_half<2>(jb, a.g, lds, job, dt, &mg); break;
-        case 3: grad_body_x3_half<3>(jb, a.g, lds, job, dt, &mg); break;
-        default: grad_body_x3_half<4>(jb, a.g, lds, job, dt, &mg); break;
+        case 1: grad_body_x3_half<1, false>(jb, a.g, lds, job, dt, 0, &mg); break;
+        case 2: grad_body_x3_half<2, false>(jb, a.g, lds, job, dt, 0, &mg); break;
+        case 3: grad_body_x3_half<3, false>(jb, a.g, lds, job, dt, 0, &mg); break;
+        default: grad_body_x3_half<4, false>(jb, a.g, lds, job, dt, 0, &mg); break;
     }
 }
 
@@ -3755,15 +3845,25 @@ static int make_plan(const CflShape *s, int64_t rows, int groups, bool train, Pl
     // is short enough for one workgroup per tile, a gradient tile is complete inside its workgroup and the fused tail
     // needs no hand-off.  Not for the siamese pairing (two sides per tile) and not with the fp32-MFMA contraction.
     pl->grad_half = false;
-    if (train && debug_env("CFL_EXACT_FP32") <= 0 && debug_env("CFL_DEBUG_GRAD_HALF") >= 0 && debug_env("CFL_DEBUG_P") <= 0) {
+    if (train && debug_env("CFL_EXACT_FP32") <= 0 && debug_env("CFL_DEBUG_GRAD_HALF") >= 0) {
         const int ht = s->D / 32;
         const bool paired = s->dist_type == CFL_DIST_SIAMESE && !s->directed;
         // (measured: -2.6 us at B = 512 and with weight-norm, -5.9 us at B = 1024, -1.6 us at B = 2048; +5 us at B = 4096; +0.8 us
         // with 192 workgroups on 256 CUs, config 4 -- hence the bounds)
-        if (!paired && ht * njobs >= 256 && ht * njobs <= 640 && pl->R <= 4096) {
+        // Beyond 2048 rows per side the rows are split in two (one published half tile per finisher): measured against
+        // P = 1 -2.5 us at B = 1536 and -2.5 .. -3.9 us at B = 2048, +0.9 us at B = 1024; against the 64-d form -1 us at B = 3072
+        if (!paired && ht * njobs >= 256 && ht * njobs <= 640 && pl->R <= 6144 && debug_env("CFL_DEBUG_P") <= 0) {
+            pl->grad_half = true;
+            P = pl->R > 2048 ? 2 : 1;
+        }
+        // siamese: side 0's half tile is published, side 1's workgroup of the same tile finishes -- ONE published tile per
+        // finisher and twice as many finishers as the 64-d / P = 2 form (config 3: three tiles per finisher)
+        if (paired && ht * njobs >= 256 && ht * njobs <= 640 && pl->R <= 2048 && debug_env("CFL_DEBUG_P") <= 0) {
             pl->grad_half = true;
             P = 1;
         }
+        // CFL_DEBUG_GRAD_HALF=1: half tiles with whatever row split was chosen above / forced by CFL_DEBUG_P (experiments)
+        if (debug_env("CFL_DEBUG_GRAD_HALF") > 0 && round_up(pl->R, 256 * P) <= 8192) pl->grad_half = true;   // (staged row addresses: 64 KB of LDS)
     }
     // matrix-core arithmetic of the weight-gradient contraction: bf16x3 (fp32-equivalent, default) or,
     // with CFL_EXACT_FP32=1 in the environment, the k-ordered fp32 FMA chains of v_mfma_f32_16x16x4_f32
@@ -3870,7 +3970,7 @@ static int make_plan(const CflShape *s, int64_t rows, int groups, bool train, Pl
         pl->wpart[0] = take((size_t)P * hs->npad * s->D);
         pl->wpart[1] = take((size_t)P * hd->npad * s->D);
         pl->regpart = take((size_t)pl->nregblocks);
-        pl->nhandoff = njobs * (s->D / 64);
+        pl->nhandoff = njobs * (s->D / 32);   // (half tiles; the 64-d forms use the first half)
         pl->handoff = take(2 * (size_t)pl->nhandoff + 64);   // tickets, flags, + the reduction blocks' counter
     }
     // proj + mid in one launch: pcd, plain heads (weight-norm needs the column norms of the same launch), sides of at
@@ -3888,7 +3988,7 @@ static int make_plan(const CflShape *s, int64_t rows, int groups, bool train, Pl
         // row math inside the weight-gradient launch: half-tile form, wave-per-row math with one column per lane
         const int wide = hs->npad > hd->npad ? hs->npad : hd->npad;
         // (opt-in, CFL_DEBUG_MIDGRAD=1 | 2: measured 4.4 us SLOWER per step than the separate mid launch, profiles/r03_midgrad_measurement.md)
-        pl->midgrad = train && pl->grad_half && !pl->fold && debug_env("CFL_DEBUG_MIDGRAD") > 0 &&
+        pl->midgrad = train && pl->grad_half && pl->P == 1 && !(s->dist_type == CFL_DIST_SIAMESE && !s->directed) && !pl->fold && debug_env("CFL_DEBUG_MIDGRAD") > 0 &&
                       (s->dist_type == CFL_DIST_PCD || s->dist_type == CFL_DIST_SIAMESE) && wide <= 64 && s->K <= 64 &&
                       !pl->mid_generic && !pl->mid_norow && pl->Rpad % 4 == 0 && (pl->lay.total / 4096 + 2) < 4096;
         pl->mg_flags = take(pl->midgrad ? (size_t)pl->Rpad / 4 + pl->nregblocks + 64 : 0);
@@ -4517,8 +4617,10 @@ static int run_pairs(const CflShape *s, const CflNorm *norm, const CflLossCfg *l
             mg.early_x = debug_env("CFL_DEBUG_MIDGRAD") != 2;
             hipLaunchKernelGGL(cfl_midgrad_half_kernel, dim3(mg.first_contr + nj * mg.ntile), dim3(256),
                                4 * 4 * 4 * 64 * sizeof(f32x4), st, mg);
-        } else if (pl.grad_half)
+        } else if (pl.grad_half && pl.P == 1 && !paired)
             hipLaunchKernelGGL(cfl_grad_x3_half_kernel, dim3(s->D / 32, 1, nj + 1), dim3(256), 4 * 4 * 4 * 64 * sizeof(f32x4), st, ga);
+        else if (pl.grad_half)
+            hipLaunchKernelGGL(cfl_grad_x3_half_split_kernel, dim3(s->D / 32, pl.P, nj + 1), dim3(256), 4 * 4 * 4 * 64 * sizeof(f32x4), st, ga);
         else if (pl.x3 && pl.Rpad / pl.P <= 8192)
             hipLaunchKernelGGL(cfl_grad_x3_kernel, grid, dim3(256), 4 * 4 * 4 * 64 * sizeof(f32x4), st, ga);
         else if (pl.x3)

@@ -647,6 +647,61 @@ def test_fused_gradient_tail_siamese_equals_finalize_kernel(B, D, L, wn, lkw, P,
     assert np.isfinite(res['fused'][-1][1].cpu().numpy()).all()
 
 
+@pytest.mark.parametrize('dist,B,D,K,L,wn,P', [
+    ('pcd', 1536, 4096, 3, 20, False, 0),      # default plan: 32-d tiles, rows split in two (2048 < rows per side <= 6144)
+    ('pcd', 512, 1024, 3, 20, True, 2), ('pcd', 256, 576, 2, 7, False, 4), ('pcd', 1024, 2048, 5, 20, True, 2),
+    ('siamese', 512, 1024, 1, 256, True, 0),   # config 3's default: side 0's half tile published, side 1 finishes
+    ('siamese', 256, 576, 1, 40, True, 2), ('siamese', 128, 1024, 1, 20, False, 4), ('siamese', 64, 256, 1, 7, False, 1)])
+def test_half_tile_gradient_with_hand_off_equals_finalize_kernel(dist, B, D, K, L, wn, P, monkeypatch):
+    """cfl_grad_x3_half_kernel with a row split and / or the siamese pairing: the first P - 1 row ranges (and all of
+    side 0) publish their 32-d partial tile, the last row range finishes it (at most three published tiles per round
+    trip, summed in the finalize kernel's order).  P > 0 forces half tiles with that split (CFL_DEBUG_GRAD_HALF=1 +
+    CFL_DEBUG_P); P = 0 takes the plan's own choice, which must be the half-tile kernel for these shapes.
+    Bit-identical to the four-launch form over 200 steps."""
+    from cfl.engine import PairEngine
+    rng = np.random.RandomState(8)
+    cfg = O.EncoderCfg(D=D, L=L, K=K, dist_type=dist, style='cfl' if wn else 'dist')
+    params = O.init_encoder_params(cfg, rng, np.float32)
+    if wn:
+        params = {k: (v * (1.0 + 0.3 * rng.rand(*v.shape)).astype(np.float32) if k.endswith('/g') else v)
+                  for k, v in params.items()}
+    pool = [[torch.from_numpy(np.abs(rng.randn(B, D)).astype(np.float32) * 3).cuda() for _ in range(4)]
+            for _ in range(3)]
+    res = {}
+    if P:
+        monkeypatch.setenv('CFL_DEBUG_P', str(P))
+        monkeypatch.setenv('CFL_DEBUG_GRAD_HALF', '1')
+    for mode in ('fused', 'finalize'):
+        monkeypatch.setenv('CFL_DEBUG_NOFUSE', '0' if mode == 'fused' else '1')
+        H.reload_env()
+        eng = PairEngine(D, L, K, dist, weight_norm=cfg.weight_norm, has_bias=cfg.has_bias, norm=H.make_norm(1 / 8.0),
+                         loss=H.make_loss(reg_const=1e-3), params=params, batch_size=B)
+        snaps = []
+        for it in range(200):
+            eng.step(pool[it % 3])
+            if it in (0, 1, 7, 199):
+                snaps.append([t.clone() for t in (eng.theta, eng.m, eng.v, eng.grad, eng.scalars)])
+        eng.fwd_bwd(pool[1])
+        snaps.append([eng.grad.clone(), eng.scalars.clone(), eng.theta.clone()])
+        res[mode] = snaps
+    monkeypatch.undo()
+    H.reload_env()
+    for a, b in zip(res['fused'], res['finalize']):
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
+    assert np.isfinite(res['fused'][-1][1].cpu().numpy()).all()
+    # and against the 64-d / row-split kernel (different summation order across the split: close, not identical)
+    monkeypatch.setenv('CFL_DEBUG_GRAD_HALF', '-1')
+    H.reload_env()
+    eng = PairEngine(D, L, K, dist, weight_norm=cfg.weight_norm, has_bias=cfg.has_bias, norm=H.make_norm(1 / 8.0),
+                     loss=H.make_loss(reg_const=1e-3), params=params, batch_size=B)
+    eng.step(pool[0])
+    monkeypatch.undo()
+    H.reload_env()
+    ref = res['fused'][0]
+    assert float((eng.grad - ref[3]).abs().max()) <= 2e-5 * float(ref[3].abs().max())
+
+
 @pytest.mark.parametrize('dist,directed,wn,B,D,L,K,act,lkw', [
     ('monomer', False, True, 128, 1024, 64, 3, None, dict(pos_weight=0.0625, reg_const=1e-3)),
     ('monomer', False, False, 64, 512, 12, 2, 'tanh', dict(reg_const=1e-3)),
