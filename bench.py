@@ -587,7 +587,7 @@ def main():
             # (the library picks the weight-gradient form per shape: 32-d tiles when D/32 x jobs >= 256 workgroups --
             # without a row split up to 2048 rows per side, the headline shape; rows split in two up to 6144 --, else
             # 64-d tiles with row ranges)
-            'kernel': (('cfl_grad_x3_half_kernel' if 2 * B <= 2048 else 'cfl_grad_x3_half_split_kernel' if 2 * B <= 6144
+            'kernel': ((('cfl_grad_x3_half_kernel' if 2 * B <= 2048 else 'cfl_grad_x3_half_split_kernel' if 2 * B <= 6144
                         else 'cfl_grad_x3_kernel') if 256 <= (D // 32) * 2 <= 640 else 'cfl_grad_x3_kernel')
                        if dom == 'grad' and os.environ.get('CFL_EXACT_FP32', '0') in ('', '0') else 'cfl_%s_kernel' % dom),
             # `achieved` / `frac` are on the HBM roof (BASELINE's metric: input bytes); `binding_roof` names the roof
