@@ -124,8 +124,8 @@ def lib():
         C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_size_t, C.c_void_p]
     L.cfl_pair_train_step_idx.restype = C.c_int
     L.cfl_pair_train_steps_idx.argtypes = [
-        C.POINTER(CflShape), C.POINTER(CflNorm), C.POINTER(CflLossCfg), C.c_void_p, C.c_int64, C.c_void_p,
-        C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_char_p, C.c_int64, C.c_void_p,
+        C.POINTER(CflShape), C.POINTER(CflNorm), C.POINTER(CflLossCfg), C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
+        C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_char_p, C.c_int64, C.c_void_p,
         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float,
         C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_void_p, C.c_size_t, C.c_void_p]
     L.cfl_pair_train_steps_idx.restype = C.c_int
@@ -160,7 +160,7 @@ def lib():
     L.cfl_dp_adam.restype = C.c_int
     L.cfl_profile_enable.argtypes = [C.c_int]
     L.cfl_profile_read.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_int64)]
-    if L.cfl_version() != 2:
+    if L.cfl_version() != 3:
         raise CflHipError('libcfl_hip.so ABI version mismatch')
     _lib = L
     return L
@@ -312,8 +312,9 @@ def pair_train_steps_idx(shape, norm, loss, table, pos_pairs, neg_pairs, pos_hea
     b1p, b2p = C.c_float(beta1_power), C.c_float(beta2_power)
     sw = bytes(bytearray(int(bool(x)) for x in switched)) if switched is not None else None
     _check(lib().cfl_pair_train_steps_idx(
-        C.byref(shape), C.byref(norm), C.byref(loss), tp, trows, _dev(pos_pairs, torch.int32),
-        _dev(neg_pairs, torch.int32), int(pos_head), int(neg_head), int(batch_rows), int(shard_lo), int(rows), sw,
+        C.byref(shape), C.byref(norm), C.byref(loss), tp, trows, _dev(pos_pairs, torch.int32), int(pos_pairs.shape[0]),
+        _dev(neg_pairs, torch.int32), int(neg_pairs.shape[0]), int(pos_head), int(neg_head), int(batch_rows),
+        int(shard_lo), int(rows), sw,
         int(nsteps), _dev(theta), _dev(m), _dev(v), _dev(grad), _dev(scalars), float(lr), float(beta1),
         float(beta2), float(eps), C.byref(b1p), C.byref(b2p), workspace.data_ptr(),
         workspace.numel() * workspace.element_size(), _stream()))

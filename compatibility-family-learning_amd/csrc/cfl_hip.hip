@@ -4746,8 +4746,8 @@ extern "C" int cfl_pair_train_step_idx(const CflShape *shape, const CflNorm *nor
 // the values of the LAST step.  switched[i] != 0 swaps source and target of step i (data_switch,
 // cfl/input_data.py:575-577); NULL = never.
 extern "C" int cfl_pair_train_steps_idx(const CflShape *shape, const CflNorm *norm, const CflLossCfg *loss,
-                                        const float *table, int64_t table_rows, const int32_t *pos_pairs,
-                                        const int32_t *neg_pairs, int64_t pos_head, int64_t neg_head,
+                                        const float *table, int64_t table_rows, const int32_t *pos_pairs, int64_t n_pos,
+                                        const int32_t *neg_pairs, int64_t n_neg, int64_t pos_head, int64_t neg_head,
                                         int64_t batch_rows, int64_t shard_lo, int64_t rows,
                                         const uint8_t *switched, int64_t nsteps, float *theta, float *m, float *v,
                                         float *grad, float *scalars, float lr, float beta1, float beta2, float eps,
@@ -4760,6 +4760,10 @@ extern "C" int cfl_pair_train_steps_idx(const CflShape *shape, const CflNorm *no
     if (nsteps <= 0 || batch_rows <= 0 || rows <= 0 || shard_lo < 0 || shard_lo + rows > batch_rows ||
         pos_head < 0 || neg_head < 0)
         return set_err(CFL_E_SHAPE, "bad step window");
+    if (nsteps > (1ll << 40) / batch_rows || pos_head + nsteps * batch_rows > n_pos || neg_head + nsteps * batch_rows > n_neg)
+        return set_err(CFL_E_SHAPE, "step window runs past the pair lists: heads %lld / %lld + %lld steps x %lld rows, lists %lld / %lld",
+                       (long long)pos_head, (long long)neg_head, (long long)nsteps, (long long)batch_rows,
+                       (long long)n_pos, (long long)n_neg);
     float b1p = *beta1_power, b2p = *beta2_power;
     for (int64_t i = 0; i < nsteps; ++i) {
         const int32_t *ps = pos_pairs + 2 * (pos_head + i * batch_rows + shard_lo);

@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define CFL_ABI_VERSION 2
+#define CFL_ABI_VERSION 3
 
 /* error codes */
 #define CFL_OK 0
@@ -222,10 +222,11 @@ int cfl_pair_train_step_idx(const CflShape *shape, const CflNorm *norm, const Cf
  * cfl/bin/train_dist.py:77-87 between two read-backs of the display scalars.  lr_t is derived per step from the float32
  * power accumulators *beta1_power / *beta2_power (HOST floats, TF's beta1_power / beta2_power variables), which are
  * advanced by nsteps.  switched: HOST bytes [nsteps] (data_switch coin flips, cfl/input_data.py:575-577) or NULL.
- * grad / scalars hold the last step's values.                                                                   */
+ * grad / scalars hold the last step's values.  n_pos / n_neg: rows of the two pair lists; a window that runs past the
+ * end of either (head + nsteps * batch_rows > n) is rejected with CFL_E_SHAPE before anything is launched.         */
 int cfl_pair_train_steps_idx(const CflShape *shape, const CflNorm *norm, const CflLossCfg *loss,
-                             const float *table, int64_t table_rows, const int32_t *pos_pairs,
-                             const int32_t *neg_pairs, int64_t pos_head, int64_t neg_head, int64_t batch_rows,
+                             const float *table, int64_t table_rows, const int32_t *pos_pairs, int64_t n_pos,
+                             const int32_t *neg_pairs, int64_t n_neg, int64_t pos_head, int64_t neg_head, int64_t batch_rows,
                              int64_t shard_lo, int64_t rows, const uint8_t *switched, int64_t nsteps, float *theta,
                              float *m, float *v, float *grad, float *scalars, float lr, float beta1, float beta2,
                              float eps, float *beta1_power, float *beta2_power, void *workspace,

@@ -503,6 +503,20 @@ def test_step_windows_equal_single_indexed_steps(tmp_path):
     assert a.head_labeled_pos == b.head_labeled_pos and a.head_labeled_neg == b.head_labeled_neg
     assert np.array_equal(a.pairs_pos, b.pairs_pos) and np.array_equal(a.pairs_neg, b.pairs_neg)
     assert a._rng.rand() == b._rng.rand()
+    # a window that runs past the end of a pair list is rejected before anything is launched (the index arrays
+    # themselves would be read out of bounds; table indices are clamped, list positions cannot be)
+    win = ra.next_windows(B, 2)
+    while win is None:                 # (an epoch wrap is due: take it with a single step)
+        ea.step(ra.next_indexed(B))
+        win = ra.next_windows(B, 2)
+    before = ea.theta.clone()
+    with pytest.raises(H.CflHipError, match='past the pair lists'):
+        H.pair_train_steps_idx(ea.shape, ea.norm, ea.loss, win.table, win.pos_pairs, win.neg_pairs,
+                               win.pos_pairs.shape[0] - B, win.neg_head, win.batch_rows, win.shard_lo, win.rows, None, 2,
+                               ea.theta, ea.m, ea.v, ea.grad, ea.scalars, ea._workspace(win.rows, 2),
+                               np.float32(ea.lr), ea.beta1, ea.beta2, ea.eps, ea.beta1_power, ea.beta2_power)
+    torch.cuda.synchronize()
+    assert torch.equal(ea.theta, before)
 
 
 @pytest.mark.parametrize('D,L,K,n,act_norm', [(4096, 20, 3, 8192, False), (2048, 20, 5, 4500, False), (1088, 12, 2, 3000, True),
