@@ -1,8 +1,5 @@
-C3="--input-size 1024 --latent-size 256 --num-components 1 --dist-type siamese --caffe-margin 100 --weight-norm"
-C4="--input-size 2048 --latent-size 20 --num-components 5 --weight-norm --batch-size 1024"
-python tools/kernel_probe.py $C4 --tag c4 2>&1 | tail -1
-CFL_DEBUG_PROJ_X3=1 python tools/kernel_probe.py $C4 --tag c4_x3fwd 2>&1 | tail -1
-python tools/kernel_probe.py $C3 --tag c3 2>&1 | tail -1
-CFL_DEBUG_PROJ_X3=1 python tools/kernel_probe.py $C3 --tag c3_x3fwd 2>&1 | tail -1
-python tools/kernel_probe.py --tag hl 2>&1 | tail -1
-CFL_DEBUG_PROJ_X3=1 python tools/kernel_probe.py --tag hl_x3fwd 2>&1 | tail -1
+# forward forms at training batch sizes: default vs forced bf16x3 forward (its W-plane launch is the `colnorm` entry)
+for B in 1024 2048 3072 4096; do
+python tools/kernel_probe.py --batch-size $B --steps 200 --tag b${B} 2>&1 | tail -1
+CFL_DEBUG_PROJ_X3=1 python tools/kernel_probe.py --batch-size $B --steps 200 --tag b${B}_x3fwd 2>&1 | tail -1
+done
