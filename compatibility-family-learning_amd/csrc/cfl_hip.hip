@@ -4,7 +4,7 @@
 //
 // One training step = 3 launches on the caller's stream, for every model:
 //   proj       projection partials  Y_s = X[:, slice_s] . W[slice_s, :]  (fp32 MFMA, k-ordered: chunk-at-a-time or
-//              streaming form; bf16x3 with LDS-shared W planes from 8192 rows per side, after a small plane-split
+//              streaming form; bf16x3 with LDS-shared W planes from 4096 (scoring) / 3072 (training) rows per side, after a small plane-split
 //              launch; weight-norm: the column norms ride in the launch as an extra slice)
 //   mid        slice-sum + bias/scale/activation, distance, loss, dL/dY
 //              (+ extra blocks: L2-regulariser partial sums)
@@ -1011,7 +1011,7 @@ __global__ __launch_bounds__(256) void cfl_wplanes_kernel(WPlanesArgs w) {   // 
     for (int p = 0; p < 3; ++p) *(bf16x8 *)(dst + p * 512) = f[p];
 }
 
-template <int NT>
+template <int NT, bool KEEP>   // KEEP: x loaded with the default cache policy (training: the weight gradient re-reads it from the Infinity Cache)
 __device__ __forceinline__ void px3_unit(const Px3Args &a, const ProjJob &jb, int tile, int slice, char *smem) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1057,8 +1057,10 @@ __device__ __forceinline__ void px3_unit(const Px3Args &a, const ProjJob &jb, in
     auto loadA = [&](int q, f32x4 *dst) {
         const int qq = q < a.Kq ? q : a.Kq - 1;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)   // nt: x is read once by this launch -- keep it from displacing the W planes in L2
-            dst[i] = __builtin_nontemporal_load((const f32x4 *)(xrow[i] + qq * 32));   // (measured: -6 % scoring, -9 % at B = 8192)
+        for (int i = 0; i < 4; ++i) {   // nt: x is read once by this launch -- keep it from displacing the W planes in L2
+            if (KEEP) dst[i] = *(const f32x4 *)(xrow[i] + qq * 32);
+            else dst[i] = __builtin_nontemporal_load((const f32x4 *)(xrow[i] + qq * 32));   // (measured: -6 % scoring, -9 % at B = 8192)
+        }
     };
     // prologue: W of steps 0 .. AHEAD-1, x of steps 0 .. 3 (consumption order); own W pieces of step 0 landed, barrier
 #pragma unroll
@@ -1138,27 +1140,31 @@ __device__ __forceinline__ void px3_unit(const Px3Args &a, const ProjJob &jb, in
         }
 }
 
-extern "C" __global__ __launch_bounds__(256, 2) void cfl_proj_x3_kernel(Px3Args a_) {
-    CFL_KERNARG_IN_PLACE(Px3Args, a, a_);
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int w = blockIdx.x;
-    for (int i = 0;; ++i) {
-        // snake order over the heavy-to-light unit list (as the ring form)
-        const int base = (i >> 1) * 2 * a.nwg;
-        const int uid = (i & 1) ? base + 2 * a.nwg - 1 - w : base + w;
-        if (uid >= a.nunits) break;
-        const int per_job = a.tiles * a.S;
-        const int job = a.order[uid / per_job], rem = uid % per_job;
-        const int tile = rem / a.S, slice = rem % a.S;
-        const ProjJob &jb = a.job[job];
-        switch (jb.nt) {
-            case 1: px3_unit<1>(a, jb, tile, slice, smem); break;
-            case 2: px3_unit<2>(a, jb, tile, slice, smem); break;
-            case 3: px3_unit<3>(a, jb, tile, slice, smem); break;
-            default: px3_unit<4>(a, jb, tile, slice, smem); break;
-        }
+#define CFL_PROJ_X3_KERNEL(NAME, KEEP)                                                              \
+    extern "C" __global__ __launch_bounds__(256, 2) void NAME(Px3Args a_) {                             \
+        CFL_KERNARG_IN_PLACE(Px3Args, a, a_);                                                           \
+        extern __shared__ __attribute__((aligned(16))) char smem[];                                     \
+        const int w = blockIdx.x;                                                                       \
+        for (int i = 0;; ++i) {                                                                         \
+            /* snake order over the heavy-to-light unit list (as the ring form) */                      \
+            const int base = (i >> 1) * 2 * a.nwg;                                                      \
+            const int uid = (i & 1) ? base + 2 * a.nwg - 1 - w : base + w;                              \
+            if (uid >= a.nunits) break;                                                                 \
+            const int per_job = a.tiles * a.S;                                                          \
+            const int job = a.order[uid / per_job], rem = uid % per_job;                                \
+            const int tile = rem / a.S, slice = rem % a.S;                                              \
+            const ProjJob &jb = a.job[job];                                                             \
+            switch (jb.nt) {                                                                            \
+                case 1: px3_unit<1, KEEP>(a, jb, tile, slice, smem); break;                             \
+                case 2: px3_unit<2, KEEP>(a, jb, tile, slice, smem); break;                             \
+                case 3: px3_unit<3, KEEP>(a, jb, tile, slice, smem); break;                             \
+                default: px3_unit<4, KEEP>(a, jb, tile, slice, smem); break;                            \
+            }                                                                                           \
+        }                                                                                               \
     }
-}
+CFL_PROJ_X3_KERNEL(cfl_proj_x3_kernel, false)        // scoring, and training batches larger than the Infinity Cache
+CFL_PROJ_X3_KERNEL(cfl_proj_x3_keep_kernel, true)    // training: x stays cached for the weight gradient
+#undef CFL_PROJ_X3_KERNEL
 
 extern "C" __global__ __launch_bounds__(256) void cfl_proj_kernel(ProjArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -3911,10 +3917,15 @@ static int make_plan(const CflShape *s, int64_t rows, int groups, bool train, Pl
         const int ov = debug_env("CFL_DEBUG_PROJ_X3");
         const int tiles = (pl->R + 127) / 128;
         int rs = 1;
-        while (rs < 16 && njobs * tiles * rs < 512 && (s->D / 128) % (2 * rs) == 0 && s->D / (2 * rs) >= 512) rs *= 2;
+        const int want_units = debug_env("CFL_DEBUG_X3_UNITS") > 0 ? debug_env("CFL_DEBUG_X3_UNITS") : 384;
+        while (rs < 16 && njobs * tiles * rs < want_units && (s->D / 128) % (2 * rs) == 0 && s->D / (2 * rs) >= 512) rs *= 2;
         const int units = njobs * tiles * rs;
         const bool ok = s->D % 128 == 0 && (s->D / 128) % rs == 0 && units >= 256 && pl->x3;
-        if (ok && ov >= 0 && (ov > 0 || pl->R >= 8192)) {
+        // From 4096 rows per side for scoring calls (-7 % at 4096 pairs, +11 % at 2048), from 3072 (B >= 1536) in training --
+        // there x is loaded with the default cache policy while both sides are within reach of the Infinity Cache, so that
+        // the weight gradient's re-read hits it.  Bench medians, same box, step us with / without: B = 1536 69.2 / 76.3,
+        // 2048 81.0 / 84.0, 3072 109.2 / 117.5, 4096 140.8 / 145.2 (and 143.2 with streamed x loads)
+        if (ok && ov >= 0 && (ov > 0 || pl->R >= (train ? 3072 : 4096))) {
             pl->proj_x3 = true;
             pl->ring_tiles = tiles;
             pl->ring_units = units;
@@ -4219,7 +4230,10 @@ static int run_pairs(const CflShape *s, const CflNorm *norm, const CflLossCfg *l
             xa.tiles = pl.ring_tiles; xa.nunits = pl.ring_units; xa.nwg = pl.ring_nwg; xa.Kq = Q / pl.S;
             xa.norm = nd;
             ProfScope ps(st, CFL_K_PROJ);
-            hipLaunchKernelGGL(cfl_proj_x3_kernel, dim3(pl.ring_nwg), dim3(256), PX3_LDS_BYTES, st, xa);
+            // training with both sides' rows within reach of the 256 MB Infinity Cache: keep x for the weight gradient
+            const bool keep = train && 2.0 * pl.R * s->D * 4.0 <= (debug_env("CFL_DEBUG_X3_KEEP_MB") > 0 ? debug_env("CFL_DEBUG_X3_KEEP_MB") * 1e6 : 300e6) && debug_env("CFL_DEBUG_PROJ_X3_KEEP") >= 0;
+            if (keep) hipLaunchKernelGGL(cfl_proj_x3_keep_kernel, dim3(pl.ring_nwg), dim3(256), PX3_LDS_BYTES, st, xa);
+            else hipLaunchKernelGGL(cfl_proj_x3_kernel, dim3(pl.ring_nwg), dim3(256), PX3_LDS_BYTES, st, xa);
             if (cn_slice) {
                 ProjArgs pc = pa;
                 pc.job[0].nt = 0;

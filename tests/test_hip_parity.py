@@ -118,10 +118,14 @@ STEP_CASES = [
     ('cfl', 'pcd', 2048, 20, 5, None, 1024, 1.0, dict(pos_weight=0.25), False),
     ('cfl', 'siamese', 1024, 256, 1, None, 512, 31.9098,
      dict(use_threshold=False, caffe_margin=100.0, pos_weight=0.0625), False),
-    # large batches: 8192 rows per side take the bf16x3 forward with shared W planes, 16384 also the register row math
+    # large batches (narrow inputs: exact-fp32 forward; the bf16x3 forward needs >= 256 work units), 16384 rows also the register row math
     ('dist', 'pcd', 512, 20, 3, None, 4096, 58.388599, dict(), False),
     ('dist', 'pcd', 256, 10, 4, None, 8192, 58.388599, dict(reg_const=1e-3), False),
     ('cfl', 'pcd', 384, 20, 3, None, 4096, 31.9098, dict(pos_weight=0.25), False),
+    # training batches from 1536 rows on: bf16x3 forward with x kept in cache for the weight gradient (cfl_proj_x3_keep_kernel),
+    # half-tile weight gradient with the rows split in two
+    ('dist', 'pcd', 4096, 20, 3, None, 1600, 58.388599, dict(), False),
+    ('cfl', 'pcd', 2048, 20, 3, None, 2048, 31.9098, dict(pos_weight=0.25, reg_const=1e-3), False),
     # edge shapes: single row, odd batch, minimum D, many prototypes (40 column tiles)
     ('dist', 'pcd', 64, 3, 2, None, 1, 1.0, dict(), False),
     ('cfl', 'monomer', 64, 5, 3, None, 3, 1.0, dict(reg_const=1e-3), False),
@@ -524,7 +528,7 @@ def test_step_windows_equal_single_indexed_steps(tmp_path):
 def test_projection_forms_agree(D, L, K, n, act_norm, monkeypatch):
     """The forms of the forward projection on large scoring calls (a wave owns several 128-d chunks):
     chunk-at-a-time (proj_body), streaming (proj_stream_body), the loader / consumer ring (cfl_proj_ring_kernel, opt-in)
-    and the bf16x3 form with LDS-shared W planes (cfl_proj_x3_kernel: the default from 8192 rows per side).  The
+    and the bf16x3 form with LDS-shared W planes (cfl_proj_x3_kernel: the default from 4096 rows per side in scoring calls).  The
     streaming form must reproduce the chunk-at-a-time scores BIT FOR BIT (same k-ordered FMA chains, same summation
     order); the ring sums a d slice in one wave and the bf16x3 form accumulates eight exact partial products per
     32-d block, so both are held to fp32 rounding of the scores -- and the bf16x3 form additionally to an error
@@ -659,6 +663,35 @@ def test_fused_gradient_tail_siamese_equals_finalize_kernel(B, D, L, wn, lkw, P,
         for x, y in zip(a, b):
             assert torch.equal(x, y)
     assert np.isfinite(res['fused'][-1][1].cpu().numpy()).all()
+
+
+def test_training_forward_form_follows_the_batch_size(monkeypatch):
+    """From 3072 rows per side (B = 1536) a training step projects through the bf16x3 forward (its W-plane launch shows
+    up as the extra `colnorm` entry of the library's profile), below that through the exact-fp32 forward; the switch
+    moves the step's scalars by fp32 rounding only (CFL_DEBUG_PROJ_X3=-1 forces the fp32 forward at the large batch)."""
+    from cfl.engine import PairEngine
+    rng = np.random.RandomState(3)
+    cfg = O.EncoderCfg(D=4096, L=20, K=3)
+    params = O.init_encoder_params(cfg, rng, np.float32)
+    out = {}
+    for B, env in ((512, None), (1536, None), (1536, '-1')):
+        if env is not None:
+            monkeypatch.setenv('CFL_DEBUG_PROJ_X3', env)
+        H.reload_env()
+        batch = [torch.from_numpy(np.abs(np.random.RandomState(B).randn(B, 4096)).astype(np.float32) * 13).cuda() for _ in range(4)]
+        eng = PairEngine(4096, 20, 3, norm=H.make_norm(1 / 58.388599), loss=H.make_loss(), params=params, batch_size=B)
+        H.profile_enable(True)
+        eng.step(batch)
+        torch.cuda.synchronize()
+        H.profile_enable(False)
+        out[(B, env)] = (set(H.profile_read()), eng.scalars.clone(), eng.grad.clone())
+    monkeypatch.undo()
+    H.reload_env()
+    assert 'colnorm' not in out[(512, None)][0]
+    assert 'colnorm' in out[(1536, None)][0] and 'colnorm' not in out[(1536, '-1')][0]
+    a, b = out[(1536, None)], out[(1536, '-1')]
+    assert float((a[1] - b[1]).abs().max()) <= 2e-6 * max(1.0, float(b[1].abs().max()))
+    assert float((a[2] - b[2]).abs().max()) <= 2e-5 * float(b[2].abs().max())
 
 
 @pytest.mark.parametrize('dist,B,D,K,L,wn,P', [
