@@ -2120,6 +2120,21 @@ __device__ __forceinline__ void grad_body_x3_half(const GradJob &jb, const GradA
     const float *dyl = jb.dyf + ((size_t)(kq >> 1) * 256 + (2 * (kq & 1) * 16 + i16) * 4);
     const RowSrc rs = jb.side ? a.rows[1] : a.rows[0];
     const long long *lrow = (const long long *)lds;   // row addresses of the whole batch, staged once (grad_body_x3)
+    auto loaddy = [&](int p0, f32x4 (*dyr)[NT][2]) {
+#pragma unroll
+        for (int r2 = 0; r2 < 2; ++r2)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const float *q = dyl + ((size_t)nt * RG + (p0 >> 4) + 2 * r2) * 256;
+                dyr[r2][nt][0] = *(const f32x4 *)q;
+                dyr[r2][nt][1] = *(const f32x4 *)(q + 64);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // the first chunk's dL/dy does not depend on the row addresses: requested before they are staged, so that its
+    // latency overlaps the index loads of the indexed entry points (and the staging barrier)
+    f32x4 dyr[2][NT][2];
+    if (!mg && rbeg < rstop) loaddy(rbeg, dyr);
     {
         long long *w = (long long *)lds;
         for (int r = threadIdx.x; r < a.Rpad; r += 256) w[r] = row_ptr(rs, r, a.B, a.R, a.D) - rs.x0;
@@ -2147,17 +2162,8 @@ __device__ __forceinline__ void grad_body_x3_half(const GradJob &jb, const GradA
         if (!mg->early_x && rbeg < rstop) loadx(rbeg, xfirst);
     }
     for (int p0 = rbeg; p0 < rstop; p0 += 64) {
-        f32x4 dyr[2][NT][2];
         f32x2 xr[2][8];
-#pragma unroll
-        for (int r2 = 0; r2 < 2; ++r2)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const float *q = dyl + ((size_t)nt * RG + (p0 >> 4) + 2 * r2) * 256;
-                dyr[r2][nt][0] = *(const f32x4 *)q;
-                dyr[r2][nt][1] = *(const f32x4 *)(q + 64);
-            }
-        __builtin_amdgcn_sched_barrier(0);
+        if (mg || p0 != rbeg) loaddy(p0, dyr);
         if (mg && p0 == rbeg) {
 #pragma unroll
             for (int r2 = 0; r2 < 2; ++r2)
