@@ -2136,9 +2136,10 @@ __device__ __forceinline__ void grad_body_x3_half(const GradJob &jb, const GradA
     f32x4 dyr[2][NT][2];
     if (!mg && rbeg < rstop) loaddy(rbeg, dyr);
     {
+        // every wave stages the addresses of ITS rows only: LDS operations of one wave are ordered, no workgroup barrier
         long long *w = (long long *)lds;
-        for (int r = threadIdx.x; r < a.Rpad; r += 256) w[r] = row_ptr(rs, r, a.B, a.R, a.D) - rs.x0;
-        __syncthreads();
+        for (int r = rbeg + lane; r < rend; r += 64) w[r] = row_ptr(rs, r, a.B, a.R, a.D) - rs.x0;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
     bool mg_lost = false;
     f32x2 xfirst[2][8];
