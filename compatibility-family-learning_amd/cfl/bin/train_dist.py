@@ -65,8 +65,8 @@ class DeferredScalars(object):
         host[:H.S_COUNT].copy_(eng.scalars, non_blocking=True)
         # the validation scores travel as they are (2 x n floats); the accuracy is counted on the host when the
         # slot is read -- no elementwise / reduction launches on the training stream
-        host[H.S_COUNT:H.S_COUNT + n].copy_(eng.scores(table, streams.pair(0)), non_blocking=True)
-        host[H.S_COUNT + n:].copy_(eng.scores(table, streams.pair(1)), non_blocking=True)
+        # (positive and negative pairs in ONE scoring call: two launches and one copy instead of four and two)
+        host[H.S_COUNT:].copy_(eng.scores_pos_neg(table, streams), non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
         self.pending.append((step, host, ev, eng._scalar_scale, n))

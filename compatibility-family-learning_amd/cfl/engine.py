@@ -259,6 +259,12 @@ class PairEngine(object):
         ws = self._workspace(xs.shape[0], 1)
         return H.pair_scores(self.shape, self.norm, xs, xt, self.theta, ws)
 
+    def scores_pos_neg(self, table, streams):
+        """Scores of an indexed labeled batch, positive pairs then negative pairs, in one library call
+        (the validation fetch of the training loop): [2 n]."""
+        ws = self._workspace(streams.n, 2)
+        return H.pair_scores_idx4(self.shape, self.norm, table, streams, self.theta, ws)
+
     # -- checkpoint payload --------------------------------------------------
     def state_dict(self):
         return dict(theta=self.theta.cpu(), m=self.m.cpu(), v=self.v.cpu(),

@@ -66,7 +66,7 @@ EXPORTS = ('cfl_version', 'cfl_last_error', 'cfl_layout', 'cfl_workspace_bytes',
            'cfl_gather_rows', 'cfl_profile_enable', 'cfl_profile_read', 'cfl_pair_input_grad',
            'cfl_conv_workspace_bytes', 'cfl_conv_uses_direct_kernel', 'cfl_conv2d_wn_fwd', 'cfl_conv2d_wn_bwd',
            'cfl_pair_scores_idx', 'cfl_pair_step_fwd_bwd_idx', 'cfl_pair_train_step_idx', 'cfl_reload_env',
-           'cfl_pair_train_steps_idx', 'cfl_mt19937_reshuffle', 'cfl_dp_push', 'cfl_dp_wait', 'cfl_dp_adam')
+           'cfl_pair_train_steps_idx', 'cfl_pair_scores_idx4', 'cfl_mt19937_reshuffle', 'cfl_dp_push', 'cfl_dp_wait', 'cfl_dp_adam')
 
 KERNEL_NAMES = ('colnorm', 'proj', 'mid', 'grad', 'finalize', 'adam', 'gather')
 K_COUNT = 8
@@ -113,6 +113,8 @@ def lib():
         C.POINTER(CflShape), C.POINTER(CflNorm), C.c_void_p, C.c_int64, C.POINTER(C.c_void_p), C.c_int64,
         C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     L.cfl_pair_scores_idx.restype = C.c_int
+    L.cfl_pair_scores_idx4.argtypes = L.cfl_pair_scores_idx.argtypes
+    L.cfl_pair_scores_idx4.restype = C.c_int
     L.cfl_pair_step_fwd_bwd_idx.argtypes = [
         C.POINTER(CflShape), C.POINTER(CflNorm), C.POINTER(CflLossCfg), C.c_void_p, C.c_int64,
         C.POINTER(C.c_void_p), C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
@@ -283,6 +285,18 @@ def pair_scores_idx(shape, norm, table, streams, theta, workspace, scores=None, 
         C.byref(shape), C.byref(norm), tp, rows, streams.arr, streams.stride, streams.n, _dev(theta),
         _dev(scores), _dev(dists) if dists is not None else None, workspace.data_ptr(),
         workspace.numel() * workspace.element_size(), _stream()))
+    return scores
+
+
+def pair_scores_idx4(shape, norm, table, streams, theta, workspace, scores=None):
+    """Scores of the (stream 0, stream 1) pairs followed by the (stream 2, stream 3) pairs in one call
+    (cfl_pair_scores_idx4): [2 n]."""
+    if scores is None:
+        scores = torch.empty(2 * streams.n, dtype=torch.float32, device=table.device)
+    tp, rows = _table(table)
+    _check(lib().cfl_pair_scores_idx4(
+        C.byref(shape), C.byref(norm), tp, rows, streams.arr, streams.stride, streams.n, _dev(theta),
+        _dev(scores), None, workspace.data_ptr(), workspace.numel() * workspace.element_size(), _stream()))
     return scores
 
 

@@ -4733,6 +4733,16 @@ extern "C" int cfl_pair_scores_idx(const CflShape *shape, const CflNorm *norm, c
                      workspace_bytes, (hipStream_t)stream, nullptr, &is);
 }
 
+extern "C" int cfl_pair_scores_idx4(const CflShape *shape, const CflNorm *norm, const float *table,
+                                    int64_t table_rows, const int32_t *const idx4[4], int64_t idx_stride, int64_t n,
+                                    const float *theta, float *scores, float *dists, void *workspace,
+                                    size_t workspace_bytes, cfl_stream_t stream) {
+    if (!scores) return set_err(CFL_E_SHAPE, "scores is NULL");
+    IndexSrc is = {table, table_rows, idx4, idx_stride};
+    return run_pairs(shape, norm, nullptr, nullptr, 2, n, theta, nullptr, nullptr, scores, dists, workspace,
+                     workspace_bytes, (hipStream_t)stream, nullptr, &is);
+}
+
 extern "C" int cfl_pair_step_fwd_bwd_idx(const CflShape *shape, const CflNorm *norm, const CflLossCfg *loss,
                                          const float *table, int64_t table_rows, const int32_t *const idx4[4],
                                          int64_t idx_stride, int64_t B, const float *theta, float *grad,

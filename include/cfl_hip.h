@@ -205,6 +205,13 @@ int cfl_pair_scores_idx(const CflShape *shape, const CflNorm *norm, const float 
                         const int32_t *const idx2[2], int64_t idx_stride, int64_t n, const float *theta,
                         float *scores, float *dists, void *workspace, size_t workspace_bytes,
                         cfl_stream_t stream);
+/* Scores of the n (idx4[0], idx4[1]) pairs followed by the n (idx4[2], idx4[3]) pairs in ONE projection + row-math
+ * launch pair: scores / dists [2 n].  The validation fetch `val_s_accuracy` of cfl/bin/train_dist.py:52-56, 81-82 scores a
+ * positive and a negative batch; workspace: cfl_workspace_bytes(shape, n, 2).                                      */
+int cfl_pair_scores_idx4(const CflShape *shape, const CflNorm *norm, const float *table, int64_t table_rows,
+                         const int32_t *const idx4[4], int64_t idx_stride, int64_t n, const float *theta,
+                         float *scores, float *dists, void *workspace, size_t workspace_bytes,
+                         cfl_stream_t stream);
 int cfl_pair_step_fwd_bwd_idx(const CflShape *shape, const CflNorm *norm, const CflLossCfg *loss,
                               const float *table, int64_t table_rows, const int32_t *const idx4[4],
                               int64_t idx_stride, int64_t B, const float *theta, float *grad, float *scalars,

@@ -665,6 +665,33 @@ def test_fused_gradient_tail_siamese_equals_finalize_kernel(B, D, L, wn, lkw, P,
     assert np.isfinite(res['fused'][-1][1].cpu().numpy()).all()
 
 
+def test_scores_of_a_labeled_batch_in_one_call():
+    """cfl_pair_scores_idx4 (positive pairs then negative pairs of an indexed labeled batch, one projection + row-math
+    launch pair: the validation fetch of the training loop) == two cfl_pair_scores_idx calls, to fp32 rounding (the d
+    split of the projection follows the row count, so the slice sums may associate differently)."""
+    from cfl.engine import PairEngine
+    rng = np.random.RandomState(12)
+    D, L, K, n, rows = 1024, 20, 3, 300, 5000
+    cfg = O.EncoderCfg(D=D, L=L, K=K)
+    eng = PairEngine(D, L, K, norm=H.make_norm(1 / 16.0), loss=H.make_loss(), params=_mk(cfg, rng))
+    table = torch.from_numpy(np.abs(rng.randn(rows, D)).astype(np.float32) * 4).cuda()
+    idx = [torch.from_numpy(rng.randint(0, rows, size=n).astype(np.int32)).cuda() for _ in range(4)]
+    streams = H.IndexStreams.from_tensors(idx)
+    both = eng.scores_pos_neg(table, streams).clone()
+    sp = eng.scores(table, streams.pair(0)).clone()
+    sn = eng.scores(table, streams.pair(1)).clone()
+    ref = torch.cat([sp, sn])
+    assert both.shape == (2 * n,)
+    assert float((both - ref).abs().max()) <= 1e-5 * max(1.0, float(ref.abs().max()))
+    # and against the oracle, through the dense rows the indices select
+    x = [table[i.long()].cpu().numpy().astype(np.float64) / 16.0 for i in idx]
+    p, _, thr = H.unpack_theta(eng.shape, eng.theta)
+    for lo, (a, b) in ((0, (x[0], x[1])), (n, (x[2], x[3]))):
+        want = np.asarray(O.pair_scores(cfg, _to64(p), np.float64(thr), a, b)).reshape(-1)
+        got = both[lo:lo + n].cpu().numpy()
+        assert np.abs(got - want).max() <= 1e-5 * max(1.0, np.abs(want).max())
+
+
 def test_training_forward_form_follows_the_batch_size(monkeypatch):
     """From 3072 rows per side (B = 1536) a training step projects through the bf16x3 forward (its W-plane launch shows
     up as the extra `colnorm` entry of the library's profile), below that through the exact-fp32 forward; the switch
