@@ -21,7 +21,7 @@ relays rank 0's line); under torchrun (WORLD_SIZE set) it is one of the ranks.
 Timing: W untimed warm-up steps (at least one pass over the pool), then R repeats of
 EXACTLY K steps, each repeat bracketed by barrier + synchronize on both sides and reduced
 with MAX over ranks; `ms_per_step` / `value` come from the MEDIAN repeat (min / max are
-in the line), so the timed work is >= ~0.1 s whatever K is.
+in the line), so the timed work is ~1 s whatever K is.
 
 Prints ONE JSON line (rank 0) with the driver's contract fields plus `roofline`
 (dominant kernel, HIP-event timed), `roofline_eval` (scoring kernels), `cli_loop`
@@ -57,7 +57,7 @@ def parse():
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--warmup', type=int, default=50)
     ap.add_argument('--repeats', type=int, default=0, help='timed repeats of the K-step region (0 = auto: >= 50 '
-                    'and enough for ~0.1 s of timed work)')
+                    'and enough for ~1 s of timed work)')
     ap.add_argument('--batch-size', type=int, default=512)
     ap.add_argument('--input-size', type=int, default=4096)
     ap.add_argument('--num-components', type=int, default=3)
@@ -199,6 +199,22 @@ def eval_auc(args, eng, device, teacher):
             'abs_diff': float(abs(hip['auc'] - ora['auc'])), 'accuracy_hip': round(hip['accuracy'], 6),
             'accuracy_oracle': round(ora['accuracy'], 6),
             'max_abs_score_diff': float(max(np.abs(sp - op).max(), np.abs(sn - on).max()))}
+
+
+def _rocprof_avg_us(kernel_name):
+    """Average launch duration (us) of `kernel_name` in the committed rocprofv3 summary of this command
+    (profiles/kernel_stats.csv = the latest profiles/r*_kernel_stats.csv, copied by tools/measure.sh): the figure the
+    event-timed interval of this run is to be compared with."""
+    import csv
+    path = os.path.join(ROOT, 'profiles', 'kernel_stats.csv')
+    try:
+        with open(path) as f:
+            for row in csv.DictReader(f):
+                if row.get('Name', '').split('(')[0].strip() == kernel_name:
+                    return round(float(row['AverageNs']) / 1e3, 3)
+    except Exception:
+        return None
+    return None
 
 
 def _eval_traffic():
@@ -394,6 +410,14 @@ def cli_loop(args, device):
         train_steps(model, train_src, val_src, B, None, n, on_scalars)
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
+        # the reference's cadence (--scalar-every 1): a validation batch scored and the scalars read back every iteration
+        n1 = 1000
+        train_steps(model, train_src, val_src, B, None, 50, on_scalars, scalar_every=1)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        train_steps(model, train_src, val_src, B, None, n1, on_scalars, scalar_every=1)
+        torch.cuda.synchronize()
+        el1 = time.perf_counter() - t0
         # the same loop with the host side only (index stream + call set-up, no kernels awaited): is the loop
         # GPU-bound or host-bound?
         t0 = time.perf_counter()
@@ -402,6 +426,9 @@ def cli_loop(args, device):
         host_idx_s = (time.perf_counter() - t0) / n
         return {'steps_per_s': round(n / el, 1), 'us_per_step': round(1e6 * el / n, 3),
                 'triplets_per_s': round(n * B / el, 1), 'steps': n,
+                'every1': {'us_per_step': round(1e6 * el1 / n1, 3), 'triplets_per_s': round(n1 * B / el1, 1), 'steps': n1,
+                           'what': '--scalar-every 1: the reference cadence, one validation fetch per iteration '
+                                   '(cfl/bin/train_dist.py:79-86 of the reference)'},
                 'table_mib': int(train_src.table.numel() * 4 >> 20), 'pairs': int(aux.train.pairs_pos.shape[0]),
                 'host_index_stream_us_per_step': round(1e6 * host_idx_s, 3),
                 'dataset_prep_s': round(prep_s, 1), 'final_loss': round(float(seen[-1][1]), 6),
@@ -476,12 +503,13 @@ def main():
     run(warm, 0)
     sync_all()
     _trace('warm-up done')
-    # short calibration (untimed for the result): how many repeats make ~0.1 s of timed work
+    # short calibration (untimed for the result): how many repeats make ~1 s of timed work (long enough for an external
+    # utilisation sampler to see the GPU busy; the median repeat is what is reported)
     t0 = time.perf_counter()
     run(args.steps, warm)
     sync_all()
     est = max(time.perf_counter() - t0, 1e-6)
-    repeats = args.repeats if args.repeats > 0 else int(min(2000, max(50, np.ceil(0.1 / est))))
+    repeats = args.repeats if args.repeats > 0 else int(min(5000, max(50, np.ceil(1.0 / est))))
     if world > 1:
         rt = torch.tensor([repeats], device=device, dtype=torch.int64)
         dist.broadcast(rt, 0)
@@ -535,10 +563,11 @@ def main():
                 'final_loss': round(scal['total'], 6),
                 'timing': 'median of %d repeats of the %d-step region, each bracketed by barrier + synchronize and '
                           'reduced with MAX over ranks' % (repeats, args.steps),
-                'arithmetic': 'fp32 everywhere; the weight-gradient contraction runs on the bf16 matrix cores with '
-                              'every fp32 operand split exactly in three bf16 values (six partial products, fp32 '
-                              'accumulate; error vs fp64 equal to the fp32-MFMA kernel, tests/test_hip_parity.py); '
-                              'CFL_EXACT_FP32=1 selects k-ordered fp32 MFMA for it',
+                'arithmetic': 'fp32 storage and accumulation everywhere; both contractions (projection of the fused '
+                              'single-GPU step, weight gradient) run on the bf16 matrix cores with every fp32 operand '
+                              'split exactly in three bf16 values (round-to-nearest parts, six partial products, fp32 '
+                              'accumulate; error vs fp64 equal to the fp32-MFMA kernels, tests/test_hip_parity.py, '
+                              'tests/test_planes_and_errors_gpu.py); CFL_EXACT_FP32=1 selects k-ordered fp32 MFMA',
             },
         }
 
@@ -583,13 +612,23 @@ def main():
         step_traffic = sum(v for k, v in traffic_all.items() if k in ('proj', 'mid', 'grad', 'finalize') and
                            isinstance(v, (int, float))) or None
         P_params = D * L * (K + 1) + L * (K + 1) + 1
+        # (the library picks the forms per shape.  Weight gradient: 32-d tiles when D/32 x jobs >= 256 workgroups -- without a
+        # row split up to 2048 rows per side, the headline shape; rows split in two up to 6144 --, else 64-d tiles with row
+        # ranges.  Projection of the fused single-GPU step: bf16x3 on kept planes, chunk-at-a-time below 3072 rows per side)
+        exact = os.environ.get('CFL_EXACT_FP32', '0') not in ('', '0')
+        if dom == 'grad':
+            kname = 'cfl_grad_kernel' if exact else (
+                ('cfl_grad_x3_half_kernel' if 2 * B <= 2048 else 'cfl_grad_x3_half_split_kernel' if 2 * B <= 6144
+                 else 'cfl_grad_x3_kernel') if 256 <= (D // 32) * 2 <= 640 else 'cfl_grad_x3_kernel')
+        else:
+            kname = 'cfl_proj_kernel' if (exact or world > 1) else ('cfl_proj_bx3_kernel' if 2 * B < 3072 else 'cfl_proj_x3_keep_kernel')
+        rp_us = _rocprof_avg_us(kname)
         out['roofline'] = {
-            # (the library picks the weight-gradient form per shape: 32-d tiles when D/32 x jobs >= 256 workgroups --
-            # without a row split up to 2048 rows per side, the headline shape; rows split in two up to 6144 --, else
-            # 64-d tiles with row ranges)
-            'kernel': ((('cfl_grad_x3_half_kernel' if 2 * B <= 2048 else 'cfl_grad_x3_half_split_kernel' if 2 * B <= 6144
-                        else 'cfl_grad_x3_kernel') if 256 <= (D // 32) * 2 <= 640 else 'cfl_grad_x3_kernel')
-                       if dom == 'grad' and os.environ.get('CFL_EXACT_FP32', '0') in ('', '0') else 'cfl_%s_kernel' % dom),
+            'kernel': kname,
+            # the committed rocprofv3 average of the same kernel (profiles/kernel_stats.csv, builder box) and the fraction it
+            # gives: the event-timed `frac` below is lower because the event pairs perturb the stream (see `timing`)
+            'rocprof_avg_us': rp_us,
+            'rocprof_frac': round(alg_bytes / (rp_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if rp_us else None,
             # `achieved` / `frac` are on the HBM roof (BASELINE's metric: input bytes); `binding_roof` names the roof
             # the dominant kernel sits closer to -- at L=20 that is the fp32-equivalent matrix-core roof (`mfma_f32`)
             'bound': 'hbm',
@@ -642,6 +681,7 @@ def main():
             torch.cuda.empty_cache()
             cl = cli_loop(args, device)
             cl['vs_value'] = round(cl['triplets_per_s'] / out['value'], 4)
+            cl['vs_value_every1'] = round(cl['every1']['triplets_per_s'] / out['value'], 4)
             out['cli_loop'] = cl
     elif rank == 0:
         out['cpu_baseline'] = None

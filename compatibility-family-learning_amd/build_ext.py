@@ -1,27 +1,48 @@
-"""Build libcfl_hip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+"""Build libcfl_hip.so for gfx950 with hipcc (cross-compiles without a GPU).
+
+Every source is compiled to its own object (in parallel, rebuilt only when it or a header it may include changed)
+and the objects are linked into lib/libcfl_hip.so."""
 import os
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SRCS = [os.path.join(HERE, 'csrc', f) for f in ('cfl_hip.hip', 'cfl_conv.hip', 'cfl_gan.hip', 'cfl_eval.hip', 'cfl_dp.hip')]
+NAMES = ('cfl_hip', 'cfl_conv', 'cfl_gan', 'cfl_eval', 'cfl_dp')
+SRCS = [os.path.join(HERE, 'csrc', n + '.hip') for n in NAMES]
 SRC = SRCS[0]
+HEADERS = [os.path.join(HERE, 'csrc', 'gemm_gather.h'), os.path.join(HERE, 'csrc', 'conv_halo.h'),
+           os.path.join(os.path.dirname(HERE), 'include', 'cfl_hip.h')]
+OBJ_DIR = os.path.join(HERE, 'build')
 OUT = os.path.join(HERE, 'lib', 'libcfl_hip.so')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+FLAGS = ['-O3', '--offload-arch=gfx950', '-std=c++17', '-fPIC']
+
+
+def _stale(target, deps):
+    return not os.path.exists(target) or any(os.path.getmtime(target) < os.path.getmtime(d) for d in deps)
 
 
 def build(force=False, verbose=False):
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
-    deps = SRCS + [os.path.join(HERE, 'csrc', 'gemm_gather.h'), os.path.join(HERE, 'csrc', 'conv_halo.h'),
-                   os.path.join(os.path.dirname(HERE), 'include', 'cfl_hip.h')]
-    if (not force and os.path.exists(OUT)
-            and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in deps)):
-        return OUT
-    cmd = [HIPCC, '-O3', '--offload-arch=gfx950', '-std=c++17', '-shared', '-fPIC',
-           ] + SRCS + ['-o', OUT]
-    if verbose:
-        cmd.insert(1, '-Rpass-analysis=kernel-resource-usage')
-    subprocess.check_call(cmd)
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    extra = [f for f in os.environ.get('CFL_HIPCC_FLAGS', '').split() if f]
+    jobs = []
+    for src, name in zip(SRCS, NAMES):
+        obj = os.path.join(OBJ_DIR, name + '.o')
+        if force or extra or _stale(obj, [src] + HEADERS + [os.path.abspath(__file__)]):
+            cmd = [HIPCC] + FLAGS + extra + ['-c', src, '-o', obj]
+            if verbose:
+                cmd.insert(1, '-Rpass-analysis=kernel-resource-usage')
+            jobs.append(cmd)
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(len(jobs), 5)) as ex:
+            for rc, cmd in zip(ex.map(subprocess.call, jobs), jobs):
+                if rc:
+                    raise subprocess.CalledProcessError(rc, cmd)
+    objs = [os.path.join(OBJ_DIR, n + '.o') for n in NAMES]
+    if jobs or _stale(OUT, objs):
+        subprocess.check_call([HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC'] + objs + ['-o', OUT])
     return OUT
 
 

@@ -24,7 +24,9 @@ from ..utils import (IncrementalAverage, Saver, dist_eval, load_best_stats, load
 
 logger = logging.getLogger(__name__)
 
-SCALAR_EVERY = 25  # host read-back cadence of the display scalars (steps)
+SCALAR_EVERY = 25  # default host read-back cadence of the display scalars and the validation fetch (steps); --scalar-every N
+                   # changes it, N = 1 is the reference's cadence (one val_s_accuracy fetch per iteration,
+                   # cfl/bin/train_dist.py:79-86: the validation SemiDataSet then advances exactly as the reference's does)
 
 
 class DeferredScalars(object):
@@ -80,6 +82,8 @@ class DeferredScalars(object):
             step, host, ev, scale, n = self.pending.pop(0)
             ev.synchronize()
             vals = host.numpy()
+            # a lost in-launch hand-off (sticky error word) raises here, one cadence after it happened at the latest
+            self.model.engine.check_health(vals[:H.S_COUNT])
             s = dict(zip(H.SCALAR_NAMES, (float(x) * scale for x in vals[:H.S_COUNT])))
             # batch_accuracy (cfl/bin/train_dist.py:52-56 of the reference: mean of [s_pos > 0] and [s_neg <= 0])
             sp, sn = vals[H.S_COUNT:H.S_COUNT + n], vals[H.S_COUNT + n:]
@@ -90,19 +94,21 @@ class DeferredScalars(object):
         self.poll(wait=True)
 
 
-def train_steps(model, train_src, val_src, batch_size, shard, n_steps, on_scalars=None, progress=None):
+def train_steps(model, train_src, val_src, batch_size, shard, n_steps, on_scalars=None, progress=None,
+                scalar_every=SCALAR_EVERY):
     """The iterations of the training loop (cfl/bin/train_dist.py:77-87 of the reference: one
     ``sess.run([summary, [s_optim], s_accuracy, val_s_accuracy])`` per iteration): the labeled batches of the
     seeded index stream -- as positions into the resident feature table -- go through the fused training step;
-    the display scalars (train / validation accuracy) are read back every SCALAR_EVERY iterations, without stalling
+    the display scalars (train / validation accuracy) are read back every `scalar_every` iterations, without stalling
     the stream (DeferredScalars).  The iterations between two read-backs are one engine call over windows of the
     device pair lists (on one GPU one library call; data parallel: the same windows with the gradient exchange inside
     the loop, PairEngine.step_windows)."""
     i = 0
+    every = max(1, int(scalar_every))
     deferred = DeferredScalars(model, on_scalars) if on_scalars is not None else None
     while i < n_steps:
         # the chunk ends with the next iteration whose scalars are read back (0, 25, 50, ..., and the last one)
-        stop = min((i + SCALAR_EVERY - 1) // SCALAR_EVERY * SCALAR_EVERY, n_steps - 1) + 1
+        stop = min((i + every - 1) // every * every, n_steps - 1) + 1
         win = train_src.next_windows(batch_size, stop - i, shard)
         if win is not None:
             model.engine.step_windows(win)
@@ -114,13 +120,14 @@ def train_steps(model, train_src, val_src, batch_size, shard, n_steps, on_scalar
         i += done
         if progress is not None:
             progress.update(done)
-        if deferred is not None and (last % SCALAR_EVERY == 0 or last == n_steps - 1):
+        if deferred is not None and (last % every == 0 or last == n_steps - 1):
             deferred.record(last, val_src.next_indexed(batch_size))
     if deferred is not None:
         deferred.flush()
 
 
-def train_loop(model, data, aux, batch_size, start_epoch, epochs, log_dir, checkpoint_dir, saver):
+def train_loop(model, data, aux, batch_size, start_epoch, epochs, log_dir, checkpoint_dir, saver,
+               scalar_every=SCALAR_EVERY):
     best_saver = Saver()
     nb_train = max(data.train.num_examples_labeled_pos, data.train.num_examples_labeled_neg)
     logger.warning('%d examples', nb_train)
@@ -145,20 +152,33 @@ def train_loop(model, data, aux, batch_size, start_epoch, epochs, log_dir, check
         t.set_description('epoch {}'.format(e))
         train_avg, val_avg = IncrementalAverage(), IncrementalAverage()
 
-        def on_scalars(i, s, val_acc, e=e, t=t, train_avg=train_avg, val_avg=val_avg):
+        bad = []
+
+        def on_scalars(i, s, val_acc, e=e, t=t, train_avg=train_avg, val_avg=val_avg, bad=bad):
+            if not np.isfinite(s['total']):
+                bad.append(nb_batch * e + i)
             train_avg.add(s['accuracy'])
             val_avg.add(val_acc)
             t.set_postfix(train_acc=train_avg.average, val_acc=val_avg.average)
             if scalar_log is not None:
                 scalar_log.write('{}\t{}\t{}\t{}\n'.format(nb_batch * e + i, s['total'], s['accuracy'],
                                                            s['threshold']))
-        train_steps(model, train_src, val_src, batch_size, shard, nb_batch, on_scalars, progress=t)
+        train_steps(model, train_src, val_src, batch_size, shard, nb_batch, on_scalars, progress=t,
+                    scalar_every=scalar_every)
         t.close()
         if scalar_log is not None:
             scalar_log.flush()
         gc.collect()
+        if bad:
+            # never checkpoint poisoned parameters: the previous epoch's files stay the latest ones
+            raise FloatingPointError('non-finite training loss at iteration {} (epoch {}): checkpoint not written'
+                                     .format(bad[0], e))
+        model.engine.sync_state()      # (collective when the Adam slots are sharded: one-shot exchange)
         if chief:
             saver.save(model, os.path.join(checkpoint_dir, 'model'), global_step=e)
+        if dp.world_size() > 1:
+            # the chief-only save must not let the other ranks run ahead into the next epoch's exchange unboundedly
+            dp.dist.barrier()
 
         # evaluation is collective under data parallelism (every rank scores a shard, rank 0 gathers); the two
         # numbers come back to every rank, so all ranks take the same decisions and only rank 0 writes files
@@ -169,6 +189,7 @@ def train_loop(model, data, aux, batch_size, start_epoch, epochs, log_dir, check
                            e, 1. - train_avg.average, 1. - val_stats.accuracy,
                            1. - test_stats.accuracy, val_stats.auc, test_stats.auc)
             stats.best_accuracy, stats.best_auc, stats.best_epoch = val_stats.accuracy, val_stats.auc, e
+            model.engine.sync_state()
             if chief:
                 best_saver.save(model, os.path.join(best_dir, 'model'), global_step=stats.best_epoch)
                 save_best_stats(best_accuracy_path, stats.best_epoch, stats.best_accuracy, stats.best_auc)
@@ -192,7 +213,7 @@ def setup_logging(log_dir):
 
 def train_monomer(data_name, data_root, checkpoint_root, log_root, run_tag, seed, normalize_value,
                   input_shape, batch_size, num_components, latent_size, lr, beta1, beta2, epochs,
-                  reg_const, reset):
+                  reg_const, reset, scalar_every=SCALAR_EVERY):
     dp.init_from_env()
     input_shape = tuple(input_shape)
     input_size = reduce_product(input_shape)
@@ -209,13 +230,17 @@ def train_monomer(data_name, data_root, checkpoint_root, log_root, run_tag, seed
     setup_logging(log_dir)
     saver, start_epoch = load_model(model, checkpoint_dir)
     train_loop(model=model, aux=aux, data=data, batch_size=batch_size, start_epoch=start_epoch,
-               epochs=epochs, log_dir=log_dir, checkpoint_dir=checkpoint_dir, saver=saver)
+               epochs=epochs, log_dir=log_dir, checkpoint_dir=checkpoint_dir, saver=saver, scalar_every=scalar_every)
 
 
 def parse_args(argv=None):
     parser = monomer_parser()
     parser.add_argument('--epochs', type=int, default=120)
     parser.add_argument('--reset', action='store_true')
+    # not a reference flag: the reference fetches the validation accuracy and the summaries in EVERY sess.run
+    # (cfl/bin/train_dist.py:79-86); 1 reproduces that cadence (and its validation stream), the default reads back every 25
+    parser.add_argument('--scalar-every', type=int, default=SCALAR_EVERY,
+                        help='read the display scalars / score a validation batch every N iterations (1 = reference cadence)')
     return parser.parse_args(argv)
 
 

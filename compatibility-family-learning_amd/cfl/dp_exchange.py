@@ -2,29 +2,54 @@
 reference is single-device).
 
 Default data-parallel step: proj -> mid -> grad -> RCCL all-reduce of [gradient | scalars] -> Adam (cfl/engine.py).
-With the one-shot exchange the collective is three kernels of the library instead (csrc/cfl_dp.hip):
+With the one-shot exchange the collective is three kernels of the library instead (csrc/cfl_dp.hip), shaped for
+point-to-point xGMI links -- every byte crosses exactly one link, every link carries 1/N of the buffer twice:
 
-    cfl_dp_push   this rank's buffer -> its slot in EVERY peer's exchange buffer (peer memory mapped here through
-                  hipIpc), then this rank's flag word in every peer's flag array = the step's generation
-    cfl_dp_wait   one wave waits until all `world` local flags carry the generation
-    cfl_dp_adam   sums the `world` local slots in rank order, leaves the sum in the engine's buffer (what the
-                  all-reduce would have left: gradient sums | scalar sums) and applies TF-Adam with sum / world
+    cfl_dp_rs_push    slice s of this rank's [gradient | scalars] -> rank s's slot array (peer memory mapped here through
+                      hipIpc), then this rank's A flag in every peer = the step's generation
+    cfl_dp_rs_adam    waits for the N local A flags, sums the N rows of ITS slice in rank order, applies TF-Adam to its
+                      slice of theta / m / v, pushes the updated theta slice (and the summed scalars) into every peer's
+                      stage buffer, raises its B flag there
+    cfl_dp_rs_gather  waits for the peers' B flags, copies their slices from the local stage buffer into theta
 
-No ring, no reduction tree: one hop per peer over the point-to-point xGMI links, the same summation order on every
-rank (bit-identical parameters on all ranks by construction).  Slots are double-buffered by step parity (see the
-header of csrc/cfl_dp.hip for why the flags then suffice).
+The Adam slots are SHARDED: rank r keeps slice r of m and v current (Adam work / N); `sync_optimizer_state()` -- a
+collective every rank calls before the chief writes a checkpoint -- gathers them.  After a step every rank holds
+bit-identical parameters (one writer per slice), the global scalar sums, and ITS slice of the gradient sum.
 
-The peers' buffers are exchanged ONCE, at construction, as torch IPC handles over the existing process group
-(all_gather_object): `torch.multiprocessing.reductions.reduce_tensor` on the owner, the rebuild function on the peers.
+Exchange memory is ONE fine-grained device allocation per rank (cfl_dp_alloc: hipExtMallocWithFlags(
+hipDeviceMallocFinegrained) -- the only kind of device memory for which HIP promises that a peer's stores become visible to
+a running kernel), shared once, at construction, as a raw 64-byte hipIpc handle over the existing process group.
 HSA_ENABLE_IPC_MODE_LEGACY=0 must be in the environment (dmabuf IPC; cfl.engine.init_from_env sets it).
+Waits are bounded by wall-clock time (CFL_DP_TIMEOUT_S, default 60 s): a late rank is waited for, a dead one makes the
+update NaN and `check()` -- called wherever the host reads the scalars back -- raises.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
 import torch.distributed as dist
 
 from . import hipabi as H
+
+
+class _Raw(object):
+    """a raw device address as a __cuda_array_interface__ object, so that torch can alias it"""
+
+    def __init__(self, ptr, n, typestr):
+        self.__cuda_array_interface__ = {'shape': (int(n),), 'typestr': typestr, 'data': (int(ptr), False), 'version': 2}
+
+
+def slice_floats(n, world):
+    """floats per rank of an n-float exchange buffer (n a multiple of 4): whole float4s, slice * world >= n"""
+    return (-(-(n // 4) // world)) * 4
+
+
+def owned_range(n_adam, slice_, rank):
+    """[lo, hi) of the first n_adam floats (the parameters) that rank `rank` owns: it sums their gradients, applies Adam to
+    them and keeps their Adam slots; the ranges of all ranks tile [0, n_adam) exactly once"""
+    lo = min(rank * slice_, n_adam)
+    return lo, min(lo + slice_, n_adam)
 
 
 class OneShotExchange(object):
@@ -34,53 +59,126 @@ class OneShotExchange(object):
         if self.world > 16:
             raise H.CflHipError('one-shot exchange supports up to 16 ranks')
         dev = engine.device
+        L = H.lib()
         self.n = int(engine.gradbuf.numel())
-        if self.n % 4:
-            raise H.CflHipError('gradient buffer length must be a multiple of 4')
-        # [parity][rank][n] slots and [parity][64] flag words (one 256-byte line per parity), written by the peers
-        self.slots = torch.zeros(2, self.world, self.n, dtype=torch.float32, device=dev)
-        self.flags = torch.zeros(2, 64, dtype=torch.int32, device=dev)
-        self.ticket = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.n_adam = int(engine.theta.numel())
+        # everything the kernels will require, checked BEFORE any collective (a failure on a subset of the ranks in the
+        # middle of the handle exchange would hang the others)
+        if self.n % 4 or self.n_adam % 4:
+            raise H.CflHipError('gradient buffer / parameter length must be a multiple of 4')
+        for name in ('theta', 'm', 'v', 'gradbuf'):
+            if getattr(engine, name).data_ptr() % 16:
+                raise H.CflHipError('engine.%s must be 16-byte aligned' % name)
+        self.slice = slice_floats(self.n, self.world)
+        self.timeout_s = float(os.environ.get('CFL_DP_TIMEOUT_S', '60'))
+        # layout of the allocation (floats): slots [2][world][slice] | stage [2][n] | A flags [2][64] | B flags [2][64]
+        self.o_slots = 0
+        self.o_stage = self.o_slots + 2 * self.world * self.slice
+        self.o_flags_a = self.o_stage + 2 * self.n
+        self.o_flags_b = self.o_flags_a + 2 * 64
+        self.total = self.o_flags_b + 2 * 64
+        torch.cuda.set_device(dev if dev.index is not None else torch.cuda.current_device())
+        fine = 0 if os.environ.get('CFL_DP_COARSE') == '1' else 1     # (escape hatch for experiments on one GPU only)
+        base = C.c_void_p()
+        H._check(L.cfl_dp_alloc(C.byref(base), 4 * self.total, fine))
+        self.base = base.value
+        handle = C.create_string_buffer(64)
+        H._check(L.cfl_dp_ipc_export(self.base, handle))
+        self.ticket = torch.zeros(2, dtype=torch.int32, device=dev)    # [0] push launch, [1] Adam launch
         self.lost = torch.zeros(1, dtype=torch.int32, device=dev)
         torch.cuda.synchronize(dev)
-        from torch.multiprocessing.reductions import reduce_tensor
-        mine = (reduce_tensor(self.slots), reduce_tensor(self.flags))
         handles = [None] * self.world
-        dist.all_gather_object(handles, mine)
-        self._peer_tensors = []          # keep the mappings alive
-        self._slot_base, self._flag_base = [], []
+        dist.all_gather_object(handles, handle.raw)
+        self._peer_base = []
         for r in range(self.world):
             if r == self.rank:
-                ps, pf = self.slots, self.flags
-            else:
-                (fs, as_), (ff, af) = handles[r]
-                ps, pf = fs(*as_), ff(*af)
-                # touching the mapping once from this device also enables peer access to the owner's memory
-                torch.empty(1, dtype=torch.float32, device=dev).copy_(ps.view(-1)[:1])
-            self._peer_tensors.append((ps, pf))
-            self._slot_base.append(ps.data_ptr())
-            self._flag_base.append(pf.data_ptr())
+                self._peer_base.append(self.base)
+                continue
+            p = C.c_void_p()
+            H._check(L.cfl_dp_ipc_open(handles[r], C.byref(p)))
+            self._peer_base.append(p.value)
+        self.local = torch.as_tensor(_Raw(self.base, self.total, '<f4'), device=dev)   # alias (diagnostics, tests)
         torch.cuda.synchronize(dev)
         dist.barrier()                   # nobody pushes before everyone has mapped everyone
         self.step = 0
+        self.m_v_sharded = self.world > 1
+
+    # -- addresses -------------------------------------------------------------------------------------------------
+    def _slot_row(self, base, par, row):
+        return base + 4 * (self.o_slots + (par * self.world + row) * self.slice)
+
+    def _stage(self, base, par):
+        return base + 4 * (self.o_stage + par * self.n)
+
+    def _flag(self, base, off, par, r):
+        return base + 4 * (off + par * 64 + r)
 
     def exchange_and_adam(self, engine, lr_t):
-        """engine.gradbuf (this rank's [gradient | scalars]) -> sum over ranks in engine.gradbuf; theta, m, v updated
-        with the mean gradient."""
+        """engine.gradbuf (this rank's [gradient | scalars]) -> every rank's theta updated with the mean gradient; this
+        rank's slice of m / v updated; engine.gradbuf = [this rank's slice of the gradient sum | the global scalar sums].
+        Returns the factor that turns the scalar sums into global-batch means."""
         par, gen = self.step & 1, (self.step + 1) & 0xffffffff
         if gen == 0:
             gen = 1
-        slot_ptrs = (C.c_void_p * self.world)(*[b + 4 * ((par * self.world + self.rank) * self.n)
-                                                 for b in self._slot_base])
-        flag_ptrs = (C.c_void_p * self.world)(*[b + 4 * (par * 64 + self.rank) for b in self._flag_base])
+        W, me = self.world, self.rank
+        rows = (C.c_void_p * W)(*[self._slot_row(b, par, me) for b in self._peer_base])
+        flags_a = (C.c_void_p * W)(*[self._flag(b, self.o_flags_a, par, me) for b in self._peer_base])
+        stages = (C.c_void_p * W)(*[self._stage(b, par) for b in self._peer_base])
+        flags_b = (C.c_void_p * W)(*[self._flag(b, self.o_flags_b, par, me) for b in self._peer_base])
         L = H.lib()
         st = H._stream()
-        H._check(L.cfl_dp_push(engine.gradbuf.data_ptr(), self.n, slot_ptrs, flag_ptrs, self.world, gen,
-                               self.ticket.data_ptr(), st))
-        H._check(L.cfl_dp_wait(self.flags[par].data_ptr(), self.world, gen, self.lost.data_ptr(), st))
-        H._check(L.cfl_dp_adam(engine.theta.data_ptr(), engine.m.data_ptr(), engine.v.data_ptr(),
-                               self.slots[par].data_ptr(), self.world, self.n, int(engine.theta.numel()),
-                               engine.gradbuf.data_ptr(), float(lr_t), float(engine.beta1), float(engine.beta2),
-                               float(engine.eps), self.lost.data_ptr(), st))
+        H._check(L.cfl_dp_rs_push(engine.gradbuf.data_ptr(), self.n, self.slice, rows, flags_a, W, gen,
+                                  self.ticket[0:].data_ptr(), st))
+        H._check(L.cfl_dp_rs_adam(engine.theta.data_ptr(), engine.m.data_ptr(), engine.v.data_ptr(),
+                                  self._slot_row(self.base, par, 0), self._flag(self.base, self.o_flags_a, par, 0), W, me,
+                                  self.n, self.n_adam, self.slice, engine.gradbuf.data_ptr(), stages, flags_b, float(lr_t),
+                                  float(engine.beta1), float(engine.beta2), float(engine.eps), gen, self.lost.data_ptr(),
+                                  self.timeout_s, self.ticket[1:].data_ptr(), st))
+        H._check(L.cfl_dp_rs_gather(engine.theta.data_ptr(), engine.gradbuf.data_ptr(), self._stage(self.base, par),
+                                    self._flag(self.base, self.o_flags_b, par, 0), W, me, self.n, self.n_adam, self.slice,
+                                    gen, self.lost.data_ptr(), self.timeout_s, st))
         self.step += 1
-        return 1.0 / self.world
+        return 1.0 / W
+
+    def owned(self):
+        """[lo, hi) of the parameters whose Adam slots this rank keeps current"""
+        return owned_range(self.n_adam, self.slice, self.rank)
+
+    def sync_optimizer_state(self, engine):
+        """COLLECTIVE: make m and v complete on every rank (each rank owns a slice).  Called by every rank before the
+        chief writes a checkpoint."""
+        for t in (engine.m, engine.v):
+            pad = torch.zeros(self.world * self.slice, dtype=torch.float32, device=t.device)
+            lo, hi = self.owned()
+            mine = torch.zeros(self.slice, dtype=torch.float32, device=t.device)
+            mine[:hi - lo] = t[lo:hi]
+            if dist.get_backend() == 'gloo':
+                parts = [torch.empty(self.slice, dtype=torch.float32) for _ in range(self.world)]
+                dist.all_gather(parts, mine.cpu())
+                pad.copy_(torch.cat(parts))
+            else:
+                dist.all_gather_into_tensor(pad, mine)
+            t.copy_(pad[:t.numel()])
+
+    def check(self):
+        """host side of the bounded waits: raise when a peer never arrived (synchronises the stream)"""
+        if int(self.lost.item()) != 0:
+            raise H.CflHipError('one-shot gradient exchange: a peer did not arrive within {:.0f} s at or before step {} '
+                                '(the parameters are NaN from that step on; CFL_DP_TIMEOUT_S sets the bound)'
+                                .format(self.timeout_s, self.step))
+
+    def close(self):
+        L = H.lib()
+        if getattr(self, 'base', None):
+            torch.cuda.synchronize()
+            for r, b in enumerate(self._peer_base):
+                if r != self.rank:
+                    L.cfl_dp_ipc_close(b)
+            L.cfl_dp_free(self.base)
+            self.base = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -120,6 +120,9 @@ class PairEngine(object):
         self.beta2_power = np.float32(beta2)
         self.global_step = 0
         self._ws = {}
+        # bf16 planes of theta, kept current by the fused training step (single GPU): the bf16x3 projection of large
+        # batches then needs no per-call split of the weights (include/cfl_hip.h: CflThetaPlanes)
+        self.planes = H.ThetaPlanes(self.shape, self.device)
         if batch_size:
             self._workspace(batch_size, 2)
         # data-parallel exchange: RCCL all-reduce (default) or the library's one-shot push + summing Adam
@@ -137,7 +140,11 @@ class PairEngine(object):
         if ws is None:
             n = H.workspace_bytes(self.shape, rows, groups)
             ws = torch.empty(n // 4, dtype=torch.float32, device=self.device)
-            self._ws = {k: v for k, v in self._ws.items() if k[1] != groups or k == key}
+            # a few sizes per group count stay cached: under data parallelism the training step (rows = batch / world) and
+            # the validation fetch (rows = batch) alternate, and evicting each other meant a reallocation per read-back
+            same = [k for k in self._ws if k[1] == groups]
+            for k in same[:max(0, len(same) - 2)]:
+                del self._ws[k]
             self._ws[key] = ws
         return ws
 
@@ -166,6 +173,7 @@ class PairEngine(object):
     def apply_adam(self, grad_scale=1.0):
         H.adam_tf(self.theta, self.m, self.v, self.grad, self.lr_t(), self.beta1,
                   self.beta2, self.eps, grad_scale)
+        self.planes.invalidate()
         self._advance()
 
     def _advance(self):
@@ -186,11 +194,11 @@ class PairEngine(object):
             if indexed:
                 H.pair_train_step_idx(self.shape, self.norm, self.loss, batch[0], batch[1], self.theta, self.m,
                                       self.v, self.grad, self.scalars, ws, self.lr_t(), self.beta1, self.beta2,
-                                      self.eps)
+                                      self.eps, planes=self.planes)
             else:
                 H.pair_train_step(self.shape, self.norm, self.loss, batch, self.theta, self.m,
                                   self.v, self.grad, self.scalars, ws, self.lr_t(), self.beta1,
-                                  self.beta2, self.eps)
+                                  self.beta2, self.eps, planes=self.planes)
             self._scalar_scale = 1.0
             self._advance()
             return
@@ -205,6 +213,7 @@ class PairEngine(object):
         """the ONE exchange of a data-parallel step + the replicated Adam apply"""
         if self._oneshot is not None:
             self._scalar_scale = self._oneshot.exchange_and_adam(self, self.lr_t())
+            self.planes.invalidate()
             self._advance()
             return
         # sum of [flat fp32 gradient | scalars] over xGMI
@@ -222,6 +231,10 @@ class PairEngine(object):
             # rank's rows of the window, then the collective + Adam (one host call for the iterations between two
             # read-backs; with the one-shot exchange nothing in the loop leaves the library's kernels)
             itemsize = 4
+            if (win.nsteps <= 0 or win.pos_head < 0 or win.neg_head < 0
+                    or win.pos_head + win.nsteps * win.batch_rows > win.pos_pairs.shape[0]
+                    or win.neg_head + win.nsteps * win.batch_rows > win.neg_pairs.shape[0]):
+                raise H.CflHipError('step window runs past the pair lists (as cfl_pair_train_steps_idx rejects it)')
             pp, npair = win.pos_pairs.data_ptr(), win.neg_pairs.data_ptr()
             for i in range(win.nsteps):
                 po = pp + 2 * itemsize * (win.pos_head + i * win.batch_rows + win.shard_lo)
@@ -237,7 +250,7 @@ class PairEngine(object):
             self.shape, self.norm, self.loss, win.table, win.pos_pairs, win.neg_pairs, win.pos_head, win.neg_head,
             win.batch_rows, win.shard_lo, win.rows, win.switched, win.nsteps, self.theta, self.m, self.v, self.grad,
             self.scalars, ws, np.float32(self.lr), self.beta1, self.beta2, self.eps, self.beta1_power,
-            self.beta2_power)
+            self.beta2_power, planes=self.planes)
         self.beta1_power, self.beta2_power = np.float32(b1p), np.float32(b2p)
         self.global_step += win.nsteps
         self._scalar_scale = 1.0
@@ -246,8 +259,19 @@ class PairEngine(object):
         """Host copy of the last step's scalars (synchronises the stream).  Under data parallelism they are the
         global-batch values: every scalar is a mean over this rank's rows, the shards are equal-sized, and the
         sums travelled in the gradient all-reduce."""
-        vals = self.scalars.cpu().numpy() * np.float32(self._scalar_scale)
+        raw = self.scalars.cpu().numpy()
+        self.check_health(raw)
+        vals = raw * np.float32(self._scalar_scale)
         return dict(zip(H.SCALAR_NAMES, (float(x) for x in vals)))
+
+    def check_health(self, host_scalars=None):
+        """Raise CflHipError when a training kernel reported a lost in-launch hand-off (the sticky error word of the
+        scalars array, which also travels in the data-parallel gradient sum) or the one-shot exchange timed out."""
+        if host_scalars is None:
+            host_scalars = self.scalars.cpu().numpy()
+        H.check_scalars(host_scalars)
+        if self._oneshot is not None:
+            self._oneshot.check()
 
     def scores(self, xs, xt):
         """max(thr,1e-6) - dist(src, dst), the value the reference fetches as
@@ -266,13 +290,24 @@ class PairEngine(object):
         return H.pair_scores_idx4(self.shape, self.norm, table, streams, self.theta, ws)
 
     # -- checkpoint payload --------------------------------------------------
+    def sync_state(self):
+        """COLLECTIVE under the one-shot exchange (a no-op otherwise): its Adam slots are sharded over the ranks, so every
+        rank calls this before the chief reads m / v for a checkpoint (state_dict / PairModel.checkpoint_state)."""
+        if self._oneshot is not None:
+            self._oneshot.sync_optimizer_state(self)
+
     def state_dict(self):
         return dict(theta=self.theta.cpu(), m=self.m.cpu(), v=self.v.cpu(),
                     beta1_power=float(self.beta1_power), beta2_power=float(self.beta2_power),
                     global_step=self.global_step)
 
+    def set_theta(self, theta):
+        """overwrite the parameters (checkpoint load, assignment): the kept bf16 planes are stale afterwards"""
+        self.theta.copy_(theta)
+        self.planes.invalidate()
+
     def load_state_dict(self, sd):
-        self.theta.copy_(sd['theta'])
+        self.set_theta(sd['theta'])
         self.m.copy_(sd['m'])
         self.v.copy_(sd['v'])
         self.beta1_power = np.float32(sd['beta1_power'])

@@ -28,6 +28,7 @@ SCALAR_NAMES = ('total', 'reg', 'thres', 'loss_pos', 'loss_neg', 'cd', 'accuracy
                 'mean_d_pos', 'mean_d_neg', 'mean_o_pos', 'mean_o_neg', 'threshold',
                 'dist_adapt_pos', 'dist_adapt_neg')
 S_COUNT = 16
+S_ERROR = 15      # sticky error word of the scalars array (CFL_S_ERROR, include/cfl_hip.h)
 
 
 class CflShape(C.Structure):
@@ -61,6 +62,10 @@ class CflLossCfg(C.Structure):
                 ('reg_const', C.c_float)]
 
 
+class CflThetaPlanes(C.Structure):
+    _fields_ = [('buf', C.c_void_p), ('valid', C.c_int32)]
+
+
 class CflConv(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ('B', 'H', 'W', 'Ci', 'Co', 'KH', 'KW', 'stride', 'act')]
 
@@ -72,7 +77,10 @@ EXPORTS = ('cfl_version', 'cfl_last_error', 'cfl_layout', 'cfl_workspace_bytes',
            'cfl_gather_rows', 'cfl_profile_enable', 'cfl_profile_read', 'cfl_pair_input_grad',
            'cfl_conv_workspace_bytes', 'cfl_conv_uses_direct_kernel', 'cfl_conv2d_wn_fwd', 'cfl_conv2d_wn_bwd',
            'cfl_pair_scores_idx', 'cfl_pair_step_fwd_bwd_idx', 'cfl_pair_train_step_idx', 'cfl_reload_env',
-           'cfl_pair_train_steps_idx', 'cfl_pair_scores_idx4', 'cfl_mt19937_reshuffle', 'cfl_dp_push', 'cfl_dp_wait', 'cfl_dp_adam')
+           'cfl_pair_train_steps_idx', 'cfl_pair_scores_idx4', 'cfl_mt19937_reshuffle', 'cfl_dp_alloc', 'cfl_dp_free', 'cfl_dp_ipc_export', 'cfl_dp_ipc_open', 'cfl_dp_ipc_close',
+           'cfl_dp_rs_push', 'cfl_dp_rs_adam', 'cfl_dp_rs_gather',
+           'cfl_scalars_status', 'cfl_theta_planes_bytes', 'cfl_pair_train_step_planes', 'cfl_pair_train_step_idx_planes',
+           'cfl_pair_train_steps_idx_planes')
 
 KERNEL_NAMES = ('colnorm', 'proj', 'mid', 'grad', 'finalize', 'adam', 'gather')
 K_COUNT = 8
@@ -115,6 +123,13 @@ def lib():
         C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_size_t,
         C.c_void_p]
     L.cfl_pair_train_step.restype = C.c_int
+    a = list(L.cfl_pair_train_step.argtypes)
+    L.cfl_pair_train_step_planes.argtypes = a[:14] + [C.POINTER(CflThetaPlanes)] + a[14:]
+    L.cfl_pair_train_step_planes.restype = C.c_int
+    L.cfl_theta_planes_bytes.argtypes = [C.POINTER(CflShape)]
+    L.cfl_theta_planes_bytes.restype = C.c_size_t
+    L.cfl_scalars_status.argtypes = [C.c_void_p]
+    L.cfl_scalars_status.restype = C.c_int
     L.cfl_pair_scores_idx.argtypes = [
         C.POINTER(CflShape), C.POINTER(CflNorm), C.c_void_p, C.c_int64, C.POINTER(C.c_void_p), C.c_int64,
         C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
@@ -131,12 +146,18 @@ def lib():
         C.POINTER(C.c_void_p), C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
         C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_size_t, C.c_void_p]
     L.cfl_pair_train_step_idx.restype = C.c_int
+    a = list(L.cfl_pair_train_step_idx.argtypes)
+    L.cfl_pair_train_step_idx_planes.argtypes = a[:17] + [C.POINTER(CflThetaPlanes)] + a[17:]
+    L.cfl_pair_train_step_idx_planes.restype = C.c_int
     L.cfl_pair_train_steps_idx.argtypes = [
         C.POINTER(CflShape), C.POINTER(CflNorm), C.POINTER(CflLossCfg), C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
         C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_char_p, C.c_int64, C.c_void_p,
         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float,
         C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_void_p, C.c_size_t, C.c_void_p]
     L.cfl_pair_train_steps_idx.restype = C.c_int
+    a = list(L.cfl_pair_train_steps_idx.argtypes)
+    L.cfl_pair_train_steps_idx_planes.argtypes = a[:27] + [C.POINTER(CflThetaPlanes)] + a[27:]
+    L.cfl_pair_train_steps_idx_planes.restype = C.c_int
     L.cfl_mt19937_reshuffle.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_int64, C.c_void_p, C.c_int64,
                                         C.c_void_p, C.c_void_p, C.c_void_p]
     L.cfl_mt19937_reshuffle.restype = C.c_int
@@ -159,16 +180,24 @@ def lib():
     L.cfl_conv2d_wn_bwd.argtypes = ([C.POINTER(CflConv)] + [C.c_void_p] * 5 + [C.c_float] +
                                     [C.c_void_p] * 5 + [C.c_size_t, C.c_void_p])
     L.cfl_conv2d_wn_bwd.restype = C.c_int
-    L.cfl_dp_push.argtypes = [C.c_void_p, C.c_int64, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int32, C.c_uint32,
-                              C.c_void_p, C.c_void_p]
-    L.cfl_dp_push.restype = C.c_int
-    L.cfl_dp_wait.argtypes = [C.c_void_p, C.c_int32, C.c_uint32, C.c_void_p, C.c_void_p]
-    L.cfl_dp_wait.restype = C.c_int
-    L.cfl_dp_adam.argtypes = [C.c_void_p] * 4 + [C.c_int32, C.c_int64, C.c_int64, C.c_void_p] + [C.c_float] * 4 + [C.c_void_p, C.c_void_p]
-    L.cfl_dp_adam.restype = C.c_int
+    L.cfl_dp_alloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t, C.c_int32]
+    L.cfl_dp_free.argtypes = [C.c_void_p]
+    L.cfl_dp_ipc_export.argtypes = [C.c_void_p, C.c_void_p]
+    L.cfl_dp_ipc_open.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+    L.cfl_dp_ipc_close.argtypes = [C.c_void_p]
+    L.cfl_dp_rs_push.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int32,
+                                 C.c_uint32, C.c_void_p, C.c_void_p]
+    L.cfl_dp_rs_adam.argtypes = ([C.c_void_p] * 5 + [C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_int64, C.c_void_p,
+                                                     C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)] + [C.c_float] * 4 +
+                                 [C.c_uint32, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p])
+    L.cfl_dp_rs_gather.argtypes = [C.c_void_p] * 4 + [C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_int64, C.c_uint32,
+                                                      C.c_void_p, C.c_double, C.c_void_p]
+    for f in (L.cfl_dp_alloc, L.cfl_dp_free, L.cfl_dp_ipc_export, L.cfl_dp_ipc_open, L.cfl_dp_ipc_close, L.cfl_dp_rs_push,
+              L.cfl_dp_rs_adam, L.cfl_dp_rs_gather):
+        f.restype = C.c_int
     L.cfl_profile_enable.argtypes = [C.c_int]
     L.cfl_profile_read.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_int64)]
-    if L.cfl_version() != 3:
+    if L.cfl_version() != 4:
         raise CflHipError('libcfl_hip.so ABI version mismatch')
     _lib = L
     return L
@@ -178,6 +207,37 @@ def _check(rc):
     if rc != 0:
         raise CflHipError('libcfl_hip error {}: {}'.format(
             rc, lib().cfl_last_error().decode()))
+
+
+def check_scalars(host_scalars):
+    """Raise CflHipError if a read-back scalars array carries the sticky error word (a training kernel gave up on an
+    in-launch hand-off; the parameters are NaN-poisoned from that step on).  cfl_scalars_status of the C ABI."""
+    a = np.ascontiguousarray(np.asarray(host_scalars, dtype=np.float32)[:S_COUNT])
+    _check(lib().cfl_scalars_status(a.ctypes.data))
+
+
+class ThetaPlanes(object):
+    """Caller-kept bf16 planes of theta (CflThetaPlanes): a device buffer beside theta, m, v that the fused training
+    step keeps current, so that the bf16x3 projection of the next step needs no per-call split of the weights."""
+
+    def __init__(self, shape, device):
+        n = lib().cfl_theta_planes_bytes(C.byref(shape))
+        if n == 0:
+            raise CflHipError('cfl_theta_planes_bytes: ' + lib().cfl_last_error().decode())
+        self.buf = torch.empty(n // 2, dtype=torch.int16, device=device)
+        self.c = CflThetaPlanes(self.buf.data_ptr(), 0)
+
+    def invalidate(self):
+        """theta was changed by something other than the fused training step"""
+        self.c.valid = 0
+
+    @property
+    def valid(self):
+        return bool(self.c.valid)
+
+
+def _planes(p):
+    return C.byref(p.c) if p is not None else None
 
 
 def make_shape(D, L, K, dist_type='pcd', weight_norm=False, has_bias=True,
@@ -247,12 +307,12 @@ def pair_step_fwd_bwd(shape, norm, loss, x4, theta, grad, scalars, workspace):
 
 
 def pair_train_step(shape, norm, loss, x4, theta, m, v, grad, scalars, workspace, lr_t,
-                    beta1, beta2, eps=1e-8):
+                    beta1, beta2, eps=1e-8, planes=None):
     B = x4[0].shape[0]
     arr = (C.c_void_p * 4)(*[_dev(x) for x in x4])
-    _check(lib().cfl_pair_train_step(
+    _check(lib().cfl_pair_train_step_planes(
         C.byref(shape), C.byref(norm), C.byref(loss), arr, B, _dev(theta), _dev(m), _dev(v),
-        _dev(grad), _dev(scalars), float(lr_t), float(beta1), float(beta2), float(eps),
+        _dev(grad), _dev(scalars), float(lr_t), float(beta1), float(beta2), float(eps), _planes(planes),
         workspace.data_ptr(), workspace.numel() * workspace.element_size(), _stream()))
 
 
@@ -315,28 +375,28 @@ def pair_step_fwd_bwd_idx(shape, norm, loss, table, streams, theta, grad, scalar
 
 
 def pair_train_step_idx(shape, norm, loss, table, streams, theta, m, v, grad, scalars, workspace, lr_t, beta1,
-                        beta2, eps=1e-8):
+                        beta2, eps=1e-8, planes=None):
     tp, rows = _table(table)
-    _check(lib().cfl_pair_train_step_idx(
+    _check(lib().cfl_pair_train_step_idx_planes(
         C.byref(shape), C.byref(norm), C.byref(loss), tp, rows, streams.arr, streams.stride, streams.n,
         _dev(theta), _dev(m), _dev(v), _dev(grad), _dev(scalars), float(lr_t), float(beta1), float(beta2),
-        float(eps), workspace.data_ptr(), workspace.numel() * workspace.element_size(), _stream()))
+        float(eps), _planes(planes), workspace.data_ptr(), workspace.numel() * workspace.element_size(), _stream()))
 
 
 def pair_train_steps_idx(shape, norm, loss, table, pos_pairs, neg_pairs, pos_head, neg_head, batch_rows, shard_lo,
                          rows, switched, nsteps, theta, m, v, grad, scalars, workspace, lr, beta1, beta2, eps,
-                         beta1_power, beta2_power):
+                         beta1_power, beta2_power, planes=None):
     """nsteps consecutive training steps over windows of the device pair lists (cfl_pair_train_steps_idx).
     Returns the advanced (beta1_power, beta2_power) as python floats holding float32 values."""
     tp, trows = _table(table)
     b1p, b2p = C.c_float(beta1_power), C.c_float(beta2_power)
     sw = bytes(bytearray(int(bool(x)) for x in switched)) if switched is not None else None
-    _check(lib().cfl_pair_train_steps_idx(
+    _check(lib().cfl_pair_train_steps_idx_planes(
         C.byref(shape), C.byref(norm), C.byref(loss), tp, trows, _dev(pos_pairs, torch.int32), int(pos_pairs.shape[0]),
         _dev(neg_pairs, torch.int32), int(neg_pairs.shape[0]), int(pos_head), int(neg_head), int(batch_rows),
         int(shard_lo), int(rows), sw,
         int(nsteps), _dev(theta), _dev(m), _dev(v), _dev(grad), _dev(scalars), float(lr), float(beta1),
-        float(beta2), float(eps), C.byref(b1p), C.byref(b2p), workspace.data_ptr(),
+        float(beta2), float(eps), C.byref(b1p), C.byref(b2p), _planes(planes), workspace.data_ptr(),
         workspace.numel() * workspace.element_size(), _stream()))
     return b1p.value, b2p.value
 

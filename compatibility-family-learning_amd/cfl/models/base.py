@@ -164,7 +164,7 @@ class PairModel(object):
 
     def load_checkpoint_state(self, state):
         eng = self.engine
-        eng.theta.copy_(self._pack(state['variables']))
+        eng.set_theta(self._pack(state['variables']))
         eng.m.copy_(self._pack(state['adam_m']))
         eng.v.copy_(self._pack(state['adam_v']))
         eng.beta1_power = np.float32(state['beta1_power'])
@@ -179,4 +179,4 @@ class PairModel(object):
                 cur[k] = v
             elif not ignore_missing:
                 raise KeyError(k)
-        self.engine.theta.copy_(self._pack(cur))
+        self.engine.set_theta(self._pack(cur))

@@ -501,10 +501,15 @@ class CFL(PairModel):
             train_avg = val_avg = 0.0
             for i in t:
                 self.train_step(next_train())
-                if save_iters and i > 0 and i % save_iters == 0 and saver is not None and chief:
-                    saver.save(self, os.path.join(checkpoint_dir, 'model'), global_step=nb_batch * e + i)
+                if save_iters and i > 0 and i % save_iters == 0 and saver is not None:
+                    self.engine.sync_state()      # collective when the Adam slots are sharded (one-shot exchange)
+                    if chief:
+                        saver.save(self, os.path.join(checkpoint_dir, 'model'), global_step=nb_batch * e + i)
                 if i % 50 == 0 or i == nb_batch - 1:      # host read-back only now and then
-                    s = self.scalars()
+                    s = self.scalars()                    # (raises CflHipError on a lost in-launch hand-off)
+                    if not np.isfinite(s['total']):
+                        # never checkpoint poisoned parameters: the last files written stay the latest ones
+                        raise FloatingPointError('non-finite training loss at iteration {}'.format(nb_batch * e + i))
                     if writer is not None and chief:
                         writer.add_scalars('scalars', nb_batch * e + i, s)
                     train_avg = self._ema_update('acc', s['accuracy'])
@@ -524,6 +529,7 @@ class CFL(PairModel):
                     if val_stats.auc > stats.best_auc:
                         stats.best_accuracy, stats.best_auc, stats.best_epoch = \
                             val_stats.accuracy, val_stats.auc, e
+                        self.engine.sync_state()      # collective when the Adam slots are sharded (one-shot exchange)
                         if chief:
                             best_saver.save(self, os.path.join(best_dir, 'model'), global_step=stats.best_epoch)
                             save_best_stats(best_auc_path, stats.best_epoch, stats.best_accuracy, stats.best_auc)
@@ -533,6 +539,7 @@ class CFL(PairModel):
                         # reference quirk (cfl/models/cfl.py:1463-1470): step and file
                         # carry the AUC-best `stats`, not `stats_acc`
                         step = stats.best_epoch if stats.best_epoch is not None else e
+                        self.engine.sync_state()      # collective when the Adam slots are sharded (one-shot exchange)
                         if chief:
                             best_acc_saver.save(self, os.path.join(best_acc_dir, 'model'), global_step=step)
                             save_best_stats(best_acc_path, stats.best_epoch, stats.best_accuracy, stats.best_auc)
@@ -541,8 +548,10 @@ class CFL(PairModel):
                                    e, 1. - train_avg, 1. - val_stats.accuracy, val_stats.auc)
             else:
                 logger.warning('epoch %d: avg error = train: %f val: %f', e, 1. - train_avg, 1. - val_avg)
-            if e % save_epochs == 0 and saver is not None and chief:
-                saver.save(self, os.path.join(checkpoint_dir, 'model'), global_step=(e + 1) * nb_batch)
+            if e % save_epochs == 0 and saver is not None:
+                self.engine.sync_state()      # collective when the Adam slots are sharded (one-shot exchange)
+                if chief:
+                    saver.save(self, os.path.join(checkpoint_dir, 'model'), global_step=(e + 1) * nb_batch)
 
 
     def _post_epoch(self, e, t, data, nb_batch, save_iters, saver, checkpoint_dir, writer=None):

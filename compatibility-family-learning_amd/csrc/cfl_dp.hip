@@ -1,23 +1,31 @@
 // cfl_dp.hip -- one-shot gradient exchange of the data-parallel pair step (new functionality: the reference is
 // single-device).  Opt-in alternative (CFL_DP_EXCHANGE=oneshot) to the RCCL ring all-reduce of
-// cfl/engine.py: at 1.57 MB per step a ring over 8 GPUs is 14 latency-bound hops; here every rank PUSHES its flat
-// buffer [gradient | 16 scalars] into a slot of every peer's exchange buffer over the 7 point-to-point xGMI links
-// at once (peer memory mapped through hipIpc by the host side, cfl/dp_exchange.py), and the Adam launch itself sums
-// the N slots it finds in LOCAL memory in rank order -- deterministic, identical on every rank, no reduction tree:
+// cfl/engine.py, written for what xGMI is -- seven point-to-point links per GPU, no switch: a ring all-reduce of the
+// 1.57 MB buffer [gradient | 16 scalars] over 8 GPUs is 14 latency-bound hops; here every byte crosses exactly one link,
+// every link carries 1/N of the buffer twice, and every rank applies Adam to 1/N of the parameters:
 //
-//   cfl_dp_push   src -> slot[rank] of every peer (plain 16-byte stores), __threadfence_system() by every block,
-//                 last block (device-scope ticket) releases at system scope and writes the step's generation number
-//                 into flag[rank] of every peer;
-//   cfl_dp_wait   ONE wave polls the `world` local flags (system-scope loads, bounded) -- a single workgroup, so that
-//                 ranks which share a GPU (the functional tests) can never starve each other of CUs --, then acquires;
-//   cfl_dp_adam   reads the N slots with system-scope (sc0 sc1) loads -- peers wrote them into this GPU's memory past
-//                 its L2 --, sums them in rank order, scales by 1/N, stores the summed buffer (gradient + scalars,
-//                 what every rank logs) and applies TF-Adam to the parameter part.
-// Double buffering by step parity makes the flags sufficient: a rank overwrites slot parity p at step t + 2 only
-// after its own step t + 1, which waited for every peer's step-t + 1 flag, which a peer raises after its step-t Adam
-// (the reader of parity p) in stream order.
+//   cfl_dp_rs_push    (reduce-scatter, send side) slice s of this rank's buffer -> row `rank` of rank s's slot array,
+//                     all N - 1 links at once; __threadfence_system() by every block; the last block (device-scope
+//                     ticket) releases at system scope and raises flag A[rank] = generation in every peer;
+//   cfl_dp_rs_adam    waits (bounded by wall-clock time) until the N local A flags carry the generation, sums the N rows
+//                     of ITS slice in rank order (system-scope loads; deterministic, no reduction tree), applies TF-Adam
+//                     to its slice of theta / m / v -- the Adam slots are sharded, each rank keeps 1/N of them current --
+//                     and pushes the UPDATED theta slice (and, past the parameters, the summed scalars) into every
+//                     peer's stage buffer; the last block raises flag B[rank] in every peer;
+//   cfl_dp_rs_gather  (all-gather, receive side) waits for the N - 1 B flags and copies the peers' slices from the local
+//                     stage buffer into theta (and the scalar sums into the caller's buffer).
+// Every rank ends the step with bit-identical parameters by construction (each slice has ONE writer; the others copy).
+// Per step and link: 2 x (n / N) floats (0.39 MB at the headline shape and N = 8, against 1.57 MB for the push-everything
+// form of round 3 and 2 x 7/8 x 1.57 MB around a ring).
+// Slots, stage buffers and flags live in FINE-GRAINED device memory (cfl_dp_alloc): HIP only promises that a peer's
+// stores become visible to a RUNNING kernel of the owner for such allocations.  Double buffering by step parity makes the
+// flags sufficient (a rank overwrites parity p of a peer at step t + 2 only after its own step t + 1 gather, which waited
+// for that peer's step-t + 1 B flag, raised after the peer's step-t + 1 Adam, i.e. after every reader of parity p of step t).
+// The waits are bounded by TIME (s_memrealtime, tens of seconds by default): a rank that is merely late -- a chief writing a
+// checkpoint -- is waited for; a peer that never arrives sets *lost, poisons the update with NaN, and the host raises at its
+// next read-back (cfl/dp_exchange.py: check()).
 // Exercised functionally by two processes on one GPU (tests/test_data_parallel_gpu.py); no multi-GPU node was
-// available to this build, so cross-device visibility rests on the system-scope release / acquire above.
+// available to this build.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -31,51 +39,62 @@ extern int cfl_set_err(int code, const char *fmt, ...);
 typedef float dp_f32x4 __attribute__((ext_vector_type(4)));
 
 #define CFL_DP_MAX_WORLD 16
-#define CFL_DP_SPIN_LIMIT (1 << 24)
 
 struct DpPeers {
-    float *slot[CFL_DP_MAX_WORLD];        // this rank's slot inside every peer's exchange buffer (current parity)
-    unsigned *flag[CFL_DP_MAX_WORLD];     // this rank's flag word inside every peer's flag array (current parity)
+    float *slot[CFL_DP_MAX_WORLD];        // per peer: where this rank writes (row of the slot array / stage buffer, current parity)
+    unsigned *flag[CFL_DP_MAX_WORLD];     // per peer: this rank's flag word (current parity)
     int world;
 };
 
-__global__ __launch_bounds__(256) void cfl_dp_push_kernel(const float *src, long long n4, DpPeers p, unsigned gen,
-                                                          unsigned *ticket) {
-    const long long stride = (long long)gridDim.x * 256;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
-        const dp_f32x4 v = ((const dp_f32x4 *)src)[i];
-        for (int r = 0; r < p.world; ++r) ((dp_f32x4 *)p.slot[r])[i] = v;
-    }
-    __threadfence_system();                 // this block's stores are visible system-wide ...
+// last block of a launch: every block has fenced its stores at system scope; release and raise this rank's flag in every peer
+__device__ __forceinline__ void dp_signal_peers(const DpPeers &p, unsigned gen, unsigned *ticket) {
+    __threadfence_system();
     __syncthreads();
     __shared__ unsigned last;
     if (threadIdx.x == 0) last = atomicAdd(ticket, 1u) == gridDim.x - 1 ? 1u : 0u;
     __syncthreads();
-    if (last) {                             // ... and so are all blocks' once the last one has arrived
+    if (last) {
         __threadfence_system();
         if ((int)threadIdx.x < p.world)
             __hip_atomic_store(p.flag[threadIdx.x], gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        if (threadIdx.x == 0) *ticket = 0;  // next launch on this stream starts from zero
+        if (threadIdx.x == 0) *ticket = 0;  // the next launch on this stream starts from zero
     }
 }
 
-__global__ __launch_bounds__(64) void cfl_dp_wait_kernel(const unsigned *flags, int world, unsigned gen, int *lost) {
-    const int lane = threadIdx.x;
-    int spins = 0;
-    for (;;) {
-        const unsigned v = lane < world ? __hip_atomic_load(flags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : gen;
-        if (__builtin_amdgcn_ballot_w64(v != gen) == 0) break;
-        if (++spins > CFL_DP_SPIN_LIMIT) {   // a peer never arrived: poison the update instead of hanging the GPU
-            if (lane == 0) *lost = 1;
-            break;
+// wave 0 polls the `world` local flags (one per lane, system scope) until all carry `gen` or `ticks` of the 100 MHz
+// real-time counter have passed; returns (to every thread of the block) whether they all arrived
+__device__ __forceinline__ bool dp_wait_flags(const unsigned *flags, int world, int skip, unsigned gen, unsigned long long ticks,
+                                              int *lost) {
+    __shared__ int ok_s;
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        int ok = 1;
+        for (;;) {
+            const unsigned v = (lane < world && lane != skip)
+                                   ? __hip_atomic_load(flags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : gen;
+            if (__builtin_amdgcn_ballot_w64(v != gen) == 0) break;
+            if (__builtin_amdgcn_s_memrealtime() - t0 > ticks) { ok = 0; break; }
+            __builtin_amdgcn_s_sleep(8);
         }
-        __builtin_amdgcn_s_sleep(8);
+        __threadfence_system();
+        if (lane == 0) {
+            ok_s = ok;
+            if (!ok) *lost = 1;
+        }
     }
-    __threadfence_system();
+    __syncthreads();
+    return ok_s != 0;
 }
 
-// 4 x 16 bytes straight from memory (system scope: not from this GPU's L2, which peers' writes bypass); ONE statement
-// that ends with its own wait (the compiler does not track loads issued inside inline asm)
+__device__ __forceinline__ dp_f32x4 load_sys16(const float *p) {   // system scope: not from this GPU's L2, which peers' writes bypass
+    dp_f32x4 o;
+    asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(o) : "v"(p) : "memory");
+    return o;
+}
+
+// 4 x 16 bytes straight from memory; ONE statement that ends with its own wait (the compiler does not track loads issued
+// inside inline asm)
 __device__ __forceinline__ void load_sys16x4(const float *p0, const float *p1, const float *p2, const float *p3,
                                              dp_f32x4 (&o)[4]) {
     asm volatile(
@@ -87,26 +106,40 @@ __device__ __forceinline__ void load_sys16x4(const float *p0, const float *p1, c
         : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]) : "v"(p0), "v"(p1), "v"(p2), "v"(p3) : "memory");
 }
 
-__global__ __launch_bounds__(256) void cfl_dp_adam_kernel(float *theta, float *m, float *v, const float *slots,
-                                                          int world, long long n4, long long nadam4, float *sum_out,
-                                                          float lr_t, float b1, float b2, float eps, const int *lost) {
+__global__ __launch_bounds__(256) void cfl_dp_rs_push_kernel(const float *src, long long n4, long long slice4, DpPeers p,
+                                                             unsigned gen, unsigned *ticket) {
     const long long stride = (long long)gridDim.x * 256;
-    const float scale = 1.f / (float)world;
-    const bool bad = *lost != 0;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+        const int s = (int)(i / slice4);                       // owner of element i
+        ((dp_f32x4 *)p.slot[s])[i - (long long)s * slice4] = ((const dp_f32x4 *)src)[i];
+    }
+    dp_signal_peers(p, gen, ticket);
+}
+
+__global__ __launch_bounds__(256) void cfl_dp_rs_adam_kernel(float *theta, float *m, float *v, const float *gslots,
+                                                             const unsigned *flags, int world, int rank, long long n4,
+                                                             long long nadam4, long long slice4, float *sum_out, DpPeers p,
+                                                             float lr_t, float b1, float b2, float eps, unsigned gen, int *lost,
+                                                             unsigned long long ticks, unsigned *ticket) {
+    const bool ok = dp_wait_flags(flags, world, -1, gen, ticks, lost);
+    const long long lo = (long long)rank * slice4, hi = lo + slice4 < n4 ? lo + slice4 : n4;
+    const float scale = 1.f / (float)world;
+    const long long stride = (long long)gridDim.x * 256;
+    for (long long i = lo + (long long)blockIdx.x * 256 + threadIdx.x; i < hi; i += stride) {
         dp_f32x4 g = {0.f, 0.f, 0.f, 0.f};
-        for (int r0 = 0; r0 < world; r0 += 4) {   // four slots in flight, added in rank order
+        for (int r0 = 0; r0 < world; r0 += 4) {   // four rows in flight, added in rank order
             dp_f32x4 s[4];
             const float *q[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) q[k] = slots + ((long long)(r0 + k < world ? r0 + k : 0) * n4 + i) * 4;
+            for (int k = 0; k < 4; ++k) q[k] = gslots + ((long long)(r0 + k < world ? r0 + k : 0) * slice4 + (i - lo)) * 4;
             load_sys16x4(q[0], q[1], q[2], q[3], s);
 #pragma unroll
             for (int k = 0; k < 4; ++k)
                 if (r0 + k < world) g = (r0 + k == 0) ? s[k] : g + s[k];
         }
-        if (bad) g = (dp_f32x4){NAN, NAN, NAN, NAN};
-        ((dp_f32x4 *)sum_out)[i] = g;       // the all-reduced buffer (gradient sums | scalar sums), as RCCL would leave it
+        if (!ok) g = (dp_f32x4){NAN, NAN, NAN, NAN};
+        ((dp_f32x4 *)sum_out)[i] = g;       // this rank's slice of the summed buffer (gradient sums | scalar sums)
+        dp_f32x4 out = g;
         if (i < nadam4) {
             g *= scale;
             dp_f32x4 mm = ((dp_f32x4 *)m)[i], vv = ((dp_f32x4 *)v)[i], th = ((dp_f32x4 *)theta)[i];
@@ -119,49 +152,161 @@ __global__ __launch_bounds__(256) void cfl_dp_adam_kernel(float *theta, float *m
             ((dp_f32x4 *)m)[i] = mm;
             ((dp_f32x4 *)v)[i] = vv;
             ((dp_f32x4 *)theta)[i] = th;
+            out = th;
         }
+        for (int r = 0; r < world; ++r)
+            if (r != rank) ((dp_f32x4 *)p.slot[r])[i] = out;   // all-gather, send side: one store per link
+    }
+    dp_signal_peers(p, gen, ticket);
+}
+
+__global__ __launch_bounds__(256) void cfl_dp_rs_gather_kernel(float *theta, float *sum_out, const float *stage,
+                                                               const unsigned *flags, int world, int rank, long long n4,
+                                                               long long nadam4, long long slice4, unsigned gen, int *lost,
+                                                               unsigned long long ticks) {
+    const bool ok = dp_wait_flags(flags, world, rank, gen, ticks, lost);
+    const long long lo = (long long)rank * slice4, hi = lo + slice4;
+    const long long stride = (long long)gridDim.x * 256;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+        if (i >= lo && i < hi) continue;    // own slice: written by cfl_dp_rs_adam_kernel
+        dp_f32x4 x = load_sys16(stage + i * 4);
+        if (!ok) x = (dp_f32x4){NAN, NAN, NAN, NAN};
+        if (i < nadam4) ((dp_f32x4 *)theta)[i] = x;
+        else ((dp_f32x4 *)sum_out)[i] = x;
     }
 }
 
-extern "C" int cfl_dp_push(const float *src, int64_t n, float *const *peer_slots, uint32_t *const *peer_flags,
-                           int32_t world, uint32_t generation, uint32_t *ticket, cfl_stream_t stream) {
-    if (!src || !peer_slots || !peer_flags || !ticket) return cfl_set_err(CFL_E_SHAPE, "cfl_dp_push: NULL pointer");
-    if (world < 1 || world > CFL_DP_MAX_WORLD) return cfl_set_err(CFL_E_SHAPE, "cfl_dp_push: world %d out of range", world);
-    if (n <= 0 || n % 4) return cfl_set_err(CFL_E_SHAPE, "cfl_dp_push: n=%lld must be a positive multiple of 4", (long long)n);
-    DpPeers p;
-    memset(&p, 0, sizeof(p));
-    p.world = world;
+// ---- exchange memory: fine-grained device allocations shared between the ranks' processes through hipIpc ----------------
+// HIP promises that stores of a peer GPU become visible to a RUNNING kernel of the owner only for fine-grained
+// (hipDeviceMallocFinegrained) memory; the slots and flags of the exchange are polled by running kernels, so they live
+// there.  The caller owns what it allocates here (cfl_dp_free) -- the library keeps no reference.
+extern "C" int cfl_dp_alloc(void **ptr, size_t bytes, int32_t fine_grained) {
+    if (!ptr || bytes == 0) return cfl_set_err(CFL_E_SHAPE, "cfl_dp_alloc: NULL pointer or zero size");
+    void *p = nullptr;
+    hipError_t e = fine_grained ? hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained) : hipMalloc(&p, bytes);
+    if (e != hipSuccess) return cfl_set_err(CFL_E_HIP, "cfl_dp_alloc(%zu bytes, fine_grained=%d): %s", bytes, fine_grained, hipGetErrorString(e));
+    e = hipMemset(p, 0, bytes);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) { (void)hipFree(p); return cfl_set_err(CFL_E_HIP, "cfl_dp_alloc: memset: %s", hipGetErrorString(e)); }
+    *ptr = p;
+    return CFL_OK;
+}
+
+extern "C" int cfl_dp_free(void *ptr) {
+    if (!ptr) return CFL_OK;
+    hipError_t e = hipFree(ptr);
+    return e == hipSuccess ? CFL_OK : cfl_set_err(CFL_E_HIP, "cfl_dp_free: %s", hipGetErrorString(e));
+}
+
+extern "C" int cfl_dp_ipc_export(void *ptr, void *handle64) {
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpcMemHandle_t is 64 bytes");
+    if (!ptr || !handle64) return cfl_set_err(CFL_E_SHAPE, "cfl_dp_ipc_export: NULL pointer");
+    hipIpcMemHandle_t h;
+    hipError_t e = hipIpcGetMemHandle(&h, ptr);
+    if (e != hipSuccess) return cfl_set_err(CFL_E_HIP, "hipIpcGetMemHandle: %s (HSA_ENABLE_IPC_MODE_LEGACY=0 set?)", hipGetErrorString(e));
+    memcpy(handle64, &h, 64);
+    return CFL_OK;
+}
+
+extern "C" int cfl_dp_ipc_open(const void *handle64, void **ptr) {
+    if (!ptr || !handle64) return cfl_set_err(CFL_E_SHAPE, "cfl_dp_ipc_open: NULL pointer");
+    hipIpcMemHandle_t h;
+    memcpy(&h, handle64, 64);
+    void *p = nullptr;
+    hipError_t e = hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess);
+    if (e != hipSuccess) return cfl_set_err(CFL_E_HIP, "hipIpcOpenMemHandle: %s", hipGetErrorString(e));
+    *ptr = p;
+    return CFL_OK;
+}
+
+extern "C" int cfl_dp_ipc_close(void *ptr) {
+    if (!ptr) return CFL_OK;
+    hipError_t e = hipIpcCloseMemHandle(ptr);
+    return e == hipSuccess ? CFL_OK : cfl_set_err(CFL_E_HIP, "hipIpcCloseMemHandle: %s", hipGetErrorString(e));
+}
+
+static int dp_fill_peers(DpPeers *p, float *const *slots, uint32_t *const *flags, int world, const char *who) {
+    memset(p, 0, sizeof(*p));
+    if (world < 1 || world > CFL_DP_MAX_WORLD) return cfl_set_err(CFL_E_SHAPE, "%s: world %d out of range", who, world);
+    p->world = world;
     for (int r = 0; r < world; ++r) {
-        if (!peer_slots[r] || !peer_flags[r] || ((uintptr_t)peer_slots[r] & 15))
-            return cfl_set_err(CFL_E_SHAPE, "cfl_dp_push: peer %d slot / flag NULL or misaligned", r);
-        p.slot[r] = peer_slots[r];
-        p.flag[r] = peer_flags[r];
+        if (!slots[r] || !flags[r] || ((uintptr_t)slots[r] & 15))
+            return cfl_set_err(CFL_E_SHAPE, "%s: peer %d slot / flag NULL or misaligned", who, r);
+        p->slot[r] = slots[r];
+        p->flag[r] = flags[r];
     }
-    const long long n4 = n / 4;
-    int blocks = (int)((n4 + 255) / 256);
-    if (blocks > 512) blocks = 512;
-    hipLaunchKernelGGL(cfl_dp_push_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, n4, p, generation, ticket);
-    return hipGetLastError() == hipSuccess ? CFL_OK : cfl_set_err(CFL_E_HIP, "cfl_dp_push launch failed");
+    return CFL_OK;
 }
 
-extern "C" int cfl_dp_wait(const uint32_t *flags, int32_t world, uint32_t generation, int32_t *lost, cfl_stream_t stream) {
-    if (!flags || !lost) return cfl_set_err(CFL_E_SHAPE, "cfl_dp_wait: NULL pointer");
-    if (world < 1 || world > CFL_DP_MAX_WORLD) return cfl_set_err(CFL_E_SHAPE, "cfl_dp_wait: world %d out of range", world);
-    hipLaunchKernelGGL(cfl_dp_wait_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, flags, world, generation, lost);
-    return hipGetLastError() == hipSuccess ? CFL_OK : cfl_set_err(CFL_E_HIP, "cfl_dp_wait launch failed");
+static unsigned long long dp_ticks(double timeout_s) {
+    if (!(timeout_s > 0.0)) timeout_s = 30.0;
+    return (unsigned long long)(timeout_s * 1e8);   // s_memrealtime counts at 100 MHz
 }
 
-extern "C" int cfl_dp_adam(float *theta, float *m, float *v, const float *slots, int32_t world, int64_t n,
-                           int64_t n_adam, float *sum_out, float lr_t, float beta1, float beta2, float eps,
-                           const int32_t *lost, cfl_stream_t stream) {
-    if (!theta || !m || !v || !slots || !sum_out || !lost) return cfl_set_err(CFL_E_SHAPE, "cfl_dp_adam: NULL pointer");
-    if (world < 1 || world > CFL_DP_MAX_WORLD) return cfl_set_err(CFL_E_SHAPE, "cfl_dp_adam: world %d out of range", world);
+static int dp_check_sizes(const char *who, int64_t n, int64_t n_adam, int64_t slice, int world, int rank) {
     if (n <= 0 || n % 4 || n_adam < 0 || n_adam % 4 || n_adam > n)
-        return cfl_set_err(CFL_E_SHAPE, "cfl_dp_adam: n=%lld n_adam=%lld", (long long)n, (long long)n_adam);
+        return cfl_set_err(CFL_E_SHAPE, "%s: n=%lld n_adam=%lld must be multiples of 4, n_adam <= n", who, (long long)n, (long long)n_adam);
+    if (slice <= 0 || slice % 4 || slice * world < n)
+        return cfl_set_err(CFL_E_SHAPE, "%s: slice=%lld must be a multiple of 4 with slice * world >= n", who, (long long)slice);
+    if (rank < 0 || rank >= world) return cfl_set_err(CFL_E_SHAPE, "%s: rank %d of %d", who, rank, world);
+    return CFL_OK;
+}
+
+extern "C" int cfl_dp_rs_push(const float *src, int64_t n, int64_t slice, float *const *peer_rows,
+                              uint32_t *const *peer_flags, int32_t world, uint32_t generation, uint32_t *ticket,
+                              cfl_stream_t stream) {
+    if (!src || !peer_rows || !peer_flags || !ticket) return cfl_set_err(CFL_E_SHAPE, "cfl_dp_rs_push: NULL pointer");
+    if (((uintptr_t)src & 15)) return cfl_set_err(CFL_E_SHAPE, "cfl_dp_rs_push: src must be 16-byte aligned");
+    DpPeers p;
+    int rc = dp_fill_peers(&p, peer_rows, peer_flags, world, "cfl_dp_rs_push");
+    if (rc) return rc;
+    rc = dp_check_sizes("cfl_dp_rs_push", n, 0, slice, world, 0);
+    if (rc) return rc;
     const long long n4 = n / 4;
     int blocks = (int)((n4 + 255) / 256);
-    if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(cfl_dp_adam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, theta, m, v, slots, world, n4,
-                       (long long)(n_adam / 4), sum_out, lr_t, beta1, beta2, eps, (const int *)lost);
-    return hipGetLastError() == hipSuccess ? CFL_OK : cfl_set_err(CFL_E_HIP, "cfl_dp_adam launch failed");
+    if (blocks > 256) blocks = 256;
+    hipLaunchKernelGGL(cfl_dp_rs_push_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, n4, (long long)(slice / 4), p,
+                       generation, ticket);
+    return hipGetLastError() == hipSuccess ? CFL_OK : cfl_set_err(CFL_E_HIP, "cfl_dp_rs_push launch failed");
+}
+
+extern "C" int cfl_dp_rs_adam(float *theta, float *m, float *v, const float *gslots, const uint32_t *flags, int32_t world,
+                              int32_t rank, int64_t n, int64_t n_adam, int64_t slice, float *sum_out,
+                              float *const *peer_stage, uint32_t *const *peer_flags, float lr_t, float beta1, float beta2,
+                              float eps, uint32_t generation, int32_t *lost, double timeout_s, uint32_t *ticket,
+                              cfl_stream_t stream) {
+    if (!theta || !m || !v || !gslots || !flags || !sum_out || !peer_stage || !peer_flags || !lost || !ticket)
+        return cfl_set_err(CFL_E_SHAPE, "cfl_dp_rs_adam: NULL pointer");
+    if (((uintptr_t)theta | (uintptr_t)m | (uintptr_t)v | (uintptr_t)gslots | (uintptr_t)sum_out) & 15)
+        return cfl_set_err(CFL_E_SHAPE, "cfl_dp_rs_adam: theta / m / v / slots / sum_out must be 16-byte aligned");
+    DpPeers p;
+    int rc = dp_fill_peers(&p, peer_stage, peer_flags, world, "cfl_dp_rs_adam");
+    if (rc) return rc;
+    rc = dp_check_sizes("cfl_dp_rs_adam", n, n_adam, slice, world, rank);
+    if (rc) return rc;
+    // few blocks on purpose: every block polls, and ranks that share a GPU (the functional tests) must never starve each
+    // other of compute units while they wait
+    int blocks = (int)((slice / 4 + 255) / 256);
+    if (blocks > 64) blocks = 64;
+    hipLaunchKernelGGL(cfl_dp_rs_adam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, theta, m, v, gslots, flags,
+                       world, rank, (long long)(n / 4), (long long)(n_adam / 4), (long long)(slice / 4), sum_out, p, lr_t, beta1,
+                       beta2, eps, generation, (int *)lost, dp_ticks(timeout_s), ticket);
+    return hipGetLastError() == hipSuccess ? CFL_OK : cfl_set_err(CFL_E_HIP, "cfl_dp_rs_adam launch failed");
+}
+
+extern "C" int cfl_dp_rs_gather(float *theta, float *sum_out, const float *stage, const uint32_t *flags, int32_t world,
+                                int32_t rank, int64_t n, int64_t n_adam, int64_t slice, uint32_t generation, int32_t *lost,
+                                double timeout_s, cfl_stream_t stream) {
+    if (!theta || !sum_out || !stage || !flags || !lost) return cfl_set_err(CFL_E_SHAPE, "cfl_dp_rs_gather: NULL pointer");
+    if (((uintptr_t)theta | (uintptr_t)sum_out | (uintptr_t)stage) & 15)
+        return cfl_set_err(CFL_E_SHAPE, "cfl_dp_rs_gather: theta / sum_out / stage must be 16-byte aligned");
+    if (world < 1 || world > CFL_DP_MAX_WORLD) return cfl_set_err(CFL_E_SHAPE, "cfl_dp_rs_gather: world %d out of range", world);
+    int rc = dp_check_sizes("cfl_dp_rs_gather", n, n_adam, slice, world, rank);
+    if (rc) return rc;
+    int blocks = (int)((n / 4 + 255) / 256);
+    if (blocks > 128) blocks = 128;
+    hipLaunchKernelGGL(cfl_dp_rs_gather_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, theta, sum_out, stage, flags,
+                       world, rank, (long long)(n / 4), (long long)(n_adam / 4), (long long)(slice / 4), generation, (int *)lost,
+                       dp_ticks(timeout_s));
+    return hipGetLastError() == hipSuccess ? CFL_OK : cfl_set_err(CFL_E_HIP, "cfl_dp_rs_gather launch failed");
 }

@@ -54,7 +54,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define CFL_MAX_JOBS 16
 #define CFL_MAX_REGIONS 20
 #define CFL_THR_FLOOR 1e-6f
-#define CFL_HANDOFF_SPIN_LIMIT (1 << 22)   // polls (with s_sleep) before an in-launch hand-off is declared lost
+#define CFL_HANDOFF_SPIN_LIMIT (1 << 22)   // polls (with s_sleep) before an in-launch hand-off is declared lost (default; CFL_DEBUG_SPIN_LIMIT overrides, < 0: give up at once)
+// A lost hand-off is LOUD: the kernel that gives up stores 1.0f into scalars[CFL_S_ERROR] -- a sticky word the library only
+// ever sets (the caller zeroes it once) -- and poisons what it was about to write with NaN.  The host finds the word at
+// its next read-back of the scalars (cfl_scalars_status(); PairEngine.read_scalars / DeferredScalars raise CflHipError).
 
 // ---------------------------------------------------------------------------
 // error plumbing
@@ -243,8 +246,47 @@ __device__ __forceinline__ void split3(float v, float &h, float &m, float &l) {
 __device__ __forceinline__ unsigned pack_hi16(float e0, float e1) {
     return __builtin_amdgcn_perm(__float_as_uint(e1), __float_as_uint(e0), 0x07060302u);
 }
-// three bf16x8 fragments (levels h, m, l) of the 8 floats v[0..7]
+// Round-to-nearest variant of the split (round 4): h = bf16_rne(v), m = bf16_rne(v - h), l = v - h - m -- still exact
+// (v - h and r - m are exact in fp32, l has at most 8 significant bits), but |m| <= 2^-9 |v| and |l| <= 2^-17 |v| with
+// errors of either sign, so the partial products a kernel DROPS are 16x smaller than with truncation (am*bl + al*bm +
+// al*bl <= 2^-23 |ab|, zero-mean instead of <= 2^-21 |ab|, one-signed) -- and it is cheaper: v_cvt_pk_bf16_f32 rounds and packs two
+// values per instruction and the subtractions pair up in v_pk_add_f32 (9 VALU instructions per two values against 11).
+// Used for the kept planes of theta (cfl_wplanes_kernel, the fused Adam tails) and the A operand of cfl_proj_bx3_kernel.
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split_pair_rne(float v0, float v1, unsigned &h, unsigned &m, unsigned &l) {
+    const f32x2 v = {v0, v1};
+    h = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+    const f32x2 hf = {__uint_as_float(h << 16), __uint_as_float(h & 0xffff0000u)};
+    const f32x2 r = v - hf;
+    m = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2));
+    const f32x2 mf = {__uint_as_float(m << 16), __uint_as_float(m & 0xffff0000u)};
+    l = __builtin_bit_cast(unsigned, __builtin_convertvector(r - mf, bf16x2));
+}
+__device__ __forceinline__ void split_frag_rne(const float (&v)[8], bf16x8 (&f)[3]) {
+    u32x4 ph, pm, pl;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        unsigned a, b, c;
+        split_pair_rne(v[2 * i], v[2 * i + 1], a, b, c);
+        ph[i] = a; pm[i] = b; pl[i] = c;
+    }
+    f[0] = __builtin_bit_cast(bf16x8, ph);
+    f[1] = __builtin_bit_cast(bf16x8, pm);
+    f[2] = __builtin_bit_cast(bf16x8, pl);
+}
+
+// three bf16x8 fragments (levels h, m, l) of the 8 floats v[0..7], by truncation.  (Round 4 measured the round-to-nearest
+// form above in its place, -DCFL_SPLIT_RNE: fewer instructions -- 9 against 11 per two values -- but the weight-gradient
+// launch got 0.4 .. 1.0 us SLOWER, profiles/r04_split_ab.txt: v_cvt_pk_bf16_f32 and v_pk_add_f32 do not issue at the rate
+// of the and / sub / perm chain.  Truncation stays for the operands split inside the loops; the kept planes of theta,
+// which are split once per update, are round-to-nearest -- one rounded operand is enough to make the dropped cross
+// terms zero-mean.)
 __device__ __forceinline__ void split_frag(const float (&v)[8], bf16x8 (&f)[3]) {
+#ifdef CFL_SPLIT_RNE
+    split_frag_rne(v, f);
+    return;
+#endif
     float h[8], m[8], l[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) split3(v[i], h[i], m[i], l[i]);
@@ -277,33 +319,43 @@ struct ColnormArgs {
     int D;
 };
 
-__device__ __forceinline__ void colnorm_column(const ColnormArgs &a, int col, float *red) {
-    int c = col, h = 0;
-    while (h < a.nheads && c >= a.npad[h]) { c -= a.npad[h]; ++h; }
-    if (h >= a.nheads) return;   // uniform per block
-    float acc = 0.f;
-    if (!a.strided[h]) {
-        // Wf layout: column c = 16nt + c16 lives at ((nt*G + g)*64 + q*16 + c16) float4s
-        const int G = a.D >> 4, nt = c >> 4, c16 = c & 15;
-        const f32x4 *w = (const f32x4 *)(a.theta + a.w_off[h]) + (size_t)nt * G * 64 + c16;
-        for (int i = threadIdx.x; i < G * 4; i += 256) {
-            const f32x4 v = w[(size_t)(i >> 2) * 64 + (i & 3) * 16];
-            acc += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+// One WAVE per column (round 4; a workgroup of 256 threads used to walk its columns one after the other, each with a
+// dependent round trip to memory and two barriers: with 256 columns on 64 blocks -- config 3 -- the colnorm slice was
+// the critical path of the projection launch).  All loads of a column are independent and issued together; the lane
+// sums are combined with wave_sum in a fixed order; no LDS, no barrier.  `first` / `stride` in columns.
+__device__ __forceinline__ void colnorm_columns(const ColnormArgs &a, int first, int stride) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int col = first + wave; col < a.ncols; col += stride) {
+        int c = col, h = 0;
+        while (h < a.nheads && c >= a.npad[h]) { c -= a.npad[h]; ++h; }
+        if (h >= a.nheads) return;   // uniform per wave
+        float acc = 0.f;
+        if (!a.strided[h]) {
+            // Wf layout: column c = 16nt + c16 lives at ((nt*G + g)*64 + q*16 + c16) float4s
+            const int G = a.D >> 4, nt = c >> 4, c16 = c & 15;
+            const f32x4 *w = (const f32x4 *)(a.theta + a.w_off[h]) + (size_t)nt * G * 64 + c16;
+            for (int i0 = 0; i0 < G * 4; i0 += 64 * 8) {
+                f32x4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int i = i0 + u * 64 + lane;
+                    v[u] = i < G * 4 ? w[(size_t)(i >> 2) * 64 + (i & 3) * 16] : (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc += (v[u][0] * v[u][0] + v[u][1] * v[u][1]) + (v[u][2] * v[u][2] + v[u][3] * v[u][3]);
+            }
+        } else {  // mono head V[L][kpad]: column c strided by kpad
+            const float *w = a.theta + a.w_off[h];
+            for (int l = lane; l < a.rowlen[h]; l += 64) {
+                float v = w[l * a.npad[h] + c];
+                acc = fmaf(v, v, acc);
+            }
         }
-    } else {  // mono head V[L][kpad]: column c strided by kpad
-        const float *w = a.theta + a.w_off[h];
-        for (int l = threadIdx.x; l < a.rowlen[h]; l += 256) {
-            float v = w[l * a.npad[h] + c];
-            acc = fmaf(v, v, acc);
+        acc = wave_sum(acc);
+        if (lane == 0) {
+            a.n2[a.n2_off[h] + c] = acc;
+            a.gcopy[a.n2_off[h] + c] = a.g_off[h] >= 0 ? a.theta[a.g_off[h] + c] : 1.f;
         }
-    }
-    acc = wave_sum(acc);
-    __syncthreads();             // red[] of the previous column has been read
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        a.n2[a.n2_off[h] + c] = (red[0] + red[1]) + (red[2] + red[3]);
-        a.gcopy[a.n2_off[h] + c] = a.g_off[h] >= 0 ? a.theta[a.g_off[h] + c] : 1.f;
     }
 }
 
@@ -497,6 +549,128 @@ __device__ __forceinline__ void proj_body(const ProjJob &jb, const ProjArgs &a, 
 }
 
 // ---------------------------------------------------------------------------
+// proj, bf16x3 on the chunk-at-a-time skeleton (round 4): cfl_proj_bx3_kernel.
+// At B <= 1024 the exact-fp32 projection above is bound by the fp32 matrix pipe wherever the heads are wide or the rows
+// many (config 4: 15 us of v_mfma_f32_16x16x4_f32 at peak in a 21 us launch; headline: 6.8 us per SIMD of 14); the
+// LDS-shared form (cfl_proj_x3_kernel) needs >= 512 work units of 128 rows to fill the chip and a d split that costs
+// `mid` more than it saves below ~3000 rows per side.  This form keeps everything that shapes the launch -- 32-row tiles,
+// one 128-d chunk per wave, S, the XCD-aligned order, the slab layout -- and swaps the arithmetic only:
+//   * B operand = the KEPT bf16 planes of theta (CflThetaPlanes: written by the Adam tail of the previous step, round-to-
+//     nearest split), fetched per wave as 1 KiB blocks like the fp32 fragments they replace (6 instead of 4 bytes per
+//     weight from L2; no split of W anywhere in the step);
+//   * A operand = the wave's 32 x 32 quarter of x, parked in the wave-private LDS tile as before, read back as whole
+//     128-byte rows and split round-to-nearest in the VALU slots of the matrix pipe (16 values per lane and quarter);
+//   * SIX partial products (ah bh, ah bm, am bh, ah bl, al bh, am bm) per 16x16x32 block on v_mfma_f32_16x16x32_bf16:
+//     96 matrix-pipe cycles per block against 256 for the eight fp32 MFMAs; with round-to-nearest parts the dropped terms
+//     are <= 2^-23 |ab| and zero-mean -- the size of one fp32 rounding (tests: error against the float64
+//     oracle within 2x of the exact-fp32 form's).
+// Selected by the plan when the caller keeps planes (the fused single-GPU training step); every other call keeps the
+// exact-fp32 kernel.
+// ---------------------------------------------------------------------------
+template <int NT>
+__device__ __forceinline__ void proj_body_bx3(const ProjJob &jb, const ProjArgs &a, f32x4 *lds) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int i16 = lane & 15, kq = lane >> 4;
+    const int rr8 = lane >> 3, ch8 = lane & 7;
+    const int row0 = (a.xcd ? blockIdx.y : blockIdx.x) * 32;
+    const int s = a.xcd ? blockIdx.x : blockIdx.y;
+    const int G = a.D >> 4, Q = a.D >> 5;
+    const int NC = (G + 7) >> 3;
+    const int nw = a.S * 4, wg = s * 4 + wave;
+    const int cbeg = wg * NC / nw, cend = (wg + 1) * NC / nw;
+
+    f32x4 acc[2][NT];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const float *xrow[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) xrow[i] = row_ptr(a.rows[jb.side], row0 + 8 * i + rr8, a.B, a.R, a.D) + 4 * ch8;
+    const unsigned short *pll = (const unsigned short *)jb.wf + lane * 8;   // planes of this job's first column tile
+    f32x4 *tile = lds + wave * 256;
+
+    for (int c = cbeg; c < cend; ++c) {
+        const int t0 = c * 4;                      // first 32-d quarter of the chunk
+        const bool full = Q - t0 >= 4;             // otherwise 2 quarters (D % 64 == 0)
+        bf16x8 bq[2][NT][3];
+        f32x4 araw[4][4];
+        auto loadB = [&](int qq, bf16x8 (*dst)[3]) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+                    dst[nt][pl] = *(const bf16x8 *)(pll + ((size_t)(nt * Q + t0 + qq) * 3 + pl) * 512);
+        };
+        auto loadA = [&](int qq) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) araw[qq][i] = *(const f32x4 *)(xrow[i] + (t0 + qq) * 32);
+        };
+        loadB(0, bq[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        loadA(0);
+        __builtin_amdgcn_sched_barrier(0);
+        loadB(1, bq[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        loadA(1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (full) {
+            loadA(2);
+            __builtin_amdgcn_sched_barrier(0);
+            loadA(3);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) {
+            if (qq >= 2 && !full) break;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = 8 * i + rr8;
+                tile[row * 8 + (ch8 ^ (row & 7))] = norm_apply(araw[qq][i], a.norm, (t0 + qq) * 32 + 4 * ch8);
+            }
+            bf16x8 af[2][3];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const int row = mt * 16 + i16;
+                const f32x4 c0 = tile[row * 8 + ((2 * kq) ^ (row & 7))], c1 = tile[row * 8 + ((2 * kq + 1) ^ (row & 7))];
+                float v[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
+#ifdef CFL_BX3_A_RNE
+                split_frag_rne(v, af[mt]);
+#else
+                split_frag(v, af[mt]);
+#endif
+            }
+            // six partial products, small terms first; consecutive MFMAs hit different accumulators
+#define CFL_BX3(LA, LB)                                                                                       \
+    _Pragma("unroll") for (int mt = 0; mt < 2; ++mt) _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = \
+        __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mt][LA], bq[qq & 1][nt][LB], acc[mt][nt], 0, 0, 0);
+            CFL_BX3(1, 1) CFL_BX3(2, 0) CFL_BX3(0, 2) CFL_BX3(1, 0) CFL_BX3(0, 1) CFL_BX3(0, 0)
+#undef CFL_BX3
+            if (qq < 2 && full) loadB(qq + 2, bq[qq & 1]);
+        }
+    }
+
+    // cross-wave sum and slab store: identical to proj_body
+    __syncthreads();
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) lds[(wave * 2 * NT + mt * NT + nt) * 64 + lane] = acc[mt][nt];
+    __syncthreads();
+    for (int t = wave; t < 2 * NT; t += 4) {
+        const int mt = t / NT, nt = t % NT;
+        f32x4 sum = lds[(0 * 2 * NT + t) * 64 + lane];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) sum += lds[(w * 2 * NT + t) * 64 + lane];
+        float *dst = jb.ypart + (size_t)s * jb.sstride + (size_t)(row0 + mt * 16 + 4 * kq) * jb.npad + nt * 16 + i16;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dst[(size_t)e * jb.npad] = sum[e];
+    }
+}
+
+// ---------------------------------------------------------------------------
 // proj, streaming form: the same contraction for waves that own SEVERAL 128-d chunks (S <= 2: 2048 rows per
 // side and more, and every dist_eval / dist_predict call).  proj_body above issues the 16 x loads of a chunk,
 // waits for them and multiplies, chunk after chunk: with one chunk per wave (the training step at B = 512) that
@@ -669,7 +843,7 @@ extern "C" __global__ __launch_bounds__(256) void cfl_proj_stream_kernel(ProjArg
         case 0: {
             const int nb = a.mix ? a.mixtiles : gridDim.x * gridDim.y;
             const int b0 = a.mix ? rowtile : blockIdx.y * gridDim.x + blockIdx.x;
-            for (int col = b0; col < a.cn.ncols; col += nb) colnorm_column(a.cn, col, (float *)smem);
+            colnorm_columns(a.cn, 4 * b0, 4 * nb);
             break;
         }
         case 1: proj_stream_body<1>(jb, a, lds, rowtile); break;
@@ -982,6 +1156,8 @@ struct Px3Args {
     int B, R, D, S, njobs;
     int tiles, nunits, nwg, Kq;                      // Kq = 32-d quarters per slice
     NormDev norm;
+    int ncn;                                         // weight-norm: workgroups [0, ncn) of the launch compute the column norms
+    ColnormArgs cn;                                  // (dispatched first, short; `mid` is their first consumer)
 };
 
 // W (fragment-major fp32, Wf[nt][g][q][c16][e]) -> planes[((nt * Q + tq) * 3 + p) * 512 + lane * 8 + j]:
@@ -1005,7 +1181,7 @@ __global__ __launch_bounds__(256) void cfl_wplanes_kernel(WPlanesArgs w) {   // 
     const f32x4 v0 = *(const f32x4 *)src, v1 = *(const f32x4 *)(src + 64);
     float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
     bf16x8 f[3];
-    split_frag(v, f);
+    split_frag_rne(v, f);
     unsigned short *dst = planes + ((size_t)(nt * Q + tq) * 3) * 512 + lane * 8;
 #pragma unroll
     for (int p = 0; p < 3; ++p) *(bf16x8 *)(dst + p * 512) = f[p];
@@ -1144,7 +1320,11 @@ __device__ __forceinline__ void px3_unit(const Px3Args &a, const ProjJob &jb, in
     extern "C" __global__ __launch_bounds__(256, 2) void NAME(Px3Args a_) {                             \
         CFL_KERNARG_IN_PLACE(Px3Args, a, a_);                                                           \
         extern __shared__ __attribute__((aligned(16))) char smem[];                                     \
-        const int w = blockIdx.x;                                                                       \
+        if ((int)blockIdx.x < a.ncn) {                                                                  \
+            colnorm_columns(a.cn, 4 * (int)blockIdx.x, 4 * a.ncn);                                    \
+            return;                                                                                     \
+        }                                                                                               \
+        const int w = blockIdx.x - a.ncn;                                                               \
         for (int i = 0;; ++i) {                                                                         \
             /* snake order over the heavy-to-light unit list (as the ring form) */                      \
             const int base = (i >> 1) * 2 * a.nwg;                                                      \
@@ -1173,13 +1353,30 @@ extern "C" __global__ __launch_bounds__(256) void cfl_proj_kernel(ProjArgs a) {
     switch (jb.nt) {
         case 0: {   // the colnorm slice (marked by nt == 0: no kernel-argument load of its own in front of the dispatch)
             const int nb = gridDim.x * gridDim.y;
-            for (int col = blockIdx.y * gridDim.x + blockIdx.x; col < a.cn.ncols; col += nb) colnorm_column(a.cn, col, (float *)smem);
+            colnorm_columns(a.cn, 4 * (int)(blockIdx.y * gridDim.x + blockIdx.x), 4 * nb);
             break;
         }
         case 1: proj_body<1>(jb, a, lds); break;
         case 2: proj_body<2>(jb, a, lds); break;
         case 3: proj_body<3>(jb, a, lds); break;
         default: proj_body<4>(jb, a, lds); break;
+    }
+}
+
+extern "C" __global__ __launch_bounds__(256, 2) void cfl_proj_bx3_kernel(ProjArgs a) {   // ProjJob::wf = the job's kept planes
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    f32x4 *lds = (f32x4 *)smem;
+    const ProjJob &jb = a.job[blockIdx.z];
+    switch (jb.nt) {
+        case 0: {   // the colnorm slice (reads the fp32 weights through a.cn)
+            const int nb = gridDim.x * gridDim.y;
+            colnorm_columns(a.cn, 4 * (int)(blockIdx.y * gridDim.x + blockIdx.x), 4 * nb);
+            break;
+        }
+        case 1: proj_body_bx3<1>(jb, a, lds); break;
+        case 2: proj_body_bx3<2>(jb, a, lds); break;
+        case 3: proj_body_bx3<3>(jb, a, lds); break;
+        default: proj_body_bx3<4>(jb, a, lds); break;
     }
 }
 
@@ -1240,6 +1437,8 @@ struct GradFuse {
     const float *theta;
     float *grad;                 // flat gradient, layout of theta
     float *theta_out, *m, *v;    // fused TF-Adam (m == nullptr: gradient only)
+    unsigned short *planes;      // kept bf16 planes of theta (CflThetaPlanes::buf) or nullptr: the tile finishers write the
+                                 // planes of the weights they update (ushort index 3 * theta offset of the Wf block + ...)
     float lr_t, b1, b2, eps, in_mul, reg_const;
     long long w_off[CFL_MAX_JOBS];   // theta offset of the job's Wf tile base
     // row-reduction side: red range k (kind 0) feeds the bias array at red_b[k] (npad red_npad[k], n red_n[k])
@@ -1259,6 +1458,7 @@ struct GradFuse {
     // (scalars only: one more dynamically indexed array in this argument block and hipcc copies the whole block to
     // scratch -- 2.4 KB per lane, the weight-gradient launch 2.7x slower)
     int pair_jobs;
+    int spin_limit;         // polls before a hand-off is declared lost (CFL_HANDOFF_SPIN_LIMIT; < 0: at once -- the failure test)
     long long pair_delta;   // floats from side 0's slab array to side 1's (same column chunk, same row range)
     // monomer gate head V[L][kpad] (+ gains) of the SOURCE encoder: finished by the kind-1 / kind-2 reduction blocks
     long long mono_w, mono_g;   // theta offsets (-1: none)
@@ -1386,7 +1586,7 @@ __device__ __forceinline__ void adam4(f32x4 &th, f32x4 &mm, f32x4 &vv, const f32
 }
 
 // gradient entry -> flat gradient (+ L2 term) -> optional TF-Adam, 4 consecutive parameters at `off`
-__device__ __forceinline__ void fuse_apply(const GradFuse &f, long long off, f32x4 gr, f32x4 th, f32x4 mm, f32x4 vv) {
+__device__ __forceinline__ void fuse_apply(const GradFuse &f, long long off, f32x4 gr, f32x4 &th, f32x4 mm, f32x4 vv) {   // th: updated in place (the planes are split from it)
     if (f.reg_const != 0.f) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) gr[e] = fmaf(f.reg_const, th[e], gr[e]);
@@ -1451,22 +1651,23 @@ __device__ __forceinline__ void grad_fused_tail(const GradArgs &a, int job, int 
             // Bounded: ~2^22 polls with s_sleep is > 100 ms, four orders of magnitude beyond any hand-off of a healthy
             // launch.  The waits are for workgroups dispatched BEFORE this one (smaller linear id), which never wait
             // themselves, so a time-out means the dispatch-order assumption or the visibility protocol failed.
-            int ok = 1;
-            if (expect > 0) {
+            int ok = f.spin_limit < 0 ? 0 : 1;
+            if (expect > 0 && ok) {
                 int spins = 0;
                 while (__hip_atomic_load(f.flag + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < expect) {
                     __builtin_amdgcn_s_sleep(1);
-                    if (++spins > CFL_HANDOFF_SPIN_LIMIT) { ok = 0; break; }
+                    if (++spins > f.spin_limit) { ok = 0; break; }
                 }
             }
             if (f.wn && ok) {   // the c_j column sums of this launch's reduction blocks (dispatched first, short)
                 int spins = 0;
                 while (__hip_atomic_load(f.red_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < f.red_expect) {
                     __builtin_amdgcn_s_sleep(1);
-                    if (++spins > CFL_HANDOFF_SPIN_LIMIT) { ok = 0; break; }
+                    if (++spins > f.spin_limit) { ok = 0; break; }
                 }
             }
             lds_i[0] = ok;
+            if (!ok) f.scalars[CFL_S_ERROR] = 1.f;   // sticky error word: the host raises at its next read-back
         }
         __syncthreads();
         lost = lds_i[0] == 0;
@@ -1526,6 +1727,25 @@ __device__ __forceinline__ void grad_fused_tail(const GradArgs &a, int job, int 
         } else {
 #pragma unroll
             for (int e = 0; e < 4; ++e) fuse_apply(f, base + e * 64, g[e] * f.in_mul, th[e], mm[e], vv[e]);
+        }
+        if (f.planes && f.m) {
+            // kept bf16 planes of the updated weights (cfl_wplanes_kernel's layout, bit for bit): this lane holds d =
+            // dbase + 16 kq + 4 e + e' of column i16, i.e. the two 8-value groups c = 0, 1 (e = 2c, 2c + 1) of 32-d quarter
+            // tq = (Wf row group) / 2, fragment lane (2 (g & 1) + c) * 16 + i16
+            const int lane = threadIdx.x & 63, i16 = lane & 15;
+            const int G = a.D >> 4, Q = a.D >> 5;
+            const int gg = (int)((tile_off >> 8) % (size_t)G), ntw = (int)((tile_off >> 8) / (size_t)G);
+            unsigned short *pb = f.planes + 3 * f.w_off[job] + ((size_t)(ntw * Q + (gg >> 1)) * 3) * 512;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                float vals[8] = {th[2 * c][0], th[2 * c][1], th[2 * c][2], th[2 * c][3],
+                                 th[2 * c + 1][0], th[2 * c + 1][1], th[2 * c + 1][2], th[2 * c + 1][3]};
+                bf16x8 fr[3];
+                split_frag_rne(vals, fr);
+                unsigned short *dst = pb + ((2 * (gg & 1) + c) * 16 + i16) * 8;
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) *(bf16x8 *)(dst + pl * 512) = fr[pl];
+            }
         }
     }
 }
@@ -1640,6 +1860,11 @@ __device__ __forceinline__ void grad_body(const GradJob &jb, const GradArgs &a, 
 // the step's scalars (cfl/models/cfl.py:868-949) from the row sums `sc` of the per-row loss quantities
 __device__ __forceinline__ void write_scalars(float *o, const float *sc, float regsum, int B, int use_threshold,
                                               float pos_weight, float caffe_margin, float lambda_m, float thr) {
+    // no fused multiply-adds in here: the function is inlined into the finalize kernel and into the reduction block of the
+    // weight-gradient launch, and a contraction across the call boundary (regsum = 0.5 * reg_const * rs is an expression at
+    // one call site, a value from LDS at the other) made the two differ by an ulp in `total` (round 4, found by the
+    // fused-vs-finalize test once unrelated edits moved the compiler's choice)
+#pragma clang fp contract(off)
     const float invB = 1.f / (float)B;
     const float pw = pos_weight != 0.f ? pos_weight : 1.f;
     const float lpos = sc[P_BCE_POS] * invB, lneg = sc[P_BCE_NEG] * invB;
@@ -1666,7 +1891,7 @@ __device__ __forceinline__ void write_scalars(float *o, const float *sc, float r
     o[CFL_S_DIST_ADAPT_POS] = sc[P_SQRT_POS] * invB;
     o[CFL_S_DIST_ADAPT_NEG] = sc[P_SQRT_NEG] * invB;
     o[14] = 0.f;
-    o[15] = 0.f;
+    // o[CFL_S_ERROR] is sticky: set by a kernel that gave up on a hand-off, never cleared by the library
 }
 
 // one parameter: flat gradient (+ L2 term) and optional TF-Adam (fused mode, bias / threshold entries)
@@ -1684,7 +1909,7 @@ __device__ __forceinline__ void fuse_apply1(const GradFuse &f, long long off, fl
 }
 
 // In-launch producers (the row-math blocks of cfl_midgrad_half_kernel): flag words that carry the launch's generation.
-struct MgWait { const unsigned *flags; int n; unsigned gen; int early_x; };
+struct MgWait { const unsigned *flags; int n; unsigned gen; int early_x; int spin_limit; float *err; };
 
 // one wave polls all flags (sc1 loads, bounded), ONE agent-scope acquire, drain, workgroup barrier: plain loads of
 // what the producers wrote through are valid afterwards (MI355X_MICROARCH.md, Valid forms: consumer)
@@ -1697,12 +1922,13 @@ __device__ __forceinline__ bool mg_wait_all(const MgWait &w, int *lds_i) {
             for (int i = lane; i < w.n; i += 64)
                 all = all && __hip_atomic_load(w.flags + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == w.gen;
             if (__builtin_amdgcn_ballot_w64(!all) == 0) break;
-            if (++spins > CFL_HANDOFF_SPIN_LIMIT) { ok = 0; break; }
+            if (++spins > w.spin_limit) { ok = 0; break; }
             __builtin_amdgcn_s_sleep(2);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane == 0) lds_i[0] = ok;
+        if (lane == 0 && !ok && w.err) *w.err = 1.f;   // sticky error word
     }
     __syncthreads();
     const bool ok = lds_i[0] != 0;
@@ -2259,22 +2485,23 @@ __device__ __forceinline__ void grad_body_x3_half(const GradJob &jb, const GradA
     if (f.wn) { wg = f.wn_g[job][wcol]; wn2 = f.wn_n2[job][wcol]; }
     if ((HO && expect > 0) || f.wn) {
         if (threadIdx.x == 0) {   // bounded waits, as in grad_fused_tail
-            int ok = 1;
-            if (expect > 0) {
+            int ok = f.spin_limit < 0 ? 0 : 1;
+            if (expect > 0 && ok) {
                 int spins = 0;
                 while (__hip_atomic_load(f.flag + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < expect) {
                     __builtin_amdgcn_s_sleep(1);
-                    if (++spins > CFL_HANDOFF_SPIN_LIMIT) { ok = 0; break; }
+                    if (++spins > f.spin_limit) { ok = 0; break; }
                 }
             }
             if (f.wn && ok) {   // the c_j column sums of this launch's reduction blocks (dispatched first, short)
                 int spins = 0;
                 while (__hip_atomic_load(f.red_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < f.red_expect) {
                     __builtin_amdgcn_s_sleep(1);
-                    if (++spins > CFL_HANDOFF_SPIN_LIMIT) { ok = 0; break; }
+                    if (++spins > f.spin_limit) { ok = 0; break; }
                 }
             }
             ((int *)lds)[0] = ok;
+            if (!ok) f.scalars[CFL_S_ERROR] = 1.f;   // sticky error word (see CFL_HANDOFF_SPIN_LIMIT)
         }
         __syncthreads();
         lost = lost || ((int *)lds)[0] == 0;
@@ -2321,6 +2548,16 @@ __device__ __forceinline__ void grad_body_x3_half(const GradJob &jb, const GradA
                 for (int i = 0; i < 4; ++i) gr[i] = fmaf(-s2, th[h][i], gr[i]);
             }
             fuse_apply(f, base + h * 64, gr, th[h], mm[h], vv[h]);
+        }
+        if (f.planes && f.m) {
+            // kept bf16 planes of the updated weights: this lane holds d = 32 dtile + 8 kq + (0 .. 7) of column i16 -- exactly
+            // fragment lane `lane` of quarter tq = dtile in cfl_wplanes_kernel's layout: one 16-byte store per plane
+            float vals[8] = {th[0][0], th[0][1], th[0][2], th[0][3], th[1][0], th[1][1], th[1][2], th[1][3]};
+            bf16x8 fr[3];
+            split_frag_rne(vals, fr);
+            unsigned short *dst = f.planes + 3 * f.w_off[job] + ((size_t)(ntw * (a.D >> 5) + dtile) * 3) * 512 + lane * 8;
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) *(bf16x8 *)(dst + pl * 512) = fr[pl];
         }
     }
 }
@@ -3376,6 +3613,8 @@ struct FoldArgs {
     int group, S, ntile_wgs, rows_per_wg;   // workgroups per tile, d slices, tiles * group, 32 / group
     unsigned gen;
     int sc1_loads;
+    int spin_limit;
+    float *err;                             // scalars + CFL_S_ERROR (training) or NULL
     unsigned *flags;                        // [tiles * group]
     int nt_of_job[CFL_MAX_JOBS];
 };
@@ -3407,7 +3646,10 @@ extern "C" __global__ __launch_bounds__(256) void cfl_proj_mid_kernel(ProjArgs a
         for (;;) {
             const unsigned v = lane < fa.group ? __hip_atomic_load(fl + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : fa.gen;
             if (__builtin_amdgcn_ballot_w64(v != fa.gen) == 0) break;
-            if (++spins > CFL_HANDOFF_SPIN_LIMIT) break;   // lost hand-off: the rows below read garbage -> NaN loss, no hang
+            if (++spins > fa.spin_limit) {   // lost hand-off: the rows below read garbage; the sticky error word says so
+                if (lane == 0 && fa.err) *fa.err = 1.f;
+                break;
+            }
             __builtin_amdgcn_s_sleep(1);
         }
         if (!fa.sc1_loads) {
@@ -3460,7 +3702,7 @@ extern "C" __global__ __launch_bounds__(256) void cfl_midgrad_half_kernel(MidGra
         if (threadIdx.x == 0) __hip_atomic_store(a.flags + id, a.gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
     }
-    const MgWait mg = {a.flags, a.nrow + a.nreg, a.gen, a.early_x};
+    const MgWait mg = {a.flags, a.nrow + a.nreg, a.gen, a.early_x, a.g.fuse.spin_limit < 0 ? 0 : a.g.fuse.spin_limit, a.g.fuse.scalars + CFL_S_ERROR};
     if (id < a.nrow + a.nreg + a.nred) {
         grad_red_block(a.g, (float *)smem, &mg, id - a.nrow - a.nreg, a.nred);
         return;
@@ -3737,6 +3979,14 @@ static int check_shape(const CflShape *s) {
 }
 
 extern "C" int cfl_version(void) { return CFL_ABI_VERSION; }
+
+extern "C" int cfl_scalars_status(const float *host_scalars) {
+    if (!host_scalars) return set_err(CFL_E_SHAPE, "scalars is NULL");
+    if (host_scalars[CFL_S_ERROR] != 0.f)   // (NaN compares unequal to 0 too: a poisoned word is an error)
+        return set_err(CFL_E_HANDOFF, "an in-launch hand-off was lost (a workgroup gave up waiting for its partners): the "
+                                      "parameters are poisoned with NaN from that step on -- do not checkpoint them");
+    return CFL_OK;
+}
 extern "C" const char *cfl_last_error(void) { return g_err; }
 
 extern "C" int cfl_layout(const CflShape *s, CflLayout *out) {
@@ -3788,6 +4038,8 @@ struct Plan {
     int proj_stream;  // 0: one wait per 128-d chunk (proj_body); 1: streaming form (proj_stream_body)
     bool proj_mix;    // streaming form at S == 1: column jobs interleaved in launch order
     bool proj_x3;     // bf16x3 forward with LDS-shared W planes (cfl_proj_x3_kernel); S is then its d split
+    bool planes_kept; // the caller keeps the planes beside theta (CflThetaPlanes): no per-call split launch
+    bool proj_bx3;    // ... and the chunk-at-a-time projection multiplies them on the bf16 matrix cores (cfl_proj_bx3_kernel)
     size_t wplanes[2];
     bool fold;        // proj + mid in one launch (cfl_proj_mid_kernel)
     size_t fold_flags;
@@ -3828,7 +4080,7 @@ static void side_heads(const CflShape *s, const CflLayout &lay, const CflHead **
     }
 }
 
-static int make_plan(const CflShape *s, int64_t rows, int groups, bool train, Plan *pl) {
+static int make_plan(const CflShape *s, int64_t rows, int groups, bool train, bool planes_kept, Plan *pl) {
     int rc = cfl_layout(s, &pl->lay);
     if (rc) return rc;
     if (rows <= 0 || groups < 1 || groups > 2) return set_err(CFL_E_SHAPE, "rows=%lld groups=%d", (long long)rows, groups);
@@ -3868,6 +4120,13 @@ static int make_plan(const CflShape *s, int64_t rows, int groups, bool train, Pl
         if (!paired && ht * njobs >= 256 && ht * njobs <= 640 && pl->R <= 6144 && debug_env("CFL_DEBUG_P") <= 0) {
             pl->grad_half = true;
             P = pl->R > 2048 ? 2 : 1;
+        }
+        // fewer half tiles than CUs but rows enough to split in two (config 4: 64 x 3 = 192 tiles, 2048 rows per side): 384
+        // workgroups, one published tile per finisher.  Round 4, same box: config 4 49.9 -> 47.9 us against the 64-d tiles
+        // with four row ranges (three published tiles per finisher); without the split 50.3 (profiles/r04_split_ab.txt)
+        if (!paired && ht * njobs >= 128 && ht * njobs < 256 && pl->R >= 2048 && pl->R <= 6144 && debug_env("CFL_DEBUG_P") <= 0) {
+            pl->grad_half = true;
+            P = 2;
         }
         // siamese: side 0's half tile is published, side 1's workgroup of the same tile finishes -- ONE published tile per
         // finisher and twice as many finishers as the 64-d / P = 2 form (config 3: three tiles per finisher)
@@ -3920,19 +4179,26 @@ static int make_plan(const CflShape *s, int64_t rows, int groups, bool train, Pl
     // bf16x3 forward with shared W planes: 128-row tiles, d split so that the 512 resident workgroups (two per CU) get
     // one or two units each; slices are whole 128-d chunks
     pl->proj_x3 = false;
+    pl->planes_kept = planes_kept && train;
     if (!pl->proj_ring) {
         const int ov = debug_env("CFL_DEBUG_PROJ_X3");
         const int tiles = (pl->R + 127) / 128;
         int rs = 1;
         const int want_units = debug_env("CFL_DEBUG_X3_UNITS") > 0 ? debug_env("CFL_DEBUG_X3_UNITS") : 384;
-        while (rs < 16 && njobs * tiles * rs < want_units && (s->D / 128) % (2 * rs) == 0 && s->D / (2 * rs) >= 512) rs *= 2;
+        // slices of at least 512 d -- 256 d (eight 32-d steps per unit) only to reach 256 units at all (configs 3 / 4)
+        const int min_slice = debug_env("CFL_DEBUG_X3_MINSLICE") > 0 ? debug_env("CFL_DEBUG_X3_MINSLICE") : 512;
+        while (rs < 16 && njobs * tiles * rs < want_units && (s->D / 128) % (2 * rs) == 0 && s->D / (2 * rs) >= min_slice) rs *= 2;
+        while (rs < 16 && njobs * tiles * rs < 256 && (s->D / 128) % (2 * rs) == 0 && s->D / (2 * rs) >= 256) rs *= 2;
         const int units = njobs * tiles * rs;
         const bool ok = s->D % 128 == 0 && (s->D / 128) % rs == 0 && units >= 256 && pl->x3;
         // From 4096 rows per side for scoring calls (-7 % at 4096 pairs, +11 % at 2048), from 3072 (B >= 1536) in training --
         // there x is loaded with the default cache policy while both sides are within reach of the Infinity Cache, so that
         // the weight gradient's re-read hits it.  Bench medians, same box, step us with / without: B = 1536 69.2 / 76.3,
         // 2048 81.0 / 84.0, 3072 109.2 / 117.5, 4096 140.8 / 145.2 (and 143.2 with streamed x loads)
-        if (ok && ov >= 0 && (ov > 0 || pl->R >= (train ? 3072 : 4096))) {
+        // With planes kept beside theta by the fused training step (CflThetaPlanes) the per-call W split -- a launch of
+        // ~4 us -- is gone, and the threshold of the training step drops to `kept_rows` (measured: see DESIGN section 4)
+        const int kept_rows = debug_env("CFL_DEBUG_X3_KEPT_ROWS") > 0 ? debug_env("CFL_DEBUG_X3_KEPT_ROWS") : 3072;
+        if (ok && ov >= 0 && (ov > 0 || pl->R >= (train ? (pl->planes_kept ? kept_rows : 3072) : 4096))) {
             pl->proj_x3 = true;
             pl->ring_tiles = tiles;
             pl->ring_units = units;
@@ -3950,6 +4216,11 @@ static int make_plan(const CflShape *s, int64_t rows, int groups, bool train, Pl
         pl->proj_stream = ov < 0 ? 0 : ov > 0 ? 1 : (per_wave >= 4 ? 1 : 0);
         pl->proj_mix = debug_env("CFL_DEBUG_PROJ_MIX") > 0;   // opt-in: measured +15 % (slower) on dist_eval calls
     }
+    // bf16x3 arithmetic on the chunk-at-a-time skeleton (cfl_proj_bx3_kernel): whenever the caller keeps the planes of
+    // theta current (the fused single-GPU training step) and the wave owns fewer than four chunks
+    // (CFL_DEBUG_PROJ_BX3=1: also without kept planes -- per-call split into the workspace, the tests' reference run; -1: never)
+    pl->proj_bx3 = (pl->planes_kept || debug_env("CFL_DEBUG_PROJ_BX3") > 0) && pl->x3 && !pl->proj_x3 && !pl->proj_ring &&
+                   !pl->proj_stream && debug_env("CFL_DEBUG_PROJ_BX3") >= 0;
     pl->mid_generic = debug_env("CFL_DEBUG_MID_GENERIC") > 0;
     pl->mid_norow = debug_env("CFL_DEBUG_MID_NOROW") != 0;
     pl->nrb = pl->Rpad / MID_RB;
@@ -3998,7 +4269,7 @@ static int make_plan(const CflShape *s, int64_t rows, int groups, bool train, Pl
         const int group = S * njobs;
         const int wide = hs->npad > hd->npad ? hs->npad : hd->npad;
         pl->fold = debug_env("CFL_DEBUG_FOLD") > 0 && s->dist_type == CFL_DIST_PCD && !s->weight_norm && wide <= 64 &&
-                   s->K <= 64 && S % 8 == 0 && group <= 32 && 32 % group == 0 && !pl->proj_ring && !pl->proj_stream && !pl->proj_x3 &&
+                   s->K <= 64 && S % 8 == 0 && group <= 32 && 32 % group == 0 && !pl->proj_ring && !pl->proj_stream && !pl->proj_x3 && !pl->proj_bx3 &&
                    pl->R % 32 == 0 && (!train || pl->Rpad == pl->R) && !pl->mid_generic && !pl->mid_norow;
         pl->fold_flags = take(pl->fold ? (size_t)(pl->R / 32) * group : 0);
     }
@@ -4011,8 +4282,9 @@ static int make_plan(const CflShape *s, int64_t rows, int groups, bool train, Pl
                       !pl->mid_generic && !pl->mid_norow && pl->Rpad % 4 == 0 && (pl->lay.total / 4096 + 2) < 4096;
         pl->mg_flags = take(pl->midgrad ? (size_t)pl->Rpad / 4 + pl->nregblocks + 64 : 0);
     }
-    pl->wplanes[0] = take(pl->proj_x3 ? (size_t)hs->npad * s->D * 3 / 2 : 0);   // bf16 planes: 6 bytes per weight
-    pl->wplanes[1] = take(pl->proj_x3 ? (size_t)hd->npad * s->D * 3 / 2 : 0);
+    const bool ws_planes = (pl->proj_x3 || pl->proj_bx3) && !pl->planes_kept;
+    pl->wplanes[0] = take(ws_planes ? (size_t)hs->npad * s->D * 3 / 2 : 0);   // bf16 planes: 6 bytes per weight
+    pl->wplanes[1] = take(ws_planes ? (size_t)hd->npad * s->D * 3 / 2 : 0);
     pl->n2 = take(2 * 6 * 1024);  // squared column norms + gain snapshot of up to 6 heads
     pl->total_floats = off;
     const int ks = s->dist_type == CFL_DIST_PCD ? s->K : 1;
@@ -4026,9 +4298,24 @@ static int make_plan(const CflShape *s, int64_t rows, int groups, bool train, Pl
 }
 
 extern "C" size_t cfl_workspace_bytes(const CflShape *s, int64_t rows, int32_t groups) {
-    Plan pl;
-    if (make_plan(s, rows, groups, groups == 2, &pl)) return 0;
-    return pl.total_floats * sizeof(float);
+    // one workspace serves every call shape of (rows, groups): training with and without kept planes, and the scoring
+    // call of the same size (cfl_pair_scores_idx4 runs the non-training plan with groups == 2)
+    size_t need = 0;
+    for (int train = 0; train < 2; ++train)
+        for (int kept = 0; kept < 2; ++kept) {
+            if (train && groups != 2) continue;
+            if (kept && !train) continue;
+            Plan pl;
+            if (make_plan(s, rows, groups, train != 0, kept != 0, &pl)) return 0;
+            if (pl.total_floats > need) need = pl.total_floats;
+        }
+    return need * sizeof(float);
+}
+
+extern "C" size_t cfl_theta_planes_bytes(const CflShape *s) {
+    CflLayout lay;
+    if (cfl_layout(s, &lay)) return 0;
+    return (size_t)lay.total * 6;   // three bf16 per theta float (only the weight matrices' ranges are ever written)
 }
 
 static NormDev make_norm(const CflNorm *n, float *in_mul) {
@@ -4093,8 +4380,8 @@ struct IndexSrc { const float *table; int64_t table_rows; const int32_t *const *
 static std::atomic<int> g_env_generation{0};
 extern "C" int cfl_reload_env(void) { return ++g_env_generation; }
 
-static int cached_plan(const CflShape *s, int64_t rows, int groups, bool train, Plan *out) {
-    struct Entry { CflShape s; int64_t rows; int groups; bool train; Plan pl; };
+static int cached_plan(const CflShape *s, int64_t rows, int groups, bool train, bool kept, Plan *out) {
+    struct Entry { CflShape s; int64_t rows; int groups; bool train, kept; Plan pl; };
     static thread_local std::vector<Entry> cache;
     static thread_local int seen_generation = 0;
     if (seen_generation != g_env_generation.load()) {
@@ -4103,14 +4390,14 @@ static int cached_plan(const CflShape *s, int64_t rows, int groups, bool train, 
     }
     if (!s) return set_err(CFL_E_SHAPE, "shape is NULL");
     for (const Entry &e : cache)
-        if (e.rows == rows && e.groups == groups && e.train == train && memcmp(&e.s, s, sizeof(CflShape)) == 0) {
+        if (e.rows == rows && e.groups == groups && e.train == train && e.kept == kept && memcmp(&e.s, s, sizeof(CflShape)) == 0) {
             *out = e.pl;
             return CFL_OK;
         }
-    int rc = make_plan(s, rows, groups, train, out);
+    int rc = make_plan(s, rows, groups, train, kept, out);
     if (rc) return rc;
     if (cache.size() >= 64) cache.erase(cache.begin());
-    cache.push_back({*s, rows, groups, train, *out});
+    cache.push_back({*s, rows, groups, train, kept, *out});
     return CFL_OK;
 }
 
@@ -4118,10 +4405,13 @@ static int run_pairs(const CflShape *s, const CflNorm *norm, const CflLossCfg *l
                      const float *const *x, int groups, int64_t rows, const float *theta,
                      float *grad, float *scalars, float *scores, float *dists, void *workspace,
                      size_t workspace_bytes, hipStream_t st, const AdamFuse *adam = nullptr,
-                     const IndexSrc *isrc = nullptr) {
+                     const IndexSrc *isrc = nullptr, CflThetaPlanes *kept = nullptr) {
     const bool train = grad != nullptr;
     Plan pl;
-    int rc = cached_plan(s, rows, groups, train, &pl);
+    if (kept && (!kept->buf || ((uintptr_t)kept->buf & 15))) return set_err(CFL_E_SHAPE, "theta planes buffer NULL or misaligned");
+    // planes are kept by the fused Adam tail only: a call that does not update theta in its last launch leaves them alone
+    const bool keeping = kept && train && adam && debug_env("CFL_DEBUG_NOFUSE") <= 0;
+    int rc = cached_plan(s, rows, groups, train, keeping, &pl);
     if (rc) return rc;
     if (!theta || !workspace) return set_err(CFL_E_SHAPE, "NULL theta/workspace");
     if (workspace_bytes < pl.total_floats * sizeof(float))
@@ -4203,30 +4493,41 @@ static int run_pairs(const CflShape *s, const CflNorm *norm, const CflLossCfg *l
         if (cn_slice && nj >= CFL_MAX_JOBS) return set_err(CFL_E_UNSUPPORTED, "too many column chunks");
         if (cn_slice) pa.job[nj].nt = 0;      // marks the colnorm slice
         const int nz = nj + (cn_slice ? 1 : 0);
+        // W planes of the bf16x3 forms: kept beside theta by the caller (current: nothing to do; stale: split into the kept
+        // buffer), or split per call into the workspace.  job_planes[j] = planes of job j's first column tile
+        const unsigned short *job_planes[CFL_MAX_JOBS] = {};
+        if (pl.proj_x3 || pl.proj_bx3) {
+            const int Q = s->D / 32;
+            WPlanesArgs wa;
+            memset(&wa, 0, sizeof(wa));
+            wa.G = G;
+            long long items = 0;
+            int jn = 0;
+            const bool shared_head = side[0].head->w == side[1].head->w;   // siamese: one head, one set of planes
+            for (int sd = 0; sd < 2; ++sd) {
+                const CflHead *h = side[sd].head;
+                unsigned short *planes = keeping ? (unsigned short *)kept->buf + 3 * h->w
+                                                 : (unsigned short *)(ws + pl.wplanes[shared_head ? 0 : sd]);
+                if (!(shared_head && sd == 1)) {
+                    wa.wf[sd] = theta + h->w; wa.planes[sd] = planes; wa.ntiles[sd] = h->npad / 16;
+                    items += (long long)(h->npad / 16) * Q * 64;
+                }
+                for (int c0 = 0; c0 < h->npad / 16; c0 += 4, ++jn) job_planes[jn] = planes + (size_t)c0 * Q * 3 * 512;
+            }
+            if (!(keeping && kept->valid)) {
+                ProfScope psw(st, CFL_K_COLNORM);   // (profile slot reused: the per-call split of W into bf16 planes)
+                hipLaunchKernelGGL(cfl_wplanes_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, wa);
+            }
+        }
         if (pl.fold) {
             // launched below, together with the row math (cfl_proj_mid_kernel)
         } else if (pl.proj_x3) {
             Px3Args xa;
             memset(&xa, 0, sizeof(xa));
             const int Q = s->D / 32;
-            int jn = 0;
-            {
-                ProfScope psw(st, CFL_K_COLNORM);   // (profile slot reused: the per-call split of W into bf16 planes)
-                WPlanesArgs wa;
-                memset(&wa, 0, sizeof(wa));
-                wa.G = G;
-                long long items = 0;
-                for (int sd = 0; sd < 2; ++sd) {
-                    const CflHead *h = side[sd].head;
-                    unsigned short *planes = (unsigned short *)(ws + pl.wplanes[sd]);
-                    wa.wf[sd] = theta + h->w; wa.planes[sd] = planes; wa.ntiles[sd] = h->npad / 16;
-                    items += (long long)(h->npad / 16) * Q * 64;
-                    for (int c0 = 0; c0 < h->npad / 16; c0 += 4, ++jn) {
-                        xa.job[jn] = pa.job[jn];
-                        xa.job[jn].wf = (const float *)(planes + (size_t)c0 * Q * 3 * 512);
-                    }
-                }
-                hipLaunchKernelGGL(cfl_wplanes_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, wa);
+            for (int jn = 0; jn < nj; ++jn) {
+                xa.job[jn] = pa.job[jn];
+                xa.job[jn].wf = (const float *)job_planes[jn];
             }
             int k = 0;
             for (int nt = 4; nt >= 1; --nt)
@@ -4236,17 +4537,15 @@ static int run_pairs(const CflShape *s, const CflNorm *norm, const CflLossCfg *l
             xa.B = (int)rows; xa.R = pl.R; xa.D = s->D; xa.S = pl.S; xa.njobs = nj;
             xa.tiles = pl.ring_tiles; xa.nunits = pl.ring_units; xa.nwg = pl.ring_nwg; xa.Kq = Q / pl.S;
             xa.norm = nd;
+            // weight-norm: the column norms ride in this launch as its first workgroups (as they ride in cfl_proj_kernel as
+            // a z-slice): no launch of their own
+            xa.cn = cna;
+            xa.ncn = cn_slice ? (cna.ncols < 64 ? cna.ncols : 64) : 0;
             ProfScope ps(st, CFL_K_PROJ);
             // training with both sides' rows within reach of the 256 MB Infinity Cache: keep x for the weight gradient
             const bool keep = train && 2.0 * pl.R * s->D * 4.0 <= (debug_env("CFL_DEBUG_X3_KEEP_MB") > 0 ? debug_env("CFL_DEBUG_X3_KEEP_MB") * 1e6 : 300e6) && debug_env("CFL_DEBUG_PROJ_X3_KEEP") >= 0;
-            if (keep) hipLaunchKernelGGL(cfl_proj_x3_keep_kernel, dim3(pl.ring_nwg), dim3(256), PX3_LDS_BYTES, st, xa);
-            else hipLaunchKernelGGL(cfl_proj_x3_kernel, dim3(pl.ring_nwg), dim3(256), PX3_LDS_BYTES, st, xa);
-            if (cn_slice) {
-                ProjArgs pc = pa;
-                pc.job[0].nt = 0;
-                pc.xcd = 0; pc.mix = 0;
-                hipLaunchKernelGGL(cfl_proj_kernel, dim3(64, 1, 1), dim3(256), 4 * 8 * 64 * sizeof(f32x4), st, pc);
-            }
+            if (keep) hipLaunchKernelGGL(cfl_proj_x3_keep_kernel, dim3(pl.ring_nwg + xa.ncn), dim3(256), PX3_LDS_BYTES, st, xa);
+            else hipLaunchKernelGGL(cfl_proj_x3_kernel, dim3(pl.ring_nwg + xa.ncn), dim3(256), PX3_LDS_BYTES, st, xa);
         } else if (pl.proj_ring) {
             RingArgs ra;
             memset(&ra, 0, sizeof(ra));
@@ -4284,11 +4583,22 @@ static int run_pairs(const CflShape *s, const CflNorm *norm, const CflLossCfg *l
             grid = dim3(pa.mixtiles * nz, 1, 1);
         }
         ProfScope ps(st, CFL_K_PROJ);
+        // The colnorm slice goes FIRST in dispatch order (z = 0): its blocks are short, and as the last z-slice they only
+        // started once projection workgroups had retired -- the launch ended a colnorm round trip later than it had to
+        ProjArgs pz = pa;
+        if (pl.proj_bx3)
+            for (int jn = 0; jn < nj; ++jn) pz.job[jn].wf = (const float *)job_planes[jn];
+        if (cn_slice) {
+            for (int jn = nj; jn > 0; --jn) pz.job[jn] = pz.job[jn - 1];
+            memset(&pz.job[0], 0, sizeof(pz.job[0]));   // nt == 0 marks the colnorm slice
+        }
         // 32 KiB: cross-wave sum (the 4 (8) KiB/wave transpose tiles alias it)
-        if (pl.proj_stream)
-            hipLaunchKernelGGL(cfl_proj_stream_kernel, grid, dim3(256), 4 * 8 * 64 * sizeof(f32x4), st, pa);
+        if (pl.proj_bx3)
+            hipLaunchKernelGGL(cfl_proj_bx3_kernel, grid, dim3(256), 4 * 8 * 64 * sizeof(f32x4), st, pz);
+        else if (pl.proj_stream)
+            hipLaunchKernelGGL(cfl_proj_stream_kernel, grid, dim3(256), 4 * 8 * 64 * sizeof(f32x4), st, pz);
         else
-            hipLaunchKernelGGL(cfl_proj_kernel, grid, dim3(256), 4 * 8 * 64 * sizeof(f32x4), st, pa);
+            hipLaunchKernelGGL(cfl_proj_kernel, grid, dim3(256), 4 * 8 * 64 * sizeof(f32x4), st, pz);
         }
     }
 
@@ -4423,6 +4733,8 @@ static int run_pairs(const CflShape *s, const CflNorm *norm, const CflLossCfg *l
         fo.gen = g;
         fo.flags = (unsigned *)(ws + pl.fold_flags);
         fo.sc1_loads = debug_env("CFL_DEBUG_FOLD") == 2;
+        fo.spin_limit = debug_env("CFL_DEBUG_SPIN_LIMIT") != 0 ? debug_env("CFL_DEBUG_SPIN_LIMIT") : CFL_HANDOFF_SPIN_LIMIT;
+        fo.err = scalars ? scalars + CFL_S_ERROR : nullptr;
         ProfScope ps(st, CFL_K_PROJ);
         hipLaunchKernelGGL(cfl_proj_mid_kernel, dim3(fo.ntile_wgs + nreg_blocks), dim3(256), 4 * 8 * 64 * sizeof(f32x4), st,
                            pa, ma, fo);
@@ -4522,6 +4834,9 @@ static int run_pairs(const CflShape *s, const CflNorm *norm, const CflLossCfg *l
                 f.lr_t = adam->lr_t; f.b1 = adam->b1; f.b2 = adam->b2; f.eps = adam->eps;
             }
             f.in_mul = in_mul; f.reg_const = loss->reg_const;
+            f.spin_limit = debug_env("CFL_DEBUG_SPIN_LIMIT") != 0 ? debug_env("CFL_DEBUG_SPIN_LIMIT") : CFL_HANDOFF_SPIN_LIMIT;
+            // kept planes: written by the tile finishers only when the next step's projection will read them
+            f.planes = (keeping && (pl.proj_x3 || pl.proj_bx3)) ? (unsigned short *)kept->buf : nullptr;
             int jn = 0;
             for (int sd = 0; sd < 2; ++sd) {
                 const CflHead *h = side[sd].head;
@@ -4650,6 +4965,7 @@ static int run_pairs(const CflShape *s, const CflNorm *norm, const CflLossCfg *l
             hipLaunchKernelGGL(cfl_grad_kernel, grid, dim3(256), 4 * 4 * 4 * 64 * sizeof(f32x4), st, ga);
     }
 
+    if (kept && adam) kept->valid = (keeping && pl.fused && (pl.proj_x3 || pl.proj_bx3)) ? 1 : 0;   // theta has changed; were the planes written?
     if (pl.fused) {
         HIP_TRY(hipGetLastError());
         return CFL_OK;
@@ -4703,17 +5019,26 @@ extern "C" int cfl_pair_step_fwd_bwd(const CflShape *shape, const CflNorm *norm,
                      workspace_bytes, (hipStream_t)stream);
 }
 
-extern "C" int cfl_pair_train_step(const CflShape *shape, const CflNorm *norm,
-                                   const CflLossCfg *loss, const float *const x4[4], int64_t B,
-                                   float *theta, float *m, float *v, float *grad, float *scalars,
-                                   float lr_t, float beta1, float beta2, float eps,
-                                   void *workspace, size_t workspace_bytes, cfl_stream_t stream) {
+extern "C" int cfl_pair_train_step_planes(const CflShape *shape, const CflNorm *norm,
+                                          const CflLossCfg *loss, const float *const x4[4], int64_t B,
+                                          float *theta, float *m, float *v, float *grad, float *scalars,
+                                          float lr_t, float beta1, float beta2, float eps, CflThetaPlanes *planes,
+                                          void *workspace, size_t workspace_bytes, cfl_stream_t stream) {
     if (!loss || !x4 || !grad || !scalars || !m || !v) return set_err(CFL_E_SHAPE, "NULL pointer");
     if (loss->caffe_margin != 0.f && loss->lambda_m != 0.f)
         return set_err(CFL_E_SHAPE, "caffe_margin and lambda_m are exclusive (cfl/utils.py:72-73)");
     AdamFuse af = {theta, m, v, lr_t, beta1, beta2, eps};
     return run_pairs(shape, norm, loss, x4, 2, B, theta, grad, scalars, nullptr, nullptr, workspace,
-                     workspace_bytes, (hipStream_t)stream, &af);
+                     workspace_bytes, (hipStream_t)stream, &af, nullptr, planes);
+}
+
+extern "C" int cfl_pair_train_step(const CflShape *shape, const CflNorm *norm,
+                                   const CflLossCfg *loss, const float *const x4[4], int64_t B,
+                                   float *theta, float *m, float *v, float *grad, float *scalars,
+                                   float lr_t, float beta1, float beta2, float eps,
+                                   void *workspace, size_t workspace_bytes, cfl_stream_t stream) {
+    return cfl_pair_train_step_planes(shape, norm, loss, x4, B, theta, m, v, grad, scalars, lr_t, beta1, beta2, eps,
+                                      nullptr, workspace, workspace_bytes, stream);
 }
 
 static int check_train_args(const CflLossCfg *loss, const void *grad, const void *scalars) {
@@ -4755,18 +5080,28 @@ extern "C" int cfl_pair_step_fwd_bwd_idx(const CflShape *shape, const CflNorm *n
                      workspace_bytes, (hipStream_t)stream, nullptr, &is);
 }
 
-extern "C" int cfl_pair_train_step_idx(const CflShape *shape, const CflNorm *norm, const CflLossCfg *loss,
-                                       const float *table, int64_t table_rows, const int32_t *const idx4[4],
-                                       int64_t idx_stride, int64_t B, float *theta, float *m, float *v,
-                                       float *grad, float *scalars, float lr_t, float beta1, float beta2,
-                                       float eps, void *workspace, size_t workspace_bytes, cfl_stream_t stream) {
+extern "C" int cfl_pair_train_step_idx_planes(const CflShape *shape, const CflNorm *norm, const CflLossCfg *loss,
+                                              const float *table, int64_t table_rows, const int32_t *const idx4[4],
+                                              int64_t idx_stride, int64_t B, float *theta, float *m, float *v,
+                                              float *grad, float *scalars, float lr_t, float beta1, float beta2,
+                                              float eps, CflThetaPlanes *planes, void *workspace, size_t workspace_bytes,
+                                              cfl_stream_t stream) {
     int rc = check_train_args(loss, grad, scalars);
     if (rc) return rc;
     if (!m || !v) return set_err(CFL_E_SHAPE, "NULL Adam slots");
     AdamFuse af = {theta, m, v, lr_t, beta1, beta2, eps};
     IndexSrc is = {table, table_rows, idx4, idx_stride};
     return run_pairs(shape, norm, loss, nullptr, 2, B, theta, grad, scalars, nullptr, nullptr, workspace,
-                     workspace_bytes, (hipStream_t)stream, &af, &is);
+                     workspace_bytes, (hipStream_t)stream, &af, &is, planes);
+}
+
+extern "C" int cfl_pair_train_step_idx(const CflShape *shape, const CflNorm *norm, const CflLossCfg *loss,
+                                       const float *table, int64_t table_rows, const int32_t *const idx4[4],
+                                       int64_t idx_stride, int64_t B, float *theta, float *m, float *v,
+                                       float *grad, float *scalars, float lr_t, float beta1, float beta2,
+                                       float eps, void *workspace, size_t workspace_bytes, cfl_stream_t stream) {
+    return cfl_pair_train_step_idx_planes(shape, norm, loss, table, table_rows, idx4, idx_stride, B, theta, m, v, grad,
+                                          scalars, lr_t, beta1, beta2, eps, nullptr, workspace, workspace_bytes, stream);
 }
 
 // A train of consecutive training steps on windows of the (shuffled) pair lists: step i trains rows
@@ -4776,14 +5111,14 @@ extern "C" int cfl_pair_train_step_idx(const CflShape *shape, const CflNorm *nor
 // float32 power accumulators (beta1_power / beta2_power) are advanced here; `scalars` / `grad` hold
 // the values of the LAST step.  switched[i] != 0 swaps source and target of step i (data_switch,
 // cfl/input_data.py:575-577); NULL = never.
-extern "C" int cfl_pair_train_steps_idx(const CflShape *shape, const CflNorm *norm, const CflLossCfg *loss,
-                                        const float *table, int64_t table_rows, const int32_t *pos_pairs, int64_t n_pos,
-                                        const int32_t *neg_pairs, int64_t n_neg, int64_t pos_head, int64_t neg_head,
-                                        int64_t batch_rows, int64_t shard_lo, int64_t rows,
-                                        const uint8_t *switched, int64_t nsteps, float *theta, float *m, float *v,
-                                        float *grad, float *scalars, float lr, float beta1, float beta2, float eps,
-                                        float *beta1_power, float *beta2_power, void *workspace,
-                                        size_t workspace_bytes, cfl_stream_t stream) {
+extern "C" int cfl_pair_train_steps_idx_planes(const CflShape *shape, const CflNorm *norm, const CflLossCfg *loss,
+                                               const float *table, int64_t table_rows, const int32_t *pos_pairs, int64_t n_pos,
+                                               const int32_t *neg_pairs, int64_t n_neg, int64_t pos_head, int64_t neg_head,
+                                               int64_t batch_rows, int64_t shard_lo, int64_t rows,
+                                               const uint8_t *switched, int64_t nsteps, float *theta, float *m, float *v,
+                                               float *grad, float *scalars, float lr, float beta1, float beta2, float eps,
+                                               float *beta1_power, float *beta2_power, CflThetaPlanes *planes,
+                                               void *workspace, size_t workspace_bytes, cfl_stream_t stream) {
     int rc = check_train_args(loss, grad, scalars);
     if (rc) return rc;
     if (!m || !v || !pos_pairs || !neg_pairs || !beta1_power || !beta2_power)
@@ -4805,7 +5140,7 @@ extern "C" int cfl_pair_train_steps_idx(const CflShape *shape, const CflNorm *no
         AdamFuse af = {theta, m, v, lr_t, beta1, beta2, eps};
         IndexSrc is = {table, table_rows, idx4, 2};
         rc = run_pairs(shape, norm, loss, nullptr, 2, rows, theta, grad, scalars, nullptr, nullptr, workspace,
-                       workspace_bytes, (hipStream_t)stream, &af, &is);
+                       workspace_bytes, (hipStream_t)stream, &af, &is, planes);
         if (rc) return rc;
         b1p *= beta1;
         b2p *= beta2;
@@ -4813,6 +5148,20 @@ extern "C" int cfl_pair_train_steps_idx(const CflShape *shape, const CflNorm *no
     *beta1_power = b1p;
     *beta2_power = b2p;
     return CFL_OK;
+}
+
+extern "C" int cfl_pair_train_steps_idx(const CflShape *shape, const CflNorm *norm, const CflLossCfg *loss,
+                                        const float *table, int64_t table_rows, const int32_t *pos_pairs, int64_t n_pos,
+                                        const int32_t *neg_pairs, int64_t n_neg, int64_t pos_head, int64_t neg_head,
+                                        int64_t batch_rows, int64_t shard_lo, int64_t rows,
+                                        const uint8_t *switched, int64_t nsteps, float *theta, float *m, float *v,
+                                        float *grad, float *scalars, float lr, float beta1, float beta2, float eps,
+                                        float *beta1_power, float *beta2_power, void *workspace,
+                                        size_t workspace_bytes, cfl_stream_t stream) {
+    return cfl_pair_train_steps_idx_planes(shape, norm, loss, table, table_rows, pos_pairs, n_pos, neg_pairs, n_neg, pos_head,
+                                           neg_head, batch_rows, shard_lo, rows, switched, nsteps, theta, m, v, grad, scalars,
+                                           lr, beta1, beta2, eps, beta1_power, beta2_power, nullptr, workspace,
+                                           workspace_bytes, stream);
 }
 
 // ---- input gradient of the two heads (needed when the pair rows are not leaves: ConvPCD) --
@@ -4841,7 +5190,7 @@ extern "C" int cfl_pair_input_grad(const CflShape *s, const CflNorm *norm, int64
                                    const void *workspace, size_t workspace_bytes, float *dx_src,
                                    float *dx_dst, cfl_stream_t stream) {
     Plan pl;
-    int rc = make_plan(s, B, 2, true, &pl);
+    int rc = make_plan(s, B, 2, true, false, &pl);
     if (rc) return rc;
     if (!theta || !workspace || !dx_src || !dx_dst) return set_err(CFL_E_SHAPE, "NULL pointer");
     if (workspace_bytes < pl.total_floats * sizeof(float)) return set_err(CFL_E_WORKSPACE, "workspace too small");

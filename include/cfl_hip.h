@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define CFL_ABI_VERSION 3
+#define CFL_ABI_VERSION 4
 
 /* error codes */
 #define CFL_OK 0
@@ -49,6 +49,7 @@ extern "C" {
 #define CFL_E_HIP (-2)         /* a HIP runtime call failed                     */
 #define CFL_E_UNSUPPORTED (-3) /* valid in the reference, not built yet         */
 #define CFL_E_WORKSPACE (-4)   /* workspace too small                           */
+#define CFL_E_HANDOFF (-5)     /* a kernel gave up waiting for a partner inside a launch (cfl_scalars_status) */
 
 /* dist_type: cfl/models/base.py:107-146 (== cfl/models/dist.py:70-89) */
 #define CFL_DIST_PCD 0
@@ -146,8 +147,20 @@ enum {
     CFL_S_THRESHOLD,   /* max(raw_threshold, 1e-6)                              */
     CFL_S_DIST_ADAPT_POS, /* mean(sqrt(d_pos + 1e-7)), cfl.py:897-898           */
     CFL_S_DIST_ADAPT_NEG, /* mean(sqrt(d_neg + 1e-7)), cfl.py:899-900           */
+    CFL_S_ERROR = 15,  /* STICKY error word, no reference counterpart: 0 = healthy.  A training kernel that gives up
+                        * waiting for a partner workgroup inside its launch (bounded spins of the fused weight-gradient
+                        * tail) stores 1.0 here and poisons the entries it was finishing with NaN.  The library only ever
+                        * SETS this word: the caller zeroes scalars[CFL_S_ERROR] once, before its first training call, and
+                        * checks it whenever it reads the scalars back (cfl_scalars_status).  Under data parallelism the
+                        * word travels in the [gradient | scalars] sum, so every rank sees a failure of any rank.       */
     CFL_S_COUNT = 16
 };
+
+/* HOST-ONLY: status of a scalars array that was read back from the device: CFL_OK, or CFL_E_HANDOFF (message via
+ * cfl_last_error()) when scalars[CFL_S_ERROR] != 0 -- the parameters are poisoned with NaN from that step on and must
+ * not be checkpointed.  This is how "negative code on error" reaches the caller for failures that happen inside an
+ * asynchronous launch (SURVEY 8(b) Errors): at the caller's next read-back, without a synchronisation of the library's own. */
+int cfl_scalars_status(const float *host_scalars);
 
 int cfl_version(void);
 const char *cfl_last_error(void);
@@ -184,6 +197,24 @@ int cfl_pair_step_fwd_bwd(const CflShape *shape, const CflNorm *norm,
                           float *scalars, void *workspace,
                           size_t workspace_bytes, cfl_stream_t stream);
 
+/* bf16 planes of theta (ABI 4; no reference counterpart).  At large row counts the projection runs on the bf16 matrix
+ * cores at fp32 accuracy from three bf16 "planes" of every weight (w = h + m + l exactly); splitting the weights is a
+ * launch of its own per call unless the caller keeps a plane buffer beside theta, as it keeps the Adam slots: the fused
+ * training step then WRITES the planes of the updated weights from the same registers that write theta (6 bytes per
+ * weight, no extra launch), and the next step's projection starts from current planes.
+ *   buf    dev, cfl_theta_planes_bytes(shape) bytes, 16-byte aligned, caller-owned, one per theta
+ *   valid  HOST flag: nonzero = buf holds the planes of the CURRENT theta.  The library sets it after a fused training
+ *          step that wrote the planes and clears it after a training step that did not; the CALLER clears it whenever
+ *          theta is changed by anything else (checkpoint load, cfl_adam_tf, a data-parallel update).
+ * Layout: plane p of W[d = 32 tq + 8 (lane >> 4) + j][col = 16 nt + (lane & 15)] of the head whose Wf array starts at
+ * theta offset w is the ushort at 3 w + ((nt * (D/32) + tq) * 3 + p) * 512 + lane * 8 + j -- the B operand of
+ * v_mfma_f32_16x16x32_bf16, one 1 KiB block per (column tile, 32-d quarter, plane).                                   */
+typedef struct {
+    void *buf;
+    int32_t valid;
+} CflThetaPlanes;
+size_t cfl_theta_planes_bytes(const CflShape *shape);
+
 /* Single-GPU fast path: cfl_pair_step_fwd_bwd with the TF-Adam apply fused into
  * the last kernel (theta, m, v updated in place; grad still written).  Equals
  * cfl_pair_step_fwd_bwd followed by cfl_adam_tf(..., grad_scale = 1); replaces the
@@ -193,6 +224,12 @@ int cfl_pair_train_step(const CflShape *shape, const CflNorm *norm,
                         float *theta, float *m, float *v, float *grad, float *scalars,
                         float lr_t, float beta1, float beta2, float eps,
                         void *workspace, size_t workspace_bytes, cfl_stream_t stream);
+/* ... with a kept plane buffer (planes may be NULL: identical to the call above)                                    */
+int cfl_pair_train_step_planes(const CflShape *shape, const CflNorm *norm,
+                               const CflLossCfg *loss, const float *const x4[4], int64_t B,
+                               float *theta, float *m, float *v, float *grad, float *scalars,
+                               float lr_t, float beta1, float beta2, float eps, CflThetaPlanes *planes,
+                               void *workspace, size_t workspace_bytes, cfl_stream_t stream);
 
 /* The same three entry points fed from a RESIDENT FEATURE TABLE instead of dense batches: row r of input stream k
  * is table[idx[k][r * idx_stride], :].  Replaces the batch assembly of cfl/input_data.py:542-589 + 212-228 (index
@@ -221,6 +258,11 @@ int cfl_pair_train_step_idx(const CflShape *shape, const CflNorm *norm, const Cf
                             int64_t idx_stride, int64_t B, float *theta, float *m, float *v, float *grad,
                             float *scalars, float lr_t, float beta1, float beta2, float eps, void *workspace,
                             size_t workspace_bytes, cfl_stream_t stream);
+int cfl_pair_train_step_idx_planes(const CflShape *shape, const CflNorm *norm, const CflLossCfg *loss,
+                                   const float *table, int64_t table_rows, const int32_t *const idx4[4],
+                                   int64_t idx_stride, int64_t B, float *theta, float *m, float *v, float *grad,
+                                   float *scalars, float lr_t, float beta1, float beta2, float eps,
+                                   CflThetaPlanes *planes, void *workspace, size_t workspace_bytes, cfl_stream_t stream);
 
 /* A train of `nsteps` consecutive training steps over windows of the device copies of the (shuffled) pair lists
  * pos_pairs / neg_pairs (int32 [n, 2] = (source, target) positions): step i trains rows
@@ -238,6 +280,14 @@ int cfl_pair_train_steps_idx(const CflShape *shape, const CflNorm *norm, const C
                              float *m, float *v, float *grad, float *scalars, float lr, float beta1, float beta2,
                              float eps, float *beta1_power, float *beta2_power, void *workspace,
                              size_t workspace_bytes, cfl_stream_t stream);
+int cfl_pair_train_steps_idx_planes(const CflShape *shape, const CflNorm *norm, const CflLossCfg *loss,
+                                    const float *table, int64_t table_rows, const int32_t *pos_pairs, int64_t n_pos,
+                                    const int32_t *neg_pairs, int64_t n_neg, int64_t pos_head, int64_t neg_head,
+                                    int64_t batch_rows, int64_t shard_lo, int64_t rows, const uint8_t *switched,
+                                    int64_t nsteps, float *theta, float *m, float *v, float *grad, float *scalars,
+                                    float lr, float beta1, float beta2, float eps, float *beta1_power,
+                                    float *beta2_power, CflThetaPlanes *planes, void *workspace, size_t workspace_bytes,
+                                    cfl_stream_t stream);
 
 /* HOST-ONLY (no GPU, all pointers are host pointers): the per-epoch reshuffle `pairs = pairs[rng.permutation(n)]` of
  * cfl/input_data.py:543-551 in numpy's legacy RandomState (MT19937) stream, bit for bit.  key[624] / *pos are the
@@ -421,23 +471,47 @@ int cfl_profile_enable(int on);
 int cfl_profile_read(double *ms_sum, int64_t *launches);
 
 /* One-shot gradient exchange of the data-parallel step (new functionality; the reference is single-device).  An opt-in
- * alternative to all-reducing [gradient | scalars] with RCCL: every rank pushes its buffer into its slot of every
- * peer's exchange buffer (peer device memory mapped by the caller, e.g. through hipIpc), and the Adam launch sums the
- * `world` slots in rank order (deterministic, identical on all ranks).  Host side: cfl/dp_exchange.py.
- *   cfl_dp_push   src dev [n]; peer_slots / peer_flags: HOST arrays [world] of device pointers -- this rank's slot
- *                 (n floats, 16-byte aligned) and flag word inside peer r's buffers; ticket: dev uint32, zero before the
- *                 first call (the kernel leaves it zero); generation: a number unique to this step (e.g. the step count)
- *   cfl_dp_wait   flags dev [world]: the LOCAL flag words the peers write; returns (on the stream) when all equal
- *                 `generation`; *lost (dev int32, zero-initialised by the caller) is set when the bounded wait gives up
- *   cfl_dp_adam   slots dev [world][n] (local); sum_out dev [n] receives the sum over ranks (what an all-reduce leaves);
- *                 TF-Adam with gradient sum / world on the first n_adam floats (theta, m, v).  *lost != 0 poisons the
- *                 update with NaN (a lost hand-off must be loud).                                                  */
-int cfl_dp_push(const float *src, int64_t n, float *const *peer_slots, uint32_t *const *peer_flags, int32_t world,
-                uint32_t generation, uint32_t *ticket, cfl_stream_t stream);
-int cfl_dp_wait(const uint32_t *flags, int32_t world, uint32_t generation, int32_t *lost, cfl_stream_t stream);
-int cfl_dp_adam(float *theta, float *m, float *v, const float *slots, int32_t world, int64_t n, int64_t n_adam,
-                float *sum_out, float lr_t, float beta1, float beta2, float eps, const int32_t *lost,
-                cfl_stream_t stream);
+ * alternative to all-reducing [gradient | scalars] with RCCL, shaped for point-to-point xGMI links: reduce-scatter by
+ * direct stores into the owners' slot arrays, TF-Adam on the owned 1/world of theta / m / v (the Adam slots are SHARDED:
+ * rank r keeps slice r of m and v current), all-gather of the updated theta slices by direct stores into the peers' stage
+ * buffers.  Deterministic (rank-ordered sums, one writer per parameter), bit-identical parameters on every rank.  Host
+ * side: cfl/dp_exchange.py; protocol and memory model: csrc/cfl_dp.hip.
+ *
+ * Exchange memory.  Slots, stage buffers and flag words are polled by running kernels while peers store into them, which
+ * HIP supports for FINE-GRAINED device allocations only; the caller allocates them here and shares them with the other
+ * ranks' processes through the 64-byte hipIpc handle.  The caller owns every allocation / mapping (free / close them).
+ *   cfl_dp_alloc       *ptr = zero-filled device memory on the current device (fine_grained != 0:
+ *                      hipExtMallocWithFlags(hipDeviceMallocFinegrained), else hipMalloc)
+ *   cfl_dp_ipc_export  handle64: 64 bytes to send to the peers;  cfl_dp_ipc_open maps a peer's allocation here
+ *
+ * Let n = floats of the exchanged buffer (a multiple of 4), slice = floats per rank (a multiple of 4, slice * world >= n;
+ * rank r owns [r * slice, min((r + 1) * slice, n)) ), generation = a number unique to the step (never 0).
+ *   cfl_dp_rs_push    src dev [n] (this rank's [gradient | scalars]); peer_rows[s] = row `rank` (slice floats) of rank
+ *                     s's slot array of the current parity, peer_flags[s] = this rank's A flag word there (HOST arrays
+ *                     [world] of device pointers; entry `rank` = the local ones); ticket: dev uint32, zero before the
+ *                     first call (the kernels leave it zero)
+ *   cfl_dp_rs_adam    gslots dev [world][slice] (local, current parity), flags dev [world] (local A flags); waits for
+ *                     them (at most timeout_s seconds of wall-clock time; <= 0: 30 s), sums the rows in rank order,
+ *                     writes its slice of the sum to sum_out [n], applies TF-Adam with sum / world to its slice of the
+ *                     first n_adam floats (theta, m, v), stores the updated theta slice (past n_adam: the sums) into
+ *                     peer_stage[r] [n] of every peer r != rank and raises its B flag peer_flags[r] there.  *lost (dev
+ *                     int32, zeroed by the caller) is set when the wait gives up; the update is then NaN (loud)
+ *   cfl_dp_rs_gather  stage dev [n] (local, current parity), flags dev [world] (local B flags): waits for every peer's
+ *                     flag, copies the peers' slices into theta (floats < n_adam) and sum_out (the rest)               */
+int cfl_dp_alloc(void **ptr, size_t bytes, int32_t fine_grained);
+int cfl_dp_free(void *ptr);
+int cfl_dp_ipc_export(void *ptr, void *handle64);
+int cfl_dp_ipc_open(const void *handle64, void **ptr);
+int cfl_dp_ipc_close(void *ptr);
+int cfl_dp_rs_push(const float *src, int64_t n, int64_t slice, float *const *peer_rows, uint32_t *const *peer_flags,
+                   int32_t world, uint32_t generation, uint32_t *ticket, cfl_stream_t stream);
+int cfl_dp_rs_adam(float *theta, float *m, float *v, const float *gslots, const uint32_t *flags, int32_t world,
+                   int32_t rank, int64_t n, int64_t n_adam, int64_t slice, float *sum_out, float *const *peer_stage,
+                   uint32_t *const *peer_flags, float lr_t, float beta1, float beta2, float eps, uint32_t generation,
+                   int32_t *lost, double timeout_s, uint32_t *ticket, cfl_stream_t stream);
+int cfl_dp_rs_gather(float *theta, float *sum_out, const float *stage, const uint32_t *flags, int32_t world, int32_t rank,
+                     int64_t n, int64_t n_adam, int64_t slice, uint32_t generation, int32_t *lost, double timeout_s,
+                     cfl_stream_t stream);
 
 #ifdef __cplusplus
 }

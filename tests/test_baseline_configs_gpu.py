@@ -2,7 +2,7 @@
 
 * config 1 (headline): 4096-d features, PCD K=3, L=20, batch 512 -- 100 training steps beside the oracle in float64
   AND in float32 on identical batches: three deviation series per step (HIP vs fp64, HIP vs fp32 CPU, fp32 CPU vs fp64)
-  recorded and capped at the values in CAPS (observed series: profiles/r03_trajectory_*.json), then 2 x 100 000
+  recorded and capped at the values in CAPS (observed series: profiles/r04_trajectory_*.json), then 2 x 100 000
   held-out pairs scored by the HIP scoring path and by the oracle on its own trained weights: AUC within 1e-4
   (SURVEY 8(d) "AUC check").
 * config 4 shape (2048-d, K=5, L=20, batch 1024, weight-norm heads) and config 3 (1024-d siamese L=256, hinge margin
@@ -37,7 +37,7 @@ def _planted(gen, B, D, teacher, back, s, noise):
 def _trajectory(name, style, D, K, L, B, steps, lkw, n_eval, nv, caps, min_auc=None, dist_type='pcd'):
     """HIP beside the NumPy oracle in float64 AND in float32 (the precision of the reference's TensorFlow CPU path) on
     identical batches.  Three series are measured per step, recorded (CFL_RECORD_DIR=<dir> writes
-    <dir>/trajectory_<name>.json; the committed copies are profiles/r03_trajectory_*.json) and asserted:
+    <dir>/trajectory_<name>.json; the committed copies are profiles/r04_trajectory_*.json) and asserted:
         hip_vs_fp64    |loss_HIP - loss_fp64| / max(1, |loss_fp64|)
         hip_vs_fp32    |loss_HIP - loss_fp32cpu| / max(1, ...)        (north_star's reference IS an fp32 CPU path)
         fp32_vs_fp64   |loss_fp32cpu - loss_fp64| / max(1, ...)       (what fp32 arithmetic itself costs here)
@@ -119,8 +119,8 @@ def _trajectory(name, style, D, K, L, B, steps, lkw, n_eval, nv, caps, min_auc=N
 
 # (cap on |HIP - fp64|, cap on |HIP - fp32 CPU|) per workload: 2x the worst value observed on MI355X when the bars
 # were set -- the observed series are committed as profiles/r03_trajectory_<name>.json
-CAPS = {
-    'headline': (4e-6, 2e-6),                 # observed 1.9e-6 / 6.3e-7 (fp32 CPU vs fp64: 1.3e-6)
+CAPS = {   # round 4 (projection on the bf16 matrix cores from kept planes): observed series in profiles/r04_trajectory_*.json
+    'headline': (2.5e-6, 5e-6),               # observed 1.2e-6 / 2.5e-6 (fp32 CPU vs fp64: 1.3e-6: HIP is the closer one to fp64)
     'config4': (1e-6, 1e-6),                  # observed 8.9e-8 / 3.6e-7
     'config3_pcd': (1e-6, 1e-6),              # observed 1.1e-7 / 1.5e-7
     'config3_siamese_hinge': (1e-6, 1e-6),    # observed 7.2e-8 / 2.1e-7

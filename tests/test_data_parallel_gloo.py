@@ -68,3 +68,21 @@ def test_shard_rows_cover_the_batch_exactly():
     import pytest
     with pytest.raises(ValueError):
         engine.shard_rows(100, 0, 8)
+
+
+def test_one_shot_exchange_slices_tile_the_buffer():
+    """cfl/dp_exchange.py: the reduce-scatter / sharded-Adam / all-gather exchange gives every rank a slice of whole
+    float4s; the owned parameter ranges tile [0, n_adam) exactly once for every world size, including buffers that do
+    not divide evenly and worlds larger than the number of float4s."""
+    from cfl.dp_exchange import owned_range, slice_floats
+    for n_adam in (64, 4096, 393280, 393216 + 64):
+        n = n_adam + 64                                   # [gradient | 16 scalars + pad]
+        for world in (1, 2, 3, 4, 7, 8, 16):
+            sl = slice_floats(n, world)
+            assert sl % 4 == 0 and sl * world >= n and sl * (world - 1) < n + 4 * world
+            covered = np.zeros(n_adam, np.int32)
+            for r in range(world):
+                lo, hi = owned_range(n_adam, sl, r)
+                assert 0 <= lo <= hi <= n_adam and lo % 4 == 0
+                covered[lo:hi] += 1
+            assert (covered == 1).all()

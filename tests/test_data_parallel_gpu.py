@@ -189,8 +189,10 @@ def _oneshot_worker(rank, world, port, out):
             a.step(batch)
             b.step(batch)
             sa, sb = a.read_scalars(), b.read_scalars()
-            worst = max(worst, float((a.theta - b.theta).abs().max()), float((a.grad - b.grad).abs().max() /
-                                                                               a.grad.abs().max()))
+            # (the one-shot exchange leaves every rank ITS slice of the gradient sum: reduce-scatter, not all-reduce)
+            glo, ghi = b._oneshot.owned()
+            worst = max(worst, float((a.theta - b.theta).abs().max()),
+                        float((a.grad[glo:ghi] - b.grad[glo:ghi]).abs().max() / a.grad.abs().max()))
             for k in ('total', 'accuracy', 'mean_d_pos'):
                 worst = max(worst, abs(sa[k] - sb[k]) / max(1.0, abs(sa[k])))
         # windows of device pair lists through step_windows (K steps per engine call, the exchange inside the loop)
@@ -201,6 +203,9 @@ def _oneshot_worker(rank, world, port, out):
         win = Namespace(table=table, pos_pairs=pos, neg_pairs=neg, pos_head=0, neg_head=B, batch_rows=B, shard_lo=lo,
                         rows=hi - lo, nsteps=3, switched=[False, True, False])
         c = mk('oneshot')
+        b.sync_state()                                        # collective: the Adam slots are sharded over the ranks
+        if rank == 0:                                         # the complete slots equal the all-reduce path's (replicated) ones
+            worst = max(worst, float((a.m - b.m).abs().max() / a.m.abs().max()), float((a.v - b.v).abs().max() / a.v.abs().max()))
         c.load_state_dict(b.state_dict())
         b.step_windows(win)
         for i in range(3):
@@ -222,11 +227,12 @@ def _oneshot_worker(rank, world, port, out):
 
 
 def test_oneshot_exchange_equals_allreduce_and_windows_equal_single_steps():
-    """CFL_DP_EXCHANGE=oneshot (csrc/cfl_dp.hip, cfl/dp_exchange.py): every rank pushes [gradient | scalars] into its
-    slot of every peer's buffer (mapped through hipIpc), the Adam launch sums the slots in rank order.  Two ranks on
-    the one GPU: parameters / gradient sums / scalars equal the all-reduce path to 1e-6, both ranks hold identical
-    parameters, no hand-off was lost; and PairEngine.step_windows under data parallelism (K steps per call, the exchange
-    inside the loop) equals the same steps taken one at a time, bit for bit."""
+    """CFL_DP_EXCHANGE=oneshot (csrc/cfl_dp.hip, cfl/dp_exchange.py): reduce-scatter by direct stores into the owners'
+    slot arrays (fine-grained device memory mapped through hipIpc), TF-Adam on the owned slice of theta / m / v (sharded
+    Adam slots), all-gather of the updated theta slices by direct stores.  Two ranks on the one GPU: parameters / owned
+    gradient sums / scalars / gathered Adam slots equal the all-reduce path to 1e-6, both ranks hold identical parameters,
+    no hand-off was lost; and PairEngine.step_windows under data parallelism (K steps per call, the exchange inside the
+    loop) equals the same steps taken one at a time, bit for bit."""
     ctx = mp.get_context('spawn')
     out = ctx.SimpleQueue()
     port = 33500 + os.getpid() % 2000

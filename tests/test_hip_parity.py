@@ -487,6 +487,9 @@ def test_fused_gradient_tail_equals_finalize_kernel(B, D, K, L, reg, P, monkeypa
     res = {}
     if P:
         monkeypatch.setenv('CFL_DEBUG_P', str(P))
+    # the same forward arithmetic in both modes: the bf16x3 projection the fused step uses with its kept planes, with a
+    # per-call split of the weights in the four-launch form (which updates theta in the finalize launch and keeps none)
+    monkeypatch.setenv('CFL_DEBUG_PROJ_BX3', '1')
     for mode in ('fused', 'finalize'):
         monkeypatch.setenv('CFL_DEBUG_NOFUSE', '0' if mode == 'fused' else '1')
         H.reload_env()
@@ -509,9 +512,10 @@ def test_fused_gradient_tail_equals_finalize_kernel(B, D, K, L, reg, P, monkeypa
         res[mode] = snaps
     monkeypatch.undo()
     H.reload_env()
-    for a, b in zip(res['fused'], res['finalize']):
-        for x, y in zip(a, b):
-            assert torch.equal(x, y)
+    for si, (a, b) in enumerate(zip(res['fused'], res['finalize'])):
+        for ti, (x, y) in enumerate(zip(a, b)):
+            assert torch.equal(x, y), (si, ti, (x != y).nonzero().flatten()[:8].tolist(), x.flatten()[(x != y).flatten()][:4].tolist(),
+                                       y.flatten()[(x != y).flatten()][:4].tolist())
     assert np.isfinite(res['fused'][-1][1].cpu().numpy()).all()
 
 
@@ -682,6 +686,9 @@ def test_fused_gradient_tail_siamese_equals_finalize_kernel(B, D, L, wn, lkw, P,
     res = {}
     if P:
         monkeypatch.setenv('CFL_DEBUG_P', str(P))
+    # the same forward arithmetic in both modes: the bf16x3 projection the fused step uses with its kept planes, with a
+    # per-call split of the weights in the four-launch form (which updates theta in the finalize launch and keeps none)
+    monkeypatch.setenv('CFL_DEBUG_PROJ_BX3', '1')
     for mode in ('fused', 'finalize'):
         monkeypatch.setenv('CFL_DEBUG_NOFUSE', '0' if mode == 'fused' else '1')
         H.reload_env()
@@ -703,9 +710,10 @@ def test_fused_gradient_tail_siamese_equals_finalize_kernel(B, D, L, wn, lkw, P,
         res[mode] = snaps
     monkeypatch.undo()
     H.reload_env()
-    for a, b in zip(res['fused'], res['finalize']):
-        for x, y in zip(a, b):
-            assert torch.equal(x, y)
+    for si, (a, b) in enumerate(zip(res['fused'], res['finalize'])):
+        for ti, (x, y) in enumerate(zip(a, b)):
+            assert torch.equal(x, y), (si, ti, (x != y).nonzero().flatten()[:8].tolist(), x.flatten()[(x != y).flatten()][:4].tolist(),
+                                       y.flatten()[(x != y).flatten()][:4].tolist())
     assert np.isfinite(res['fused'][-1][1].cpu().numpy()).all()
 
 
@@ -737,32 +745,44 @@ def test_scores_of_a_labeled_batch_in_one_call():
 
 
 def test_training_forward_form_follows_the_batch_size(monkeypatch):
-    """From 3072 rows per side (B = 1536) a training step projects through the bf16x3 forward (its W-plane launch shows
-    up as the extra `colnorm` entry of the library's profile), below that through the exact-fp32 forward; the switch
-    moves the step's scalars by fp32 rounding only (CFL_DEBUG_PROJ_X3=-1 forces the fp32 forward at the large batch)."""
+    """The fused training step keeps the bf16 planes of theta (CflThetaPlanes) and projects on the bf16 matrix cores:
+    chunk-at-a-time form (cfl_proj_bx3_kernel) at the headline batch, LDS-shared form (cfl_proj_x3_kernel) from 3072 rows
+    per side.  Only the FIRST step of an engine splits the weights in a launch of its own (the library's profile lists it
+    under `colnorm`); from the second step on the Adam tail has written the planes.  Against the exact-fp32 forward
+    (CFL_DEBUG_PROJ_BX3=-1 / CFL_DEBUG_PROJ_X3=-1) the step's scalars move by fp32 rounding only."""
     from cfl.engine import PairEngine
     rng = np.random.RandomState(3)
     cfg = O.EncoderCfg(D=4096, L=20, K=3)
     params = O.init_encoder_params(cfg, rng, np.float32)
     out = {}
-    for B, env in ((512, None), (1536, None), (1536, '-1')):
-        if env is not None:
-            monkeypatch.setenv('CFL_DEBUG_PROJ_X3', env)
+    for B, exact in ((512, False), (512, True), (1536, False), (1536, True)):
+        if exact:
+            monkeypatch.setenv('CFL_DEBUG_PROJ_X3', '-1')
+            monkeypatch.setenv('CFL_DEBUG_PROJ_BX3', '-1')
+        else:
+            monkeypatch.delenv('CFL_DEBUG_PROJ_X3', raising=False)
+            monkeypatch.delenv('CFL_DEBUG_PROJ_BX3', raising=False)
         H.reload_env()
         batch = [torch.from_numpy(np.abs(np.random.RandomState(B).randn(B, 4096)).astype(np.float32) * 13).cuda() for _ in range(4)]
         eng = PairEngine(4096, 20, 3, norm=H.make_norm(1 / 58.388599), loss=H.make_loss(), params=params, batch_size=B)
-        H.profile_enable(True)
-        eng.step(batch)
-        torch.cuda.synchronize()
-        H.profile_enable(False)
-        out[(B, env)] = (set(H.profile_read()), eng.scalars.clone(), eng.grad.clone())
+        kinds = []
+        for _ in range(2):
+            H.profile_enable(True)
+            eng.step(batch)
+            torch.cuda.synchronize()
+            H.profile_enable(False)
+            kinds.append(set(H.profile_read()))
+        out[(B, exact)] = (kinds, eng.scalars.clone(), eng.grad.clone(), eng.planes.valid)
     monkeypatch.undo()
     H.reload_env()
-    assert 'colnorm' not in out[(512, None)][0]
-    assert 'colnorm' in out[(1536, None)][0] and 'colnorm' not in out[(1536, '-1')][0]
-    a, b = out[(1536, None)], out[(1536, '-1')]
-    assert float((a[1] - b[1]).abs().max()) <= 2e-6 * max(1.0, float(b[1].abs().max()))
-    assert float((a[2] - b[2]).abs().max()) <= 2e-5 * float(b[2].abs().max())
+    for B in (512, 1536):
+        kinds, _, _, valid = out[(B, False)]
+        assert 'colnorm' in kinds[0] and 'colnorm' not in kinds[1] and valid       # split once, then kept by the Adam tail
+        kinds, _, _, valid = out[(B, True)]
+        assert 'colnorm' not in kinds[0] and 'colnorm' not in kinds[1] and not valid
+        a, b = out[(B, False)], out[(B, True)]
+        assert float((a[1] - b[1]).abs().max()) <= 2e-6 * max(1.0, float(b[1].abs().max()))
+        assert float((a[2] - b[2]).abs().max()) <= 2e-5 * float(b[2].abs().max())
 
 
 @pytest.mark.parametrize('dist,B,D,K,L,wn,P', [
@@ -789,6 +809,9 @@ def test_half_tile_gradient_with_hand_off_equals_finalize_kernel(dist, B, D, K, 
     if P:
         monkeypatch.setenv('CFL_DEBUG_P', str(P))
         monkeypatch.setenv('CFL_DEBUG_GRAD_HALF', '1')
+    # the same forward arithmetic in both modes: the bf16x3 projection the fused step uses with its kept planes, with a
+    # per-call split of the weights in the four-launch form (which updates theta in the finalize launch and keeps none)
+    monkeypatch.setenv('CFL_DEBUG_PROJ_BX3', '1')
     for mode in ('fused', 'finalize'):
         monkeypatch.setenv('CFL_DEBUG_NOFUSE', '0' if mode == 'fused' else '1')
         H.reload_env()
@@ -804,9 +827,10 @@ def test_half_tile_gradient_with_hand_off_equals_finalize_kernel(dist, B, D, K, 
         res[mode] = snaps
     monkeypatch.undo()
     H.reload_env()
-    for a, b in zip(res['fused'], res['finalize']):
-        for x, y in zip(a, b):
-            assert torch.equal(x, y)
+    for si, (a, b) in enumerate(zip(res['fused'], res['finalize'])):
+        for ti, (x, y) in enumerate(zip(a, b)):
+            assert torch.equal(x, y), (si, ti, (x != y).nonzero().flatten()[:8].tolist(), x.flatten()[(x != y).flatten()][:4].tolist(),
+                                       y.flatten()[(x != y).flatten()][:4].tolist())
     assert np.isfinite(res['fused'][-1][1].cpu().numpy()).all()
     # and against the 64-d / row-split kernel (different summation order across the split: close, not identical)
     monkeypatch.setenv('CFL_DEBUG_GRAD_HALF', '-1')
@@ -840,6 +864,9 @@ def test_fused_gradient_tail_monomer_and_directed_equal_finalize_kernel(dist, di
     params_dst = _mk(cfg, rng) if directed else None
     pool = [[torch.from_numpy(np.abs(rng.randn(B, D)).astype(np.float32) * 3).cuda() for _ in range(4)] for _ in range(3)]
     res = {}
+    # the same forward arithmetic in both modes: the bf16x3 projection the fused step uses with its kept planes, with a
+    # per-call split of the weights in the four-launch form (which updates theta in the finalize launch and keeps none)
+    monkeypatch.setenv('CFL_DEBUG_PROJ_BX3', '1')
     for mode in ('fused', 'finalize'):
         monkeypatch.setenv('CFL_DEBUG_NOFUSE', '0' if mode == 'fused' else '1')
         H.reload_env()
@@ -862,9 +889,10 @@ def test_fused_gradient_tail_monomer_and_directed_equal_finalize_kernel(dist, di
         res[mode] = snaps
     monkeypatch.undo()
     H.reload_env()
-    for a, b in zip(res['fused'], res['finalize']):
-        for x, y in zip(a, b):
-            assert torch.equal(x, y)
+    for si, (a, b) in enumerate(zip(res['fused'], res['finalize'])):
+        for ti, (x, y) in enumerate(zip(a, b)):
+            assert torch.equal(x, y), (si, ti, (x != y).nonzero().flatten()[:8].tolist(), x.flatten()[(x != y).flatten()][:4].tolist(),
+                                       y.flatten()[(x != y).flatten()][:4].tolist())
     assert np.isfinite(res['fused'][-1][1].cpu().numpy()).all()
 
 
