@@ -322,10 +322,12 @@ struct ColnormArgs {
 // One WAVE per column (round 4; a workgroup of 256 threads used to walk its columns one after the other, each with a
 // dependent round trip to memory and two barriers: with 256 columns on 64 blocks -- config 3 -- the colnorm slice was
 // the critical path of the projection launch).  All loads of a column are independent and issued together; the lane
-// sums are combined with wave_sum in a fixed order; no LDS, no barrier.  `first` / `stride` in columns.
-__device__ __forceinline__ void colnorm_columns(const ColnormArgs &a, int first, int stride) {
+// sums are combined with wave_sum in a fixed order; no LDS, no barrier.  Columns are dealt to the nb blocks of the slice
+// first and to the four waves of a block second (column c -> block c mod nb, wave (c / nb) mod 4), so that few columns on
+// many blocks (headline shape with weight norm: 96 on 256) still run one per block, all at once.
+__device__ __forceinline__ void colnorm_columns(const ColnormArgs &a, int block, int nb) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int col = first + wave; col < a.ncols; col += stride) {
+    for (int col = block + wave * nb; col < a.ncols; col += 4 * nb) {
         int c = col, h = 0;
         while (h < a.nheads && c >= a.npad[h]) { c -= a.npad[h]; ++h; }
         if (h >= a.nheads) return;   // uniform per wave
@@ -334,15 +336,15 @@ __device__ __forceinline__ void colnorm_columns(const ColnormArgs &a, int first,
             // Wf layout: column c = 16nt + c16 lives at ((nt*G + g)*64 + q*16 + c16) float4s
             const int G = a.D >> 4, nt = c >> 4, c16 = c & 15;
             const f32x4 *w = (const f32x4 *)(a.theta + a.w_off[h]) + (size_t)nt * G * 64 + c16;
-            for (int i0 = 0; i0 < G * 4; i0 += 64 * 8) {
-                f32x4 v[8];
+            for (int i0 = 0; i0 < G * 4; i0 += 64 * 16) {   // (D = 4096: all 16 loads of a lane in one round trip)
+                f32x4 v[16];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
+                for (int u = 0; u < 16; ++u) {
                     const int i = i0 + u * 64 + lane;
                     v[u] = i < G * 4 ? w[(size_t)(i >> 2) * 64 + (i & 3) * 16] : (f32x4){0.f, 0.f, 0.f, 0.f};
                 }
 #pragma unroll
-                for (int u = 0; u < 8; ++u) acc += (v[u][0] * v[u][0] + v[u][1] * v[u][1]) + (v[u][2] * v[u][2] + v[u][3] * v[u][3]);
+                for (int u = 0; u < 16; ++u) acc += (v[u][0] * v[u][0] + v[u][1] * v[u][1]) + (v[u][2] * v[u][2] + v[u][3] * v[u][3]);
             }
         } else {  // mono head V[L][kpad]: column c strided by kpad
             const float *w = a.theta + a.w_off[h];
@@ -567,28 +569,28 @@ __device__ __forceinline__ void proj_body(const ProjJob &jb, const ProjArgs &a, 
 // Selected by the plan when the caller keeps planes (the fused single-GPU training step); every other call keeps the
 // exact-fp32 kernel.
 // ---------------------------------------------------------------------------
-template <int NT>
+template <int NT, int MT = 2>   // MT = 16-row blocks per wave: 2 = the 32-row tiles of every plan; 1 = the 16-row experiment (CFL_DEBUG_PROJ_ROWS16)
 __device__ __forceinline__ void proj_body_bx3(const ProjJob &jb, const ProjArgs &a, f32x4 *lds) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i16 = lane & 15, kq = lane >> 4;
     const int rr8 = lane >> 3, ch8 = lane & 7;
-    const int row0 = (a.xcd ? blockIdx.y : blockIdx.x) * 32;
+    const int row0 = (a.xcd ? blockIdx.y : blockIdx.x) * (16 * MT);
     const int s = a.xcd ? blockIdx.x : blockIdx.y;
     const int G = a.D >> 4, Q = a.D >> 5;
     const int NC = (G + 7) >> 3;
     const int nw = a.S * 4, wg = s * 4 + wave;
     const int cbeg = wg * NC / nw, cend = (wg + 1) * NC / nw;
 
-    f32x4 acc[2][NT];
+    f32x4 acc[MT][NT];
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const float *xrow[4];
+    const float *xrow[2 * MT];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) xrow[i] = row_ptr(a.rows[jb.side], row0 + 8 * i + rr8, a.B, a.R, a.D) + 4 * ch8;
+    for (int i = 0; i < 2 * MT; ++i) xrow[i] = row_ptr(a.rows[jb.side], row0 + 8 * i + rr8, a.B, a.R, a.D) + 4 * ch8;
     const unsigned short *pll = (const unsigned short *)jb.wf + lane * 8;   // planes of this job's first column tile
     f32x4 *tile = lds + wave * 256;
 
@@ -596,7 +598,7 @@ __device__ __forceinline__ void proj_body_bx3(const ProjJob &jb, const ProjArgs 
         const int t0 = c * 4;                      // first 32-d quarter of the chunk
         const bool full = Q - t0 >= 4;             // otherwise 2 quarters (D % 64 == 0)
         bf16x8 bq[2][NT][3];
-        f32x4 araw[4][4];
+        f32x4 araw[4][2 * MT];
         auto loadB = [&](int qq, bf16x8 (*dst)[3]) {
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
@@ -606,7 +608,7 @@ __device__ __forceinline__ void proj_body_bx3(const ProjJob &jb, const ProjArgs 
         };
         auto loadA = [&](int qq) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) araw[qq][i] = *(const f32x4 *)(xrow[i] + (t0 + qq) * 32);
+            for (int i = 0; i < 2 * MT; ++i) araw[qq][i] = *(const f32x4 *)(xrow[i] + (t0 + qq) * 32);
         };
         loadB(0, bq[0]);
         __builtin_amdgcn_sched_barrier(0);
@@ -626,13 +628,13 @@ __device__ __forceinline__ void proj_body_bx3(const ProjJob &jb, const ProjArgs 
         for (int qq = 0; qq < 4; ++qq) {
             if (qq >= 2 && !full) break;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < 2 * MT; ++i) {
                 const int row = 8 * i + rr8;
                 tile[row * 8 + (ch8 ^ (row & 7))] = norm_apply(araw[qq][i], a.norm, (t0 + qq) * 32 + 4 * ch8);
             }
-            bf16x8 af[2][3];
+            bf16x8 af[MT][3];
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
+            for (int mt = 0; mt < MT; ++mt) {
                 const int row = mt * 16 + i16;
                 const f32x4 c0 = tile[row * 8 + ((2 * kq) ^ (row & 7))], c1 = tile[row * 8 + ((2 * kq + 1) ^ (row & 7))];
                 float v[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
@@ -644,7 +646,7 @@ __device__ __forceinline__ void proj_body_bx3(const ProjJob &jb, const ProjArgs 
             }
             // six partial products, small terms first; consecutive MFMAs hit different accumulators
 #define CFL_BX3(LA, LB)                                                                                       \
-    _Pragma("unroll") for (int mt = 0; mt < 2; ++mt) _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = \
+    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = \
         __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mt][LA], bq[qq & 1][nt][LB], acc[mt][nt], 0, 0, 0);
             CFL_BX3(1, 1) CFL_BX3(2, 0) CFL_BX3(0, 2) CFL_BX3(1, 0) CFL_BX3(0, 1) CFL_BX3(0, 0)
 #undef CFL_BX3
@@ -655,15 +657,15 @@ __device__ __forceinline__ void proj_body_bx3(const ProjJob &jb, const ProjArgs 
     // cross-wave sum and slab store: identical to proj_body
     __syncthreads();
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) lds[(wave * 2 * NT + mt * NT + nt) * 64 + lane] = acc[mt][nt];
+        for (int nt = 0; nt < NT; ++nt) lds[(wave * MT * NT + mt * NT + nt) * 64 + lane] = acc[mt][nt];
     __syncthreads();
-    for (int t = wave; t < 2 * NT; t += 4) {
+    for (int t = wave; t < MT * NT; t += 4) {
         const int mt = t / NT, nt = t % NT;
-        f32x4 sum = lds[(0 * 2 * NT + t) * 64 + lane];
+        f32x4 sum = lds[(0 * MT * NT + t) * 64 + lane];
 #pragma unroll
-        for (int w = 1; w < 4; ++w) sum += lds[(w * 2 * NT + t) * 64 + lane];
+        for (int w = 1; w < 4; ++w) sum += lds[(w * MT * NT + t) * 64 + lane];
         float *dst = jb.ypart + (size_t)s * jb.sstride + (size_t)(row0 + mt * 16 + 4 * kq) * jb.npad + nt * 16 + i16;
 #pragma unroll
         for (int e = 0; e < 4; ++e) dst[(size_t)e * jb.npad] = sum[e];
@@ -843,7 +845,7 @@ extern "C" __global__ __launch_bounds__(256) void cfl_proj_stream_kernel(ProjArg
         case 0: {
             const int nb = a.mix ? a.mixtiles : gridDim.x * gridDim.y;
             const int b0 = a.mix ? rowtile : blockIdx.y * gridDim.x + blockIdx.x;
-            colnorm_columns(a.cn, 4 * b0, 4 * nb);
+            colnorm_columns(a.cn, b0, nb);
             break;
         }
         case 1: proj_stream_body<1>(jb, a, lds, rowtile); break;
@@ -1321,7 +1323,7 @@ __device__ __forceinline__ void px3_unit(const Px3Args &a, const ProjJob &jb, in
         CFL_KERNARG_IN_PLACE(Px3Args, a, a_);                                                           \
         extern __shared__ __attribute__((aligned(16))) char smem[];                                     \
         if ((int)blockIdx.x < a.ncn) {                                                                  \
-            colnorm_columns(a.cn, 4 * (int)blockIdx.x, 4 * a.ncn);                                    \
+            colnorm_columns(a.cn, (int)blockIdx.x, a.ncn);                                            \
             return;                                                                                     \
         }                                                                                               \
         const int w = blockIdx.x - a.ncn;                                                               \
@@ -1353,7 +1355,7 @@ extern "C" __global__ __launch_bounds__(256) void cfl_proj_kernel(ProjArgs a) {
     switch (jb.nt) {
         case 0: {   // the colnorm slice (marked by nt == 0: no kernel-argument load of its own in front of the dispatch)
             const int nb = gridDim.x * gridDim.y;
-            colnorm_columns(a.cn, 4 * (int)(blockIdx.y * gridDim.x + blockIdx.x), 4 * nb);
+            colnorm_columns(a.cn, (int)(blockIdx.y * gridDim.x + blockIdx.x), nb);
             break;
         }
         case 1: proj_body<1>(jb, a, lds); break;
@@ -1370,13 +1372,29 @@ extern "C" __global__ __launch_bounds__(256, 2) void cfl_proj_bx3_kernel(ProjArg
     switch (jb.nt) {
         case 0: {   // the colnorm slice (reads the fp32 weights through a.cn)
             const int nb = gridDim.x * gridDim.y;
-            colnorm_columns(a.cn, 4 * (int)(blockIdx.y * gridDim.x + blockIdx.x), 4 * nb);
+            colnorm_columns(a.cn, (int)(blockIdx.y * gridDim.x + blockIdx.x), nb);
             break;
         }
         case 1: proj_body_bx3<1>(jb, a, lds); break;
         case 2: proj_body_bx3<2>(jb, a, lds); break;
         case 3: proj_body_bx3<3>(jb, a, lds); break;
         default: proj_body_bx3<4>(jb, a, lds); break;
+    }
+}
+
+// Round-4 experiment (CFL_DEBUG_PROJ_ROWS16=1 with CFL_DEBUG_S=4): 16-row tiles, twice as many row tiles, half
+// as many d slices -- each wave 16 rows x 2 chunks.  Halves the partial slabs `mid` sums, doubles the W-plane traffic per
+// row.  Measured: profiles/r04_rows16_ab.txt.
+extern "C" __global__ __launch_bounds__(256, 2) void cfl_proj_bx3_rows16_kernel(ProjArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    f32x4 *lds = (f32x4 *)smem;
+    const ProjJob &jb = a.job[blockIdx.z];
+    switch (jb.nt) {
+        case 0: colnorm_columns(a.cn, (int)(blockIdx.y * gridDim.x + blockIdx.x), gridDim.x * gridDim.y); break;
+        case 1: proj_body_bx3<1, 1>(jb, a, lds); break;
+        case 2: proj_body_bx3<2, 1>(jb, a, lds); break;
+        case 3: proj_body_bx3<3, 1>(jb, a, lds); break;
+        default: proj_body_bx3<4, 1>(jb, a, lds); break;
     }
 }
 
@@ -4575,7 +4593,8 @@ static int run_pairs(const CflShape *s, const CflNorm *norm, const CflLossCfg *l
                 hipLaunchKernelGGL(cfl_proj_kernel, dim3(64, 1, 1), dim3(256), 4 * 8 * 64 * sizeof(f32x4), st, pc);
             }
         } else {
-        const int rtiles = (pl.R + 31) / 32;
+        const bool rows16 = pl.proj_bx3 && debug_env("CFL_DEBUG_PROJ_ROWS16") > 0;   // (experiment: 16-row tiles)
+        const int rtiles = rows16 ? (pl.R + 15) / 16 : (pl.R + 31) / 32;
         dim3 grid(rtiles, pl.S, nz);
         if (pa.xcd) grid = dim3(pl.S, rtiles, nz);
         if (pl.proj_stream && pl.proj_mix && pl.S == 1 && nz > 1) {
@@ -4593,7 +4612,9 @@ static int run_pairs(const CflShape *s, const CflNorm *norm, const CflLossCfg *l
             memset(&pz.job[0], 0, sizeof(pz.job[0]));   // nt == 0 marks the colnorm slice
         }
         // 32 KiB: cross-wave sum (the 4 (8) KiB/wave transpose tiles alias it)
-        if (pl.proj_bx3)
+        if (rows16)
+            hipLaunchKernelGGL(cfl_proj_bx3_rows16_kernel, grid, dim3(256), 4 * 8 * 64 * sizeof(f32x4), st, pz);
+        else if (pl.proj_bx3)
             hipLaunchKernelGGL(cfl_proj_bx3_kernel, grid, dim3(256), 4 * 8 * 64 * sizeof(f32x4), st, pz);
         else if (pl.proj_stream)
             hipLaunchKernelGGL(cfl_proj_stream_kernel, grid, dim3(256), 4 * 8 * 64 * sizeof(f32x4), st, pz);
