@@ -10,7 +10,7 @@ from . import hipabi as H
 from .hipabi import CflConv, _check, _dev, _stream
 
 EXPORTS = ('cfl_conv_transpose_workspace_bytes', 'cfl_conv2d_transpose_wn_fwd', 'cfl_conv2d_transpose_wn_bwd',
-           'cfl_ew_act_fwd', 'cfl_ew_act_bwd', 'cfl_ew_add_act', 'cfl_ew_axpy', 'cfl_ew_affine_clip', 'cfl_subpixel2x_fwd',
+           'cfl_ew_act_fwd', 'cfl_ew_act_bwd', 'cfl_ew_act_bwd_add', 'cfl_ew_add_act', 'cfl_ew_axpy', 'cfl_ew_affine_clip', 'cfl_subpixel2x_fwd',
            'cfl_subpixel2x_bwd', 'cfl_concat_cols', 'cfl_gather_prototype', 'cfl_bce_logits',
            'cfl_rowdist_loss', 'cfl_perturb_workspace_bytes', 'cfl_perturb', 'cfl_grad_penalty', 'cfl_copy_cols',
            'cfl_tile_concat_channels', 'cfl_tile_concat_channels_bwd', 'cfl_auc_workspace_bytes', 'cfl_auc', 'cfl_image_transform',
@@ -34,6 +34,7 @@ def lib():
     L.cfl_ew_act_fwd.argtypes = [vp, vp, i64, i32, vp]
     L.cfl_ew_act_bwd.argtypes = [vp, vp, vp, i64, i32, vp]
     L.cfl_ew_add_act.argtypes = [vp, vp, vp, i64, i32, vp]
+    L.cfl_ew_act_bwd_add.argtypes = [vp, vp, vp, i64, i32, vp]
     L.cfl_ew_axpy.argtypes = [f32, vp, vp, i64, vp]
     L.cfl_ew_affine_clip.argtypes = [vp, vp, i64, C.POINTER(H.CflNorm), vp]
     L.cfl_subpixel2x_fwd.argtypes = [vp, vp, i64, i32, i32, i32, i32, vp]
@@ -141,6 +142,12 @@ def act_bwd(y, dy, act, out=None):
     out = torch.empty_like(dy) if out is None else out
     _check(lib().cfl_ew_act_bwd(_dev(y), _dev(dy), _dev(out), dy.numel(), EW[act], _stream()))
     return out
+
+
+def act_bwd_add(y, dy, act, acc):
+    """acc += dy * act'(y)"""
+    _check(lib().cfl_ew_act_bwd_add(_dev(y), _dev(dy), _dev(acc), dy.numel(), EW[act], _stream()))
+    return acc
 
 
 def add_act(a, b, act, out=None):

@@ -14,6 +14,7 @@ double backward of the discriminator, which for this piecewise-linear network is
 bias-free forward pass with the activation slopes frozen (see `gp_grads`).
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -143,23 +144,62 @@ class WNLayer(object):
         G.conv_fwd(d, x, self.p('V'), self.p('g'), self.p('biases') if bias else None, y, ws.get(d, t), t, cache=self.cache())
         return y
 
-    def bwd(self, x, y, dy, ws, need_dx=True, need_dw=True, grad=None, need_db=True):
-        """dx (or None); parameter gradients are written into `grad` (a flat buffer shaped like theta)."""
+    def bwd(self, x, y, dy, ws, need_dx=True, need_dw=True, grad=None, need_db=True, act='layer'):
+        """dx (or None); parameter gradients are written into `grad` (a flat buffer shaped like theta).
+        `act` overrides the activation whose slope at `y` multiplies dy (a residual join's lrelu folded into the
+        backward of the block's second convolution: y = the join's output).
+
+        The weight-gradient product (GEMM, split-K sums, weight-norm finalisation: 3-5 launches) does not feed the
+        backward chain -- only dx does -- so it is enqueued on the workspace's SIDE stream and overlaps the input
+        gradients of this and the following layers (round 4: most launches of the MrCGAN step are far too small to
+        fill 256 CUs on their own).  `Workspace.join()` orders the side stream back before the gradients are read."""
         t = self.kind == 'convt'
+        act = self.act if act == 'layer' else act
         B, Hh, W, _ = x.shape
-        d = self.desc(B, Hh, W, self.act)
+        d = self.desc(B, Hh, W, act)
         dx = torch.empty(B, Hh, W, self.ci, dtype=torch.float32, device=dy.device) if need_dx else None
-        G.conv_bwd(d, x, self.p('V'), self.p('g'), y, dy, ws.get(d, t), dx=dx,
-                   dV=self.p('V', grad) if need_dw else None, dg=self.p('g', grad) if need_dw else None,
-                   db=self.p('biases', grad) if (need_dw and need_db) else None, transposed=t, cache=self.cache())
+        cache = self.cache()
+        dV = self.p('V', grad) if need_dw else None
+        dg = self.p('g', grad) if need_dw else None
+        db = self.p('biases', grad) if (need_dw and need_db) else None
+        side = ws.side_stream if (need_dw and not t and cache is not None and G.ConvCache.enabled
+                                  and (cache.flags.value & 1)) else None      # (bit 0: the cached weight-norm scale is valid)
+        if side is None:
+            G.conv_bwd(d, x, self.p('V'), self.p('g'), y, dy, ws.get(d, t), dx=dx, dV=dV, dg=dg, db=db, transposed=t,
+                       cache=cache)
+            return dx
+        side.wait_stream(torch.cuda.current_stream())          # x, y, dy were produced on the main stream
+        with torch.cuda.stream(side):
+            G.conv_bwd(d, x, self.p('V'), self.p('g'), y, dy, ws.side_ws.get(d, t), dx=None, dV=dV, dg=dg, db=db,
+                       transposed=t, cache=cache)
+        for tt in (x, y, dy):
+            if tt is not None:
+                tt.record_stream(side)                          # the allocator must not recycle them under the side stream
+        ws.side_used = True
+        if need_dx:
+            G.conv_bwd(d, x, self.p('V'), self.p('g'), y, dy, ws.get(d, t), dx=dx, dV=None, dg=None, db=None,
+                       transposed=t, cache=cache)
         return dx
 
 
 class Workspace(object):
-    def __init__(self, device):
+    # CFL_GAN_OVERLAP=0 keeps every launch of a network on one stream (A/B runs, debugging)
+    overlap = os.environ.get('CFL_GAN_OVERLAP', '1') not in ('0', '')
+
+    def __init__(self, device, side=True):
         self.device = device
         self.buf = torch.empty(1024, dtype=torch.float32, device=device)
         self._need = {}
+        # weight-gradient products run on a side stream with a workspace of their own (WNLayer.bwd)
+        self.side_stream = torch.cuda.Stream(device=device) if (side and Workspace.overlap) else None
+        self.side_ws = Workspace(device, side=False) if self.side_stream is not None else None
+        self.side_used = False
+
+    def join(self):
+        """order the side stream's work (weight gradients) before whatever the current stream does next"""
+        if self.side_stream is not None and self.side_used:
+            torch.cuda.current_stream().wait_stream(self.side_stream)
+            self.side_used = False
 
     def get(self, d, transposed):
         key = (d.B, d.H, d.W, d.Ci, d.Co, d.KH, d.KW, d.stride, transposed)
@@ -303,6 +343,7 @@ class Generator(_Net):
                 _, layer, x, y = item
                 need_dx = layer is not self.fc1 or self.fc_t is not None
                 d = layer.bwd(x, y, d.reshape(y.shape), self.ws, need_dx=need_dx, need_dw=True, grad=self.pool.grad)
+        self.ws.join()
 
 
 class Discriminator(_Net):
@@ -400,12 +441,24 @@ class Discriminator(_Net):
         lat = self.lat_head.fwd(f, self.ws).view(N, self.latent_size)
         return disc, lat, (tape, f)
 
-    def backward(self, tapef, lo, hi, d_disc, d_lat, need_dx, need_dw, grad=None, record=None):
+    def chain(self, k):
+        """(stream, workspace) of independent backward chain k = 1, 2 (the post-epoch step runs the d-loss backward, the
+        gradient-penalty passes and the g-loss backward + generator backward side by side: cfl/models/mrcgan.py); None
+        when CFL_GAN_OVERLAP=0"""
+        if not Workspace.overlap:
+            return None
+        if not hasattr(self, '_chains'):
+            self._chains = [(torch.cuda.Stream(device=self.device), Workspace(self.device)) for _ in range(2)]
+        return self._chains[k - 1]
+
+    def backward(self, tapef, lo, hi, d_disc, d_lat, need_dx, need_dw, grad=None, record=None, ws=None):
         """Backward over the rows [lo, hi) of a recorded forward.  d_disc [n,1] / d_lat [n,L] (either
         may be None).  Returns d/d input rows [n, prod(ae_shape)] when need_dx.  `record`, when a
-        list, receives the upstream gradient of every layer (for `gp_grads`)."""
+        list, receives the upstream gradient of every layer (for `gp_grads`).  `ws`: the workspace to use (a chain's own
+        when several backward passes of this network run on different streams)."""
         tape, f = tapef
         n = hi - lo
+        ws = self.ws if ws is None else ws
         grad = self.pool.grad if grad is None else grad
         fr = f[lo:hi]
         df = None
@@ -413,12 +466,12 @@ class Discriminator(_Net):
             dy = d_disc.view(n, 1, 1, 1)
             if record is not None:
                 record.append(dy)
-            df = self.disc_head.bwd(fr, None, dy, self.ws, True, need_dw, grad)
+            df = self.disc_head.bwd(fr, None, dy, ws, True, need_dw, grad)
         elif need_dw:
             for w in ('V', 'g', 'biases'):
                 self.disc_head.p(w, grad).zero_()
         if d_lat is not None:
-            dl = self.lat_head.bwd(fr, None, d_lat.view(n, 1, 1, self.latent_size), self.ws, True, need_dw, grad)
+            dl = self.lat_head.bwd(fr, None, d_lat.view(n, 1, 1, self.latent_size), ws, True, need_dw, grad)
             df = dl if df is None else G.axpy(1.0, dl, df)
         elif need_dw:
             for w in ('V', 'g', 'biases'):
@@ -431,7 +484,7 @@ class Discriminator(_Net):
                 dh, dt = G.tile_concat_channels_bwd(d.contiguous(), C1, True, need_dw and self.fc_t is not None)
                 if dt is not None:
                     self.fc_t.bwd(t_in[lo:hi].view(n, 1, 1, -1), t_out[lo:hi].view(n, 1, 1, -1),
-                                  dt.view(n, 1, 1, -1), self.ws, False, True, grad)
+                                  dt.view(n, 1, 1, -1), ws, False, True, grad)
                 d = dh
                 continue
             if item[0] == 'conv':
@@ -440,21 +493,27 @@ class Discriminator(_Net):
                 if record is not None:
                     record.append(d)
                 last = layer is first_layer and item is tape[0]
-                d = layer.bwd(x[lo:hi], y[lo:hi], d, self.ws, need_dx or not last, need_dw, grad)
+                d = layer.bwd(x[lo:hi], y[lo:hi], d, ws, need_dx or not last, need_dw, grad)
             else:
                 _, a, b, h, r1, r2, out = item
                 d = df.view(out[lo:hi].shape) if d is None else d
-                dpre = G.act_bwd(out[lo:hi], d, 'lrelu')          # d (r2 + h)
                 if record is not None:
+                    dpre = G.act_bwd(out[lo:hi], d, 'lrelu')          # d (r2 + h)
                     record.append(dpre)
-                dr1 = b.bwd(r1[lo:hi], r2[lo:hi], dpre, self.ws, True, need_dw, grad)
-                if record is not None:
+                    dr1 = b.bwd(r1[lo:hi], r2[lo:hi], dpre, ws, True, need_dw, grad)
                     record.append(dr1)
-                dh = a.bwd(h[lo:hi], r1[lo:hi], dr1, self.ws, True, need_dw, grad)
-                d = G.axpy(1.0, dpre, dh)
+                    dh = a.bwd(h[lo:hi], r1[lo:hi], dr1, ws, True, need_dw, grad)
+                    d = G.axpy(1.0, dpre, dh)
+                else:
+                    # the join's lrelu slope is applied inside conv b's backward (its dy loaders multiply by act'(y) anyway:
+                    # y = the join's output) and once more in the fused add at the end: two launches fewer per block
+                    dr1 = b.bwd(r1[lo:hi], out[lo:hi], d, ws, True, need_dw, grad, act='lrelu')
+                    dh = a.bwd(h[lo:hi], r1[lo:hi], dr1, ws, True, need_dw, grad)
+                    d = G.act_bwd_add(out[lo:hi], d, 'lrelu', dh)     # dh += d * lrelu'(out)
+        ws.join()
         return d.view(n, -1) if (need_dx and d is not None) else None
 
-    def gp_grads(self, tapef, lo, hi, lambda_gp, loss_out, grad):
+    def gp_grads(self, tapef, lo, hi, lambda_gp, loss_out, grad, ws=None):
         """Gradient penalty lambda * mean((||dD/dX_hat|| - 1)^2) over the rows [lo, hi) of a recorded
         forward (the X_hat rows) and its gradient w.r.t. the discriminator variables, into `grad`.
 
@@ -466,9 +525,10 @@ class Discriminator(_Net):
         input replaced by v_l and the upstream gradient by the recorded u_{l+1}."""
         tape, f = tapef
         n = hi - lo
+        ws = self.ws if ws is None else ws
         ones = torch.ones(n, 1, dtype=torch.float32, device=self.device)
         rec = []
-        u0 = self.backward(tapef, lo, hi, ones, None, True, False, record=rec)
+        u0 = self.backward(tapef, lo, hi, ones, None, True, False, record=rec, ws=ws)
         v = G.grad_penalty(u0.contiguous(), lambda_gp, loss_out, need_v=True)
         # rec was filled from the head back to the input; walk it in forward order
         it = iter(reversed(rec))
@@ -480,24 +540,25 @@ class Discriminator(_Net):
             if item[0] == 'conv':
                 _, layer, x, y = item
                 dy = next(it)
-                layer.bwd(v, y[lo:hi], dy, self.ws, False, True, grad, need_db=False)
-                lin = layer.fwd(v, self.ws, act=None, bias=False)
+                layer.bwd(v, y[lo:hi], dy, ws, False, True, grad, need_db=False)
+                lin = layer.fwd(v, ws, act=None, bias=False)
                 v = G.act_bwd(y[lo:hi], lin, layer.act) if layer.act else lin
             else:
                 _, a, b, h, r1, r2, out = item
                 dr1 = next(it)     # upstream of conv a (recorded after dpre, so it comes first in reverse)
                 dpre = next(it)    # upstream of conv b
-                a.bwd(v, r1[lo:hi], dr1, self.ws, False, True, grad, need_db=False)
-                lin = a.fwd(v, self.ws, act=None, bias=False)
+                a.bwd(v, r1[lo:hi], dr1, ws, False, True, grad, need_db=False)
+                lin = a.fwd(v, ws, act=None, bias=False)
                 v1 = G.act_bwd(r1[lo:hi], lin, 'lrelu')
-                b.bwd(v1, None, dpre, self.ws, False, True, grad, need_db=False)
-                v2 = b.fwd(v1, self.ws, act=None, bias=False)
+                b.bwd(v1, None, dpre, ws, False, True, grad, need_db=False)
+                v2 = b.fwd(v1, ws, act=None, bias=False)
                 G.axpy(1.0, v, v2)                                   # v_r2 + v_h
                 v = G.act_bwd(out[lo:hi], v2, 'lrelu')
         dy = next(it)
-        self.disc_head.bwd(v.reshape(n, 1, 1, self.feat), None, dy, self.ws, False, True, grad, need_db=False)
+        self.disc_head.bwd(v.reshape(n, 1, 1, self.feat), None, dy, ws, False, True, grad, need_db=False)
         for layer_bias in [nme for nme in self.pool.order if nme.endswith('/biases')]:
             self.pool.view(layer_bias, grad).zero_()
+        ws.join()
         for w in ('V', 'g'):
             self.lat_head.p(w, grad).zero_()
             if self.fc_t is not None:

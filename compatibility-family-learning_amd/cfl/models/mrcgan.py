@@ -95,10 +95,25 @@ class GanPhase(object):
         G.bce_logits(d_logit[2 * B:3 * B], 0.0, 0.5, sc[S_D_PRJ:S_D_PRJ + 1], sc[S_FRAC_PRJ:S_FRAC_PRJ + 1],
                      dd[2 * B:3 * B])
         G.rowdist_loss(d_lat[0:B], enc_act, 0, 0.0, 1.0, sc[S_D_LAT:S_D_LAT + 1], dl[0:B])
-        disc.backward(d_tape, 0, 3 * B, dd, dl, need_dx=False, need_dw=True, grad=disc.pool.grad)
+        # Three backward chains hang off the one discriminator forward and do not feed each other: the d-loss backward
+        # (discriminator variables), the gradient-penalty passes (X_hat rows, into grad2) and the g-loss backward through D
+        # and then G.  Most of their ~500 launches are far too small to fill 256 CUs, so the first two run on streams of
+        # their own (own workspaces) beside the third; they are joined before the gradients are added and applied.
+        main = torch.cuda.current_stream()
+        c1, c2 = disc.chain(1), (disc.chain(2) if self.lambda_gp else None)
+        if c1 is not None:
+            c1[0].wait_stream(main)
+            with torch.cuda.stream(c1[0]):
+                disc.backward(d_tape, 0, 3 * B, dd, dl, need_dx=False, need_dw=True, grad=disc.pool.grad, ws=c1[1])
+        else:
+            disc.backward(d_tape, 0, 3 * B, dd, dl, need_dx=False, need_dw=True, grad=disc.pool.grad)
         if self.lambda_gp:
-            disc.gp_grads(d_tape, 4 * B, 5 * B, self.lambda_gp, sc[S_D_GP:S_D_GP + 1], disc.pool.grad2)
-            G.axpy(1.0, disc.pool.grad2, disc.pool.grad)
+            if c2 is not None:
+                c2[0].wait_stream(main)
+                with torch.cuda.stream(c2[0]):
+                    disc.gp_grads(d_tape, 4 * B, 5 * B, self.lambda_gp, sc[S_D_GP:S_D_GP + 1], disc.pool.grad2, ws=c2[1])
+            else:
+                disc.gp_grads(d_tape, 4 * B, 5 * B, self.lambda_gp, sc[S_D_GP:S_D_GP + 1], disc.pool.grad2)
 
         # ---- generator loss: gradient w.r.t. the images [g | g_prj | g_neg], then through G ------
         gd = torch.zeros(3 * B, 1, dtype=torch.float32, device=self.device)
@@ -114,6 +129,11 @@ class GanPhase(object):
                            gl[2 * B:3 * B])
         d_img = disc.backward(d_tape, B, 4 * B, gd, gl, need_dx=True, need_dw=False)
         gen.backward(g_tape, d_img.contiguous())
+        for c in (c1, c2):
+            if c is not None:
+                main.wait_stream(c[0])
+        if self.lambda_gp:
+            G.axpy(1.0, disc.pool.grad2, disc.pool.grad)
         if self.keep_tapes:
             self.last_tapes = (g_tape, d_tape)
 

@@ -682,12 +682,17 @@ extern "C" int cfl_conv_uses_direct_kernel(const CflConv *c, int product) {
 // ---- per-layer cache of what depends on the weights only ----------------------------------------------------
 // [scale Co | n2 Co | column-chunk scratch | pad] [halo planes, forward] [halo planes, input gradient].  The caller owns
 // the buffer and the validity bits (CFL_CONV_CACHE_*): it clears them whenever V or the gains change.
+// Cache layout: [header: scale, n2, scratch | forward planes | input-gradient planes].  The plane regions are sized and
+// placed from the channel counts alone (halo_planes_bytes), never from the batch / image size of the call at hand: a
+// layer is called with several batch sizes between two updates of its weights (round 4: the offsets used to follow
+// HaloPlan::ok of the call, which a different batch size could flip while the validity bits stayed set).
 static size_t conv_cache_planes_off(const ConvGeom &g) { return conv_ws_header_floats(g) * sizeof(float); }
+static size_t conv_cache_fwd_bytes(const ConvGeom &g) { return halo_shape(g) ? halo_planes_bytes(g.Ci, g.Co) : 0; }
+static size_t conv_cache_dx_bytes(const ConvGeom &g) { return halo_shape(g) ? halo_planes_bytes(g.Co, g.Ci) : 0; }
 extern "C" size_t cfl_conv_cache_bytes(const CflConv *c) {
     ConvGeom g;
     if (make_geom(c, &g)) return 0;
-    const HaloPlan hf = halo_fwd_plan(g), hd = halo_dx_plan(g);
-    return conv_cache_planes_off(g) + (hf.ok ? (hf.wp_bytes + 15) / 16 * 16 : 0) + (hd.ok ? (hd.wp_bytes + 15) / 16 * 16 : 0);
+    return conv_cache_planes_off(g) + conv_cache_fwd_bytes(g) + conv_cache_dx_bytes(g);
 }
 // scale / n2 / scratch pointers of a call: in the cache (computed once per weight version) or in the workspace header
 static void conv_scale_of(const ConvGeom &g, const float *V, const float *gain, void *workspace, void *cache,
@@ -733,6 +738,17 @@ extern "C" int cfl_conv2d_wn_fwd_cached(const CflConv *c, const float *x, const 
     else
         gemm_gather(g.B * g.OH * g.OW, g.Co, rows, gg_klen(rows, 1), Im2colX{x, g}, FilterKN{V, g.Co},
                     StoreFwd{y, scale, bias, g.Co, g.act}, st);
+    // The input-gradient planes of the layer are built here too, on the forward's stream, the first time the layer is
+    // touched after an update: the backward passes of a step may run on several streams at once (MrCGAN: three chains
+    // share every discriminator layer), and a plane set must not be built on one of them while another reads it.
+    if (cache && !(*cache_flags & CFL_CONV_CACHE_PLANES_DX)) {
+        const HaloPlan hd = halo_dx_plan(g);
+        if (hd.ok) {
+            halo_prep_planes(hd, g.Co, g.Ci, V, scale, g.Ci, g.Co, 1,
+                             (unsigned short *)((char *)cache + conv_cache_planes_off(g) + conv_cache_fwd_bytes(g)), st);
+            *cache_flags |= CFL_CONV_CACHE_PLANES_DX;
+        }
+    }
     return hipGetLastError() == hipSuccess ? CFL_OK : cfl_set_err(CFL_E_HIP, "conv fwd launch failed");
 }
 
@@ -777,11 +793,8 @@ extern "C" int cfl_conv2d_wn_bwd_cached(const CflConv *c, const float *x, const 
         if (hp.ok) {
             // 3x3 stride 1: the input gradient is the same direct convolution over dy * act'(y) with the flipped,
             // scale-weighted filter (conv_halo.h)
-            unsigned short *planes = nullptr;
-            if (cache) {
-                const HaloPlan hf = halo_fwd_plan(g);
-                planes = (unsigned short *)((char *)cache + conv_cache_planes_off(g) + (hf.ok ? (hf.wp_bytes + 15) / 16 * 16 : 0));
-            }
+            unsigned short *planes = cache ? (unsigned short *)((char *)cache + conv_cache_planes_off(g) + conv_cache_fwd_bytes(g))
+                                           : nullptr;
             const bool prep = !cache || !(*cache_flags & CFL_CONV_CACHE_PLANES_DX);
             halo_conv(hp, g.B, g.H, g.W, g.Co, g.Ci, dy, y, g.act, V, scale, g.Ci, g.Co, 1, nullptr, 0, dx, slab, st, planes, prep);
             if (cache) *cache_flags |= CFL_CONV_CACHE_PLANES_DX;

@@ -47,6 +47,13 @@ __global__ __launch_bounds__(EW_THREADS) void ew_act_bwd_kernel(const float *y, 
     for (int64_t i = blockIdx.x * (int64_t)EW_THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * EW_THREADS)
         dx[i] = dy[i] * ew_slope(y[i], act);
 }
+// acc += dy * act'(y): the backward of a residual join act(r + h) towards h, added onto the gradient that arrives
+// through the block's convolutions (one launch instead of act_bwd + axpy)
+__global__ __launch_bounds__(EW_THREADS) void ew_act_bwd_add_kernel(const float *y, const float *dy, float *acc,
+                                                                    int64_t n, int act) {
+    for (int64_t i = blockIdx.x * (int64_t)EW_THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * EW_THREADS)
+        acc[i] = fmaf(dy[i], ew_slope(y[i], act), acc[i]);
+}
 __global__ __launch_bounds__(EW_THREADS) void ew_add_act_kernel(const float *a, const float *b, float *y,
                                                                 int64_t n, int act) {
     for (int64_t i = blockIdx.x * (int64_t)EW_THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * EW_THREADS)
@@ -383,6 +390,13 @@ extern "C" int cfl_ew_act_bwd(const float *y, const float *dy, float *dx, int64_
     if (n == 0) return CFL_OK;
     hipLaunchKernelGGL(ew_act_bwd_kernel, dim3(ew_blocks(n)), dim3(EW_THREADS), 0, (hipStream_t)stream, y, dy, dx, n, act);
     return done("ew_act_bwd");
+}
+
+extern "C" int cfl_ew_act_bwd_add(const float *y, const float *dy, float *acc, int64_t n, int act, cfl_stream_t stream) {
+    if (!y || !dy || !acc || n < 0 || act < 0 || act > CFL_EW_SIGMOID) return cfl_set_err(CFL_E_SHAPE, "cfl_ew_act_bwd_add: bad argument");
+    if (n == 0) return CFL_OK;
+    hipLaunchKernelGGL(ew_act_bwd_add_kernel, dim3(ew_blocks(n)), dim3(EW_THREADS), 0, (hipStream_t)stream, y, dy, acc, n, act);
+    return done("ew_act_bwd_add");
 }
 
 extern "C" int cfl_ew_add_act(const float *a, const float *b, float *y, int64_t n, int act, cfl_stream_t stream) {

@@ -409,6 +409,23 @@ static inline HaloPlan halo_plan(int B, int H, int W, int K, int N) {
     pl.ok = true;
     return pl;
 }
+// bytes of the prepared filter planes of a (K channels in, N channels out) direction -- a function of the channel counts
+// only (the cache of a layer is laid out with it whatever batch / image size a call has); 0 when the direction can never
+// run on the halo kernel
+static inline size_t halo_planes_bytes(int K, int N) {
+    if (halo_off() || !gg_use_x3() || K % 32 != 0 || N % 4 != 0 || N < 32) return 0;
+    const int tn = N >= 128 ? 128 : (N >= 64 ? 64 : 32);
+    const int Npad = (N + tn - 1) / tn * tn;
+    return ((size_t)9 * (K / 32) * 3 * Npad * 32 * sizeof(unsigned short) + 15) / 16 * 16;
+}
+// the filter preparation alone (what halo_conv does first when need_prep): lets a caller build the planes of BOTH
+// directions while it is on one stream, before several streams use them
+static inline void halo_prep_planes(const HaloPlan &pl, int K, int N, const float *V, const float *scale, int Ci, int Co,
+                                    int dgrad, unsigned short *wp, hipStream_t st) {
+    const long long prep = 9ll * pl.nchunks * pl.Npad * 4;
+    hipLaunchKernelGGL(conv_halo_prep_kernel, dim3((unsigned)((prep + 255) / 256)), dim3(256), 0, st, V, scale, Ci, Co,
+                       dgrad, K, N, pl.Npad, wp);
+}
 static inline size_t halo_scratch_bytes(const HaloPlan &pl) {
     return pl.ok ? ((pl.wp_bytes + 15) / 16 * 16 + pl.slab_floats * sizeof(float)) : 0;
 }

@@ -398,6 +398,9 @@ int cfl_conv2d_transpose_wn_bwd(const CflConv *conv, const float *x, const float
 int cfl_ew_act_fwd(const float *x, float *y, int64_t n, int act, cfl_stream_t stream);
 int cfl_ew_act_bwd(const float *y, const float *dy, float *dx, int64_t n, int act, cfl_stream_t stream);
 int cfl_ew_add_act(const float *a, const float *b, float *y, int64_t n, int act, cfl_stream_t stream);
+/* acc += dy * act'(y): backward of a residual join towards its skip input, accumulated onto the gradient that arrived
+ * through the block's convolutions (cfl/models/blocks.py:150-170 differentiated)                              */
+int cfl_ew_act_bwd_add(const float *y, const float *dy, float *acc, int64_t n, int act, cfl_stream_t stream);
 int cfl_ew_axpy(float alpha, const float *x, float *y, int64_t n, cfl_stream_t stream);
 /* y = clip(x * mul + add, lo, hi): data / ae / latent normaliser (cfl/ops.py:66-143, 302-349) applied
  * to a batch that does not enter the fused pair kernels (images for the conv stacks, GAN inputs). */
