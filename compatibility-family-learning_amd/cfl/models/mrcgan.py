@@ -58,6 +58,7 @@ class GanPhase(object):
         # signs from them); off by default so that a step's activations are released when it returns
         self.keep_tapes = False
         self.last_tapes = None
+        self.timing = None      # set to {} to have step() record where its chains end (ms from the start of the step)
 
     def generate(self, z, c):
         """Generator activations for display / sampling (cfl.bin.sample)."""
@@ -72,11 +73,20 @@ class GanPhase(object):
            Returns the scalars tensor (a view; read it after the step)."""
         B, Ld, sc = self.B, self.latent_size, self.scalars
         gen, disc = self.gen, self.disc
+        marks = [] if self.timing is not None else None     # (diagnostic: CFL-event marks along the chains, tools/gan_chain_probe.py)
+
+        def mark(name, stream=None):
+            if marks is not None:
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record(stream if stream is not None else torch.cuda.current_stream())
+                marks.append((name, ev))
+        mark('start')
         # ---- generator: rows [g | g_prj | g_neg] ------------------------------------------------
         zc = torch.empty(3 * B, self.z_dim + Ld, dtype=torch.float32, device=self.device)
         for i, c in enumerate((enc_act, prj_c, neg_c)):
             G.concat_cols(z, c, out=zc[i * B:(i + 1) * B])
         fake, g_tape = gen.forward(zc)
+        mark('g_forward')
         # ---- discriminator: rows [real | g | g_prj | g_neg | X_hat] -----------------------------
         nrow = 5 * B if self.lambda_gp else 4 * B
         x_all = torch.empty(nrow, self.ae_size, dtype=torch.float32, device=self.device)
@@ -85,6 +95,7 @@ class GanPhase(object):
         if self.lambda_gp:
             G.perturb(real, eps, self.lambda_dra, out=x_all[4 * B:5 * B])
         d_logit, d_lat, d_tape = disc.forward(x_all)
+        mark('d_forward')
 
         # ---- discriminator loss and gradient (variables only) -----------------------------------
         dd = torch.zeros(3 * B, 1, dtype=torch.float32, device=self.device)
@@ -105,6 +116,7 @@ class GanPhase(object):
             c1[0].wait_stream(main)
             with torch.cuda.stream(c1[0]):
                 disc.backward(d_tape, 0, 3 * B, dd, dl, need_dx=False, need_dw=True, grad=disc.pool.grad, ws=c1[1])
+                mark('chain1_d_loss_backward')
         else:
             disc.backward(d_tape, 0, 3 * B, dd, dl, need_dx=False, need_dw=True, grad=disc.pool.grad)
         if self.lambda_gp:
@@ -112,6 +124,7 @@ class GanPhase(object):
                 c2[0].wait_stream(main)
                 with torch.cuda.stream(c2[0]):
                     disc.gp_grads(d_tape, 4 * B, 5 * B, self.lambda_gp, sc[S_D_GP:S_D_GP + 1], disc.pool.grad2, ws=c2[1])
+                    mark('chain2_gradient_penalty')
             else:
                 disc.gp_grads(d_tape, 4 * B, 5 * B, self.lambda_gp, sc[S_D_GP:S_D_GP + 1], disc.pool.grad2)
 
@@ -127,8 +140,11 @@ class GanPhase(object):
         if self.m_prj:
             G.rowdist_loss(d_lat[3 * B:4 * B], neg_tgt_act, 2, self.m_prj, 1.0, sc[S_G_NEG:S_G_NEG + 1],
                            gl[2 * B:3 * B])
+        # (tried: this chain on a high-priority stream -- 15.5 -> 16.4 ms, tools/gan_chain_probe.py; not kept)
         d_img = disc.backward(d_tape, B, 4 * B, gd, gl, need_dx=True, need_dw=False)
+        mark('main_g_loss_backward_through_d')
         gen.backward(g_tape, d_img.contiguous())
+        mark('main_g_backward')
         for c in (c1, c2):
             if c is not None:
                 main.wait_stream(c[0])
@@ -140,6 +156,11 @@ class GanPhase(object):
         if apply:
             disc.adam()
             gen.adam()
+        mark('end')
+        if marks is not None:
+            torch.cuda.synchronize()
+            t0 = marks[0][1]
+            self.timing = {name: t0.elapsed_time(ev) for name, ev in marks}
         return sc
 
     def step_cgan(self, real_pos, real_neg, pos_c, neg_c, z, eps, apply=True):
