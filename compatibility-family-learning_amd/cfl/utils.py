@@ -193,7 +193,8 @@ def _scores(model, data, batch_size, negative):
 
 
 RESIDENT_EVAL_ROWS = 32768   # pairs per scoring launch when the split's features live in HBM (measured on one MI355X:
-#                              8192 pairs per call reach 0.35 of the HBM roof, 32768 reach 0.43-0.45: profiles/r03_*)
+#                              8192 pairs per call reach 0.40-0.42 of the HBM roof, 32768 reach 0.53-0.56: profiles/r03_d_eval_*,
+#                              bench.py roofline_eval.dist_eval_call)
 
 
 def _resident_ready(model, data):

@@ -22,8 +22,9 @@ sigmoid_cross_entropy_with_logits, Adam, ... restated from TF's documentation)
 were never compared with a real TensorFlow run.  Further pins: the analytic
 known-answer tests of SURVEY.md App. A.7, float64 finite differences of every
 analytic gradient and a torch-autograd cross-check (tests/test_oracle.py).  The
-data / eval side (oracle/data_oracle.py) is pinned against vectors captured by
-importing the reference unmodified (tests/golden/).
+data / eval side (the host restatements in compatibility-family-learning_amd/cfl/input_data.py and
+cfl/bin/evaluate_total.py; dist_eval below) is pinned against vectors captured by importing the reference
+unmodified (tests/golden/make_data_goldens.py, tests/test_input_data.py, tests/test_evaluate_total.py).
 
 All citations are ``path:line`` relative to the reference tree.
 

@@ -1,5 +1,5 @@
 #!/bin/bash
-# PMC passes over the headline training step (bench.py) (run on the GPU box).  Usage: bash tools/pmc_eval.sh <tag> "<counters pass 1>" "<counters pass 2>" ...
+# PMC passes over the headline training step (bench.py) (run on the GPU box).  Usage: bash tools/pmc_step.sh <tag> "<counters pass 1>" "<counters pass 2>" ...
 set -u
 tag=$1; shift
 export TMPDIR=/tmp
