@@ -14,7 +14,7 @@ EXPORTS = ('cfl_conv_transpose_workspace_bytes', 'cfl_conv2d_transpose_wn_fwd', 
            'cfl_subpixel2x_bwd', 'cfl_concat_cols', 'cfl_gather_prototype', 'cfl_bce_logits',
            'cfl_rowdist_loss', 'cfl_perturb_workspace_bytes', 'cfl_perturb', 'cfl_grad_penalty', 'cfl_copy_cols',
            'cfl_tile_concat_channels', 'cfl_tile_concat_channels_bwd', 'cfl_auc_workspace_bytes', 'cfl_auc', 'cfl_image_transform',
-           'cfl_ew_affine_clip_channels', 'cfl_conv_cache_bytes', 'cfl_conv2d_wn_fwd_cached', 'cfl_conv2d_wn_bwd_cached')
+           'cfl_ew_affine_clip_channels', 'cfl_conv_cache_bytes', 'cfl_conv2d_wn_fwd_cached', 'cfl_conv2d_wn_bwd_cached', 'cfl_conv2d_wn_fwd_fused')
 
 EW = {None: 0, 'linear': 0, 'lrelu': 1, 'relu': 2, 'tanh': 3, 'sigmoid': 4}
 
@@ -61,6 +61,8 @@ def lib():
     L.cfl_conv2d_wn_fwd_cached.argtypes = [C.POINTER(CflConv)] + [vp] * 6 + [sz, vp, sz, C.POINTER(C.c_int32), vp]
     L.cfl_conv2d_wn_bwd_cached.argtypes = ([C.POINTER(CflConv)] + [vp] * 5 + [f32] + [vp] * 5 +
                                            [sz, vp, sz, C.POINTER(C.c_int32), vp])
+    L.cfl_conv2d_wn_fwd_fused.argtypes = ([C.POINTER(CflConv)] + [vp] * 5 + [C.c_int32, vp, vp, sz, vp, sz,
+                                                                            C.POINTER(C.c_int32), vp])
     for n in EXPORTS:
         if n not in ('cfl_conv_transpose_workspace_bytes', 'cfl_perturb_workspace_bytes', 'cfl_auc_workspace_bytes',
                      'cfl_conv_cache_bytes'):
@@ -104,8 +106,20 @@ class ConvCache(object):
         return self
 
 
-def conv_fwd(conv, x, V, g, b, y, ws, transposed=False, cache=None):
+def conv_fwd(conv, x, V, g, b, y, ws, transposed=False, cache=None, residual=None, subpixel=False):
+    """residual / subpixel: store epilogues of cfl_conv2d_wn_fwd_fused (y = act(conv + b + residual); y stored 2x
+    sub-pixel shuffled [B, 2OH, 2OW, Co/4]); plain convolutions only."""
     L = lib()
+    if residual is not None or subpixel:
+        if transposed:
+            raise H.CflHipError('residual / sub-pixel epilogues exist for the plain convolution only')
+        use = cache is not None and ConvCache.enabled
+        if use:
+            cache.ensure(conv, x.device)
+        _check(L.cfl_conv2d_wn_fwd_fused(C.byref(conv), _dev(x), _dev(V), _opt(g), _opt(b), _opt(residual), int(bool(subpixel)),
+                                         _dev(y), ws.data_ptr(), ws.numel() * 4, cache.buf.data_ptr() if use else None,
+                                         cache.buf.numel() * 4 if use else 0, C.byref(cache.flags) if use else None, _stream()))
+        return y
     if cache is not None and not transposed and ConvCache.enabled:
         cache.ensure(conv, x.device)
         _check(L.cfl_conv2d_wn_fwd_cached(C.byref(conv), _dev(x), _dev(V), _opt(g), _opt(b), _dev(y), ws.data_ptr(),

@@ -133,15 +133,19 @@ class WNLayer(object):
             return Hh * self.stride, W * self.stride
         return -(-Hh // self.stride), -(-W // self.stride)
 
-    def fwd(self, x, ws, act='layer', bias=True):
-        """x [B,H,W,Ci] -> y [B,OH,OW,Co]."""
+    def fwd(self, x, ws, act='layer', bias=True, residual=None, subpixel=False):
+        """x [B,H,W,Ci] -> y [B,OH,OW,Co].  residual [B,OH,OW,Co]: y = act(conv + b + residual) (a residual block's join as
+        the store epilogue of its second convolution); subpixel: y is stored 2x sub-pixel shuffled, [B,2OH,2OW,Co/4] -- the
+        activation (element-wise) then plays the role of the shuffle's own."""
         act = self.act if act == 'layer' else act
         B, Hh, W, _ = x.shape
         d = self.desc(B, Hh, W, act)
         t = self.kind == 'convt'
         oh, ow = self.out_hw(Hh, W)
-        y = torch.empty(B, oh, ow, self.co, dtype=torch.float32, device=x.device)
-        G.conv_fwd(d, x, self.p('V'), self.p('g'), self.p('biases') if bias else None, y, ws.get(d, t), t, cache=self.cache())
+        shape = (B, 2 * oh, 2 * ow, self.co // 4) if subpixel else (B, oh, ow, self.co)
+        y = torch.empty(shape, dtype=torch.float32, device=x.device)
+        G.conv_fwd(d, x, self.p('V'), self.p('g'), self.p('biases') if bias else None, y, ws.get(d, t), t, cache=self.cache(),
+                   residual=residual, subpixel=subpixel)
         return y
 
     def bwd(self, x, y, dy, ws, need_dx=True, need_dw=True, grad=None, need_db=True, act='layer'):
@@ -307,18 +311,24 @@ class Generator(_Net):
         h = h.view(N, self.start, self.start, self.fc_dim)
         sr = self.gan_type == 'srgan'
         for blk in self.blocks:
-            y = blk.fwd(h, self.ws)
-            tape.append(('layer', blk, h, y))
             if sr:
-                s = G.subpixel_fwd(y, 'relu')
+                # conv -> sub-pixel shuffle -> relu in ONE launch: the shuffle is the convolution's store epilogue and the
+                # un-shuffled output, which nothing reads (the layer has no activation of its own), is never materialised
+                s = blk.fwd(h, self.ws, act='relu', subpixel=True)
+                tape.append(('layer', blk, h, None))
                 tape.append(('subpixel', 'relu', s))
                 y = s
+            else:
+                y = blk.fwd(h, self.ws)
+                tape.append(('layer', blk, h, y))
             h = y
-        y = self.out.fwd(h, self.ws)
-        tape.append(('layer', self.out, h, y))
         if sr:
-            y = G.subpixel_fwd(y, None)
+            y = self.out.fwd(h, self.ws, subpixel=True)
+            tape.append(('layer', self.out, h, None))
             tape.append(('subpixel', None, None))
+        else:
+            y = self.out.fwd(h, self.ws)
+            tape.append(('layer', self.out, h, y))
         outputs = y.view(N, -1)
         acts = G.act_fwd(outputs, self.data_type) if self.data_type != 'linear' else outputs
         tape.append(('data_act', acts))
@@ -342,7 +352,9 @@ class Generator(_Net):
             else:
                 _, layer, x, y = item
                 need_dx = layer is not self.fc1 or self.fc_t is not None
-                d = layer.bwd(x, y, d.reshape(y.shape), self.ws, need_dx=need_dx, need_dw=True, grad=self.pool.grad)
+                N_, Hh, W = x.shape[0], x.shape[1], x.shape[2]
+                oh, ow = layer.out_hw(Hh, W)
+                d = layer.bwd(x, y, d.reshape(N_, oh, ow, layer.co), self.ws, need_dx=need_dx, need_dw=True, grad=self.pool.grad)
         self.ws.join()
 
 
@@ -421,9 +433,9 @@ class Discriminator(_Net):
         for si, (res, down) in enumerate(self.stages):
             for a, b in res:
                 r1 = a.fwd(h, self.ws)
-                r2 = b.fwd(r1, self.ws)
-                out = G.add_act(r2, h, 'lrelu')
-                tape.append(('res', a, b, h, r1, r2, out))
+                # out = lrelu(conv_b(r1) + h): the join is the store epilogue of conv b (r2 itself is read by nothing)
+                out = b.fwd(r1, self.ws, act='lrelu', residual=h)
+                tape.append(('res', a, b, h, r1, None, out))
                 h = out
             if self.cond_stage == si:
                 if t is None:
@@ -500,7 +512,7 @@ class Discriminator(_Net):
                 if record is not None:
                     dpre = G.act_bwd(out[lo:hi], d, 'lrelu')          # d (r2 + h)
                     record.append(dpre)
-                    dr1 = b.bwd(r1[lo:hi], r2[lo:hi], dpre, ws, True, need_dw, grad)
+                    dr1 = b.bwd(r1[lo:hi], None, dpre, ws, True, need_dw, grad)
                     record.append(dr1)
                     dh = a.bwd(h[lo:hi], r1[lo:hi], dr1, ws, True, need_dw, grad)
                     d = G.axpy(1.0, dpre, dh)

@@ -144,8 +144,19 @@ struct FilterKN {  // B(k, n = co) = V[k][co]
 };
 struct StoreFwd {
     float *y; const float *scale, *bias; int Co, act;
+    const float *res;   // residual [M, Co] added before the activation, or nullptr
+    int subH, subW;     // > 0: 2x sub-pixel shuffled store, m = (b, oh, ow) of an subH x subW output (conv_halo.h: HaloArgs::subpixel)
     __device__ void operator()(int m, int n, float v, int) const {
-        y[(size_t)m * Co + n] = act_apply(v * scale[n] + (bias ? bias[n] : 0.f), act);
+        v = v * scale[n] + (bias ? bias[n] : 0.f);      // (the order of the separate kernels: (conv + b) + residual)
+        if (res) v += res[(size_t)m * Co + n];
+        v = act_apply(v, act);
+        if (subH > 0) {
+            const int ow = m % subW, t = m / subW, oh = t % subH, b = t / subH;
+            const int Cq = Co >> 2, q = n / Cq, c = n - q * Cq;
+            y[((((size_t)b * 2 * subH + 2 * oh + (q >> 1)) * (2 * subW)) + 2 * ow + (q & 1)) * Cq + c] = v;
+        } else {
+            y[(size_t)m * Co + n] = v;
+        }
     }
 };
 struct DyGather {  // A(m = (b,ih,iw), k = (kh,kw,co)) = dy_pre[b,(ih+pt-kh)/S,(iw+pl-kw)/S,co] * scale[co]
@@ -706,13 +717,17 @@ static void conv_scale_of(const ConvGeom &g, const float *V, const float *gain, 
     }
 }
 
-extern "C" int cfl_conv2d_wn_fwd_cached(const CflConv *c, const float *x, const float *V, const float *gain,
-                                        const float *bias, float *y, void *workspace, size_t workspace_bytes,
-                                        void *cache, size_t cache_bytes, int32_t *cache_flags, cfl_stream_t stream) {
+extern "C" int cfl_conv2d_wn_fwd_fused(const CflConv *c, const float *x, const float *V, const float *gain,
+                                       const float *bias, const float *residual, int32_t subpixel, float *y, void *workspace,
+                                       size_t workspace_bytes, void *cache, size_t cache_bytes, int32_t *cache_flags,
+                                       cfl_stream_t stream) {
     ConvGeom g;
     int rc = make_geom(c, &g);
     if (rc) return rc;
     if (!x || !V || !y || !workspace) return cfl_set_err(CFL_E_SHAPE, "NULL pointer");
+    if (subpixel && (g.Co % 4 != 0)) return cfl_set_err(CFL_E_SHAPE, "sub-pixel store needs Co %% 4 == 0");
+    if ((residual || subpixel) && g.KH == 1 && g.KW == 1 && g.H == 1 && g.W == 1 && g.S == 1 && g.Co <= 2)
+        return cfl_set_err(CFL_E_UNSUPPORTED, "residual / sub-pixel epilogue on the narrow fully connected layer");
     if (workspace_bytes < cfl_conv_workspace_bytes(c)) return cfl_set_err(CFL_E_WORKSPACE, "conv workspace too small");
     if (cache && (!cache_flags || cache_bytes < cfl_conv_cache_bytes(c) || ((uintptr_t)cache & 15)))
         return cfl_set_err(CFL_E_WORKSPACE, "conv cache too small / misaligned / without flags");
@@ -725,19 +740,21 @@ extern "C" int cfl_conv2d_wn_fwd_cached(const CflConv *c, const float *x, const 
     if (g.KH == 1 && g.KW == 1 && g.H == 1 && g.W == 1 && g.S == 1 && g.Co <= 2)
         hipLaunchKernelGGL(fc_narrow_fwd_kernel, dim3((g.B + 3) / 4), dim3(256), 0, st, x, V, scale, bias, g.B, g.Ci,
                            g.Co, g.act, y);
-    else if (hp.ok) {   // 3x3 stride 1: direct halo-tile kernel (weight-norm scale folded into the prepared filters)
+    else if (hp.ok && !(subpixel && (g.Co / 4) % 4 != 0)) {   // 3x3 stride 1: direct halo-tile kernel (weight-norm scale folded into the prepared filters)
         unsigned short *planes = cache ? (unsigned short *)((char *)cache + conv_cache_planes_off(g)) : nullptr;
         const bool prep = !cache || !(*cache_flags & CFL_CONV_CACHE_PLANES_FWD);
         halo_conv(hp, g.B, g.H, g.W, g.Ci, g.Co, x, nullptr, 0, V, scale, g.Ci, g.Co, 0, bias, g.act, y,
-                  (float *)workspace + conv_ws_header_floats(g), st, planes, prep);
+                  (float *)workspace + conv_ws_header_floats(g), st, planes, prep, residual,
+                  (subpixel && (g.Co / 4) % 4 == 0) ? 1 : 0);
         if (cache) *cache_flags |= CFL_CONV_CACHE_PLANES_FWD;
     }
     else if (vec)
         gemm_gather_modes<GG_VEC_K, GG_VEC_MN>(g.B * g.OH * g.OW, g.Co, rows, gg_klen(rows, 1), Im2colX{x, g},
-                                               FilterKN{V, g.Co}, StoreFwd{y, scale, bias, g.Co, g.act}, st);
+                                               FilterKN{V, g.Co},
+                                               StoreFwd{y, scale, bias, g.Co, g.act, residual, subpixel ? g.OH : 0, subpixel ? g.OW : 0}, st);
     else
         gemm_gather(g.B * g.OH * g.OW, g.Co, rows, gg_klen(rows, 1), Im2colX{x, g}, FilterKN{V, g.Co},
-                    StoreFwd{y, scale, bias, g.Co, g.act}, st);
+                    StoreFwd{y, scale, bias, g.Co, g.act, residual, subpixel ? g.OH : 0, subpixel ? g.OW : 0}, st);
     // The input-gradient planes of the layer are built here too, on the forward's stream, the first time the layer is
     // touched after an update: the backward passes of a step may run on several streams at once (MrCGAN: three chains
     // share every discriminator layer), and a plane set must not be built on one of them while another reads it.
@@ -750,6 +767,13 @@ extern "C" int cfl_conv2d_wn_fwd_cached(const CflConv *c, const float *x, const 
         }
     }
     return hipGetLastError() == hipSuccess ? CFL_OK : cfl_set_err(CFL_E_HIP, "conv fwd launch failed");
+}
+
+extern "C" int cfl_conv2d_wn_fwd_cached(const CflConv *c, const float *x, const float *V, const float *gain,
+                                        const float *bias, float *y, void *workspace, size_t workspace_bytes,
+                                        void *cache, size_t cache_bytes, int32_t *cache_flags, cfl_stream_t stream) {
+    return cfl_conv2d_wn_fwd_fused(c, x, V, gain, bias, nullptr, 0, y, workspace, workspace_bytes, cache, cache_bytes, cache_flags,
+                                   stream);
 }
 
 extern "C" int cfl_conv2d_wn_fwd(const CflConv *c, const float *x, const float *V, const float *gain,

@@ -38,7 +38,11 @@ struct HaloArgs {
     float slope_neg, slope_zero;   // act'(pre) from the sign of y: y > 0 ? 1 : (y < 0 ? neg : zero)
     const unsigned short *wp;      // prepared filter planes
     float *out;            // [B, H, W, N], or slabs [splits][B*H*W][N] when splits > 1
-    const float *bias;     // epilogue (splits == 1): out = act(acc + bias[n]); nullptr = no bias
+    const float *bias;     // epilogue (splits == 1): out = act(acc + bias[n] [+ res]); nullptr = no bias
+    const float *res;      // residual input [B, H, W, N] added before the activation (round 4: the join of a residual block as
+                           // the store epilogue of its second convolution), or nullptr
+    int subpixel;          // 1: the result is stored 2x sub-pixel shuffled, out [B, 2H, 2W, N/4] (cfl/layers.py:212-250 is a
+                           // pure index remap: channel n = (2 i + j) N/4 + c of pixel (h, w) -> channel c of pixel (2h+i, 2w+j))
     int act;               // epilogue activation (0 none, 1 lrelu, 2 relu)
     int B, H, W, K, N, Npad;
     int tiles_x, tiles_y;  // 128-pixel tiles per image (both 1 for the whole-image tiles)
@@ -345,28 +349,51 @@ __global__ __launch_bounds__(256) void conv_halo_x3_kernel(HaloArgs p) {
             const int img = pix / (TW * TH), r = pix - img * (TW * TH), py = r / TW, px = r - py * TW;
             const int b = b0 + img, oy = oy0 + py, ox = ox0 + px;
             if (b >= p.B || oy >= p.H || ox >= p.W) continue;
-            float *row = out + (((size_t)b * p.H + oy) * p.W + ox) * p.N;
+            const size_t pixoff = (((size_t)b * p.H + oy) * p.W + ox) * p.N;
+            float *row = out + pixoff;
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const int n = n0 + (wn * NT + nt) * 16 + r16;
                 if (n >= p.N) continue;
                 float v = acc[mt][nt][e];
-                if (!raw) v = halo_act(v + (p.bias ? p.bias[n] : 0.f), p.act);
+                if (!raw) {
+                    v += p.bias ? p.bias[n] : 0.f;            // (the order of the separate kernels: (conv + b) + residual)
+                    if (p.res) v += p.res[pixoff + n];
+                    v = halo_act(v, p.act);
+                    if (p.subpixel) {
+                        const int Cq = p.N >> 2, i = n / Cq, c = n - i * Cq;
+                        out[((((size_t)b * 2 * p.H + 2 * oy + (i >> 1)) * (2 * p.W)) + 2 * ox + (i & 1)) * Cq + c] = v;
+                        continue;
+                    }
+                }
                 row[n] = v;
             }
         }
 }
 
-// out[i] = act(sum_z slab[z][i] + bias[n]),  4 elements per thread (N % 4 == 0)
+// out[i] = act(sum_z slab[z][i] + bias[n] [+ res[i]]),  4 elements per thread (N % 4 == 0); subpixel (H, W > 0, N % 16 == 0):
+// stored shuffled as in the kernel's own epilogue
 __global__ __launch_bounds__(256) void conv_halo_reduce_kernel(const float *slab, int splits, size_t stride, size_t n4,
-                                                               int N, const float *bias, int act, float *out) {
+                                                               int N, const float *bias, int act, float *out,
+                                                               const float *res, int subH, int subW) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n4) return;
     gg_f32x4 s = *(const gg_f32x4 *)(slab + 4 * i);
     for (int z = 1; z < splits; ++z) s += *(const gg_f32x4 *)(slab + (size_t)z * stride + 4 * i);
     const int n = (int)((4 * i) % (size_t)N);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) s[e] = halo_act(s[e] + (bias ? bias[n + e] : 0.f), act);
+    for (int e = 0; e < 4; ++e) s[e] += bias ? bias[n + e] : 0.f;
+    if (res) s += *(const gg_f32x4 *)(res + 4 * i);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) s[e] = halo_act(s[e], act);
+    if (subH > 0) {
+        const size_t pix = (4 * i) / (size_t)N;
+        const int ox = (int)(pix % subW), oy = (int)((pix / subW) % subH);
+        const size_t b = pix / ((size_t)subW * subH);
+        const int Cq = N >> 2, q = n / Cq, c = n - q * Cq;      // (Cq % 4 == 0: the four channels stay in one quarter)
+        *(gg_f32x4 *)(out + (((b * 2 * subH + 2 * oy + (q >> 1)) * (2 * subW)) + 2 * ox + (q & 1)) * Cq + c) = s;
+        return;
+    }
     *(gg_f32x4 *)(out + 4 * i) = s;
 }
 
@@ -464,7 +491,8 @@ static inline void halo_launch_tw(const HaloArgs &a, int tn, dim3 grid, hipStrea
 static inline void halo_conv(const HaloPlan &pl, int B, int H, int W, int K, int N, const float *a, const float *ya,
                              int slope_act, const float *V, const float *scale, int Ci, int Co, int dgrad,
                              const float *bias, int act, float *out, void *scratch, hipStream_t st,
-                             unsigned short *planes_cache = nullptr, bool need_prep = true) {
+                             unsigned short *planes_cache = nullptr, bool need_prep = true, const float *res = nullptr,
+                             int subpixel = 0) {
     unsigned short *wp = planes_cache ? planes_cache : (unsigned short *)scratch;
     float *slab = (float *)((char *)scratch + (pl.wp_bytes + 15) / 16 * 16);
     const long long prep = 9ll * pl.nchunks * pl.Npad * 4;
@@ -475,7 +503,7 @@ static inline void halo_conv(const HaloPlan &pl, int B, int H, int W, int K, int
     memset(&h, 0, sizeof(h));
     h.a = a; h.ya = (ya && slope_act != 0) ? ya : nullptr;
     h.slope_neg = slope_act == 1 ? 0.2f : 0.f; h.slope_zero = 0.f;
-    h.wp = wp; h.out = pl.splits > 1 ? slab : out; h.bias = bias; h.act = act;
+    h.wp = wp; h.out = pl.splits > 1 ? slab : out; h.bias = bias; h.act = act; h.res = res; h.subpixel = subpixel;
     h.B = B; h.H = H; h.W = W; h.K = K; h.N = N; h.Npad = pl.Npad;
     h.tiles_x = pl.tiles_x; h.tiles_y = pl.tiles_y; h.nchunks = pl.nchunks;
     h.chunks_per_split = pl.chunks_per_split; h.slab_stride = (size_t)B * H * W * N;
@@ -487,6 +515,6 @@ static inline void halo_conv(const HaloPlan &pl, int B, int H, int W, int K, int
     if (pl.splits > 1) {
         const size_t n4 = h.slab_stride / 4;
         hipLaunchKernelGGL(conv_halo_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, slab, pl.splits,
-                           h.slab_stride, n4, N, bias, act, out);
+                           h.slab_stride, n4, N, bias, act, out, res, subpixel ? H : 0, subpixel ? W : 0);
     }
 }

@@ -370,6 +370,14 @@ int cfl_conv2d_wn_bwd_cached(const CflConv *conv, const float *x, const float *V
                              const float *y, const float *dy, float reg_const, float *dx, float *dV,
                              float *dg, float *db, void *workspace, size_t workspace_bytes,
                              void *cache, size_t cache_bytes, int32_t *cache_flags, cfl_stream_t stream);
+/* The forward with two store epilogues of the MrCGAN stacks folded in (cache nullable as above):
+ *   residual  dev [B,OH,OW,Co] or NULL: y = act(conv + b + residual) -- the join of a residual block
+ *             (cfl/models/blocks.py:150-170: lrelu(conv_b(...) + h)) as the epilogue of its second convolution
+ *   subpixel  != 0: y is stored 2x sub-pixel shuffled, [B, 2 OH, 2 OW, Co/4] (conv2d_subpixel, cfl/layers.py:212-250, is an
+ *             index remap of the convolution's output; the activation commutes with it).  Co % 4 == 0.            */
+int cfl_conv2d_wn_fwd_fused(const CflConv *conv, const float *x, const float *V, const float *g, const float *b,
+                            const float *residual, int32_t subpixel, float *y, void *workspace, size_t workspace_bytes,
+                            void *cache, size_t cache_bytes, int32_t *cache_flags, cfl_stream_t stream);
 
 /* Weight-normalised TRANSPOSED convolution (conv2d_transpose_weight_norm, cfl/layers.py:253-361):
  * x [B,H,W,Ci], V [KH,KW,Co,Ci] (norm over kh,kw,ci per OUTPUT channel), y [B,H*stride,W*stride,Co],

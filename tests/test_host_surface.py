@@ -229,3 +229,54 @@ def test_cli_entry_points_cap_the_host_thread_pool(monkeypatch):
         assert torch.get_num_threads() <= 2
     finally:
         torch.set_num_threads(before)
+
+
+def test_scalar_every_flag_and_read_back_cadence():
+    """--scalar-every N (not a reference flag; default 25; 1 = the reference's per-iteration validation fetch,
+    cfl/bin/train_dist.py:79-86 of the reference): the flag parses, and train_steps reads back at iterations 0, N, 2N, ...
+    and the last one, taking exactly one validation batch per read-back -- checked with a stand-in engine (no GPU)."""
+    from argparse import Namespace
+    assert train_dist.parse_args([]).scalar_every == 25
+    assert train_dist.parse_args(['--scalar-every', '1']).scalar_every == 1
+
+    class Src(object):
+        def __init__(self):
+            self.windows, self.singles = [], 0
+
+        def next_windows(self, batch, nsteps, shard=None):
+            self.windows.append(nsteps)
+            return Namespace(nsteps=nsteps)
+
+        def next_indexed(self, batch, shard=None):
+            self.singles += 1
+            return ('table', 'streams')
+
+    class Engine(object):
+        steps = 0
+
+        def step_windows(self, win):
+            self.steps += win.nsteps
+
+    for every, n_steps in ((25, 60), (1, 7), (10, 10), (4, 1)):
+        recorded = []
+        train, val, model = Src(), Src(), Namespace(engine=Engine())
+        orig = train_dist.DeferredScalars
+
+        class Rec(object):
+            def __init__(self, model, on_scalars):
+                pass
+
+            def record(self, step, val_batch):
+                recorded.append(step)
+
+            def flush(self):
+                pass
+        train_dist.DeferredScalars = Rec
+        try:
+            train_dist.train_steps(model, train, val, 8, None, n_steps, on_scalars=lambda *a: None, scalar_every=every)
+        finally:
+            train_dist.DeferredScalars = orig
+        want = sorted(set(list(range(0, n_steps, every)) + [n_steps - 1]))
+        assert recorded == want, (every, n_steps, recorded)
+        assert model.engine.steps == n_steps and sum(train.windows) == n_steps
+        assert val.singles == len(want)            # one validation batch per read-back: at N = 1 the reference's stream
