@@ -222,3 +222,48 @@ def test_exact_fp32_gemm_path_in_a_fresh_process():
                        env=env, cwd=root, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert ' passed' in r.stdout and 'deselected' in r.stdout, r.stdout[-500:]
+
+
+@pytest.mark.parametrize('B,Hh,Ww,Ci,Co,K,S,act', [
+    (3, 16, 16, 64, 128, 3, 1, 'lrelu'),     # halo kernel, one image per tile
+    (5, 8, 8, 128, 256, 3, 1, 'relu'),       # two images per tile; Co / 4 = 64
+    (11, 4, 4, 256, 256, 3, 1, 'lrelu'),     # eight images per tile, split-K over channel chunks (the reduce kernel's epilogue)
+    (2, 16, 16, 64, 12, 3, 1, None),         # the generator's output layer: Co / 4 = 3 -> gathered GEMM, scalar stores
+    (2, 8, 8, 6, 72, 4, 2, 'relu'),          # stride 2 / even kernel on the gathered GEMM
+    (2, 16, 16, 32, 36, 3, 1, 'lrelu'),      # Co / 4 = 9: halo-eligible layer whose shuffled store takes the GEMM path
+])
+def test_fused_store_epilogues_equal_the_separate_kernels(B, Hh, Ww, Ci, Co, K, S, act):
+    """cfl_conv2d_wn_fwd_fused: y = act(conv + b + residual) must equal the convolution followed by cfl_ew_add_act, and the
+    sub-pixel shuffled store must equal the convolution followed by cfl_subpixel2x_fwd -- BIT FOR BIT (same operations in
+    the same order; the shuffle is a pure index remap), on the halo kernel, its split-K reduce kernel and the gathered GEMM."""
+    from cfl import hipgan as G
+    rng = np.random.RandomState(3)
+    dev = 'cuda'
+    x = torch.tensor(rng.randn(B, Hh, Ww, Ci).astype(np.float32), device=dev)
+    V = torch.tensor((rng.randn(K, K, Ci, Co) * 0.2).astype(np.float32), device=dev)
+    g = torch.tensor((1.0 + 0.3 * rng.randn(Co)).astype(np.float32), device=dev)
+    b = torch.tensor((0.1 * rng.randn(Co)).astype(np.float32), device=dev)
+    plain = H.make_conv(B, Hh, Ww, Ci, Co, K, K, S, None)
+    fused = H.make_conv(B, Hh, Ww, Ci, Co, K, K, S, act)
+    oh, ow = H.conv_out_hw(plain)
+    ws = H.conv_workspace(plain, dev)
+    y0 = torch.empty(B, oh, ow, Co, device=dev)
+    G.conv_fwd(plain, x, V, g, b, y0, ws)
+    res = torch.tensor(rng.randn(B, oh, ow, Co).astype(np.float32), device=dev)
+    # residual join
+    want = G.add_act(y0, res, act)
+    got = torch.full_like(y0, float('nan'))
+    G.conv_fwd(fused, x, V, g, b, got, ws, residual=res)
+    assert torch.equal(got, want)
+    # sub-pixel shuffled store (+ activation)
+    want = G.subpixel_fwd(y0, act)
+    got = torch.full((B, 2 * oh, 2 * ow, Co // 4), float('nan'), device=dev)
+    G.conv_fwd(fused, x, V, g, b, got, ws, subpixel=True)
+    assert torch.equal(got, want)
+    # both, through a per-layer cache (the path the MrCGAN stacks take)
+    cache = G.ConvCache()
+    want = G.subpixel_fwd(G.add_act(y0, res, None), act)
+    got = torch.full((B, 2 * oh, 2 * ow, Co // 4), float('nan'), device=dev)
+    for _ in range(2):          # second call: cached scale / planes
+        G.conv_fwd(fused, x, V, g, b, got, ws, cache=cache, residual=res, subpixel=True)
+    assert torch.equal(got, want)
