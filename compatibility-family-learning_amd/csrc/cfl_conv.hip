@@ -740,12 +740,11 @@ extern "C" int cfl_conv2d_wn_fwd_fused(const CflConv *c, const float *x, const f
     if (g.KH == 1 && g.KW == 1 && g.H == 1 && g.W == 1 && g.S == 1 && g.Co <= 2)
         hipLaunchKernelGGL(fc_narrow_fwd_kernel, dim3((g.B + 3) / 4), dim3(256), 0, st, x, V, scale, bias, g.B, g.Ci,
                            g.Co, g.act, y);
-    else if (hp.ok && !(subpixel && (g.Co / 4) % 4 != 0)) {   // 3x3 stride 1: direct halo-tile kernel (weight-norm scale folded into the prepared filters)
+    else if (hp.ok) {   // 3x3 stride 1: direct halo-tile kernel (weight-norm scale folded into the prepared filters)
         unsigned short *planes = cache ? (unsigned short *)((char *)cache + conv_cache_planes_off(g)) : nullptr;
         const bool prep = !cache || !(*cache_flags & CFL_CONV_CACHE_PLANES_FWD);
         halo_conv(hp, g.B, g.H, g.W, g.Ci, g.Co, x, nullptr, 0, V, scale, g.Ci, g.Co, 0, bias, g.act, y,
-                  (float *)workspace + conv_ws_header_floats(g), st, planes, prep, residual,
-                  (subpixel && (g.Co / 4) % 4 == 0) ? 1 : 0);
+                  (float *)workspace + conv_ws_header_floats(g), st, planes, prep, residual, subpixel ? 1 : 0);
         if (cache) *cache_flags |= CFL_CONV_CACHE_PLANES_FWD;
     }
     else if (vec)

@@ -1412,6 +1412,7 @@ extern "C" __global__ __launch_bounds__(256, 2) void cfl_proj_bx3_rows16_kernel(
 struct GradJob {
     int side;              // 0 = src rows, 1 = dst rows (GradArgs::rows)
     const float *dyf;      // dYf tile base: blocks [(nt)*RG + rg]
+    const unsigned short *dyp;   // plan.dy_pre: the job's first column tile inside the dL/dy planes written by mid (put_planes)
     float *wpart;          // Wf tile base inside slab 0; slabs are pstride apart
     long long pstride;     // floats between row-range slabs (npad * D)
     int nt;
@@ -2333,7 +2334,8 @@ __device__ __forceinline__ void grad_body_x3(const GradJob &jb, const GradArgs &
 // ---------------------------------------------------------------------------
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-template <int NT, bool HO>   // HO: row split and / or siamese pairing (hand-off tail); false: the tile is complete in the workgroup
+template <int NT, bool HO, bool PRE = false>   // HO: row split and / or siamese pairing (hand-off tail); false: the tile is complete in the workgroup
+                                               // PRE: dL/dy arrives as bf16 planes written by mid (GradJob::dyp): no split of it here
 __device__ __forceinline__ void grad_body_x3_half(const GradJob &jb, const GradArgs &a, f32x4 *lds, int job, int dtile,
                                                   int p, const MgWait *mg = nullptr) {
     const int lane = threadIdx.x & 63;
@@ -2364,7 +2366,21 @@ __device__ __forceinline__ void grad_body_x3_half(const GradJob &jb, const GradA
     const float *dyl = jb.dyf + ((size_t)(kq >> 1) * 256 + (2 * (kq & 1) * 16 + i16) * 4);
     const RowSrc rs = jb.side ? a.rows[1] : a.rows[0];
     const long long *lrow = (const long long *)lds;   // row addresses of the whole batch, staged once (grad_body_x3)
+    const unsigned short *dypl = PRE ? jb.dyp + lane * 8 : nullptr;
+    const int RG2 = a.Rpad >> 5;
+    bf16x8 dyq[2][NT][3];   // PRE: the planes themselves
     auto loaddy = [&](int p0, f32x4 (*dyr)[NT][2]) {
+        if (PRE) {
+#pragma unroll
+            for (int r2 = 0; r2 < 2; ++r2)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl)
+                        dyq[r2][nt][pl] = *(const bf16x8 *)(dypl + (((size_t)nt * RG2 + (p0 >> 5) + r2) * 3 + pl) * 512);
+            __builtin_amdgcn_sched_barrier(0);
+            return;
+        }
 #pragma unroll
         for (int r2 = 0; r2 < 2; ++r2)
 #pragma unroll
@@ -2422,10 +2438,15 @@ __device__ __forceinline__ void grad_body_x3_half(const GradJob &jb, const GradA
             bf16x8 bf[NT][3];
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                float v[8];
+                if (PRE) {
 #pragma unroll
-                for (int jj = 0; jj < 8; ++jj) v[jj] = dyr[r2][nt][jj >> 2][jj & 3];
-                split_frag(v, bf[nt]);
+                    for (int pl = 0; pl < 3; ++pl) bf[nt][pl] = dyq[r2][nt][pl];
+                } else {
+                    float v[8];
+#pragma unroll
+                    for (int jj = 0; jj < 8; ++jj) v[jj] = dyr[r2][nt][jj >> 2][jj & 3];
+                    split_frag(v, bf[nt]);
+                }
             }
             if (a.norm.elementwise) {
 #pragma unroll
@@ -2611,6 +2632,37 @@ extern "C" __global__ __launch_bounds__(256) void cfl_grad_x3_half_split_kernel(
     }
 }
 
+// ... and both with dL/dy pre-split into bf16 planes by mid (plan.dy_pre: wide heads)
+extern "C" __global__ __launch_bounds__(256) void cfl_grad_x3_half_pre_kernel(GradArgs a_) {
+    CFL_KERNARG_IN_PLACE(GradArgs, a, a_);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    f32x4 *lds = (f32x4 *)smem;
+    if (blockIdx.z == 0) { grad_red_block(a, (float *)smem); return; }
+    const GradJob &jb = a.job[blockIdx.z - 1];
+    const int job = (int)blockIdx.z - 1, dt = grad_dtile(a.tps);
+    switch (jb.nt) {
+        case 1: grad_body_x3_half<1, false, true>(jb, a, lds, job, dt, 0); break;
+        case 2: grad_body_x3_half<2, false, true>(jb, a, lds, job, dt, 0); break;
+        case 3: grad_body_x3_half<3, false, true>(jb, a, lds, job, dt, 0); break;
+        default: grad_body_x3_half<4, false, true>(jb, a, lds, job, dt, 0); break;
+    }
+}
+
+extern "C" __global__ __launch_bounds__(256) void cfl_grad_x3_half_split_pre_kernel(GradArgs a_) {
+    CFL_KERNARG_IN_PLACE(GradArgs, a, a_);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    f32x4 *lds = (f32x4 *)smem;
+    if (blockIdx.z == 0) { grad_red_block(a, (float *)smem); return; }
+    const GradJob &jb = a.job[blockIdx.z - 1];
+    const int job = (int)blockIdx.z - 1, dt = grad_dtile(a.tps);
+    switch (jb.nt) {
+        case 1: grad_body_x3_half<1, true, true>(jb, a, lds, job, dt, (int)blockIdx.y); break;
+        case 2: grad_body_x3_half<2, true, true>(jb, a, lds, job, dt, (int)blockIdx.y); break;
+        case 3: grad_body_x3_half<3, true, true>(jb, a, lds, job, dt, (int)blockIdx.y); break;
+        default: grad_body_x3_half<4, true, true>(jb, a, lds, job, dt, (int)blockIdx.y); break;
+    }
+}
+
 // Two kernels rather than one with both bodies: eight inlined instantiations make the compiler keep `a` on the
 // stack (1.5 KiB of scratch per lane, occupancy 1).
 template <bool STAGED>
@@ -2665,6 +2717,9 @@ struct MidSide {
     const float *g;       // wn gains or null
     const float *n2;      // wn squared column norms or null
     float *dyf;           // fragment-major dL/dy (unscaled)
+    unsigned short *dyp;  // or null: the three truncation-split bf16 planes of dL/dy in the B-fragment order of the K = 32 MFMA
+                          // (plan.dy_pre: wide heads -- the weight-gradient launch then loads planes instead of splitting dL/dy
+                          // once per 32-d tile)
     float *cwf;           // fragment-major dL/dy * (x_hat.V) (weight-norm gain rows) or null
     int n, npad;
     int is_proto;         // 1: columns are k*L + l ; 0: columns are l
@@ -2767,6 +2822,18 @@ __device__ __forceinline__ f32x4 slab_sum(const float *src, long long sstride) {
 }
 
 // float offset of (row r, column c) inside a fragment-major buffer with RG row groups
+// dL/dy planes (MidSide::dyp): level p of dy[row r][col c] at ((nt * RG2 + r / 32) * 3 + p) * 512 + (8-row group (r / 8) % 4) * 128 +
+// (c % 16) * 8 + r % 8 -- lane (c16, kq) of the weight-gradient MFMA reads its 8 rows of a plane as ONE 16-byte load.  The split is
+// split3 (truncation): bit for bit what the weight-gradient kernels compute when they split dL/dy themselves.
+__device__ __forceinline__ void put_planes(unsigned short *dyp, int r, int c, int RG2, float dy) {
+    float h, m, l;
+    split3(dy, h, m, l);
+    unsigned short *q = dyp + ((size_t)(c >> 4) * RG2 + (r >> 5)) * 3 * 512 + (((r >> 3) & 3) * 16 + (c & 15)) * 8 + (r & 7);
+    q[0] = (unsigned short)(__float_as_uint(h) >> 16);
+    q[512] = (unsigned short)(__float_as_uint(m) >> 16);
+    q[1024] = (unsigned short)(__float_as_uint(l) >> 16);
+}
+
 __device__ __forceinline__ size_t frag_off(int r, int c, int RG) {
     return ((size_t)(c >> 4) * RG + (r >> 4)) * 256 + (((r >> 2) & 3) * 16 + (c & 15)) * 4 + (r & 3);
 }
@@ -3589,12 +3656,14 @@ __device__ __forceinline__ void mid_row_body(const MidArgs &a, int r, bool lead,
             const float dy = cs[j] ? dP * dd * act_grad(P[j], a.act) : 0.f;
             const size_t o_ = frag_off(r, c[j], RG);
             put(ss.dyf + o_, dy);
+            if (ss.dyp) put_planes(ss.dyp, r, c[j], a.Rpad >> 5, dy);
             if (ss.cwf) put(ss.cwf + o_, dy * xvs[j]);
         }
         if (c[j] < sd.npad) {
             const float dy = cd[j] ? dv * dd * act_grad(v[j], a.act) : 0.f;
             const size_t o_ = frag_off(r, c[j], RG);
             put(sd.dyf + o_, dy);
+            if (sd.dyp) put_planes(sd.dyp, r, c[j], a.Rpad >> 5, dy);
             if (sd.cwf) put(sd.cwf + o_, dy * xvd[j]);
         }
     }
@@ -4065,6 +4134,8 @@ struct Plan {
     int ring_tiles, ring_units, ring_nwg;
     bool grad_half;   // 32-d tiles, no row split (cfl_grad_x3_half_kernel)
     bool midgrad;     // ... with the row math inside the same launch (cfl_midgrad_half_kernel)
+    bool dy_pre;      // mid also writes dL/dy as bf16 planes and the half-tile weight gradient loads them (wide heads)
+    size_t dyp[2];
     size_t mg_flags;
     bool fused;       // gradient + Adam finished inside the weight-gradient launch (GradFuse)
     size_t handoff;   // workspace offset of the hand-off tickets + flags (ints), nhandoff of each
@@ -4301,6 +4372,22 @@ static int make_plan(const CflShape *s, int64_t rows, int groups, bool train, bo
         pl->mg_flags = take(pl->midgrad ? (size_t)pl->Rpad / 4 + pl->nregblocks + 64 : 0);
     }
     const bool ws_planes = (pl->proj_x3 || pl->proj_bx3) && !pl->planes_kept;
+    {
+        // dL/dy pre-split by mid (round-4 experiment, OPT-IN: CFL_DEBUG_DY_PRE=1): the weight-gradient launch splits dL/dy once
+        // per 32-d tile -- D / 32 times over -- and at wide heads that split is most of its VALU work (config 3: 3.2 M
+        // instructions per launch, two thirds of them this split).  Bit-identical, and SLOWER everywhere it was measured
+        // (profiles/r04_dy_pre_ab.txt: config 3 41.7 -> 44.5 us, config 4 46.9 -> 51.4, headline +-0): the planes are 1.5x
+        // the bytes through the vector-memory path that already bounds these launches, mid's 2-byte scattered stores
+        // cost it 1.5 - 2.7 us, and the split it removes was hidden behind the x latency.  Wave-per-row mid only.
+        const int wide = hs->npad > hd->npad ? hs->npad : hd->npad;
+        const bool small_reg = (s->K <= 8 && pl->Lq <= 2) || (s->K <= 4 && pl->Lq <= 4);
+        const bool row_mid = (s->dist_type == CFL_DIST_PCD || s->dist_type == CFL_DIST_SIAMESE) && wide <= 256 && s->K <= 64 &&
+                             !pl->mid_norow && !pl->mid_generic && !(small_reg && pl->R >= 16384);
+        const int ov = debug_env("CFL_DEBUG_DY_PRE");
+        pl->dy_pre = train && pl->grad_half && pl->x3 && row_mid && !pl->fold && !pl->midgrad && ov > 0;
+        pl->dyp[0] = take(pl->dy_pre ? (size_t)hs->npad * rp * 3 / 2 : 0);
+        pl->dyp[1] = take(pl->dy_pre ? (size_t)hd->npad * rp * 3 / 2 : 0);
+    }
     pl->wplanes[0] = take(ws_planes ? (size_t)hs->npad * s->D * 3 / 2 : 0);   // bf16 planes: 6 bytes per weight
     pl->wplanes[1] = take(ws_planes ? (size_t)hd->npad * s->D * 3 / 2 : 0);
     pl->n2 = take(2 * 6 * 1024);  // squared column norms + gain snapshot of up to 6 heads
@@ -4635,6 +4722,7 @@ static int run_pairs(const CflShape *s, const CflNorm *norm, const CflLossCfg *l
         m.g = h->g >= 0 ? theta + h->g : nullptr;
         m.n2 = s->weight_norm ? n2base + n2_off[side[sd].enc][side[sd].which] : nullptr;
         m.dyf = train ? ws + pl.dyf[sd] : nullptr;
+        m.dyp = (train && pl.dy_pre) ? (unsigned short *)(ws + pl.dyp[sd]) : nullptr;
         m.cwf = pl.has_cw ? ws + pl.cwf[sd] : nullptr;
         m.n = h->n; m.npad = h->npad;
         m.is_proto = side[sd].which == 1;
@@ -4807,6 +4895,7 @@ static int run_pairs(const CflShape *s, const CflNorm *norm, const CflLossCfg *l
                 GradJob &j = ga.job[nj++];
                 j.side = sd;
                 j.dyf = ws + pl.dyf[sd] + (size_t)c0 * RG * 256;
+                j.dyp = pl.dy_pre ? (const unsigned short *)(ws + pl.dyp[sd]) + (size_t)c0 * (pl.Rpad / 32) * 3 * 512 : nullptr;
                 j.wpart = ws + pl.wpart[sd] + (size_t)c0 * G * 256;
                 j.pstride = (long long)h->npad * s->D;
                 j.nt = tiles - c0 < 4 ? tiles - c0 : 4;
@@ -4974,8 +5063,12 @@ static int run_pairs(const CflShape *s, const CflNorm *norm, const CflLossCfg *l
             mg.early_x = debug_env("CFL_DEBUG_MIDGRAD") != 2;
             hipLaunchKernelGGL(cfl_midgrad_half_kernel, dim3(mg.first_contr + nj * mg.ntile), dim3(256),
                                4 * 4 * 4 * 64 * sizeof(f32x4), st, mg);
-        } else if (pl.grad_half && pl.P == 1 && !paired)
+        } else if (pl.grad_half && pl.P == 1 && !paired && pl.dy_pre)
+            hipLaunchKernelGGL(cfl_grad_x3_half_pre_kernel, dim3(s->D / 32, 1, nj + 1), dim3(256), 4 * 4 * 4 * 64 * sizeof(f32x4), st, ga);
+        else if (pl.grad_half && pl.P == 1 && !paired)
             hipLaunchKernelGGL(cfl_grad_x3_half_kernel, dim3(s->D / 32, 1, nj + 1), dim3(256), 4 * 4 * 4 * 64 * sizeof(f32x4), st, ga);
+        else if (pl.grad_half && pl.dy_pre)
+            hipLaunchKernelGGL(cfl_grad_x3_half_split_pre_kernel, dim3(s->D / 32, pl.P, nj + 1), dim3(256), 4 * 4 * 4 * 64 * sizeof(f32x4), st, ga);
         else if (pl.grad_half)
             hipLaunchKernelGGL(cfl_grad_x3_half_split_kernel, dim3(s->D / 32, pl.P, nj + 1), dim3(256), 4 * 4 * 4 * 64 * sizeof(f32x4), st, ga);
         else if (pl.x3 && pl.Rpad / pl.P <= 8192)

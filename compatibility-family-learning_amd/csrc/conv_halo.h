@@ -371,7 +371,7 @@ __global__ __launch_bounds__(256) void conv_halo_x3_kernel(HaloArgs p) {
         }
 }
 
-// out[i] = act(sum_z slab[z][i] + bias[n] [+ res[i]]),  4 elements per thread (N % 4 == 0); subpixel (H, W > 0, N % 16 == 0):
+// out[i] = act(sum_z slab[z][i] + bias[n] [+ res[i]]),  4 elements per thread (N % 4 == 0); subpixel (H, W > 0):
 // stored shuffled as in the kernel's own epilogue
 __global__ __launch_bounds__(256) void conv_halo_reduce_kernel(const float *slab, int splits, size_t stride, size_t n4,
                                                                int N, const float *bias, int act, float *out,
@@ -390,8 +390,12 @@ __global__ __launch_bounds__(256) void conv_halo_reduce_kernel(const float *slab
         const size_t pix = (4 * i) / (size_t)N;
         const int ox = (int)(pix % subW), oy = (int)((pix / subW) % subH);
         const size_t b = pix / ((size_t)subW * subH);
-        const int Cq = N >> 2, q = n / Cq, c = n - q * Cq;      // (Cq % 4 == 0: the four channels stay in one quarter)
-        *(gg_f32x4 *)(out + (((b * 2 * subH + 2 * oy + (q >> 1)) * (2 * subW)) + 2 * ox + (q & 1)) * Cq + c) = s;
+        const int Cq = N >> 2;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {      // (scalar stores: four consecutive channels may straddle two quarters when Cq % 4 != 0)
+            const int q = (n + e) / Cq, c = (n + e) - q * Cq;
+            out[(((b * 2 * subH + 2 * oy + (q >> 1)) * (2 * subW)) + 2 * ox + (q & 1)) * Cq + c] = s[e];
+        }
         return;
     }
     *(gg_f32x4 *)(out + 4 * i) = s;

@@ -230,7 +230,7 @@ def test_exact_fp32_gemm_path_in_a_fresh_process():
     (11, 4, 4, 256, 256, 3, 1, 'lrelu'),     # eight images per tile, split-K over channel chunks (the reduce kernel's epilogue)
     (2, 16, 16, 64, 12, 3, 1, None),         # the generator's output layer: Co / 4 = 3 -> gathered GEMM, scalar stores
     (2, 8, 8, 6, 72, 4, 2, 'relu'),          # stride 2 / even kernel on the gathered GEMM
-    (2, 16, 16, 32, 36, 3, 1, 'lrelu'),      # Co / 4 = 9: halo-eligible layer whose shuffled store takes the GEMM path
+    (2, 16, 16, 32, 36, 3, 1, 'lrelu'),      # Co / 4 = 9 on the halo kernel: four consecutive channels straddle two quarters
 ])
 def test_fused_store_epilogues_equal_the_separate_kernels(B, Hh, Ww, Ci, Co, K, S, act):
     """cfl_conv2d_wn_fwd_fused: y = act(conv + b + residual) must equal the convolution followed by cfl_ew_add_act, and the
