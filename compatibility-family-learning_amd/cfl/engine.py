@@ -283,11 +283,11 @@ class PairEngine(object):
         ws = self._workspace(xs.shape[0], 1)
         return H.pair_scores(self.shape, self.norm, xs, xt, self.theta, ws)
 
-    def scores_pos_neg(self, table, streams):
+    def scores_pos_neg(self, table, streams, out=None):
         """Scores of an indexed labeled batch, positive pairs then negative pairs, in one library call
-        (the validation fetch of the training loop): [2 n]."""
+        (the validation fetch of the training loop): [2 n] (written into `out` when given)."""
         ws = self._workspace(streams.n, 2)
-        return H.pair_scores_idx4(self.shape, self.norm, table, streams, self.theta, ws)
+        return H.pair_scores_idx4(self.shape, self.norm, table, streams, self.theta, ws, scores=out)
 
     # -- checkpoint payload --------------------------------------------------
     def sync_state(self):
