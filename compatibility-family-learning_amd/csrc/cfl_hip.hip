@@ -36,6 +36,7 @@
 //   losses     cfl/models/cfl.py:868-949, cfl/models/dist.py:253-284
 //   Adam       tf.train.AdamOptimizer (TF-1.x), cfl/models/cfl.py:1077-1085
 #include <hip/hip_runtime.h>
+#include <type_traits>
 
 #include <atomic>
 #include <cmath>
@@ -2780,6 +2781,15 @@ __device__ __forceinline__ float sum_p(float x) {
     x = dpp_add<0x140>(x);  // other half of the 16-lane row
     return x;
 }
+// sum over the 64 lanes, the same value in every lane: four DPP adds inside the 16-lane rows, then the four row sums
+// through v_readlane (SGPRs).  The wave-per-row mid kernel IS its latency chain (tools/mid_stamp_probe.py); wave_sum's six
+// ds_bpermute round trips through the LDS crossbar were ~450-750 cycles of it.
+__device__ __forceinline__ float wave_sum_dpp(float x) {
+    const int r = __float_as_int(sum_p(x));
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(r, 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(r, 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(r, 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(r, 48));
+    return (r0 + r1) + (r2 + r3);
+}
 // 1-ulp hardware transcendentals (v_exp_f32 / v_log_f32 / v_rcp_f32 / v_sqrt_f32): the
 // per-row math is one wave per block, so its instruction count is its latency.
 __device__ __forceinline__ float fexp(float x) { return __expf(x); }
@@ -3443,6 +3453,7 @@ __device__ __forceinline__ void mid_row_body(const MidArgs &a, int r, bool lead,
     const int lane = threadIdx.x & 63;
     constexpr int CW = 64 * J;
     float *Pl = W, *Vl = W + CW, *Rl = W + 2 * CW, *T = W + 3 * CW, *S = W + 4 * CW, *Q = W + 5 * CW;
+    RSTAMP(0);
     const bool valid = r < a.R;
     const int L = a.L, K = a.K, RG = a.Rpad >> 4;
     const MidSide &ss = a.side[0], &sd = a.side[1];
@@ -3458,60 +3469,99 @@ __device__ __forceinline__ void mid_row_body(const MidArgs &a, int r, bool lead,
         ll[j] = cs[j] ? c[j] - kk[j] * L : 0;
     }
 
-    // ---- head parameters: requested before the slice loads, so that this one-wave-per-row kernel (whose
-    // latency chain IS its duration) pays one memory round trip for everything it reads, not two ------------
+    // ---- head parameters + slice sums: EVERY load of this phase is unconditional and issued in one batch ---------------
+    // This one-wave-per-row kernel IS its latency chain.  Round 4 (tools/mid_stamp_probe.py + the ISA): written with
+    // `cond ? ptr[i] : const` / `s < S ? slab[s] : 0` the loads sat inside uniform branches, and hipcc's waitcnt pass
+    // drains the queue (s_waitcnt vmcnt(0)) at every such join -- the 16 + 16 slab loads went out one round trip after
+    // the other (3.2 us of the 6.7 us wave lifetime at the headline shape: 7700 -> 4100 cycles with this form).  Now:
+    // absent arrays point at a dummy word and their values are replaced by selects, and the slab count is a template
+    // parameter of the loader (switch on S BEFORE anything is in flight), so the compiler sees straight-line loads.
     const float thr_raw = *a.thr;
     float scs[J], scd[J], bs[J], bd[J], ys[J], yd[J];
     {
+        const bool wn = a.weight_norm != 0;
+        const float *gsp = wn ? ss.g : a.thr, *nsp = wn ? ss.n2 : a.thr, *gdp = wn ? sd.g : a.thr, *ndp = wn ? sd.n2 : a.thr;
+        const float *bsp = ss.b ? ss.b : a.thr, *bdp = sd.b ? sd.b : a.thr;
+        const bool hbs = ss.b != nullptr, hbd = sd.b != nullptr;
         float gs[J], ns[J], gd[J], nd[J];
 #pragma unroll
         for (int j = 0; j < J; ++j) {
             const int ks = cs[j] ? c[j] : 0, kd = cd[j] ? c[j] : 0;   // clamped: unconditional loads
-            gs[j] = a.weight_norm ? ss.g[ks] : 1.f;
-            ns[j] = a.weight_norm ? ss.n2[ks] : 1.f;
-            gd[j] = a.weight_norm ? sd.g[kd] : 1.f;
-            nd[j] = a.weight_norm ? sd.n2[kd] : 1.f;
-            bs[j] = ss.b ? ss.b[ks] : 0.f;
-            bd[j] = sd.b ? sd.b[kd] : 0.f;
+            gs[j] = gsp[wn ? ks : 0];
+            ns[j] = nsp[wn ? ks : 0];
+            gd[j] = gdp[wn ? kd : 0];
+            nd[j] = ndp[wn ? kd : 0];
+            bs[j] = bsp[hbs ? ks : 0];
+            bd[j] = bdp[hbd ? kd : 0];
         }
-        __builtin_amdgcn_sched_barrier(0);
-    // ---- slice sums + head epilogue (J columns per lane) ---------------------------
-    // all slice loads of both sides are independent and in flight together (summed in
-    // slice order afterwards)
-        float ts[J][16], td[J][16];
+        const float *srcs[J], *srcd[J];
 #pragma unroll
         for (int j = 0; j < J; ++j) {
             const int ccs = c[j] < ss.npad ? c[j] : 0, ccd = c[j] < sd.npad ? c[j] : 0;
-            const float *srcs = (FOLD == 1 || FOLD == 2) ? ss.ypart + fold_off(0, r, ccs, a.Rpad >> 5, ss.npad >> 4)
-                                     : ss.ypart + (size_t)r * ss.npad + ccs;
-            const float *srcd = (FOLD == 1 || FOLD == 2) ? sd.ypart + fold_off(0, r, ccd, a.Rpad >> 5, sd.npad >> 4)
-                                     : sd.ypart + (size_t)r * sd.npad + ccd;
+            srcs[j] = (FOLD == 1 || FOLD == 2) ? ss.ypart + fold_off(0, r, ccs, a.Rpad >> 5, ss.npad >> 4)
+                                               : ss.ypart + (size_t)r * ss.npad + ccs;
+            srcd[j] = (FOLD == 1 || FOLD == 2) ? sd.ypart + fold_off(0, r, ccd, a.Rpad >> 5, sd.npad >> 4)
+                                               : sd.ypart + (size_t)r * sd.npad + ccd;
+        }
+        // all slice loads of both sides are independent and in flight together; summed in slice order afterwards
+        // (the same order of additions as before: s = 0, 1, ..., S - 1)
+        auto slabs = [&](auto ns_c) {
+            constexpr int NS = decltype(ns_c)::value;
+            float ts[J][NS], td[J][NS];
 #pragma unroll
-            for (int s = 0; s < 16; ++s) {
-                if (FOLD == 2) {
-                    ts[j][s] = s < a.S ? __hip_atomic_load(srcs + (size_t)s * ss.sstride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
-                    td[j][s] = s < a.S ? __hip_atomic_load(srcd + (size_t)s * sd.sstride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
-                } else {
-                    ts[j][s] = s < a.S ? srcs[(size_t)s * ss.sstride] : 0.f;
-                    td[j][s] = s < a.S ? srcd[(size_t)s * sd.sstride] : 0.f;
+            for (int j = 0; j < J; ++j)
+#pragma unroll
+                for (int sl = 0; sl < NS; ++sl) {
+                    if (FOLD == 2) {
+                        ts[j][sl] = __hip_atomic_load(srcs[j] + (size_t)sl * ss.sstride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        td[j][sl] = __hip_atomic_load(srcd[j] + (size_t)sl * sd.sstride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    } else {
+                        ts[j][sl] = srcs[j][(size_t)sl * ss.sstride];
+                        td[j][sl] = srcd[j][(size_t)sl * sd.sstride];
+                    }
+                }
+#pragma unroll
+            for (int j = 0; j < J; ++j) {
+                ys[j] = 0.f;
+                yd[j] = 0.f;
+#pragma unroll
+                for (int sl = 0; sl < NS; ++sl) { ys[j] += ts[j][sl]; yd[j] += td[j][sl]; }
+            }
+        };
+        switch (a.S) {   // (uniform; the d split is a power of two up to 16, anything else from CFL_DEBUG_S: generic tail)
+            case 1: slabs(std::integral_constant<int, 1>()); break;
+            case 2: slabs(std::integral_constant<int, 2>()); break;
+            case 4: slabs(std::integral_constant<int, 4>()); break;
+            case 8: slabs(std::integral_constant<int, 8>()); break;
+            case 16: slabs(std::integral_constant<int, 16>()); break;
+            default: {
+                // any other split: clamped slice indices (re-reads of the last slice are masked out), still branch-free
+                const int S1 = a.S - 1;
+#pragma unroll
+                for (int j = 0; j < J; ++j) {
+                    float accs = 0.f, accd = 0.f, ts[16], td[16];
+#pragma unroll
+                    for (int sl = 0; sl < 16; ++sl) {
+                        const int sc = sl < a.S ? sl : S1;
+                        ts[sl] = srcs[j][(size_t)sc * ss.sstride];
+                        td[sl] = srcd[j][(size_t)sc * sd.sstride];
+                    }
+#pragma unroll
+                    for (int sl = 0; sl < 16; ++sl) { accs += sl < a.S ? ts[sl] : 0.f; accd += sl < a.S ? td[sl] : 0.f; }
+                    ys[j] = accs;
+                    yd[j] = accd;
                 }
             }
         }
 #pragma unroll
         for (int j = 0; j < J; ++j) {
-            scs[j] = (a.weight_norm && cs[j]) ? gs[j] * __builtin_amdgcn_rsqf(ns[j]) : 1.f;
-            scd[j] = (a.weight_norm && cd[j]) ? gd[j] * __builtin_amdgcn_rsqf(nd[j]) : 1.f;
-            if (!cs[j]) bs[j] = 0.f;
-            if (!cd[j]) bd[j] = 0.f;
-        }
-#pragma unroll
-        for (int j = 0; j < J; ++j) {
-            ys[j] = 0.f;
-            yd[j] = 0.f;
-#pragma unroll
-            for (int s = 0; s < 16; ++s) { ys[j] += ts[j][s]; yd[j] += td[j][s]; }
+            scs[j] = (wn && cs[j]) ? gs[j] * __builtin_amdgcn_rsqf(ns[j]) : 1.f;
+            scd[j] = (wn && cd[j]) ? gd[j] * __builtin_amdgcn_rsqf(nd[j]) : 1.f;
+            bs[j] = (hbs && cs[j]) ? bs[j] : 0.f;
+            bd[j] = (hbd && cd[j]) ? bd[j] : 0.f;
         }
     }
+    RSTAMP(1);   // slabs summed: the loads have landed
     float xvs[J], xvd[J], P[J], v[J];
 #pragma unroll
     for (int j = 0; j < J; ++j) {
@@ -3533,6 +3583,9 @@ __device__ __forceinline__ void mid_row_body(const MidArgs &a, int r, bool lead,
     if (K > 1) {
 #pragma unroll
         for (int j = 0; j < J; ++j) T[c[j]] = diff[j] * diff[j];
+        // (measured, round 4: the segment sums with LDS reads batched eight at a time -- clamped indices, masked values, all
+        // lanes -- and the K-loops on v_readlane instead of LDS broadcasts: this phase 4170 -> 4800 cycles at the headline
+        // shape.  Three lanes reading a segment each is cheap; sixty-four reading strided segments is not.  Left as it was.)
         float e = 0.f;
         if (lane < K)
             for (int i = 0; i < L; ++i) e += T[lane * L + i];
@@ -3555,7 +3608,7 @@ __device__ __forceinline__ void mid_row_body(const MidArgs &a, int r, bool lead,
             Rl[c[j]] = rl[j];
             dsum = fmaf(rl[j], rl[j], dsum);
         }
-        d = wave_sum(dsum);
+        d = wave_sum_dpp(dsum);
 #pragma unroll
         for (int j = 0; j < J; ++j) T[c[j]] = cs[j] ? Rl[ll[j]] * P[j] : 0.f;
         float q = 0.f;
@@ -3573,10 +3626,11 @@ __device__ __forceinline__ void mid_row_body(const MidArgs &a, int r, bool lead,
         float dsum = 0.f;
 #pragma unroll
         for (int j = 0; j < J; ++j) dsum = fmaf(diff[j], diff[j], dsum);
-        d = wave_sum(dsum);
+        d = wave_sum_dpp(dsum);
     }
 
     // ---- threshold, loss, dL/dd ------------------------------------------------------
+    RSTAMP(2);   // distance done
     const float thr = fmaxf(thr_raw, CFL_THR_FLOOR);
     const float o = thr - d;
     if (!a.train) {
@@ -3638,6 +3692,7 @@ __device__ __forceinline__ void mid_row_body(const MidArgs &a, int r, bool lead,
         put(a.rowqf + frag_off(r, lane, RG), qv);
     }
 
+    RSTAMP(3);   // loss + row quantities stored
     // ---- backward: J source columns and (columns < L) J destination columns per lane ----
 #pragma unroll
     for (int j = 0; j < J; ++j) {
@@ -3667,6 +3722,11 @@ __device__ __forceinline__ void mid_row_body(const MidArgs &a, int r, bool lead,
             if (sd.cwf) put(sd.cwf + o_, dy * xvd[j]);
         }
     }
+    RSTAMP(4);   // stores issued
+#ifdef CFL_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    RSTAMP(5);   // stores acknowledged
+#endif
 }
 
 template <int J>
