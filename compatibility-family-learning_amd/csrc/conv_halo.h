@@ -473,7 +473,12 @@ static inline HaloPlan halo_plan(int B, int H, int W, int K, int N) {
     pl.ntiles = (N + pl.tn - 1) / pl.tn;
     pl.Npad = pl.ntiles * pl.tn;
     pl.nchunks = K / 32;
-    const long long tiles = (long long)pl.ptiles * pl.ntiles;
+    // (the split count is planned on 128-column tiles whatever tile runs: the summation order of every output, and with
+    // it every recorded trajectory, stays what it was before the 64-column tile became the default; CFL_DEBUG_HALO_SPLIT_TN=1
+    // plans on the tile that runs)
+    static const int split_tn = [] { const char *e = getenv("CFL_DEBUG_HALO_SPLIT_TN"); return e ? atoi(e) : 0; }();
+    const int tn_plan = split_tn ? pl.tn : (N >= 128 ? 128 : pl.tn);
+    const long long tiles = (long long)pl.ptiles * ((N + tn_plan - 1) / tn_plan);
     int want = (int)((512 + tiles - 1) / tiles);
     if (want > pl.nchunks) want = pl.nchunks;
     if (want > 32) want = 32;
