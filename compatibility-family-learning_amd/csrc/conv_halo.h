@@ -452,9 +452,13 @@ static inline bool halo_off() {
 // wave, 85 % with two -- tools/microbench/mfma_peak.hip) and two independent workgroups hide each other's barriers.
 // Round 4, same box: 300x16x16x256->512 0.925 -> 0.82 ms, 300x8x8x512->1024 0.97 -> 0.94 ms, 500x16x16x64->64 (already a
 // 64-column tile, now two per CU) 0.090 -> 0.064 ms.  CFL_DEBUG_HALO_TN=128 restores the wide tile, =32 forces the narrow one.
-static inline int halo_tn_of(int N) {
+// (the 4-wide tile -- eight 4x4 images, 288 halo rows, 78 KiB -- takes the 64-column tile too: 500x4x4x256->256 0.076 -> 0.069 ms,
+// 300x4x4x64->2048 0.123 -> 0.086 ms; the 32-column tile loses everywhere: tools/halo_probe.py)
+static inline int halo_tn_base(int N) { return N >= 128 ? 128 : (N >= 64 ? 64 : 32); }   // also the padding unit of the planes
+static inline int halo_tn_of(int N, int tw) {
     static const int cap = [] { const char *e = getenv("CFL_DEBUG_HALO_TN"); const int v = e ? atoi(e) : 0; return v == 32 || v == 128 ? v : 64; }();
-    const int tn = N >= 128 ? 128 : (N >= 64 ? 64 : 32);
+    const int tn = halo_tn_base(N);
+    (void)tw;
     return tn < cap ? tn : cap;
 }
 
@@ -469,9 +473,10 @@ static inline HaloPlan halo_plan(int B, int H, int W, int K, int N) {
     else if (W == 4 && H == 4) { pl.tw = 4; pl.tiles_x = pl.tiles_y = 1; pl.ptiles = (B + 7) / 8; }
     else return pl;
     if ((size_t)B * H * W * (size_t)K >= 0xffffffffull) return pl;     // 32-bit element offsets of A
-    pl.tn = halo_tn_of(N);
+    pl.tn = halo_tn_of(N, pl.tw);
     pl.ntiles = (N + pl.tn - 1) / pl.tn;
-    pl.Npad = pl.ntiles * pl.tn;
+    // the planes are padded to the BASE tile whatever tile runs: their layout is a function of the channel counts alone
+    pl.Npad = (N + halo_tn_base(N) - 1) / halo_tn_base(N) * halo_tn_base(N);
     pl.nchunks = K / 32;
     // (the split count is planned on 128-column tiles whatever tile runs: the summation order of every output, and with
     // it every recorded trajectory, stays what it was before the 64-column tile became the default; CFL_DEBUG_HALO_SPLIT_TN=1
@@ -495,7 +500,7 @@ static inline HaloPlan halo_plan(int B, int H, int W, int K, int N) {
 // run on the halo kernel
 static inline size_t halo_planes_bytes(int K, int N) {
     if (halo_off() || !gg_use_x3() || K % 32 != 0 || N % 4 != 0 || N < 32) return 0;
-    const int tn = halo_tn_of(N);
+    const int tn = halo_tn_base(N);
     const int Npad = (N + tn - 1) / tn * tn;
     return ((size_t)9 * (K / 32) * 3 * Npad * 32 * sizeof(unsigned short) + 15) / 16 * 16;
 }

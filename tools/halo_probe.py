@@ -6,7 +6,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, 'compatibility-family-learning_amd')]
 import torch
 from cfl import hipabi as H
-shapes = [(300, 8, 8, 512, 1024), (300, 16, 16, 256, 512), (500, 32, 32, 32, 32), (500, 16, 16, 64, 64), (500, 8, 8, 128, 128)]
+shapes = [(300, 8, 8, 512, 1024), (300, 16, 16, 256, 512), (500, 32, 32, 32, 32), (500, 16, 16, 64, 64), (500, 8, 8, 128, 128),
+          (500, 4, 4, 256, 256), (300, 4, 4, 64, 2048)]
 for abl in [0]:
     for (B, Hh, W, Ci, Co) in shapes:
         conv = H.make_conv(B, Hh, W, Ci, Co, 3, 3, 1, None)
