@@ -618,7 +618,9 @@ def main():
         exact = os.environ.get('CFL_EXACT_FP32', '0') not in ('', '0')
         if dom == 'grad':
             kname = 'cfl_grad_kernel' if exact else (
-                ('cfl_grad_x3_half_kernel' if 2 * B <= 2048 else 'cfl_grad_x3_half_split_kernel' if 2 * B <= 6144
+                (('cfl_grad_x3_half_w8_kernel' if (3 * B + 255) // 256 * 256 % 512 == 0 and
+                  os.environ.get('CFL_DEBUG_GRAD_W8', '0') != '-1' else 'cfl_grad_x3_half_kernel')
+                 if 2 * B <= 2048 else 'cfl_grad_x3_half_split_kernel' if 2 * B <= 6144
                  else 'cfl_grad_x3_kernel') if 256 <= (D // 32) * 2 <= 640 else 'cfl_grad_x3_kernel')
         else:
             kname = 'cfl_proj_kernel' if (exact or world > 1) else ('cfl_proj_bx3_kernel' if 2 * B < 3072 else 'cfl_proj_x3_keep_kernel')

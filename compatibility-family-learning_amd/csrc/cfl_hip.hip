@@ -2335,7 +2335,7 @@ __device__ __forceinline__ void grad_body_x3(const GradJob &jb, const GradArgs &
 // ---------------------------------------------------------------------------
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-template <int NT, bool HO, bool PRE = false>   // HO: row split and / or siamese pairing (hand-off tail); false: the tile is complete in the workgroup
+template <int NT, bool HO, bool PRE = false, int NW = 4>   // NW: waves per workgroup (8: experiment, two waves per SIMD); HO: row split and / or siamese pairing (hand-off tail); false: the tile is complete in the workgroup
                                                // PRE: dL/dy arrives as bf16 planes written by mid (GradJob::dyp): no split of it here
 __device__ __forceinline__ void grad_body_x3_half(const GradJob &jb, const GradArgs &a, f32x4 *lds, int job, int dtile,
                                                   int p, const MgWait *mg = nullptr) {
@@ -2354,7 +2354,7 @@ __device__ __forceinline__ void grad_body_x3_half(const GradJob &jb, const GradA
     const bool side0 = paired && job < pair_jobs;
     const int slot = (paired && !side0 ? job - pair_jobs : job) * (a.D >> 5) + dtile;
     const int expect = paired ? 2 * P - 1 : P - 1;
-    const int rows_wg = HO ? a.Rpad / P : a.Rpad, rows_w = rows_wg >> 2;   // multiple of 64
+    const int rows_wg = HO ? a.Rpad / P : a.Rpad, rows_w = rows_wg / NW;   // multiple of 64
     const int rbeg = p * rows_wg + wave * rows_w, rend = rbeg + rows_w;
     const int r64 = (a.R + 63) & ~63;
     const int rstop = rend < r64 ? rend : r64;
@@ -2484,7 +2484,7 @@ __device__ __forceinline__ void grad_body_x3_half(const GradJob &jb, const GradA
     for (int t = 0; t < 2; ++t) {
         sum[t] = lds[((0 * NT + ntw) * 2 + t) * 64 + lane];
 #pragma unroll
-        for (int w = 1; w < 4; ++w) sum[t] += lds[((w * NT + ntw) * 2 + t) * 64 + lane];
+        for (int w = 1; w < NW; ++w) sum[t] += lds[((w * NT + ntw) * 2 + t) * 64 + lane];
     }
     const size_t tile_off = ((size_t)ntw * G + (dbase >> 4) + (kq >> 1)) * 256 + (2 * (kq & 1) * 16 + i16) * 4;
     if (!a.fuse.on) {
@@ -2614,6 +2614,26 @@ extern "C" __global__ __launch_bounds__(256) void cfl_grad_x3_half_kernel(GradAr
         case 2: grad_body_x3_half<2, false>(jb, a, lds, job, dt, 0); break;
         case 3: grad_body_x3_half<3, false>(jb, a, lds, job, dt, 0); break;
         default: grad_body_x3_half<4, false>(jb, a, lds, job, dt, 0); break;
+    }
+}
+
+// experiment (CFL_DEBUG_GRAD_W8=1): the same tile with EIGHT waves (two per SIMD, half the rows each)
+extern "C" __global__ __launch_bounds__(512) void cfl_grad_x3_half_w8_kernel(GradArgs a_) {
+    CFL_KERNARG_IN_PLACE(GradArgs, a, a_);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    f32x4 *lds = (f32x4 *)smem;
+    if (blockIdx.z == 0) {
+        if (threadIdx.x >= 256) return;   // (the reduction blocks are written for four waves; a finished wave does not count at a barrier)
+        grad_red_block(a, (float *)smem);
+        return;
+    }
+    const GradJob &jb = a.job[blockIdx.z - 1];
+    const int job = (int)blockIdx.z - 1, dt = grad_dtile(a.tps);
+    switch (jb.nt) {
+        case 1: grad_body_x3_half<1, false, false, 8>(jb, a, lds, job, dt, 0); break;
+        case 2: grad_body_x3_half<2, false, false, 8>(jb, a, lds, job, dt, 0); break;
+        case 3: grad_body_x3_half<3, false, false, 8>(jb, a, lds, job, dt, 0); break;
+        default: grad_body_x3_half<4, false, false, 8>(jb, a, lds, job, dt, 0); break;
     }
 }
 
@@ -4193,6 +4213,7 @@ struct Plan {
     bool proj_ring;   // loader / consumer ring form (cfl_proj_ring_kernel); S is then the ring's d split
     int ring_tiles, ring_units, ring_nwg;
     bool grad_half;   // 32-d tiles, no row split (cfl_grad_x3_half_kernel)
+    bool grad_w8;     // ... with eight waves per workgroup (cfl_grad_x3_half_w8_kernel)
     bool midgrad;     // ... with the row math inside the same launch (cfl_midgrad_half_kernel)
     bool dy_pre;      // mid also writes dL/dy as bf16 planes and the half-tile weight gradient loads them (wide heads)
     size_t dyp[2];
@@ -4445,6 +4466,12 @@ static int make_plan(const CflShape *s, int64_t rows, int groups, bool train, bo
                              !pl->mid_norow && !pl->mid_generic && !(small_reg && pl->R >= 16384);
         const int ov = debug_env("CFL_DEBUG_DY_PRE");
         pl->dy_pre = train && pl->grad_half && pl->x3 && row_mid && !pl->fold && !pl->midgrad && ov > 0;
+        // eight waves per workgroup (two per SIMD) for the unsplit half tiles: one wave per SIMD leaves the row loop's load
+        // latency and its split arithmetic (8 VALU instructions per MFMA: SQ_INSTS_VALU) with nothing to overlap with.  Not for
+        // the shared siamese heads: their fused form runs the split kernel's four-wave order, and the separate finalize launch
+        // must keep adding the same partial sums (CFL_DEBUG_GRAD_W8=-1: four waves everywhere)
+        pl->grad_w8 = train && pl->grad_half && pl->P == 1 && pl->x3 && !pl->dy_pre && !pl->midgrad && pl->Rpad % 512 == 0 &&
+                      !(s->dist_type == CFL_DIST_SIAMESE && !s->directed) && debug_env("CFL_DEBUG_GRAD_W8") >= 0;
         pl->dyp[0] = take(pl->dy_pre ? (size_t)hs->npad * rp * 3 / 2 : 0);
         pl->dyp[1] = take(pl->dy_pre ? (size_t)hd->npad * rp * 3 / 2 : 0);
     }
@@ -5125,6 +5152,8 @@ static int run_pairs(const CflShape *s, const CflNorm *norm, const CflLossCfg *l
                                4 * 4 * 4 * 64 * sizeof(f32x4), st, mg);
         } else if (pl.grad_half && pl.P == 1 && !paired && pl.dy_pre)
             hipLaunchKernelGGL(cfl_grad_x3_half_pre_kernel, dim3(s->D / 32, 1, nj + 1), dim3(256), 4 * 4 * 4 * 64 * sizeof(f32x4), st, ga);
+        else if (pl.grad_half && pl.P == 1 && !paired && pl.grad_w8)
+            hipLaunchKernelGGL(cfl_grad_x3_half_w8_kernel, dim3(s->D / 32, 1, nj + 1), dim3(512), 4 * 4 * 4 * 64 * sizeof(f32x4), st, ga);
         else if (pl.grad_half && pl.P == 1 && !paired)
             hipLaunchKernelGGL(cfl_grad_x3_half_kernel, dim3(s->D / 32, 1, nj + 1), dim3(256), 4 * 4 * 4 * 64 * sizeof(f32x4), st, ga);
         else if (pl.grad_half && pl.dy_pre)

@@ -95,7 +95,7 @@ def test_hot_kernels_keep_their_argument_block_out_of_scratch():
         seen[name] = int(scratch)
     hot = ['cfl_proj_kernel', 'cfl_proj_stream_kernel', 'cfl_proj_ring_kernel', 'cfl_grad_kernel', 'cfl_grad_x3_kernel',
            'cfl_grad_x3_longrange_kernel', 'cfl_finalize_kernel', 'cfl_adam_kernel', 'cfl_proj_mid_kernel', 'cfl_proj_x3_kernel', 'cfl_proj_x3_keep_kernel', 'cfl_grad_x3_half_kernel', 'cfl_grad_x3_half_split_kernel', 'cfl_midgrad_half_kernel',
-           'cfl_proj_bx3_kernel', 'cfl_grad_x3_half_pre_kernel', 'cfl_grad_x3_half_split_pre_kernel']
+           'cfl_proj_bx3_kernel', 'cfl_grad_x3_half_pre_kernel', 'cfl_grad_x3_half_split_pre_kernel', 'cfl_grad_x3_half_w8_kernel']
     for k in hot:
         assert k in seen, (k, sorted(seen))
         assert seen[k] == 0, (k, seen[k])

@@ -912,6 +912,7 @@ def test_row_math_inside_the_gradient_launch_equals_separate_mid_launch(B, D, K,
     res = {}
     for mode in ('inside', 'separate'):
         monkeypatch.setenv('CFL_DEBUG_MIDGRAD', '1' if mode == 'inside' else '-1')
+        monkeypatch.setenv('CFL_DEBUG_GRAD_W8', '-1')     # (the two-launch form keeps the four-wave workgroups: same sums on both sides)
         H.reload_env()
         eng = PairEngine(D, L, K, weight_norm=cfg.weight_norm, has_bias=cfg.has_bias, norm=H.make_norm(1 / 8.0),
                          loss=H.make_loss(reg_const=reg), params=params, batch_size=B)

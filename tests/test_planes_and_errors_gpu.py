@@ -282,6 +282,7 @@ def test_dy_planes_written_by_mid_equal_the_in_kernel_split(style, dist, D, L, K
     try:
         for mode in ('1', '-1'):
             monkeypatch.setenv('CFL_DEBUG_DY_PRE', mode)
+            monkeypatch.setenv('CFL_DEBUG_GRAD_W8', '-1')     # (the pre-split form keeps the four-wave workgroups)
             monkeypatch.setenv('CFL_DEBUG_GRAD_HALF', '1')       # the half-tile weight gradient at every shape of this test
             H.reload_env()
             theta = H.pack_theta(sh, p, None, 0.5 if dist != 'siamese' else 40.0, 'cuda')
