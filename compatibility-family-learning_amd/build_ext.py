@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 NAMES = ('cfl_hip', 'cfl_conv', 'cfl_gan', 'cfl_eval', 'cfl_dp')
 SRCS = [os.path.join(HERE, 'csrc', n + '.hip') for n in NAMES]
 SRC = SRCS[0]
-HEADERS = [os.path.join(HERE, 'csrc', 'gemm_gather.h'), os.path.join(HERE, 'csrc', 'conv_halo.h'),
+HEADERS = [os.path.join(HERE, 'csrc', 'gemm_gather.h'), os.path.join(HERE, 'csrc', 'conv_halo.h'), os.path.join(HERE, 'csrc', 'conv_halo_wgrad.h'),
            os.path.join(os.path.dirname(HERE), 'include', 'cfl_hip.h')]
 OBJ_DIR = os.path.join(HERE, 'build')
 OUT = os.path.join(HERE, 'lib', 'libcfl_hip.so')

@@ -457,7 +457,7 @@ def conv_out_hw(conv):
 
 def conv_uses_direct_kernel(conv, product):
     """product 'fwd' / 'dx': does this shape run on the 3x3 halo-tile kernel (csrc/conv_halo.h)?"""
-    return lib().cfl_conv_uses_direct_kernel(C.byref(conv), {'fwd': 0, 'dx': 1}[product]) == 1
+    return lib().cfl_conv_uses_direct_kernel(C.byref(conv), {'fwd': 0, 'dx': 1, 'dw': 2}[product]) == 1
 
 
 def conv_workspace(conv, device):

@@ -12,6 +12,7 @@
 #include "../../include/cfl_hip.h"
 #include "gemm_gather.h"
 #include "conv_halo.h"
+#include "conv_halo_wgrad.h"
 
 extern int cfl_set_err(int code, const char *fmt, ...);
 
@@ -638,7 +639,16 @@ static int wgrad_klen(const ConvGeom &g) {
     const long long K = (long long)g.B * g.OH * g.OW;
     return gg_klen(K, wgrad_split_count(K, (long long)g.KH * g.KW * g.Ci + 4, g.Co));
 }
-static int wgrad_splits(const ConvGeom &g) { return gg_splits((long long)g.B * g.OH * g.OW, wgrad_klen(g)); }
+// 3x3 stride 1 with 32-channel multiples on both sides: the direct halo-tile kernel (conv_halo_wgrad.h) and ITS split count
+static HaloWPlan halo_wgrad_plan_of(const ConvGeom &g) {
+    if (!(g.KH == 3 && g.KW == 3 && g.S == 1)) return HaloWPlan{};
+    return halo_wgrad_plan(g.B, g.H, g.W, g.Ci, g.Co);
+}
+static int wgrad_splits(const ConvGeom &g) {
+    const HaloWPlan hw = halo_wgrad_plan_of(g);
+    if (hw.ok) return hw.splits;
+    return gg_splits((long long)g.B * g.OH * g.OW, wgrad_klen(g));
+}
 
 // workspace = [scale Co | n2 Co | pad] + one scratch region shared by the products of a call (they run one after the
 // other on the stream): the split-K slabs of the weight gradient, or the prepared filter planes + split slabs of
@@ -687,6 +697,7 @@ __global__ __launch_bounds__(256) void fc_narrow_fwd_kernel(const float *x, cons
 extern "C" int cfl_conv_uses_direct_kernel(const CflConv *c, int product) {
     ConvGeom g;
     if (make_geom(c, &g)) return -1;
+    if (product == 2) return halo_wgrad_plan_of(g).ok ? 1 : 0;
     return (product == 0 ? halo_fwd_plan(g) : halo_dx_plan(g)).ok ? 1 : 0;
 }
 
@@ -857,7 +868,10 @@ extern "C" int cfl_conv2d_wn_bwd_cached(const CflConv *c, const float *x, const 
         // M = rows + 4: the extra row block carries the bias gradient (see Im2colXT)
         const int splits = wgrad_splits(g);
         const size_t sstride = (size_t)(rows + 4) * g.Co;
-        if (vec)
+        const HaloWPlan hw = halo_wgrad_plan_of(g);
+        if (hw.ok)
+            halo_wgrad(hw, g.B, g.H, g.W, g.Ci, g.Co, x, dy, y, g.act, slab, sstride, st);
+        else if (vec)
             gemm_gather_modes<GG_VEC_MN, GG_VEC_MN>(rows + 4, g.Co, npix, wgrad_klen(g), Im2colXT{Im2colX{x, g}, rows},
                                                     DyPre{dy, y, g.Co, g.act}, StoreSlab{slab, sstride, g.Co}, st);
         else

@@ -44,6 +44,10 @@ CONV_CASES = [
     (2, 8, 8, 96, 160, 3, 1, 'lrelu', True),       # channels not multiples of the tiles (160 -> 2 x 128, 96 -> 128)
     (2, 16, 16, 32, 36, 3, 1, None, True),         # Co % 32 != 0: forward on the halo kernel, dx on the gathered GEMM
     (2, 4, 4, 256, 512, 3, 1, None, True),         # > 2^20 filter elements: row-wise (coalesced) scale / weight-norm finalisation
+    # weight gradient on the halo-tile kernel: many pixel tiles per split and several splits (batch 40 of 32x32: 320 tiles),
+    # relu slope, 3 x 2 channel blocks; an odd batch of 8x8 images with a ragged last two-image tile and several splits
+    (40, 32, 32, 96, 64, 3, 1, 'relu', True),
+    (37, 8, 8, 64, 96, 3, 1, 'lrelu', True),
 ]
 
 
@@ -65,6 +69,8 @@ def test_conv2d_wn_fwd_bwd(B, Hh, Ww, Ci, Co, K, S, act, bias):
     direct = K == 3 and S == 1 and ((Ww % 16 == 0 and Hh % 8 == 0) or (Hh, Ww) in ((4, 4), (8, 8)))
     assert H.conv_uses_direct_kernel(conv, 'fwd') == (direct and Ci % 32 == 0 and Co % 4 == 0 and Co >= 32)
     assert H.conv_uses_direct_kernel(conv, 'dx') == (direct and Co % 32 == 0 and Ci % 4 == 0 and Ci >= 32)
+    # weight gradient on the halo-tile kernel (csrc/conv_halo_wgrad.h): 32-channel multiples on both sides, not the 4x4 images
+    assert H.conv_uses_direct_kernel(conv, 'dw') == (direct and (Hh, Ww) != (4, 4) and Ci % 32 == 0 and Co % 32 == 0)
     ws = H.conv_workspace(conv, 'cuda')
     f = lambda a: torch.tensor(a, dtype=torch.float32, device='cuda').contiguous()
     dx_, dV_, dg_, db_ = None, None, None, None
