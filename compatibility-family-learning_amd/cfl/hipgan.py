@@ -14,7 +14,8 @@ EXPORTS = ('cfl_conv_transpose_workspace_bytes', 'cfl_conv2d_transpose_wn_fwd', 
            'cfl_subpixel2x_bwd', 'cfl_concat_cols', 'cfl_gather_prototype', 'cfl_bce_logits',
            'cfl_rowdist_loss', 'cfl_perturb_workspace_bytes', 'cfl_perturb', 'cfl_grad_penalty', 'cfl_copy_cols',
            'cfl_tile_concat_channels', 'cfl_tile_concat_channels_bwd', 'cfl_auc_workspace_bytes', 'cfl_auc', 'cfl_image_transform',
-           'cfl_ew_affine_clip_channels', 'cfl_conv_cache_bytes', 'cfl_conv2d_wn_fwd_cached', 'cfl_conv2d_wn_bwd_cached', 'cfl_conv2d_wn_fwd_fused')
+           'cfl_ew_affine_clip_channels', 'cfl_conv_cache_bytes', 'cfl_conv2d_wn_fwd_cached', 'cfl_conv2d_wn_bwd_cached', 'cfl_conv2d_wn_fwd_fused', 'cfl_conv2d_wn_bwd_fused',
+           'cfl_conv_bwd_takes_subpixel')
 
 EW = {None: 0, 'linear': 0, 'lrelu': 1, 'relu': 2, 'tanh': 3, 'sigmoid': 4}
 
@@ -63,6 +64,9 @@ def lib():
                                            [sz, vp, sz, C.POINTER(C.c_int32), vp])
     L.cfl_conv2d_wn_fwd_fused.argtypes = ([C.POINTER(CflConv)] + [vp] * 5 + [C.c_int32, vp, vp, sz, vp, sz,
                                                                             C.POINTER(C.c_int32), vp])
+    L.cfl_conv2d_wn_bwd_fused.argtypes = ([C.POINTER(CflConv)] + [vp] * 5 + [C.c_int32, f32] + [vp] * 5 +
+                                          [sz, vp, sz, C.POINTER(C.c_int32), vp])
+    L.cfl_conv_bwd_takes_subpixel.argtypes = [C.POINTER(CflConv)]
     for n in EXPORTS:
         if n not in ('cfl_conv_transpose_workspace_bytes', 'cfl_perturb_workspace_bytes', 'cfl_auc_workspace_bytes',
                      'cfl_conv_cache_bytes'):
@@ -131,8 +135,27 @@ def conv_fwd(conv, x, V, g, b, y, ws, transposed=False, cache=None, residual=Non
     return y
 
 
-def conv_bwd(conv, x, V, g, y, dy, ws, dx=None, dV=None, dg=None, db=None, reg_const=0.0, transposed=False, cache=None):
+def conv_bwd_takes_subpixel(conv):
+    """can conv_bwd(..., dy_subpixel=True) read dy / y in the 2x sub-pixel shuffled layout for this shape?"""
+    return lib().cfl_conv_bwd_takes_subpixel(C.byref(conv)) == 1
+
+
+def conv_bwd(conv, x, V, g, y, dy, ws, dx=None, dV=None, dg=None, db=None, reg_const=0.0, transposed=False, cache=None,
+             dy_subpixel=False):
+    """dy_subpixel: dy (and y) are [B, 2OH, 2OW, Co/4], the layout conv_fwd(subpixel=True) stores -- the un-shuffle of the
+    gradient (subpixel_bwd) folded into the dy loaders of the halo-tile kernels (only where conv_bwd_takes_subpixel())."""
     L = lib()
+    if dy_subpixel:
+        if transposed:
+            raise CflHipError('dy_subpixel: not for transposed convolutions')
+        has_cache = cache is not None and ConvCache.enabled
+        if has_cache:
+            cache.ensure(conv, dy.device)
+        _check(L.cfl_conv2d_wn_bwd_fused(C.byref(conv), _opt(x), _dev(V), _opt(g), _opt(y), _dev(dy), 1, float(reg_const),
+                                         _opt(dx), _opt(dV), _opt(dg), _opt(db), ws.data_ptr(), ws.numel() * 4,
+                                         cache.buf.data_ptr() if has_cache else None, cache.buf.numel() * 4 if has_cache else 0,
+                                         C.byref(cache.flags) if has_cache else None, _stream()))
+        return dx
     if cache is not None and not transposed and ConvCache.enabled:
         cache.ensure(conv, dy.device)
         _check(L.cfl_conv2d_wn_bwd_cached(C.byref(conv), _opt(x), _dev(V), _opt(g), _opt(y), _dev(dy), float(reg_const),

@@ -148,7 +148,7 @@ class WNLayer(object):
                    residual=residual, subpixel=subpixel)
         return y
 
-    def bwd(self, x, y, dy, ws, need_dx=True, need_dw=True, grad=None, need_db=True, act='layer'):
+    def bwd(self, x, y, dy, ws, need_dx=True, need_dw=True, grad=None, need_db=True, act='layer', dy_subpixel=False):
         """dx (or None); parameter gradients are written into `grad` (a flat buffer shaped like theta).
         `act` overrides the activation whose slope at `y` multiplies dy (a residual join's lrelu folded into the
         backward of the block's second convolution: y = the join's output).
@@ -168,22 +168,27 @@ class WNLayer(object):
         db = self.p('biases', grad) if (need_dw and need_db) else None
         side = ws.side_stream if (need_dw and not t and cache is not None and G.ConvCache.enabled
                                   and (cache.flags.value & 1)) else None      # (bit 0: the cached weight-norm scale is valid)
+        sp = dict(dy_subpixel=True) if dy_subpixel else {}      # dy / y in the shuffled layout of fwd(subpixel=True)
         if side is None:
             G.conv_bwd(d, x, self.p('V'), self.p('g'), y, dy, ws.get(d, t), dx=dx, dV=dV, dg=dg, db=db, transposed=t,
-                       cache=cache)
+                       cache=cache, **sp)
             return dx
         side.wait_stream(torch.cuda.current_stream())          # x, y, dy were produced on the main stream
         with torch.cuda.stream(side):
             G.conv_bwd(d, x, self.p('V'), self.p('g'), y, dy, ws.side_ws.get(d, t), dx=None, dV=dV, dg=dg, db=db,
-                       transposed=t, cache=cache)
+                       transposed=t, cache=cache, **sp)
         for tt in (x, y, dy):
             if tt is not None:
                 tt.record_stream(side)                          # the allocator must not recycle them under the side stream
         ws.side_used = True
         if need_dx:
             G.conv_bwd(d, x, self.p('V'), self.p('g'), y, dy, ws.get(d, t), dx=dx, dV=None, dg=None, db=None,
-                       transposed=t, cache=cache)
+                       transposed=t, cache=cache, **sp)
         return dx
+
+    def bwd_takes_subpixel(self, B, Hh, W):
+        """can bwd(..., dy_subpixel=True) be used for an input of this shape (see hipgan.conv_bwd_takes_subpixel)?"""
+        return self.kind == 'conv' and G.conv_bwd_takes_subpixel(self.desc(B, Hh, W, None))
 
 
 class Workspace(object):
@@ -249,6 +254,11 @@ class _Net(object):
 
 class Generator(_Net):
     """gan_type 'srgan' = SRGenerator, 'conv' = ConvTransposeGenerator.  Input: concat(z, c)."""
+    # CFL_GAN_FUSE_UNSHUFFLE=1: leave the un-shuffle of a sub-pixel stage's gradient to the dy loaders of the convolution below
+    # it (cfl_conv2d_wn_bwd_fused) instead of the separate pass.  Bit-identical and OPT-IN: measured 0.3-0.5 ms SLOWER per
+    # MrCGAN step (14.0-14.1 -> 14.3-14.6 ms, three alternations on one box) -- the pass it removes runs at memory speed, while
+    # the loaders of the two matrix-bound kernels then read every second pixel of the shuffled tensor and its activation too
+    fuse_unshuffle = os.environ.get('CFL_GAN_FUSE_UNSHUFFLE', '0') not in ('0', '')
 
     def __init__(self, gan_type, ae_shape, in_dim, data_type, rng, device, lr=2e-4, beta1=0.5, beta2=0.999,
                  dim=64, scope='Generator', c_dim=None, t_dim=None):
@@ -339,11 +349,19 @@ class Generator(_Net):
         N = d_acts.shape[0]
         acts = tape[-1][1]
         d = G.act_bwd(acts, d_acts, self.data_type) if self.data_type != 'linear' else d_acts
-        for item in reversed(tape[:-1]):
+        shuffled = None      # (act, s) of a sub-pixel stage whose un-shuffle is left to the dy loaders of the layer below it
+        for idx in range(len(tape) - 2, -1, -1):
+            item = tape[idx]
             if item[0] == 'subpixel':
                 _, act, s = item
                 shape = s.shape if s is not None else (N,) + self.ae_shape
-                d = G.subpixel_bwd(s, d.reshape(shape), act)
+                d = d.reshape(shape)
+                # the convolution that feeds this shuffle is the tape item in front of it
+                layer, x = tape[idx - 1][1], tape[idx - 1][2]
+                if Generator.fuse_unshuffle and layer.bwd_takes_subpixel(x.shape[0], x.shape[1], x.shape[2]):
+                    shuffled = (act, s)
+                else:
+                    d = G.subpixel_bwd(s, d, act)
             elif item[0] == 'fc_t':
                 _, c, ct = item      # d = d loss / d [z | fc_t(c)]: only the fc_t columns carry on
                 dct = torch.empty(N, self.fc_t.co, dtype=torch.float32, device=self.device)
@@ -354,7 +372,13 @@ class Generator(_Net):
                 need_dx = layer is not self.fc1 or self.fc_t is not None
                 N_, Hh, W = x.shape[0], x.shape[1], x.shape[2]
                 oh, ow = layer.out_hw(Hh, W)
-                d = layer.bwd(x, y, d.reshape(N_, oh, ow, layer.co), self.ws, need_dx=need_dx, need_dw=True, grad=self.pool.grad)
+                if shuffled is not None:
+                    # d is still [N, 2oh, 2ow, co/4]; the shuffle's activation slope (at s) is applied by the loaders too
+                    act, s = shuffled
+                    shuffled = None
+                    d = layer.bwd(x, s, d, self.ws, need_dx=need_dx, need_dw=True, grad=self.pool.grad, act=act, dy_subpixel=True)
+                else:
+                    d = layer.bwd(x, y, d.reshape(N_, oh, ow, layer.co), self.ws, need_dx=need_dx, need_dw=True, grad=self.pool.grad)
         self.ws.join()
 
 

@@ -804,9 +804,31 @@ extern "C" int cfl_conv2d_wn_bwd_cached(const CflConv *c, const float *x, const 
                                         const float *y, const float *dy, float reg_const, float *dx, float *dV,
                                         float *dg, float *db, void *workspace, size_t workspace_bytes, void *cache,
                                         size_t cache_bytes, int32_t *cache_flags, cfl_stream_t stream) {
+    return cfl_conv2d_wn_bwd_fused(c, x, V, gain, y, dy, 0, reg_const, dx, dV, dg, db, workspace, workspace_bytes, cache,
+                                   cache_bytes, cache_flags, stream);
+}
+
+// 1 when the backward of this shape can take dy (and y) 2x sub-pixel shuffled: both products on the halo-tile kernels and
+// whole 32-channel chunks per quarter
+extern "C" int cfl_conv_bwd_takes_subpixel(const CflConv *c) {
+    ConvGeom g;
+    if (make_geom(c, &g)) return -1;
+    return (g.Co % 128 == 0 && halo_dx_plan(g).ok && halo_wgrad_plan_of(g).ok) ? 1 : 0;
+}
+
+extern "C" int cfl_conv2d_wn_bwd_fused(const CflConv *c, const float *x, const float *V, const float *gain,
+                                       const float *y, const float *dy, int32_t dy_subpixel, float reg_const, float *dx,
+                                       float *dV, float *dg, float *db, void *workspace, size_t workspace_bytes, void *cache,
+                                       size_t cache_bytes, int32_t *cache_flags, cfl_stream_t stream) {
     ConvGeom g;
     int rc = make_geom(c, &g);
     if (rc) return rc;
+    if (dy_subpixel) {
+        if (cfl_conv_bwd_takes_subpixel(c) != 1 || (db && !dV))
+            return cfl_set_err(CFL_E_SHAPE, "conv bwd: a shuffled dy needs the halo-tile kernels for both products and Co %% 128 == 0 "
+                                            "(cfl_conv_bwd_takes_subpixel); un-shuffle with cfl_subpixel2x_bwd instead");
+    }
+    const int dy_cq = dy_subpixel ? g.Co / 4 : 0;
     if (!V || !dy || !workspace || (!x && dV) || (!dV && !dx)) return cfl_set_err(CFL_E_SHAPE, "NULL pointer");
     if (!y) {
         if (g.act != 0) return cfl_set_err(CFL_E_SHAPE, "conv bwd: y is required when act != 0");
@@ -830,7 +852,8 @@ extern "C" int cfl_conv2d_wn_bwd_cached(const CflConv *c, const float *x, const 
             unsigned short *planes = cache ? (unsigned short *)((char *)cache + conv_cache_planes_off(g) + conv_cache_fwd_bytes(g))
                                            : nullptr;
             const bool prep = !cache || !(*cache_flags & CFL_CONV_CACHE_PLANES_DX);
-            halo_conv(hp, g.B, g.H, g.W, g.Co, g.Ci, dy, y, g.act, V, scale, g.Ci, g.Co, 1, nullptr, 0, dx, slab, st, planes, prep);
+            halo_conv(hp, g.B, g.H, g.W, g.Co, g.Ci, dy, y, g.act, V, scale, g.Ci, g.Co, 1, nullptr, 0, dx, slab, st, planes, prep,
+                      nullptr, 0, dy_cq);
             if (cache) *cache_flags |= CFL_CONV_CACHE_PLANES_DX;
         } else if (g.S == 2 && g.H % 2 == 0 && g.W % 2 == 0) {
             // four dense sub-problems, one per parity class of the input pixel
@@ -870,7 +893,7 @@ extern "C" int cfl_conv2d_wn_bwd_cached(const CflConv *c, const float *x, const 
         const size_t sstride = (size_t)(rows + 4) * g.Co;
         const HaloWPlan hw = halo_wgrad_plan_of(g);
         if (hw.ok)
-            halo_wgrad(hw, g.B, g.H, g.W, g.Ci, g.Co, x, dy, y, g.act, slab, sstride, st);
+            halo_wgrad(hw, g.B, g.H, g.W, g.Ci, g.Co, x, dy, y, g.act, slab, sstride, st, dy_cq);
         else if (vec)
             gemm_gather_modes<GG_VEC_MN, GG_VEC_MN>(rows + 4, g.Co, npix, wgrad_klen(g), Im2colXT{Im2colX{x, g}, rows},
                                                     DyPre{dy, y, g.Co, g.act}, StoreSlab{slab, sstride, g.Co}, st);

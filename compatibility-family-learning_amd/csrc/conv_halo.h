@@ -49,6 +49,9 @@ struct HaloArgs {
     const float *bias;     // epilogue (splits == 1): out = act(acc + bias[n] [+ res]); nullptr = no bias
     const float *res;      // residual input [B, H, W, N] added before the activation (round 4: the join of a residual block as
                            // the store epilogue of its second convolution), or nullptr
+    int a_cq;              // > 0 (input gradient of a sub-pixel layer): a and ya arrive 2x sub-pixel SHUFFLED, [B, 2H, 2W, a_cq] with
+                           // a_cq = K / 4, a multiple of 32: channel k = (2 i + j) a_cq + c of pixel (h, w) is read from channel c of
+                           // pixel (2h+i, 2w+j) -- the un-shuffle pass (cfl_subpixel2x_bwd) folded into the halo loader
     int subpixel;          // 1: the result is stored 2x sub-pixel shuffled, out [B, 2H, 2W, N/4] (cfl/layers.py:212-250 is a
                            // pure index remap: channel n = (2 i + j) N/4 + c of pixel (h, w) -> channel c of pixel (2h+i, 2w+j))
     int act;               // epilogue activation (0 none, 1 lrelu, 2 relu)
@@ -175,14 +178,23 @@ __global__ __launch_bounds__(256, TN <= 64 ? 2 : 1) void conv_halo_x3_kernel(Hal
         arow[u] = hp < HP && r < HPI ? hp : -1;              // (rows HPI .. HPIP - 1 of an image are padding)
         const int b = b0 + img, iy = oy0 + hy - 1, ix = ox0 + hx - 1;
         const bool ok = arow[u] >= 0 && b < p.B && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-        aoff[u] = ok ? (unsigned)((((size_t)b * p.H + iy) * p.W + ix) * p.K + c8) : 0xffffffffu;
+        aoff[u] = !ok ? 0xffffffffu
+                  : p.a_cq ? (unsigned)((((size_t)b * 2 * p.H + 2 * iy) * (2 * p.W) + 2 * ix) * p.a_cq + c8)
+                           : (unsigned)((((size_t)b * p.H + iy) * p.W + ix) * p.K + c8);
     }
     gg_f32x4 areg[AIT][2], yreg[SLOPE ? AIT : 1][2];
     auto a_request = [&](int kc) {
+        // channel chunk kc -> offset from the item's chunk-0 address (uniform).  Shuffled source: the chunk lies in ONE quarter
+        // (a_cq % 32 == 0), i.e. one of the four sub-pixels (i, j), channels c0 .. c0 + 31 there
+        size_t coff = (size_t)kc * 32;
+        if (p.a_cq) {
+            const int n0 = kc * 32, qd = n0 / p.a_cq, c0 = n0 - qd * p.a_cq;
+            coff = (size_t)((qd >> 1) * 2 * p.W + (qd & 1)) * p.a_cq + c0;
+        }
 #pragma unroll
         for (int u = 0; u < AIT; ++u) {
             const bool ok = aoff[u] != 0xffffffffu;
-            const size_t o = ok ? (size_t)aoff[u] + (size_t)kc * 32 : (size_t)0;   // safe address, selected below
+            const size_t o = ok ? (size_t)aoff[u] + coff : (size_t)0;   // safe address, selected below
             areg[u][0] = *(const gg_f32x4 *)(p.a + o);
             areg[u][1] = *(const gg_f32x4 *)(p.a + o + 4);
             if (SLOPE) {
@@ -550,7 +562,7 @@ static inline void halo_conv(const HaloPlan &pl, int B, int H, int W, int K, int
                              int slope_act, const float *V, const float *scale, int Ci, int Co, int dgrad,
                              const float *bias, int act, float *out, void *scratch, hipStream_t st,
                              unsigned short *planes_cache = nullptr, bool need_prep = true, const float *res = nullptr,
-                             int subpixel = 0) {
+                             int subpixel = 0, int a_cq = 0) {
     unsigned short *wp = planes_cache ? planes_cache : (unsigned short *)scratch;
     float *slab = (float *)((char *)scratch + (pl.wp_bytes + 15) / 16 * 16);
     const long long prep = 9ll * pl.nchunks * pl.Npad * 4;
@@ -561,7 +573,7 @@ static inline void halo_conv(const HaloPlan &pl, int B, int H, int W, int K, int
     memset(&h, 0, sizeof(h));
     h.a = a; h.ya = (ya && slope_act != 0) ? ya : nullptr;
     h.slope_neg = slope_act == 1 ? 0.2f : 0.f; h.slope_zero = 0.f;
-    h.wp = wp; h.out = pl.splits > 1 ? slab : out; h.bias = bias; h.act = act; h.res = res; h.subpixel = subpixel;
+    h.wp = wp; h.out = pl.splits > 1 ? slab : out; h.bias = bias; h.act = act; h.res = res; h.subpixel = subpixel; h.a_cq = a_cq;
     h.B = B; h.H = H; h.W = W; h.K = K; h.N = N; h.Npad = pl.Npad;
     h.tiles_x = pl.tiles_x; h.tiles_y = pl.tiles_y; h.nchunks = pl.nchunks;
     h.chunks_per_split = pl.chunks_per_split; h.slab_stride = (size_t)B * H * W * N;

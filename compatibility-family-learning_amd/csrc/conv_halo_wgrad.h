@@ -30,6 +30,7 @@ struct HaloWArgs {
     const float *dy;       // [B, H, W, Co]
     const float *ya;       // y of the layer (slope source) or nullptr
     float slope_neg, slope_zero;
+    int dy_cq;             // > 0: dy and ya arrive 2x sub-pixel shuffled, [B, 2H, 2W, dy_cq], dy_cq = Co / 4 a multiple of 32
     float *slab;           // [splits][9 Ci + 4][Co]
     size_t slab_stride;
     int B, H, W, Ci, Co;
@@ -115,7 +116,13 @@ __global__ __launch_bounds__(256, 2) void conv_halo_wgrad_kernel(HaloWArgs p) {
         for (int u = 0; u < 2; ++u) {
             const int b = b0 + (dcode[u] >> 16), oy = oy0 + ((dcode[u] >> 8) & 255), ox = ox0 + (dcode[u] & 255);
             const bool ok = b < p.B && oy < p.H && ox < p.W;
-            const size_t o = ok ? (((size_t)b * p.H + oy) * p.W + ox) * p.Co + co0 + xoct : (size_t)0;
+            size_t o = 0;
+            if (p.dy_cq) {   // this workgroup's 32 channels lie in one quarter = one sub-pixel (i, j) of the shuffled gradient
+                const int qd = co0 / p.dy_cq, c0 = co0 - qd * p.dy_cq;
+                o = ok ? (((size_t)b * 2 * p.H + 2 * oy + (qd >> 1)) * (2 * p.W) + 2 * ox + (qd & 1)) * p.dy_cq + c0 + xoct : (size_t)0;
+            } else {
+                o = ok ? (((size_t)b * p.H + oy) * p.W + ox) * p.Co + co0 + xoct : (size_t)0;
+            }
             dreg[u][0] = *(const gg_f32x4 *)(p.dy + o); dreg[u][1] = *(const gg_f32x4 *)(p.dy + o + 4);
             okmask = ok ? (okmask | (1u << (8 + u))) : (okmask & ~(1u << (8 + u)));
             if (SLOPE) {
@@ -316,12 +323,12 @@ static inline void halo_wgrad_launch(const HaloWArgs &a, dim3 grid, hipStream_t 
 
 // slab: [splits][9 Ci + 4][Co] (rows 9 Ci + 1 .. + 3 are never read)
 static inline void halo_wgrad(const HaloWPlan &pl, int B, int H, int W, int Ci, int Co, const float *x, const float *dy,
-                              const float *ya, int slope_act, float *slab, size_t slab_stride, hipStream_t st) {
+                              const float *ya, int slope_act, float *slab, size_t slab_stride, hipStream_t st, int dy_cq = 0) {
     HaloWArgs h;
     memset(&h, 0, sizeof(h));
     h.x = x; h.dy = dy; h.ya = (ya && slope_act != 0) ? ya : nullptr;
     h.slope_neg = slope_act == 1 ? 0.2f : 0.f; h.slope_zero = 0.f;
-    h.slab = slab; h.slab_stride = slab_stride;
+    h.slab = slab; h.slab_stride = slab_stride; h.dy_cq = dy_cq;
     h.B = B; h.H = H; h.W = W; h.Ci = Ci; h.Co = Co;
     h.tiles_x = pl.tiles_x; h.tiles_y = pl.tiles_y; h.ptiles = pl.ptiles; h.tiles_per_split = pl.tiles_per_split;
     const dim3 grid(Ci / 32, Co / 32, pl.splits);

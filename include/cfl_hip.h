@@ -370,6 +370,17 @@ int cfl_conv2d_wn_bwd_cached(const CflConv *conv, const float *x, const float *V
                              const float *y, const float *dy, float reg_const, float *dx, float *dV,
                              float *dg, float *db, void *workspace, size_t workspace_bytes,
                              void *cache, size_t cache_bytes, int32_t *cache_flags, cfl_stream_t stream);
+/* The backward with the sub-pixel un-shuffle folded into its dy loaders (round 4; cache nullable as above):
+ *   dy_subpixel != 0: dy -- and y, the layer's activated output, when conv->act != 0 -- arrive 2x sub-pixel shuffled,
+ *             [B, 2 OH, 2 OW, Co/4], exactly as cfl_conv2d_wn_fwd_fused(subpixel = 1) stored y; equal bit for bit to
+ *             cfl_subpixel2x_bwd followed by the plain backward.  Only where cfl_conv_bwd_takes_subpixel() returns 1 (3x3
+ *             stride 1, both products on the halo-tile kernels, Co % 128 == 0); CFL_E_SHAPE otherwise.
+ * Reference: tf.gradients through conv2d_subpixel + activation, cfl/layers.py:212-250. */
+int cfl_conv_bwd_takes_subpixel(const CflConv *conv);
+int cfl_conv2d_wn_bwd_fused(const CflConv *conv, const float *x, const float *V, const float *g, const float *y,
+                            const float *dy, int32_t dy_subpixel, float reg_const, float *dx, float *dV, float *dg, float *db,
+                            void *workspace, size_t workspace_bytes, void *cache, size_t cache_bytes, int32_t *cache_flags,
+                            cfl_stream_t stream);
 /* The forward with two store epilogues of the MrCGAN stacks folded in (cache nullable as above):
  *   residual  dev [B,OH,OW,Co] or NULL: y = act(conv + b + residual) -- the join of a residual block
  *             (cfl/models/blocks.py:150-170: lrelu(conv_b(...) + h)) as the epilogue of its second convolution

@@ -273,3 +273,52 @@ def test_fused_store_epilogues_equal_the_separate_kernels(B, Hh, Ww, Ci, Co, K, 
     for _ in range(2):          # second call: cached scale / planes
         G.conv_fwd(fused, x, V, g, b, got, ws, cache=cache, residual=res, subpixel=True)
     assert torch.equal(got, want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('B,Hh,Ww,Ci,Co,act', [
+    (5, 8, 8, 64, 256, 'relu'),        # two-image tiles, ragged last tile, generator block shape in small
+    (3, 16, 16, 32, 128, 'relu'),      # one image per tile: one 32-channel chunk per quarter
+    (2, 16, 32, 64, 384, None),        # no activation after the shuffle (y not needed), three 32-channel chunks per quarter
+    (4, 8, 8, 32, 128, 'lrelu'),
+])
+def test_backward_with_the_unshuffle_in_the_dy_loaders_equals_the_separate_kernel(B, Hh, Ww, Ci, Co, act):
+    """cfl_conv2d_wn_bwd_fused(dy_subpixel = 1): dy and the activated output arrive 2x sub-pixel shuffled, the layout
+    cfl_conv2d_wn_fwd_fused(subpixel = 1) stores; dx, dV, dg, db must equal cfl_subpixel2x_bwd followed by the plain backward
+    BIT FOR BIT (the loaders form the same dy * act'(y) products and feed the same kernels), with and without the cache."""
+    from cfl import hipgan as G
+    rng = np.random.RandomState(5)
+    dev = 'cuda'
+    t = lambda a: torch.tensor(np.asarray(a, np.float32), device=dev)
+    x, V = t(rng.randn(B, Hh, Ww, Ci)), t(rng.randn(3, 3, Ci, Co) * 0.2)
+    g = t(1.0 + 0.3 * rng.randn(Co))
+    s = t(rng.randn(B, 2 * Hh, 2 * Ww, Co // 4))          # stands for the activated, shuffled output (only its signs matter)
+    if act == 'relu':
+        s = torch.relu(s)
+    d = t(rng.randn(B, 2 * Hh, 2 * Ww, Co // 4))
+    plain = H.make_conv(B, Hh, Ww, Ci, Co, 3, 3, 1, None)
+    fused = H.make_conv(B, Hh, Ww, Ci, Co, 3, 3, 1, act)
+    assert G.conv_bwd_takes_subpixel(fused)
+    ws = H.conv_workspace(plain, dev)
+    outs = {}
+    for mode in ('separate', 'fused', 'fused+cache'):
+        dx = torch.full((B, Hh, Ww, Ci), float('nan'), device=dev)
+        dV, dg, db = torch.full_like(V, float('nan')), torch.full_like(g, float('nan')), torch.full_like(g, float('nan'))
+        if mode == 'separate':
+            dyp = G.subpixel_bwd(s if act else None, d, act)
+            G.conv_bwd(plain, x, V, g, None, dyp, ws, dx=dx, dV=dV, dg=dg, db=db, reg_const=1e-3)
+        else:
+            cache = G.ConvCache() if mode.endswith('cache') else None
+            for _ in range(2 if cache is not None else 1):
+                G.conv_bwd(fused, x, V, g, s if act else None, d, ws, dx=dx, dV=dV, dg=dg, db=db, reg_const=1e-3, cache=cache,
+                           dy_subpixel=True)
+        outs[mode] = (dx, dV, dg, db)
+    for mode in ('fused', 'fused+cache'):
+        for got, want, name in zip(outs[mode], outs['separate'], ('dx', 'dV', 'dg', 'db')):
+            assert torch.equal(got, want), (mode, name, float((got - want).abs().max()))
+    # shapes that cannot take the shuffled layout say so
+    assert not G.conv_bwd_takes_subpixel(H.make_conv(B, 4, 4, Ci, Co, 3, 3, 1, act))
+    assert not G.conv_bwd_takes_subpixel(H.make_conv(B, Hh, Ww, Ci, 96, 3, 3, 1, act))
+    with pytest.raises(H.CflHipError):
+        G.conv_bwd(H.make_conv(B, Hh, Ww, Ci, 96, 3, 3, 1, act), x, t(rng.randn(3, 3, Ci, 96)), t(np.ones(96)), None,
+                   t(rng.randn(B, 2 * Hh, 2 * Ww, 24)), ws, dx=torch.empty_like(x), dy_subpixel=True)
