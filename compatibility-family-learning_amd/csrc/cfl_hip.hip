@@ -1297,11 +1297,16 @@ __device__ __forceinline__ void px3_unit(const Px3Args &a, const ProjJob &jb, in
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl) bf[nt][pl] = ws[(nt * 3 + pl) * 64];
-            // eight of the nine partial products, small terms first; consecutive MFMAs hit different accumulators
+            // six partial products (round 4; eight until the W planes were split round-to-nearest: with one rounded operand the
+            // dropped cross terms x_m w_l + x_l w_m + x_l w_l are zero-mean and <= 2^-22 |x w|, as in cfl_proj_bx3_kernel),
+            // small terms first; consecutive MFMAs hit different accumulators
 #define PX3_MM(LA, LB)                                                                                        \
     _Pragma("unroll") for (int mt = 0; mt < 2; ++mt) _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = \
         __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mt][LA], bf[nt][LB], acc[mt][nt], 0, 0, 0);
-            PX3_MM(2, 1) PX3_MM(1, 2) PX3_MM(1, 1) PX3_MM(2, 0) PX3_MM(0, 2) PX3_MM(1, 0) PX3_MM(0, 1) PX3_MM(0, 0)
+#ifdef CFL_PX3_EIGHT
+            PX3_MM(2, 1) PX3_MM(1, 2)
+#endif
+            PX3_MM(1, 1) PX3_MM(2, 0) PX3_MM(0, 2) PX3_MM(1, 0) PX3_MM(0, 1) PX3_MM(0, 0)
 #undef PX3_MM
             // own W pieces of step q + 1 have landed (issued at step q - 2: W(q+2), W(q+3) and 4 x quarters are younger)
             // (younger in the queue: x(q+2), W(q+2), x(q+3), W(q+3), x(q+4) = 12 loads + 2 * mine pieces)
