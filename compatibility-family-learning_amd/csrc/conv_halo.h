@@ -496,7 +496,11 @@ static inline HaloPlan halo_plan(int B, int H, int W, int K, int N) {
     static const int split_tn = [] { const char *e = getenv("CFL_DEBUG_HALO_SPLIT_TN"); return e ? atoi(e) : 0; }();
     const int tn_plan = split_tn ? pl.tn : (N >= 128 ? 128 : pl.tn);
     const long long tiles = (long long)pl.ptiles * ((N + tn_plan - 1) / tn_plan);
-    int want = (int)((512 + tiles - 1) / tiles);
+    // split-K only for launches of fewer than ~128 tiles (512 until the end of round 4: with the chains of the MrCGAN step
+    // side by side a layer no longer has to fill the chip on its own, and every split costs a slab round trip and a reduce
+    // launch -- step 13.7-13.8 -> 13.4-13.5 ms at 128, 64 and 32 alike, 13.7 without any split; CFL_DEBUG_HALO_SPLIT_WGS=<n>)
+    static const int wgs = [] { const char *e = getenv("CFL_DEBUG_HALO_SPLIT_WGS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 128; }();
+    int want = (int)((wgs + tiles - 1) / tiles);
     if (want > pl.nchunks) want = pl.nchunks;
     if (want > 32) want = 32;
     if (want < 1) want = 1;
