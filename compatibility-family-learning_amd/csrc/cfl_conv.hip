@@ -248,15 +248,25 @@ struct FilterT {   // B(k = (kh,kw,co), n = ci) = V[kh,kw,ci,co]
 // With stride 2 an input pixel (ih, iw) only meets the taps kh == (ih + pt) mod 2, kw == (iw + pl) mod 2,
 // so the plain gather multiplies 3/4 zeros.  Per parity class (ph, pw) = (ih & 1, iw & 1) the gradient is
 // a dense GEMM over the taps kh = 2 kh' + oh0, kw = 2 kw' + ow0 (K = ceil(KH/2) ceil(KW/2) Co).
+// parity class of a stride-2 input-gradient product: from the members, or from the grid (four classes stacked in z)
+struct S2Class { int ph, pw, oh0, ow0; };
+__device__ __forceinline__ S2Class s2_class(int nsp, int ph, int pw, int oh0, int ow0, int pt, int pl) {
+    if (nsp <= 0) return S2Class{ph, pw, oh0, ow0};
+    const int c = (int)blockIdx.z / nsp, h = c >> 1, w = c & 1;
+    return S2Class{h, w, (h + pt) & 1, (w + pl) & 1};
+}
 struct DyGatherS2 {   // A(m = (b, i, j), k = (kh', kw', co)), input pixel (2i + ph, 2j + pw)
-    const float *dy, *y, *scale; ConvGeom g; int ph, pw, oh0, ow0, KH2, KW2, H2, W2; gg_div dKW2, dH2, dW2;
+    const float *dy, *y, *scale; ConvGeom g; int ph_, pw_, oh0_, ow0_, KH2, KW2, H2, W2; gg_div dKW2, dH2, dW2;
+    int nsp;   // > 0: the four classes are stacked in grid z (class = blockIdx.z / nsp); 0: the class of the members
+    __device__ __forceinline__ S2Class cls() const { return s2_class(nsp, ph_, pw_, oh0_, ow0_, g.pt, g.pl); }
     __device__ bool locate(int m, int k, size_t *o, int *co) const {
         int j, t, i, b, t2, a0, a1;
         gg_divmod(m, dW2, t, j); gg_divmod(t, dH2, b, i);
         gg_divmod(k, g.dCo, t2, *co); gg_divmod(t2, dKW2, a1, a0);
-        const int kw = 2 * a0 + ow0, kh = 2 * a1 + oh0;
+        const S2Class c = cls();
+        const int kw = 2 * a0 + c.ow0, kh = 2 * a1 + c.oh0;
         if (kh >= g.KH || kw >= g.KW) return false;
-        const int nh = 2 * i + ph + g.pt - kh, nw = 2 * j + pw + g.pl - kw;   // even by construction
+        const int nh = 2 * i + c.ph + g.pt - kh, nw = 2 * j + c.pw + g.pl - kw;   // even by construction
         if (nh < 0 || nw < 0) return false;
         const int oh = nh >> 1, ow = nw >> 1;
         if (oh >= g.OH || ow >= g.OW) return false;
@@ -283,12 +293,14 @@ struct DyGatherS2 {   // A(m = (b, i, j), k = (kh', kw', co)), input pixel (2i +
     __device__ Fix fix(int m) const {
         int j, t, i, b;
         gg_divmod(m, dW2, t, j); gg_divmod(t, dH2, b, i);
-        return Fix{b * g.OH, 2 * i + ph + g.pt, 2 * j + pw + g.pl};
+        const S2Class c = cls();
+        return Fix{b * g.OH, 2 * i + c.ph + g.pt, 2 * j + c.pw + g.pl};
     }
     __device__ Str stream(int k) const {
         int co, t2, a0, a1;
         gg_divmod(k, g.dCo, t2, co); gg_divmod(t2, dKW2, a1, a0);
-        const int kw = 2 * a0 + ow0, kh = 2 * a1 + oh0;
+        const S2Class c = cls();
+        const int kw = 2 * a0 + c.ow0, kh = 2 * a1 + c.oh0;
         return Str{(kh >= g.KH || kw >= g.KW) ? -1 : kh, kw, co};
     }
     __device__ gg_f32x4 get(const Fix &a, const Str &s, bool ok) const {
@@ -306,18 +318,22 @@ struct DyGatherS2 {   // A(m = (b, i, j), k = (kh', kw', co)), input pixel (2i +
     }
 };
 struct FilterTS2 {    // B(k = (kh', kw', co), n = ci) = V[2kh'+oh0, 2kw'+ow0, ci, co]
-    const float *V; ConvGeom g; int oh0, ow0, KW2; gg_div dKW2;
+    const float *V; ConvGeom g; int oh0_, ow0_, KW2; gg_div dKW2;
+    int nsp;   // (as DyGatherS2)
+    __device__ __forceinline__ S2Class cls() const { return s2_class(nsp, 0, 0, oh0_, ow0_, g.pt, g.pl); }
     __device__ float operator()(int k, int n) const {
         int co, t2, a0, a1;
         gg_divmod(k, g.dCo, t2, co); gg_divmod(t2, dKW2, a1, a0);
-        const int kw = 2 * a0 + ow0, kh = 2 * a1 + oh0;
+        const S2Class c = cls();
+        const int kw = 2 * a0 + c.ow0, kh = 2 * a1 + c.oh0;
         if (kh >= g.KH || kw >= g.KW) return 0.f;
         return V[((size_t)(kh * g.KW + kw) * g.Ci + n) * g.Co + co];
     }
     __device__ gg_f32x4 v4(int k, int n) const {
         int co, t2, a0, a1;
         gg_divmod(k, g.dCo, t2, co); gg_divmod(t2, dKW2, a1, a0);
-        const int kw = 2 * a0 + ow0, kh = 2 * a1 + oh0;
+        const S2Class c = cls();
+        const int kw = 2 * a0 + c.ow0, kh = 2 * a1 + c.oh0;
         if (kh >= g.KH || kw >= g.KW) return (gg_f32x4){0.f, 0.f, 0.f, 0.f};
         return *(const gg_f32x4 *)(V + ((size_t)(kh * g.KW + kw) * g.Ci + n) * g.Co + co);
     }
@@ -327,7 +343,8 @@ struct FilterTS2 {    // B(k = (kh', kw', co), n = ci) = V[2kh'+oh0, 2kw'+ow0, c
     __device__ Str stream(int k) const {
         int co, t2, a0, a1;
         gg_divmod(k, g.dCo, t2, co); gg_divmod(t2, dKW2, a1, a0);
-        const int kw = 2 * a0 + ow0, kh = 2 * a1 + oh0;
+        const S2Class c = cls();
+        const int kw = 2 * a0 + c.ow0, kh = 2 * a1 + c.oh0;
         return Str{(size_t)(kh * g.KW + kw) * g.Ci * g.Co + co, kh < g.KH && kw < g.KW};
     }
     __device__ gg_f32x4 get(const Fix &a, const Str &s, bool ok) const {
@@ -338,11 +355,15 @@ struct FilterTS2 {    // B(k = (kh', kw', co), n = ci) = V[2kh'+oh0, 2kw'+ow0, c
 };
 struct StoreS2 {      // class-local pixel m = (b, i, j) -> dx[b, 2i+ph, 2j+pw, n]
     float *out; int ld, H, W, H2, W2, ph, pw; gg_div dH2, dW2;
-    __device__ void operator()(int m, int n, float v, int) const {
+    int nsp;   // > 0: launched from the stacked GEMM itself (class = z / nsp); 0: the class of the members (the reduce kernel
+               // sets them per grid row with `of_class`)
+    __device__ void operator()(int m, int n, float v, int z) const {
         int j, t, i, b;
         gg_divmod(m, dW2, t, j); gg_divmod(t, dH2, b, i);
-        out[(((size_t)b * H + 2 * i + ph) * W + 2 * j + pw) * ld + n] = v;
+        const int c = nsp > 0 ? z / nsp : 2 * ph + pw;
+        out[(((size_t)b * H + 2 * i + (c >> 1)) * W + 2 * j + (c & 1)) * ld + n] = v;
     }
+    __device__ StoreS2 of_class(int c) const { StoreS2 s = *this; s.nsp = 0; s.ph = c >> 1; s.pw = c & 1; return s; }
 };
 struct StorePlain {
     float *out; int ld;
@@ -403,12 +424,15 @@ struct StoreSlab {
 // split-K partial sums of an input-gradient GEMM -> the Store functor of the unsplit launch (4 columns per thread)
 template <class Store>
 __global__ __launch_bounds__(256) void slab_reduce_store_kernel(const float *slab, int splits, size_t stride, int M,
-                                                                int N, Store st) {
+                                                                int N, Store st0) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     const int n4 = N / 4;
     if (i >= (size_t)M * n4) return;
     const int m = (int)(i / n4), n = (int)(i - (size_t)m * n4) * 4;
-    const float *p = slab + (size_t)m * N + n;
+    // grid row = product of a stacked launch (the parity classes of a stride-2 input gradient): its slabs follow the
+    // previous product's
+    const Store st = st0.of_class((int)blockIdx.y);
+    const float *p = slab + (size_t)blockIdx.y * splits * stride + (size_t)m * N + n;
     gg_f32x4 acc = *(const gg_f32x4 *)p;
     for (int z = 1; z < splits; ++z) acc += *(const gg_f32x4 *)(p + (size_t)z * stride);
 #pragma unroll
@@ -416,13 +440,14 @@ __global__ __launch_bounds__(256) void slab_reduce_store_kernel(const float *sla
 }
 // The stride-2 input gradient of the small feature maps (4x4 ... 16x16 images, 256 ... 64 channels) has a long
 // contraction (taps/4 x Co) and few output tiles: unsplit, a few dozen workgroups walk hundreds of K steps (measured:
-// 0.47 ms for 1.7 GF at the 4x4 stage of config 5).  Splits over K for ~768 workgroups, >= 128 k per split.
+// 0.47 ms for 1.7 GF at the 4x4 stage of config 5).  Splits over K for ~768 workgroups IN THE LAUNCH (its four parity
+// classes together), >= 128 k per split.
 static int dx_s2_splits(const ConvGeom &g) {
     if (g.Ci % 4 != 0 || g.Co % 4 != 0) return 1;
     const long long M = (long long)g.B * (g.H / 2) * (g.W / 2), N = g.Ci;
     const int K2 = ((g.KH + 1) / 2) * ((g.KW + 1) / 2) * g.Co;
     const long long tiles = ((M + 63) / 64) * ((N + 63) / 64);
-    long long s = (768 + tiles - 1) / tiles;
+    long long s = (768 + 4 * tiles - 1) / (4 * tiles);
     if (s > K2 / 128) s = K2 / 128;
     if (s > 32) s = 32;
     if (s < 1) s = 1;
@@ -672,7 +697,7 @@ extern "C" size_t cfl_conv_workspace_bytes(const CflConv *c) {
     if (hd > region) region = hd;
     if (g.S == 2 && g.H % 2 == 0 && g.W % 2 == 0) {
         const int sp = dx_s2_splits(g);
-        const size_t s2 = sp > 1 ? (size_t)sp * g.B * (g.H / 2) * (g.W / 2) * g.Ci * sizeof(float) : 0;
+        const size_t s2 = sp > 1 ? (size_t)4 * sp * g.B * (g.H / 2) * (g.W / 2) * g.Ci * sizeof(float) : 0;   // four stacked classes
         if (s2 > region) region = s2;
     }
     return conv_ws_header_floats(g) * sizeof(float) + region;
@@ -859,26 +884,34 @@ extern "C" int cfl_conv2d_wn_bwd_fused(const CflConv *c, const float *x, const f
             // four dense sub-problems, one per parity class of the input pixel
             const int KH2 = (g.KH + 1) / 2, KW2 = (g.KW + 1) / 2, H2 = g.H / 2, W2 = g.W / 2;
             const int K2 = KH2 * KW2 * g.Co;
-            for (int ph = 0; ph < 2; ++ph)
-                for (int pw = 0; pw < 2; ++pw) {
-                    const int oh0 = (ph + g.pt) & 1, ow0 = (pw + g.pl) & 1;
-                    const gg_div dKW2 = gg_make_div(KW2), dH2 = gg_make_div(H2), dW2 = gg_make_div(W2);
-                    DyGatherS2 fa{dy, y, scale, g, ph, pw, oh0, ow0, KH2, KW2, H2, W2, dKW2, dH2, dW2};
-                    FilterTS2 fb{V, g, oh0, ow0, KW2, dKW2};
-                    StoreS2 fs{dx, g.Ci, g.H, g.W, H2, W2, ph, pw, dH2, dW2};
-                    const int sp = dx_s2_splits(g);
-                    if (g.Co % 4 == 0 && sp > 1) {
-                        const int M2 = g.B * H2 * W2, klen = gg_klen(K2, sp), nsp = gg_splits(K2, klen);
-                        const size_t sstride = (size_t)M2 * g.Ci;
-                        gemm_gather_modes<GG_VEC_K, GG_VEC_K>(M2, g.Ci, K2, klen, fa, fb, StoreSlab{slab, sstride, g.Ci}, st);
-                        const size_t items = (size_t)M2 * (g.Ci / 4);
-                        hipLaunchKernelGGL(slab_reduce_store_kernel<StoreS2>, dim3((unsigned)((items + 255) / 256)),
-                                           dim3(256), 0, st, slab, nsp, sstride, M2, g.Ci, fs);
-                    } else if (g.Co % 4 == 0)
-                        gemm_gather_modes<GG_VEC_K, GG_VEC_K>(g.B * H2 * W2, g.Ci, K2, gg_klen(K2, 1), fa, fb, fs, st);
-                    else
+            const gg_div dKW2 = gg_make_div(KW2), dH2 = gg_make_div(H2), dW2 = gg_make_div(W2);
+            if (g.Co % 4 == 0) {
+                // ... stacked in grid z of ONE launch (round 4: four launches + four reduce launches per call before; the
+                // functors take the class from blockIdx.z): 4x the workgroups per launch for products that are far too small
+                // to fill the chip one at a time
+                const int sp = dx_s2_splits(g);
+                const int M2 = g.B * H2 * W2, klen = gg_klen(K2, sp), nsp = gg_splits(K2, klen);
+                DyGatherS2 fa{dy, y, scale, g, 0, 0, 0, 0, KH2, KW2, H2, W2, dKW2, dH2, dW2, nsp};
+                FilterTS2 fb{V, g, 0, 0, KW2, dKW2, nsp};
+                StoreS2 fs{dx, g.Ci, g.H, g.W, H2, W2, 0, 0, dH2, dW2, nsp};
+                if (nsp > 1) {
+                    const size_t sstride = (size_t)M2 * g.Ci;
+                    gemm_gather_modes<GG_VEC_K, GG_VEC_K>(M2, g.Ci, K2, klen, fa, fb, StoreSlab{slab, sstride, g.Ci}, st, 4);
+                    const size_t items = (size_t)M2 * (g.Ci / 4);
+                    hipLaunchKernelGGL(slab_reduce_store_kernel<StoreS2>, dim3((unsigned)((items + 255) / 256), 4),
+                                       dim3(256), 0, st, slab, nsp, sstride, M2, g.Ci, fs);
+                } else
+                    gemm_gather_modes<GG_VEC_K, GG_VEC_K>(M2, g.Ci, K2, klen, fa, fb, fs, st, 4);
+            } else {
+                for (int ph = 0; ph < 2; ++ph)
+                    for (int pw = 0; pw < 2; ++pw) {
+                        const int oh0 = (ph + g.pt) & 1, ow0 = (pw + g.pl) & 1;
+                        DyGatherS2 fa{dy, y, scale, g, ph, pw, oh0, ow0, KH2, KW2, H2, W2, dKW2, dH2, dW2, 0};
+                        FilterTS2 fb{V, g, oh0, ow0, KW2, dKW2, 0};
+                        StoreS2 fs{dx, g.Ci, g.H, g.W, H2, W2, ph, pw, dH2, dW2, 0};
                         gemm_gather(g.B * H2 * W2, g.Ci, K2, gg_klen(K2, 1), fa, fb, fs, st);
-                }
+                    }
+            }
         } else if (g.Co % 4 == 0)
             gemm_gather_modes<GG_VEC_K, GG_VEC_K>(g.B * g.H * g.W, g.Ci, g.KH * g.KW * g.Co,
                                                   gg_klen(g.KH * g.KW * g.Co, 1), DyGather{dy, y, scale, g},

@@ -64,7 +64,10 @@ __global__ __launch_bounds__(256) void gemm_gather_kernel(int M, int N, int K, i
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r16 = lane & 15, q = lane >> 4;
     const int m0 = blockIdx.x * TM, n0 = blockIdx.y * TN;
-    const int kbeg = blockIdx.z * klen, kend = min(K, kbeg + klen);
+    // blockIdx.z = batch * splits + split (batch > 0 only for launches that stack independent products in z: the four
+    // parity classes of a stride-2 input gradient, whose functors read the class from blockIdx.z themselves)
+    const int zsp = (int)blockIdx.z % ((K + klen - 1) / klen);
+    const int kbeg = zsp * klen, kend = min(K, kbeg + klen);
     const int lm = tid >> 2, lk = (tid & 3) * 4;    // scalar / vec-k staging: 4 k's of one row / column
     const int tk = tid >> 4, tm = (tid & 15) * 4;   // vec-mn staging of A: one k, 4 rows (per 64-row pass)
     const int bk = tid / (TN / 4), bn = (tid % (TN / 4)) * 4;   // vec-mn staging of B (threads < 4 TN)
@@ -251,7 +254,10 @@ __global__ __launch_bounds__(256) void gemm_gather_x3_kernel(int M, int N, int K
     const int wm = wave / WN, wn = wave % WN;
     const int r16 = lane & 15, q = lane >> 4;
     const int m0 = blockIdx.x * TM, n0 = blockIdx.y * TN;
-    const int kbeg = blockIdx.z * klen, kend = min(K, kbeg + klen);
+    // blockIdx.z = batch * splits + split (batch > 0 only for launches that stack independent products in z: the four
+    // parity classes of a stride-2 input gradient, whose functors read the class from blockIdx.z themselves)
+    const int zsp = (int)blockIdx.z % ((K + klen - 1) / klen);
+    const int kbeg = zsp * klen, kend = min(K, kbeg + klen);
     // staging work items (8 values each), 64 rows / columns x 32 k per pass:
     //   VEC_K : one row / column, 8 consecutive k (two 16-byte gathers)          -> one b128 store per plane
     //   VEC_MN: 4 consecutive rows / columns at k and at k+1 (two 16-byte gathers) -> two b64 stores per plane
@@ -415,8 +421,9 @@ static inline int gg_splits(long long K, int klen) { return (int)((K + klen - 1)
 
 template <int AMODE, int BMODE, class LoadA, class LoadB, class Store>
 static inline void gemm_gather_modes(int M, int N, int K, int klen, LoadA la, LoadB lb, Store st,
-                                     hipStream_t stream) {
-    const int splits = gg_splits(K, klen);
+                                     hipStream_t stream, int zbatch = 1) {
+    const int nsp = gg_splits(K, klen);
+    const int splits = nsp * zbatch;      // grid z (tile choice below: as many workgroups)
     if constexpr (AMODE != GG_SCALAR && BMODE != GG_SCALAR) {
         if (gg_use_x3()) {
             if (N <= 16) {
