@@ -61,6 +61,15 @@ def test_subpixel_concat_gather():
     CO.conv2d_subpixel(xt, 2, 'relu').backward(torch.tensor(dy, dtype=torch.float64))
     dx = G.subpixel_bwd(y, _dev(dy), 'relu')
     assert np.array_equal(dx.cpu().numpy(), xt.grad.numpy().astype(np.float32))
+    # C % 16 == 0: the four-channels-per-thread form of the backward (with and without an activation)
+    for act in ('relu', None):
+        x = rng.randn(3, 4, 6, 48).astype(np.float32)
+        xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+        yt = CO.conv2d_subpixel(xt, 2, act)
+        dy = rng.randn(*yt.shape).astype(np.float32)
+        yt.backward(torch.tensor(dy, dtype=torch.float64))
+        dx = G.subpixel_bwd(_dev(yt.detach().numpy().astype(np.float32)) if act else None, _dev(dy), act)
+        assert np.array_equal(dx.cpu().numpy(), xt.grad.numpy().astype(np.float32))
     a, b = rng.randn(7, 3).astype(np.float32), rng.randn(7, 5).astype(np.float32)
     assert np.array_equal(G.concat_cols(_dev(a), _dev(b)).cpu().numpy(), np.concatenate([a, b], 1))
     P = rng.randn(6, 3, 4).astype(np.float32)
