@@ -564,6 +564,9 @@ class Discriminator(_Net):
         ws = self.ws if ws is None else ws
         ones = torch.ones(n, 1, dtype=torch.float32, device=self.device)
         rec = []
+        # entries no product below writes (biases: they drop out of the penalty; the latent head; fc_t) must read zero: ONE fill
+        # of the flat buffer in front of everything instead of a fill per bias vector behind it (25 launches per step)
+        grad.zero_()
         u0 = self.backward(tapef, lo, hi, ones, None, True, False, record=rec, ws=ws)
         v = G.grad_penalty(u0.contiguous(), lambda_gp, loss_out, need_v=True)
         # rec was filled from the head back to the input; walk it in forward order
@@ -592,10 +595,4 @@ class Discriminator(_Net):
                 v = G.act_bwd(out[lo:hi], v2, 'lrelu')
         dy = next(it)
         self.disc_head.bwd(v.reshape(n, 1, 1, self.feat), None, dy, ws, False, True, grad, need_db=False)
-        for layer_bias in [nme for nme in self.pool.order if nme.endswith('/biases')]:
-            self.pool.view(layer_bias, grad).zero_()
         ws.join()
-        for w in ('V', 'g'):
-            self.lat_head.p(w, grad).zero_()
-            if self.fc_t is not None:
-                self.fc_t.p(w, grad).zero_()
