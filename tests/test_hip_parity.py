@@ -215,6 +215,9 @@ def test_step_fwd_bwd(style, dist, D, L, K, act, B, nv, lkw, directed):
             json.dump(doc, f, indent=1, sort_keys=True)
         return
     caps = _grad_caps()
+    fuzz_cap = os.environ.get('CFL_FUZZ_GRAD_CAP')     # tools/fuzz_parity.py: random shapes have no record; one generous fp32-level cap
+    if cid not in caps and fuzz_cap:
+        caps = {cid: {'worst': 0.5 * float(fuzz_cap)}}
     assert cid in caps, 'no recorded gradient error for %s: run with CFL_RECORD_GRAD_ERRORS=%s' % (cid, GRAD_ERR_FILE)
     cap = max(2.0 * caps[cid]['worst'], GRAD_FLOOR)
     for k, e in observed.items():

@@ -6,6 +6,9 @@ import os, sys, traceback
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, 'compatibility-family-learning_amd')]
 import numpy as np
+# random shapes have no recorded gradient error (tests/test_hip_parity.py): one cap.  1e-5 of a tensor's scale: the worst seen so far is
+# 4.7e-6 (D=1024 L=78 K=3 B=2: dL/dy itself is that far from float64 -- CFL_EXACT_FP32=1 gives 4.6e-6 -- two rows, exp / log chains)
+os.environ.setdefault('CFL_FUZZ_GRAD_CAP', '1e-5')
 import tests.test_hip_parity as T
 import __graft_entry__ as g
 g.build()
