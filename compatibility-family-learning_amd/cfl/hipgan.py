@@ -15,7 +15,7 @@ EXPORTS = ('cfl_conv_transpose_workspace_bytes', 'cfl_conv2d_transpose_wn_fwd', 
            'cfl_rowdist_loss', 'cfl_perturb_workspace_bytes', 'cfl_perturb', 'cfl_grad_penalty', 'cfl_copy_cols',
            'cfl_tile_concat_channels', 'cfl_tile_concat_channels_bwd', 'cfl_auc_workspace_bytes', 'cfl_auc', 'cfl_image_transform',
            'cfl_ew_affine_clip_channels', 'cfl_conv_cache_bytes', 'cfl_conv2d_wn_fwd_cached', 'cfl_conv2d_wn_bwd_cached', 'cfl_conv2d_wn_fwd_fused', 'cfl_conv2d_wn_bwd_fused',
-           'cfl_conv_bwd_takes_subpixel')
+           'cfl_conv_bwd_takes_subpixel', 'cfl_conv_prepare_cached')
 
 EW = {None: 0, 'linear': 0, 'lrelu': 1, 'relu': 2, 'tanh': 3, 'sigmoid': 4}
 
@@ -67,6 +67,7 @@ def lib():
     L.cfl_conv2d_wn_bwd_fused.argtypes = ([C.POINTER(CflConv)] + [vp] * 5 + [C.c_int32, f32] + [vp] * 5 +
                                           [sz, vp, sz, C.POINTER(C.c_int32), vp])
     L.cfl_conv_bwd_takes_subpixel.argtypes = [C.POINTER(CflConv)]
+    L.cfl_conv_prepare_cached.argtypes = [C.POINTER(CflConv), vp, vp, vp, sz, C.POINTER(C.c_int32), vp]
     for n in EXPORTS:
         if n not in ('cfl_conv_transpose_workspace_bytes', 'cfl_perturb_workspace_bytes', 'cfl_auc_workspace_bytes',
                      'cfl_conv_cache_bytes'):
@@ -133,6 +134,15 @@ def conv_fwd(conv, x, V, g, b, y, ws, transposed=False, cache=None, residual=Non
     fn = L.cfl_conv2d_transpose_wn_fwd if transposed else L.cfl_conv2d_wn_fwd
     _check(fn(C.byref(conv), _dev(x), _dev(V), _opt(g), _opt(b), _dev(y), ws.data_ptr(), ws.numel() * 4, _stream()))
     return y
+
+
+def conv_prepare(conv, V, g, cache):
+    """rebuild what is missing in a layer's cache (weight-norm scale, filter planes) without running the layer"""
+    if cache is None or not ConvCache.enabled:
+        return
+    cache.ensure(conv, V.device)
+    _check(lib().cfl_conv_prepare_cached(C.byref(conv), _dev(V), _opt(g), cache.buf.data_ptr(), cache.buf.numel() * 4,
+                                         C.byref(cache.flags), _stream()))
 
 
 def conv_bwd_takes_subpixel(conv):

@@ -49,6 +49,7 @@ class ParamPool(object):
         self.total = 0
         self.theta = None
         self.version = 0     # bumped whenever theta changes (Adam, load): per-layer weight caches key on it
+        self.layers = []     # the WNLayers whose variables live here (cache preparation behind the optimizer step)
 
     def add(self, name, value):
         value = np.asarray(value, np.float32)
@@ -110,6 +111,8 @@ class WNLayer(object):
         # layer sees per step and rebuilt when the pool's version moves (include/cfl_hip.h: cfl_conv2d_wn_*_cached)
         self._cache = G.ConvCache() if kind != 'convt' else None
         self._cache_version = -1
+        self._prep_desc = None       # shape of the layer's first forward call: what `prepare` rebuilds the cache for
+        pool.layers.append(self)
 
     def cache(self):
         if self._cache is not None and self._cache_version != self.pool.version:
@@ -119,6 +122,11 @@ class WNLayer(object):
 
     def p(self, what, base=None):
         return self.pool.view(self.scope + '/' + what, base)
+
+    def prepare(self):
+        """rebuild the cache (scale, filter planes) for the current weights on the current stream, without running the layer"""
+        if self._cache is not None and self._prep_desc is not None:
+            G.conv_prepare(self._prep_desc, self.p('V'), self.p('g'), self.cache())
 
     def desc(self, B, Hh, W, act):
         key = (B, Hh, W, act)
@@ -140,6 +148,8 @@ class WNLayer(object):
         act = self.act if act == 'layer' else act
         B, Hh, W, _ = x.shape
         d = self.desc(B, Hh, W, act)
+        if self._prep_desc is None:
+            self._prep_desc = d
         t = self.kind == 'convt'
         oh, ow = self.out_hw(Hh, W)
         shape = (B, 2 * oh, 2 * ow, self.co // 4) if subpixel else (B, oh, ow, self.co)
@@ -232,10 +242,33 @@ class _Net(object):
         return float(np.float32(self.lr) * np.sqrt(np.float32(1) - self.beta2_power) /
                      (np.float32(1) - self.beta1_power))
 
+    # CFL_GAN_PREP_AHEAD=0: leave every layer's cache to its first convolution of the next step (A/B runs)
+    prep_ahead = os.environ.get('CFL_GAN_PREP_AHEAD', '1') not in ('0', '')
+
+    def prepare_caches(self):
+        """Right behind the optimizer step: rebuild every layer's weight-norm scale and filter planes on a side stream, so
+        that the next step's forward chains do not carry ~3 small launches in front of every layer's first convolution
+        (`join_prepare` orders the side stream back in front of the first use)."""
+        if not (_Net.prep_ahead and Workspace.overlap and G.ConvCache.enabled):
+            return
+        if not hasattr(self, '_prep_stream'):
+            self._prep_stream = torch.cuda.Stream(device=self.device)
+        self._prep_stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self._prep_stream):
+            for layer in self.pool.layers:
+                layer.prepare()
+        self._prep_pending = True
+
+    def join_prepare(self):
+        if getattr(self, '_prep_pending', False):
+            torch.cuda.current_stream().wait_stream(self._prep_stream)
+            self._prep_pending = False
+
     def adam(self):
         p = self.pool
         H.adam_tf(p.theta, p.m, p.v, p.grad, self.lr_t(), self.beta1, self.beta2, self.eps)
         p.touch()
+        self.prepare_caches()
         self.beta1_power = np.float32(self.beta1_power * np.float32(self.beta1))
         self.beta2_power = np.float32(self.beta2_power * np.float32(self.beta2))
 
@@ -304,6 +337,7 @@ class Generator(_Net):
 
     def forward(self, zc):
         """zc [N, z_dim + c_dim] -> (activations [N, prod(ae_shape)], tape)."""
+        self.join_prepare()
         N = zc.shape[0]
         tape = []
         if self.fc_t is not None:
@@ -447,6 +481,7 @@ class Discriminator(_Net):
 
     # tape entries: ('conv', layer, x, y) | ('res', a, b, h, r1, r2, out) | ('tcat', C1, t_in, t_out)
     def forward(self, x_flat, t=None):
+        self.join_prepare()
         N = x_flat.shape[0]
         tape = []
         h = x_flat.view((N,) + self.ae_shape)

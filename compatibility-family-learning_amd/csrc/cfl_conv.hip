@@ -804,6 +804,39 @@ extern "C" int cfl_conv2d_wn_fwd_fused(const CflConv *c, const float *x, const f
     return hipGetLastError() == hipSuccess ? CFL_OK : cfl_set_err(CFL_E_HIP, "conv fwd launch failed");
 }
 
+// Everything of a layer's cache that is missing, WITHOUT running the layer: the weight-norm scale and the filter planes of
+// the forward / input-gradient halo kernels (for the products that take them at this call shape).  Lets a caller rebuild the
+// caches of all layers right behind the optimizer step, on a side stream, instead of in front of every layer's first
+// convolution of the next step (MrCGAN: ~70 launches of 5 us on the forward chains).
+extern "C" int cfl_conv_prepare_cached(const CflConv *c, const float *V, const float *gain, void *cache, size_t cache_bytes,
+                                       int32_t *cache_flags, cfl_stream_t stream) {
+    ConvGeom g;
+    int rc = make_geom(c, &g);
+    if (rc) return rc;
+    if (!V || !cache || !cache_flags) return cfl_set_err(CFL_E_SHAPE, "NULL pointer");
+    if (cache_bytes < cfl_conv_cache_bytes(c) || ((uintptr_t)cache & 15))
+        return cfl_set_err(CFL_E_WORKSPACE, "conv cache too small / misaligned");
+    hipStream_t st = (hipStream_t)stream;
+    float *scale, *n2;
+    conv_scale_of(g, V, gain, cache, cache, cache_flags, &scale, &n2, st);
+    if (!(*cache_flags & CFL_CONV_CACHE_PLANES_FWD)) {
+        const HaloPlan hp = halo_fwd_plan(g);
+        if (hp.ok) {
+            halo_prep_planes(hp, g.Ci, g.Co, V, scale, g.Ci, g.Co, 0, (unsigned short *)((char *)cache + conv_cache_planes_off(g)), st);
+            *cache_flags |= CFL_CONV_CACHE_PLANES_FWD;
+        }
+    }
+    if (!(*cache_flags & CFL_CONV_CACHE_PLANES_DX)) {
+        const HaloPlan hd = halo_dx_plan(g);
+        if (hd.ok) {
+            halo_prep_planes(hd, g.Co, g.Ci, V, scale, g.Ci, g.Co, 1,
+                             (unsigned short *)((char *)cache + conv_cache_planes_off(g) + conv_cache_fwd_bytes(g)), st);
+            *cache_flags |= CFL_CONV_CACHE_PLANES_DX;
+        }
+    }
+    return hipGetLastError() == hipSuccess ? CFL_OK : cfl_set_err(CFL_E_HIP, "conv prepare launch failed");
+}
+
 extern "C" int cfl_conv2d_wn_fwd_cached(const CflConv *c, const float *x, const float *V, const float *gain,
                                         const float *bias, float *y, void *workspace, size_t workspace_bytes,
                                         void *cache, size_t cache_bytes, int32_t *cache_flags, cfl_stream_t stream) {

@@ -370,6 +370,12 @@ int cfl_conv2d_wn_bwd_cached(const CflConv *conv, const float *x, const float *V
                              const float *y, const float *dy, float reg_const, float *dx, float *dV,
                              float *dg, float *db, void *workspace, size_t workspace_bytes,
                              void *cache, size_t cache_bytes, int32_t *cache_flags, cfl_stream_t stream);
+/* Rebuild whatever of a layer's cache is not valid -- weight-norm scale, forward / input-gradient filter planes for the
+ * products that take the halo kernel at this call shape -- without running the layer (e.g. for all layers right behind the
+ * optimizer step, on a side stream).  The planes are laid out from the channel counts alone, so a cache prepared with one
+ * batch size serves calls with another. */
+int cfl_conv_prepare_cached(const CflConv *conv, const float *V, const float *g, void *cache, size_t cache_bytes,
+                            int32_t *cache_flags, cfl_stream_t stream);
 /* The backward with the sub-pixel un-shuffle folded into its dy loaders (round 4; cache nullable as above):
  *   dy_subpixel != 0: dy -- and y, the layer's activated output, when conv->act != 0 -- arrive 2x sub-pixel shuffled,
  *             [B, 2 OH, 2 OW, Co/4], exactly as cfl_conv2d_wn_fwd_fused(subpixel = 1) stored y; equal bit for bit to
