@@ -257,12 +257,14 @@ class _Net(object):
         with torch.cuda.stream(self._prep_stream):
             for layer in self.pool.layers:
                 layer.prepare()
-        self._prep_pending = True
+            self._prep_event = torch.cuda.Event()
+            self._prep_event.record()
 
     def join_prepare(self):
-        if getattr(self, '_prep_pending', False):
-            torch.cuda.current_stream().wait_stream(self._prep_stream)
-            self._prep_pending = False
+        """every entry point that reads a layer's cache waits -- on whatever stream it runs -- for the last preparation"""
+        ev = getattr(self, '_prep_event', None)
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
 
     def adam(self):
         p = self.pool
@@ -380,6 +382,7 @@ class Generator(_Net):
 
     def backward(self, tape, d_acts):
         """Writes d g_total / d generator variables into pool.grad (d_acts = d g_total / d activations)."""
+        self.join_prepare()     # (a no-op after a forward; a backward over an old tape right behind an optimizer step must wait too)
         N = d_acts.shape[0]
         acts = tape[-1][1]
         d = G.act_bwd(acts, d_acts, self.data_type) if self.data_type != 'linear' else d_acts
@@ -527,6 +530,7 @@ class Discriminator(_Net):
         may be None).  Returns d/d input rows [n, prod(ae_shape)] when need_dx.  `record`, when a
         list, receives the upstream gradient of every layer (for `gp_grads`).  `ws`: the workspace to use (a chain's own
         when several backward passes of this network run on different streams)."""
+        self.join_prepare()
         tape, f = tapef
         n = hi - lo
         ws = self.ws if ws is None else ws
