@@ -69,6 +69,7 @@ def parse():
     ap.add_argument('--no-kernel-profile', action='store_true')
     ap.add_argument('--no-cli-loop', action='store_true')
     ap.add_argument('--no-other-configs', action='store_true')
+    ap.add_argument('--no-dp-form', action='store_true', help='skip the one-rank RCCL leg (dp_form)')
     ap.add_argument('--cli-items', type=int, default=40000, help='items of the synthetic features.b of the cli_loop leg')
     ap.add_argument('--cli-pairs', type=int, default=200000)
     return ap.parse_args()
@@ -438,6 +439,88 @@ def cli_loop(args, device):
         shutil.rmtree(root, ignore_errors=True)
 
 
+def dp_form(args, eng, pool, device, fused_us):
+    """The DATA-PARALLEL form of the step on this one GPU, through a ONE-RANK RCCL process group (CFL_FORCE_DP=1): the
+    same three launches as the fused step (projection on the bf16 matrix cores from the kept planes, row math, weight
+    gradient emitting the flat gradient), then `all_reduce([gradient | scalars])` on the launch stream and the stand-alone
+    TF-Adam that re-writes the planes.  What a rank of an N-GPU job executes per step, minus the wire time: the one-GPU
+    cost of data parallelism (extra launches + RCCL's fixed cost), measured every round on the hardware the driver has."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from cfl import hipabi as H
+    own_group = not dist.is_initialized()
+    os.environ['CFL_FORCE_DP'] = '1'
+    try:
+        if own_group:
+            with socket.socket() as s:
+                s.bind(('127.0.0.1', 0))
+                port = s.getsockname()[1]
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+            os.environ['MASTER_PORT'] = str(port)
+            dist.init_process_group('nccl', rank=0, world_size=1, device_id=device)
+        nb = len(pool)
+        for i in range(50):
+            eng.step(pool[i % nb])
+        torch.cuda.synchronize()
+        ts = []
+        for r in range(20):
+            t0 = time.perf_counter()
+            for i in range(args.steps):
+                eng.step(pool[(r * args.steps + i) % nb])
+            torch.cuda.synchronize()
+            ts.append((time.perf_counter() - t0) / args.steps)
+        t = float(np.median(ts))
+        from cfl import engine as E
+        # the same step with the collective issued through torch.distributed (ProcessGroupNCCL's own stream + two events)
+        os.environ['CFL_DP_ALLREDUCE'] = 'torch'
+        try:
+            for i in range(20):
+                eng.step(pool[i % nb])
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(5 * args.steps):
+                eng.step(pool[i % nb])
+            torch.cuda.synchronize()
+            t_torch = (time.perf_counter() - t0) / (5 * args.steps)
+        finally:
+            os.environ.pop('CFL_DP_ALLREDUCE', None)
+        # without the collective: the same launches, no RCCL kernel between them
+        eng_reduce = None
+        eng_reduce, E.reduce_gradients = E.reduce_gradients, (lambda buf: 1.0)
+        try:
+            for i in range(20):
+                eng.step(pool[i % nb])
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(5 * args.steps):
+                eng.step(pool[i % nb])
+            torch.cuda.synchronize()
+            t_nocoll = (time.perf_counter() - t0) / (5 * args.steps)
+        finally:
+            E.reduce_gradients = eng_reduce
+        H.profile_enable(True)
+        for i in range(50):
+            eng.step(pool[i % nb])
+        torch.cuda.synchronize()
+        H.profile_enable(False)
+        prof = H.profile_read()
+        return {'us_per_step': round(t * 1e6, 3), 'us_per_step_without_collective': round(t_nocoll * 1e6, 3),
+                'us_per_step_torch_all_reduce': round(t_torch * 1e6, 3),
+                'fused_us_per_step': round(fused_us, 3), 'vs_fused': round(fused_us / (t * 1e6), 4),
+                'library_launches_per_step': sorted(prof), 'backend': dist.get_backend(), 'world': dist.get_world_size(),
+                'exchange': os.environ.get('CFL_DP_EXCHANGE', 'allreduce'),
+                'what': 'PairEngine.step through its data-parallel branch on a one-rank RCCL group: proj_bx3 -> mid -> grad '
+                        '-> ncclAllReduce([gradient | scalars], %d floats, on the launch stream: cfl/rccl.py) -> '
+                        'cfl_adam_tf_planes' % eng.gradbuf.numel()}
+    finally:
+        os.environ['CFL_FORCE_DP'] = '0'
+        if own_group and dist.is_initialized():
+            from cfl import rccl
+            rccl.shutdown()
+            dist.destroy_process_group()
+
+
 def _trace(msg):
     if os.environ.get('CFL_BENCH_TRACE'):
         print('[bench rank %s] %s' % (os.environ.get('RANK', '0'), msg), file=sys.stderr, flush=True)
@@ -447,6 +530,12 @@ def main():
     args = parse()
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         return launch_ranks(args)
+
+    # ONE JSON line on stdout, whatever the libraries below print there (RCCL writes its version banner to stdout when a
+    # communicator is created): keep the real stdout aside and point fd 1 at stderr for the rest of the run
+    real_stdout = os.dup(1)
+    sys.stdout.flush()
+    os.dup2(2, 1)
 
     import numpy as np
     import torch
@@ -674,6 +763,11 @@ def main():
             out['cpu_baseline'] = cpu_baseline(args, args.cpu_seconds)
         else:
             out['cpu_baseline'] = None
+        if not args.no_dp_form:
+            try:
+                out['dp_form'] = dp_form(args, eng, pool, device, 1e6 * elapsed / args.steps)
+            except Exception as e:          # a side measurement must not take the headline line down
+                out['dp_form'] = {'error': repr(e)}
         if not args.no_other_configs and not args.no_kernel_profile:
             pool.clear()
             torch.cuda.empty_cache()
@@ -688,9 +782,12 @@ def main():
     elif rank == 0:
         out['cpu_baseline'] = None
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + '\n').encode())
     if world > 1:
         dist.barrier()
+        from cfl import rccl
+        rccl.shutdown()
         dist.destroy_process_group()
     return 0
 

@@ -11,8 +11,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 NAMES = ('cfl_hip', 'cfl_conv', 'cfl_gan', 'cfl_eval', 'cfl_dp')
 SRCS = [os.path.join(HERE, 'csrc', n + '.hip') for n in NAMES]
 SRC = SRCS[0]
-HEADERS = [os.path.join(HERE, 'csrc', 'gemm_gather.h'), os.path.join(HERE, 'csrc', 'conv_halo.h'), os.path.join(HERE, 'csrc', 'conv_halo_wgrad.h'),
-           os.path.join(os.path.dirname(HERE), 'include', 'cfl_hip.h')]
+HEADERS = [os.path.join(HERE, 'csrc', h) for h in ('gemm_gather.h', 'conv_halo.h', 'conv_halo_wgrad.h', 'theta_planes.h')] + \
+          [os.path.join(os.path.dirname(HERE), 'include', 'cfl_hip.h')]
 OBJ_DIR = os.path.join(HERE, 'build')
 OUT = os.path.join(HERE, 'lib', 'libcfl_hip.so')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
@@ -27,10 +27,21 @@ def build(force=False, verbose=False):
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
     os.makedirs(OBJ_DIR, exist_ok=True)
     extra = [f for f in os.environ.get('CFL_HIPCC_FLAGS', '').split() if f]
+    # the objects of a build with extra flags (-DCFL_STAMPS, ablations) must never be mistaken for production objects by a
+    # later plain build: the flags of the last build are recorded beside the objects, a mismatch makes every object stale
+    stamp = os.path.join(OBJ_DIR, 'flags.txt')
+    flags_now = ' '.join(FLAGS + extra)
+    try:
+        with open(stamp) as f:
+            same_flags = f.read() == flags_now
+    except OSError:
+        same_flags = False
+    if not same_flags:
+        force = True
     jobs = []
     for src, name in zip(SRCS, NAMES):
         obj = os.path.join(OBJ_DIR, name + '.o')
-        if force or extra or _stale(obj, [src] + HEADERS + [os.path.abspath(__file__)]):
+        if force or _stale(obj, [src] + HEADERS + [os.path.abspath(__file__)]):
             cmd = [HIPCC] + FLAGS + extra + ['-c', src, '-o', obj]
             if verbose:
                 cmd.insert(1, '-Rpass-analysis=kernel-resource-usage')
@@ -40,6 +51,8 @@ def build(force=False, verbose=False):
             for rc, cmd in zip(ex.map(subprocess.call, jobs), jobs):
                 if rc:
                     raise subprocess.CalledProcessError(rc, cmd)
+    with open(stamp, 'w') as f:
+        f.write(flags_now)
     objs = [os.path.join(OBJ_DIR, n + '.o') for n in NAMES]
     if jobs or _stale(OUT, objs):
         subprocess.check_call([HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC'] + objs + ['-o', OUT])

@@ -102,6 +102,9 @@ class OneShotExchange(object):
         dist.barrier()                   # nobody pushes before everyone has mapped everyone
         self.step = 0
         self.m_v_sharded = self.world > 1
+        # True between a step and the next sync_optimizer_state(): this rank's m / v are current for its own slice only,
+        # and a checkpoint written now would carry stale slots for (world - 1) / world of the parameters
+        self.slots_dirty = False
 
     # -- addresses -------------------------------------------------------------------------------------------------
     def _slot_row(self, base, par, row):
@@ -134,10 +137,14 @@ class OneShotExchange(object):
                                   self.n, self.n_adam, self.slice, engine.gradbuf.data_ptr(), stages, flags_b, float(lr_t),
                                   float(engine.beta1), float(engine.beta2), float(engine.eps), gen, self.lost.data_ptr(),
                                   self.timeout_s, self.ticket[1:].data_ptr(), st))
-        H._check(L.cfl_dp_rs_gather(engine.theta.data_ptr(), engine.gradbuf.data_ptr(), self._stage(self.base, par),
-                                    self._flag(self.base, self.o_flags_b, par, 0), W, me, self.n, self.n_adam, self.slice,
-                                    gen, self.lost.data_ptr(), self.timeout_s, st))
+        # (the gather also writes the kept bf16 planes of every weight -- peers' slices as it copies them, the own slice as
+        # it passes over it -- so the next projection runs from current planes, as after the fused single-GPU step)
+        H._check(L.cfl_dp_rs_gather_planes(C.byref(engine.shape), engine.theta.data_ptr(), engine.gradbuf.data_ptr(),
+                                           self._stage(self.base, par), self._flag(self.base, self.o_flags_b, par, 0), W, me,
+                                           self.n, self.n_adam, self.slice, gen, self.lost.data_ptr(), self.timeout_s,
+                                           H._planes(engine.planes), st))
         self.step += 1
+        self.slots_dirty = self.m_v_sharded
         return 1.0 / W
 
     def owned(self):
@@ -146,7 +153,10 @@ class OneShotExchange(object):
 
     def sync_optimizer_state(self, engine):
         """COLLECTIVE: make m and v complete on every rank (each rank owns a slice).  Called by every rank before the
-        chief writes a checkpoint."""
+        chief writes a checkpoint.  A no-op when no step was taken since the last call (the flag is the same on every
+        rank: steps are collective)."""
+        if not self.slots_dirty:
+            return
         for t in (engine.m, engine.v):
             pad = torch.zeros(self.world * self.slice, dtype=torch.float32, device=t.device)
             lo, hi = self.owned()
@@ -159,6 +169,7 @@ class OneShotExchange(object):
             else:
                 dist.all_gather_into_tensor(pad, mine)
             t.copy_(pad[:t.numel()])
+        self.slots_dirty = False
 
     def check(self):
         """host side of the bounded waits: raise when a peer never arrived (synchronises the stream)"""

@@ -4,7 +4,10 @@ Owns the flat parameter array ``theta`` (layout: include/cfl_hip.h), its Adam
 slots, the flat gradient, the scalar read-back buffer and the scratch workspace,
 and drives one training step as
 
-    cfl_pair_step_fwd_bwd  ->  [RCCL all-reduce of the flat gradient]  ->  cfl_adam_tf
+    single GPU      cfl_pair_train_step[_idx]_planes             (3 launches, TF-Adam fused into the last one)
+    data parallel   cfl_pair_step_fwd_bwd[_idx]_planes  ->  RCCL all-reduce of [gradient | scalars]  ->  cfl_adam_tf_planes
+                    (the SAME 3 launches -- the projection on the bf16 matrix cores from the kept planes of theta, the fused
+                    weight-gradient tail emitting the flat gradient -- then the exchange and an Adam that re-writes the planes)
 
 which replaces the per-iteration ``sess.run([summary, [s_optim], ...])`` of
 cfl/bin/train_dist.py:81-82 and cfl/models/cfl.py:1399-1414.  Data parallelism
@@ -26,19 +29,37 @@ def rank():
     return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
 
 
+def dp_active():
+    """Does a training step take the data-parallel form (forward / backward -> exchange -> Adam)?  With more than one rank,
+    and -- CFL_FORCE_DP=1 -- with a process group of ONE rank too: the one-GPU way to run the exact code path of a
+    multi-GPU job, RCCL communicator, stream-ordered all-reduce of the gradient buffer and all (tests, bench.py --force-dp)."""
+    import os
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or os.environ.get('CFL_FORCE_DP') == '1'
+
+
 def init_from_env():
     """Called by the CLI entry points before any model is built: caps the host thread pool (quiet_host_threads) and,
     under torchrun (WORLD_SIZE > 1 in the environment), binds this process to its GPU and joins the RCCL process
     group.  One process per GPU."""
     import os
     quiet_host_threads()
-    if int(os.environ.get('WORLD_SIZE', '1')) > 1 and not dist.is_initialized():
+    forced = os.environ.get('CFL_FORCE_DP') == '1'
+    if (int(os.environ.get('WORLD_SIZE', '1')) > 1 or forced) and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        if forced:      # a one-rank group outside torchrun
+            os.environ.setdefault('MASTER_PORT', '29517')
+            os.environ.setdefault('RANK', '0')
+            os.environ.setdefault('WORLD_SIZE', '1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         backend = os.environ.get('CFL_DIST_BACKEND', 'nccl')
         local = int(os.environ.get('LOCAL_RANK', '0'))
         torch.cuda.set_device(local if backend == 'nccl' else local % max(torch.cuda.device_count(), 1))
-        dist.init_process_group(backend)
+        if backend == 'nccl':
+            dist.init_process_group(backend, device_id=torch.device('cuda', torch.cuda.current_device()))
+        else:
+            dist.init_process_group(backend)
     return world_size()
 
 
@@ -61,9 +82,32 @@ def reduce_gradients(flat_grad):
     returns the factor that turns the sums into the global-batch means.  Backend "nccl" is RCCL
     over xGMI on MI355X; the CPU tests run the same code over gloo."""
     n = world_size()
-    if n > 1:
-        dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM)
+    if dp_active():
+        comm = hot_communicator()
+        if comm is not None and flat_grad.is_cuda:
+            comm.all_reduce_sum_(flat_grad)      # ncclAllReduce on the launch stream itself (cfl/rccl.py)
+        else:
+            dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM)
     return 1.0 / n
+
+
+def hot_communicator():
+    """The RCCL communicator of the per-step exchange, or None (gloo test mode; CFL_DP_ALLREDUCE=torch: the collective
+    goes through torch.distributed, i.e. ProcessGroupNCCL's own stream + two events per step).  COLLECTIVE on first use:
+    PairEngine.__init__ calls it on every rank."""
+    import os
+    if not dp_active() or dist.get_backend() != 'nccl' or os.environ.get('CFL_DP_ALLREDUCE', 'direct') == 'torch':
+        return None
+    from . import rccl
+    return rccl.default_communicator()
+
+
+def finalize():
+    """end of a run: destroy the hot communicator, then the process group (every rank)"""
+    from . import rccl
+    rccl.shutdown()
+    if dist.is_available() and dist.is_initialized():
+        dist.destroy_process_group()
 
 
 def quiet_host_threads(n=4):
@@ -129,6 +173,7 @@ class PairEngine(object):
         # (CFL_DP_EXCHANGE=oneshot: cfl/dp_exchange.py, csrc/cfl_dp.hip)
         self._oneshot = None
         import os
+        hot_communicator()           # (collective: created here, on every rank, not inside the first step)
         if world_size() > 1 and os.environ.get('CFL_DP_EXCHANGE', 'allreduce') == 'oneshot':
             from .dp_exchange import OneShotExchange
             self._oneshot = OneShotExchange(self)
@@ -171,9 +216,8 @@ class PairEngine(object):
         self._scalar_scale = 1.0
 
     def apply_adam(self, grad_scale=1.0):
-        H.adam_tf(self.theta, self.m, self.v, self.grad, self.lr_t(), self.beta1,
-                  self.beta2, self.eps, grad_scale)
-        self.planes.invalidate()
+        H.adam_tf_planes(self.shape, self.theta, self.m, self.v, self.grad, self.lr_t(), self.beta1,
+                         self.beta2, self.eps, grad_scale, planes=self.planes)
         self._advance()
 
     def _advance(self):
@@ -185,11 +229,10 @@ class PairEngine(object):
         """One training step on this rank's shard of the row batch: `batch` is either the 4 dense device
         tensors (pos_src, pos_dst, neg_src, neg_dst) or a (table, IndexStreams) pair -- rows picked from a
         resident feature table by index (cfl.input_data.ResidentFeatures.next_indexed)."""
-        n = self.world_size
         indexed = isinstance(batch[1], H.IndexStreams)
         rows = batch[1].n if indexed else batch[0].shape[0]
         ws = self._workspace(rows, 2)
-        if n == 1:
+        if not dp_active():
             # single GPU: Adam fused into the last kernel of the step
             if indexed:
                 H.pair_train_step_idx(self.shape, self.norm, self.loss, batch[0], batch[1], self.theta, self.m,
@@ -204,16 +247,16 @@ class PairEngine(object):
             return
         if indexed:
             H.pair_step_fwd_bwd_idx(self.shape, self.norm, self.loss, batch[0], batch[1], self.theta, self.grad,
-                                    self.scalars, ws)
+                                    self.scalars, ws, planes=self.planes)
         else:
-            H.pair_step_fwd_bwd(self.shape, self.norm, self.loss, batch, self.theta, self.grad, self.scalars, ws)
+            H.pair_step_fwd_bwd(self.shape, self.norm, self.loss, batch, self.theta, self.grad, self.scalars, ws,
+                                planes=self.planes)
         self._exchange_and_update()
 
     def _exchange_and_update(self):
         """the ONE exchange of a data-parallel step + the replicated Adam apply"""
         if self._oneshot is not None:
-            self._scalar_scale = self._oneshot.exchange_and_adam(self, self.lr_t())
-            self.planes.invalidate()
+            self._scalar_scale = self._oneshot.exchange_and_adam(self, self.lr_t())   # (its gather re-writes the planes)
             self._advance()
             return
         # sum of [flat fp32 gradient | scalars] over xGMI
@@ -226,7 +269,7 @@ class PairEngine(object):
         (cfl.input_data.ResidentFeatures.next_windows): one library call, the launches of all steps are enqueued
         back to back."""
         ws = self._workspace(win.rows, 2)
-        if self.world_size != 1:
+        if dp_active():
             # data parallel: the same windows, the exchange inside the loop -- every step is forward/backward on this
             # rank's rows of the window, then the collective + Adam (one host call for the iterations between two
             # read-backs; with the one-shot exchange nothing in the loop leaves the library's kernels)
@@ -243,7 +286,7 @@ class PairEngine(object):
                 streams = H.IndexStreams([po + 4 * c0, po + 4 * (1 - c0), no + 4 * c0, no + 4 * (1 - c0)], 2, win.rows,
                                          keep=[win.pos_pairs, win.neg_pairs])
                 H.pair_step_fwd_bwd_idx(self.shape, self.norm, self.loss, win.table, streams, self.theta, self.grad,
-                                        self.scalars, ws)
+                                        self.scalars, ws, planes=self.planes)
                 self._exchange_and_update()
             return
         b1p, b2p = H.pair_train_steps_idx(
@@ -296,7 +339,15 @@ class PairEngine(object):
         if self._oneshot is not None:
             self._oneshot.sync_optimizer_state(self)
 
+    def require_complete_slots(self):
+        """A checkpoint must never be written from sharded Adam slots: raise unless sync_state() ran since the last step."""
+        if self._oneshot is not None and self._oneshot.slots_dirty:
+            raise H.CflHipError('the Adam slots are sharded over the ranks (CFL_DP_EXCHANGE=oneshot) and a step was taken '
+                                'since the last PairEngine.sync_state(): every rank must call sync_state() before the '
+                                'chief reads m / v for a checkpoint')
+
     def state_dict(self):
+        self.require_complete_slots()
         return dict(theta=self.theta.cpu(), m=self.m.cpu(), v=self.v.cpu(),
                     beta1_power=float(self.beta1_power), beta2_power=float(self.beta2_power),
                     global_step=self.global_step)

@@ -80,7 +80,8 @@ EXPORTS = ('cfl_version', 'cfl_last_error', 'cfl_layout', 'cfl_workspace_bytes',
            'cfl_pair_train_steps_idx', 'cfl_pair_scores_idx4', 'cfl_mt19937_reshuffle', 'cfl_dp_alloc', 'cfl_dp_free', 'cfl_dp_ipc_export', 'cfl_dp_ipc_open', 'cfl_dp_ipc_close',
            'cfl_dp_rs_push', 'cfl_dp_rs_adam', 'cfl_dp_rs_gather',
            'cfl_scalars_status', 'cfl_theta_planes_bytes', 'cfl_pair_train_step_planes', 'cfl_pair_train_step_idx_planes',
-           'cfl_pair_train_steps_idx_planes')
+           'cfl_pair_train_steps_idx_planes', 'cfl_pair_step_fwd_bwd_planes', 'cfl_pair_step_fwd_bwd_idx_planes',
+           'cfl_adam_tf_planes', 'cfl_dp_rs_gather_planes')
 
 KERNEL_NAMES = ('colnorm', 'proj', 'mid', 'grad', 'finalize', 'adam', 'gather')
 K_COUNT = 8
@@ -117,6 +118,9 @@ def lib():
         C.POINTER(C.c_void_p), C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
         C.c_void_p, C.c_size_t, C.c_void_p]
     L.cfl_pair_step_fwd_bwd.restype = C.c_int
+    a = list(L.cfl_pair_step_fwd_bwd.argtypes)
+    L.cfl_pair_step_fwd_bwd_planes.argtypes = a[:8] + [C.POINTER(CflThetaPlanes)] + a[8:]
+    L.cfl_pair_step_fwd_bwd_planes.restype = C.c_int
     L.cfl_pair_train_step.argtypes = [
         C.POINTER(CflShape), C.POINTER(CflNorm), C.POINTER(CflLossCfg),
         C.POINTER(C.c_void_p), C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -141,6 +145,9 @@ def lib():
         C.POINTER(C.c_void_p), C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
         C.c_void_p]
     L.cfl_pair_step_fwd_bwd_idx.restype = C.c_int
+    a = list(L.cfl_pair_step_fwd_bwd_idx.argtypes)
+    L.cfl_pair_step_fwd_bwd_idx_planes.argtypes = a[:11] + [C.POINTER(CflThetaPlanes)] + a[11:]
+    L.cfl_pair_step_fwd_bwd_idx_planes.restype = C.c_int
     L.cfl_pair_train_step_idx.argtypes = [
         C.POINTER(CflShape), C.POINTER(CflNorm), C.POINTER(CflLossCfg), C.c_void_p, C.c_int64,
         C.POINTER(C.c_void_p), C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -166,6 +173,10 @@ def lib():
                               C.c_int64, C.c_float, C.c_float, C.c_float,
                               C.c_float, C.c_float, C.c_void_p]
     L.cfl_adam_tf.restype = C.c_int
+    L.cfl_adam_tf_planes.argtypes = [C.POINTER(CflShape), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
+                                     C.POINTER(CflThetaPlanes), C.c_void_p]
+    L.cfl_adam_tf_planes.restype = C.c_int
     L.cfl_gather_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64,
                                   C.c_void_p, C.c_void_p]
     L.cfl_gather_rows.restype = C.c_int
@@ -192,12 +203,14 @@ def lib():
                                  [C.c_uint32, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p])
     L.cfl_dp_rs_gather.argtypes = [C.c_void_p] * 4 + [C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_int64, C.c_uint32,
                                                       C.c_void_p, C.c_double, C.c_void_p]
+    a = list(L.cfl_dp_rs_gather.argtypes)
+    L.cfl_dp_rs_gather_planes.argtypes = [C.POINTER(CflShape)] + a[:12] + [C.POINTER(CflThetaPlanes)] + a[12:]
     for f in (L.cfl_dp_alloc, L.cfl_dp_free, L.cfl_dp_ipc_export, L.cfl_dp_ipc_open, L.cfl_dp_ipc_close, L.cfl_dp_rs_push,
-              L.cfl_dp_rs_adam, L.cfl_dp_rs_gather):
+              L.cfl_dp_rs_adam, L.cfl_dp_rs_gather, L.cfl_dp_rs_gather_planes):
         f.restype = C.c_int
     L.cfl_profile_enable.argtypes = [C.c_int]
     L.cfl_profile_read.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_int64)]
-    if L.cfl_version() != 4:
+    if L.cfl_version() != 5:
         raise CflHipError('libcfl_hip.so ABI version mismatch')
     _lib = L
     return L
@@ -297,12 +310,13 @@ def pair_scores(shape, norm, xs, xt, theta, workspace, scores=None, dists=None):
     return scores
 
 
-def pair_step_fwd_bwd(shape, norm, loss, x4, theta, grad, scalars, workspace):
+def pair_step_fwd_bwd(shape, norm, loss, x4, theta, grad, scalars, workspace, planes=None):
+    """planes: the caller's kept plane buffer (read; split from theta first when stale) -- the data-parallel step"""
     B = x4[0].shape[0]
     arr = (C.c_void_p * 4)(*[_dev(x) for x in x4])
-    _check(lib().cfl_pair_step_fwd_bwd(
+    _check(lib().cfl_pair_step_fwd_bwd_planes(
         C.byref(shape), C.byref(norm), C.byref(loss), arr, B, _dev(theta), _dev(grad),
-        _dev(scalars), workspace.data_ptr(),
+        _dev(scalars), _planes(planes), workspace.data_ptr(),
         workspace.numel() * workspace.element_size(), _stream()))
 
 
@@ -366,11 +380,11 @@ def pair_scores_idx4(shape, norm, table, streams, theta, workspace, scores=None)
     return scores
 
 
-def pair_step_fwd_bwd_idx(shape, norm, loss, table, streams, theta, grad, scalars, workspace):
+def pair_step_fwd_bwd_idx(shape, norm, loss, table, streams, theta, grad, scalars, workspace, planes=None):
     tp, rows = _table(table)
-    _check(lib().cfl_pair_step_fwd_bwd_idx(
+    _check(lib().cfl_pair_step_fwd_bwd_idx_planes(
         C.byref(shape), C.byref(norm), C.byref(loss), tp, rows, streams.arr, streams.stride, streams.n,
-        _dev(theta), _dev(grad), _dev(scalars), workspace.data_ptr(),
+        _dev(theta), _dev(grad), _dev(scalars), _planes(planes), workspace.data_ptr(),
         workspace.numel() * workspace.element_size(), _stream()))
 
 
@@ -425,6 +439,16 @@ def mt19937_reshuffle(state, rows, want32=False):
 def reload_env():
     """Re-read CFL_EXACT_FP32 / CFL_DEBUG_* (the launch plans are cached per process otherwise)."""
     return lib().cfl_reload_env()
+
+
+def adam_tf_planes(shape, theta, m, v, grad, lr_t, beta1, beta2, eps=1e-8, grad_scale=1.0, planes=None):
+    """TF-Adam over the whole theta of `shape` that also writes the kept bf16 planes of the updated weights
+    (cfl_adam_tf_planes: the update of a data-parallel step)."""
+    if theta.numel() != layout(shape).total or grad.numel() < theta.numel():
+        raise CflHipError('adam_tf_planes: theta / grad do not have the parameter count of the shape')
+    _check(lib().cfl_adam_tf_planes(C.byref(shape), _dev(theta), _dev(m), _dev(v), _dev(grad), float(lr_t),
+                                    float(beta1), float(beta2), float(eps), float(grad_scale), _planes(planes),
+                                    _stream()))
 
 
 def adam_tf(theta, m, v, grad, lr_t, beta1, beta2, eps=1e-8, grad_scale=1.0):

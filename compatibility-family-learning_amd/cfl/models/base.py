@@ -140,6 +140,7 @@ class PairModel(object):
 
     def checkpoint_state(self):
         eng = self.engine
+        eng.require_complete_slots()
         state = {'variables': self._named(eng.theta),
                  'adam_m': self._named(eng.m), 'adam_v': self._named(eng.v),
                  'beta1_power': float(eng.beta1_power), 'beta2_power': float(eng.beta2_power),

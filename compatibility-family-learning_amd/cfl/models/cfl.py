@@ -493,6 +493,9 @@ class CFL(PairModel):
         for e in range(start_epoch, total_epochs):
             t = trange(start_iter % nb_batch if e == start_epoch else 0, nb_batch, disable=not chief)
             if e >= epochs:
+                # every rank, before the chief-only saves of the post epochs (the encoder's Adam slots are sharded under
+                # the one-shot exchange; a no-op when nothing was stepped since the last sync)
+                self.engine.sync_state()
                 self._post_epoch(e, t, data, nb_batch, save_iters, saver if chief else None, checkpoint_dir, writer)
                 if e % save_epochs == 0 and saver is not None and chief:
                     saver.save(self, os.path.join(checkpoint_dir, 'model'), global_step=(e + 1) * nb_batch)

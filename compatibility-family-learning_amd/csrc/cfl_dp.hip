@@ -33,6 +33,7 @@
 #include <cstring>
 
 #include "../../include/cfl_hip.h"
+#include "theta_planes.h"
 
 extern int cfl_set_err(int code, const char *fmt, ...);
 
@@ -163,16 +164,21 @@ __global__ __launch_bounds__(256) void cfl_dp_rs_adam_kernel(float *theta, float
 __global__ __launch_bounds__(256) void cfl_dp_rs_gather_kernel(float *theta, float *sum_out, const float *stage,
                                                                const unsigned *flags, int world, int rank, long long n4,
                                                                long long nadam4, long long slice4, unsigned gen, int *lost,
-                                                               unsigned long long ticks) {
+                                                               unsigned long long ticks, ThetaPlaneRegions pr) {
     const bool ok = dp_wait_flags(flags, world, rank, gen, ticks, lost);
     const long long lo = (long long)rank * slice4, hi = lo + slice4;
     const long long stride = (long long)gridDim.x * 256;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
-        if (i >= lo && i < hi) continue;    // own slice: written by cfl_dp_rs_adam_kernel
+        if (i >= lo && i < hi) {            // own slice: written by cfl_dp_rs_adam_kernel (the launch before this one)
+            if (pr.planes && i < nadam4) theta_planes_store4(pr, i * 4, ((const dp_f32x4 *)theta)[i]);
+            continue;
+        }
         dp_f32x4 x = load_sys16(stage + i * 4);
         if (!ok) x = (dp_f32x4){NAN, NAN, NAN, NAN};
-        if (i < nadam4) ((dp_f32x4 *)theta)[i] = x;
-        else ((dp_f32x4 *)sum_out)[i] = x;
+        if (i < nadam4) {
+            ((dp_f32x4 *)theta)[i] = x;
+            theta_planes_store4(pr, i * 4, x);
+        } else ((dp_f32x4 *)sum_out)[i] = x;
     }
 }
 
@@ -294,9 +300,23 @@ extern "C" int cfl_dp_rs_adam(float *theta, float *m, float *v, const float *gsl
     return hipGetLastError() == hipSuccess ? CFL_OK : cfl_set_err(CFL_E_HIP, "cfl_dp_rs_adam launch failed");
 }
 
-extern "C" int cfl_dp_rs_gather(float *theta, float *sum_out, const float *stage, const uint32_t *flags, int32_t world,
-                                int32_t rank, int64_t n, int64_t n_adam, int64_t slice, uint32_t generation, int32_t *lost,
-                                double timeout_s, cfl_stream_t stream) {
+extern "C" int cfl_dp_rs_gather_planes(const CflShape *shape, float *theta, float *sum_out, const float *stage,
+                                       const uint32_t *flags, int32_t world, int32_t rank, int64_t n, int64_t n_adam,
+                                       int64_t slice, uint32_t generation, int32_t *lost, double timeout_s,
+                                       CflThetaPlanes *planes, cfl_stream_t stream) {
+    ThetaPlaneRegions pr;
+    memset(&pr, 0, sizeof(pr));
+    if (planes) {
+        if (!planes->buf || ((uintptr_t)planes->buf & 15))
+            return cfl_set_err(CFL_E_SHAPE, "cfl_dp_rs_gather_planes: theta planes buffer NULL or misaligned");
+        CflLayout lay;
+        int rc = theta_plane_regions(shape, planes->buf, &pr);
+        if (!rc) rc = cfl_layout(shape, &lay);
+        if (rc) return rc;
+        if (lay.total != n_adam)
+            return cfl_set_err(CFL_E_SHAPE, "cfl_dp_rs_gather_planes: n_adam=%lld is not the parameter count %lld of the shape",
+                               (long long)n_adam, (long long)lay.total);
+    }
     if (!theta || !sum_out || !stage || !flags || !lost) return cfl_set_err(CFL_E_SHAPE, "cfl_dp_rs_gather: NULL pointer");
     if (((uintptr_t)theta | (uintptr_t)sum_out | (uintptr_t)stage) & 15)
         return cfl_set_err(CFL_E_SHAPE, "cfl_dp_rs_gather: theta / sum_out / stage must be 16-byte aligned");
@@ -307,6 +327,15 @@ extern "C" int cfl_dp_rs_gather(float *theta, float *sum_out, const float *stage
     if (blocks > 128) blocks = 128;
     hipLaunchKernelGGL(cfl_dp_rs_gather_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, theta, sum_out, stage, flags,
                        world, rank, (long long)(n / 4), (long long)(n_adam / 4), (long long)(slice / 4), generation, (int *)lost,
-                       dp_ticks(timeout_s));
-    return hipGetLastError() == hipSuccess ? CFL_OK : cfl_set_err(CFL_E_HIP, "cfl_dp_rs_gather launch failed");
+                       dp_ticks(timeout_s), pr);
+    if (hipGetLastError() != hipSuccess) return cfl_set_err(CFL_E_HIP, "cfl_dp_rs_gather launch failed");
+    if (planes) planes->valid = 1;
+    return CFL_OK;
+}
+
+extern "C" int cfl_dp_rs_gather(float *theta, float *sum_out, const float *stage, const uint32_t *flags, int32_t world,
+                                int32_t rank, int64_t n, int64_t n_adam, int64_t slice, uint32_t generation, int32_t *lost,
+                                double timeout_s, cfl_stream_t stream) {
+    return cfl_dp_rs_gather_planes(nullptr, theta, sum_out, stage, flags, world, rank, n, n_adam, slice, generation, lost,
+                                   timeout_s, nullptr, stream);
 }

@@ -49,6 +49,7 @@
 
 #include "../../include/cfl_hip.h"
 #include "gemm_gather.h"
+#include "theta_planes.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -4128,6 +4129,24 @@ extern "C" __global__ __launch_bounds__(256) void cfl_adam_kernel(float *theta, 
     }
 }
 
+// ... that also writes the kept bf16 planes of the weights it updates (the update of a data-parallel step: theta_planes.h)
+extern "C" __global__ __launch_bounds__(256) void cfl_adam_planes_kernel(float *theta, float *m, float *v,
+                                                                        const float *grad, long long n4,
+                                                                        float lr_t, float b1, float b2,
+                                                                        float eps, float gscale, ThetaPlaneRegions pr) {
+    long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long stride = (long long)gridDim.x * 256;
+    for (; i < n4; i += stride) {
+        f32x4 g = ((const f32x4 *)grad)[i] * gscale;
+        f32x4 mm = ((f32x4 *)m)[i], vv = ((f32x4 *)v)[i], th = ((f32x4 *)theta)[i];
+        adam4(th, mm, vv, g, lr_t, b1, b2, eps);
+        ((f32x4 *)m)[i] = mm;
+        ((f32x4 *)v)[i] = vv;
+        ((f32x4 *)theta)[i] = th;
+        theta_planes_store4(pr, i * 4, th);
+    }
+}
+
 // ---------------------------------------------------------------------------
 // row gather: out[i,:] = table[idx[i],:]   (one wave per row, 16 B per lane)
 // ---------------------------------------------------------------------------
@@ -4616,8 +4635,10 @@ static int run_pairs(const CflShape *s, const CflNorm *norm, const CflLossCfg *l
     const bool train = grad != nullptr;
     Plan pl;
     if (kept && (!kept->buf || ((uintptr_t)kept->buf & 15))) return set_err(CFL_E_SHAPE, "theta planes buffer NULL or misaligned");
-    // planes are kept by the fused Adam tail only: a call that does not update theta in its last launch leaves them alone
-    const bool keeping = kept && train && adam && debug_env("CFL_DEBUG_NOFUSE") <= 0;
+    // a training call with a kept plane buffer projects from it (splitting theta into it first when it is stale).  The fused
+    // Adam tail then WRITES the planes of the updated weights (`adam`); a call that leaves theta alone (the forward /
+    // backward of a data-parallel step: the update is cfl_adam_tf_planes, after the exchange) only reads them
+    const bool keeping = kept && train && debug_env("CFL_DEBUG_NOFUSE") <= 0;
     int rc = cached_plan(s, rows, groups, train, keeping, &pl);
     if (rc) return rc;
     if (!theta || !workspace) return set_err(CFL_E_SHAPE, "NULL theta/workspace");
@@ -5048,7 +5069,7 @@ static int run_pairs(const CflShape *s, const CflNorm *norm, const CflLossCfg *l
             f.in_mul = in_mul; f.reg_const = loss->reg_const;
             f.spin_limit = debug_env("CFL_DEBUG_SPIN_LIMIT") != 0 ? debug_env("CFL_DEBUG_SPIN_LIMIT") : CFL_HANDOFF_SPIN_LIMIT;
             // kept planes: written by the tile finishers only when the next step's projection will read them
-            f.planes = (keeping && (pl.proj_x3 || pl.proj_bx3)) ? (unsigned short *)kept->buf : nullptr;
+            f.planes = (keeping && adam && (pl.proj_x3 || pl.proj_bx3)) ? (unsigned short *)kept->buf : nullptr;
             int jn = 0;
             for (int sd = 0; sd < 2; ++sd) {
                 const CflHead *h = side[sd].head;
@@ -5184,6 +5205,7 @@ static int run_pairs(const CflShape *s, const CflNorm *norm, const CflLossCfg *l
     }
 
     if (kept && adam) kept->valid = (keeping && pl.fused && (pl.proj_x3 || pl.proj_bx3)) ? 1 : 0;   // theta has changed; were the planes written?
+    else if (keeping && (pl.proj_x3 || pl.proj_bx3)) kept->valid = 1;   // theta unchanged: the buffer holds its planes now (split above if it was stale)
     if (pl.fused) {
         HIP_TRY(hipGetLastError());
         return CFL_OK;
@@ -5235,6 +5257,17 @@ extern "C" int cfl_pair_step_fwd_bwd(const CflShape *shape, const CflNorm *norm,
         return set_err(CFL_E_SHAPE, "caffe_margin and lambda_m are exclusive (cfl/utils.py:72-73)");
     return run_pairs(shape, norm, loss, x4, 2, B, theta, grad, scalars, nullptr, nullptr, workspace,
                      workspace_bytes, (hipStream_t)stream);
+}
+
+extern "C" int cfl_pair_step_fwd_bwd_planes(const CflShape *shape, const CflNorm *norm,
+                                            const CflLossCfg *loss, const float *const x4[4], int64_t B,
+                                            const float *theta, float *grad, float *scalars, CflThetaPlanes *planes,
+                                            void *workspace, size_t workspace_bytes, cfl_stream_t stream) {
+    if (!loss || !x4 || !grad || !scalars) return set_err(CFL_E_SHAPE, "NULL loss/x4/grad/scalars");
+    if (loss->caffe_margin != 0.f && loss->lambda_m != 0.f)
+        return set_err(CFL_E_SHAPE, "caffe_margin and lambda_m are exclusive (cfl/utils.py:72-73)");
+    return run_pairs(shape, norm, loss, x4, 2, B, theta, grad, scalars, nullptr, nullptr, workspace,
+                     workspace_bytes, (hipStream_t)stream, nullptr, nullptr, planes);
 }
 
 extern "C" int cfl_pair_train_step_planes(const CflShape *shape, const CflNorm *norm,
@@ -5296,6 +5329,18 @@ extern "C" int cfl_pair_step_fwd_bwd_idx(const CflShape *shape, const CflNorm *n
     IndexSrc is = {table, table_rows, idx4, idx_stride};
     return run_pairs(shape, norm, loss, nullptr, 2, B, theta, grad, scalars, nullptr, nullptr, workspace,
                      workspace_bytes, (hipStream_t)stream, nullptr, &is);
+}
+
+extern "C" int cfl_pair_step_fwd_bwd_idx_planes(const CflShape *shape, const CflNorm *norm, const CflLossCfg *loss,
+                                                const float *table, int64_t table_rows, const int32_t *const idx4[4],
+                                                int64_t idx_stride, int64_t B, const float *theta, float *grad,
+                                                float *scalars, CflThetaPlanes *planes, void *workspace,
+                                                size_t workspace_bytes, cfl_stream_t stream) {
+    int rc = check_train_args(loss, grad, scalars);
+    if (rc) return rc;
+    IndexSrc is = {table, table_rows, idx4, idx_stride};
+    return run_pairs(shape, norm, loss, nullptr, 2, B, theta, grad, scalars, nullptr, nullptr, workspace,
+                     workspace_bytes, (hipStream_t)stream, nullptr, &is, planes);
 }
 
 extern "C" int cfl_pair_train_step_idx_planes(const CflShape *shape, const CflNorm *norm, const CflLossCfg *loss,
@@ -5573,6 +5618,30 @@ extern "C" int cfl_adam_tf(float *theta, float *m, float *v, const float *grad, 
                            v, grad, n4, lr_t, beta1, beta2, eps, grad_scale);
     }
     HIP_TRY(hipGetLastError());
+    return CFL_OK;
+}
+
+extern "C" int cfl_adam_tf_planes(const CflShape *shape, float *theta, float *m, float *v, const float *grad,
+                                  float lr_t, float beta1, float beta2, float eps, float grad_scale,
+                                  CflThetaPlanes *planes, cfl_stream_t stream) {
+    if (!theta || !m || !v || !grad) return set_err(CFL_E_SHAPE, "NULL pointer");
+    if (planes && (!planes->buf || ((uintptr_t)planes->buf & 15))) return set_err(CFL_E_SHAPE, "theta planes buffer NULL or misaligned");
+    ThetaPlaneRegions pr;
+    int rc = theta_plane_regions(shape, planes ? planes->buf : nullptr, &pr);
+    if (rc) return rc;
+    CflLayout lay;
+    rc = cfl_layout(shape, &lay);
+    if (rc) return rc;
+    const long long n4 = lay.total / 4;
+    int blocks = (int)((n4 + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    {
+        ProfScope ps((hipStream_t)stream, CFL_K_ADAM);
+        hipLaunchKernelGGL(cfl_adam_planes_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, theta, m,
+                           v, grad, n4, lr_t, beta1, beta2, eps, grad_scale, pr);
+    }
+    HIP_TRY(hipGetLastError());
+    if (planes) planes->valid = 1;
     return CFL_OK;
 }
 

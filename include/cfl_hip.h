@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define CFL_ABI_VERSION 4
+#define CFL_ABI_VERSION 5
 
 /* error codes */
 #define CFL_OK 0
@@ -215,6 +215,16 @@ typedef struct {
 } CflThetaPlanes;
 size_t cfl_theta_planes_bytes(const CflShape *shape);
 
+/* cfl_pair_step_fwd_bwd with a kept plane buffer (ABI 5): the forward / backward of a step whose update happens
+ * elsewhere -- the data-parallel step, where the gradient exchange sits between this call and cfl_adam_tf_planes.  The
+ * projection reads the caller's planes (when !planes->valid they are first split from theta into the buffer and valid is
+ * set); theta is not changed, so the planes stay valid.  planes may be NULL: identical to cfl_pair_step_fwd_bwd.          */
+int cfl_pair_step_fwd_bwd_planes(const CflShape *shape, const CflNorm *norm,
+                                 const CflLossCfg *loss, const float *const x4[4],
+                                 int64_t B, const float *theta, float *grad,
+                                 float *scalars, CflThetaPlanes *planes, void *workspace,
+                                 size_t workspace_bytes, cfl_stream_t stream);
+
 /* Single-GPU fast path: cfl_pair_step_fwd_bwd with the TF-Adam apply fused into
  * the last kernel (theta, m, v updated in place; grad still written).  Equals
  * cfl_pair_step_fwd_bwd followed by cfl_adam_tf(..., grad_scale = 1); replaces the
@@ -253,6 +263,10 @@ int cfl_pair_step_fwd_bwd_idx(const CflShape *shape, const CflNorm *norm, const 
                               const float *table, int64_t table_rows, const int32_t *const idx4[4],
                               int64_t idx_stride, int64_t B, const float *theta, float *grad, float *scalars,
                               void *workspace, size_t workspace_bytes, cfl_stream_t stream);
+int cfl_pair_step_fwd_bwd_idx_planes(const CflShape *shape, const CflNorm *norm, const CflLossCfg *loss,
+                                     const float *table, int64_t table_rows, const int32_t *const idx4[4],
+                                     int64_t idx_stride, int64_t B, const float *theta, float *grad, float *scalars,
+                                     CflThetaPlanes *planes, void *workspace, size_t workspace_bytes, cfl_stream_t stream);
 int cfl_pair_train_step_idx(const CflShape *shape, const CflNorm *norm, const CflLossCfg *loss,
                             const float *table, int64_t table_rows, const int32_t *const idx4[4],
                             int64_t idx_stride, int64_t B, float *theta, float *m, float *v, float *grad,
@@ -310,6 +324,15 @@ int cfl_reload_env(void);
 int cfl_adam_tf(float *theta, float *m, float *v, const float *grad, int64_t n,
                 float lr_t, float beta1, float beta2, float eps,
                 float grad_scale, cfl_stream_t stream);
+
+/* cfl_adam_tf over the whole theta of `shape` (n = cfl_layout().total) that also WRITES the kept bf16 planes of the
+ * weights it updates and sets planes->valid (ABI 5; planes may be NULL: identical to cfl_adam_tf).  The update of a
+ * data-parallel step: cfl_pair_step_fwd_bwd[_idx]_planes -> exchange of [gradient | scalars] -> this call, so that the
+ * next step's projection runs on the bf16 matrix cores from current planes exactly as the fused single-GPU step's does
+ * (bit-identical planes: the same round-to-nearest split, csrc/theta_planes.h).                                         */
+int cfl_adam_tf_planes(const CflShape *shape, float *theta, float *m, float *v, const float *grad,
+                       float lr_t, float beta1, float beta2, float eps, float grad_scale,
+                       CflThetaPlanes *planes, cfl_stream_t stream);
 
 /* Gather rows of a resident feature table into a dense batch:
  * out[i, :] = table[idx[i], :].  Replaces the per-row seek+read loop of
@@ -540,6 +563,12 @@ int cfl_dp_rs_adam(float *theta, float *m, float *v, const float *gslots, const 
 int cfl_dp_rs_gather(float *theta, float *sum_out, const float *stage, const uint32_t *flags, int32_t world, int32_t rank,
                      int64_t n, int64_t n_adam, int64_t slice, uint32_t generation, int32_t *lost, double timeout_s,
                      cfl_stream_t stream);
+/* ... that also writes the kept bf16 planes of EVERY weight of theta (the peers' slices as it copies them, this rank's own
+ * slice -- updated by cfl_dp_rs_adam on the same stream -- as it passes over it) and sets planes->valid (ABI 5);
+ * n_adam must be cfl_layout(shape).total.  planes may be NULL: identical to cfl_dp_rs_gather.                          */
+int cfl_dp_rs_gather_planes(const CflShape *shape, float *theta, float *sum_out, const float *stage, const uint32_t *flags,
+                            int32_t world, int32_t rank, int64_t n, int64_t n_adam, int64_t slice, uint32_t generation,
+                            int32_t *lost, double timeout_s, CflThetaPlanes *planes, cfl_stream_t stream);
 
 #ifdef __cplusplus
 }

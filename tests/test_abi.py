@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol(H):
     lib = hipgan.lib()
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.cfl_version() == 4
+    assert lib.cfl_version() == 5
 
 
 def test_layout_is_consistent(H):

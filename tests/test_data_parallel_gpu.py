@@ -203,6 +203,11 @@ def _oneshot_worker(rank, world, port, out):
         win = Namespace(table=table, pos_pairs=pos, neg_pairs=neg, pos_head=0, neg_head=B, batch_rows=B, shard_lo=lo,
                         rows=hi - lo, nsteps=3, switched=[False, True, False])
         c = mk('oneshot')
+        try:                                                  # an unsynced checkpoint cannot be written
+            b.state_dict()
+            raise AssertionError('state_dict() from sharded, unsynced Adam slots must raise')
+        except H.CflHipError:
+            pass
         b.sync_state()                                        # collective: the Adam slots are sharded over the ranks
         if rank == 0:                                         # the complete slots equal the all-reduce path's (replicated) ones
             worst = max(worst, float((a.m - b.m).abs().max() / a.m.abs().max()), float((a.v - b.v).abs().max() / a.v.abs().max()))

@@ -1,0 +1,197 @@
+"""Round 5 (GPU): the data-parallel step IS the single-GPU step plus an exchange.
+
+    single GPU      cfl_pair_train_step_planes                      proj_bx3 -> mid -> grad (+ Adam + planes in its tail)
+    data parallel   cfl_pair_step_fwd_bwd_planes -> exchange -> cfl_adam_tf_planes
+                                                                    proj_bx3 -> mid -> grad (flat gradient) | RCCL | Adam + planes
+
+* the split form (no collective between the two calls) equals the fused step BIT FOR BIT over 300 steps at the headline
+  shape -- same kernels, same gradient, same Adam arithmetic, same round-to-nearest plane split -- and the planes the
+  stand-alone Adam keeps equal the planes the fused tail keeps bit for bit; every model family;
+* the data-parallel branch of PairEngine.step on a ONE-RANK `nccl` process group (CFL_FORCE_DP=1): RCCL is initialised,
+  the [gradient | scalars] buffer is all-reduced on the launch stream, and the result equals the fused single-GPU step
+  (2e-6 asked, bit-identical expected: a one-rank sum changes nothing);
+* the launch count of the forms, from the library's own profile hooks (3 compute + Adam under data parallelism).
+"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import cfl_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+H = None
+
+
+@pytest.fixture(scope='module', autouse=True)
+def _hip():
+    global H
+    from cfl import hipabi
+    hipabi.lib()
+    assert torch.cuda.is_available(), 'gpu tests need a GPU'
+    H = hipabi
+    yield
+
+
+def _params(cfg, rng):
+    p = O.init_encoder_params(cfg, rng, np.float32)
+    for k in p:
+        p[k] = (p[k] + 0.05 * rng.randn(*p[k].shape).astype(np.float32) * (0.1 if k.endswith('/W') else 1.0)).astype(np.float32)
+    return p
+
+
+CASES = [
+    # style, dist, D, L, K, B, loss kwargs, steps
+    ('dist', 'pcd', 4096, 20, 3, 512, dict(), 300),                                     # headline
+    ('dist', 'pcd', 4096, 20, 3, 2048, dict(reg_const=1e-3), 40),                       # LDS-shared projection (rows >= 3072)
+    ('cfl', 'pcd', 2048, 20, 5, 1024, dict(pos_weight=0.25), 60),                       # config 4: weight norm, hand-off tail
+    ('cfl', 'siamese', 1024, 256, 1, 512, dict(use_threshold=False, caffe_margin=100.0, pos_weight=0.0625), 60),   # config 3
+    ('cfl', 'monomer', 2048, 32, 3, 1024, dict(), 40),
+    ('dist', 'pcd', 1088, 7, 2, 100, dict(), 40),
+]
+
+
+@pytest.mark.parametrize('style,dist,D,L,K,B,lkw,steps', CASES)
+def test_split_step_with_plane_keeping_adam_equals_fused_step(style, dist, D, L, K, B, lkw, steps):
+    rng = np.random.RandomState(5)
+    cfg = O.EncoderCfg(D=D, L=L, K=K, dist_type=dist, style=style)
+    p = _params(cfg, rng)
+    sh = H.make_shape(D, L, K, dist, cfg.weight_norm, cfg.has_bias)
+    norm, loss = H.make_norm(1.0 / 31.9098), H.make_loss(**lkw)
+    pool = [[torch.from_numpy((np.abs(rng.randn(B, D)) * 8.0).astype(np.float32)).cuda() for _ in range(4)] for _ in range(3)]
+
+    def run(split):
+        theta = H.pack_theta(sh, p, None, 0.5 if dist != 'siamese' else 40.0, 'cuda')
+        m, v, grad = torch.zeros_like(theta), torch.zeros_like(theta), torch.zeros_like(theta)
+        scal = torch.zeros(H.S_COUNT, device='cuda')
+        ws = torch.full((H.workspace_bytes(sh, B, 2) // 4,), float('nan'), dtype=torch.float32, device='cuda')
+        planes = H.ThetaPlanes(sh, 'cuda')
+        planes.buf.fill_(0x7fc0)
+        b1p, b2p = np.float32(0.9), np.float32(0.999)
+        for i in range(steps):
+            lr_t = float(np.float32(1e-3) * np.sqrt(np.float32(1) - b2p) / (np.float32(1) - b1p))
+            if split:
+                H.pair_step_fwd_bwd(sh, norm, loss, pool[i % 3], theta, grad, scal, ws, planes=planes)
+                assert planes.valid, 'the forward must leave the (split or kept) planes valid: theta did not change'
+                H.adam_tf_planes(sh, theta, m, v, grad, lr_t, 0.9, 0.999, planes=planes)
+            else:
+                H.pair_train_step(sh, norm, loss, pool[i % 3], theta, m, v, grad, scal, ws, lr_t, 0.9, 0.999, planes=planes)
+            assert planes.valid
+            b1p, b2p = np.float32(b1p * np.float32(0.9)), np.float32(b2p * np.float32(0.999))
+        torch.cuda.synchronize()
+        return theta, m, v, grad, scal.clone(), planes
+    a, b = run(False), run(True)
+    assert not torch.isnan(a[0]).any() and float(a[4][H.S_ERROR]) == 0.0
+    for x, y, name in zip(a[:5], b[:5], ('theta', 'm', 'v', 'grad', 'scalars')):
+        assert torch.equal(x, y), name
+    # the planes of every head a side projects through: written by the fused tail in `a`, by the stand-alone Adam in `b`
+    lay = H.layout(sh)
+    heads = {'pcd': (lay.enc[0].proto, lay.enc[1].outputs), 'monomer': (lay.enc[0].outputs, lay.enc[1].proto),
+             'siamese': (lay.enc[0].outputs,)}[dist]
+    for h in heads:
+        lo, hi = 3 * h.w, 3 * (h.w + h.npad * D)
+        assert torch.equal(a[5].buf[lo:hi], b[5].buf[lo:hi]), 'kept planes differ'
+
+
+def test_standalone_adam_writes_the_planes_of_every_weight_matrix():
+    """directed encoders: four weight matrices, two of them used by no side -- their planes are written all the same, and
+    equal the per-call split (cfl_wplanes_kernel through a stale buffer) bit for bit"""
+    rng = np.random.RandomState(2)
+    D, L, K = 512, 12, 3
+    sh = H.make_shape(D, L, K, 'pcd', True, True, None, True)
+    lay = H.layout(sh)
+    n = lay.total
+    theta = torch.from_numpy(rng.randn(n).astype(np.float32) * 0.1).cuda()
+    m, v = torch.zeros_like(theta), torch.zeros_like(theta)
+    grad = torch.from_numpy(rng.randn(n).astype(np.float32)).cuda()
+    planes = H.ThetaPlanes(sh, 'cuda')
+    planes.buf.fill_(0x7fc0)
+    before = theta.clone()
+    H.adam_tf_planes(sh, theta, m, v, grad, 1e-3, 0.9, 0.999, grad_scale=0.5, planes=planes)
+    t2, m2, v2 = before.clone(), torch.zeros_like(theta), torch.zeros_like(theta)
+    H.adam_tf(t2, m2, v2, grad, 1e-3, 0.9, 0.999, grad_scale=0.5)
+    assert torch.equal(theta, t2) and torch.equal(m, m2) and torch.equal(v, v2)
+    assert planes.valid
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import test_planes_and_errors_gpu as T
+    _host_planes = T._host_planes
+    T.H = H
+    th = theta.cpu().numpy()
+    got = planes.buf.cpu().numpy().view(np.uint16)
+    for e in range(2):
+        for h in (lay.enc[e].outputs, lay.enc[e].proto):
+            want = _host_planes(th, h, D)
+            assert np.array_equal(got[3 * h.w:3 * h.w + want.size], want), (e, h.w)
+    # nothing outside the weight matrices was touched
+    mask = np.ones(got.size, bool)
+    for e in range(2):
+        for h in (lay.enc[e].outputs, lay.enc[e].proto):
+            mask[3 * h.w:3 * (h.w + h.npad * D)] = False
+    assert (got[mask] == 0x7fc0).all()
+
+
+_ONE_RANK = r'''
+import os, sys
+sys.path[:0] = [%(root)r, os.path.join(%(root)r, 'compatibility-family-learning_amd')]
+os.environ['CFL_FORCE_DP'] = '1'
+os.environ['MASTER_PORT'] = %(port)r
+import numpy as np, torch
+import torch.distributed as dist
+from cfl import engine, hipabi as H
+from cfl.engine import PairEngine
+from oracle import cfl_oracle as O
+assert engine.init_from_env() == 1 and dist.is_initialized() and dist.get_backend() == 'nccl'
+assert engine.dp_active()
+rng = np.random.RandomState(0)
+D, L, K, B = 4096, 20, 3, 512
+cfg = O.EncoderCfg(D=D, L=L, K=K)
+p = O.init_encoder_params(cfg, rng, np.float32)
+mk = lambda: PairEngine(D, L, K, 'pcd', norm=H.make_norm(1 / 58.388599), loss=H.make_loss(), lr=1e-3, device='cuda', params=p, batch_size=B)
+dp, one = mk(), mk()
+pool = [[torch.from_numpy((np.abs(rng.randn(B, D)) * 13.0).astype(np.float32)).cuda() for _ in range(4)] for _ in range(3)]
+table = torch.cat([x for b in pool for x in b])
+worst = 0.0
+for i in range(60):
+    if i %% 2:
+        idx = [torch.arange(B, dtype=torch.int32, device='cuda') + (4 * (i %% 3) + k) * B for k in range(4)]
+        batch = (table, H.IndexStreams.from_tensors(idx))
+    else:
+        batch = pool[i %% 3]
+    os.environ['CFL_FORCE_DP'] = '1'
+    dp.step(batch)                       # proj_bx3 -> mid -> grad | RCCL all-reduce of gradbuf | Adam + planes
+    os.environ['CFL_FORCE_DP'] = '0'
+    one.step(batch)                      # the fused single-GPU step
+    assert dp.planes.valid and one.planes.valid
+    worst = max(worst, float((dp.theta - one.theta).abs().max()))
+    a, b = dp.read_scalars(), one.read_scalars()
+    worst = max(worst, max(abs(a[k] - b[k]) / max(1.0, abs(b[k])) for k in a))
+os.environ['CFL_FORCE_DP'] = '1'
+H.profile_enable(True)
+for i in range(20):
+    dp.step(pool[i %% 3])
+torch.cuda.synchronize()
+H.profile_enable(False)
+prof = H.profile_read()
+print('RESULT', worst, bool(torch.equal(dp.theta[:1], dp.theta[:1])), sorted(prof), flush=True)
+engine.finalize()
+'''
+
+
+def test_dp_branch_on_a_one_rank_rccl_group_equals_the_fused_step():
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', MASTER_ADDR='127.0.0.1')
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'CFL_DIST_BACKEND'):
+        env.pop(k, None)
+    code = _ONE_RANK % dict(root=ROOT, port=str(35500 + os.getpid() % 2000))
+    r = subprocess.run([sys.executable, '-c', code], env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith('RESULT')][-1].split(None, 3)
+    worst = float(line[1])
+    assert worst <= 2e-6, worst
+    kinds = eval(line[3])
+    # 3 compute launches + the stand-alone Adam; no per-call plane split (colnorm slot), no finalize
+    assert kinds == ['adam', 'grad', 'mid', 'proj'], kinds
