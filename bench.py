@@ -701,21 +701,13 @@ def main():
         step_traffic = sum(v for k, v in traffic_all.items() if k in ('proj', 'mid', 'grad', 'finalize') and
                            isinstance(v, (int, float))) or None
         P_params = D * L * (K + 1) + L * (K + 1) + 1
-        # (the library picks the forms per shape.  Weight gradient: 32-d tiles when D/32 x jobs >= 256 workgroups -- without a
-        # row split up to 2048 rows per side, the headline shape; rows split in two up to 6144 --, else 64-d tiles with row
-        # ranges.  Projection of the fused single-GPU step: bf16x3 on kept planes, chunk-at-a-time below 3072 rows per side)
-        exact = os.environ.get('CFL_EXACT_FP32', '0') not in ('', '0')
-        if dom == 'grad':
-            kname = 'cfl_grad_kernel' if exact else (
-                (('cfl_grad_x3_half_w8_kernel' if (3 * B + 255) // 256 * 256 % 512 == 0 and
-                  os.environ.get('CFL_DEBUG_GRAD_W8', '0') != '-1' else 'cfl_grad_x3_half_kernel')
-                 if 2 * B <= 2048 else 'cfl_grad_x3_half_split_kernel' if 2 * B <= 6144
-                 else 'cfl_grad_x3_kernel') if 256 <= (D // 32) * 2 <= 640 else 'cfl_grad_x3_kernel')
-        else:
-            kname = 'cfl_proj_kernel' if (exact or world > 1) else ('cfl_proj_bx3_kernel' if 2 * B < 3072 else 'cfl_proj_x3_keep_kernel')
+        # kernel names from the library's own planner (cfl_plan_describe): ONE dispatch truth
+        plan = H.plan_describe(eng.shape, B, 2, True, True)
+        kname = plan['grad'] if dom == 'grad' else plan['proj']
         rp_us = _rocprof_avg_us(kname)
         out['roofline'] = {
             'kernel': kname,
+            'plan': plan,
             # the committed rocprofv3 average of the same kernel (profiles/kernel_stats.csv, builder box) and the fraction it
             # gives: the event-timed `frac` below is lower because the event pairs perturb the stream (see `timing`)
             'rocprof_avg_us': rp_us,

@@ -66,6 +66,13 @@ class CflThetaPlanes(C.Structure):
     _fields_ = [('buf', C.c_void_p), ('valid', C.c_int32)]
 
 
+class CflPlanInfo(C.Structure):
+    _fields_ = ([(n, C.c_char * 40) for n in ('proj', 'mid', 'grad', 'tail')] +
+                [(n, C.c_int32) for n in ('launches', 'per_call_plane_split', 'S', 'P', 'rows_padded', 'column_jobs',
+                                          'proj_tile_rows', 'proj_workgroups', 'grad_tile_d', 'grad_workgroups',
+                                          'grad_waves', 'fused_tail', 'reads_planes', 'xcd_aligned')])
+
+
 class CflConv(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ('B', 'H', 'W', 'Ci', 'Co', 'KH', 'KW', 'stride', 'act')]
 
@@ -81,7 +88,7 @@ EXPORTS = ('cfl_version', 'cfl_last_error', 'cfl_layout', 'cfl_workspace_bytes',
            'cfl_dp_rs_push', 'cfl_dp_rs_adam', 'cfl_dp_rs_gather',
            'cfl_scalars_status', 'cfl_theta_planes_bytes', 'cfl_pair_train_step_planes', 'cfl_pair_train_step_idx_planes',
            'cfl_pair_train_steps_idx_planes', 'cfl_pair_step_fwd_bwd_planes', 'cfl_pair_step_fwd_bwd_idx_planes',
-           'cfl_adam_tf_planes', 'cfl_dp_rs_gather_planes')
+           'cfl_adam_tf_planes', 'cfl_dp_rs_gather_planes', 'cfl_plan_describe')
 
 KERNEL_NAMES = ('colnorm', 'proj', 'mid', 'grad', 'finalize', 'adam', 'gather')
 K_COUNT = 8
@@ -132,6 +139,9 @@ def lib():
     L.cfl_pair_train_step_planes.restype = C.c_int
     L.cfl_theta_planes_bytes.argtypes = [C.POINTER(CflShape)]
     L.cfl_theta_planes_bytes.restype = C.c_size_t
+    L.cfl_plan_describe.argtypes = [C.POINTER(CflShape), C.c_int64, C.c_int32, C.c_int32, C.c_int32,
+                                    C.POINTER(CflPlanInfo)]
+    L.cfl_plan_describe.restype = C.c_int
     L.cfl_scalars_status.argtypes = [C.c_void_p]
     L.cfl_scalars_status.restype = C.c_int
     L.cfl_pair_scores_idx.argtypes = [
@@ -278,6 +288,19 @@ def layout(shape):
     lay = CflLayout()
     _check(lib().cfl_layout(C.byref(shape), C.byref(lay)))
     return lay
+
+
+def plan_describe(shape, rows, groups=2, train=True, planes_kept=True):
+    """The kernels and launch geometry of a call of this shape, from the library's own planner (cfl_plan_describe):
+    a dict of kernel names (proj / mid / grad / tail) and integers (launches, S, P, workgroups, ...).  Host-only."""
+    info = CflPlanInfo()
+    _check(lib().cfl_plan_describe(C.byref(shape), int(rows), int(groups), int(bool(train)), int(bool(planes_kept)),
+                                   C.byref(info)))
+    out = {}
+    for name, _ in CflPlanInfo._fields_:
+        v = getattr(info, name)
+        out[name] = v.decode() if isinstance(v, bytes) else int(v)
+    return out
 
 
 def workspace_bytes(shape, rows, groups):

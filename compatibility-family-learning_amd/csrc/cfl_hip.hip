@@ -398,16 +398,13 @@ struct ProjArgs {
     RowSrc rows[2];
     int B, R, Rpad, D, S;
     int xcd;  // 1: blockIdx.x enumerates the d slices (see cfl_xcd_aligned)
-    int mix, mixjobs, mixtiles;   // streaming form, S == 1: 1-d grid, jobs dealt in groups of 8 (proj_stream_kernel_body)
     NormDev norm;
     int njobs;            // z-slices [0, njobs) project; slice njobs (weight-norm only) computes the column norms
     ColnormArgs cn;
 };
 
-// FOLD (cfl_proj_mid_kernel): the partial tile is PUBLISHED -- written through (sc1) as whole 1 KiB C/D fragments into
-// the fold layout (fold_off), the storing wave drains -- instead of stored row-major; (rowtile, s) come from the caller.
-template <int NT, bool FOLD = false>
-__device__ __forceinline__ void proj_body(const ProjJob &jb, const ProjArgs &a, f32x4 *lds, int rowtile = -1, int sl = -1) {
+template <int NT>
+__device__ __forceinline__ void proj_body(const ProjJob &jb, const ProjArgs &a, f32x4 *lds) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // provably uniform
     const int r16 = lane & 15, q4 = lane >> 4;  // MFMA: row / k index
@@ -415,8 +412,8 @@ __device__ __forceinline__ void proj_body(const ProjJob &jb, const ProjArgs &a, 
     // Workgroups are dealt to the 8 XCDs round-robin by linear id.  With the d slices fastest an XCD
     // only ever touches 1/8 of the weights (one slice of every column tile) and one d band of x --
     // the same band the weight-gradient launch assigns to it, so part of x is still in that XCD's L2.
-    const int row0 = (FOLD ? rowtile : (a.xcd ? blockIdx.y : blockIdx.x)) * 32;
-    const int s = FOLD ? sl : (a.xcd ? blockIdx.x : blockIdx.y);
+    const int row0 = (a.xcd ? blockIdx.y : blockIdx.x) * 32;
+    const int s = a.xcd ? blockIdx.x : blockIdx.y;
     const int G = a.D >> 4;           // 16-d groups
     const int NC = (G + 7) >> 3;      // 128-d chunks
     const int nw = a.S * 4, wg = s * 4 + wave;
@@ -524,29 +521,6 @@ __device__ __forceinline__ void proj_body(const ProjJob &jb, const ProjArgs &a, 
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) lds[(wave * 2 * NT + mt * NT + nt) * 64 + lane] = acc[mt][nt];
     __syncthreads();
-    if (FOLD) {
-        // a wave owns tiles t = wave and wave + 4 (< 2 NT <= 8): both published by ONE statement that ends with its
-        // own drain (store4_sc1_wait explains why stores and wait must not be separate asm statements)
-        f32x4 sum[2];
-        float *dst[2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int t = wave + 4 * i;
-            const int tt = t < 2 * NT ? t : 0;
-            const int mt = tt / NT, nt = tt % NT;
-            sum[i] = lds[(0 * 2 * NT + tt) * 64 + lane];
-#pragma unroll
-            for (int w = 1; w < 4; ++w) sum[i] += lds[(w * 2 * NT + tt) * 64 + lane];
-            dst[i] = jb.ypart + (size_t)s * jb.sstride +
-                     ((size_t)((row0 >> 5) * 2 + mt) * (jb.npad >> 4) + nt) * 256 + lane * 4;
-        }
-        if (wave + 4 < 2 * NT)
-            asm volatile("global_store_dwordx4 %0, %1, off sc1\n\tglobal_store_dwordx4 %2, %3, off sc1\n\ts_waitcnt vmcnt(0)"
-                         :: "v"(dst[0]), "v"(sum[0]), "v"(dst[1]), "v"(sum[1]) : "memory");
-        else if (wave < 2 * NT)
-            asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" :: "v"(dst[0]), "v"(sum[0]) : "memory");
-        return;
-    }
     for (int t = wave; t < 2 * NT; t += 4) {
         const int mt = t / NT, nt = t % NT;
         f32x4 sum = lds[(0 * 2 * NT + t) * 64 + lane];
@@ -581,28 +555,28 @@ __device__ __forceinline__ void proj_body(const ProjJob &jb, const ProjArgs &a, 
 // Selected by the plan when the caller keeps planes (the fused single-GPU training step); every other call keeps the
 // exact-fp32 kernel.
 // ---------------------------------------------------------------------------
-template <int NT, int MT = 2>   // MT = 16-row blocks per wave: 2 = the 32-row tiles of every plan; 1 = the 16-row experiment (CFL_DEBUG_PROJ_ROWS16)
+template <int NT>
 __device__ __forceinline__ void proj_body_bx3(const ProjJob &jb, const ProjArgs &a, f32x4 *lds) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i16 = lane & 15, kq = lane >> 4;
     const int rr8 = lane >> 3, ch8 = lane & 7;
-    const int row0 = (a.xcd ? blockIdx.y : blockIdx.x) * (16 * MT);
+    const int row0 = (a.xcd ? blockIdx.y : blockIdx.x) * 32;
     const int s = a.xcd ? blockIdx.x : blockIdx.y;
     const int G = a.D >> 4, Q = a.D >> 5;
     const int NC = (G + 7) >> 3;
     const int nw = a.S * 4, wg = s * 4 + wave;
     const int cbeg = wg * NC / nw, cend = (wg + 1) * NC / nw;
 
-    f32x4 acc[MT][NT];
+    f32x4 acc[2][NT];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+    for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const float *xrow[2 * MT];
+    const float *xrow[4];
 #pragma unroll
-    for (int i = 0; i < 2 * MT; ++i) xrow[i] = row_ptr(a.rows[jb.side], row0 + 8 * i + rr8, a.B, a.R, a.D) + 4 * ch8;
+    for (int i = 0; i < 4; ++i) xrow[i] = row_ptr(a.rows[jb.side], row0 + 8 * i + rr8, a.B, a.R, a.D) + 4 * ch8;
     const unsigned short *pll = (const unsigned short *)jb.wf + lane * 8;   // planes of this job's first column tile
     f32x4 *tile = lds + wave * 256;
 
@@ -610,7 +584,7 @@ __device__ __forceinline__ void proj_body_bx3(const ProjJob &jb, const ProjArgs 
         const int t0 = c * 4;                      // first 32-d quarter of the chunk
         const bool full = Q - t0 >= 4;             // otherwise 2 quarters (D % 64 == 0)
         bf16x8 bq[2][NT][3];
-        f32x4 araw[4][2 * MT];
+        f32x4 araw[4][4];
         auto loadB = [&](int qq, bf16x8 (*dst)[3]) {
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
@@ -620,7 +594,7 @@ __device__ __forceinline__ void proj_body_bx3(const ProjJob &jb, const ProjArgs 
         };
         auto loadA = [&](int qq) {
 #pragma unroll
-            for (int i = 0; i < 2 * MT; ++i) araw[qq][i] = *(const f32x4 *)(xrow[i] + (t0 + qq) * 32);
+            for (int i = 0; i < 4; ++i) araw[qq][i] = *(const f32x4 *)(xrow[i] + (t0 + qq) * 32);
         };
         loadB(0, bq[0]);
         __builtin_amdgcn_sched_barrier(0);
@@ -640,13 +614,13 @@ __device__ __forceinline__ void proj_body_bx3(const ProjJob &jb, const ProjArgs 
         for (int qq = 0; qq < 4; ++qq) {
             if (qq >= 2 && !full) break;
 #pragma unroll
-            for (int i = 0; i < 2 * MT; ++i) {
+            for (int i = 0; i < 4; ++i) {
                 const int row = 8 * i + rr8;
                 tile[row * 8 + (ch8 ^ (row & 7))] = norm_apply(araw[qq][i], a.norm, (t0 + qq) * 32 + 4 * ch8);
             }
-            bf16x8 af[MT][3];
+            bf16x8 af[2][3];
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
+            for (int mt = 0; mt < 2; ++mt) {
                 const int row = mt * 16 + i16;
                 const f32x4 c0 = tile[row * 8 + ((2 * kq) ^ (row & 7))], c1 = tile[row * 8 + ((2 * kq + 1) ^ (row & 7))];
                 float v[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
@@ -658,7 +632,7 @@ __device__ __forceinline__ void proj_body_bx3(const ProjJob &jb, const ProjArgs 
             }
             // six partial products, small terms first; consecutive MFMAs hit different accumulators
 #define CFL_BX3(LA, LB)                                                                                       \
-    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = \
+    _Pragma("unroll") for (int mt = 0; mt < 2; ++mt) _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = \
         __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mt][LA], bq[qq & 1][nt][LB], acc[mt][nt], 0, 0, 0);
             CFL_BX3(1, 1) CFL_BX3(2, 0) CFL_BX3(0, 2) CFL_BX3(1, 0) CFL_BX3(0, 1) CFL_BX3(0, 0)
 #undef CFL_BX3
@@ -669,15 +643,15 @@ __device__ __forceinline__ void proj_body_bx3(const ProjJob &jb, const ProjArgs 
     // cross-wave sum and slab store: identical to proj_body
     __syncthreads();
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+    for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) lds[(wave * MT * NT + mt * NT + nt) * 64 + lane] = acc[mt][nt];
+        for (int nt = 0; nt < NT; ++nt) lds[(wave * 2 * NT + mt * NT + nt) * 64 + lane] = acc[mt][nt];
     __syncthreads();
-    for (int t = wave; t < MT * NT; t += 4) {
+    for (int t = wave; t < 2 * NT; t += 4) {
         const int mt = t / NT, nt = t % NT;
-        f32x4 sum = lds[(0 * MT * NT + t) * 64 + lane];
+        f32x4 sum = lds[(0 * 2 * NT + t) * 64 + lane];
 #pragma unroll
-        for (int w = 1; w < 4; ++w) sum += lds[(w * MT * NT + t) * 64 + lane];
+        for (int w = 1; w < 4; ++w) sum += lds[(w * 2 * NT + t) * 64 + lane];
         float *dst = jb.ypart + (size_t)s * jb.sstride + (size_t)(row0 + mt * 16 + 4 * kq) * jb.npad + nt * 16 + i16;
 #pragma unroll
         for (int e = 0; e < 4; ++e) dst[(size_t)e * jb.npad] = sum[e];
@@ -698,8 +672,6 @@ __device__ __forceinline__ void proj_body_bx3(const ProjJob &jb, const ProjArgs 
 // which nothing was issued and drains the queue (s_waitcnt vmcnt(0)) in front of every quarter -- measured: no
 // gain at all over proj_body.  Arithmetic, accumulation order and output are those of proj_body bit for bit
 // (k-ordered fp32 FMA chains per wave, waves summed in wave order).
-//   MIX: workgroups of all column jobs are dealt in groups of 8 (one per XCD) over ONE grid dimension, so that the
-//   co-resident workgroups of a CU are a mix of wide (64-column) and narrow jobs.
 // ---------------------------------------------------------------------------
 template <int NT>
 __device__ __forceinline__ void proj_stream_body(const ProjJob &jb, const ProjArgs &a, f32x4 *lds, int rowtile) {
@@ -708,7 +680,7 @@ __device__ __forceinline__ void proj_stream_body(const ProjJob &jb, const ProjAr
     const int r16 = lane & 15, q4 = lane >> 4;
     const int rr8 = lane >> 3, ch8 = lane & 7;
     const int row0 = rowtile * 32;
-    const int s = a.mix ? 0 : (a.xcd ? blockIdx.x : blockIdx.y);
+    const int s = a.xcd ? blockIdx.x : blockIdx.y;
     const int G = a.D >> 4;
     const int NC = (G + 7) >> 3;
     const int nw = a.S * 4, wg = s * 4 + wave;
@@ -844,20 +816,11 @@ __device__ __forceinline__ void proj_stream_body(const ProjJob &jb, const ProjAr
 extern "C" __global__ __launch_bounds__(256) void cfl_proj_stream_kernel(ProjArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     f32x4 *lds = (f32x4 *)smem;
-    int z = blockIdx.z, rowtile = a.xcd ? blockIdx.y : blockIdx.x;
-    if (a.mix) {
-        // linear id -> (job, row tile): groups of 8 consecutive workgroups (one per XCD) share a job
-        const int id = blockIdx.x, nz = a.mixjobs;
-        z = (id >> 3) % nz;
-        rowtile = (id / (8 * nz)) * 8 + (id & 7);
-        if (rowtile * 32 >= a.R && a.job[z].nt != 0) return;
-    }
-    const ProjJob &jb = a.job[z];
+    const int rowtile = a.xcd ? blockIdx.y : blockIdx.x;
+    const ProjJob &jb = a.job[blockIdx.z];
     switch (jb.nt) {
         case 0: {
-            const int nb = a.mix ? a.mixtiles : gridDim.x * gridDim.y;
-            const int b0 = a.mix ? rowtile : blockIdx.y * gridDim.x + blockIdx.x;
-            colnorm_columns(a.cn, b0, nb);
+            colnorm_columns(a.cn, (int)(blockIdx.y * gridDim.x + blockIdx.x), gridDim.x * gridDim.y);
             break;
         }
         case 1: proj_stream_body<1>(jb, a, lds, rowtile); break;
@@ -867,275 +830,11 @@ extern "C" __global__ __launch_bounds__(256) void cfl_proj_stream_kernel(ProjArg
     }
 }
 
-// ---------------------------------------------------------------------------
-// proj, ring form (large row counts: rows per side >= 2048, every dist_eval / dist_predict call).
-// Counters of the streaming form above on a dist_eval call (profiles/r03_a_*): the matrix pipe is busy 40 % of
-// the launch while the waves spend 77 % of their cycles stalled AT ISSUE (SQ_WAIT_INST_ANY) -- not in s_waitcnt.
-// A wave that both loads and multiplies is in-order: when the vector-memory path is backed up (16 KiB of x in
-// flight per wave, and every wave fetching its own W fragments from L2: 2 bytes of W per byte of x) its next
-// load sits at issue and the MFMAs behind it cannot start.  Ablations say the same: loads alone 62 us, MFMAs +
-// W alone 58 us, together 82 us.  So loading and multiplying are separated:
-//   workgroup = 8 waves: 4 LOADER waves + 4 CONSUMER waves (one of each per SIMD), one workgroup per CU;
-//   work unit  = (column job, 128-row tile, d slice): consumer j owns rows 32j .. 32j+31 of the tile for the whole
-//                slice (no cross-wave sum), the 4 consumers share the W fragments of a step through LDS (a
-//                quarter of the L2 -> CU traffic of the per-wave fetches);
-//   step       = 64 d (two 32-d quarters).  A ring of RING_SLOTS slots in LDS, slot = [2 x 4 x (32 rows x 32 d) |
-//                4*NT W blocks]; everything arrives by LDS-DMA (global_load_lds_dwordx4: no VGPRs, no ds_write):
-//                x in 8-row x 128-B pieces whose per-lane SOURCE address is pre-swizzled so that the lane-linear
-//                LDS image is the XOR-swizzled A-fragment tile of proj_body; W blocks are already fragment-major
-//                (1 KiB = one piece, read back lane-linear);
-//   protocol   = per step: loaders issue the pieces of step t + 2 into the slot the consumers left at the previous
-//                barrier, wait (counted vmcnt) until step t + 1 has landed, barrier; consumers read the fragments
-//                of step t (ds_read_b128, all requested up front, consumed progressively), multiply, barrier.
-//                One step (48 KiB per CU) stays in flight across every barrier; a consumer never issues a
-//                vector-memory instruction in the loop.  A loader issues 8 + NT pieces per step.
-//   A workgroup walks up to RING_UNITS units as ONE stream of steps (the ring runs across the seams); units are
-//   dealt heavy-to-light in snake order, so every workgroup gets the same mix of wide and narrow jobs.
-// Arithmetic per output element: the same k-ordered fp32 FMA chain as proj_body over the wave's d range; a d slice
-// is summed by one wave here (by four in proj_body), so results differ from the other forms by fp32 rounding of
-// the slice sums only.
-// ---------------------------------------------------------------------------
-#define RING_SLOTS 3
-#define RING_UNITS 4
-#define RING_SLOT_FLOATS (12 * 1024)           // 32 KiB of x + 16 KiB of W
-#define RING_LDS_BYTES (RING_SLOTS * RING_SLOT_FLOATS * 4)
-
-struct RingArgs {
-    ProjJob job[CFL_MAX_JOBS];
-    int order[CFL_MAX_JOBS];   // job indices, widest first
-    RowSrc rows[2];
-    int B, R, D, S, njobs;
-    int tiles, nunits, nwg, Kh;   // 128-row tiles per side, units = njobs * tiles * S, workgroups, 64-d steps per slice
-    int dbg;                      // CFL_DEBUG_RING_ABL (timing experiments only): 1 no x pieces, 2 no W pieces, 4 no MFMAs
-    NormDev norm;
-};
-
 // one 1 KiB LDS-DMA piece: lane l's 16 bytes at gsrc land at lds_dst + 16 l (lds_dst wave-uniform byte address)
 __device__ __forceinline__ void glds16(const float *gsrc, unsigned lds_dst) {
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
-}
-// wait until at most `pieces` (9 .. 12: the pieces of ONE step) of this wave's DMA pieces are outstanding
-__device__ __forceinline__ void ring_wait_all_but(int pieces) {
-    switch (pieces) {
-        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
-        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
-        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-        case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
-        case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
-        case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
-        case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
-        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-    }
-}
-
-__device__ __forceinline__ void ring_unit_of(const RingArgs &a, int uid, int &job, int &tile, int &slice) {
-    const int per_job = a.tiles * a.S;
-    job = a.order[uid / per_job];
-    const int rem = uid % per_job;
-    tile = rem / a.S;
-    slice = rem % a.S;
-}
-// the i-th unit of workgroup w (snake order over the heavy-to-light list); -1: none
-__device__ __forceinline__ int ring_uid(const RingArgs &a, int w, int i) {
-    const int base = (i >> 1) * 2 * a.nwg;
-    const int uid = (i & 1) ? base + 2 * a.nwg - 1 - w : base + w;
-    return uid < a.nunits ? uid : -1;
-}
-
-template <int NT>
-__device__ __forceinline__ void ring_consume_unit(const RingArgs &a, const ProjJob &jb, int tile, int slice, int t0,
-                                                  const float *lds, int cj) {
-    const int lane = threadIdx.x & 63;
-    const int r16 = lane & 15, q4 = lane >> 4;
-    f32x4 acc[2][NT];
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const int d0 = slice * a.Kh * 64;
-    // Two fragment sets, one per 32-d half of a step: the reads of a half are in flight while the other half is
-    // multiplied, and the step's barrier sits between its two MFMA groups -- when it is reached both halves of the
-    // slot are in registers (the slot is free), and the first half of the NEXT step is requested right behind it.
-    f32x4 af[2][2][2], bq[2][2][NT];   // [set = half][..]
-    auto readh = [&](int slot, int h) {
-        const f32x4 *xs = (const f32x4 *)(lds + slot * RING_SLOT_FLOATS + (h * 4 + cj) * 1024);
-        const f32x4 *wsl = (const f32x4 *)(lds + slot * RING_SLOT_FLOATS + 8192 + h * 2 * NT * 256) + lane;
-#pragma unroll
-        for (int gg = 0; gg < 2; ++gg) {
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt) af[h][mt][gg] = xs[(mt * 16 + r16) * 8 + ((4 * gg + q4) ^ (r16 & 7))];
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) bq[h][gg][nt] = wsl[(gg * NT + nt) * 64];
-        }
-    };
-    auto mult = [&](int q, int h) {
-        if (a.norm.elementwise) {
-#pragma unroll
-            for (int gg = 0; gg < 2; ++gg)
-#pragma unroll
-                for (int mt = 0; mt < 2; ++mt)
-                    af[h][mt][gg] = norm_apply(af[h][mt][gg], a.norm, d0 + q * 64 + h * 32 + 4 * (4 * gg + q4));
-        }
-        if (a.dbg & 4) {   // timing experiments: fragments consumed, nothing multiplied
-#pragma unroll
-            for (int gg = 0; gg < 2; ++gg) {
-                asm volatile("" ::"v"(af[h][0][gg]), "v"(af[h][1][gg]));
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) asm volatile("" ::"v"(bq[h][gg][nt]));
-            }
-            return;
-        }
-#pragma unroll
-        for (int gg = 0; gg < 2; ++gg)
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-#pragma unroll
-                for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt)
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[h][mt][gg][e], bq[h][gg][nt][e], acc[mt][nt], 0, 0, 0);
-    };
-    readh(t0 % RING_SLOTS, 0);
-    for (int q = 0; q < a.Kh; ++q) {
-        const int slot = (t0 + q) % RING_SLOTS;
-        readh(slot, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        mult(q, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // both halves of the slot are in registers: it may be refilled
-        if (t0 == 0 && q == 0) RSTAMP(2);
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (q + 1 < a.Kh) readh((t0 + q + 1) % RING_SLOTS, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        mult(q, 1);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    if (t0 == 0) RSTAMP(3);
-    // C layout: col = lane & 15, rows 4 (lane >> 4) .. + 3  ->  Ypart[slice][row][npad]
-    const int row0 = tile * 128 + cj * 32;
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            float *dst = jb.ypart + (size_t)slice * jb.sstride + (size_t)(row0 + mt * 16 + 4 * q4) * jb.npad + nt * 16 + r16;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) dst[(size_t)e * jb.npad] = acc[mt][nt][e];
-        }
-}
-
-extern "C" __global__ __launch_bounds__(512) void cfl_proj_ring_kernel(RingArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const float *lds = (const float *)smem;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int w = blockIdx.x;
-    const int G = a.D >> 4;
-    int nu = 0;
-#pragma unroll
-    for (int i = 0; i < RING_UNITS; ++i) nu += ring_uid(a, w, i) >= 0 ? 1 : 0;   // units are a prefix (uid grows with i)
-    const int T = nu * a.Kh;
-
-    if (wave >= 4) {
-        // ---------------- loader wave lj: x rows 32 lj .. 32 lj + 31 of every unit's tile, W blocks lj + 4k ------------
-        const int lj = wave - 4;
-        const float *xp[RING_UNITS][4];
-        const float *wp[RING_UNITS][4];
-        int unt[RING_UNITS];
-        typedef __attribute__((address_space(3))) char lds_char;
-        const unsigned lds0 = (unsigned)(uintptr_t)(lds_char *)smem;   // LDS byte address of the ring
-#pragma unroll
-        for (int u = 0; u < RING_UNITS; ++u) {
-            int job = 0, tile = 0, slice = 0;
-            const int uid = ring_uid(a, w, u);
-            ring_unit_of(a, uid >= 0 ? uid : 0, job, tile, slice);
-            const ProjJob &jb = a.job[job];
-            const RowSrc rs = jb.side ? a.rows[1] : a.rows[0];
-            const int rr = lane >> 3, ch = (lane & 7) ^ (rr & 7);   // LDS position l <-> (row l >> 3, chunk (l & 7) ^ row)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                xp[u][i] = row_ptr(rs, tile * 128 + lj * 32 + 8 * i + rr, a.B, a.R, a.D) + slice * a.Kh * 64 + 4 * ch;
-            unt[u] = jb.nt;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int b = lj + 4 * k;                 // block b = (h * 2 + gg) * NT + nt of the step's W tile, b < 4 NT
-                const int hg = b / jb.nt, nt = b - hg * jb.nt;   // hg = 2 h + gg = the 16-d group inside the step
-                wp[u][k] = jb.wf + ((size_t)nt * G + 4 * slice * a.Kh + (hg & 3)) * 256 + lane * 4;
-            }
-        }
-        // the row pointers of an indexed source come from index loads: every ordinary load has returned before the
-        // first DMA piece is issued (none is issued after this point)
-        RSTAMP(0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        RSTAMP(1);
-        auto issue = [&](int t) -> int {   // returns the pieces issued
-            const int u = t / a.Kh, q = t - u * a.Kh;
-            const unsigned sb = lds0 + (unsigned)((t % RING_SLOTS) * RING_SLOT_FLOATS) * 4;
-            int n = 0;
-#pragma unroll
-            for (int uu = 0; uu < RING_UNITS; ++uu)
-                if (uu == u) {   // (static register indexing)
-                    if (!(a.dbg & 1)) {
-#pragma unroll
-                        for (int h = 0; h < 2; ++h)
-#pragma unroll
-                            for (int i = 0; i < 4; ++i)
-                                glds16(xp[uu][i] + q * 64 + h * 32, sb + ((h * 4 + lj) * 1024 + i * 256) * 4);
-                        n += 8;
-                    }
-                    if (!(a.dbg & 2)) {
-#pragma unroll
-                        for (int k = 0; k < 4; ++k)
-                            if (k < unt[uu]) glds16(wp[uu][k] + (size_t)q * 1024, sb + (8192 + (lj + 4 * k) * 256) * 4);
-                        n += unt[uu];
-                    }
-                }
-            return n;
-        };
-        int pend = 0;                       // pieces of the newest step issued
-        if (T > 0) pend = issue(0);
-        if (T > 1) pend = issue(1);
-        RSTAMP(2);
-        ring_wait_all_but(T > 1 ? pend : 0);   // step 0 has landed
-        RSTAMP(3);
-        __builtin_amdgcn_s_barrier();
-        for (int t = 0; t < T; ++t) {
-            // step t + 2 goes into the slot of step t - 1, which the consumers left at the last barrier
-            if (t + 2 < T) { pend = issue(t + 2); ring_wait_all_but(pend); }   // step t + 1 has landed
-            else ring_wait_all_but(0);
-            if (t == 0) RSTAMP(4);
-            if (t == a.Kh - 1) RSTAMP(5);
-            __builtin_amdgcn_s_barrier();
-            if (t == a.Kh - 1) RSTAMP(6);
-        }
-        RSTAMP(7);
-        return;
-    }
-
-    // ---------------- consumer wave cj ------------------------------------------------------------------------------
-    RSTAMP(0);
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    RSTAMP(1);
-    int t0 = 0;
-    for (int u = 0; u < nu; ++u) {
-        int job, tile, slice;
-        ring_unit_of(a, ring_uid(a, w, u), job, tile, slice);
-        const ProjJob &jb = a.job[job];
-        switch (jb.nt) {
-            case 1: ring_consume_unit<1>(a, jb, tile, slice, t0, lds, wave); break;
-            case 2: ring_consume_unit<2>(a, jb, tile, slice, t0, lds, wave); break;
-            case 3: ring_consume_unit<3>(a, jb, tile, slice, t0, lds, wave); break;
-            default: ring_consume_unit<4>(a, jb, tile, slice, t0, lds, wave); break;
-        }
-        t0 += a.Kh;
-        if (u == 0) RSTAMP(4);
-    }
-    RSTAMP(5);
 }
 
 // ---------------------------------------------------------------------------
@@ -1399,22 +1098,6 @@ extern "C" __global__ __launch_bounds__(256, 2) void cfl_proj_bx3_kernel(ProjArg
     }
 }
 
-// Round-4 experiment (CFL_DEBUG_PROJ_ROWS16=1 with CFL_DEBUG_S=4): 16-row tiles, twice as many row tiles, half
-// as many d slices -- each wave 16 rows x 2 chunks.  Halves the partial slabs `mid` sums, doubles the W-plane traffic per
-// row.  Measured: profiles/r04_rows16_ab.txt.
-extern "C" __global__ __launch_bounds__(256, 2) void cfl_proj_bx3_rows16_kernel(ProjArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    f32x4 *lds = (f32x4 *)smem;
-    const ProjJob &jb = a.job[blockIdx.z];
-    switch (jb.nt) {
-        case 0: colnorm_columns(a.cn, (int)(blockIdx.y * gridDim.x + blockIdx.x), gridDim.x * gridDim.y); break;
-        case 1: proj_body_bx3<1, 1>(jb, a, lds); break;
-        case 2: proj_body_bx3<2, 1>(jb, a, lds); break;
-        case 3: proj_body_bx3<3, 1>(jb, a, lds); break;
-        default: proj_body_bx3<4, 1>(jb, a, lds); break;
-    }
-}
-
 // ---------------------------------------------------------------------------
 // grad: Wpart[p] (Wf layout) = sum_{r in range p} X[r][d] * dY[r][c]
 //   workgroup = 4 waves, one 64-d tile and one row range; the waves split the range
@@ -1429,7 +1112,6 @@ extern "C" __global__ __launch_bounds__(256, 2) void cfl_proj_bx3_rows16_kernel(
 struct GradJob {
     int side;              // 0 = src rows, 1 = dst rows (GradArgs::rows)
     const float *dyf;      // dYf tile base: blocks [(nt)*RG + rg]
-    const unsigned short *dyp;   // plan.dy_pre: the job's first column tile inside the dL/dy planes written by mid (put_planes)
     float *wpart;          // Wf tile base inside slab 0; slabs are pstride apart
     long long pstride;     // floats between row-range slabs (npad * D)
     int nt;
@@ -1944,34 +1626,6 @@ __device__ __forceinline__ void fuse_apply1(const GradFuse &f, long long off, fl
     }
 }
 
-// In-launch producers (the row-math blocks of cfl_midgrad_half_kernel): flag words that carry the launch's generation.
-struct MgWait { const unsigned *flags; int n; unsigned gen; int early_x; int spin_limit; float *err; };
-
-// one wave polls all flags (sc1 loads, bounded), ONE agent-scope acquire, drain, workgroup barrier: plain loads of
-// what the producers wrote through are valid afterwards (MI355X_MICROARCH.md, Valid forms: consumer)
-__device__ __forceinline__ bool mg_wait_all(const MgWait &w, int *lds_i) {
-    if ((threadIdx.x >> 6) == 0) {
-        const int lane = threadIdx.x & 63;
-        int spins = 0, ok = 1;
-        for (;;) {
-            bool all = true;
-            for (int i = lane; i < w.n; i += 64)
-                all = all && __hip_atomic_load(w.flags + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == w.gen;
-            if (__builtin_amdgcn_ballot_w64(!all) == 0) break;
-            if (++spins > w.spin_limit) { ok = 0; break; }
-            __builtin_amdgcn_s_sleep(2);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) lds_i[0] = ok;
-        if (lane == 0 && !ok && w.err) *w.err = 1.f;   // sticky error word
-    }
-    __syncthreads();
-    const bool ok = lds_i[0] != 0;
-    __syncthreads();
-    return ok;
-}
-
 // column sums of tile `idx` of a fragment-major buffer (the whole workgroup): lane (kq, c16) adds its 4 rows; the
 // result is valid in lanes 0 .. 15 of wave 0.  `buf2` (dual ranges: side 0's tile of a shared head) is summed the same
 // way in the same pass and returned in *cs2.
@@ -2021,14 +1675,11 @@ __device__ __forceinline__ float tile_colsum(const float *buf, int idx, int RG, 
     return cs;
 }
 
-__device__ __forceinline__ void grad_red_block(const GradArgs &a, float *lds, const MgWait *mg = nullptr, int first = -1,
-                                               int nblocks = 0) {   // (forceinline: an out-of-line call takes the address of the argument block, which then lives in scratch)
+__device__ __forceinline__ void grad_red_block(const GradArgs &a, float *lds) {   // (forceinline: an out-of-line call takes the address of the argument block, which then lives in scratch)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // mg: the row math runs in this launch; its outputs are complete once every producer's flag carries the generation
-    const bool mg_ok = mg ? mg_wait_all(*mg, (int *)lds + 512) : true;
-    const int nblk = first >= 0 ? nblocks : gridDim.x * gridDim.y;
+    const int nblk = gridDim.x * gridDim.y;
     const int RG = a.Rpad >> 4;
-    for (int job = first >= 0 ? first : blockIdx.y * gridDim.x + blockIdx.x; job < a.red_total; job += nblk) {
+    for (int job = blockIdx.y * gridDim.x + blockIdx.x; job < a.red_total; job += nblk) {
         int k = 0, idx = job;
         while (k < a.nred - 1 && idx >= a.red[k].count) { idx -= a.red[k].count; ++k; }
         const RedRange &rr = a.red[k];
@@ -2075,7 +1726,6 @@ __device__ __forceinline__ void grad_red_block(const GradArgs &a, float *lds, co
                         if (lane == 0)
                             write_scalars(f.scalars, lds + 64, 0.5f * f.reg_const * rs, f.B, f.use_threshold,
                                           f.pos_weight, f.caffe_margin, f.lambda_m, f.thr_copy[0]);
-                        if (lane == 0 && !mg_ok) f.scalars[CFL_S_TOTAL] = NAN;   // lost in-launch hand-off: loud, not silent
                     }
                 } else if (f.red_b[k] >= 0 && wave == 0) {
                     const int c = idx * 16 + lane;
@@ -2351,10 +2001,9 @@ __device__ __forceinline__ void grad_body_x3(const GradJob &jb, const GradArgs &
 // ---------------------------------------------------------------------------
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-template <int NT, bool HO, bool PRE = false, int NW = 4>   // NW: waves per workgroup (8: experiment, two waves per SIMD); HO: row split and / or siamese pairing (hand-off tail); false: the tile is complete in the workgroup
-                                               // PRE: dL/dy arrives as bf16 planes written by mid (GradJob::dyp): no split of it here
+template <int NT, bool HO, int NW = 4>   // NW: waves per workgroup (8: two waves per SIMD); HO: row split and / or siamese pairing (hand-off tail); false: the tile is complete in the workgroup
 __device__ __forceinline__ void grad_body_x3_half(const GradJob &jb, const GradArgs &a, f32x4 *lds, int job, int dtile,
-                                                  int p, const MgWait *mg = nullptr) {
+                                                  int p) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i16 = lane & 15, kq = lane >> 4;
@@ -2383,21 +2032,7 @@ __device__ __forceinline__ void grad_body_x3_half(const GradJob &jb, const GradA
     const float *dyl = jb.dyf + ((size_t)(kq >> 1) * 256 + (2 * (kq & 1) * 16 + i16) * 4);
     const RowSrc rs = jb.side ? a.rows[1] : a.rows[0];
     const long long *lrow = (const long long *)lds;   // row addresses of the whole batch, staged once (grad_body_x3)
-    const unsigned short *dypl = PRE ? jb.dyp + lane * 8 : nullptr;
-    const int RG2 = a.Rpad >> 5;
-    bf16x8 dyq[2][NT][3];   // PRE: the planes themselves
     auto loaddy = [&](int p0, f32x4 (*dyr)[NT][2]) {
-        if (PRE) {
-#pragma unroll
-            for (int r2 = 0; r2 < 2; ++r2)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                    for (int pl = 0; pl < 3; ++pl)
-                        dyq[r2][nt][pl] = *(const bf16x8 *)(dypl + (((size_t)nt * RG2 + (p0 >> 5) + r2) * 3 + pl) * 512);
-            __builtin_amdgcn_sched_barrier(0);
-            return;
-        }
 #pragma unroll
         for (int r2 = 0; r2 < 2; ++r2)
 #pragma unroll
@@ -2411,15 +2046,13 @@ __device__ __forceinline__ void grad_body_x3_half(const GradJob &jb, const GradA
     // the first chunk's dL/dy does not depend on the row addresses: requested before they are staged, so that its
     // latency overlaps the index loads of the indexed entry points (and the staging barrier)
     f32x4 dyr[2][NT][2];
-    if (!mg && rbeg < rstop) loaddy(rbeg, dyr);
+    if (rbeg < rstop) loaddy(rbeg, dyr);
     {
         // every wave stages the addresses of ITS rows only: LDS operations of one wave are ordered, no workgroup barrier
         long long *w = (long long *)lds;
         for (int r = rbeg + lane; r < rend; r += 64) w[r] = row_ptr(rs, r, a.B, a.R, a.D) - rs.x0;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
-    bool mg_lost = false;
-    f32x2 xfirst[2][8];
     auto loadx = [&](int p0, f32x2 (*dst)[8]) {
 #pragma unroll
         for (int r2 = 0; r2 < 2; ++r2) {
@@ -2432,38 +2065,19 @@ __device__ __forceinline__ void grad_body_x3_half(const GradJob &jb, const GradA
             __builtin_amdgcn_sched_barrier(0);
         }
     };
-    if (mg) {
-        // the row math runs in this launch (cfl_midgrad_half_kernel): x does not depend on it -- the first chunk's x
-        // is requested BEFORE waiting for dL/dY, so the wait overlaps the arrival of x
-        if (mg->early_x && rbeg < rstop) loadx(rbeg, xfirst);
-        mg_lost = !mg_wait_all(*mg, (int *)lds + 8192);   // (behind the staged addresses: <= 4096 rows x 8 bytes)
-        if (!mg->early_x && rbeg < rstop) loadx(rbeg, xfirst);
-    }
     for (int p0 = rbeg; p0 < rstop; p0 += 64) {
         f32x2 xr[2][8];
-        if (mg || p0 != rbeg) loaddy(p0, dyr);
-        if (mg && p0 == rbeg) {
-#pragma unroll
-            for (int r2 = 0; r2 < 2; ++r2)
-#pragma unroll
-                for (int jj = 0; jj < 8; ++jj) xr[r2][jj] = xfirst[r2][jj];
-        } else {
-            loadx(p0, xr);
-        }
+        if (p0 != rbeg) loaddy(p0, dyr);
+        loadx(p0, xr);
 #pragma unroll
         for (int r2 = 0; r2 < 2; ++r2) {
             bf16x8 bf[NT][3];
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                if (PRE) {
+                float v[8];
 #pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) bf[nt][pl] = dyq[r2][nt][pl];
-                } else {
-                    float v[8];
-#pragma unroll
-                    for (int jj = 0; jj < 8; ++jj) v[jj] = dyr[r2][nt][jj >> 2][jj & 3];
-                    split_frag(v, bf[nt]);
-                }
+                for (int jj = 0; jj < 8; ++jj) v[jj] = dyr[r2][nt][jj >> 2][jj & 3];
+                split_frag(v, bf[nt]);
             }
             if (a.norm.elementwise) {
 #pragma unroll
@@ -2537,7 +2151,7 @@ __device__ __forceinline__ void grad_body_x3_half(const GradJob &jb, const GradA
     }
     const int wcol = ntw * 16 + i16;
     float wg = 1.f, wn2 = 1.f;
-    bool lost = mg_lost;
+    bool lost = false;
     if (f.wn) { wg = f.wn_g[job][wcol]; wn2 = f.wn_n2[job][wcol]; }
     if ((HO && expect > 0) || f.wn) {
         if (threadIdx.x == 0) {   // bounded waits, as in grad_fused_tail
@@ -2633,7 +2247,7 @@ extern "C" __global__ __launch_bounds__(256) void cfl_grad_x3_half_kernel(GradAr
     }
 }
 
-// experiment (CFL_DEBUG_GRAD_W8=1): the same tile with EIGHT waves (two per SIMD, half the rows each)
+// the same tile with EIGHT waves (two per SIMD, half the rows each): the headline plan (CFL_DEBUG_GRAD_W8=-1: four waves)
 extern "C" __global__ __launch_bounds__(512) void cfl_grad_x3_half_w8_kernel(GradArgs a_) {
     CFL_KERNARG_IN_PLACE(GradArgs, a, a_);
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -2646,10 +2260,10 @@ extern "C" __global__ __launch_bounds__(512) void cfl_grad_x3_half_w8_kernel(Gra
     const GradJob &jb = a.job[blockIdx.z - 1];
     const int job = (int)blockIdx.z - 1, dt = grad_dtile(a.tps);
     switch (jb.nt) {
-        case 1: grad_body_x3_half<1, false, false, 8>(jb, a, lds, job, dt, 0); break;
-        case 2: grad_body_x3_half<2, false, false, 8>(jb, a, lds, job, dt, 0); break;
-        case 3: grad_body_x3_half<3, false, false, 8>(jb, a, lds, job, dt, 0); break;
-        default: grad_body_x3_half<4, false, false, 8>(jb, a, lds, job, dt, 0); break;
+        case 1: grad_body_x3_half<1, false, 8>(jb, a, lds, job, dt, 0); break;
+        case 2: grad_body_x3_half<2, false, 8>(jb, a, lds, job, dt, 0); break;
+        case 3: grad_body_x3_half<3, false, 8>(jb, a, lds, job, dt, 0); break;
+        default: grad_body_x3_half<4, false, 8>(jb, a, lds, job, dt, 0); break;
     }
 }
 
@@ -2666,37 +2280,6 @@ extern "C" __global__ __launch_bounds__(256) void cfl_grad_x3_half_split_kernel(
         case 2: grad_body_x3_half<2, true>(jb, a, lds, job, dt, (int)blockIdx.y); break;
         case 3: grad_body_x3_half<3, true>(jb, a, lds, job, dt, (int)blockIdx.y); break;
         default: grad_body_x3_half<4, true>(jb, a, lds, job, dt, (int)blockIdx.y); break;
-    }
-}
-
-// ... and both with dL/dy pre-split into bf16 planes by mid (plan.dy_pre: wide heads)
-extern "C" __global__ __launch_bounds__(256) void cfl_grad_x3_half_pre_kernel(GradArgs a_) {
-    CFL_KERNARG_IN_PLACE(GradArgs, a, a_);
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    f32x4 *lds = (f32x4 *)smem;
-    if (blockIdx.z == 0) { grad_red_block(a, (float *)smem); return; }
-    const GradJob &jb = a.job[blockIdx.z - 1];
-    const int job = (int)blockIdx.z - 1, dt = grad_dtile(a.tps);
-    switch (jb.nt) {
-        case 1: grad_body_x3_half<1, false, true>(jb, a, lds, job, dt, 0); break;
-        case 2: grad_body_x3_half<2, false, true>(jb, a, lds, job, dt, 0); break;
-        case 3: grad_body_x3_half<3, false, true>(jb, a, lds, job, dt, 0); break;
-        default: grad_body_x3_half<4, false, true>(jb, a, lds, job, dt, 0); break;
-    }
-}
-
-extern "C" __global__ __launch_bounds__(256) void cfl_grad_x3_half_split_pre_kernel(GradArgs a_) {
-    CFL_KERNARG_IN_PLACE(GradArgs, a, a_);
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    f32x4 *lds = (f32x4 *)smem;
-    if (blockIdx.z == 0) { grad_red_block(a, (float *)smem); return; }
-    const GradJob &jb = a.job[blockIdx.z - 1];
-    const int job = (int)blockIdx.z - 1, dt = grad_dtile(a.tps);
-    switch (jb.nt) {
-        case 1: grad_body_x3_half<1, true, true>(jb, a, lds, job, dt, (int)blockIdx.y); break;
-        case 2: grad_body_x3_half<2, true, true>(jb, a, lds, job, dt, (int)blockIdx.y); break;
-        case 3: grad_body_x3_half<3, true, true>(jb, a, lds, job, dt, (int)blockIdx.y); break;
-        default: grad_body_x3_half<4, true, true>(jb, a, lds, job, dt, (int)blockIdx.y); break;
     }
 }
 
@@ -2754,9 +2337,6 @@ struct MidSide {
     const float *g;       // wn gains or null
     const float *n2;      // wn squared column norms or null
     float *dyf;           // fragment-major dL/dy (unscaled)
-    unsigned short *dyp;  // or null: the three truncation-split bf16 planes of dL/dy in the B-fragment order of the K = 32 MFMA
-                          // (plan.dy_pre: wide heads -- the weight-gradient launch then loads planes instead of splitting dL/dy
-                          // once per 32-d tile)
     float *cwf;           // fragment-major dL/dy * (x_hat.V) (weight-norm gain rows) or null
     int n, npad;
     int is_proto;         // 1: columns are k*L + l ; 0: columns are l
@@ -2868,18 +2448,6 @@ __device__ __forceinline__ f32x4 slab_sum(const float *src, long long sstride) {
 }
 
 // float offset of (row r, column c) inside a fragment-major buffer with RG row groups
-// dL/dy planes (MidSide::dyp): level p of dy[row r][col c] at ((nt * RG2 + r / 32) * 3 + p) * 512 + (8-row group (r / 8) % 4) * 128 +
-// (c % 16) * 8 + r % 8 -- lane (c16, kq) of the weight-gradient MFMA reads its 8 rows of a plane as ONE 16-byte load.  The split is
-// split3 (truncation): bit for bit what the weight-gradient kernels compute when they split dL/dy themselves.
-__device__ __forceinline__ void put_planes(unsigned short *dyp, int r, int c, int RG2, float dy) {
-    float h, m, l;
-    split3(dy, h, m, l);
-    unsigned short *q = dyp + ((size_t)(c >> 4) * RG2 + (r >> 5)) * 3 * 512 + (((r >> 3) & 3) * 16 + (c & 15)) * 8 + (r & 7);
-    q[0] = (unsigned short)(__float_as_uint(h) >> 16);
-    q[512] = (unsigned short)(__float_as_uint(m) >> 16);
-    q[1024] = (unsigned short)(__float_as_uint(l) >> 16);
-}
-
 __device__ __forceinline__ size_t frag_off(int r, int c, int RG) {
     return ((size_t)(c >> 4) * RG + (r >> 4)) * 256 + (((r >> 2) & 3) * 16 + (c & 15)) * 4 + (r & 3);
 }
@@ -3472,19 +3040,8 @@ __global__ __launch_bounds__(64) void cfl_mid_kernel(MidArgs a) {
 // per slice, every per-column quantity is one VALU op, and the few cross-column sums
 // go through a 1 KiB wave-private LDS scratch.  Same arithmetic, same outputs.
 // ---------------------------------------------------------------------------
-// FOLD: the body runs inside the projection launch (cfl_proj_mid_kernel): the partial sums then lie in the published
-// fragment-major tiles (fold_off) instead of the row-major slabs.  `lead`: the one wave of the launch that also
-// clears the hand-off flags of the weight-gradient launch and snapshots the threshold.
-// float offset of (slice s, row r, column c) inside a side's published partial tiles: [s][32-row tile][mt][nt] blocks of
-// 1 KiB in the C/D layout of the 16x16 MFMA (lane = col & 15 + 16 (row & 15) / 4, element row & 3)
-__device__ __forceinline__ size_t fold_off(int s, int r, int c, int tiles_r, int nts) {
-    const int rin = r & 31;
-    const size_t block = ((size_t)(s * tiles_r + (r >> 5)) * 2 + (rin >> 4)) * nts + (c >> 4);
-    return block * 256 + (((c & 15) + 16 * ((rin & 15) >> 2)) << 2) + (rin & 3);
-}
-
-template <int J, int FOLD>   // J = columns per lane: sides of up to 64 * J padded columns; FOLD 2: sc1 loads of the partial tiles;
-                              // FOLD 3: row-major slabs in, outputs written through (sc1) for consumers inside the same launch
+// `lead`: the one wave of the launch that also clears the hand-off flags of the weight-gradient launch and snapshots the threshold
+template <int J>   // J = columns per lane: sides of up to 64 * J padded columns
 __device__ __forceinline__ void mid_row_body(const MidArgs &a, int r, bool lead, float *W) {
     const int lane = threadIdx.x & 63;
     constexpr int CW = 64 * J;
@@ -3534,10 +3091,8 @@ __device__ __forceinline__ void mid_row_body(const MidArgs &a, int r, bool lead,
 #pragma unroll
         for (int j = 0; j < J; ++j) {
             const int ccs = c[j] < ss.npad ? c[j] : 0, ccd = c[j] < sd.npad ? c[j] : 0;
-            srcs[j] = (FOLD == 1 || FOLD == 2) ? ss.ypart + fold_off(0, r, ccs, a.Rpad >> 5, ss.npad >> 4)
-                                               : ss.ypart + (size_t)r * ss.npad + ccs;
-            srcd[j] = (FOLD == 1 || FOLD == 2) ? sd.ypart + fold_off(0, r, ccd, a.Rpad >> 5, sd.npad >> 4)
-                                               : sd.ypart + (size_t)r * sd.npad + ccd;
+            srcs[j] = ss.ypart + (size_t)r * ss.npad + ccs;
+            srcd[j] = sd.ypart + (size_t)r * sd.npad + ccd;
         }
         // all slice loads of both sides are independent and in flight together; summed in slice order afterwards
         // (the same order of additions as before: s = 0, 1, ..., S - 1)
@@ -3548,13 +3103,8 @@ __device__ __forceinline__ void mid_row_body(const MidArgs &a, int r, bool lead,
             for (int j = 0; j < J; ++j)
 #pragma unroll
                 for (int sl = 0; sl < NS; ++sl) {
-                    if (FOLD == 2) {
-                        ts[j][sl] = __hip_atomic_load(srcs[j] + (size_t)sl * ss.sstride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        td[j][sl] = __hip_atomic_load(srcd[j] + (size_t)sl * sd.sstride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    } else {
-                        ts[j][sl] = srcs[j][(size_t)sl * ss.sstride];
-                        td[j][sl] = srcd[j][(size_t)sl * sd.sstride];
-                    }
+                    ts[j][sl] = srcs[j][(size_t)sl * ss.sstride];
+                    td[j][sl] = srcd[j][(size_t)sl * sd.sstride];
                 }
 #pragma unroll
             for (int j = 0; j < J; ++j) {
@@ -3697,16 +3247,10 @@ __device__ __forceinline__ void mid_row_body(const MidArgs &a, int r, bool lead,
         if (is_pos) dd += pw * a.lambda_m * invB;
     }
     if (!valid) dd = 0.f;
-    auto put = [&](float *q, float val) {   // (FOLD 3: visible to the other workgroups of this launch once drained)
-        if (FOLD == 3) __hip_atomic_store(q, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else *q = val;
-    };
+    auto put = [&](float *q, float val) { *q = val; };
     if (lead && lane == 0) put(a.thr_copy, thr);
     if (lead && a.zero_i)
-        for (int i = lane; i < a.nzero; i += 64) {
-            if (FOLD == 3) __hip_atomic_store(a.zero_i + i, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            else a.zero_i[i] = 0;
-        }
+        for (int i = lane; i < a.nzero; i += 64) a.zero_i[i] = 0;
     if (lane < 16) {
         const bool pos = valid && is_pos, neg = valid && !is_pos;
         float qv = 0.f;
@@ -3747,14 +3291,12 @@ __device__ __forceinline__ void mid_row_body(const MidArgs &a, int r, bool lead,
             const float dy = cs[j] ? dP * dd * act_grad(P[j], a.act) : 0.f;
             const size_t o_ = frag_off(r, c[j], RG);
             put(ss.dyf + o_, dy);
-            if (ss.dyp) put_planes(ss.dyp, r, c[j], a.Rpad >> 5, dy);
             if (ss.cwf) put(ss.cwf + o_, dy * xvs[j]);
         }
         if (c[j] < sd.npad) {
             const float dy = cd[j] ? dv * dd * act_grad(v[j], a.act) : 0.f;
             const size_t o_ = frag_off(r, c[j], RG);
             put(sd.dyf + o_, dy);
-            if (sd.dyp) put_planes(sd.dyp, r, c[j], a.Rpad >> 5, dy);
             if (sd.cwf) put(sd.cwf + o_, dy * xvd[j]);
         }
     }
@@ -3773,139 +3315,9 @@ __global__ __launch_bounds__(256) void cfl_mid_row_kernel(MidArgs a) {
         if (wave == 0) mid_reg_block(a, blockIdx.x - a.nrb);
         return;
     }
-    mid_row_body<J, 0>(a, blockIdx.x * 4 + wave, blockIdx.x == 0 && wave == 0, (float *)smem + wave * 6 * 64 * J);
+    mid_row_body<J>(a, blockIdx.x * 4 + wave, blockIdx.x == 0 && wave == 0, (float *)smem + wave * 6 * 64 * J);
 }
 
-// ---------------------------------------------------------------------------
-// proj + mid in ONE launch (round-3 experiment, VERDICT item "all-arrive fold"; opt-in: CFL_DEBUG_FOLD=1).
-// The S x jobs = `group` workgroups that produce the partial sums of one 32-row tile have CONSECUTIVE linear ids
-// (id = tile * group + job * S + s: still s = id mod 8, the XCD alignment of the plain launch).  Each
-//   * projects its (job, slice) partial tile and PUBLISHES it: sc1 (write-through) 16-byte stores of whole C/D
-//     fragments, every storing wave drains, workgroup barrier, one lane stores the launch's generation number into the
-//     member's flag word (sc1);
-//   * waits until all `group` flag words of its tile carry this launch's generation (one wave polls them with sc1 loads,
-//     one word per lane; bounded), then ONE agent-scope acquire + drain + barrier (two workgroups share a CU here, which
-//     is outside the configurations the sc1-load-only hand-off is measured for: MI355X_MICROARCH.md, Valid forms);
-//   * runs the distance / loss / dL/dY math of ITS 32 / group rows (wave per row: mid_row_body).
-// No mid launch, no kernel boundary between the partial sums and their consumers.  Flags are never cleared: the
-// generation is a per-process launch counter, so a stale or uninitialised word matches with probability 2^-32.
-// No deadlock under in-order dispatch whatever the residency: a waiting workgroup only waits for members of its own
-// group, which are the next workgroups the dispatcher hands out.
-// ---------------------------------------------------------------------------
-struct FoldArgs {
-    int group, S, ntile_wgs, rows_per_wg;   // workgroups per tile, d slices, tiles * group, 32 / group
-    unsigned gen;
-    int sc1_loads;
-    int spin_limit;
-    float *err;                             // scalars + CFL_S_ERROR (training) or NULL
-    unsigned *flags;                        // [tiles * group]
-    int nt_of_job[CFL_MAX_JOBS];
-};
-
-extern "C" __global__ __launch_bounds__(256) void cfl_proj_mid_kernel(ProjArgs a, MidArgs ma, FoldArgs fa) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    f32x4 *lds = (f32x4 *)smem;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int id = blockIdx.x;
-    if (id >= fa.ntile_wgs) {   // the L2-regulariser partial sums (mid's extra blocks)
-        if (wave == 0) mid_reg_block(ma, id - fa.ntile_wgs);
-        return;
-    }
-    const int tile = id / fa.group, member = id - tile * fa.group;
-    const int job = member / fa.S, sl = member - job * fa.S;
-    const ProjJob &jb = a.job[job];
-    switch (jb.nt) {
-        case 1: proj_body<1, true>(jb, a, lds, tile, sl); break;
-        case 2: proj_body<2, true>(jb, a, lds, tile, sl); break;
-        case 3: proj_body<3, true>(jb, a, lds, tile, sl); break;
-        default: proj_body<4, true>(jb, a, lds, tile, sl); break;
-    }
-    __syncthreads();   // every storing wave has drained its published fragments
-    unsigned *fl = fa.flags + (size_t)tile * fa.group;
-    if (threadIdx.x == 0) __hip_atomic_store(fl + member, fa.gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (wave == 0) {
-        int spins = 0;
-        for (;;) {
-            const unsigned v = lane < fa.group ? __hip_atomic_load(fl + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : fa.gen;
-            if (__builtin_amdgcn_ballot_w64(v != fa.gen) == 0) break;
-            if (++spins > fa.spin_limit) {   // lost hand-off: the rows below read garbage; the sticky error word says so
-                if (lane == 0 && fa.err) *fa.err = 1.f;
-                break;
-            }
-            __builtin_amdgcn_s_sleep(1);
-        }
-        if (!fa.sc1_loads) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-    }
-    __syncthreads();
-    if (wave < fa.rows_per_wg) {
-        const int r = tile * 32 + member * fa.rows_per_wg + wave;
-        // sc1_loads (CFL_DEBUG_FOLD=2, timing experiment): no acquire, every load of a published tile is an sc1 load --
-        // the form the guide measured valid at ONE workgroup per CU only; two share a CU here
-        if (fa.sc1_loads) mid_row_body<1, 2>(ma, r, id == 0 && wave == 0, (float *)smem + wave * 6 * 64);
-        else mid_row_body<1, 1>(ma, r, id == 0 && wave == 0, (float *)smem + wave * 6 * 64);
-    }
-}
-
-// ---------------------------------------------------------------------------
-// mid inside the weight-gradient launch (round 3; the half-tile form only): one launch =
-//   [row-math blocks | L2-regulariser blocks | reduction blocks | (pad to 8) | contraction workgroups (job, 32-d tile)]
-// in linear-id = dispatch order.  The row-math blocks (wave per row, mid_row_body) never wait; they write dL/dY and the
-// per-row loss quantities THROUGH (sc1), drain, barrier, and raise one flag word each that carries the launch's
-// generation.  A contraction workgroup stages its row addresses, REQUESTS THE FIRST CHUNK OF x -- which does not depend on
-// dL/dY -- and only then waits for the flags (one wave polls, one agent acquire, barrier): the latency chain of the row
-// math (~4.5 us) was meant to hide behind the arrival of x instead of occupying a launch of its own (7.1 us + a kernel
-// boundary).  The reduction blocks wait the same way.  No deadlock: producers are dispatched first and never wait.
-// MEASURED (profiles/r03_midgrad_measurement.md): bit-identical, but 4.4 us per step SLOWER than the separate mid launch
-// (with or without the early x request) -- like the proj + mid fold, the in-launch hand-off (written-through 4-byte
-// stores, drain, 260 workgroups polling 256 flags, acquire) costs more than the boundary it removes.  Opt-in only.
-// ---------------------------------------------------------------------------
-struct MidGradArgs {
-    GradArgs g;
-    MidArgs m;
-    unsigned gen;
-    unsigned *flags;     // [nrow + nreg]
-    int nrow, nreg, nred, first_contr, ntile;   // row-math blocks, regulariser blocks, reduction blocks, first contraction id, D / 32
-    int early_x;
-};
-
-extern "C" __global__ __launch_bounds__(256) void cfl_midgrad_half_kernel(MidGradArgs a_) {
-    CFL_KERNARG_IN_PLACE(MidGradArgs, a, a_);
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int id = blockIdx.x;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (id < a.nrow + a.nreg) {
-        if (id < a.nrow) mid_row_body<1, 3>(a.m, id * 4 + wave, id == 0 && wave == 0, (float *)smem + wave * 6 * 64);
-        else if (wave == 0) mid_reg_block(a.m, id - a.nrow);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its written-through outputs
-        __syncthreads();
-        if (threadIdx.x == 0) __hip_atomic_store(a.flags + id, a.gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return;
-    }
-    const MgWait mg = {a.flags, a.nrow + a.nreg, a.gen, a.early_x, a.g.fuse.spin_limit < 0 ? 0 : a.g.fuse.spin_limit, a.g.fuse.scalars + CFL_S_ERROR};
-    if (id < a.nrow + a.nreg + a.nred) {
-        grad_red_block(a.g, (float *)smem, &mg, id - a.nrow - a.nreg, a.nred);
-        return;
-    }
-    if (id < a.first_contr) return;
-    const int c = id - a.first_contr;
-    const int job = c / a.ntile;
-    // XCD-aligned tile order as in the plain launch: first_contr is a multiple of 8, so c mod 8 = blockIdx.x mod 8
-    const int cx = c - job * a.ntile;
-    int dt = cx;
-    if (a.g.tps > 0) { const int k = cx & 7, j = cx >> 3; dt = ((j / a.g.tps) * 8 + k) * a.g.tps + j % a.g.tps; }
-    const GradJob &jb = a.g.job[job];
-    f32x4 *lds = (f32x4 *)smem;
-    switch (jb.nt) {
-        case 1: grad_body_x3_half<1, false>(jb, a.g, lds, job, dt, 0, &mg); break;
-        case 2: grad_body_x3_half<2, false>(jb, a.g, lds, job, dt, 0, &mg); break;
-        case 3: grad_body_x3_half<3, false>(jb, a.g, lds, job, dt, 0, &mg); break;
-        default: grad_body_x3_half<4, false>(jb, a.g, lds, job, dt, 0, &mg); break;
-    }
-}
 
 // ---------------------------------------------------------------------------
 // finalize: weight-gradient slabs + row-reduced column sums -> flat gradient ;
@@ -4225,8 +3637,22 @@ extern "C" int cfl_layout(const CflShape *s, CflLayout *out) {
 }
 
 // ---- execution plan --------------------------------------------------------
+// The kernels a plan launches: decided ONCE, in make_plan; run_pairs switches on these, cfl_plan_describe reports them.
+enum ProjKernel { PK_EXACT = 0, PK_BX3, PK_STREAM, PK_X3, PK_X3_KEEP };
+enum MidKernel { MK_ROW1 = 0, MK_ROW2, MK_ROW4, MK_REG_K4_LQ2, MK_REG_K8_LQ2, MK_REG_K4_LQ4, MK_GENERIC };
+enum GradKernel { GK_NONE = 0, GK_HALF_W8, GK_HALF, GK_HALF_SPLIT, GK_X3, GK_X3_LONGRANGE, GK_EXACT };
+static const char *const kProjKernelName[] = {"cfl_proj_kernel", "cfl_proj_bx3_kernel", "cfl_proj_stream_kernel",
+                                              "cfl_proj_x3_kernel", "cfl_proj_x3_keep_kernel"};
+static const char *const kMidKernelName[] = {"cfl_mid_row_kernel<1>", "cfl_mid_row_kernel<2>", "cfl_mid_row_kernel<4>",
+                                             "cfl_mid_kernel<4, 2>", "cfl_mid_kernel<8, 2>", "cfl_mid_kernel<4, 4>",
+                                             "cfl_mid_kernel<0, 0>"};
+static const char *const kGradKernelName[] = {"", "cfl_grad_x3_half_w8_kernel", "cfl_grad_x3_half_kernel",
+                                              "cfl_grad_x3_half_split_kernel", "cfl_grad_x3_kernel",
+                                              "cfl_grad_x3_longrange_kernel", "cfl_grad_kernel"};
+
 struct Plan {
     CflLayout lay;
+    int proj_kernel, mid_kernel, grad_kernel;   // ProjKernel / MidKernel / GradKernel
     int R, Rpad, S, P, nrb, nregblocks;
     int kpad, lpad, Lq;
     bool has_cw, mono;
@@ -4237,21 +3663,13 @@ struct Plan {
     bool x3;   // bf16x3 matrix-core path for the weight gradient
     bool xcd;  // XCD-aligned launch order of proj / grad (cfl_xcd_aligned)
     int proj_stream;  // 0: one wait per 128-d chunk (proj_body); 1: streaming form (proj_stream_body)
-    bool proj_mix;    // streaming form at S == 1: column jobs interleaved in launch order
     bool proj_x3;     // bf16x3 forward with LDS-shared W planes (cfl_proj_x3_kernel); S is then its d split
     bool planes_kept; // the caller keeps the planes beside theta (CflThetaPlanes): no per-call split launch
     bool proj_bx3;    // ... and the chunk-at-a-time projection multiplies them on the bf16 matrix cores (cfl_proj_bx3_kernel)
     size_t wplanes[2];
-    bool fold;        // proj + mid in one launch (cfl_proj_mid_kernel)
-    size_t fold_flags;
-    bool proj_ring;   // loader / consumer ring form (cfl_proj_ring_kernel); S is then the ring's d split
-    int ring_tiles, ring_units, ring_nwg;
+    int x3_tiles, x3_units, x3_nwg;   // cfl_proj_x3_kernel: 128-row tiles per side, work units (job, tile, d slice), workgroups
     bool grad_half;   // 32-d tiles, no row split (cfl_grad_x3_half_kernel)
     bool grad_w8;     // ... with eight waves per workgroup (cfl_grad_x3_half_w8_kernel)
-    bool midgrad;     // ... with the row math inside the same launch (cfl_midgrad_half_kernel)
-    bool dy_pre;      // mid also writes dL/dy as bf16 planes and the half-tile weight gradient loads them (wide heads)
-    size_t dyp[2];
-    size_t mg_flags;
     bool fused;       // gradient + Adam finished inside the weight-gradient launch (GradFuse)
     size_t handoff;   // workspace offset of the hand-off tickets + flags (ints), nhandoff of each
     int nhandoff;
@@ -4361,30 +3779,11 @@ static int make_plan(const CflShape *s, int64_t rows, int groups, bool train, bo
     if (S > maxS) S = pow2_floor(maxS);
     if (S > 16) S = 16;
     if (debug_env("CFL_DEBUG_S") > 0) S = debug_env("CFL_DEBUG_S");
-    // ring form: >= 2048 rows per side; d split so that every workgroup (one per CU) gets two work units
-    pl->proj_ring = false;
-    {
-        const int ov = debug_env("CFL_DEBUG_PROJ_RING");
-        const int tiles = (pl->R + 127) / 128;
-        int rs = 1;
-        while (rs < 16 && njobs * tiles * rs < 512 && s->D / (2 * rs) >= 256 && (s->D / 64) % (2 * rs) == 0) rs *= 2;
-        const int units = njobs * tiles * rs;
-        const bool ok = (s->D / 64) % rs == 0 && s->D / 64 / rs >= 2 && units <= RING_UNITS * 256 && units >= 192;
-        if (ok && ov > 0) {   // opt-in (CFL_DEBUG_PROJ_RING=1): measured within +-6 % of the streaming form, see DESIGN.md
-            pl->proj_ring = true;
-            pl->ring_tiles = tiles;
-            pl->ring_units = units;
-            int nwg = (units + 1) / 2;
-            if (nwg > 256) nwg = 256;
-            pl->ring_nwg = nwg;
-            S = rs;
-        }
-    }
     // bf16x3 forward with shared W planes: 128-row tiles, d split so that the 512 resident workgroups (two per CU) get
     // one or two units each; slices are whole 128-d chunks
     pl->proj_x3 = false;
     pl->planes_kept = planes_kept && train;
-    if (!pl->proj_ring) {
+    {
         const int ov = debug_env("CFL_DEBUG_PROJ_X3");
         const int tiles = (pl->R + 127) / 128;
         int rs = 1;
@@ -4404,26 +3803,25 @@ static int make_plan(const CflShape *s, int64_t rows, int groups, bool train, bo
         const int kept_rows = debug_env("CFL_DEBUG_X3_KEPT_ROWS") > 0 ? debug_env("CFL_DEBUG_X3_KEPT_ROWS") : 3072;
         if (ok && ov >= 0 && (ov > 0 || pl->R >= (train ? (pl->planes_kept ? kept_rows : 3072) : 4096))) {
             pl->proj_x3 = true;
-            pl->ring_tiles = tiles;
-            pl->ring_units = units;
-            pl->ring_nwg = units < 512 ? units : 512;
+            pl->x3_tiles = tiles;
+            pl->x3_units = units;
+            pl->x3_nwg = units < 512 ? units : 512;
             S = rs;
         }
     }
     pl->S = S;
-    pl->xcd = !pl->proj_ring && !pl->proj_x3 && cfl_xcd_aligned(S, s->D / 64);
+    pl->xcd = !pl->proj_x3 && cfl_xcd_aligned(S, s->D / 64);
     // streaming projection when a wave owns at least four 128-d chunks (measured: equal to the chunk-at-a-time form at
     // two, -11 % at eight; CFL_DEBUG_PROJ_STREAM: -1 never, 1 always)
     {
         const int per_wave = nchunks / (4 * S);
         const int ov = debug_env("CFL_DEBUG_PROJ_STREAM");
         pl->proj_stream = ov < 0 ? 0 : ov > 0 ? 1 : (per_wave >= 4 ? 1 : 0);
-        pl->proj_mix = debug_env("CFL_DEBUG_PROJ_MIX") > 0;   // opt-in: measured +15 % (slower) on dist_eval calls
     }
     // bf16x3 arithmetic on the chunk-at-a-time skeleton (cfl_proj_bx3_kernel): whenever the caller keeps the planes of
     // theta current (the fused single-GPU training step) and the wave owns fewer than four chunks
     // (CFL_DEBUG_PROJ_BX3=1: also without kept planes -- per-call split into the workspace, the tests' reference run; -1: never)
-    pl->proj_bx3 = (pl->planes_kept || debug_env("CFL_DEBUG_PROJ_BX3") > 0) && pl->x3 && !pl->proj_x3 && !pl->proj_ring &&
+    pl->proj_bx3 = (pl->planes_kept || debug_env("CFL_DEBUG_PROJ_BX3") > 0) && pl->x3 && !pl->proj_x3 &&
                    !pl->proj_stream && debug_env("CFL_DEBUG_PROJ_BX3") >= 0;
     pl->mid_generic = debug_env("CFL_DEBUG_MID_GENERIC") > 0;
     pl->mid_norow = debug_env("CFL_DEBUG_MID_NOROW") != 0;
@@ -4466,48 +3864,14 @@ static int make_plan(const CflShape *s, int64_t rows, int groups, bool train, bo
         pl->nhandoff = njobs * (s->D / 32);   // (half tiles; the 64-d forms use the first half)
         pl->handoff = take(2 * (size_t)pl->nhandoff + 64);   // tickets, flags, + the reduction blocks' counter
     }
-    // proj + mid in one launch: pcd, plain heads (weight-norm needs the column norms of the same launch), sides of at
-    // most 64 padded columns (wave-per-row math), S a multiple of 8 (XCD alignment), S * jobs workgroups per 32-row
-    // tile sharing its 32 rows evenly, and -- training -- no padding rows beyond R (mid zero-fills them)
-    {
-        const int group = S * njobs;
-        const int wide = hs->npad > hd->npad ? hs->npad : hd->npad;
-        pl->fold = debug_env("CFL_DEBUG_FOLD") > 0 && s->dist_type == CFL_DIST_PCD && !s->weight_norm && wide <= 64 &&
-                   s->K <= 64 && S % 8 == 0 && group <= 32 && 32 % group == 0 && !pl->proj_ring && !pl->proj_stream && !pl->proj_x3 && !pl->proj_bx3 &&
-                   pl->R % 32 == 0 && (!train || pl->Rpad == pl->R) && !pl->mid_generic && !pl->mid_norow;
-        pl->fold_flags = take(pl->fold ? (size_t)(pl->R / 32) * group : 0);
-    }
-    {
-        // row math inside the weight-gradient launch: half-tile form, wave-per-row math with one column per lane
-        const int wide = hs->npad > hd->npad ? hs->npad : hd->npad;
-        // (opt-in, CFL_DEBUG_MIDGRAD=1 | 2: measured 4.4 us SLOWER per step than the separate mid launch, profiles/r03_midgrad_measurement.md)
-        pl->midgrad = train && pl->grad_half && pl->P == 1 && !(s->dist_type == CFL_DIST_SIAMESE && !s->directed) && !pl->fold && debug_env("CFL_DEBUG_MIDGRAD") > 0 &&
-                      (s->dist_type == CFL_DIST_PCD || s->dist_type == CFL_DIST_SIAMESE) && wide <= 64 && s->K <= 64 &&
-                      !pl->mid_generic && !pl->mid_norow && pl->Rpad % 4 == 0 && (pl->lay.total / 4096 + 2) < 4096;
-        pl->mg_flags = take(pl->midgrad ? (size_t)pl->Rpad / 4 + pl->nregblocks + 64 : 0);
-    }
     const bool ws_planes = (pl->proj_x3 || pl->proj_bx3) && !pl->planes_kept;
     {
-        // dL/dy pre-split by mid (round-4 experiment, OPT-IN: CFL_DEBUG_DY_PRE=1): the weight-gradient launch splits dL/dy once
-        // per 32-d tile -- D / 32 times over -- and at wide heads that split is most of its VALU work (config 3: 3.2 M
-        // instructions per launch, two thirds of them this split).  Bit-identical, and SLOWER everywhere it was measured
-        // (profiles/r04_dy_pre_ab.txt: config 3 41.7 -> 44.5 us, config 4 46.9 -> 51.4, headline +-0): the planes are 1.5x
-        // the bytes through the vector-memory path that already bounds these launches, mid's 2-byte scattered stores
-        // cost it 1.5 - 2.7 us, and the split it removes was hidden behind the x latency.  Wave-per-row mid only.
-        const int wide = hs->npad > hd->npad ? hs->npad : hd->npad;
-        const bool small_reg = (s->K <= 8 && pl->Lq <= 2) || (s->K <= 4 && pl->Lq <= 4);
-        const bool row_mid = (s->dist_type == CFL_DIST_PCD || s->dist_type == CFL_DIST_SIAMESE) && wide <= 256 && s->K <= 64 &&
-                             !pl->mid_norow && !pl->mid_generic && !(small_reg && pl->R >= 16384);
-        const int ov = debug_env("CFL_DEBUG_DY_PRE");
-        pl->dy_pre = train && pl->grad_half && pl->x3 && row_mid && !pl->fold && !pl->midgrad && ov > 0;
         // eight waves per workgroup (two per SIMD) for the unsplit half tiles: one wave per SIMD leaves the row loop's load
         // latency and its split arithmetic (8 VALU instructions per MFMA: SQ_INSTS_VALU) with nothing to overlap with.  Not for
         // the shared siamese heads: their fused form runs the split kernel's four-wave order, and the separate finalize launch
         // must keep adding the same partial sums (CFL_DEBUG_GRAD_W8=-1: four waves everywhere)
-        pl->grad_w8 = train && pl->grad_half && pl->P == 1 && pl->x3 && !pl->dy_pre && !pl->midgrad && pl->Rpad % 512 == 0 &&
+        pl->grad_w8 = train && pl->grad_half && pl->P == 1 && pl->x3 && pl->Rpad % 512 == 0 &&
                       !(s->dist_type == CFL_DIST_SIAMESE && !s->directed) && debug_env("CFL_DEBUG_GRAD_W8") >= 0;
-        pl->dyp[0] = take(pl->dy_pre ? (size_t)hs->npad * rp * 3 / 2 : 0);
-        pl->dyp[1] = take(pl->dy_pre ? (size_t)hd->npad * rp * 3 / 2 : 0);
     }
     pl->wplanes[0] = take(ws_planes ? (size_t)hs->npad * s->D * 3 / 2 : 0);   // bf16 planes: 6 bytes per weight
     pl->wplanes[1] = take(ws_planes ? (size_t)hd->npad * s->D * 3 / 2 : 0);
@@ -4520,6 +3884,73 @@ static int make_plan(const CflShape *s, int64_t rows, int groups, bool train, bo
     const int mw = pl->mono ? ((s->L * pl->kpad + 3) & ~3) : 0;
     pl->mid_lds = ((size_t)(MID_RB + 2) * pl->ys + mw + (size_t)slots * 64) * sizeof(float);
     if (pl->mid_lds > 160 * 1024) return set_err(CFL_E_UNSUPPORTED, "L*K too large for the mid kernel");
+    // ---- the kernels ---------------------------------------------------------------------------------------------------
+    if (pl->proj_x3) {
+        // training with both sides' rows within reach of the 256 MB Infinity Cache: x is loaded with the default policy, so
+        // that the weight gradient's re-read hits it
+        const double keep_bytes = debug_env("CFL_DEBUG_X3_KEEP_MB") > 0 ? debug_env("CFL_DEBUG_X3_KEEP_MB") * 1e6 : 300e6;
+        const bool keep = train && 2.0 * pl->R * s->D * 4.0 <= keep_bytes && debug_env("CFL_DEBUG_PROJ_X3_KEEP") >= 0;
+        pl->proj_kernel = keep ? PK_X3_KEEP : PK_X3;
+    } else {
+        pl->proj_kernel = pl->proj_bx3 ? PK_BX3 : pl->proj_stream ? PK_STREAM : PK_EXACT;
+    }
+    {
+        // one wave per row: pcd (any K <= 64) and siamese with up to 256 padded columns per side.  Many rows of the small-K
+        // shapes run the 4-rows-per-wave register form instead.  Measured: scoring 32768 pairs 13 vs 24 us; training 32768
+        // rows (B = 8192) 14.4 vs 20.4 us -- but 9.7 vs 11.2 us the other way at B = 512 ... 2048 (the wave-per-row form is
+        // the shorter latency chain, the register form the smaller instruction count)
+        const int wide = hs->npad > hd->npad ? hs->npad : hd->npad;
+        const bool small_reg = (s->K <= 8 && pl->Lq <= 2) || (s->K <= 4 && pl->Lq <= 4);
+        const bool row_ok = (s->dist_type == CFL_DIST_PCD || s->dist_type == CFL_DIST_SIAMESE) && wide <= 256 &&
+                            s->K <= 64 && !pl->mid_norow && !(small_reg && pl->R >= (train ? 16384 : 4096));
+        const bool generic_only = pl->mid_generic != 0;
+        pl->mid_kernel = generic_only ? MK_GENERIC
+                         : row_ok ? (wide <= 64 ? MK_ROW1 : wide <= 128 ? MK_ROW2 : MK_ROW4)
+                         : (s->K <= 4 && pl->Lq <= 2) ? MK_REG_K4_LQ2
+                         : (s->K <= 8 && pl->Lq <= 2) ? MK_REG_K8_LQ2
+                         : (s->K <= 4 && pl->Lq <= 4) ? MK_REG_K4_LQ4 : MK_GENERIC;
+    }
+    pl->grad_kernel = GK_NONE;
+    if (train) {
+        // (the siamese pairing of the FUSED tail always takes the hand-off kernel: two sides feed one head)
+        const bool paired = pl->fused && s->dist_type == CFL_DIST_SIAMESE && !s->directed;
+        pl->grad_kernel = (pl->grad_half && pl->P == 1 && !paired) ? (pl->grad_w8 ? GK_HALF_W8 : GK_HALF)
+                          : pl->grad_half ? GK_HALF_SPLIT
+                          : pl->x3 ? (pl->Rpad / pl->P <= 8192 ? GK_X3 : GK_X3_LONGRANGE) : GK_EXACT;
+    }
+    return CFL_OK;
+}
+
+// HOST-ONLY introspection (include/cfl_hip.h): what a call of this shape will launch -- from the same plan run_pairs executes
+extern "C" int cfl_plan_describe(const CflShape *s, int64_t rows, int32_t groups, int32_t train, int32_t planes_kept,
+                                 CflPlanInfo *out) {
+    if (!out) return set_err(CFL_E_SHAPE, "cfl_plan_describe: out is NULL");
+    if (train && groups != 2) return set_err(CFL_E_SHAPE, "cfl_plan_describe: a training call has 2 pair groups");
+    Plan pl;
+    const bool kept = planes_kept && train && debug_env("CFL_DEBUG_NOFUSE") <= 0;
+    int rc = make_plan(s, rows, groups, train != 0, kept, &pl);
+    if (rc) return rc;
+    memset(out, 0, sizeof(*out));
+    snprintf(out->proj, sizeof(out->proj), "%s", kProjKernelName[pl.proj_kernel]);
+    snprintf(out->mid, sizeof(out->mid), "%s", kMidKernelName[pl.mid_kernel]);
+    snprintf(out->grad, sizeof(out->grad), "%s", kGradKernelName[pl.grad_kernel]);
+    snprintf(out->tail, sizeof(out->tail), "%s", (train && !pl.fused) ? "cfl_finalize_kernel" : "");
+    const bool per_call_split = (pl.proj_x3 || pl.proj_bx3) && !pl.planes_kept;
+    out->launches = 2 + (train ? 1 : 0) + ((train && !pl.fused) ? 1 : 0) + (per_call_split ? 1 : 0);
+    out->per_call_plane_split = per_call_split;
+    out->S = pl.S; out->P = pl.P; out->rows_padded = pl.Rpad;
+    out->proj_tile_rows = pl.proj_x3 ? 128 : 32;
+    const CflHead *hs, *hd;
+    side_heads(s, pl.lay, &hs, &hd);
+    const int njobs = (hs->npad / 16 + 3) / 4 + (hd->npad / 16 + 3) / 4;
+    out->column_jobs = njobs;
+    out->proj_workgroups = pl.proj_x3 ? pl.x3_nwg : ((pl.R + 31) / 32) * pl.S * njobs;
+    out->grad_tile_d = train ? (pl.grad_half ? 32 : 64) : 0;
+    out->grad_workgroups = train ? (s->D / out->grad_tile_d) * pl.P * njobs : 0;
+    out->grad_waves = train ? (pl.grad_kernel == GK_HALF_W8 ? 8 : 4) : 0;
+    out->fused_tail = train && pl.fused;
+    out->reads_planes = pl.proj_x3 || pl.proj_bx3;
+    out->xcd_aligned = pl.xcd;
     return CFL_OK;
 }
 
@@ -4707,7 +4138,7 @@ static int run_pairs(const CflShape *s, const CflNorm *norm, const CflLossCfg *l
                 ProjJob &j = pa.job[nj++];
                 j.side = sd;
                 j.wf = theta + h->w + (size_t)c0 * G * 256;
-                j.ypart = ws + pl.ypart[sd] + (size_t)c0 * (pl.fold ? 256 : 16);   // fold: 1 KiB fragment blocks
+                j.ypart = ws + pl.ypart[sd] + (size_t)c0 * 16;
                 j.sstride = (long long)h->npad * rp;
                 j.nt = tiles - c0 < 4 ? tiles - c0 : 4;
                 j.npad = h->npad;
@@ -4747,9 +4178,7 @@ static int run_pairs(const CflShape *s, const CflNorm *norm, const CflLossCfg *l
                 hipLaunchKernelGGL(cfl_wplanes_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, wa);
             }
         }
-        if (pl.fold) {
-            // launched below, together with the row math (cfl_proj_mid_kernel)
-        } else if (pl.proj_x3) {
+        if (pl.proj_x3) {
             Px3Args xa;
             memset(&xa, 0, sizeof(xa));
             const int Q = s->D / 32;
@@ -4763,54 +4192,19 @@ static int run_pairs(const CflShape *s, const CflNorm *norm, const CflLossCfg *l
                     if (pa.job[i].nt == nt) xa.order[k++] = i;
             xa.rows[0] = rsrc[0]; xa.rows[1] = rsrc[1];
             xa.B = (int)rows; xa.R = pl.R; xa.D = s->D; xa.S = pl.S; xa.njobs = nj;
-            xa.tiles = pl.ring_tiles; xa.nunits = pl.ring_units; xa.nwg = pl.ring_nwg; xa.Kq = Q / pl.S;
+            xa.tiles = pl.x3_tiles; xa.nunits = pl.x3_units; xa.nwg = pl.x3_nwg; xa.Kq = Q / pl.S;
             xa.norm = nd;
             // weight-norm: the column norms ride in this launch as its first workgroups (as they ride in cfl_proj_kernel as
             // a z-slice): no launch of their own
             xa.cn = cna;
             xa.ncn = cn_slice ? (cna.ncols < 64 ? cna.ncols : 64) : 0;
             ProfScope ps(st, CFL_K_PROJ);
-            // training with both sides' rows within reach of the 256 MB Infinity Cache: keep x for the weight gradient
-            const bool keep = train && 2.0 * pl.R * s->D * 4.0 <= (debug_env("CFL_DEBUG_X3_KEEP_MB") > 0 ? debug_env("CFL_DEBUG_X3_KEEP_MB") * 1e6 : 300e6) && debug_env("CFL_DEBUG_PROJ_X3_KEEP") >= 0;
-            if (keep) hipLaunchKernelGGL(cfl_proj_x3_keep_kernel, dim3(pl.ring_nwg + xa.ncn), dim3(256), PX3_LDS_BYTES, st, xa);
-            else hipLaunchKernelGGL(cfl_proj_x3_kernel, dim3(pl.ring_nwg + xa.ncn), dim3(256), PX3_LDS_BYTES, st, xa);
-        } else if (pl.proj_ring) {
-            RingArgs ra;
-            memset(&ra, 0, sizeof(ra));
-            for (int i = 0; i < nj; ++i) ra.job[i] = pa.job[i];
-            // widest jobs first (stable)
-            int k = 0;
-            for (int nt = 4; nt >= 1; --nt)
-                for (int i = 0; i < nj; ++i)
-                    if (pa.job[i].nt == nt) ra.order[k++] = i;
-            ra.rows[0] = rsrc[0]; ra.rows[1] = rsrc[1];
-            ra.B = (int)rows; ra.R = pl.R; ra.D = s->D; ra.S = pl.S; ra.njobs = nj;
-            ra.tiles = pl.ring_tiles; ra.nunits = pl.ring_units; ra.nwg = pl.ring_nwg; ra.Kh = s->D / 64 / pl.S;
-            ra.norm = nd;
-            ra.dbg = debug_env("CFL_DEBUG_RING_ABL");
-            static std::atomic<bool> attr{false};   // > 64 KiB of dynamic LDS needs the opt-in
-            if (!attr.load()) {
-                HIP_TRY(hipFuncSetAttribute((const void *)cfl_proj_ring_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                            RING_LDS_BYTES));
-                attr.store(true);
-            }
-            ProfScope ps(st, CFL_K_PROJ);
-            hipLaunchKernelGGL(cfl_proj_ring_kernel, dim3(pl.ring_nwg), dim3(512), RING_LDS_BYTES, st, ra);
-            if (cn_slice) {   // weight-norm column norms: the colnorm slice alone, in the chunk-at-a-time kernel
-                ProjArgs pc = pa;
-                pc.job[0].nt = 0;
-                pc.xcd = 0; pc.mix = 0;
-                hipLaunchKernelGGL(cfl_proj_kernel, dim3(64, 1, 1), dim3(256), 4 * 8 * 64 * sizeof(f32x4), st, pc);
-            }
+            if (pl.proj_kernel == PK_X3_KEEP) hipLaunchKernelGGL(cfl_proj_x3_keep_kernel, dim3(pl.x3_nwg + xa.ncn), dim3(256), PX3_LDS_BYTES, st, xa);
+            else hipLaunchKernelGGL(cfl_proj_x3_kernel, dim3(pl.x3_nwg + xa.ncn), dim3(256), PX3_LDS_BYTES, st, xa);
         } else {
-        const bool rows16 = pl.proj_bx3 && debug_env("CFL_DEBUG_PROJ_ROWS16") > 0;   // (experiment: 16-row tiles)
-        const int rtiles = rows16 ? (pl.R + 15) / 16 : (pl.R + 31) / 32;
+        const int rtiles = (pl.R + 31) / 32;
         dim3 grid(rtiles, pl.S, nz);
         if (pa.xcd) grid = dim3(pl.S, rtiles, nz);
-        if (pl.proj_stream && pl.proj_mix && pl.S == 1 && nz > 1) {
-            pa.mix = 1; pa.mixjobs = nz; pa.mixtiles = (int)round_up(rtiles, 8);
-            grid = dim3(pa.mixtiles * nz, 1, 1);
-        }
         ProfScope ps(st, CFL_K_PROJ);
         // The colnorm slice goes FIRST in dispatch order (z = 0): its blocks are short, and as the last z-slice they only
         // started once projection workgroups had retired -- the launch ended a colnorm round trip later than it had to
@@ -4822,14 +4216,11 @@ static int run_pairs(const CflShape *s, const CflNorm *norm, const CflLossCfg *l
             memset(&pz.job[0], 0, sizeof(pz.job[0]));   // nt == 0 marks the colnorm slice
         }
         // 32 KiB: cross-wave sum (the 4 (8) KiB/wave transpose tiles alias it)
-        if (rows16)
-            hipLaunchKernelGGL(cfl_proj_bx3_rows16_kernel, grid, dim3(256), 4 * 8 * 64 * sizeof(f32x4), st, pz);
-        else if (pl.proj_bx3)
-            hipLaunchKernelGGL(cfl_proj_bx3_kernel, grid, dim3(256), 4 * 8 * 64 * sizeof(f32x4), st, pz);
-        else if (pl.proj_stream)
-            hipLaunchKernelGGL(cfl_proj_stream_kernel, grid, dim3(256), 4 * 8 * 64 * sizeof(f32x4), st, pz);
-        else
-            hipLaunchKernelGGL(cfl_proj_kernel, grid, dim3(256), 4 * 8 * 64 * sizeof(f32x4), st, pz);
+        switch (pl.proj_kernel) {
+            case PK_BX3: hipLaunchKernelGGL(cfl_proj_bx3_kernel, grid, dim3(256), 4 * 8 * 64 * sizeof(f32x4), st, pz); break;
+            case PK_STREAM: hipLaunchKernelGGL(cfl_proj_stream_kernel, grid, dim3(256), 4 * 8 * 64 * sizeof(f32x4), st, pz); break;
+            default: hipLaunchKernelGGL(cfl_proj_kernel, grid, dim3(256), 4 * 8 * 64 * sizeof(f32x4), st, pz); break;
+        }
         }
     }
 
@@ -4845,7 +4236,6 @@ static int run_pairs(const CflShape *s, const CflNorm *norm, const CflLossCfg *l
         m.g = h->g >= 0 ? theta + h->g : nullptr;
         m.n2 = s->weight_norm ? n2base + n2_off[side[sd].enc][side[sd].which] : nullptr;
         m.dyf = train ? ws + pl.dyf[sd] : nullptr;
-        m.dyp = (train && pl.dy_pre) ? (unsigned short *)(ws + pl.dyp[sd]) : nullptr;
         m.cwf = pl.has_cw ? ws + pl.cwf[sd] : nullptr;
         m.n = h->n; m.npad = h->npad;
         m.is_proto = side[sd].which == 1;
@@ -4952,54 +4342,19 @@ static int run_pairs(const CflShape *s, const CflNorm *norm, const CflLossCfg *l
             if (nreg_blocks > pl.nregblocks) return set_err(CFL_E_WORKSPACE, "regpart too small");
         }
     }
-    if (pl.fold) {
-        static std::atomic<unsigned> fold_gen{1};
-        FoldArgs fo;
-        memset(&fo, 0, sizeof(fo));
-        fo.S = pl.S;
-        fo.group = pl.S * pa.njobs;
-        fo.rows_per_wg = 32 / fo.group;
-        fo.ntile_wgs = (pl.R / 32) * fo.group;
-        unsigned g = fold_gen.fetch_add(1);
-        if (g == 0) g = fold_gen.fetch_add(1);
-        fo.gen = g;
-        fo.flags = (unsigned *)(ws + pl.fold_flags);
-        fo.sc1_loads = debug_env("CFL_DEBUG_FOLD") == 2;
-        fo.spin_limit = debug_env("CFL_DEBUG_SPIN_LIMIT") != 0 ? debug_env("CFL_DEBUG_SPIN_LIMIT") : CFL_HANDOFF_SPIN_LIMIT;
-        fo.err = scalars ? scalars + CFL_S_ERROR : nullptr;
-        ProfScope ps(st, CFL_K_PROJ);
-        hipLaunchKernelGGL(cfl_proj_mid_kernel, dim3(fo.ntile_wgs + nreg_blocks), dim3(256), 4 * 8 * 64 * sizeof(f32x4), st,
-                           pa, ma, fo);
-    } else if (pl.midgrad) {
-        // the row math rides in the weight-gradient launch (cfl_midgrad_half_kernel, below)
-    } else {
+    {
         ProfScope ps(st, CFL_K_MID);
         const dim3 mgrid(ma.nrb + nreg_blocks), mblk(64);
-        const bool generic_only = pl.mid_generic != 0;
-        // one wave per row: pcd (any K <= 64) and siamese with up to 256 padded columns per side
-        const int wide = side[0].head->npad > side[1].head->npad ? side[0].head->npad : side[1].head->npad;
-        // many rows of the small-K shapes run the 4-rows-per-wave register form instead of wave-per-row.  Measured:
-        // scoring 32768 pairs 13 vs 24 us; training 32768 rows (B = 8192) 14.4 vs 20.4 us -- but 9.7 vs 11.2 us the
-        // other way at B = 512 ... 2048 (the wave-per-row form is the shorter latency chain, the register form the
-        // smaller instruction count)
-        const bool small_reg = (s->K <= 8 && pl.Lq <= 2) || (s->K <= 4 && pl.Lq <= 4);
-        const bool row_ok = (s->dist_type == CFL_DIST_PCD || s->dist_type == CFL_DIST_SIAMESE) && wide <= 256 &&
-                            s->K <= 64 && !pl.mid_norow && !(small_reg && pl.R >= (train ? 16384 : 4096));
         const dim3 rgrid(ma.nrb + nreg_blocks);
-        if (!generic_only && row_ok && wide <= 64)
-            hipLaunchKernelGGL((cfl_mid_row_kernel<1>), rgrid, dim3(256), 4 * 6 * 64 * sizeof(float), st, ma);
-        else if (!generic_only && row_ok && wide <= 128)
-            hipLaunchKernelGGL((cfl_mid_row_kernel<2>), rgrid, dim3(256), 4 * 6 * 128 * sizeof(float), st, ma);
-        else if (!generic_only && row_ok)
-            hipLaunchKernelGGL((cfl_mid_row_kernel<4>), rgrid, dim3(256), 4 * 6 * 256 * sizeof(float), st, ma);
-        else if (!generic_only && s->K <= 4 && pl.Lq <= 2)
-            hipLaunchKernelGGL((cfl_mid_kernel<4, 2>), mgrid, mblk, pl.mid_lds, st, ma);
-        else if (!generic_only && s->K <= 8 && pl.Lq <= 2)
-            hipLaunchKernelGGL((cfl_mid_kernel<8, 2>), mgrid, mblk, pl.mid_lds, st, ma);
-        else if (!generic_only && s->K <= 4 && pl.Lq <= 4)
-            hipLaunchKernelGGL((cfl_mid_kernel<4, 4>), mgrid, mblk, pl.mid_lds, st, ma);
-        else
-            hipLaunchKernelGGL((cfl_mid_kernel<0, 0>), mgrid, mblk, pl.mid_lds, st, ma);
+        switch (pl.mid_kernel) {
+            case MK_ROW1: hipLaunchKernelGGL((cfl_mid_row_kernel<1>), rgrid, dim3(256), 4 * 6 * 64 * sizeof(float), st, ma); break;
+            case MK_ROW2: hipLaunchKernelGGL((cfl_mid_row_kernel<2>), rgrid, dim3(256), 4 * 6 * 128 * sizeof(float), st, ma); break;
+            case MK_ROW4: hipLaunchKernelGGL((cfl_mid_row_kernel<4>), rgrid, dim3(256), 4 * 6 * 256 * sizeof(float), st, ma); break;
+            case MK_REG_K4_LQ2: hipLaunchKernelGGL((cfl_mid_kernel<4, 2>), mgrid, mblk, pl.mid_lds, st, ma); break;
+            case MK_REG_K8_LQ2: hipLaunchKernelGGL((cfl_mid_kernel<8, 2>), mgrid, mblk, pl.mid_lds, st, ma); break;
+            case MK_REG_K4_LQ4: hipLaunchKernelGGL((cfl_mid_kernel<4, 4>), mgrid, mblk, pl.mid_lds, st, ma); break;
+            default: hipLaunchKernelGGL((cfl_mid_kernel<0, 0>), mgrid, mblk, pl.mid_lds, st, ma); break;
+        }
     }
     if (!train) {
         HIP_TRY(hipGetLastError());
@@ -5018,7 +4373,6 @@ static int run_pairs(const CflShape *s, const CflNorm *norm, const CflLossCfg *l
                 GradJob &j = ga.job[nj++];
                 j.side = sd;
                 j.dyf = ws + pl.dyf[sd] + (size_t)c0 * RG * 256;
-                j.dyp = pl.dy_pre ? (const unsigned short *)(ws + pl.dyp[sd]) + (size_t)c0 * (pl.Rpad / 32) * 3 * 512 : nullptr;
                 j.wpart = ws + pl.wpart[sd] + (size_t)c0 * G * 256;
                 j.pstride = (long long)h->npad * s->D;
                 j.nt = tiles - c0 < 4 ? tiles - c0 : 4;
@@ -5170,38 +4524,16 @@ static int run_pairs(const CflShape *s, const CflNorm *norm, const CflLossCfg *l
         ga.tps = pl.xcd ? (s->D / (pl.grad_half ? 32 : 64)) / pl.S : 0;
         dim3 grid(s->D / 64, pl.P, nj + 1);
         ProfScope ps(st, CFL_K_GRAD);
-        if (pl.midgrad) {
-            static std::atomic<unsigned> mg_gen{1};
-            MidGradArgs mg;
-            memset(&mg, 0, sizeof(mg));
-            mg.g = ga; mg.m = ma;
-            unsigned g = mg_gen.fetch_add(1);
-            if (g == 0) g = mg_gen.fetch_add(1);
-            mg.gen = g;
-            mg.flags = (unsigned *)(ws + pl.mg_flags);
-            mg.nrow = ma.nrb; mg.nreg = nreg_blocks;
-            mg.nred = ga.red_total < 128 ? ga.red_total : 128;
-            mg.first_contr = (int)round_up(mg.nrow + mg.nreg + mg.nred, 8);
-            mg.ntile = s->D / 32;
-            mg.early_x = debug_env("CFL_DEBUG_MIDGRAD") != 2;
-            hipLaunchKernelGGL(cfl_midgrad_half_kernel, dim3(mg.first_contr + nj * mg.ntile), dim3(256),
-                               4 * 4 * 4 * 64 * sizeof(f32x4), st, mg);
-        } else if (pl.grad_half && pl.P == 1 && !paired && pl.dy_pre)
-            hipLaunchKernelGGL(cfl_grad_x3_half_pre_kernel, dim3(s->D / 32, 1, nj + 1), dim3(256), 4 * 4 * 4 * 64 * sizeof(f32x4), st, ga);
-        else if (pl.grad_half && pl.P == 1 && !paired && pl.grad_w8)
-            hipLaunchKernelGGL(cfl_grad_x3_half_w8_kernel, dim3(s->D / 32, 1, nj + 1), dim3(512), 4 * 4 * 4 * 64 * sizeof(f32x4), st, ga);
-        else if (pl.grad_half && pl.P == 1 && !paired)
-            hipLaunchKernelGGL(cfl_grad_x3_half_kernel, dim3(s->D / 32, 1, nj + 1), dim3(256), 4 * 4 * 4 * 64 * sizeof(f32x4), st, ga);
-        else if (pl.grad_half && pl.dy_pre)
-            hipLaunchKernelGGL(cfl_grad_x3_half_split_pre_kernel, dim3(s->D / 32, pl.P, nj + 1), dim3(256), 4 * 4 * 4 * 64 * sizeof(f32x4), st, ga);
-        else if (pl.grad_half)
-            hipLaunchKernelGGL(cfl_grad_x3_half_split_kernel, dim3(s->D / 32, pl.P, nj + 1), dim3(256), 4 * 4 * 4 * 64 * sizeof(f32x4), st, ga);
-        else if (pl.x3 && pl.Rpad / pl.P <= 8192)
-            hipLaunchKernelGGL(cfl_grad_x3_kernel, grid, dim3(256), 4 * 4 * 4 * 64 * sizeof(f32x4), st, ga);
-        else if (pl.x3)
-            hipLaunchKernelGGL(cfl_grad_x3_longrange_kernel, grid, dim3(256), 4 * 4 * 4 * 64 * sizeof(f32x4), st, ga);
-        else
-            hipLaunchKernelGGL(cfl_grad_kernel, grid, dim3(256), 4 * 4 * 4 * 64 * sizeof(f32x4), st, ga);
+        const size_t glds = 4 * 4 * 4 * 64 * sizeof(f32x4);
+        const dim3 hgrid(s->D / 32, pl.P, nj + 1);
+        switch (pl.grad_kernel) {
+            case GK_HALF_W8: hipLaunchKernelGGL(cfl_grad_x3_half_w8_kernel, hgrid, dim3(512), glds, st, ga); break;
+            case GK_HALF: hipLaunchKernelGGL(cfl_grad_x3_half_kernel, hgrid, dim3(256), glds, st, ga); break;
+            case GK_HALF_SPLIT: hipLaunchKernelGGL(cfl_grad_x3_half_split_kernel, hgrid, dim3(256), glds, st, ga); break;
+            case GK_X3: hipLaunchKernelGGL(cfl_grad_x3_kernel, grid, dim3(256), glds, st, ga); break;
+            case GK_X3_LONGRANGE: hipLaunchKernelGGL(cfl_grad_x3_longrange_kernel, grid, dim3(256), glds, st, ga); break;
+            default: hipLaunchKernelGGL(cfl_grad_kernel, grid, dim3(256), glds, st, ga); break;
+        }
     }
 
     if (kept && adam) kept->valid = (keeping && pl.fused && (pl.proj_x3 || pl.proj_bx3)) ? 1 : 0;   // theta has changed; were the planes written?

@@ -312,6 +312,26 @@ int cfl_pair_train_steps_idx_planes(const CflShape *shape, const CflNorm *norm, 
 int cfl_mt19937_reshuffle(uint32_t *key, int32_t *pos, int64_t n, const int64_t *rows_in, int64_t cols,
                           int64_t *rows_out, int64_t *perm_out, int32_t *rows_out32);
 
+/* HOST-ONLY introspection (ABI 5; no reference counterpart): the kernels and the launch geometry the library will use
+ * for a call of this shape -- produced by the same planner the entry points execute, so that benchmarks, profiles and
+ * documentation name kernels from ONE source instead of re-deriving the dispatch.
+ *   rows / groups  as cfl_workspace_bytes (groups 2 = a training batch or cfl_pair_scores_idx4; 1 = scoring)
+ *   train          nonzero: forward + backward (+ update); planes_kept: the caller passes a CflThetaPlanes buffer        */
+typedef struct {
+    char proj[40], mid[40], grad[40], tail[40];   /* kernel names ("" = no such launch; tail = a separate finalize launch) */
+    int32_t launches;              /* kernel launches of the call, without the stand-alone Adam of a data-parallel step  */
+    int32_t per_call_plane_split;  /* 1: + cfl_wplanes_kernel in every call (bf16x3 projection without kept planes)      */
+    int32_t S, P;                  /* d slices of the projection, row ranges of the weight gradient                      */
+    int32_t rows_padded, column_jobs;
+    int32_t proj_tile_rows, proj_workgroups;
+    int32_t grad_tile_d, grad_workgroups, grad_waves;
+    int32_t fused_tail;            /* gradient (+ Adam, + planes) finished inside the weight-gradient launch             */
+    int32_t reads_planes;          /* the projection multiplies bf16 planes of theta                                     */
+    int32_t xcd_aligned;           /* blockIdx -> tile mapping deals d slices / d tiles one per XCD                      */
+} CflPlanInfo;
+int cfl_plan_describe(const CflShape *shape, int64_t rows, int32_t groups, int32_t train, int32_t planes_kept,
+                      CflPlanInfo *out);
+
 /* The launch plan of a (shape, rows, groups) combination is computed once per process and thread; the tuning /
  * diagnostic overrides it reads from the environment (CFL_EXACT_FP32, CFL_DEBUG_*) are re-read after this call. */
 int cfl_reload_env(void);

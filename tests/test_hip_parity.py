@@ -578,14 +578,14 @@ def test_step_windows_equal_single_indexed_steps(tmp_path):
                                               (4096, 64, 1, 2100, False)])
 def test_projection_forms_agree(D, L, K, n, act_norm, monkeypatch):
     """The forms of the forward projection on large scoring calls (a wave owns several 128-d chunks):
-    chunk-at-a-time (proj_body), streaming (proj_stream_body), the loader / consumer ring (cfl_proj_ring_kernel, opt-in)
+    chunk-at-a-time (proj_body), streaming (proj_stream_body)
     and the bf16x3 form with LDS-shared W planes (cfl_proj_x3_kernel: the default from 4096 rows per side in scoring calls).  The
     streaming form must reproduce the chunk-at-a-time scores BIT FOR BIT (same k-ordered FMA chains, same summation
-    order); the ring sums a d slice in one wave and the bf16x3 form accumulates eight exact partial products per
-    32-d block, so both are held to fp32 rounding of the scores -- and the bf16x3 form additionally to an error
+    order); the bf16x3 form accumulates eight exact partial products per
+    32-d block, so it is held to fp32 rounding of the scores -- and additionally to an error
     against the float64 oracle no larger than twice the exact-fp32 form's -- and every form to 1e-5 of the oracle.
     Shapes: the dist_eval call (two jobs, 4 / 2 column tiles), 7 column tiles on the source side (jobs of 4 + 3
-    tiles), D % 128 == 64 with an element-wise normaliser (the ring / bf16x3 forms decline it), a K = 1 model."""
+    tiles), D % 128 == 64 with an element-wise normaliser (the bf16x3 form declines it), a K = 1 model."""
     rng = np.random.RandomState(99)
     cfg = O.EncoderCfg(D=D, L=L, K=K)
     p = _mk(cfg, rng)
@@ -596,9 +596,8 @@ def test_projection_forms_agree(D, L, K, n, act_norm, monkeypatch):
     xt = torch.from_numpy(_inputs(rng, n, D, nv / 4)).cuda()
     norm = H.make_norm(1.0 / nv, -0.05, 0.0, 0.9) if act_norm else H.make_norm(1.0 / nv)
 
-    def run(stream, ring, x3):
+    def run(stream, x3):
         monkeypatch.setenv('CFL_DEBUG_PROJ_STREAM', str(stream))
-        monkeypatch.setenv('CFL_DEBUG_PROJ_RING', str(ring))
         monkeypatch.setenv('CFL_DEBUG_PROJ_X3', str(x3))
         H.reload_env()
         ws = torch.full((H.workspace_bytes(sh, n, 1) // 4,), float('nan'), dtype=torch.float32, device='cuda')
@@ -606,65 +605,23 @@ def test_projection_forms_agree(D, L, K, n, act_norm, monkeypatch):
         torch.cuda.synchronize()
         return out
     try:
-        classic, stream, ring, x3 = run(-1, -1, -1), run(1, -1, -1), run(-1, 1, -1), run(-1, -1, 1)
+        classic, stream, x3 = run(-1, -1), run(1, -1), run(-1, 1)
     finally:
-        for k in ('CFL_DEBUG_PROJ_STREAM', 'CFL_DEBUG_PROJ_RING', 'CFL_DEBUG_PROJ_X3'):
+        for k in ('CFL_DEBUG_PROJ_STREAM', 'CFL_DEBUG_PROJ_X3'):
             monkeypatch.delenv(k)
         H.reload_env()
     assert torch.equal(classic, stream)
     scale = max(1.0, float(classic.abs().max()))
-    assert float((classic - ring).abs().max()) <= 4e-6 * scale
     assert float((classic - x3).abs().max()) <= 4e-6 * scale
     f = (lambda x: O.normalize_v2(x.cpu().numpy().astype(np.float64), scale=1.0 / nv, mean=0.05, norm=1.0, clip_min=0.0,
                                   clip_max=0.9)) if act_norm else (lambda x: x.cpu().numpy().astype(np.float64) / nv)
     sub = slice(0, 1500)
     ref = O.pair_scores(cfg, _to64(p), np.float64(thr), f(xs[sub]), f(xt[sub]))
     err = {}
-    for name, got in (('classic', classic), ('ring', ring), ('x3', x3)):
+    for name, got in (('classic', classic), ('x3', x3)):
         err[name] = np.abs(got[sub].cpu().numpy() - ref).max()
         assert err[name] <= 1e-5 * max(1.0, np.abs(ref).max()), (name, err[name])
     assert err['x3'] <= max(2.0 * err['classic'], 2e-6 * scale), err
-
-
-@pytest.mark.parametrize('B,D,K,L,reg', [(512, 4096, 3, 20, 0.0), (512, 4096, 4, 10, 1e-3), (256, 2048, 3, 20, 0.0)])
-def test_projection_with_folded_row_math_equals_three_launch_step(B, D, K, L, reg, monkeypatch):
-    """CFL_DEBUG_FOLD=1: distance / loss / dL/dY run inside the projection launch (cfl_proj_mid_kernel: partial tiles
-    published by their S x jobs producers, every producer waits for its tile's group and then does its share of the
-    rows).  Same sums in the same order: parameters, Adam slots, gradient and scalars must equal the three-launch
-    step BIT FOR BIT over 200 steps (~13 000 tile hand-offs per step), and so must the scores of a scoring call."""
-    rng = np.random.RandomState(3)
-    cfg = O.EncoderCfg(D=D, L=L, K=K)
-    p = _mk(cfg, rng)
-    sh = _shape(cfg)
-    norm, loss = H.make_norm(1.0 / 58.388599), H.make_loss(reg_const=reg)
-    pool = [[torch.from_numpy(_inputs(rng, B, D, 13.0)).cuda() for _ in range(4)] for _ in range(5)]
-
-    def run(fold):
-        monkeypatch.setenv('CFL_DEBUG_FOLD', str(fold))
-        H.reload_env()
-        theta = H.pack_theta(sh, p, None, 0.5, 'cuda')
-        m, v = torch.zeros_like(theta), torch.zeros_like(theta)
-        grad = torch.zeros_like(theta)
-        scal = torch.zeros(H.S_COUNT, device='cuda')
-        ws = torch.full((H.workspace_bytes(sh, B, 2) // 4,), float('nan'), dtype=torch.float32, device='cuda')
-        hist = []
-        for i in range(200):
-            H.pair_train_step(sh, norm, loss, pool[i % 5], theta, m, v, grad, scal, ws, 1e-3, 0.9, 0.999)
-            if i % 20 == 0:
-                hist.append(scal.clone())
-        ws1 = torch.full((H.workspace_bytes(sh, B, 1) // 4,), float('nan'), dtype=torch.float32, device='cuda')
-        sc = H.pair_scores(sh, norm, pool[0][0], pool[0][1], theta, ws1).clone()
-        torch.cuda.synchronize()
-        return theta, m, v, grad, torch.stack(hist), sc
-    try:
-        a, b, c = run(0), run(1), run(2)      # 2: the sc1-load variant of the hand-off (timing experiment)
-    finally:
-        monkeypatch.delenv('CFL_DEBUG_FOLD')
-        H.reload_env()
-    assert not torch.isnan(b[0]).any()
-    for other in (b, c):
-        for x, y, name in zip(a, other, ('theta', 'm', 'v', 'grad', 'scalars', 'scores')):
-            assert torch.equal(x, y), name
 
 
 @pytest.mark.parametrize('B,D,L,wn,lkw,P', [
@@ -897,45 +854,3 @@ def test_fused_gradient_tail_monomer_and_directed_equal_finalize_kernel(dist, di
             assert torch.equal(x, y), (si, ti, (x != y).nonzero().flatten()[:8].tolist(), x.flatten()[(x != y).flatten()][:4].tolist(),
                                        y.flatten()[(x != y).flatten()][:4].tolist())
     assert np.isfinite(res['fused'][-1][1].cpu().numpy()).all()
-
-
-@pytest.mark.parametrize('B,D,K,L,wn,reg', [(512, 4096, 3, 20, False, 0.0), (512, 4096, 4, 10, False, 1e-3),
-                                            (1024, 4096, 3, 20, True, 1e-3), (256, 8192, 2, 12, False, 0.0),
-                                            (100, 4096, 4, 10, False, 0.0)])
-def test_row_math_inside_the_gradient_launch_equals_separate_mid_launch(B, D, K, L, wn, reg, monkeypatch):
-    """cfl_midgrad_half_kernel: the distance / loss / dL/dY math runs as the first blocks of the weight-gradient launch
-    (outputs written through, one generation flag per block), the contraction workgroups request their first chunk of x
-    and then wait for the flags (opt-in CFL_DEBUG_MIDGRAD=1: it measured slower than the separate launch).  Two launches
-    per step instead of three; parameters, Adam slots, gradient and scalars must equal the three-launch step BIT FOR BIT over 300 steps (256+ producer flags x 260 consumers per step)."""
-    from cfl.engine import PairEngine
-    rng = np.random.RandomState(12)
-    cfg = O.EncoderCfg(D=D, L=L, K=K, style='cfl' if wn else 'dist')
-    params = O.init_encoder_params(cfg, rng, np.float32)
-    pool = [[torch.from_numpy(np.abs(rng.randn(B, D)).astype(np.float32) * 3).cuda() for _ in range(4)] for _ in range(3)]
-    res = {}
-    for mode in ('inside', 'separate'):
-        monkeypatch.setenv('CFL_DEBUG_MIDGRAD', '1' if mode == 'inside' else '-1')
-        monkeypatch.setenv('CFL_DEBUG_GRAD_W8', '-1')     # (the two-launch form keeps the four-wave workgroups: same sums on both sides)
-        H.reload_env()
-        eng = PairEngine(D, L, K, weight_norm=cfg.weight_norm, has_bias=cfg.has_bias, norm=H.make_norm(1 / 8.0),
-                         loss=H.make_loss(reg_const=reg), params=params, batch_size=B)
-        H.profile_enable(True)
-        eng.step(pool[0])
-        torch.cuda.synchronize()
-        H.profile_enable(False)
-        kinds = set(H.profile_read())
-        assert ('mid' in kinds) == (mode == 'separate'), kinds
-        snaps = []
-        for it in range(300):
-            eng.step(pool[it % 3])
-            if it in (0, 1, 7, 299):
-                snaps.append([t.clone() for t in (eng.theta, eng.m, eng.v, eng.grad, eng.scalars)])
-        eng.fwd_bwd(pool[1])
-        snaps.append([eng.grad.clone(), eng.scalars.clone(), eng.theta.clone()])
-        res[mode] = snaps
-    monkeypatch.undo()
-    H.reload_env()
-    for a, b in zip(res['inside'], res['separate']):
-        for x, y in zip(a, b):
-            assert torch.equal(x, y)
-    assert np.isfinite(res['inside'][-1][1].cpu().numpy()).all()

@@ -260,45 +260,3 @@ def test_bx3_forward_is_fp32_equivalent(style, dist, D, L, K, B, nv, lkw):
         errs[keep] = e
     for k in errs[True]:
         assert errs[True][k] <= max(2.0 * errs[False][k], 1e-6), (k, errs[True][k], errs[False][k])
-
-
-@pytest.mark.parametrize('style,dist,D,L,K,B,lkw', [
-    ('cfl', 'siamese', 1024, 256, 1, 512, dict(use_threshold=False, caffe_margin=100.0, pos_weight=0.0625)),   # config 3: paired half tiles
-    ('cfl', 'pcd', 2048, 20, 5, 1024, dict(pos_weight=0.25)),                                                  # config 4: half tiles, rows split in two
-    ('dist', 'pcd', 4096, 20, 3, 512, dict()),                                                                 # headline: half tiles, no hand-off
-    ('cfl', 'pcd', 1024, 64, 3, 200, dict(lambda_m=0.5, reg_const=1e-3)),                                      # ragged rows (R % 32 != 0), 4 + 4 + 4 column tiles
-])
-def test_dy_planes_written_by_mid_equal_the_in_kernel_split(style, dist, D, L, K, B, lkw, monkeypatch):
-    """plan.dy_pre (opt-in experiment, CFL_DEBUG_DY_PRE=1; measured slower -- profiles/r04_dy_pre_ab.txt): mid writes dL/dy also as truncation-split bf16
-    planes in the B-fragment order and the half-tile weight gradient loads them instead of splitting dL/dy once per 32-d
-    tile.  Same split, same products, same order: training must be bit-identical with and without."""
-    rng = np.random.RandomState(21)
-    cfg = O.EncoderCfg(D=D, L=L, K=K, dist_type=dist, style=style)
-    p = _params(cfg, rng)
-    sh = H.make_shape(D, L, K, dist, cfg.weight_norm, cfg.has_bias)
-    norm, loss = H.make_norm(1.0 / 31.9098), H.make_loss(**lkw)
-    pool = [[torch.from_numpy((np.abs(rng.randn(B, D)) * 8.0).astype(np.float32)).cuda() for _ in range(4)] for _ in range(3)]
-    res = {}
-    try:
-        for mode in ('1', '-1'):
-            monkeypatch.setenv('CFL_DEBUG_DY_PRE', mode)
-            monkeypatch.setenv('CFL_DEBUG_GRAD_W8', '-1')     # (the pre-split form keeps the four-wave workgroups)
-            monkeypatch.setenv('CFL_DEBUG_GRAD_HALF', '1')       # the half-tile weight gradient at every shape of this test
-            H.reload_env()
-            theta = H.pack_theta(sh, p, None, 0.5 if dist != 'siamese' else 40.0, 'cuda')
-            m, v, grad = torch.zeros_like(theta), torch.zeros_like(theta), torch.zeros_like(theta)
-            scal = torch.zeros(H.S_COUNT, device='cuda')
-            ws = torch.full((H.workspace_bytes(sh, B, 2) // 4,), float('nan'), dtype=torch.float32, device='cuda')
-            planes = H.ThetaPlanes(sh, 'cuda')
-            hist = []
-            for i in range(10):
-                H.pair_train_step(sh, norm, loss, pool[i % 3], theta, m, v, grad, scal, ws, 1e-3, 0.9, 0.999, planes=planes)
-                hist.append(scal.clone())
-            torch.cuda.synchronize()
-            res[mode] = (theta, m, v, grad, torch.stack(hist))
-    finally:
-        monkeypatch.undo()
-        H.reload_env()
-    assert not torch.isnan(res['1'][0]).any()
-    for x, y, name in zip(res['1'], res['-1'], ('theta', 'm', 'v', 'grad', 'scalars')):
-        assert torch.equal(x, y), name

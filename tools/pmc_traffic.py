@@ -10,8 +10,8 @@ warm-up are included (same kernels, same shapes); the result is bytes per launch
 import csv, glob, json, os, sys
 from collections import defaultdict
 
-KEYS = {'cfl_proj_kernel': 'proj', 'cfl_proj_bx3_kernel': 'proj', 'cfl_proj_stream_kernel': 'proj', 'cfl_proj_ring_kernel': 'proj', 'cfl_proj_mid_kernel': 'proj', 'cfl_proj_x3_kernel': 'proj', 'cfl_proj_x3_keep_kernel': 'proj', 'cfl_wplanes_kernel': 'wplanes', 'cfl_mid_row_kernel': 'mid', 'cfl_mid_kernel': 'mid',
-        'cfl_grad_kernel': 'grad', 'cfl_grad_x3_kernel': 'grad', 'cfl_grad_x3_longrange_kernel': 'grad', 'cfl_grad_x3_half_kernel': 'grad', 'cfl_grad_x3_half_w8_kernel': 'grad', 'cfl_grad_x3_half_split_kernel': 'grad', 'cfl_finalize_kernel': 'finalize', 'cfl_adam_kernel': 'adam'}
+KEYS = {'cfl_proj_kernel': 'proj', 'cfl_proj_bx3_kernel': 'proj', 'cfl_proj_stream_kernel': 'proj', 'cfl_proj_x3_kernel': 'proj', 'cfl_proj_x3_keep_kernel': 'proj', 'cfl_wplanes_kernel': 'wplanes', 'cfl_mid_row_kernel': 'mid', 'cfl_mid_kernel': 'mid',
+        'cfl_grad_kernel': 'grad', 'cfl_grad_x3_kernel': 'grad', 'cfl_grad_x3_longrange_kernel': 'grad', 'cfl_grad_x3_half_kernel': 'grad', 'cfl_grad_x3_half_w8_kernel': 'grad', 'cfl_grad_x3_half_split_kernel': 'grad', 'cfl_finalize_kernel': 'finalize', 'cfl_adam_kernel': 'adam', 'cfl_adam_planes_kernel': 'adam'}
 
 
 def collect(d, counter):
