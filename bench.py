@@ -21,7 +21,7 @@ relays rank 0's line); under torchrun (WORLD_SIZE set) it is one of the ranks.
 Timing: W untimed warm-up steps (at least one pass over the pool), then R repeats of
 EXACTLY K steps, each repeat bracketed by barrier + synchronize on both sides and reduced
 with MAX over ranks; `ms_per_step` / `value` come from the MEDIAN repeat (min / max are
-in the line), so the timed work is ~1 s whatever K is.
+in the line), so the timed work is ~6 s (--timed-seconds) whatever K is.
 
 Prints ONE JSON line (rank 0) with the driver's contract fields plus `roofline`
 (dominant kernel, HIP-event timed), `roofline_eval` (scoring kernels), `cli_loop`
@@ -47,6 +47,7 @@ for _p in (ROOT, PKG):
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 FP32_MFMA_PEAK_TF = 157.3  # dense fp32 MFMA peak (same guide)
+BF16X3_PEAK_TF = 2500.0 / 6.0  # fp32-equivalent ceiling of the bf16x3 arithmetic: dense bf16 peak / six partial products
 NORMALIZE_VALUE = 58.388599
 NOISE = float(os.environ.get("CFL_BENCH_NOISE", "0.3"))  # target-side noise of the planted positives
 
@@ -57,7 +58,9 @@ def parse():
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--warmup', type=int, default=50)
     ap.add_argument('--repeats', type=int, default=0, help='timed repeats of the K-step region (0 = auto: >= 50 '
-                    'and enough for ~1 s of timed work)')
+                    'and enough for --timed-seconds of timed work)')
+    ap.add_argument('--timed-seconds', type=float, default=6.0, help='target length of the timed headline region (auto '
+                    'repeats): longer than the 5 s period of an external utilisation sampler')
     ap.add_argument('--batch-size', type=int, default=512)
     ap.add_argument('--input-size', type=int, default=4096)
     ap.add_argument('--num-components', type=int, default=3)
@@ -341,8 +344,19 @@ def other_configs(device):
             torch.cuda.synchronize()
             H.profile_enable(False)
             prof = H.profile_read()
+            # algorithmic flops per row: forward 2 D N + weight gradient 2 D N per side, N = head columns;
+            # siamese: both sides through ONE head of L columns (16 D L), pcd: L + K L columns over the two sides (8 D L (K+1))
+            flops_row = 16.0 * D * L if dist == 'siamese' else 8.0 * D * L * (K + 1)
+            tf = flops_row * B / t / 1e12
+            plan = H.plan_describe(eng.shape, B, 2, True, True)
             out[name] = {'us_per_step': round(t * 1e6, 2), 'rows_per_s': round(B / t, 1), 'batch_rows': B,
                          'launches_per_step': len(prof), 'hbm_frac_step': round(16.0 * D * B / t / 1e9 / HBM_PEAK_GBS, 4),
+                         # fp32-equivalent matrix work of the step against the fp32-MFMA roof and against the ceiling of the
+                         # bf16x3 arithmetic the kernels actually issue (2.5 PF bf16 / 6 partial products)
+                         'mfma_tflops_step': round(tf, 2), 'mfma_frac_step': round(tf / FP32_MFMA_PEAK_TF, 4),
+                         'bf16x3_frac_step': round(tf / BF16X3_PEAK_TF, 4),
+                         'binding_roof': 'mfma' if tf / FP32_MFMA_PEAK_TF > 16.0 * D * B / t / 1e9 / HBM_PEAK_GBS else 'hbm',
+                         'kernels': [plan['proj'], plan['mid'], plan['grad']],
                          'final_loss': round(eng.read_scalars()['total'], 6)}
             del pool, eng
             torch.cuda.empty_cache()
@@ -366,7 +380,19 @@ def other_configs(device):
             ph.step(*batch)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / n
-        out['config5_mrcgan_64x64_b100'] = {'ms_per_step': round(dt * 1e3, 3), 'images_per_s': round(B / dt, 1)}
+        from cfl import hipgan
+        hipgan.flop_counter = [0]
+        ph.step(*batch)
+        torch.cuda.synchronize()
+        flops, hipgan.flop_counter = float(hipgan.flop_counter[0]), None
+        out['config5_mrcgan_64x64_b100'] = {
+            'ms_per_step': round(dt * 1e3, 3), 'images_per_s': round(B / dt, 1),
+            # analytic flops of every convolution product the step issues (forward / input gradient / weight gradient of
+            # the batched G and D passes and the gradient-penalty double backward; counted by cfl.hipgan as it calls the
+            # library) over the step time: the conv stacks are matrix-bound
+            'roofline': {'bound': 'mfma', 'flops_per_step': flops, 'achieved': round(flops / dt / 1e12, 1), 'unit': 'TFLOP/s',
+                         'peak_fp32_mfma': FP32_MFMA_PEAK_TF, 'frac_fp32_mfma': round(flops / dt / 1e12 / FP32_MFMA_PEAK_TF, 4),
+                         'peak_bf16x3': round(BF16X3_PEAK_TF, 1), 'frac_bf16x3': round(flops / dt / 1e12 / BF16X3_PEAK_TF, 4)}}
         del ph
         torch.cuda.empty_cache()
     except Exception as e:
@@ -592,13 +618,13 @@ def main():
     run(warm, 0)
     sync_all()
     _trace('warm-up done')
-    # short calibration (untimed for the result): how many repeats make ~1 s of timed work (long enough for an external
-    # utilisation sampler to see the GPU busy; the median repeat is what is reported)
+    # short calibration (untimed for the result): how many repeats make --timed-seconds (6 s) of timed work -- longer than the
+    # 5 s period of an external utilisation sampler, so that it sees the GPU busy; the median repeat is what is reported
     t0 = time.perf_counter()
     run(args.steps, warm)
     sync_all()
     est = max(time.perf_counter() - t0, 1e-6)
-    repeats = args.repeats if args.repeats > 0 else int(min(5000, max(50, np.ceil(1.0 / est))))
+    repeats = args.repeats if args.repeats > 0 else int(min(50000, max(50, np.ceil(args.timed_seconds / est))))
     if world > 1:
         rt = torch.tensor([repeats], device=device, dtype=torch.int64)
         dist.broadcast(rt, 0)

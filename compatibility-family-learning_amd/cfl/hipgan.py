@@ -111,10 +111,23 @@ class ConvCache(object):
         return self
 
 
+# Analytic flop count of the convolution products issued (bench.py's MrCGAN roofline figure): set `flop_counter = [0]`,
+# run a step, read flop_counter[0].  One product (forward, input gradient or weight gradient) of a layer is
+# 2 * B * OH * OW * KH * KW * Ci * Co flops (transposed: per INPUT pixel).  None = not counting.
+flop_counter = None
+
+
+def _count_flops(conv, transposed, products):
+    if flop_counter is not None and products:
+        oh, ow = (conv.H, conv.W) if transposed else (-(-conv.H // conv.stride), -(-conv.W // conv.stride))
+        flop_counter[0] += products * 2 * conv.B * oh * ow * conv.KH * conv.KW * conv.Ci * conv.Co
+
+
 def conv_fwd(conv, x, V, g, b, y, ws, transposed=False, cache=None, residual=None, subpixel=False):
     """residual / subpixel: store epilogues of cfl_conv2d_wn_fwd_fused (y = act(conv + b + residual); y stored 2x
     sub-pixel shuffled [B, 2OH, 2OW, Co/4]); plain convolutions only."""
     L = lib()
+    _count_flops(conv, transposed, 1)
     if residual is not None or subpixel:
         if transposed:
             raise H.CflHipError('residual / sub-pixel epilogues exist for the plain convolution only')
@@ -155,6 +168,7 @@ def conv_bwd(conv, x, V, g, y, dy, ws, dx=None, dV=None, dg=None, db=None, reg_c
     """dy_subpixel: dy (and y) are [B, 2OH, 2OW, Co/4], the layout conv_fwd(subpixel=True) stores -- the un-shuffle of the
     gradient (subpixel_bwd) folded into the dy loaders of the halo-tile kernels (only where conv_bwd_takes_subpixel())."""
     L = lib()
+    _count_flops(conv, transposed, int(dx is not None) + int(dV is not None))
     if dy_subpixel:
         if transposed:
             raise CflHipError('dy_subpixel: not for transposed convolutions')
