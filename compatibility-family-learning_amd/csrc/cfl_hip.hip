@@ -3315,6 +3315,9 @@ __global__ __launch_bounds__(256) void cfl_mid_row_kernel(MidArgs a) {
         if (wave == 0) mid_reg_block(a, blockIdx.x - a.nrb);
         return;
     }
+    // (Round 5 measured the other placement: row tiles dealt over the XCDs by proj -- all d slices and column jobs of a 32-row
+    // tile on ONE XCD -- and the blocks here taking the rows whose slabs their own XCD's L2 still holds.  mid -0.2 us, proj
+    // +0.6, grad +0.5: the slab loads are not what this launch waits for.  profiles/r05_mid_xcd_ab.txt; not kept)
     mid_row_body<J>(a, blockIdx.x * 4 + wave, blockIdx.x == 0 && wave == 0, (float *)smem + wave * 6 * 64 * J);
 }
 
@@ -4270,6 +4273,7 @@ static int run_pairs(const CflShape *s, const CflNorm *norm, const CflLossCfg *l
     ma.scores = scores; ma.dists = dists;
     ma.nrb = train ? pl.nrb : (pl.R + MID_RB - 1) / MID_RB;
     ma.ys = pl.ys;
+
 
     // regions (shared by the mid regulariser blocks and finalize)
     FinArgs fa;
