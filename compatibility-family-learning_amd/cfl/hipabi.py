@@ -318,7 +318,14 @@ def _dev(t, dtype=torch.float32):
     return t.data_ptr()
 
 
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+
+
 def _stream():
+    """the HIP stream torch would launch on now, as an integer handle (torch.cuda.current_stream().cuda_stream costs ~8 us of
+    Python per call -- 400 calls per MrCGAN step; the raw getter a fraction of a microsecond)"""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 

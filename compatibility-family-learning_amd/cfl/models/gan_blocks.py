@@ -50,6 +50,7 @@ class ParamPool(object):
         self.theta = None
         self.version = 0     # bumped whenever theta changes (Adam, load): per-layer weight caches key on it
         self.layers = []     # the WNLayers whose variables live here (cache preparation behind the optimizer step)
+        self._views = {}     # (name, buffer address) -> view
 
     def add(self, name, value):
         value = np.asarray(value, np.float32)
@@ -71,9 +72,16 @@ class ParamPool(object):
         self._init = None
 
     def view(self, name, base=None):
-        o, shp = self.specs[name]
+        """the variable `name` as a view of `base` (theta, an Adam slot or a gradient buffer).  Views are cached per
+        (name, buffer): a post-epoch step asks for ~600 of them, and slicing + reshaping each time was a fifth of the
+        host time of the step (tools/gan_host_profile.py)."""
         base = self.theta if base is None else base
-        return base[o:o + int(np.prod(shp))].view(shp)
+        key = (name, base.data_ptr())
+        v = self._views.get(key)
+        if v is None:
+            o, shp = self.specs[name]
+            v = self._views[key] = base[o:o + int(np.prod(shp))].view(shp)
+        return v
 
     def named(self, base=None):
         return {n: self.view(n, base).detach().cpu().numpy().copy() for n in self.order}
@@ -483,36 +491,42 @@ class Discriminator(_Net):
         self.pool.finalize()
 
     # tape entries: ('conv', layer, x, y) | ('res', a, b, h, r1, r2, out) | ('tcat', C1, t_in, t_out)
-    def forward(self, x_flat, t=None):
+    def forward(self, x_flat, t=None, ws=None):
+        """`ws`: the workspace to use (a chain's own when a second forward of this network runs on another stream)"""
         self.join_prepare()
         N = x_flat.shape[0]
         tape = []
         h = x_flat.view((N,) + self.ae_shape)
+        if ws is None:
+            return self._forward(h, N, t, self.ws, tape)
+        return self._forward(h, N, t, ws, tape)
+
+    def _forward(self, h, N, t, ws, tape):
         if self.stem is not None:
-            y = self.stem.fwd(h, self.ws)
+            y = self.stem.fwd(h, ws)
             tape.append(('conv', self.stem, h, y))
             h = y
         for si, (res, down) in enumerate(self.stages):
             for a, b in res:
-                r1 = a.fwd(h, self.ws)
+                r1 = a.fwd(h, ws)
                 # out = lrelu(conv_b(r1) + h): the join is the store epilogue of conv b (r2 itself is read by nothing)
-                out = b.fwd(r1, self.ws, act='lrelu', residual=h)
+                out = b.fwd(r1, ws, act='lrelu', residual=h)
                 tape.append(('res', a, b, h, r1, None, out))
                 h = out
             if self.cond_stage == si:
                 if t is None:
                     raise H.CflHipError('this discriminator is conditional: pass t')
                 t_in = t.contiguous()
-                t_out = self.fc_t.fwd(t_in.view(N, 1, 1, -1), self.ws).view(N, -1) if self.fc_t is not None else t_in
+                t_out = self.fc_t.fwd(t_in.view(N, 1, 1, -1), ws).view(N, -1) if self.fc_t is not None else t_in
                 C1 = h.shape[3]
                 h = G.tile_concat_channels(h, t_out)
                 tape.append(('tcat', C1, t_in, t_out))
-            y = down.fwd(h, self.ws)
+            y = down.fwd(h, ws)
             tape.append(('conv', down, h, y))
             h = y
         f = h.view(N, 1, 1, self.feat)
-        disc = self.disc_head.fwd(f, self.ws).view(N, 1)
-        lat = self.lat_head.fwd(f, self.ws).view(N, self.latent_size)
+        disc = self.disc_head.fwd(f, ws).view(N, 1)
+        lat = self.lat_head.fwd(f, ws).view(N, self.latent_size)
         return disc, lat, (tape, f)
 
     def chain(self, k):

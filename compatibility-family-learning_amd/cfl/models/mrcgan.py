@@ -17,6 +17,8 @@ ranges that carry gradient: d-loss on [real | g | g_prj] (variables only), g-los
 D(x, t) on (pos target, c_pos) / (g, c_pos) / (neg target, c_neg) / (g_int, c_half) / (X_hat, c_pos);
 d = BCE(real,1) + (BCE(fake,0) + BCE(neg,0))/2 + GP;  g = BCE(fake,1) + BCE(int,1).
 """
+import os
+
 import numpy as np
 import torch
 
@@ -30,6 +32,8 @@ S_D_REAL, S_D_ENC, S_D_PRJ, S_D_GP, S_D_LAT, S_G_ENC, S_G_PRJ, S_G_LAT, S_G_NEG,
 
 
 class GanPhase(object):
+    gp_early = os.environ.get('CFL_GAN_GP_EARLY', '1') not in ('0', '')
+
     def __init__(self, gan_type, ae_shape, data_type, z_dim, latent_size, batch_size, device, rng,
                  g_lr=2e-4, g_beta1=0.5, g_beta2=0.999, d_lr=2e-4, d_beta1=0.5, d_beta2=0.999,
                  lambda_gp=None, lambda_dra=0.5, m_enc=None, m_prj=None, cgan=False, c_dim=None, t_dim=None):
@@ -81,18 +85,40 @@ class GanPhase(object):
                 ev.record(stream if stream is not None else torch.cuda.current_stream())
                 marks.append((name, ev))
         mark('start')
+        main = torch.cuda.current_stream()
+        c1, c2 = disc.chain(1), (disc.chain(2) if self.lambda_gp else None)
+        # The gradient-penalty chain -- X_hat, its OWN discriminator forward, the backward to the input and the double
+        # backward -- depends on nothing the generator produces: it starts HERE, on its own stream and workspace, beside the
+        # generator forward (2 ms of layers far too small to fill 256 CUs) instead of behind the batched discriminator
+        # forward, which then carries 4 B rows instead of 5 B.  (Round 5; CFL_GAN_GP_EARLY=0: X_hat rides in the batched forward)
+        gp_early = bool(self.lambda_gp) and c2 is not None and GanPhase.gp_early
+        if gp_early:
+            start_ev = torch.cuda.Event()
+            start_ev.record(main)
+
+        def gp_chain():
+            # (enqueued BEHIND the generator forward -- the host needs ~3 ms to enqueue this chain, and the critical chain's
+            # first launches must not wait for that -- but ordered only behind the start of the step)
+            c2[0].wait_event(start_ev)
+            with torch.cuda.stream(c2[0]):
+                x_hat = G.perturb(real, eps, self.lambda_dra)
+                _, _, tape = disc.forward(x_hat, ws=c2[1])
+                disc.gp_grads(tape, 0, B, self.lambda_gp, sc[S_D_GP:S_D_GP + 1], disc.pool.grad2, ws=c2[1])
+                mark('chain2_gradient_penalty')
+                return tape if self.keep_tapes else None
         # ---- generator: rows [g | g_prj | g_neg] ------------------------------------------------
         zc = torch.empty(3 * B, self.z_dim + Ld, dtype=torch.float32, device=self.device)
         for i, c in enumerate((enc_act, prj_c, neg_c)):
             G.concat_cols(z, c, out=zc[i * B:(i + 1) * B])
         fake, g_tape = gen.forward(zc)
         mark('g_forward')
+        gp_tape = gp_chain() if gp_early else None
         # ---- discriminator: rows [real | g | g_prj | g_neg | X_hat] -----------------------------
-        nrow = 5 * B if self.lambda_gp else 4 * B
+        nrow = 5 * B if (self.lambda_gp and not gp_early) else 4 * B
         x_all = torch.empty(nrow, self.ae_size, dtype=torch.float32, device=self.device)
         x_all[:B].copy_(real)
         x_all[B:4 * B].copy_(fake)
-        if self.lambda_gp:
+        if self.lambda_gp and not gp_early:
             G.perturb(real, eps, self.lambda_dra, out=x_all[4 * B:5 * B])
         d_logit, d_lat, d_tape = disc.forward(x_all)
         mark('d_forward')
@@ -110,8 +136,6 @@ class GanPhase(object):
         # (discriminator variables), the gradient-penalty passes (X_hat rows, into grad2) and the g-loss backward through D
         # and then G.  Most of their ~500 launches are far too small to fill 256 CUs, so the first two run on streams of
         # their own (own workspaces) beside the third; they are joined before the gradients are added and applied.
-        main = torch.cuda.current_stream()
-        c1, c2 = disc.chain(1), (disc.chain(2) if self.lambda_gp else None)
         if c1 is not None:
             c1[0].wait_stream(main)
             with torch.cuda.stream(c1[0]):
@@ -119,7 +143,7 @@ class GanPhase(object):
                 mark('chain1_d_loss_backward')
         else:
             disc.backward(d_tape, 0, 3 * B, dd, dl, need_dx=False, need_dw=True, grad=disc.pool.grad)
-        if self.lambda_gp:
+        if self.lambda_gp and not gp_early:
             if c2 is not None:
                 c2[0].wait_stream(main)
                 with torch.cuda.stream(c2[0]):
@@ -150,8 +174,8 @@ class GanPhase(object):
                 main.wait_stream(c[0])
         if self.lambda_gp:
             G.axpy(1.0, disc.pool.grad2, disc.pool.grad)
-        if self.keep_tapes:
-            self.last_tapes = (g_tape, d_tape)
+        if self.keep_tapes:     # (X_hat's activations: rows [4B, 5B) of d_tape, or rows [0, B) of the third tape)
+            self.last_tapes = (g_tape, d_tape, gp_tape if gp_early else None)
 
         if apply:
             disc.adam()

@@ -130,7 +130,8 @@ def test_convpcd_trajectory_with_equal_masks():
 def _gan_masks(mf, ph, B, gan_type, lambda_gp):
     """queue the masks of one recorded GanPhase.step in the order oracle/gan_oracle.py gan_losses evaluates them:
     G(enc), G(neg), G(prj) -- HIP rows [g | g_prj | g_neg] -- then D(real), D(g), D(g_prj), D(g_neg)[, D(X_hat)]"""
-    g_tape, (d_tape, _) = ph.last_tapes
+    g_tape, (d_tape, _) = ph.last_tapes[0], ph.last_tapes[1]
+    gp = ph.last_tapes[2][0] if len(ph.last_tapes) > 2 and ph.last_tapes[2] is not None else None   # X_hat's own forward
     for blk in (0, 2, 1):
         rows = slice(blk * B, (blk + 1) * B)
         for item in g_tape:
@@ -140,7 +141,10 @@ def _gan_masks(mf, ph, B, gan_type, lambda_gp):
                 mf.push('relu', item[2][rows])
     for blk in range(5 if lambda_gp else 4):
         rows = slice(blk * B, (blk + 1) * B)
-        for item in d_tape:
+        src = d_tape
+        if blk == 4 and gp is not None:
+            src, rows = gp, slice(0, B)
+        for item in src:
             if item[0] == 'conv':
                 if item[1].act == 'lrelu':
                     mf.push('lrelu', item[3][rows])
