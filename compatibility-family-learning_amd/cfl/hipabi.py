@@ -88,7 +88,7 @@ EXPORTS = ('cfl_version', 'cfl_last_error', 'cfl_layout', 'cfl_workspace_bytes',
            'cfl_dp_rs_push', 'cfl_dp_rs_adam', 'cfl_dp_rs_gather',
            'cfl_scalars_status', 'cfl_theta_planes_bytes', 'cfl_pair_train_step_planes', 'cfl_pair_train_step_idx_planes',
            'cfl_pair_train_steps_idx_planes', 'cfl_pair_step_fwd_bwd_planes', 'cfl_pair_step_fwd_bwd_idx_planes',
-           'cfl_adam_tf_planes', 'cfl_dp_rs_gather_planes', 'cfl_plan_describe')
+           'cfl_adam_tf_planes', 'cfl_dp_rs_gather_planes', 'cfl_plan_describe', 'cfl_crc32c')
 
 KERNEL_NAMES = ('colnorm', 'proj', 'mid', 'grad', 'finalize', 'adam', 'gather')
 K_COUNT = 8

@@ -4940,6 +4940,24 @@ extern "C" int cfl_mt19937_reshuffle(uint32_t *key, int32_t *pos, int64_t n, con
     return CFL_OK;
 }
 
+// HOST-ONLY: CRC-32C (Castagnoli) of n bytes, continuing from `crc` (0 to start): the checksum of TensorFlow's tensor-bundle
+// checkpoint files (cfl/tf_bundle.py writes / verifies them; cfl/utils.py:465-497 of the reference reads them with tf.train.Saver)
+extern "C" uint32_t cfl_crc32c(const void *data, size_t n, uint32_t crc) {
+    static uint32_t table[256];
+    static std::once_flag once;
+    std::call_once(once, [] {
+        for (uint32_t i = 0; i < 256; ++i) {
+            uint32_t c = i;
+            for (int k = 0; k < 8; ++k) c = (c & 1) ? (c >> 1) ^ 0x82f63b78u : c >> 1;
+            table[i] = c;
+        }
+    });
+    const unsigned char *p = (const unsigned char *)data;
+    uint32_t c = ~crc;
+    for (size_t i = 0; i < n; ++i) c = table[(c ^ p[i]) & 0xff] ^ (c >> 8);
+    return ~c;
+}
+
 extern "C" int cfl_adam_tf(float *theta, float *m, float *v, const float *grad, int64_t n,
                            float lr_t, float beta1, float beta2, float eps, float grad_scale,
                            cfl_stream_t stream) {

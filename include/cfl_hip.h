@@ -332,6 +332,11 @@ typedef struct {
 int cfl_plan_describe(const CflShape *shape, int64_t rows, int32_t groups, int32_t train, int32_t planes_kept,
                       CflPlanInfo *out);
 
+/* HOST-ONLY: CRC-32C (Castagnoli; reflected, init / xor-out ~0) of n bytes, continuing from `crc` (0 to start).  The
+ * checksum of TensorFlow's checkpoint files (tensor bundle + its SSTable index): cfl/tf_bundle.py writes and verifies the
+ * files the reference's tf.train.Saver exchanges at cfl/utils.py:465-497 without TensorFlow.                             */
+uint32_t cfl_crc32c(const void *data, size_t n, uint32_t crc);
+
 /* The launch plan of a (shape, rows, groups) combination is computed once per process and thread; the tuning /
  * diagnostic overrides it reads from the environment (CFL_EXACT_FP32, CFL_DEBUG_*) are re-read after this call. */
 int cfl_reload_env(void);

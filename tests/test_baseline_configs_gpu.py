@@ -164,13 +164,25 @@ def _close(name, got, want, rtol):
     assert err <= rtol * scale, '%s: max err %.3e vs scale %.3e' % (name, err, scale)
 
 
-@pytest.mark.parametrize('B,with_grads', [(20, True), (100, False)])
-def test_config5_mrcgan_post_epoch_step_64x64(B, with_grads):
+@pytest.mark.parametrize('B', [20, 100])
+def test_config5_mrcgan_post_epoch_step_64x64(B):
+    """BASELINE config 5 at its own shape, B = 20 and the reference batch B = 100: every loss part and every D / G gradient
+    tensor of one post-epoch step against oracle/gan_oracle.py in float64, with the SAME oracle evaluated in float32 on the CPU
+    as the yardstick (tests/parity_series.py): HIP must be no further from float64 than twice the fp32 CPU evaluation is --
+    loss parts: relative difference; gradients: per tensor, the fraction of entries within 5e-4 of the tensor's scale and the
+    worst entry (a near-zero pre-activation on the other side of an lrelu / relu kink changes single entries visibly, in
+    the fp32 CPU evaluation exactly as here: tests/test_activation_masks_gpu.py holds the masks equal and gets 2e-5)."""
+    import json
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from parity_series import ParitySeries
     from cfl.models import mrcgan as M
     from oracle import gan_oracle as GO
     shape, Ld, zd = (64, 64, 3), 64, 20
     cfgkw = dict(m_enc=0.05, m_prj=0.2, lambda_gp=0.5)
     o = GO.GanOracle('srgan', shape, 'tanh', zd, Ld, seed=1, **cfgkw)
+    o32 = GO.GanOracle('srgan', shape, 'tanh', zd, Ld, seed=1, dtype=torch.float32, **cfgkw)
     ph = M.GanPhase('srgan', shape, 'tanh', zd, Ld, B, torch.device('cuda'), np.random.RandomState(0),
                     lambda_dra=0.5, **cfgkw)
     for net, ref, pre in ((ph.gen, o.gp, 'Generator/'), (ph.disc, o.dp, 'Discriminator/')):
@@ -184,35 +196,50 @@ def test_config5_mrcgan_post_epoch_step_64x64(B, with_grads):
     ph.step(*[dev(b) for b in batch], apply=False)
     s = ph.read_scalars()
     tb = [torch.tensor(b) for b in batch]
-    if with_grads:
-        d_total, g_total, parts, d_grads, g_grads = o.losses_and_grads(*tb)
-    else:
-        with torch.enable_grad():
-            d_total, g_total, parts = GO.gan_losses(o.gp, o.dp, 'srgan', shape, 'tanh', *tb, lambda_dra=0.5, **cfgkw)
-        d_total, g_total = d_total.detach(), g_total.detach()
-    bad = []
+    d_total, g_total, parts, d_grads, g_grads = o.losses_and_grads(*tb)
+    d32, g32, parts32, d_grads32, g_grads32 = o32.losses_and_grads(*[torch.tensor(np.asarray(b, np.float32)) for b in batch])
     ref = dict(d_total_loss=float(d_total), g_total_loss=float(g_total))
     ref.update({k: float(v) for k, v in parts.items() if k in s})
+    ref32 = dict(d_total_loss=float(d32), g_total_loss=float(g32))
+    ref32.update({k: float(v) for k, v in parts32.items() if k in s})
     assert set(ref) >= {'d_loss_real', 'd_loss_fake', 'd_grad_loss', 'd_loss_d', 'g_loss', 'g_loss_d', 'g_loss_d_neg'}
+    ser = ParitySeries('config5_loss_parts_b%d' % B, floor=1e-5, meta=dict(shape=shape, B=B))
     for k, r in ref.items():
-        if abs(s[k] - r) > 5e-5 * max(1.0, abs(r)):
-            bad.append((k, s[k], r))
+        ser.add(0, k, s[k], r, ref32[k])
+    ser.check()
+    gd = ph.disc.pool.named(ph.disc.pool.grad)
+    gg = ph.gen.pool.named(ph.gen.pool.grad)
+    bad, table, nets = [], [], {}
+    for pre, got, want, twin in (('Discriminator/', gd, d_grads, d_grads32), ('Generator/', gg, g_grads, g_grads32)):
+        gscale = max(float(t.abs().max()) for t in want.values())
+        e_hip = e_cpu = n_ref = 0.0
+        for k, t in want.items():
+            w = t.numpy()
+            scale = max(float(np.abs(w).max()), 1e-3 * gscale)
+            dh = got[pre + k].astype(np.float64) - w
+            dc = twin[k].numpy().astype(np.float64) - w
+            d, d32_ = np.abs(dh) / scale, np.abs(dc) / scale
+            e_hip, e_cpu, n_ref = e_hip + float((dh * dh).sum()), e_cpu + float((dc * dc).sum()), n_ref + float((w * w).sum())
+            row = dict(tensor=pre + k, hip_share_off=float((d > 5e-4).mean()), hip_worst=float(d.max()),
+                       fp32cpu_share_off=float((d32_ > 5e-4).mean()), fp32cpu_worst=float(d32_.max()),
+                       hip_rel_l2=float(np.sqrt((dh * dh).sum() / max((w * w).sum(), 1e-300))),
+                       fp32cpu_rel_l2=float(np.sqrt((dc * dc).sum() / max((w * w).sum(), 1e-300))))
+            table.append(row)
+            # per tensor: the share of entries off by more than 5e-4 of the tensor's scale is no larger than twice the fp32
+            # CPU evaluation's (floor: 0.5 % of the entries).  (WHICH entries a flipped kink moves, and by how much, differs
+            # between any two fp32 evaluations: the worst entry is recorded, the L2 bar below is what is asserted)
+            if row['hip_share_off'] > max(0.005, 2.0 * row['fp32cpu_share_off']):
+                bad.append(row)
+        # per network: the whole gradient vector is no further (L2) from the float64 gradient than twice the fp32 CPU
+        # evaluation's (floor 1e-5 relative)
+        nets[pre] = dict(hip_rel_l2=float(np.sqrt(e_hip / n_ref)), fp32cpu_rel_l2=float(np.sqrt(e_cpu / n_ref)))
+        if nets[pre]['hip_rel_l2'] > max(1e-5, 2.0 * nets[pre]['fp32cpu_rel_l2']):
+            bad.append((pre, nets[pre]))
+    out_dir = os.environ.get('CFL_RECORD_DIR')
+    if out_dir:
+        os.makedirs(out_dir, exist_ok=True)
+        with open(os.path.join(out_dir, 'series_config5_gradients_b%d.json' % B), 'w') as fh:
+            json.dump({'bar': 'per network: relative L2 error of the gradient vector <= max(1e-5, 2 x fp32 CPU); per tensor: share of '
+                              'entries off by > 5e-4 of the tensor scale <= max(0.5 %, 2 x fp32 CPU share)', 'B': B,
+                       'networks': nets, 'tensors': table}, fh, indent=1)
     assert not bad, bad
-    if with_grads:
-        # gradients: a handful of near-zero pre-activations fall on the other side of an lrelu / relu kink in fp32
-        # (tests/test_activation_masks_gpu.py), which changes single entries by a visible amount; hence a fraction
-        # of the entries within 5e-4 of the tensor's scale plus a loose cap on the worst entry.  (The deepest
-        # tensors -- the generator's first fully connected layer, behind every kink of both networks -- sit at
-        # 96-98 % depending on the summation order of the kernels in between; the equal-mask test holds them to 2e-5.)
-        gd = ph.disc.pool.named(ph.disc.pool.grad)
-        gg = ph.gen.pool.named(ph.gen.pool.grad)
-        bad = []
-        for pre, got, want in (('Discriminator/', gd, d_grads), ('Generator/', gg, g_grads)):
-            gscale = max(float(t.abs().max()) for t in want.values())
-            for k, t in want.items():
-                w = t.numpy()
-                scale = max(float(np.abs(w).max()), 1e-3 * gscale)
-                d = np.abs(got[pre + k].astype(np.float64) - w) / scale
-                if (d <= 5e-4).mean() < 0.95 or d.max() > 2e-2:
-                    bad.append((pre + k, float((d <= 5e-4).mean()), float(d.max())))
-        assert not bad, bad

@@ -1,9 +1,14 @@
 """MI355X parity of the MrCGAN stacks / post-epoch step against the torch-fp64 oracle
 (oracle/gan_oracle.py).  Small shapes so that the CPU oracle (double backward through
 the discriminator) finishes in seconds."""
+import os
+import sys
+
 import numpy as np
 import pytest
 import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 
@@ -203,9 +208,17 @@ def test_discriminator_fwd_bwd_gp(gan_type, shape):
     ('srgan', (8, 8, 3), 0.05, 0.2, None),
 ])
 def test_post_epoch_step_matches_oracle(gan_type, shape, m_enc, m_prj, lambda_gp):
+    """Three free-running post-epoch steps beside the oracle in float64 AND beside the same oracle in float32 on the CPU:
+    every loss part of every step must be no further from float64 than twice what the fp32 CPU evaluation of the same
+    graph is (tests/parity_series.py; floor 1e-5 = north_star's bar; observed 1e-7 .. 5e-7, profiles/r05_series_gan_post_epoch_*.json)."""
+    from parity_series import ParitySeries
     G, GB, M, GO, _ = _mods()
     B, Ld, zd = 4, 6, 5
     o = GO.GanOracle(gan_type, shape, 'tanh', zd, Ld, seed=1, m_enc=m_enc, m_prj=m_prj, lambda_gp=lambda_gp)
+    o32 = GO.GanOracle(gan_type, shape, 'tanh', zd, Ld, seed=1, m_enc=m_enc, m_prj=m_prj, lambda_gp=lambda_gp,
+                       dtype=torch.float32)
+    ser = ParitySeries('gan_post_epoch_%s_%dx%d%s' % (gan_type, shape[0], shape[1], '' if lambda_gp else '_nogp'), floor=1e-5,
+                       meta=dict(gan_type=gan_type, shape=shape, B=B, steps=3, lambda_gp=lambda_gp))
     ph = M.GanPhase(gan_type, shape, 'tanh', zd, Ld, B, torch.device('cuda'), np.random.RandomState(0),
                     lambda_gp=lambda_gp, lambda_dra=0.5, m_enc=m_enc, m_prj=m_prj)
     _load(ph.gen.pool, o.gp, 'Generator/')
@@ -216,24 +229,27 @@ def test_post_epoch_step_matches_oracle(gan_type, shape, m_enc, m_prj, lambda_gp
         batch = [np.tanh(rng.randn(B, N)), 0.3 * rng.randn(B, Ld), 0.3 * rng.randn(B, Ld), 0.3 * rng.randn(B, Ld),
                  0.3 * rng.randn(B, Ld), rng.randn(B, zd), rng.rand(B, 1)]
         d_total, g_total, parts = o.step(*[torch.tensor(b) for b in batch])
+        d32, g32, parts32 = o32.step(*[torch.tensor(np.asarray(b, np.float32)) for b in batch])
         ph.step(*[_dev(b) for b in batch])
         s = ph.read_scalars()
-        tol = 5e-5 if it == 0 else 2e-3
-        for k in ('d_loss_real', 'd_loss_fake', 'd_loss_d', 'g_loss', 'g_loss_d'):
-            assert abs(s[k] - float(parts[k])) <= tol * max(1.0, abs(float(parts[k]))), (it, k, s[k], float(parts[k]))
-        if lambda_gp:
-            assert abs(s['d_grad_loss'] - float(parts['d_grad_loss'])) <= tol, (it, s['d_grad_loss'])
-        if m_prj:
-            assert abs(s['g_loss_d_neg'] - float(parts['g_loss_d_neg'])) <= tol
-        assert abs(s['d_total_loss'] - float(d_total)) <= tol * max(1.0, abs(float(d_total)))
-        assert abs(s['g_total_loss'] - float(g_total)) <= tol * max(1.0, abs(float(g_total)))
+        keys = ['d_loss_real', 'd_loss_fake', 'd_loss_d', 'g_loss', 'g_loss_d'] + (['d_grad_loss'] if lambda_gp else []) + \
+               (['g_loss_d_neg'] if m_prj else [])
+        for k in keys:
+            ser.add(it, k, s[k], float(parts[k]), float(parts32[k]))
+        ser.add(it, 'd_total_loss', s['d_total_loss'], float(d_total), float(d32))
+        ser.add(it, 'g_total_loss', s['g_total_loss'], float(g_total), float(g32))
+        if it == 0:      # before any update: pure forward precision, no yardstick needed
+            assert all(r[2] <= 1e-5 for r in ser.rows), ser.rows
+    ser.check()
     # variables after 3 simultaneous Adam steps (Adam's first steps are +-lr per element, so a
     # handful of sign flips of ~zero gradients are tolerated)
-    for pool, ref, pre in ((ph.gen.pool, o.gp, 'Generator/'), (ph.disc.pool, o.dp, 'Discriminator/')):
+    # ... and no more of them than the fp32 CPU evaluation has
+    for pool, ref, ref32, pre in ((ph.gen.pool, o.gp, o32.gp, 'Generator/'), (ph.disc.pool, o.dp, o32.dp, 'Discriminator/')):
         got = pool.named()
         for k, v in ref.items():
             diff = np.abs(got[pre + k] - v.numpy())
-            assert (diff <= 2e-4).mean() >= 0.97, (k, diff.max())
+            diff32 = np.abs(ref32[k].numpy().astype(np.float64) - v.numpy())
+            assert (diff <= 2e-4).mean() >= min(0.97, (diff32 <= 2e-4).mean() - 0.02), (k, diff.max(), (diff32 <= 2e-4).mean())
 
 
 def test_conditional_discriminator_srgan_64():

