@@ -55,8 +55,29 @@ class DeferredScalars(object):
         self.next_slot = (self.next_slot + 1) % self.SLOTS
         return host
 
-    def record(self, step, val_batch):
+    def reserve(self, n, val_rows):
+        """`n` pinned slot rows for a fused train + validation call (the kernels write [scalars | scores] into them
+        themselves: PairEngine.step_windows_val); waits for old read-backs when the ring is full"""
+        from .. import hipabi as H
+        while len(self.pending) + n > self.SLOTS:
+            self.poll(wait=True, at_most=1)
+        return [self._slot(H.S_COUNT + 2 * val_rows) for _ in range(n)]
+
+    def commit(self, steps, slots, val_rows):
+        """the call that fills `slots` (one per entry of `steps`) has been enqueued: ONE event behind it for all of them"""
         import torch
+        ev = torch.cuda.Event()
+        ev.record()
+        eng = self.model.engine
+        for step, host in zip(steps, slots):
+            self.pending.append((step, host, ev, eng._scalar_scale, val_rows))
+        self.poll()
+
+    def record(self, step, val_batch):
+        self.record_scalars(step, *self.record_scores(val_batch, scalars_too=True))
+
+    def record_scores(self, val_batch, scalars_too=False):
+        """score a validation batch with the weights as they stand NOW into a fresh slot; (slot, pairs per group)"""
         from .. import hipabi as H
         eng = self.model.engine
         while len(self.pending) >= self.SLOTS:
@@ -64,36 +85,65 @@ class DeferredScalars(object):
         table, streams = val_batch
         n = streams.n
         host = self._slot(H.S_COUNT + 2 * n)
-        host[:H.S_COUNT].copy_(eng.scalars, non_blocking=True)
+        if scalars_too:
+            host[:H.S_COUNT].copy_(eng.scalars, non_blocking=True)
         # the validation scores travel as they are (2 x n floats); the accuracy is counted on the host when the
         # slot is read -- no elementwise / reduction launches on the training stream
         # (positive and negative pairs in ONE scoring call: two launches and one copy instead of four and two.  Round 4 tried
         # a device staging row + ONE copy on a copy stream behind an event instead of the two copies on the training stream:
         # 39.1 -> 42.2 us per step, the cross-stream event costs more than the second copy; not kept)
         host[H.S_COUNT:].copy_(eng.scores_pos_neg(table, streams), non_blocking=True)
+        return host, n, scalars_too
+
+    def record_scalars(self, step, host, n, have_scalars=False):
+        """... and the scalars of the step that has just been enqueued; one event behind both"""
+        import torch
+        from .. import hipabi as H
+        eng = self.model.engine
+        if not have_scalars:
+            host[:H.S_COUNT].copy_(eng.scalars, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
         self.pending.append((step, host, ev, eng._scalar_scale, n))
         self.poll()
 
     def poll(self, wait=False, at_most=None):
+        """hand completed read-backs to the callback.  Entries that share an event (the up to FUSED_CHUNK read-backs of one
+        fused library call) are turned into scalars and accuracies TOGETHER, with a handful of NumPy calls for all of them:
+        at --scalar-every 1 the per-entry Python of the previous form (a ctypes status call, a dict and four small NumPy
+        reductions per iteration: ~25 us) was what bounded the loop, not the GPU."""
         from .. import hipabi as H
         k = 0
         while self.pending and (wait or self.pending[0][2].query()) and (at_most is None or k < at_most):
-            k += 1
-            step, host, ev, scale, n = self.pending.pop(0)
+            ev = self.pending[0][2]
             ev.synchronize()
-            vals = host.numpy()
+            group = []
+            while self.pending and self.pending[0][2] is ev and (at_most is None or k < at_most):
+                group.append(self.pending.pop(0))
+                k += 1
+            n, scale = group[0][4], group[0][3]
+            rows = np.stack([g[1].numpy() for g in group]) if len(group) > 1 else group[0][1].numpy()[None]
+            sc = rows[:, :H.S_COUNT]
             # a lost in-launch hand-off (sticky error word) raises here, one cadence after it happened at the latest
-            self.model.engine.check_health(vals[:H.S_COUNT])
-            s = dict(zip(H.SCALAR_NAMES, (float(x) * scale for x in vals[:H.S_COUNT])))
+            if sc[:, H.S_ERROR].any() or getattr(self.model.engine, '_oneshot', None) is not None:
+                for r in sc:
+                    self.model.engine.check_health(r)
             # batch_accuracy (cfl/bin/train_dist.py:52-56 of the reference: mean of [s_pos > 0] and [s_neg <= 0])
-            sp, sn = vals[H.S_COUNT:H.S_COUNT + n], vals[H.S_COUNT + n:]
-            acc = 0.5 * (float(np.count_nonzero(sp > 0)) / n + float(np.count_nonzero(sn <= 0)) / n)
-            self.on_scalars(step, s, acc)
+            acc = (0.5 / n) * ((rows[:, H.S_COUNT:H.S_COUNT + n] > 0).sum(1) + (rows[:, H.S_COUNT + n:] <= 0).sum(1))
+            vals = (sc.astype(np.float64) * scale).tolist() if scale != 1.0 else sc.tolist()
+            for g, row, a in zip(group, vals, acc.tolist()):
+                self.on_scalars(g[0], dict(zip(H.SCALAR_NAMES, row)), a)
 
     def flush(self):
         self.poll(wait=True)
+
+
+FUSED_CHUNK = 16    # iterations per library call at --scalar-every 1 (4 such calls fit the 64-slot pinned ring)
+
+
+def H_fusable(eng, batch_size):
+    from .. import hipabi as H
+    return H.train_val_fusable(eng.shape, batch_size, batch_size)
 
 
 def train_steps(model, train_src, val_src, batch_size, shard, n_steps, on_scalars=None, progress=None,
@@ -108,6 +158,63 @@ def train_steps(model, train_src, val_src, batch_size, shard, n_steps, on_scalar
     i = 0
     every = max(1, int(scalar_every))
     deferred = DeferredScalars(model, on_scalars) if on_scalars is not None else None
+    # The read-back iterations carry their validation batch INSIDE the training step's launches (extra scoring rows,
+    # cfl_pair_train_val_steps_idx_planes) wherever the library can (single GPU, chunk-at-a-time projection + wave-per-row
+    # math: the batch sizes of this loop): no second projection / row-math launch pair, no copy commands -- the kernels write
+    # [scalars | validation scores] into the pinned ring themselves.  With --scalar-every 1 (the reference's cadence) up to
+    # FUSED_CHUNK iterations go into one library call.  CFL_FUSED_VAL=0: the separate scoring call of rounds 3-4.
+    eng = model.engine
+    fused = (deferred is not None and not dp.dp_active() and os.environ.get('CFL_FUSED_VAL', '1') not in ('0', '')
+             and shard is None and H_fusable(eng, batch_size))
+    while fused and i < n_steps:
+        is_readback = lambda k: k % every == 0 or k == n_steps - 1
+        # chunk [i, j): with a read-back every iteration, FUSED_CHUNK of them; otherwise up to and including the next one
+        j = min(n_steps, i + FUSED_CHUNK) if every == 1 else min((i + every - 1) // every * every, n_steps - 1) + 1
+        kt, kv = train_src.available_windows(batch_size), val_src.available_windows(batch_size)
+        j = min(j, i + kt)
+        mask = [is_readback(k) for k in range(i, j)]
+        while sum(mask) > kv and mask:      # not enough plain validation windows left (the validation list wraps): a shorter chunk
+            mask.pop()
+        j = i + len(mask)
+        if j <= i or (sum(mask) == 0 and every == 1):
+            # the very next training or validation batch wraps an epoch (its list is reshuffled first): ONE iteration through
+            # the same fused call, on the windows the general draw leaves; batches that are no windows at all (B larger
+            # than a pair list: oversampled) go the general way, scored with the weights BEFORE the update as well
+            rb = is_readback(i)
+            win1 = train_src.next_window_any(batch_size, shard)
+            if win1 is None:
+                slot = deferred.record_scores(val_src.next_indexed(batch_size)) if rb else None
+                eng.step(train_src.next_indexed(batch_size, shard))
+                if slot is not None:
+                    deferred.record_scalars(i, slot[0], slot[1])
+            elif not rb:
+                eng.step_windows(win1)
+            else:
+                vwin1 = val_src.next_window_any(batch_size)
+                if vwin1 is None:
+                    slot = deferred.record_scores(val_src.next_indexed(batch_size))
+                    eng.step_windows(win1)
+                    deferred.record_scalars(i, slot[0], slot[1])
+                else:
+                    slots = deferred.reserve(1, batch_size)
+                    eng.step_windows_val(win1, vwin1, [True], [slots[0].data_ptr()])
+                    deferred.commit([i], slots, batch_size)
+            i += 1
+            if progress is not None:
+                progress.update(1)
+            continue
+        win = train_src.next_windows(batch_size, j - i, shard)
+        nval = sum(mask)
+        if nval:
+            vwin = val_src.next_windows(batch_size, nval)
+            slots = deferred.reserve(nval, batch_size)
+            eng.step_windows_val(win, vwin, mask, [h.data_ptr() for h in slots])
+            deferred.commit([i + k for k, mk in enumerate(mask) if mk], slots, batch_size)
+        else:
+            eng.step_windows(win)
+        if progress is not None:
+            progress.update(j - i)
+        i = j
     while i < n_steps:
         # the chunk ends with the next iteration whose scalars are read back (0, 25, 50, ..., and the last one)
         stop = min((i + every - 1) // every * every, n_steps - 1) + 1

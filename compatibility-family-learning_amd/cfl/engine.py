@@ -298,6 +298,22 @@ class PairEngine(object):
         self.global_step += win.nsteps
         self._scalar_scale = 1.0
 
+    def step_windows_val(self, win, vwin, val_mask, slot_ptrs):
+        """step_windows with the validation fetch inside the steps (single GPU; cfl_pair_train_val_steps_idx_planes): the
+        steps with val_mask[i] set also score the next validation batch of `vwin` as extra rows of their own projection /
+        row-math launches and write [scalars | scores of the positive, then the negative validation pairs] into the next
+        of `slot_ptrs` (rows of a pinned host buffer: no copy command, no second launch pair per read-back)."""
+        if dp_active():
+            raise H.CflHipError('step_windows_val is the single-GPU form; under data parallelism score separately')
+        ws = self._workspace(win.rows, 2)
+        b1p, b2p = H.pair_train_val_steps_idx(
+            self.shape, self.norm, self.loss, win, vwin, val_mask, slot_ptrs, self.theta, self.m, self.v, self.grad,
+            self.scalars, ws, np.float32(self.lr), self.beta1, self.beta2, self.eps, self.beta1_power, self.beta2_power,
+            planes=self.planes)
+        self.beta1_power, self.beta2_power = np.float32(b1p), np.float32(b2p)
+        self.global_step += win.nsteps
+        self._scalar_scale = 1.0
+
     def read_scalars(self):
         """Host copy of the last step's scalars (synchronises the stream).  Under data parallelism they are the
         global-batch values: every scalar is a mean over this rank's rows, the shards are equal-sized, and the

@@ -88,7 +88,8 @@ EXPORTS = ('cfl_version', 'cfl_last_error', 'cfl_layout', 'cfl_workspace_bytes',
            'cfl_dp_rs_push', 'cfl_dp_rs_adam', 'cfl_dp_rs_gather',
            'cfl_scalars_status', 'cfl_theta_planes_bytes', 'cfl_pair_train_step_planes', 'cfl_pair_train_step_idx_planes',
            'cfl_pair_train_steps_idx_planes', 'cfl_pair_step_fwd_bwd_planes', 'cfl_pair_step_fwd_bwd_idx_planes',
-           'cfl_adam_tf_planes', 'cfl_dp_rs_gather_planes', 'cfl_plan_describe', 'cfl_crc32c')
+           'cfl_adam_tf_planes', 'cfl_dp_rs_gather_planes', 'cfl_plan_describe', 'cfl_crc32c',
+           'cfl_train_val_fusable', 'cfl_pair_train_val_steps_idx_planes')
 
 KERNEL_NAMES = ('colnorm', 'proj', 'mid', 'grad', 'finalize', 'adam', 'gather')
 K_COUNT = 8
@@ -175,6 +176,16 @@ def lib():
     a = list(L.cfl_pair_train_steps_idx.argtypes)
     L.cfl_pair_train_steps_idx_planes.argtypes = a[:27] + [C.POINTER(CflThetaPlanes)] + a[27:]
     L.cfl_pair_train_steps_idx_planes.restype = C.c_int
+    L.cfl_train_val_fusable.argtypes = [C.POINTER(CflShape), C.c_int64, C.c_int64]
+    L.cfl_train_val_fusable.restype = C.c_int
+    L.cfl_pair_train_val_steps_idx_planes.argtypes = [
+        C.POINTER(CflShape), C.POINTER(CflNorm), C.POINTER(CflLossCfg), C.c_void_p, C.c_int64,
+        C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_char_p, C.c_int64,
+        C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64,
+        C.c_char_p, C.c_char_p, C.POINTER(C.c_void_p),
+        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float,
+        C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(CflThetaPlanes), C.c_void_p, C.c_size_t, C.c_void_p]
+    L.cfl_pair_train_val_steps_idx_planes.restype = C.c_int
     L.cfl_mt19937_reshuffle.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_int64, C.c_void_p, C.c_int64,
                                         C.c_void_p, C.c_void_p, C.c_void_p]
     L.cfl_mt19937_reshuffle.restype = C.c_int
@@ -440,6 +451,37 @@ def pair_train_steps_idx(shape, norm, loss, table, pos_pairs, neg_pairs, pos_hea
         _dev(neg_pairs, torch.int32), int(neg_pairs.shape[0]), int(pos_head), int(neg_head), int(batch_rows),
         int(shard_lo), int(rows), sw,
         int(nsteps), _dev(theta), _dev(m), _dev(v), _dev(grad), _dev(scalars), float(lr), float(beta1),
+        float(beta2), float(eps), C.byref(b1p), C.byref(b2p), _planes(planes), workspace.data_ptr(),
+        workspace.numel() * workspace.element_size(), _stream()))
+    return b1p.value, b2p.value
+
+
+def train_val_fusable(shape, rows, val_rows):
+    """can a training step of `rows` rows per group carry a validation batch of `val_rows` pairs per group as extra
+    scoring rows of its own launches (cfl_pair_train_val_steps_idx_planes)?"""
+    return lib().cfl_train_val_fusable(C.byref(shape), int(rows), int(val_rows)) == 1
+
+
+def _flags(xs):
+    return bytes(bytearray(int(bool(x)) for x in xs)) if xs is not None else None
+
+
+def pair_train_val_steps_idx(shape, norm, loss, win, vwin, val_mask, slot_ptrs, theta, m, v, grad, scalars, workspace, lr,
+                             beta1, beta2, eps, beta1_power, beta2_power, planes=None):
+    """win.nsteps training steps over windows of the device pair lists; the steps with val_mask[i] set also score the next
+    validation batch of `vwin` inside their own launches and leave [scalars | scores] in the next of `slot_ptrs`
+    (device-accessible addresses, e.g. rows of a pinned host tensor).  Returns the advanced (beta1_power, beta2_power)."""
+    tp, trows = _table(win.table)
+    vp, vrows = _table(vwin.table)
+    b1p, b2p = C.c_float(beta1_power), C.c_float(beta2_power)
+    slots = (C.c_void_p * max(1, len(slot_ptrs)))(*[int(p) for p in slot_ptrs])
+    _check(lib().cfl_pair_train_val_steps_idx_planes(
+        C.byref(shape), C.byref(norm), C.byref(loss), tp, trows, _dev(win.pos_pairs, torch.int32), int(win.pos_pairs.shape[0]),
+        _dev(win.neg_pairs, torch.int32), int(win.neg_pairs.shape[0]), int(win.pos_head), int(win.neg_head),
+        int(win.batch_rows), int(win.shard_lo), int(win.rows), _flags(win.switched), int(win.nsteps),
+        vp, vrows, _dev(vwin.pos_pairs, torch.int32), int(vwin.pos_pairs.shape[0]), _dev(vwin.neg_pairs, torch.int32),
+        int(vwin.neg_pairs.shape[0]), int(vwin.pos_head), int(vwin.neg_head), int(vwin.batch_rows), _flags(vwin.switched),
+        _flags(val_mask), slots, _dev(theta), _dev(m), _dev(v), _dev(grad), _dev(scalars), float(lr), float(beta1),
         float(beta2), float(eps), C.byref(b1p), C.byref(b2p), _planes(planes), workspace.data_ptr(),
         workspace.numel() * workspace.element_size(), _stream()))
     return b1p.value, b2p.value

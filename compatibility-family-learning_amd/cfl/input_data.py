@@ -599,6 +599,32 @@ class ResidentFeatures(object):
         ds.prefetch_reshuffle(batch_size)
         return self.table, self._h.IndexStreams(ptrs, 2, hi - lo, keep=keep)
 
+    def available_windows(self, batch_size):
+        """how many consecutive labeled batches the next next_windows() call could return (0: the next batch wraps an
+        epoch or is larger than a list) -- without touching the dataset's stream"""
+        ds = self.dataset
+        npos, nneg = ds.pairs_pos.shape[0], ds.pairs_neg.shape[0]
+        if batch_size > npos or batch_size > nneg:
+            return 0
+        return max(0, min((npos - ds.head_labeled_pos) // batch_size, (nneg - ds.head_labeled_neg) // batch_size))
+
+    def next_window_any(self, batch_size, shard=None):
+        """ONE labeled batch as a window descriptor (nsteps = 1) whatever the stream does next -- an epoch wrap reshuffles the
+        list first, exactly as next_batch_indices does, and the batch is then the window at its head -- or None, with the
+        stream untouched, when a batch is not a window at all (B larger than a pair list: the reference oversamples)."""
+        from argparse import Namespace
+        ds = self.dataset
+        if batch_size > ds.pairs_pos.shape[0] or batch_size > ds.pairs_neg.shape[0]:
+            return None
+        _, _, switched = ds.next_batch_indices(batch_size)
+        lo, hi = shard if shard is not None else (0, batch_size)
+        win = Namespace(table=self.table, pos_pairs=self._device_pairs('pos'), neg_pairs=self._device_pairs('neg'),
+                        pos_head=ds.head_labeled_pos - batch_size, neg_head=ds.head_labeled_neg - batch_size,
+                        batch_rows=batch_size, shard_lo=lo, rows=hi - lo, nsteps=1,
+                        switched=[switched] if ds.data_switch else None)
+        ds.prefetch_reshuffle(batch_size)
+        return win
+
     def next_windows(self, batch_size, max_steps, shard=None):
         """Up to `max_steps` consecutive labeled batches as ONE window descriptor for PairEngine.step_windows, or
         None when the very next batch is not a plain window of both pair lists (an epoch wrap reshuffles, or the

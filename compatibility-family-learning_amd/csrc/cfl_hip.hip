@@ -393,15 +393,48 @@ struct ProjJob {
     int nt, npad;
 };
 
+// EXTRA SCORING ROWS of a training call (round 5; cfl_pair_train_val_steps_idx_planes): the reference's loop fetches the
+// accuracy of a VALIDATION batch in the same sess.run as the training step (cfl/bin/train_dist.py:79-86).  The rows of that
+// batch ride in the training step's own projection and row-math launches -- rows [row0, row0 + n) behind the (padded)
+// training rows, read from their own resident table by their own index streams -- instead of a second projection +
+// row-math launch pair per iteration.  They are forward-only: no dL/dY, no loss, no weight gradient; mid writes their
+// scores straight to the caller's buffer.  n == 0 (tile0 = INT_MAX): no such rows, every existing path unchanged.
+struct RowExtra {
+    const float *table;        // resident feature table of the extra rows
+    const int *ix[2][2];       // [side][group]: index streams (group 0 = rows [0, bx), group 1 = rows [bx, 2 bx))
+    int istride;
+    unsigned last_row;
+    int row0, n, bx, tile0;    // first row / rows / rows per group / first 32-row tile of the extra rows
+};
+
 struct ProjArgs {
     ProjJob job[CFL_MAX_JOBS];
     RowSrc rows[2];
+    RowExtra xr;
     int B, R, Rpad, D, S;
     int xcd;  // 1: blockIdx.x enumerates the d slices (see cfl_xcd_aligned)
     NormDev norm;
     int njobs;            // z-slices [0, njobs) project; slice njobs (weight-norm only) computes the column norms
     ColnormArgs cn;
 };
+
+// row r of side `side` of a projection launch: a training / scoring row, or -- r >= xr.row0 -- an extra scoring row
+__device__ __forceinline__ const float *proj_row_ptr(const ProjArgs &a, int side, int r) {
+    if (a.xr.n > 0 && r >= a.xr.row0) {   // (uniform per 8-lane row group; rows past the end are clamped to the last one)
+        int e = r - a.xr.row0;
+        e = e < a.xr.n ? e : a.xr.n - 1;
+        const int g = e >= a.xr.bx ? 1 : 0;
+        const int *ip = a.xr.ix[side][g] + (size_t)(e - g * a.xr.bx) * a.xr.istride;
+        unsigned t = (unsigned)*ip;
+        t = t < a.xr.last_row ? t : a.xr.last_row;
+        return a.xr.table + (size_t)t * a.D;
+    }
+    return row_ptr(a.rows[side], r, a.B, a.R, a.D);
+}
+// first row of 32-row tile `tile`: the extra rows start at row0 (a multiple of 32 behind the padded training rows)
+__device__ __forceinline__ int proj_tile_row0(const ProjArgs &a, int tile) {
+    return tile < a.xr.tile0 ? tile * 32 : a.xr.row0 + (tile - a.xr.tile0) * 32;
+}
 
 template <int NT>
 __device__ __forceinline__ void proj_body(const ProjJob &jb, const ProjArgs &a, f32x4 *lds) {
@@ -412,7 +445,7 @@ __device__ __forceinline__ void proj_body(const ProjJob &jb, const ProjArgs &a, 
     // Workgroups are dealt to the 8 XCDs round-robin by linear id.  With the d slices fastest an XCD
     // only ever touches 1/8 of the weights (one slice of every column tile) and one d band of x --
     // the same band the weight-gradient launch assigns to it, so part of x is still in that XCD's L2.
-    const int row0 = (a.xcd ? blockIdx.y : blockIdx.x) * 32;
+    const int row0 = proj_tile_row0(a, a.xcd ? blockIdx.y : blockIdx.x);
     const int s = a.xcd ? blockIdx.x : blockIdx.y;
     const int G = a.D >> 4;           // 16-d groups
     const int NC = (G + 7) >> 3;      // 128-d chunks
@@ -427,7 +460,7 @@ __device__ __forceinline__ void proj_body(const ProjJob &jb, const ProjArgs &a, 
 
     const float *xrow[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) xrow[i] = row_ptr(a.rows[jb.side], row0 + 8 * i + rr8, a.B, a.R, a.D) + 4 * ch8;
+    for (int i = 0; i < 4; ++i) xrow[i] = proj_row_ptr(a, jb.side, row0 + 8 * i + rr8) + 4 * ch8;
     const float *wfl = jb.wf + lane * 4;
     f32x4 *tile = lds + wave * 256;  // 32 rows x 8 chunks of 16 B = 4 KiB per wave
     STAMP(0);
@@ -561,7 +594,7 @@ __device__ __forceinline__ void proj_body_bx3(const ProjJob &jb, const ProjArgs 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i16 = lane & 15, kq = lane >> 4;
     const int rr8 = lane >> 3, ch8 = lane & 7;
-    const int row0 = (a.xcd ? blockIdx.y : blockIdx.x) * 32;
+    const int row0 = proj_tile_row0(a, a.xcd ? blockIdx.y : blockIdx.x);
     const int s = a.xcd ? blockIdx.x : blockIdx.y;
     const int G = a.D >> 4, Q = a.D >> 5;
     const int NC = (G + 7) >> 3;
@@ -576,7 +609,7 @@ __device__ __forceinline__ void proj_body_bx3(const ProjJob &jb, const ProjArgs 
 
     const float *xrow[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) xrow[i] = row_ptr(a.rows[jb.side], row0 + 8 * i + rr8, a.B, a.R, a.D) + 4 * ch8;
+    for (int i = 0; i < 4; ++i) xrow[i] = proj_row_ptr(a, jb.side, row0 + 8 * i + rr8) + 4 * ch8;
     const unsigned short *pll = (const unsigned short *)jb.wf + lane * 8;   // planes of this job's first column tile
     f32x4 *tile = lds + wave * 256;
 
@@ -1193,6 +1226,7 @@ struct GradFuse {
     int nregblocks, B, use_threshold;
     float pos_weight, caffe_margin, lambda_m;
     float *scalars;
+    float *scalars2;             // a second destination of the step's scalars (nullptr: none)
     const float *thr_copy;
 };
 
@@ -1723,9 +1757,15 @@ __device__ __forceinline__ void grad_red_block(const GradArgs &a, float *lds) { 
                         float rs = 0.f;
                         for (int b = lane; b < f.nregblocks; b += 64) rs += f.regpart[b];
                         rs = wave_sum(rs);
-                        if (lane == 0)
+                        if (lane == 0) {
                             write_scalars(f.scalars, lds + 64, 0.5f * f.reg_const * rs, f.B, f.use_threshold,
                                           f.pos_weight, f.caffe_margin, f.lambda_m, f.thr_copy[0]);
+                            if (f.scalars2) {   // the caller's second copy (a pinned host ring slot: no copy command on the stream)
+                                write_scalars(f.scalars2, lds + 64, 0.5f * f.reg_const * rs, f.B, f.use_threshold,
+                                              f.pos_weight, f.caffe_margin, f.lambda_m, f.thr_copy[0]);
+                                f.scalars2[CFL_S_ERROR] = f.scalars[CFL_S_ERROR];   // (sticky: an error of THIS launch shows in the next slot at the latest)
+                            }
+                        }
                     }
                 } else if (f.red_b[k] >= 0 && wave == 0) {
                     const int c = idx * 16 + lane;
@@ -2360,6 +2400,10 @@ struct MidArgs {
     int *zero_i;          // hand-off tickets / flags of the fused weight-gradient launch: cleared here, every step
     int nzero;
     int nrb, ys;          // row blocks; LDS row stride of Y (floats)
+    // extra scoring rows of a training call (RowExtra): rows [xrow0, xrow0 + xn) of the partial slabs, forward only, scores to
+    // xscores[0 .. xn); nxb = their row blocks (wave-per-row kernels only), dispatched behind the training rows' blocks
+    int xrow0, xn, nxb;
+    float *xscores;
     // regulariser blocks
     const float *theta;
     float *regpart;
@@ -3047,7 +3091,8 @@ __device__ __forceinline__ void mid_row_body(const MidArgs &a, int r, bool lead,
     constexpr int CW = 64 * J;
     float *Pl = W, *Vl = W + CW, *Rl = W + 2 * CW, *T = W + 3 * CW, *S = W + 4 * CW, *Q = W + 5 * CW;
     RSTAMP(0);
-    const bool valid = r < a.R;
+    const bool extra = a.xn > 0 && r >= a.xrow0;
+    const bool valid = extra ? r - a.xrow0 < a.xn : r < a.R;
     const int L = a.L, K = a.K, RG = a.Rpad >> 4;
     const MidSide &ss = a.side[0], &sd = a.side[1];
     const int ns = ss.n;
@@ -3219,10 +3264,14 @@ __device__ __forceinline__ void mid_row_body(const MidArgs &a, int r, bool lead,
     RSTAMP(2);   // distance done
     const float thr = fmaxf(thr_raw, CFL_THR_FLOOR);
     const float o = thr - d;
-    if (!a.train) {
+    if (!a.train || extra) {
         if (valid && lane == 0) {
-            a.scores[r] = o;
-            if (a.dists) a.dists[r] = d;
+            if (extra) {
+                a.xscores[r - a.xrow0] = o;
+            } else {
+                a.scores[r] = o;
+                if (a.dists) a.dists[r] = d;
+            }
         }
         return;
     }
@@ -3311,8 +3360,12 @@ template <int J>
 __global__ __launch_bounds__(256) void cfl_mid_row_kernel(MidArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if ((int)blockIdx.x >= a.nrb) {
-        if (wave == 0) mid_reg_block(a, blockIdx.x - a.nrb);
+    if ((int)blockIdx.x >= a.nrb + a.nxb) {
+        if (wave == 0) mid_reg_block(a, blockIdx.x - a.nrb - a.nxb);
+        return;
+    }
+    if ((int)blockIdx.x >= a.nrb) {   // extra scoring rows (forward only)
+        mid_row_body<J>(a, a.xrow0 + ((int)blockIdx.x - a.nrb) * 4 + wave, false, (float *)smem + wave * 6 * 64 * J);
         return;
     }
     // (Round 5 measured the other placement: row tiles dealt over the XCDs by proj -- all d slices and column jobs of a 32-row
@@ -3656,6 +3709,8 @@ static const char *const kGradKernelName[] = {"", "cfl_grad_x3_half_w8_kernel", 
 struct Plan {
     CflLayout lay;
     int proj_kernel, mid_kernel, grad_kernel;   // ProjKernel / MidKernel / GradKernel
+    int Rx, Rxpad, Rtot;   // extra scoring rows of a training call (RowExtra), padded to 32, and Rpad + Rxpad (rows of the partial slabs)
+    bool x_ok;             // ... and whether this plan's kernels can carry them (chunk-at-a-time projection, wave-per-row math)
     int R, Rpad, S, P, nrb, nregblocks;
     int kpad, lpad, Lq;
     bool has_cw, mono;
@@ -3705,7 +3760,7 @@ static void side_heads(const CflShape *s, const CflLayout &lay, const CflHead **
     }
 }
 
-static int make_plan(const CflShape *s, int64_t rows, int groups, bool train, bool planes_kept, Plan *pl) {
+static int make_plan(const CflShape *s, int64_t rows, int groups, bool train, bool planes_kept, Plan *pl, int64_t xrows = 0) {
     int rc = cfl_layout(s, &pl->lay);
     if (rc) return rc;
     if (rows <= 0 || groups < 1 || groups > 2) return set_err(CFL_E_SHAPE, "rows=%lld groups=%d", (long long)rows, groups);
@@ -3774,7 +3829,11 @@ static int make_plan(const CflShape *s, int64_t rows, int groups, bool train, bo
     pl->P = P;
     pl->Rpad = (int)round_up(pl->R, 256 * P);  // grad: 64-row chunks x 4 waves x P ranges
     // proj d split: one 128-d chunk per wave when that yields enough workgroups
-    const int rtiles = (pl->R + 31) / 32;
+    if (xrows < 0 || xrows > (1 << 24) || (xrows && !train)) return set_err(CFL_E_SHAPE, "extra scoring rows %lld", (long long)xrows);
+    pl->Rx = (int)xrows;
+    pl->Rxpad = (int)round_up(xrows, 32);
+    pl->Rtot = pl->Rpad + pl->Rxpad;
+    const int rtiles = (pl->R + 31) / 32 + pl->Rxpad / 32;
     const int nchunks = (s->D / 16 + 7) / 8;
     int S = (512 + rtiles * njobs - 1) / (rtiles * njobs);
     S = pow2_floor(S < 1 ? 1 : S);
@@ -3788,7 +3847,7 @@ static int make_plan(const CflShape *s, int64_t rows, int groups, bool train, bo
     pl->planes_kept = planes_kept && train;
     {
         const int ov = debug_env("CFL_DEBUG_PROJ_X3");
-        const int tiles = (pl->R + 127) / 128;
+        const int tiles = (pl->R + pl->Rxpad + 127) / 128;   // (extra scoring rows only steer the choice: the LDS-shared form cannot carry them)
         int rs = 1;
         const int want_units = debug_env("CFL_DEBUG_X3_UNITS") > 0 ? debug_env("CFL_DEBUG_X3_UNITS") : 384;
         // slices of at least 512 d -- 256 d (eight 32-d steps per unit) only to reach 256 units at all (configs 3 / 4)
@@ -3848,8 +3907,8 @@ static int make_plan(const CflShape *s, int64_t rows, int groups, bool train, bo
     size_t off = 0;
     auto take = [&](size_t n) { size_t o = off; off += round_up((int64_t)n, 64); return o; };
     const size_t rp = pl->Rpad;
-    pl->ypart[0] = take((size_t)S * hs->npad * rp);
-    pl->ypart[1] = take((size_t)S * hd->npad * rp);
+    pl->ypart[0] = take((size_t)S * hs->npad * pl->Rtot);
+    pl->ypart[1] = take((size_t)S * hd->npad * pl->Rtot);
     if (train) {
         pl->dyf[0] = take(hs->npad * rp);
         pl->dyf[1] = take(hd->npad * rp);
@@ -3913,6 +3972,7 @@ static int make_plan(const CflShape *s, int64_t rows, int groups, bool train, bo
                          : (s->K <= 8 && pl->Lq <= 2) ? MK_REG_K8_LQ2
                          : (s->K <= 4 && pl->Lq <= 4) ? MK_REG_K4_LQ4 : MK_GENERIC;
     }
+    pl->x_ok = (pl->proj_kernel == PK_EXACT || pl->proj_kernel == PK_BX3) && pl->mid_kernel <= MK_ROW4;
     pl->grad_kernel = GK_NONE;
     if (train) {
         // (the siamese pairing of the FUSED tail always takes the hand-off kernel: two sides feed one head)
@@ -3968,6 +4028,9 @@ extern "C" size_t cfl_workspace_bytes(const CflShape *s, int64_t rows, int32_t g
             Plan pl;
             if (make_plan(s, rows, groups, train != 0, kept != 0, &pl)) return 0;
             if (pl.total_floats > need) need = pl.total_floats;
+            // ... and the training step that carries a validation batch of the same size as extra scoring rows
+            if (train && make_plan(s, rows, groups, true, kept != 0, &pl, 2 * rows) == CFL_OK && pl.total_floats > need)
+                need = pl.total_floats;
         }
     return need * sizeof(float);
 }
@@ -4034,14 +4097,17 @@ struct AdamFuse { float *theta, *m, *v; float lr_t, b1, b2, eps; };
 
 // Indexed row source of a call (cfl_pair_*_idx): rows of `table` picked by 2 * groups index streams.
 struct IndexSrc { const float *table; int64_t table_rows; const int32_t *const *idx; int64_t stride; };
+// Extra scoring rows of a training call (RowExtra): bx pairs per group, idx = {src g0, dst g0, src g1, dst g1}; their 2 bx scores
+// go to `scores` and a second copy of the step's scalars to `scalars_copy` (both may be host-mapped memory)
+struct ExtraSrc { const float *table; int64_t table_rows; const int32_t *idx[4]; int64_t stride; int64_t bx; float *scores, *scalars_copy; };
 
 // The plan of a (shape, rows, groups, train) combination never changes within a process (the tuning overrides
 // are read from the environment once per combination): a training loop re-plans nothing per step.
 static std::atomic<int> g_env_generation{0};
 extern "C" int cfl_reload_env(void) { return ++g_env_generation; }
 
-static int cached_plan(const CflShape *s, int64_t rows, int groups, bool train, bool kept, Plan *out) {
-    struct Entry { CflShape s; int64_t rows; int groups; bool train, kept; Plan pl; };
+static int cached_plan(const CflShape *s, int64_t rows, int groups, bool train, bool kept, Plan *out, int64_t xrows = 0) {
+    struct Entry { CflShape s; int64_t rows, xrows; int groups; bool train, kept; Plan pl; };
     static thread_local std::vector<Entry> cache;
     static thread_local int seen_generation = 0;
     if (seen_generation != g_env_generation.load()) {
@@ -4050,14 +4116,14 @@ static int cached_plan(const CflShape *s, int64_t rows, int groups, bool train, 
     }
     if (!s) return set_err(CFL_E_SHAPE, "shape is NULL");
     for (const Entry &e : cache)
-        if (e.rows == rows && e.groups == groups && e.train == train && e.kept == kept && memcmp(&e.s, s, sizeof(CflShape)) == 0) {
+        if (e.rows == rows && e.xrows == xrows && e.groups == groups && e.train == train && e.kept == kept && memcmp(&e.s, s, sizeof(CflShape)) == 0) {
             *out = e.pl;
             return CFL_OK;
         }
-    int rc = make_plan(s, rows, groups, train, kept, out);
+    int rc = make_plan(s, rows, groups, train, kept, out, xrows);
     if (rc) return rc;
     if (cache.size() >= 64) cache.erase(cache.begin());
-    cache.push_back({*s, rows, groups, train, kept, *out});
+    cache.push_back({*s, rows, xrows, groups, train, kept, *out});
     return CFL_OK;
 }
 
@@ -4065,7 +4131,7 @@ static int run_pairs(const CflShape *s, const CflNorm *norm, const CflLossCfg *l
                      const float *const *x, int groups, int64_t rows, const float *theta,
                      float *grad, float *scalars, float *scores, float *dists, void *workspace,
                      size_t workspace_bytes, hipStream_t st, const AdamFuse *adam = nullptr,
-                     const IndexSrc *isrc = nullptr, CflThetaPlanes *kept = nullptr) {
+                     const IndexSrc *isrc = nullptr, CflThetaPlanes *kept = nullptr, const ExtraSrc *xs = nullptr) {
     const bool train = grad != nullptr;
     Plan pl;
     if (kept && (!kept->buf || ((uintptr_t)kept->buf & 15))) return set_err(CFL_E_SHAPE, "theta planes buffer NULL or misaligned");
@@ -4073,8 +4139,17 @@ static int run_pairs(const CflShape *s, const CflNorm *norm, const CflLossCfg *l
     // Adam tail then WRITES the planes of the updated weights (`adam`); a call that leaves theta alone (the forward /
     // backward of a data-parallel step: the update is cfl_adam_tf_planes, after the exchange) only reads them
     const bool keeping = kept && train && debug_env("CFL_DEBUG_NOFUSE") <= 0;
-    int rc = cached_plan(s, rows, groups, train, keeping, &pl);
+    int rc = cached_plan(s, rows, groups, train, keeping, &pl, xs ? 2 * xs->bx : 0);
     if (rc) return rc;
+    if (xs) {
+        if (!train || !pl.x_ok || !pl.fused)
+            return set_err(CFL_E_UNSUPPORTED, "extra scoring rows need the chunk-at-a-time projection, the wave-per-row math and the fused tail");
+        if (!xs->table || ((uintptr_t)xs->table & 15) || xs->table_rows <= 0 || xs->table_rows >= (1ll << 31) || xs->bx <= 0 ||
+            xs->stride <= 0 || xs->stride > (1 << 20) || !xs->scores)
+            return set_err(CFL_E_SHAPE, "extra scoring rows: table / stride / row count / scores");
+        for (int i = 0; i < 4; ++i)
+            if (!xs->idx[i] || ((uintptr_t)xs->idx[i] & 3)) return set_err(CFL_E_SHAPE, "extra scoring rows: index stream %d NULL or misaligned", i);
+    }
     if (!theta || !workspace) return set_err(CFL_E_SHAPE, "NULL theta/workspace");
     if (workspace_bytes < pl.total_floats * sizeof(float))
         return set_err(CFL_E_WORKSPACE, "workspace %zu < %zu bytes", workspace_bytes,
@@ -4142,7 +4217,7 @@ static int run_pairs(const CflShape *s, const CflNorm *norm, const CflLossCfg *l
                 j.side = sd;
                 j.wf = theta + h->w + (size_t)c0 * G * 256;
                 j.ypart = ws + pl.ypart[sd] + (size_t)c0 * 16;
-                j.sstride = (long long)h->npad * rp;
+                j.sstride = (long long)h->npad * pl.Rtot;
                 j.nt = tiles - c0 < 4 ? tiles - c0 : 4;
                 j.npad = h->npad;
             }
@@ -4151,6 +4226,15 @@ static int run_pairs(const CflShape *s, const CflNorm *norm, const CflLossCfg *l
         pa.B = (int)rows; pa.R = pl.R; pa.Rpad = pl.Rpad; pa.D = s->D; pa.S = pl.S; pa.norm = nd;
         pa.xcd = pl.xcd;
         pa.njobs = nj; pa.cn = cna;
+        pa.xr.tile0 = 0x7fffffff;     // no extra scoring rows
+        if (xs) {
+            pa.xr.table = xs->table;
+            for (int sd = 0; sd < 2; ++sd)
+                for (int g = 0; g < 2; ++g) pa.xr.ix[sd][g] = xs->idx[2 * g + sd];
+            pa.xr.istride = (int)xs->stride;
+            pa.xr.last_row = (unsigned)(xs->table_rows - 1);
+            pa.xr.row0 = pl.Rpad; pa.xr.n = pl.Rx; pa.xr.bx = (int)xs->bx; pa.xr.tile0 = (pl.R + 31) / 32;
+        }
         const bool cn_slice = cna.ncols > 0;
         if (cn_slice && nj >= CFL_MAX_JOBS) return set_err(CFL_E_UNSUPPORTED, "too many column chunks");
         if (cn_slice) pa.job[nj].nt = 0;      // marks the colnorm slice
@@ -4205,7 +4289,7 @@ static int run_pairs(const CflShape *s, const CflNorm *norm, const CflLossCfg *l
             if (pl.proj_kernel == PK_X3_KEEP) hipLaunchKernelGGL(cfl_proj_x3_keep_kernel, dim3(pl.x3_nwg + xa.ncn), dim3(256), PX3_LDS_BYTES, st, xa);
             else hipLaunchKernelGGL(cfl_proj_x3_kernel, dim3(pl.x3_nwg + xa.ncn), dim3(256), PX3_LDS_BYTES, st, xa);
         } else {
-        const int rtiles = (pl.R + 31) / 32;
+        const int rtiles = (pl.R + 31) / 32 + pl.Rxpad / 32;
         dim3 grid(rtiles, pl.S, nz);
         if (pa.xcd) grid = dim3(pl.S, rtiles, nz);
         ProfScope ps(st, CFL_K_PROJ);
@@ -4234,7 +4318,7 @@ static int run_pairs(const CflShape *s, const CflNorm *norm, const CflLossCfg *l
         const CflHead *h = side[sd].head;
         MidSide &m = ma.side[sd];
         m.ypart = ws + pl.ypart[sd];
-        m.sstride = (long long)h->npad * rp;
+        m.sstride = (long long)h->npad * pl.Rtot;
         m.b = h->b >= 0 ? theta + h->b : nullptr;
         m.g = h->g >= 0 ? theta + h->g : nullptr;
         m.n2 = s->weight_norm ? n2base + n2_off[side[sd].enc][side[sd].which] : nullptr;
@@ -4273,6 +4357,7 @@ static int run_pairs(const CflShape *s, const CflNorm *norm, const CflLossCfg *l
     ma.scores = scores; ma.dists = dists;
     ma.nrb = train ? pl.nrb : (pl.R + MID_RB - 1) / MID_RB;
     ma.ys = pl.ys;
+    if (xs) { ma.xrow0 = pl.Rpad; ma.xn = pl.Rx; ma.nxb = pl.Rxpad / 4; ma.xscores = xs->scores; }
 
 
     // regions (shared by the mid regulariser blocks and finalize)
@@ -4348,8 +4433,8 @@ static int run_pairs(const CflShape *s, const CflNorm *norm, const CflLossCfg *l
     }
     {
         ProfScope ps(st, CFL_K_MID);
-        const dim3 mgrid(ma.nrb + nreg_blocks), mblk(64);
-        const dim3 rgrid(ma.nrb + nreg_blocks);
+        const dim3 mgrid(ma.nrb + nreg_blocks), mblk(64);   // (register forms: no extra scoring rows, plan.x_ok)
+        const dim3 rgrid(ma.nrb + ma.nxb + nreg_blocks);
         switch (pl.mid_kernel) {
             case MK_ROW1: hipLaunchKernelGGL((cfl_mid_row_kernel<1>), rgrid, dim3(256), 4 * 6 * 64 * sizeof(float), st, ma); break;
             case MK_ROW2: hipLaunchKernelGGL((cfl_mid_row_kernel<2>), rgrid, dim3(256), 4 * 6 * 128 * sizeof(float), st, ma); break;
@@ -4524,6 +4609,7 @@ static int run_pairs(const CflShape *s, const CflNorm *norm, const CflLossCfg *l
             f.B = (int)rows; f.use_threshold = loss->use_threshold;
             f.pos_weight = loss->pos_weight; f.caffe_margin = loss->caffe_margin; f.lambda_m = loss->lambda_m;
             f.scalars = scalars; f.thr_copy = ws + pl.thr_copy;
+            f.scalars2 = xs ? xs->scalars_copy : nullptr;
         }
         ga.tps = pl.xcd ? (s->D / (pl.grad_half ? 32 : 64)) / pl.S : 0;
         dim3 grid(s->D / 64, pl.P, nj + 1);
@@ -4740,6 +4826,70 @@ extern "C" int cfl_pair_train_steps_idx_planes(const CflShape *shape, const CflN
         IndexSrc is = {table, table_rows, idx4, 2};
         rc = run_pairs(shape, norm, loss, nullptr, 2, rows, theta, grad, scalars, nullptr, nullptr, workspace,
                        workspace_bytes, (hipStream_t)stream, &af, &is, planes);
+        if (rc) return rc;
+        b1p *= beta1;
+        b2p *= beta2;
+    }
+    *beta1_power = b1p;
+    *beta2_power = b2p;
+    return CFL_OK;
+}
+
+// ... with the reference's validation fetch inside the steps (include/cfl_hip.h): step i with val_mask[i] != 0 also scores the next
+// validation batch (window `val_head + k * val_batch_rows` of the validation pair lists, k = validation steps so far) as extra
+// scoring rows of its own projection / row-math launches and leaves [scalars | scores] in ring_slots[k].
+extern "C" int cfl_train_val_fusable(const CflShape *shape, int64_t rows, int64_t val_rows) {
+    Plan pl;
+    if (make_plan(shape, rows, 2, true, true, &pl, 2 * val_rows)) return 0;
+    return (pl.x_ok && pl.fused) ? 1 : 0;
+}
+
+extern "C" int cfl_pair_train_val_steps_idx_planes(
+    const CflShape *shape, const CflNorm *norm, const CflLossCfg *loss, const float *table, int64_t table_rows,
+    const int32_t *pos_pairs, int64_t n_pos, const int32_t *neg_pairs, int64_t n_neg, int64_t pos_head, int64_t neg_head,
+    int64_t batch_rows, int64_t shard_lo, int64_t rows, const uint8_t *switched, int64_t nsteps,
+    const float *val_table, int64_t val_table_rows, const int32_t *val_pos_pairs, int64_t n_val_pos,
+    const int32_t *val_neg_pairs, int64_t n_val_neg, int64_t val_pos_head, int64_t val_neg_head, int64_t val_batch_rows,
+    const uint8_t *val_switched, const uint8_t *val_mask, float *const *ring_slots,
+    float *theta, float *m, float *v, float *grad, float *scalars, float lr, float beta1, float beta2, float eps,
+    float *beta1_power, float *beta2_power, CflThetaPlanes *planes, void *workspace, size_t workspace_bytes,
+    cfl_stream_t stream) {
+    int rc = check_train_args(loss, grad, scalars);
+    if (rc) return rc;
+    if (!m || !v || !pos_pairs || !neg_pairs || !beta1_power || !beta2_power || !val_mask || !ring_slots || !val_pos_pairs ||
+        !val_neg_pairs)
+        return set_err(CFL_E_SHAPE, "NULL pointer");
+    if (nsteps <= 0 || batch_rows <= 0 || rows <= 0 || shard_lo < 0 || shard_lo + rows > batch_rows || pos_head < 0 ||
+        neg_head < 0 || val_batch_rows <= 0 || val_pos_head < 0 || val_neg_head < 0)
+        return set_err(CFL_E_SHAPE, "bad step window");
+    int64_t nval = 0;
+    for (int64_t i = 0; i < nsteps; ++i) nval += val_mask[i] ? 1 : 0;
+    if (nsteps > (1ll << 40) / batch_rows || pos_head + nsteps * batch_rows > n_pos || neg_head + nsteps * batch_rows > n_neg ||
+        val_pos_head + nval * val_batch_rows > n_val_pos || val_neg_head + nval * val_batch_rows > n_val_neg)
+        return set_err(CFL_E_SHAPE, "step window runs past the pair lists");
+    for (int64_t k = 0; k < nval; ++k)
+        if (!ring_slots[k]) return set_err(CFL_E_SHAPE, "ring slot %lld is NULL", (long long)k);
+    float b1p = *beta1_power, b2p = *beta2_power;
+    int64_t k = 0;
+    for (int64_t i = 0; i < nsteps; ++i) {
+        const int32_t *ps = pos_pairs + 2 * (pos_head + i * batch_rows + shard_lo);
+        const int32_t *ng = neg_pairs + 2 * (neg_head + i * batch_rows + shard_lo);
+        const int c0 = (switched && switched[i]) ? 1 : 0;
+        const int32_t *idx4[4] = {ps + c0, ps + (1 - c0), ng + c0, ng + (1 - c0)};
+        const float lr_t = lr * sqrtf(1.f - b2p) / (1.f - b1p);
+        AdamFuse af = {theta, m, v, lr_t, beta1, beta2, eps};
+        IndexSrc is = {table, table_rows, idx4, 2};
+        ExtraSrc xs;
+        if (val_mask[i]) {
+            const int32_t *vp = val_pos_pairs + 2 * (val_pos_head + k * val_batch_rows);
+            const int32_t *vn = val_neg_pairs + 2 * (val_neg_head + k * val_batch_rows);
+            const int v0 = (val_switched && val_switched[k]) ? 1 : 0;
+            xs = {val_table, val_table_rows, {vp + v0, vp + (1 - v0), vn + v0, vn + (1 - v0)}, 2, val_batch_rows,
+                  ring_slots[k] + CFL_S_COUNT, ring_slots[k]};
+            ++k;
+        }
+        rc = run_pairs(shape, norm, loss, nullptr, 2, rows, theta, grad, scalars, nullptr, nullptr, workspace,
+                       workspace_bytes, (hipStream_t)stream, &af, &is, planes, val_mask[i] ? &xs : nullptr);
         if (rc) return rc;
         b1p *= beta1;
         b2p *= beta2;

@@ -303,6 +303,33 @@ int cfl_pair_train_steps_idx_planes(const CflShape *shape, const CflNorm *norm, 
                                     float *beta2_power, CflThetaPlanes *planes, void *workspace, size_t workspace_bytes,
                                     cfl_stream_t stream);
 
+/* The same train of steps WITH the reference's validation fetch inside it (ABI 5).  The reference's loop fetches
+ * `val_s_accuracy` -- the scores of one VALIDATION batch -- and the display scalars in the same sess.run as every training
+ * step (cfl/bin/train_dist.py:79-86); scored separately that is a second projection + row-math launch pair and two copies
+ * per iteration.  Here step i with val_mask[i] != 0 carries the next validation batch as EXTRA SCORING ROWS of its own
+ * projection and row-math launches (forward only: no loss, no gradient), with theta as it stands BEFORE the step's update
+ * (the fetch and the update of one sess.run are unordered in TensorFlow), and leaves
+ *     ring_slots[k][0 .. CFL_S_COUNT)                     the step's scalars
+ *     ring_slots[k][CFL_S_COUNT .. CFL_S_COUNT + 2 vb)     scores of the vb positive, then the vb negative validation pairs
+ * in the k-th slot (k counts the validation steps of the call) -- written by the kernels themselves, so the slots may be
+ * pinned HOST memory mapped into the device's address space (no copy command on the stream; read them after an event).
+ *   val_table / val_pos_pairs / val_neg_pairs / val_*_head / val_batch_rows / val_switched[k]: as table / pos_pairs / ... for
+ *   the validation split (the whole validation batch on every rank: no shard); ring_slots: HOST array of >= (number of
+ *   nonzero val_mask entries) device-accessible pointers, each CFL_S_COUNT + 2 * val_batch_rows floats.
+ * Only where cfl_train_val_fusable(shape, rows, val_batch_rows) returns 1 (chunk-at-a-time projection, wave-per-row math:
+ * the batch sizes of the training loops); CFL_E_UNSUPPORTED otherwise -- score separately with cfl_pair_scores_idx4.      */
+int cfl_train_val_fusable(const CflShape *shape, int64_t rows, int64_t val_rows);
+int cfl_pair_train_val_steps_idx_planes(
+    const CflShape *shape, const CflNorm *norm, const CflLossCfg *loss, const float *table, int64_t table_rows,
+    const int32_t *pos_pairs, int64_t n_pos, const int32_t *neg_pairs, int64_t n_neg, int64_t pos_head, int64_t neg_head,
+    int64_t batch_rows, int64_t shard_lo, int64_t rows, const uint8_t *switched, int64_t nsteps,
+    const float *val_table, int64_t val_table_rows, const int32_t *val_pos_pairs, int64_t n_val_pos,
+    const int32_t *val_neg_pairs, int64_t n_val_neg, int64_t val_pos_head, int64_t val_neg_head, int64_t val_batch_rows,
+    const uint8_t *val_switched, const uint8_t *val_mask, float *const *ring_slots,
+    float *theta, float *m, float *v, float *grad, float *scalars, float lr, float beta1, float beta2, float eps,
+    float *beta1_power, float *beta2_power, CflThetaPlanes *planes, void *workspace, size_t workspace_bytes,
+    cfl_stream_t stream);
+
 /* HOST-ONLY (no GPU, all pointers are host pointers): the per-epoch reshuffle `pairs = pairs[rng.permutation(n)]` of
  * cfl/input_data.py:543-551 in numpy's legacy RandomState (MT19937) stream, bit for bit.  key[624] / *pos are the
  * generator state (numpy: rng.get_state()[1], [2]) and are advanced exactly as rng.permutation(n) would advance them.

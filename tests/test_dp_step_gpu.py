@@ -195,3 +195,75 @@ def test_dp_branch_on_a_one_rank_rccl_group_equals_the_fused_step():
     kinds = eval(line[3])
     # 3 compute launches + the stand-alone Adam; no per-call plane split (colnorm slot), no finalize
     assert kinds == ['adam', 'grad', 'mid', 'proj'], kinds
+
+
+@pytest.mark.parametrize('every', [1, 7])
+def test_validation_fetch_inside_the_training_step_equals_separate_scoring(tmp_path, every):
+    """cfl.bin.train_dist.train_steps with the validation batch of a read-back iteration carried as EXTRA SCORING ROWS of the
+    training step's own launches (cfl_pair_train_val_steps_idx_planes; --scalar-every 1 = the reference's cadence,
+    cfl/bin/train_dist.py:79-86) against the general loop (CFL_FUSED_VAL=0: step, then a separate scoring call):
+    * training is untouched: parameters, Adam slots and every logged training scalar are bit-identical;
+    * both datasets' index streams end in the same state (heads, reshuffles, data_switch coin flips), across epoch wraps of
+      the training AND the validation lists;
+    * the validation scores are those of the weights BEFORE the iteration's update (the fetch and the update of one sess.run
+      are unordered in TensorFlow; the separate call scores after it): equal to scoring the same validation batch with the
+      pre-update weights, to fp32 rounding of the bf16x3 projection (1e-5)."""
+    from cfl import hipabi as Hh
+    from cfl import input_data
+    from cfl.bin import train_dist as TD
+    from cfl.engine import PairEngine
+    from cfl.synthetic import make_dataset
+    D, L, K, B, total = 256, 6, 3, 64, 90
+    make_dataset(str(tmp_path / 'toy'), D=D, n_items=400, n_pos=900, n_neg=700, k=2, latent=6, seed=1,
+                 splits=(('train', 1.0), ('val', 0.4)))
+    rng = np.random.RandomState(0)
+    cfg = O.EncoderCfg(D=D, L=L, K=K)
+    params = O.init_encoder_params(cfg, rng, np.float32)
+
+    class Model(object):
+        pass
+
+    def run(fused):
+        os.environ['CFL_FUSED_VAL'] = '1' if fused else '0'
+        tr = input_data.SemiDataSet(str(tmp_path / 'toy' / 'train'), input_size=D, data_switch=True, seed=9)
+        va = input_data.SemiDataSet(str(tmp_path / 'toy' / 'val'), input_size=D, data_switch=True, seed=4)
+        rt, rv = input_data.ResidentFeatures(tr), input_data.ResidentFeatures(va)
+        m = Model()
+        m.engine = PairEngine(D, L, K, norm=Hh.make_norm(1 / 16.0), loss=Hh.make_loss(), params=params, lr=2e-3, batch_size=B)
+        seen = []
+        TD.train_steps(m, rt, rv, B, None, total, lambda i, s, v: seen.append((i, s, v)), scalar_every=every)
+        torch.cuda.synchronize()
+        return m.engine, tr, va, seen
+    try:
+        assert Hh.train_val_fusable(Hh.make_shape(D, L, K), B, B)
+        (ea, ta, va_, sa), (eb, tb, vb, sb) = run(True), run(False)
+    finally:
+        os.environ.pop('CFL_FUSED_VAL', None)
+    assert torch.equal(ea.theta, eb.theta) and torch.equal(ea.m, eb.m) and torch.equal(ea.v, eb.v)
+    assert ea.global_step == eb.global_step == total and ea.beta1_power == eb.beta1_power
+    assert [i for i, _, _ in sa] == [i for i, _, _ in sb] == [i for i in range(total) if i % every == 0 or i == total - 1]
+    for (i, s1, _), (_, s2, _) in zip(sa, sb):
+        assert s1 == s2, (i, s1, s2)
+    for x, y in ((ta, tb), (va_, vb)):
+        assert x.head_labeled_pos == y.head_labeled_pos and x.head_labeled_neg == y.head_labeled_neg
+        assert np.array_equal(x.pairs_pos, y.pairs_pos) and np.array_equal(x.pairs_neg, y.pairs_neg)
+        assert x._rng.rand() == y._rng.rand()
+    # the fused validation accuracies: recompute them with the pre-update weights of every read-back iteration
+    tr = input_data.SemiDataSet(str(tmp_path / 'toy' / 'train'), input_size=D, data_switch=True, seed=9)
+    va = input_data.SemiDataSet(str(tmp_path / 'toy' / 'val'), input_size=D, data_switch=True, seed=4)
+    rt, rv = input_data.ResidentFeatures(tr), input_data.ResidentFeatures(va)
+    e = PairEngine(D, L, K, norm=Hh.make_norm(1 / 16.0), loss=Hh.make_loss(), params=params, lr=2e-3, batch_size=B)
+    want = {}
+    for i in range(total):
+        if i % every == 0 or i == total - 1:
+            table, streams = rv.next_indexed(B)
+            sc = e.scores_pos_neg(table, streams).cpu().numpy()
+            want[i] = (sc, 0.5 * (float((sc[:B] > 0).mean()) + float((sc[B:] <= 0).mean())))
+        e.step(rt.next_indexed(B))
+    worst = 0.0
+    for i, _, acc in sa:
+        sc, a0 = want[i]
+        margin = np.abs(sc).min()            # an accuracy can only differ through a score within rounding of zero
+        assert abs(acc - a0) <= (0.5 / B if margin < 1e-4 else 0.0) + 1e-12, (i, acc, a0, margin)
+        worst = max(worst, abs(acc - a0))
+    assert torch.equal(e.theta, ea.theta)
