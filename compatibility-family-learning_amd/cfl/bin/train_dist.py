@@ -143,6 +143,8 @@ FUSED_CHUNK = 16    # iterations per library call at --scalar-every 1 (4 such ca
 
 def H_fusable(eng, batch_size):
     from .. import hipabi as H
+    if not hasattr(eng, 'step_windows_val'):
+        return False
     return H.train_val_fusable(eng.shape, batch_size, batch_size)
 
 

@@ -235,7 +235,8 @@ def test_cli_entry_points_cap_the_host_thread_pool(monkeypatch):
 def test_scalar_every_flag_and_read_back_cadence():
     """--scalar-every N (not a reference flag; default 25; 1 = the reference's per-iteration validation fetch,
     cfl/bin/train_dist.py:79-86 of the reference): the flag parses, and train_steps reads back at iterations 0, N, 2N, ...
-    and the last one, taking exactly one validation batch per read-back -- checked with a stand-in engine (no GPU)."""
+    and the last one, taking exactly one validation batch per read-back -- checked with a stand-in engine (no GPU; the
+    general loop: the form with the validation rows inside the step's launches is tests/test_dp_step_gpu.py)."""
     from argparse import Namespace
     assert train_dist.parse_args([]).scalar_every == 25
     assert train_dist.parse_args(['--scalar-every', '1']).scalar_every == 1
