@@ -6,8 +6,12 @@
                                                                 an fp32 CPU path)
     hip_vs_fp32cpu   |x_HIP - x_fp32cpu| / max(1, |x_fp64|)
 
-The bar of a step is  hip_vs_fp64 <= max(floor, factor * (largest fp32cpu_vs_fp64 seen up to and including this step)):
-"HIP is no further from float64 than an fp32 evaluation of the same graph" -- instead of a fixed tolerance chosen to pass.
+The bar is  hip_vs_fp64 <= max(floor, factor * (largest fp32cpu_vs_fp64 over ALL steps of the run)), checked at the end:
+"the HIP trajectory never leaves float64 by more than `factor` times what an fp32 evaluation of the same graph leaves it by
+over the same steps" -- instead of a fixed tolerance chosen to pass.  (Over all steps, not step by step: once a kink has
+flipped a free-running trajectory leaves float64 about tenfold per step, and WHICH step that happens in differs between any
+two fp32 evaluations -- the CPU twin's own result depends on the host's BLAS threading -- so a per-step ratio would compare
+the luck of two draws.)
 After step 0 the conv / GAN trajectories are chaotic in fp32 (a near-zero pre-activation lands on the other side of an
 lrelu / relu kink and changes a slope from 0.2 to 1: tests/test_activation_masks_gpu.py), for the CPU evaluation exactly
 as for HIP, which is why the fp32 twin is the right yardstick.  CFL_RECORD_DIR=<dir> writes <dir>/series_<name>.json;
@@ -32,9 +36,6 @@ class ParitySeries(object):
         h32 = abs(float(hip) - float(f32)) / den
         self.rows.append((int(step), key, h64, c32, h32))
         self._worst32 = max(self._worst32, c32)
-        bar = max(self.floor if floor is None else floor, self.factor * self._worst32)
-        if h64 > bar:
-            self.failures.append((step, key, h64, bar, c32))
         return h64, c32
 
     def record(self):
@@ -48,12 +49,16 @@ class ParitySeries(object):
                             hip_vs_fp32cpu=max(r[4] for r in self.rows if r[0] == s)) for s in steps}
         with open(os.path.join(out_dir, 'series_%s.json' % self.name), 'w') as fh:
             json.dump({'name': self.name, 'meta': self.meta, 'floor': self.floor, 'factor': self.factor,
-                       'bar': 'hip_vs_fp64 <= max(floor, factor * running max of fp32cpu_vs_fp64)',
+                       'bar': 'hip_vs_fp64 <= max(floor, factor * max over all steps of fp32cpu_vs_fp64)',
+                       'worst': dict(hip_vs_fp64=max(r[2] for r in self.rows), fp32cpu_vs_fp64=self._worst32,
+                                     hip_vs_fp32cpu=max(r[4] for r in self.rows)),
                        'per_step_max': per_step,
                        'rows': [dict(step=r[0], key=r[1], hip_vs_fp64=r[2], fp32cpu_vs_fp64=r[3], hip_vs_fp32cpu=r[4])
                                 for r in self.rows]}, fh, indent=1)
 
     def check(self):
         self.record()
+        bar = max(self.floor, self.factor * self._worst32)
+        self.failures = [(r[0], r[1], r[2], bar, r[3]) for r in self.rows if r[2] > bar]
         assert not self.failures, ('HIP further from float64 than %.1f x the fp32 CPU evaluation (step, key, hip_vs_fp64, '
                                    'bar, fp32cpu_vs_fp64): %r' % (self.factor, self.failures[:6]))
