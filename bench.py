@@ -734,6 +734,13 @@ def main():
         out['roofline'] = {
             'kernel': kname,
             'plan': plan,
+            # north_star asks for >= 60 % of the HBM roofline: unreachable at this batch size by construction, and the line says so
+            'note': 'B = %d rows = %.1f MB of input per step is %.1f us at the 8 TB/s peak; the step is three DEPENDENT launches '
+                    '(projection -> row math -> weight gradient + Adam) whose fixed cost (dispatch ~2.6 us each, cold first '
+                    'miss, latency chains) is ~21 us of it (B-sweep fit t = 20.7 us + B / 35.4 M rows/s, '
+                    'profiles/r04_p_b_sweep.md): 0.60 of HBM is out of reach at this batch size, and B -> infinity reaches '
+                    '0.29 (x is read twice, PMC traffic 1.1x algorithmic per launch).  What the fraction measures here is '
+                    'launch latency, not wasted bandwidth; DESIGN.md section 4' % (B, alg_bytes / 1e6, alg_bytes / 8e12 * 1e6),
             # the committed rocprofv3 average of the same kernel (profiles/kernel_stats.csv, builder box) and the fraction it
             # gives: the event-timed `frac` below is lower because the event pairs perturb the stream (see `timing`)
             'rocprof_avg_us': rp_us,

@@ -8,7 +8,7 @@ cd /tmp
 i=0
 for c in "$@"; do
   i=$((i+1))
-  rocprofv3 --pmc $c --output-format csv -d $O/pmc$i -o run -- python3 $R/bench.py --steps 60 --warmup 10 --repeats 1 --no-cpu-baseline --no-kernel-profile --no-cli-loop --no-other-configs > $O/pmc$i.log 2>&1
+  rocprofv3 --pmc $c --output-format csv -d $O/pmc$i -o run -- python3 $R/bench.py --steps 60 --warmup 10 --repeats 1 --no-cpu-baseline --no-kernel-profile --no-cli-loop --no-other-configs --no-dp-form > $O/pmc$i.log 2>&1
   f=$(find $O/pmc$i -name "*counter_collection.csv" | head -1)
   if [ -n "$f" ]; then
     python3 - "$f" <<'PY' > $O/pmc$i.summary.txt
