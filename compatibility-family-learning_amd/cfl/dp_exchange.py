@@ -79,24 +79,41 @@ class OneShotExchange(object):
         self.total = self.o_flags_b + 2 * 64
         torch.cuda.set_device(dev if dev.index is not None else torch.cuda.current_device())
         fine = 0 if os.environ.get('CFL_DP_COARSE') == '1' else 1     # (escape hatch for experiments on one GPU only)
-        base = C.c_void_p()
-        H._check(L.cfl_dp_alloc(C.byref(base), 4 * self.total, fine))
-        self.base = base.value
-        handle = C.create_string_buffer(64)
-        H._check(L.cfl_dp_ipc_export(self.base, handle))
+        # Allocation / export / mapping can fail on a SUBSET of the ranks (out of memory, IPC mode): every phase ends with an
+        # exchange of (ok, message) so that all ranks raise together instead of some hanging in the next collective
+        self.base, handle, err = None, C.create_string_buffer(64), None
+        try:
+            base = C.c_void_p()
+            H._check(L.cfl_dp_alloc(C.byref(base), 4 * self.total, fine))
+            self.base = base.value
+            H._check(L.cfl_dp_ipc_export(self.base, handle))
+        except H.CflHipError as e:
+            err = str(e)
         self.ticket = torch.zeros(2, dtype=torch.int32, device=dev)    # [0] push launch, [1] Adam launch
-        self.lost = torch.zeros(1, dtype=torch.int32, device=dev)
+        # the kernels' `lost` word lives in PINNED HOST memory (they write it only when a wait gives up): check() reads it
+        # without touching the stream
+        self.lost = torch.zeros(1, dtype=torch.int32).pin_memory()
         torch.cuda.synchronize(dev)
         handles = [None] * self.world
-        dist.all_gather_object(handles, handle.raw)
+        dist.all_gather_object(handles, (err, handle.raw))
+        self._raise_together([h[0] for h in handles], 'allocating / exporting the exchange memory')
+        handles = [h[1] for h in handles]
         self._peer_base = []
+        err = None
         for r in range(self.world):
             if r == self.rank:
                 self._peer_base.append(self.base)
                 continue
             p = C.c_void_p()
-            H._check(L.cfl_dp_ipc_open(handles[r], C.byref(p)))
+            try:
+                H._check(L.cfl_dp_ipc_open(handles[r], C.byref(p)))
+            except H.CflHipError as e:
+                err = err or ('peer %d: %s' % (r, e))
+                p = C.c_void_p(0)
             self._peer_base.append(p.value)
+        errs = [None] * self.world
+        dist.all_gather_object(errs, err)
+        self._raise_together(errs, 'mapping the peers\' exchange memory')
         self.local = torch.as_tensor(_Raw(self.base, self.total, '<f4'), device=dev)   # alias (diagnostics, tests)
         torch.cuda.synchronize(dev)
         dist.barrier()                   # nobody pushes before everyone has mapped everyone
@@ -105,6 +122,11 @@ class OneShotExchange(object):
         # True between a step and the next sync_optimizer_state(): this rank's m / v are current for its own slice only,
         # and a checkpoint written now would carry stale slots for (world - 1) / world of the parameters
         self.slots_dirty = False
+
+    def _raise_together(self, errs, what):
+        bad = [(r, e) for r, e in enumerate(errs) if e]
+        if bad:
+            raise H.CflHipError('one-shot exchange: %s failed on rank(s) %s: %s' % (what, [r for r, _ in bad], bad[0][1]))
 
     # -- addresses -------------------------------------------------------------------------------------------------
     def _slot_row(self, base, par, row):
@@ -172,8 +194,10 @@ class OneShotExchange(object):
         self.slots_dirty = False
 
     def check(self):
-        """host side of the bounded waits: raise when a peer never arrived (synchronises the stream)"""
-        if int(self.lost.item()) != 0:
+        """host side of the bounded waits: raise when a peer never arrived.  No synchronisation: `lost` is pinned host memory
+        the kernels write only when a wait gives up; the parameters are NaN from that step on, so every rank's loss turns
+        non-finite in the same iteration and the training loops stop there whichever rank sees this word first."""
+        if int(self.lost[0]) != 0:
             raise H.CflHipError('one-shot gradient exchange: a peer did not arrive within {:.0f} s at or before step {} '
                                 '(the parameters are NaN from that step on; CFL_DP_TIMEOUT_S sets the bound)'
                                 .format(self.timeout_s, self.step))

@@ -686,6 +686,16 @@ static HaloPlan halo_fwd_plan(const ConvGeom &g) {
 static HaloPlan halo_dx_plan(const ConvGeom &g) {
     return halo_shape(g) ? halo_plan(g.B, g.H, g.W, g.Co, g.Ci) : HaloPlan{};
 }
+// Plans for PREPARING a layer's cached filter planes: taken at B = 1, i.e. from the image size and the channel counts only.
+// A plan's `ok` also depends on the batch (32-bit element offsets), and the forward of a step runs at another batch than the
+// backward slices that later read the planes on several streams at once: whether the planes get built must not depend on
+// the batch of the call that happens to build them (the planes' layout never did: nchunks / Npad are channel counts).
+static HaloPlan halo_fwd_prep_plan(const ConvGeom &g) {
+    return halo_shape(g) ? halo_plan(1, g.H, g.W, g.Ci, g.Co) : HaloPlan{};
+}
+static HaloPlan halo_dx_prep_plan(const ConvGeom &g) {
+    return halo_shape(g) ? halo_plan(1, g.H, g.W, g.Co, g.Ci) : HaloPlan{};
+}
 
 extern "C" size_t cfl_conv_workspace_bytes(const CflConv *c) {
     ConvGeom g;
@@ -794,7 +804,7 @@ extern "C" int cfl_conv2d_wn_fwd_fused(const CflConv *c, const float *x, const f
     // touched after an update: the backward passes of a step may run on several streams at once (MrCGAN: three chains
     // share every discriminator layer), and a plane set must not be built on one of them while another reads it.
     if (cache && !(*cache_flags & CFL_CONV_CACHE_PLANES_DX)) {
-        const HaloPlan hd = halo_dx_plan(g);
+        const HaloPlan hd = halo_dx_prep_plan(g);
         if (hd.ok) {
             halo_prep_planes(hd, g.Co, g.Ci, V, scale, g.Ci, g.Co, 1,
                              (unsigned short *)((char *)cache + conv_cache_planes_off(g) + conv_cache_fwd_bytes(g)), st);
@@ -820,14 +830,14 @@ extern "C" int cfl_conv_prepare_cached(const CflConv *c, const float *V, const f
     float *scale, *n2;
     conv_scale_of(g, V, gain, cache, cache, cache_flags, &scale, &n2, st);
     if (!(*cache_flags & CFL_CONV_CACHE_PLANES_FWD)) {
-        const HaloPlan hp = halo_fwd_plan(g);
+        const HaloPlan hp = halo_fwd_prep_plan(g);
         if (hp.ok) {
             halo_prep_planes(hp, g.Ci, g.Co, V, scale, g.Ci, g.Co, 0, (unsigned short *)((char *)cache + conv_cache_planes_off(g)), st);
             *cache_flags |= CFL_CONV_CACHE_PLANES_FWD;
         }
     }
     if (!(*cache_flags & CFL_CONV_CACHE_PLANES_DX)) {
-        const HaloPlan hd = halo_dx_plan(g);
+        const HaloPlan hd = halo_dx_prep_plan(g);
         if (hd.ok) {
             halo_prep_planes(hd, g.Co, g.Ci, V, scale, g.Ci, g.Co, 1,
                              (unsigned short *)((char *)cache + conv_cache_planes_off(g) + conv_cache_fwd_bytes(g)), st);

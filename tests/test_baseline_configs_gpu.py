@@ -243,3 +243,23 @@ def test_config5_mrcgan_post_epoch_step_64x64(B):
                               'entries off by > 5e-4 of the tensor scale <= max(0.5 %, 2 entries, 2 x fp32 CPU share)', 'B': B,
                        'networks': nets, 'tensors': table}, fh, indent=1)
     assert not bad, bad
+
+
+def test_exact_fp32_headline_trajectory_keeps_the_round3_bar():
+    """CFL_EXACT_FP32=1 (k-ordered fp32 MFMA in both contractions; read when a plan is first built, hence a fresh
+    process): the headline trajectory at the bars the exact path held before the bf16x3 projection became the default
+    (|HIP - fp64| <= 4e-6, |HIP - fp32 CPU| <= 2e-6 over 100 steps; round 3 observed 1.9e-6 / 6.3e-7) -- so that the exact
+    path cannot regress unnoticed behind the default arithmetic's looser caps."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ('import sys; sys.path[:0] = [%r, %r, %r]\n'
+            'import test_baseline_configs_gpu as T\n'
+            'r = T._trajectory("headline_exact_fp32", "dist", 4096, 3, 20, 512, 100, dict(), 16384, T.NV, (4e-6, 2e-6), min_auc=0.52)\n'
+            'print("EXACT", r["max"]["hip_vs_fp64"], r["max"]["hip_vs_fp32cpu"])\n'
+            % (root, os.path.join(root, 'compatibility-family-learning_amd'), os.path.join(root, 'tests')))
+    env = dict(os.environ, CFL_EXACT_FP32='1')
+    r = subprocess.run([sys.executable, '-c', code], env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    assert 'EXACT' in r.stdout
