@@ -16,7 +16,7 @@ import numpy as np
 from tqdm import trange
 
 from .. import engine as dp
-from ..input_data import ResidentFeatures, load_data_sets
+from ..input_data import feature_source, load_data_sets
 from ..models.dist import construct_model
 from ..ops import normalizer, unnormalizer
 from ..utils import (IncrementalAverage, Saver, dist_eval, load_best_stats, load_model, log_args,
@@ -245,8 +245,8 @@ def train_loop(model, data, aux, batch_size, start_epoch, epochs, log_dir, check
     logger.warning('model: %s', model.get_name())
     nb_batch = nb_train // batch_size
 
-    train_src = ResidentFeatures(aux.train, model.device)
-    val_src = ResidentFeatures(aux.val, model.device)
+    train_src = feature_source(aux.train, model.device)     # resident in HBM, or streamed when the table does not fit
+    val_src = feature_source(aux.val, model.device)
 
     best_dir = os.path.join(checkpoint_dir, 'best_acc_model')
     os.makedirs(best_dir, exist_ok=True)

@@ -28,6 +28,9 @@ from collections import defaultdict
 from io import BytesIO
 
 import numpy as np
+
+import logging
+logger = logging.getLogger(__name__)
 from numpy.random import RandomState
 
 ID_BYTES = 10  # every item id is exactly 10 ASCII bytes
@@ -661,3 +664,128 @@ class ResidentFeatures(object):
             n = min(batch_size, host.shape[0] - i)
             base = dev.data_ptr() + 8 * i
             yield self.table, self._h.IndexStreams([base, base + 4], 2, n, keep=[dev])
+
+
+class StreamedFeatures(object):
+    """A split whose ``features.b`` does NOT fit in HBM (or ``CFL_FEATURES=stream``): the file stays memory-mapped on the
+    host and every batch's rows are gathered into pinned staging memory and copied to the device asynchronously --
+    SURVEY 8(f).1's second option, replacing the reference's one seek + read per vector (cfl/input_data.py:212-228) with
+    one vectorised gather + one DMA per batch.  Same interface as ResidentFeatures: a batch is handed to the kernels as a
+    (mini table, IndexStreams) pair -- the 4 x B gathered rows uploaded as a small table that the indexed entry points
+    walk with the identity index streams -- so every consumer (training step, validation fetch, dist_eval / dist_predict)
+    is unchanged and the arithmetic is the resident path's bit for bit.  The dataset's seeded index stream is advanced by
+    the same calls (bit-exact).  Staging buffers rotate (NBUF): the copy of batch i+1 overlaps the step of batch i; a
+    buffer is reused only after the event behind its last upload.  Windows of device pair lists do not exist here
+    (next_windows / next_window_any return None: the loops take their per-iteration path)."""
+
+    NBUF = 3
+
+    def __init__(self, dataset, device='cuda'):
+        import torch
+        from . import hipabi
+        self._h = hipabi
+        self.dataset = dataset
+        self.file = dataset._file
+        self.input_size = int(self.file.input_size)
+        self.padded_size = (self.input_size + 63) // 64 * 64
+        self.device = torch.device(device)
+        if self.device.type != 'cuda':
+            raise hipabi.CflHipError('StreamedFeatures feeds a HIP device (no CPU fallback)')
+        self._ring = {}        # rows per upload -> [next, [(pinned, device, event), ...]]
+        self._arange = {}      # rows per stream -> int32 device vector 0 .. n-1 (the identity index stream)
+        self.table = None      # (no resident table)
+
+    def _buffers(self, rows):
+        import torch
+        ring = self._ring.get(rows)
+        if ring is None:
+            bufs = []
+            for _ in range(self.NBUF):
+                pinned = torch.zeros(rows, self.padded_size, dtype=torch.float32).pin_memory()     # (pad columns stay zero)
+                bufs.append([pinned, torch.empty(rows, self.padded_size, dtype=torch.float32, device=self.device), None])
+            ring = self._ring[rows] = [0, bufs]
+        slot = ring[1][ring[0]]
+        ring[0] = (ring[0] + 1) % self.NBUF
+        if slot[2] is not None:
+            slot[2].synchronize()          # the previous upload from this pinned buffer has left it
+        return slot
+
+    def _upload(self, position_lists):
+        """rows file[positions] of every list, concatenated, as one device mini table [sum(len), padded D]"""
+        import torch
+        total = sum(len(p) for p in position_lists)
+        slot = self._buffers(total)
+        host = slot[0].numpy()
+        o = 0
+        x = self.file.records['x']
+        for p in position_lists:
+            n = len(p)
+            host[o:o + n, :self.input_size] = x[np.asarray(p, dtype=np.int64)]
+            o += n
+        slot[1].copy_(slot[0], non_blocking=True)
+        slot[2] = torch.cuda.Event()
+        slot[2].record()
+        return slot[1]
+
+    def _identity(self, n, base):
+        import torch
+        key = (n, base)
+        t = self._arange.get(key)
+        if t is None:
+            t = self._arange[key] = torch.arange(base, base + n, dtype=torch.int32, device=self.device)
+        return t
+
+    def _streams(self, n, groups):
+        ts = [self._identity(n, k * n) for k in range(groups)]
+        return self._h.IndexStreams([t.data_ptr() for t in ts], 1, n, keep=ts)
+
+    def next_indexed(self, batch_size, shard=None):
+        pos, neg, switched = self.dataset.next_batch_indices(batch_size)
+        lo, hi = shard if shard is not None else (0, batch_size)
+        c = (1, 0) if switched else (0, 1)
+        table = self._upload([pos[lo:hi, c[0]], pos[lo:hi, c[1]], neg[lo:hi, c[0]], neg[lo:hi, c[1]]])
+        return table, self._streams(hi - lo, 4)
+
+    def next_batch(self, batch_size, shard=None):
+        table, streams = self.next_indexed(batch_size, shard)
+        n = streams.n
+        return tuple(table[k * n:(k + 1) * n] for k in range(4))
+
+    def available_windows(self, batch_size):
+        return 0
+
+    def next_windows(self, batch_size, max_steps, shard=None):
+        return None
+
+    def next_window_any(self, batch_size, shard=None):
+        return None
+
+    def whole_indexed(self, which, batch_size, rows=None):
+        host = getattr(self.dataset, 'pairs_' + which)
+        lo, hi = rows if rows is not None else (0, host.shape[0])
+        host = host[lo:hi]
+        step = min(int(batch_size), 4096)      # (2 x 4096 rows of 4 D bytes per staging buffer, not dist_eval's 32768-pair calls)
+        for i in range(0, host.shape[0], step):
+            chunk = host[i:i + step]
+            table = self._upload([chunk[:, 0], chunk[:, 1]])
+            yield table, self._streams(chunk.shape[0], 2)
+
+
+def feature_source(dataset, device='cuda'):
+    """ResidentFeatures when the split's feature table fits the device comfortably, StreamedFeatures otherwise.
+    CFL_FEATURES=resident|stream forces the choice; CFL_RESIDENT_FRACTION (default 0.6) is the share of the device's FREE
+    memory a table may take (the table is uploaded once and stays)."""
+    import torch
+    mode = os.environ.get('CFL_FEATURES', 'auto')
+    if mode == 'stream':
+        return StreamedFeatures(dataset, device)
+    if mode != 'resident' and torch.cuda.is_available():
+        ff = dataset._file
+        need = ff.n * ((int(ff.input_size) + 63) // 64 * 64) * 4
+        dev = torch.device(device)
+        free, _ = torch.cuda.mem_get_info(dev if dev.index is not None else torch.cuda.current_device())
+        if need > float(os.environ.get('CFL_RESIDENT_FRACTION', '0.6')) * free:
+            logger.warning('%s: %.1f GB of features do not fit %.1f GB of free device memory: streaming batches from the host',
+                           ff.path, need / 1e9, free / 1e9)
+            return StreamedFeatures(dataset, device)
+    return ResidentFeatures(dataset, device)

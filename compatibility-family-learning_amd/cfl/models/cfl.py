@@ -475,11 +475,11 @@ class CFL(PairModel):
         # (cfl_gather_rows); under torchrun every rank walks the same seeded index stream and trains on
         # its own slice of each global batch
         from .. import engine as dp
-        from ..input_data import ResidentFeatures
+        from ..input_data import feature_source
         resident = None
         if not data.train.is_image and self.trunk is None and self.train_data_transformer is None \
                 and self.val_data_transformer is None and self._explicit_norm is None:
-            resident = (ResidentFeatures(data.train, self.device), ResidentFeatures(data.val, self.device))
+            resident = (feature_source(data.train, self.device), feature_source(data.val, self.device))
         shard = dp.shard_rows(self.batch_size) if dp.world_size() > 1 else None
         if shard is not None and resident is None:
             raise NotImplementedError('data-parallel training needs a vector dataset (resident features)')

@@ -207,14 +207,14 @@ def _resident_ready(model, data):
         return None
     try:
         import torch
-        from .input_data import ResidentFeatures
+        from .input_data import feature_source
     except Exception:          # pragma: no cover
         return None
     if not torch.cuda.is_available():
         return None
     res = getattr(data, '_resident', None)
     if res is None or res.device != model.device:
-        res = data._resident = ResidentFeatures(data, model.device)
+        res = data._resident = feature_source(data, model.device)
     if res.padded_size != model.padded_size:
         return None
     return res

@@ -402,3 +402,52 @@ def test_cfl_directed_conv_encoders(tmp_path):
     assert 'CFL/DistEncoderDst/outputs/fully_connected/V' in v
     predict.start(base + ['--predict-root', str(tmp_path / 'pred')])
     assert (tmp_path / 'pred' / 'px' / 'cfl_pcd_conv_di_sigmoid_ls_8_nc_2_ut' / 'predict_acc.txt').exists()
+
+
+def test_streamed_features_train_and_evaluate_like_resident_features(tmp_path, monkeypatch):
+    """StreamedFeatures (a features.b that does not fit HBM, SURVEY 8(f).1's second option: mmap + pinned gather + async copy
+    per batch; forced here with CFL_FEATURES=stream) against ResidentFeatures on the same dataset and seeds: the same index
+    stream (heads, reshuffles, data_switch flips), bit-identical parameters after training through train_steps (with the
+    validation fetch), bit-identical logged scalars, and the same dist_eval AUC / accuracy."""
+    from cfl import hipabi as H
+    from cfl import input_data, utils
+    from cfl.bin import train_dist as TD
+    from cfl.engine import PairEngine
+    from cfl.synthetic import make_dataset
+    D, L, K, B, total = 200, 6, 2, 48, 70          # D % 64 != 0: the pad columns of the staging rows stay zero
+    make_dataset(str(tmp_path / 'toy'), D=D, n_items=300, n_pos=500, n_neg=420, k=2, latent=6, seed=3, scale=4.0,
+                 splits=(('train', 1.0), ('val', 0.4)))
+    rng = np.random.RandomState(0)
+    cfg = O.EncoderCfg(D=256, L=L, K=K)
+    params = O.init_encoder_params(cfg, rng, np.float32)
+    for k in list(params):
+        if k.endswith('/W'):
+            params[k][D:] = 0.0
+
+    class Model(object):
+        pass
+
+    def run(mode):
+        monkeypatch.setenv('CFL_FEATURES', mode)
+        tr = input_data.SemiDataSet(str(tmp_path / 'toy' / 'train'), input_size=D, data_switch=True, seed=9)
+        va = input_data.SemiDataSet(str(tmp_path / 'toy' / 'val'), input_size=D, data_switch=False, seed=4)
+        st, sv = input_data.feature_source(tr), input_data.feature_source(va)
+        assert type(st).__name__ == ('StreamedFeatures' if mode == 'stream' else 'ResidentFeatures')
+        m = Model()
+        m.engine = PairEngine(256, L, K, norm=H.make_norm(1 / 16.0, valid_cols=D), loss=H.make_loss(reg_const=1e-3), params=params,
+                              lr=2e-3, batch_size=B)
+        seen = []
+        TD.train_steps(m, st, sv, B, None, total, lambda i, s, v: seen.append((i, s, v)), scalar_every=5)
+        # scoring of every validation pair through the source's chunked iterator
+        sc = [torch.cat([m.engine.scores(t, s).clone() for t, s in sv.whole_indexed(w, 64)]) for w in ('pos', 'neg')]
+        torch.cuda.synchronize()
+        return m.engine, tr, va, seen, sc
+    a, b = run('resident'), run('stream')
+    assert torch.equal(a[0].theta, b[0].theta) and torch.equal(a[0].m, b[0].m)
+    assert [(i, s) for i, s, _ in a[3]] == [(i, s) for i, s, _ in b[3]]
+    assert [v for _, _, v in a[3]] == [v for _, _, v in b[3]]
+    for x, y in ((a[1], b[1]), (a[2], b[2])):
+        assert x.head_labeled_pos == y.head_labeled_pos and np.array_equal(x.pairs_pos, y.pairs_pos)
+        assert x._rng.rand() == y._rng.rand()
+    for x, y in zip(a[4], b[4]):
+        assert torch.equal(x, y)
