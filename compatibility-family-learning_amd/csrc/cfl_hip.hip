@@ -398,13 +398,13 @@ struct ProjJob {
 // batch ride in the training step's own projection and row-math launches -- rows [row0, row0 + n) behind the (padded)
 // training rows, read from their own resident table by their own index streams -- instead of a second projection +
 // row-math launch pair per iteration.  They are forward-only: no dL/dY, no loss, no weight gradient; mid writes their
-// scores straight to the caller's buffer.  n == 0 (tile0 = INT_MAX): no such rows, every existing path unchanged.
+// scores straight to the caller's buffer.  n == 0 (tile0 = 0): no such rows, every existing path unchanged.
 struct RowExtra {
     const float *table;        // resident feature table of the extra rows
     const int *ix[2][2];       // [side][group]: index streams (group 0 = rows [0, bx), group 1 = rows [bx, 2 bx))
     int istride;
     unsigned last_row;
-    int row0, n, bx, tile0;    // first row / rows / rows per group / first 32-row tile of the extra rows
+    int row0, n, bx, tile0;    // first row / rows / rows per group / number of 32-row tiles of the extra rows (dispatched first)
 };
 
 struct ProjArgs {
@@ -431,9 +431,11 @@ __device__ __forceinline__ const float *proj_row_ptr(const ProjArgs &a, int side
     }
     return row_ptr(a.rows[side], r, a.B, a.R, a.D);
 }
-// first row of 32-row tile `tile`: the extra rows start at row0 (a multiple of 32 behind the padded training rows)
+// first row of 32-row tile `tile`.  The extra rows' tiles come FIRST in dispatch order (tiles [0, xr.tile0), rows from xr.row0 on),
+// the training rows' tiles after them, so that what the projection touched last is what the weight gradient re-reads (measured
+// either way: 44.5 us per iteration both -- the +1.3 us of the weight-gradient launch beside extra rows is not cache eviction)
 __device__ __forceinline__ int proj_tile_row0(const ProjArgs &a, int tile) {
-    return tile < a.xr.tile0 ? tile * 32 : a.xr.row0 + (tile - a.xr.tile0) * 32;
+    return tile < a.xr.tile0 ? a.xr.row0 + tile * 32 : (tile - a.xr.tile0) * 32;
 }
 
 template <int NT>
@@ -4226,14 +4228,14 @@ static int run_pairs(const CflShape *s, const CflNorm *norm, const CflLossCfg *l
         pa.B = (int)rows; pa.R = pl.R; pa.Rpad = pl.Rpad; pa.D = s->D; pa.S = pl.S; pa.norm = nd;
         pa.xcd = pl.xcd;
         pa.njobs = nj; pa.cn = cna;
-        pa.xr.tile0 = 0x7fffffff;     // no extra scoring rows
+        pa.xr.tile0 = 0;              // no extra scoring rows
         if (xs) {
             pa.xr.table = xs->table;
             for (int sd = 0; sd < 2; ++sd)
                 for (int g = 0; g < 2; ++g) pa.xr.ix[sd][g] = xs->idx[2 * g + sd];
             pa.xr.istride = (int)xs->stride;
             pa.xr.last_row = (unsigned)(xs->table_rows - 1);
-            pa.xr.row0 = pl.Rpad; pa.xr.n = pl.Rx; pa.xr.bx = (int)xs->bx; pa.xr.tile0 = (pl.R + 31) / 32;
+            pa.xr.row0 = pl.Rpad; pa.xr.n = pl.Rx; pa.xr.bx = (int)xs->bx; pa.xr.tile0 = pl.Rxpad / 32;
         }
         const bool cn_slice = cna.ncols > 0;
         if (cn_slice && nj >= CFL_MAX_JOBS) return set_err(CFL_E_UNSUPPORTED, "too many column chunks");
