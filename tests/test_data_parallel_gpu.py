@@ -47,14 +47,21 @@ def _worker(rank, world, port, out):
         lo, hi = engine.shard_rows(B)
         worst = 0.0
         ref = mk() if rank == 0 else None
-        for it in range(4):
+        for it in range(300):
             idx = [torch.tensor(rng.randint(0, 500, size=B).astype(np.int32), device='cuda') for _ in range(4)]
             full = [table[i.long()].contiguous() for i in idx]
+            if rank == 0:
+                # the single-GPU twin starts every step from the data-parallel engine's state: 300 single steps are compared,
+                # not two free-running trajectories (whose summation-order differences compound through Adam)
+                ref.theta.copy_(eng.theta); ref.m.copy_(eng.m); ref.v.copy_(eng.v)
+                ref.beta1_power, ref.beta2_power = eng.beta1_power, eng.beta2_power
             if it % 2 == 0:
                 eng.step([x[lo:hi].contiguous() for x in full])                      # dense shard
             else:
                 eng.step((table, H.IndexStreams.from_tensors([i[lo:hi].contiguous() for i in idx])))
             assert eng.world_size == world
+            if it % 10 and it < 290:
+                continue                                   # (every step is taken; every tenth and the last ten are compared)
             s = eng.read_scalars()
             if rank == 0:
                 # the single-GPU step on the whole global batch (no collective: fwd_bwd + Adam by hand)
@@ -89,7 +96,10 @@ def test_sharded_steps_equal_the_single_gpu_step():
         assert p.exitcode == 0
     worst, same = out.get()
     assert same
-    assert worst < 2e-6, worst        # summation order differs from one rank: 1e-5 bar of SURVEY 8(e)
+    # (300 steps, each compared from the same state.  The data-parallel step projects on the bf16 matrix cores from kept planes,
+    # the twin's fwd_bwd with the exact-fp32 kernel, and the row sums are split over two ranks: observed 2.1e-6, bar 5e-6,
+    # SURVEY 8(e) allows 1e-5)
+    assert worst < 5e-6, worst
 
 
 def _eval_worker(rank, world, port, path, out):
@@ -183,7 +193,7 @@ def _oneshot_worker(rank, world, port, out):
         table = torch.tensor(np.abs(rng.randn(500, D)).astype(np.float32), device='cuda')
         lo, hi = engine.shard_rows(B)
         worst = 0.0
-        for it in range(6):
+        for it in range(100):
             idx = [torch.tensor(rng.randint(0, 500, size=B).astype(np.int32), device='cuda') for _ in range(4)]
             batch = (table, H.IndexStreams.from_tensors([i[lo:hi].contiguous() for i in idx]))
             a.step(batch)
