@@ -95,16 +95,38 @@ class Communicator(object):
 _default = None
 
 
+_unavailable = False
+
+
 def default_communicator():
-    """the process-wide communicator of the hot exchange, created on first use (collective)"""
-    global _default
-    if _default is None:
-        _default = Communicator()
+    """The process-wide communicator of the hot exchange, created on first use (COLLECTIVE), or None when it cannot be
+    created on EVERY rank -- librccl not loadable through ctypes, ncclCommInitRank failing somewhere: the ranks agree on the
+    outcome over the torch process group (a MIN all-reduce of a success flag), so that either all of them enqueue
+    ncclAllReduce on their launch streams or all of them fall back to torch.distributed.all_reduce; a split would hang."""
+    global _default, _unavailable
+    if _default is None and not _unavailable:
+        comm, err = None, None
+        try:
+            comm = Communicator()
+        except Exception as e:          # noqa: BLE001 (anything: OSError from ctypes, RcclError, AttributeError of a missing symbol)
+            err = e
+        ok = torch.tensor([0 if comm is None else 1], dtype=torch.int32, device='cuda')
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 1:
+            _default = comm
+        else:
+            _unavailable = True
+            if comm is not None:
+                comm.close()
+            import logging
+            logging.getLogger(__name__).warning('direct RCCL all-reduce unavailable (%s on this rank): the gradient exchange goes '
+                                                'through torch.distributed.all_reduce', err or 'failed on another rank')
     return _default
 
 
 def shutdown():
-    global _default
+    global _default, _unavailable
     if _default is not None:
         _default.close()
         _default = None
+    _unavailable = False
