@@ -59,7 +59,7 @@ def parse():
     ap.add_argument('--warmup', type=int, default=50)
     ap.add_argument('--repeats', type=int, default=0, help='timed repeats of the K-step region (0 = auto: >= 50 '
                     'and enough for --timed-seconds of timed work)')
-    ap.add_argument('--timed-seconds', type=float, default=6.0, help='target length of the timed headline region (auto '
+    ap.add_argument('--timed-seconds', type=float, default=7.0, help='target length of the timed headline region (auto '
                     'repeats): longer than the 5 s period of an external utilisation sampler')
     ap.add_argument('--batch-size', type=int, default=512)
     ap.add_argument('--input-size', type=int, default=4096)
