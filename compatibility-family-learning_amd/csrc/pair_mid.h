@@ -864,7 +864,82 @@ __device__ __forceinline__ void mid_row_body(const MidArgs &a, int r, bool lead,
     float d, sk[J], rl[J], dlk[J];
 #pragma unroll
     for (int j = 0; j < J; ++j) { sk[j] = 1.f; rl[j] = 0.f; dlk[j] = 0.f; }
-    if (K > 1) {
+    // K <= MID_KU prototypes (round 5): the per-prototype sums e_k = sum_l (v_l - P_kl)^2 and q_k = -2 sum_l r_l P_kl are MASKED
+    // WAVE SUMS (four DPP adds + four v_readlane each, the K of them independent) whose results are wave-uniform: logits, soft-min
+    // weights s_k, q-bar and dl_k then live in scalar registers and every per-column use is a select -- no LDS at all in the
+    // soft-min.  The form below it (any K) lets lane k walk its segment of L values through LDS: two serial chains of L
+    // dependent ds_read + add (2 x ~2000 cycles at L = 20) plus K-long LDS broadcast loops, half of this one-wave-per-row
+    // kernel's lifetime (tools/mid_stamp_probe.py: distance phase 4270 of 11870 cycles).  Same formulas; the sums add in
+    // butterfly order instead of l = 0, 1, ..., L - 1.
+    constexpr int MID_KU = 8;
+    float su[MID_KU], dlu[MID_KU];      // uniform: s_k, dl_k
+#pragma unroll
+    for (int k = 0; k < MID_KU; ++k) { su[k] = 0.f; dlu[k] = 0.f; }
+    const bool ku = K > 1 && K <= MID_KU;
+    if (ku) {
+        float eu[MID_KU];
+#pragma unroll
+        for (int k = 0; k < MID_KU; ++k) {
+            eu[k] = 0.f;
+            if (k < K) {
+                float part = 0.f;
+#pragma unroll
+                for (int j = 0; j < J; ++j) part += (cs[j] && kk[j] == k) ? diff[j] * diff[j] : 0.f;
+                eu[k] = wave_sum_dpp(part);
+            }
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < MID_KU; ++k) if (k < K) mx = fmaxf(mx, -eu[k]);
+        float den = 0.f;
+#pragma unroll
+        for (int k = 0; k < MID_KU; ++k) if (k < K) den += fexp(-eu[k] - mx);
+        const float inv = frcp(den);
+#pragma unroll
+        for (int k = 0; k < MID_KU; ++k) if (k < K) su[k] = fexp(-eu[k] - mx) * inv;
+        float dsum = 0.f;
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            float s0 = su[0];
+#pragma unroll
+            for (int k = 1; k < MID_KU; ++k) s0 = kk[j] == k ? su[k] : s0;
+            sk[j] = s0;
+            float m = 0.f;
+            if (cd[j]) {
+#pragma unroll
+                for (int k = 0; k < MID_KU; ++k) if (k < K) m = fmaf(su[k], Pl[k * L + c[j]], m);
+            }
+            rl[j] = cd[j] ? v[j] - m : 0.f;
+            Rl[c[j]] = rl[j];
+            dsum = fmaf(rl[j], rl[j], dsum);
+        }
+        d = wave_sum_dpp(dsum);
+        float t2[J];
+#pragma unroll
+        for (int j = 0; j < J; ++j) t2[j] = cs[j] ? Rl[ll[j]] * P[j] : 0.f;
+        float qu[MID_KU], qbar = 0.f;
+#pragma unroll
+        for (int k = 0; k < MID_KU; ++k) {
+            qu[k] = 0.f;
+            if (k < K) {
+                float part = 0.f;
+#pragma unroll
+                for (int j = 0; j < J; ++j) part += kk[j] == k ? t2[j] : 0.f;
+                qu[k] = -2.f * wave_sum_dpp(part);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < MID_KU; ++k) if (k < K) qbar = fmaf(su[k], qu[k], qbar);
+#pragma unroll
+        for (int k = 0; k < MID_KU; ++k) if (k < K) dlu[k] = su[k] * (qu[k] - qbar);
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            float x0 = dlu[0];
+#pragma unroll
+            for (int k = 1; k < MID_KU; ++k) x0 = kk[j] == k ? dlu[k] : x0;
+            dlk[j] = x0;
+        }
+    } else if (K > 1) {
 #pragma unroll
         for (int j = 0; j < J; ++j) T[c[j]] = diff[j] * diff[j];
         // (measured, round 4: the segment sums with LDS reads batched eight at a time -- clamped indices, masked values, all
@@ -983,8 +1058,12 @@ __device__ __forceinline__ void mid_row_body(const MidArgs &a, int r, bool lead,
             const float rls = Rl[ll[j]];
             dP = -2.f * sk[j] * rls + 2.f * dlk[j] * diff[j];
             dv = 2.f * rl[j];
-            if (cd[j])
+            if (cd[j] && ku) {
+#pragma unroll
+                for (int k = 0; k < MID_KU; ++k) if (k < K) dv = fmaf(-2.f * dlu[k], v[j] - Pl[k * L + c[j]], dv);
+            } else if (cd[j]) {
                 for (int i = 0; i < K; ++i) dv = fmaf(-2.f * T[i], v[j] - Pl[i * L + c[j]], dv);
+            }
         } else {
             dP = -2.f * diff[j];
             dv = 2.f * (v[j] - Pl[c[j]]);
