@@ -144,3 +144,38 @@ def test_converter_tf_directions_round_trip_with_tf1_names(tmp_path):
     # a reference-written checkpoint also carries ExponentialMovingAverage shadows: dropped on the way in
     tensors['CFL/Mean_3/ExponentialMovingAverage'] = np.float32(0.5)
     assert 'CFL/Mean_3/ExponentialMovingAverage' not in C.from_tf_names(tensors)
+
+
+def test_reader_parses_a_hand_assembled_table(tmp_path):
+    """An SSTable assembled byte by byte from the format description (LevelDB table_format.md / tensorflow/core/lib/io) WITHOUT
+    the writer under test: two data blocks (the second with a shared key prefix), an empty metaindex block, an index block with
+    one entry per data block, the 48-byte footer.  Pins the reader to the layout rather than to its own writer."""
+    def vi(n):
+        out = bytearray()
+        while n >= 0x80:
+            out.append((n & 0x7f) | 0x80)
+            n >>= 7
+        out.append(n)
+        return bytes(out)
+
+    def entry(shared, key_suffix, value):
+        return vi(shared) + vi(len(key_suffix)) + vi(len(value)) + key_suffix + value
+
+    def block(entries_bytes, restarts):
+        body = entries_bytes + b''.join(struct.pack('<I', r) for r in restarts) + struct.pack('<I', len(restarts))
+        return body, body + b'\x00' + struct.pack('<I', T.mask(T.crc32c(b'\x00', T.crc32c(body))))
+    # data block 1: "" -> header, "a/b" -> "one"      data block 2: "a/bc" -> "two", "a/bd" -> "three" (shares "a/b")
+    b1_body, b1 = block(entry(0, b'', b'\x08\x01') + entry(0, b'a/b', b'one'), [0])
+    b2_body, b2 = block(entry(0, b'a/bc', b'two') + entry(3, b'd', b'three'), [0])
+    meta_body, meta = block(b'', [0])
+    off1, off2, offm = 0, len(b1), len(b1) + len(b2)
+    idx_entries = entry(0, b'a/b', vi(off1) + vi(len(b1_body))) + entry(0, b'a/bd', vi(off2) + vi(len(b2_body)))
+    r2 = len(entry(0, b'a/b', vi(off1) + vi(len(b1_body))))
+    idx_body, idx = block(idx_entries, [0, r2])
+    offi = offm + len(meta)
+    footer = vi(offm) + vi(len(meta_body)) + vi(offi) + vi(len(idx_body))
+    footer += b'\x00' * (40 - len(footer)) + struct.pack('<II', 0x8b80fb57, 0xdb477524)     # magic: low word first
+    path = str(tmp_path / 'hand.index')
+    open(path, 'wb').write(b1 + b2 + meta + idx + footer)
+    got = T.read_table(path)
+    assert list(got.items()) == [(b'', b'\x08\x01'), (b'a/b', b'one'), (b'a/bc', b'two'), (b'a/bd', b'three')]
