@@ -535,6 +535,7 @@ static int make_plan(const CflShape *s, int64_t rows, int groups, bool train, bo
     // is short enough for one workgroup per tile, a gradient tile is complete inside its workgroup and the fused tail
     // needs no hand-off.  Not for the siamese pairing (two sides per tile) and not with the fp32-MFMA contraction.
     pl->grad_half = false;
+    bool pad512 = false;
     if (train && debug_env("CFL_EXACT_FP32") <= 0 && debug_env("CFL_DEBUG_GRAD_HALF") >= 0) {
         const int ht = s->D / 32;
         const bool paired = s->dist_type == CFL_DIST_SIAMESE && !s->directed;
@@ -542,9 +543,18 @@ static int make_plan(const CflShape *s, int64_t rows, int groups, bool train, bo
         // with 192 workgroups on 256 CUs, config 4 -- hence the bounds)
         // Beyond 2048 rows per side the rows are split in two (one published half tile per finisher): measured against
         // P = 1 -2.5 us at B = 1536 and -2.5 .. -3.9 us at B = 2048, +0.9 us at B = 1024; against the 64-d form -1 us at B = 3072
-        if (!paired && ht * njobs >= 256 && ht * njobs <= 640 && pl->R <= 6144 && debug_env("CFL_DEBUG_P") <= 0) {
+        // Round 5: with eight waves per workgroup (cfl_grad_x3_half_w8_kernel, two per SIMD) the UNSPLIT tile wins far beyond 2048
+        // rows per side -- same box, bench medians, step us with P = 1 / with the rows split in two (64-d tiles from 7168): B = 1280
+        // 59.9 / 63.9, 1536 61.8 / 65.1, 2048 73.9 / 77.3, 2560 92.4 / 95.1, 3072 101.9 / 103.6, 3584 116.9 / 132.6; B = 4096
+        // 144.9 / 142.7 (profiles/r05_b2048_ab.txt): one workgroup per tile up to 7680 rows (the staged row addresses: 60 KB of
+        // LDS), rows padded to whole 512-row groups so that the eight-wave kernel applies
+        if (!paired && ht * njobs >= 256 && ht * njobs <= 640 && pl->R <= 7680 && debug_env("CFL_DEBUG_P") <= 0) {
+            const int P64 = P;                                           // (row split of the 64-d form, from above)
             pl->grad_half = true;
-            P = pl->R > 2048 ? 2 : 1;
+            P = 1;
+            pad512 = pl->R > 2048 && debug_env("CFL_DEBUG_GRAD_W8") >= 0;
+            if (!pad512 && pl->R > 6144) { pl->grad_half = false; P = P64; }   // (four waves only: the old bounds)
+            else if (!pad512 && pl->R > 2048) P = 2;
         }
         // fewer half tiles than CUs but rows enough to split in two (config 4: 64 x 3 = 192 tiles, 2048 rows per side): 384
         // workgroups, one published tile per finisher.  Round 4, same box: config 4 49.9 -> 47.9 us against the 64-d tiles
@@ -572,7 +582,7 @@ static int make_plan(const CflShape *s, int64_t rows, int groups, bool train, bo
     // launch's own reduction blocks.  CFL_DEBUG_NOFUSE=1: the escape hatch (separate finalize launch)
     pl->fused = train && debug_env("CFL_DEBUG_NOFUSE") <= 0;
     pl->P = P;
-    pl->Rpad = (int)round_up(pl->R, 256 * P);  // grad: 64-row chunks x 4 waves x P ranges
+    pl->Rpad = (int)round_up(pl->R, pad512 ? 512 : 256 * P);  // grad: 64-row chunks x 4 (8) waves x P ranges
     // proj d split: one 128-d chunk per wave when that yields enough workgroups
     if (xrows < 0 || xrows > (1 << 24) || (xrows && !train)) return set_err(CFL_E_SHAPE, "extra scoring rows %lld", (long long)xrows);
     pl->Rx = (int)xrows;

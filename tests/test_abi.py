@@ -118,7 +118,7 @@ def test_plan_describe_names_the_kernels_of_the_baseline_shapes(H):
     nokeep = H.plan_describe(H.make_shape(4096, 20, 3), 512, planes_kept=False)
     assert nokeep['proj'] == 'cfl_proj_kernel' and nokeep['reads_planes'] == 0
     big = H.plan_describe(H.make_shape(4096, 20, 3), 2048)
-    assert big['proj'] == 'cfl_proj_x3_keep_kernel' and big['grad'] == 'cfl_grad_x3_half_split_kernel' and big['P'] == 2
+    assert big['proj'] == 'cfl_proj_x3_keep_kernel' and big['grad'] == 'cfl_grad_x3_half_w8_kernel' and big['P'] == 1 and big['rows_padded'] == 4096
     ev = H.plan_describe(H.make_shape(4096, 20, 3), 32768, groups=1, train=False, planes_kept=False)
     assert ev['proj'] == 'cfl_proj_x3_kernel' and ev['grad'] == '' and ev['per_call_plane_split'] == 1 and ev['launches'] == 3
     c3 = H.plan_describe(H.make_shape(1024, 256, 1, 'siamese', True, False), 512)
