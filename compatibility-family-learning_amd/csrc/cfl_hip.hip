@@ -617,7 +617,9 @@ static int make_plan(const CflShape *s, int64_t rows, int groups, bool train, bo
         // 2048 81.0 / 84.0, 3072 109.2 / 117.5, 4096 140.8 / 145.2 (and 143.2 with streamed x loads)
         // With planes kept beside theta by the fused training step (CflThetaPlanes) the per-call W split -- a launch of
         // ~4 us -- is gone, and the threshold of the training step drops to `kept_rows` (measured: see DESIGN section 4)
-        const int kept_rows = debug_env("CFL_DEBUG_X3_KEPT_ROWS") > 0 ? debug_env("CFL_DEBUG_X3_KEPT_ROWS") : 3072;
+        // (round 5, the eight-wave weight gradient behind both: B = 768 43.8 / 44.1 us per step chunk-at-a-time / LDS-shared, B = 1024
+        // 49.4 / 50.1, B = 1280 60.2 / 57.1 -- profiles/r05_kept_rows_ab.txt: the LDS-shared form from 2560 rows per call)
+        const int kept_rows = debug_env("CFL_DEBUG_X3_KEPT_ROWS") > 0 ? debug_env("CFL_DEBUG_X3_KEPT_ROWS") : 2560;
         if (ok && ov >= 0 && (ov > 0 || pl->R >= (train ? (pl->planes_kept ? kept_rows : 3072) : 4096))) {
             pl->proj_x3 = true;
             pl->x3_tiles = tiles;

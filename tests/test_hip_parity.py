@@ -708,8 +708,8 @@ def test_scores_of_a_labeled_batch_in_one_call():
 
 def test_training_forward_form_follows_the_batch_size(monkeypatch):
     """The fused training step keeps the bf16 planes of theta (CflThetaPlanes) and projects on the bf16 matrix cores:
-    chunk-at-a-time form (cfl_proj_bx3_kernel) at the headline batch, LDS-shared form (cfl_proj_x3_kernel) from 3072 rows
-    per side.  Only the FIRST step of an engine splits the weights in a launch of its own (the library's profile lists it
+    chunk-at-a-time form (cfl_proj_bx3_kernel) at the headline batch, LDS-shared form (cfl_proj_x3_kernel) from 2560 rows per call
+    (round 5; 3072 until then).  Only the FIRST step of an engine splits the weights in a launch of its own (the library's profile lists it
     under `colnorm`); from the second step on the Adam tail has written the planes.  Against the exact-fp32 forward
     (CFL_DEBUG_PROJ_BX3=-1 / CFL_DEBUG_PROJ_X3=-1) the step's scalars move by fp32 rounding only."""
     from cfl.engine import PairEngine
