@@ -559,9 +559,11 @@ static int make_plan(const CflShape *s, int64_t rows, int groups, bool train, bo
         // fewer half tiles than CUs but rows enough to split in two (config 4: 64 x 3 = 192 tiles, 2048 rows per side): 384
         // workgroups, one published tile per finisher.  Round 4, same box: config 4 49.9 -> 47.9 us against the 64-d tiles
         // with four row ranges (three published tiles per finisher); without the split 50.3 (profiles/r04_split_ab.txt)
+        // (round 5: unsplit with eight waves where the rows come in whole 512-row groups -- 192 workgroups x 8 waves: config 4 48.2 ->
+        // 47.4 us, profiles/r05_c4_p1_ab.txt)
         if (!paired && ht * njobs >= 128 && ht * njobs < 256 && pl->R >= 2048 && pl->R <= 6144 && debug_env("CFL_DEBUG_P") <= 0) {
             pl->grad_half = true;
-            P = 2;
+            P = (round_up(pl->R, 256) % 512 == 0 && debug_env("CFL_DEBUG_GRAD_W8") >= 0) ? 1 : 2;
         }
         // siamese: side 0's half tile is published, side 1's workgroup of the same tile finishes -- ONE published tile per
         // finisher and twice as many finishers as the 64-d / P = 2 form (config 3: three tiles per finisher)

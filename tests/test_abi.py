@@ -124,6 +124,6 @@ def test_plan_describe_names_the_kernels_of_the_baseline_shapes(H):
     c3 = H.plan_describe(H.make_shape(1024, 256, 1, 'siamese', True, False), 512)
     assert c3['grad'] == 'cfl_grad_x3_half_split_kernel' and c3['mid'] == 'cfl_mid_row_kernel<4>'
     c4 = H.plan_describe(H.make_shape(2048, 20, 5, 'pcd', True, True), 1024)
-    assert c4['proj'] == 'cfl_proj_bx3_kernel' and c4['P'] == 2 and c4['column_jobs'] == 3
+    assert c4['proj'] == 'cfl_proj_bx3_kernel' and c4['P'] == 1 and c4['grad'] == 'cfl_grad_x3_half_w8_kernel' and c4['column_jobs'] == 3
     with pytest.raises(H.CflHipError):
         H.plan_describe(H.make_shape(4096, 20, 3), 512, groups=1, train=True)
