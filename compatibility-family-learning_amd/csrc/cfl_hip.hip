@@ -593,7 +593,15 @@ static int make_plan(const CflShape *s, int64_t rows, int groups, bool train, bo
     const int rtiles = (pl->R + 31) / 32 + pl->Rxpad / 32;
     const int nchunks = (s->D / 16 + 7) / 8;
     int S = (512 + rtiles * njobs - 1) / (rtiles * njobs);
-    S = pow2_floor(S < 1 ? 1 : S);
+    {
+        // power of two below the wanted split -- or, training, EIGHT (one slice per XCD: the aligned launch order of proj and grad)
+        // when 6 or 7 are wanted (round 5: B = 640 wants 7: 41.4 us per step with S = 8 against 43.2 with 4; B = 768 (6) 43.7 /
+        // 44.4; B = 1024 (4) stays -- profiles/r05_s_ab.txt.  Not a general round-to-nearest: config 4 wants 3, and S = 4
+        // instead of 2 costs it 1.3 us, profiles/r05_c4_s_ab.txt)
+        const int want_s = S < 1 ? 1 : S;
+        S = pow2_floor(want_s);
+        if (train && S == 4 && want_s >= 6) S = 8;
+    }
     int maxS = (nchunks + 3) / 4;  // at least one chunk per wave
     if (S > maxS) S = pow2_floor(maxS);
     if (S > 16) S = 16;
