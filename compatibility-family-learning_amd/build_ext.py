@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 NAMES = ('cfl_hip', 'cfl_conv', 'cfl_gan', 'cfl_eval', 'cfl_dp')
 SRCS = [os.path.join(HERE, 'csrc', n + '.hip') for n in NAMES]
 SRC = SRCS[0]
-HEADERS = [os.path.join(HERE, 'csrc', h) for h in ('gemm_gather.h', 'conv_halo.h', 'conv_halo_wgrad.h', 'theta_planes.h',
+HEADERS = [os.path.join(HERE, 'csrc', h) for h in ('gemm_gather.h', 'conv_halo.h', 'conv_halo_wgrad.h', 'conv_stem.h', 'theta_planes.h',
                                                     'pair_proj.h', 'pair_grad.h', 'pair_mid.h', 'pair_finalize.h')] + \
           [os.path.join(os.path.dirname(HERE), 'include', 'cfl_hip.h')]
 OBJ_DIR = os.path.join(HERE, 'build')

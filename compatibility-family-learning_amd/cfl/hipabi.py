@@ -552,8 +552,9 @@ def conv_out_hw(conv):
 
 
 def conv_uses_direct_kernel(conv, product):
-    """product 'fwd' / 'dx': does this shape run on the 3x3 halo-tile kernel (csrc/conv_halo.h)?"""
-    return lib().cfl_conv_uses_direct_kernel(C.byref(conv), {'fwd': 0, 'dx': 1, 'dw': 2}[product]) == 1
+    """product 'fwd' / 'dx' / 'dw': does this shape run on the 3x3 halo-tile kernels (csrc/conv_halo*.h)?  'stem': is it the
+    3-channel 4x4 stride-2 image stem with kernels of its own (csrc/conv_stem.h)?"""
+    return lib().cfl_conv_uses_direct_kernel(C.byref(conv), {'fwd': 0, 'dx': 1, 'dw': 2, 'stem': 3}[product]) == 1
 
 
 def conv_workspace(conv, device):

@@ -13,6 +13,7 @@
 #include "gemm_gather.h"
 #include "conv_halo.h"
 #include "conv_halo_wgrad.h"
+#include "conv_stem.h"
 
 extern int cfl_set_err(int code, const char *fmt, ...);
 
@@ -669,9 +670,12 @@ static HaloWPlan halo_wgrad_plan_of(const ConvGeom &g) {
     if (!(g.KH == 3 && g.KW == 3 && g.S == 1)) return HaloWPlan{};
     return halo_wgrad_plan(g.B, g.H, g.W, g.Ci, g.Co);
 }
+// the 3-channel image stem (4x4 stride 2): direct exact-fp32 kernels for all three products (conv_stem.h)
+static bool stem_shape(const ConvGeom &g) { return stem_shape_ok(g.H, g.W, g.Ci, g.Co, g.KH, g.KW, g.S); }
 static int wgrad_splits(const ConvGeom &g) {
     const HaloWPlan hw = halo_wgrad_plan_of(g);
     if (hw.ok) return hw.splits;
+    if (stem_shape(g)) return stem_dw_splits(g.B, g.OH, g.OW);
     return gg_splits((long long)g.B * g.OH * g.OW, wgrad_klen(g));
 }
 
@@ -732,6 +736,7 @@ __global__ __launch_bounds__(256) void fc_narrow_fwd_kernel(const float *x, cons
 extern "C" int cfl_conv_uses_direct_kernel(const CflConv *c, int product) {
     ConvGeom g;
     if (make_geom(c, &g)) return -1;
+    if (product == 3) return stem_shape(g) ? 1 : 0;   // the image stem's own kernels (all three products)
     if (product == 2) return halo_wgrad_plan_of(g).ok ? 1 : 0;
     return (product == 0 ? halo_fwd_plan(g) : halo_dx_plan(g)).ok ? 1 : 0;
 }
@@ -793,6 +798,8 @@ extern "C" int cfl_conv2d_wn_fwd_fused(const CflConv *c, const float *x, const f
                   (float *)workspace + conv_ws_header_floats(g), st, planes, prep, residual, subpixel ? 1 : 0);
         if (cache) *cache_flags |= CFL_CONV_CACHE_PLANES_FWD;
     }
+    else if (stem_shape(g) && !residual && !subpixel)
+        stem_fwd(g.B, g.H, g.W, g.Co, x, V, scale, bias, g.act, y, st);
     else if (vec)
         gemm_gather_modes<GG_VEC_K, GG_VEC_MN>(g.B * g.OH * g.OW, g.Co, rows, gg_klen(rows, 1), Im2colX{x, g},
                                                FilterKN{V, g.Co},
@@ -923,6 +930,8 @@ extern "C" int cfl_conv2d_wn_bwd_fused(const CflConv *c, const float *x, const f
             halo_conv(hp, g.B, g.H, g.W, g.Co, g.Ci, dy, y, g.act, V, scale, g.Ci, g.Co, 1, nullptr, 0, dx, slab, st, planes, prep,
                       nullptr, 0, dy_cq);
             if (cache) *cache_flags |= CFL_CONV_CACHE_PLANES_DX;
+        } else if (stem_shape(g)) {
+            stem_dx(g.B, g.H, g.W, g.Co, dy, y, g.act, V, scale, dx, st);
         } else if (g.S == 2 && g.H % 2 == 0 && g.W % 2 == 0) {
             // four dense sub-problems, one per parity class of the input pixel
             const int KH2 = (g.KH + 1) / 2, KW2 = (g.KW + 1) / 2, H2 = g.H / 2, W2 = g.W / 2;
@@ -970,6 +979,8 @@ extern "C" int cfl_conv2d_wn_bwd_fused(const CflConv *c, const float *x, const f
         const HaloWPlan hw = halo_wgrad_plan_of(g);
         if (hw.ok)
             halo_wgrad(hw, g.B, g.H, g.W, g.Ci, g.Co, x, dy, y, g.act, slab, sstride, st, dy_cq);
+        else if (stem_shape(g))
+            stem_dw(g.B, g.H, g.W, g.Co, x, dy, y, g.act, slab, sstride, st);
         else if (vec)
             gemm_gather_modes<GG_VEC_MN, GG_VEC_MN>(rows + 4, g.Co, npix, wgrad_klen(g), Im2colXT{Im2colX{x, g}, rows},
                                                     DyPre{dy, y, g.Co, g.act}, StoreSlab{slab, sstride, g.Co}, st);

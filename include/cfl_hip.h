@@ -414,7 +414,9 @@ typedef struct {
 } CflConv;
 size_t cfl_conv_workspace_bytes(const CflConv *conv);
 /* Introspection (tests, profiling): 1 when `product` (0 = forward, 1 = input gradient, 2 = weight gradient) of this shape
- * runs on a direct 3x3 halo-tile kernel, 0 when it runs on the gathered GEMM; negative on a bad shape.  No reference counterpart. */
+ * runs on a direct 3x3 halo-tile kernel, 0 when it runs on the gathered GEMM; negative on a bad shape.  product 3: 1 when the
+ * shape is the 3-channel 4x4 stride-2 image stem, whose three products run on the kernels of csrc/conv_stem.h.  No reference
+ * counterpart. */
 int cfl_conv_uses_direct_kernel(const CflConv *conv, int product);
 int cfl_conv2d_wn_fwd(const CflConv *conv, const float *x, const float *V, const float *g,
                       const float *b, float *y, void *workspace, size_t workspace_bytes,

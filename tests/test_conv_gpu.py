@@ -48,6 +48,14 @@ CONV_CASES = [
     # relu slope, 3 x 2 channel blocks; an odd batch of 8x8 images with a ragged last two-image tile and several splits
     (40, 32, 32, 96, 64, 3, 1, 'relu', True),
     (37, 8, 8, 64, 96, 3, 1, 'lrelu', True),
+    # the 3-channel image stem (4x4 stride 2, csrc/conv_stem.h): the config-5 shape; a ragged 16-pixel segment without
+    # activation / bias; 64 channels with two segments per row; the narrowest image (both edges in one patch row);
+    # enough pixels for several weight-gradient slabs (pre-summed in groups)
+    (3, 64, 64, 3, 32, 4, 2, 'lrelu', True),
+    (2, 16, 24, 3, 32, 4, 2, None, False),
+    (5, 8, 40, 3, 64, 4, 2, 'relu', True),
+    (2, 6, 4, 3, 16, 4, 2, 'lrelu', True),
+    (40, 32, 32, 3, 32, 4, 2, 'lrelu', True),
 ]
 
 
@@ -71,6 +79,8 @@ def test_conv2d_wn_fwd_bwd(B, Hh, Ww, Ci, Co, K, S, act, bias):
     assert H.conv_uses_direct_kernel(conv, 'dx') == (direct and Co % 32 == 0 and Ci % 4 == 0 and Ci >= 32)
     # weight gradient on the halo-tile kernel (csrc/conv_halo_wgrad.h): 32-channel multiples on both sides, not the 4x4 images
     assert H.conv_uses_direct_kernel(conv, 'dw') == (direct and (Hh, Ww) != (4, 4) and Ci % 32 == 0 and Co % 32 == 0)
+    assert H.conv_uses_direct_kernel(conv, 'stem') == (K == 4 and S == 2 and Ci == 3 and Co in (16, 32, 64)
+                                                       and Hh % 2 == 0 and Ww % 2 == 0 and Ww >= 4)
     ws = H.conv_workspace(conv, 'cuda')
     f = lambda a: torch.tensor(a, dtype=torch.float32, device='cuda').contiguous()
     dx_, dV_, dg_, db_ = None, None, None, None
