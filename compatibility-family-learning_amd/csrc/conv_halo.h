@@ -459,6 +459,15 @@ static inline bool halo_off() {
     return off != 0;
 }
 
+// Fewest output channels the kernel takes (on a 32-column tile, the rest zero planes).  Round 5: 4 instead of 32 -- the
+// generator's image layer (128 -> 12 channels, sub-pixel store) ran on the gathered GEMM, whose loop is bound by its gather
+// arithmetic whatever N is: 0.26 ms for 34 GF at B = 300; the padded halo tile does 2.7x the matrix work and is still several
+// times faster.  CFL_DEBUG_HALO_NMIN=32 restores the old bound.
+static inline int halo_nmin() {
+    static const int v = [] { const char *e = getenv("CFL_DEBUG_HALO_NMIN"); const int n = e ? atoi(e) : 0; return n > 0 ? n : 4; }();
+    return v;
+}
+
 // Channel tile.  64 columns x 128 pixels at TWO workgroups per CU (59-80 KiB of LDS, <= 256 registers) beats the 128-column
 // tile at one: a single wave per SIMD cannot keep the matrix pipe busy on its own (bare MFMA loop: 59 % of peak with one
 // wave, 85 % with two -- tools/microbench/mfma_peak.hip) and two independent workgroups hide each other's barriers.
@@ -479,7 +488,7 @@ static inline HaloPlan halo_plan(int B, int H, int W, int K, int N) {
     HaloPlan pl;
     memset(&pl, 0, sizeof(pl));
     if (halo_off() || !gg_use_x3()) return pl;
-    if (K % 32 != 0 || N % 4 != 0 || N < 32) return pl;
+    if (K % 32 != 0 || N % 4 != 0 || N < halo_nmin()) return pl;
     if (W % 16 == 0 && H % 8 == 0) { pl.tw = 16; pl.tiles_x = W / 16; pl.tiles_y = H / 8; pl.ptiles = B * pl.tiles_x * pl.tiles_y; }
     else if (W == 8 && H == 8) { pl.tw = 8; pl.tiles_x = pl.tiles_y = 1; pl.ptiles = (B + 1) / 2; }
     else if (W == 4 && H == 4) { pl.tw = 4; pl.tiles_x = pl.tiles_y = 1; pl.ptiles = (B + 7) / 8; }
@@ -515,7 +524,7 @@ static inline HaloPlan halo_plan(int B, int H, int W, int K, int N) {
 // only (the cache of a layer is laid out with it whatever batch / image size a call has); 0 when the direction can never
 // run on the halo kernel
 static inline size_t halo_planes_bytes(int K, int N) {
-    if (halo_off() || !gg_use_x3() || K % 32 != 0 || N % 4 != 0 || N < 32) return 0;
+    if (halo_off() || !gg_use_x3() || K % 32 != 0 || N % 4 != 0 || N < halo_nmin()) return 0;
     const int tn = halo_tn_base(N);
     const int Npad = (N + tn - 1) / tn * tn;
     return ((size_t)9 * (K / 32) * 3 * Npad * 32 * sizeof(unsigned short) + 15) / 16 * 16;

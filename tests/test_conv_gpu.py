@@ -48,6 +48,10 @@ CONV_CASES = [
     # relu slope, 3 x 2 channel blocks; an odd batch of 8x8 images with a ragged last two-image tile and several splits
     (40, 32, 32, 96, 64, 3, 1, 'relu', True),
     (37, 8, 8, 64, 96, 3, 1, 'lrelu', True),
+    # fewer than 32 output channels on the halo kernel's 32-column tile (the generator's image layer: 128 -> 12): forward with
+    # N = 12; input gradient with N = Ci = 12
+    (2, 16, 16, 64, 12, 3, 1, None, True),
+    (3, 8, 8, 12, 64, 3, 1, 'lrelu', True),
     # the 3-channel image stem (4x4 stride 2, csrc/conv_stem.h): the config-5 shape; a ragged 16-pixel segment without
     # activation / bias; 64 channels with two segments per row; the narrowest image (both edges in one patch row);
     # enough pixels for several weight-gradient slabs (pre-summed in groups)
@@ -75,8 +79,8 @@ def test_conv2d_wn_fwd_bwd(B, Hh, Ww, Ci, Co, K, S, act, bias):
 
     conv = H.make_conv(B, Hh, Ww, Ci, Co, K, K, S, act)
     direct = K == 3 and S == 1 and ((Ww % 16 == 0 and Hh % 8 == 0) or (Hh, Ww) in ((4, 4), (8, 8)))
-    assert H.conv_uses_direct_kernel(conv, 'fwd') == (direct and Ci % 32 == 0 and Co % 4 == 0 and Co >= 32)
-    assert H.conv_uses_direct_kernel(conv, 'dx') == (direct and Co % 32 == 0 and Ci % 4 == 0 and Ci >= 32)
+    assert H.conv_uses_direct_kernel(conv, 'fwd') == (direct and Ci % 32 == 0 and Co % 4 == 0)
+    assert H.conv_uses_direct_kernel(conv, 'dx') == (direct and Co % 32 == 0 and Ci % 4 == 0)
     # weight gradient on the halo-tile kernel (csrc/conv_halo_wgrad.h): 32-channel multiples on both sides, not the 4x4 images
     assert H.conv_uses_direct_kernel(conv, 'dw') == (direct and (Hh, Ww) != (4, 4) and Ci % 32 == 0 and Co % 32 == 0)
     assert H.conv_uses_direct_kernel(conv, 'stem') == (K == 4 and S == 2 and Ci == 3 and Co in (16, 32, 64)
@@ -264,7 +268,7 @@ def test_exact_fp32_gemm_path_in_a_fresh_process():
     (3, 16, 16, 64, 128, 3, 1, 'lrelu'),     # halo kernel, one image per tile
     (5, 8, 8, 128, 256, 3, 1, 'relu'),       # two images per tile; Co / 4 = 64
     (11, 4, 4, 256, 256, 3, 1, 'lrelu'),     # eight images per tile, split-K over channel chunks (the reduce kernel's epilogue)
-    (2, 16, 16, 64, 12, 3, 1, None),         # the generator's output layer: Co / 4 = 3 -> gathered GEMM, scalar stores
+    (2, 16, 16, 64, 12, 3, 1, None),         # the generator's output layer: Co / 4 = 3 -> halo kernel on a padded 32-column tile (round 5)
     (2, 8, 8, 6, 72, 4, 2, 'relu'),          # stride 2 / even kernel on the gathered GEMM
     (2, 16, 16, 32, 36, 3, 1, 'lrelu'),      # Co / 4 = 9 on the halo kernel: four consecutive channels straddle two quarters
 ])
