@@ -57,6 +57,11 @@ for it in range(N):
     S = int(rng.choice([1, 2])) if K > 1 else 1
     act = rng.choice([None, 'lrelu', 'relu'])
     bias = bool(rng.rand() < 0.7)
+    if os.environ.get('FUZZ_STEM'):     # the 3-channel 4x4 stride-2 image stem (csrc/conv_stem.h): even sides, W >= 4, Co 16 / 32 / 64
+        B = int(rng.choice([1, 2, 3, 7, 33]))
+        Hh = int(rng.choice([2, 4, 6, 10, 16, 32, 64]))
+        Ww = int(rng.choice([4, 6, 8, 12, 30, 32, 34, 64, 70]))
+        Ci, Co, K, S = 3, int(rng.choice([16, 32, 64])), 4, 2
     desc = (B, Hh, Ww, Ci, Co, K, S, act, bias)
     try:
         T.test_conv2d_wn_fwd_bwd(*desc)
