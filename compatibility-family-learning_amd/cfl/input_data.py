@@ -221,6 +221,99 @@ def load_double_images_by_offsets(path, offsets, raw_latent=False):
             np.array(latents, dtype=np.float32).reshape((len(offsets), -1)))
 
 
+class DecodedRecords(object):
+    """Decoded image (+ latent) records of one image / double ``features.b``, kept in host memory (new functionality; SURVEY.md
+    8(f).1).  The reference seeks, reads and DECODES every record of every batch, every iteration
+    (cfl/input_data.py:67-133: ~600 PNG decodes per MrCGAN post-epoch iteration at batch 100 -- an order of magnitude more
+    host time than the GPU step it feeds).  Here a record is decoded ONCE, the first time a batch asks for it: its pixels
+    go into one uint8 table [n_records, H*W*C] (12 KiB per 64x64x3 image), its latent into one float32 table, and a batch
+    is a fancy-index gather of table rows followed by the reference's own conversion ``uint8.astype(float32) / 255.`` --
+    the same values bit for bit, applied to the gathered rows instead of image by image.
+
+    Records that are not uint8 images of one common shape make the table give up (`usable` False): the caller reads such a
+    file record by record as before.  CFL_IMAGE_TABLE_MB caps the tables (default 32768); 0 disables them."""
+
+    def __init__(self, path, offsets, is_double, raw_latent):
+        self.path, self.is_double, self.raw_latent = path, is_double, raw_latent
+        offs = np.sort(np.asarray(list(offsets), dtype=np.int64))
+        self.row_of = {int(o): i for i, o in enumerate(offs)}
+        self._off_of = offs       # row -> byte offset
+        self.n = offs.shape[0]
+        self.have = np.zeros(self.n, dtype=bool)
+        self.images = None        # uint8 [n, H*W*C], allocated at the first decode
+        self.latents = None       # float32 [n, Dl]
+        self.usable = self.n > 0 and self.cap_bytes() > 0
+
+    @staticmethod
+    def cap_bytes():
+        try:
+            return int(float(os.environ.get('CFL_IMAGE_TABLE_MB', '32768')) * (1 << 20))
+        except ValueError:
+            return 32768 << 20
+
+    def _decode(self, offsets):
+        """[(uint8 pixels, latent or None)] of the records at `offsets`, or None when a record does not fit the tables"""
+        out = []
+        with open(self.path, 'rb') as infile:
+            for offset in offsets:
+                infile.seek(int(offset) + ID_BYTES)
+                if self.is_double:
+                    size1, size2 = struct.unpack('<ii', infile.read(8))
+                else:
+                    size1, size2 = struct.unpack('<i', infile.read(4))[0], 0
+                img = imread(BytesIO(infile.read(size1)))
+                if img.dtype != np.uint8:
+                    return None
+                lat = None
+                if self.is_double:
+                    if self.raw_latent:
+                        lat = np.frombuffer(infile.read(size2), dtype='<f4')
+                    else:
+                        lat = np.asarray(np.load(BytesIO(infile.read(size2)))['data'], dtype=np.float32).reshape(-1)
+                out.append((img.reshape(-1), lat))
+        return out
+
+    def rows(self, offsets):
+        """table rows of the records at `offsets`, decoding the ones not seen yet; None when the table cannot serve them"""
+        if not self.usable:
+            return None
+        try:
+            rows = np.fromiter((self.row_of[int(o)] for o in offsets), dtype=np.int64, count=len(offsets))
+        except KeyError:
+            return None
+        missing = np.unique(rows[~self.have[rows]])
+        if missing.size:
+            dec = self._decode(self._off_of[missing])
+            if dec is None:
+                self.usable = False
+                return None
+            if self.images is None:
+                px = dec[0][0].shape[0]
+                dl = dec[0][1].shape[0] if self.is_double else 0
+                if self.n * (px + 4 * dl) > self.cap_bytes():
+                    self.usable = False
+                    return None
+                self.images = np.empty((self.n, px), dtype=np.uint8)
+                self.latents = np.empty((self.n, dl), dtype=np.float32) if self.is_double else None
+            for r, (img, lat) in zip(missing, dec):
+                if img.shape[0] != self.images.shape[1] or (self.is_double and lat.shape[0] != self.latents.shape[1]):
+                    self.usable = False       # ragged records: the per-record readers handle (or reject) them as before
+                    return None
+                self.images[r] = img
+                if self.is_double:
+                    self.latents[r] = lat
+            self.have[missing] = True
+        return rows
+
+    def load(self, offsets):
+        """what load_images_by_offsets / load_double_images_by_offsets return for `offsets`, or None"""
+        rows = self.rows(offsets)
+        if rows is None:
+            return None
+        images = self.images[rows].astype(np.float32) / 255.
+        return (images, self.latents[rows]) if self.is_double else images
+
+
 def _read_pairs(path, index, reorder=False):
     pairs = []
     with open(path) as infile:
@@ -273,6 +366,8 @@ class SemiDataSet(object):
         self.data_switch = data_switch
         self.raw_latent = raw_latent
 
+        self._records = None      # DecodedRecords of an image / double file (built at the first batch)
+        self.labeled_images = True   # False: labeled batches of a double dataset carry placeholder images (_load_labeled)
         if is_image:
             # positions are byte offsets; the unlabeled order is permuted once up front
             # (cfl/input_data.py:379-391)
@@ -311,6 +406,11 @@ class SemiDataSet(object):
     # -- feature access ------------------------------------------------------
     def _load_features_by_positions(self, indices):
         if self.is_image:
+            if self._records is None:
+                self._records = DecodedRecords(self.feature_path, self.index_to_asins, self.is_double, self.raw_latent)
+            got = self._records.load(indices)
+            if got is not None:
+                return got
             if self.is_double:
                 return load_double_images_by_offsets(self.feature_path, indices, raw_latent=self.raw_latent)
             return load_images_by_offsets(self.feature_path, indices)
@@ -427,8 +527,21 @@ class SemiDataSet(object):
         out = []
         for pairs in (pos, neg):
             for c in cols:
-                out.extend(self._parts(self._load_features_by_positions(pairs[:, c])))
+                out.extend(self._parts(self._load_labeled(pairs[:, c])))
         return tuple(out)   # 4 arrays, or 8 (image, latent interleaved) for double data
+
+    def _load_labeled(self, positions):
+        """Items of a LABELED batch.  With `labeled_images` False (set by a consumer that reads only the latents of labeled
+        double batches: the pair model on latents, the MrCGAN post epochs) the image parts are zero placeholders of the right
+        shape (a read-only broadcast, no memory) and only the latents are gathered from the decoded-record table."""
+        if self.is_double and not self.labeled_images:
+            if self._records is None:
+                self._records = DecodedRecords(self.feature_path, self.index_to_asins, self.is_double, self.raw_latent)
+            rows = self._records.rows(positions)
+            if rows is not None:
+                tab = self._records
+                return np.broadcast_to(np.zeros(1, np.float32), (rows.shape[0], tab.images.shape[1])), tab.latents[rows]
+        return self._load_features_by_positions(positions)
 
     def next_batch(self, batch_size, return_labels=False):
         return self.next_labeled_batch(batch_size, return_labels)

@@ -459,6 +459,12 @@ class CFL(PairModel):
         from tqdm import trange
         nb_train = max(data.train.num_examples_labeled_pos, data.train.num_examples_labeled_neg)
         logger.warning('%d pairs / %d images', nb_train, data.train.num_examples)
+        # labeled batches of an image + latent dataset: this model reads their latents only (select_batch; the post epochs take
+        # their images from the unlabeled streams) unless it is the --cgan baseline, which trains on the labeled images
+        if self.is_double and self.uses_latent and not self.cgan:
+            for split in (data.train, data.val):
+                if hasattr(split, 'labeled_images'):
+                    split.labeled_images = False
         nb_batch = nb_train // self.batch_size
         logger.warning('%d batches per epoch', nb_batch)
         best_auc_path = os.path.join(best_dir, 'best_accuracy')

@@ -106,3 +106,60 @@ def test_whole_batches_and_dump_image(roots, tmp_path):
     got = list(D.load_images(str(p)))
     assert [a for a, _ in got] == META['ids'][:3]
     assert np.array_equal(got[1][1], (G['images'][1].astype(np.float32) / 255.).reshape(-1))
+
+
+@pytest.mark.parametrize('kind', list(KINDS))
+def test_decoded_record_table_equals_the_per_record_readers(roots, kind, monkeypatch):
+    """DecodedRecords (records decoded once into a uint8 / latent table, batches gathered from it) must hand out exactly
+    what the reference's per-record readers do -- bit for bit, for repeated, permuted and duplicate positions -- and step
+    aside (per-record path) when the cap is 0, an offset is unknown or a record is no uint8 image."""
+    from cfl import input_data as D
+    double, raw = KINDS[kind]
+    path = str(roots / kind / 'features.b')
+    offs = (D.load_double_offsets if double else D.load_images_offsets)(path)
+    ids = META['ids']
+    pos = [offs[ids[i]] for i in (4, 0, 12, 4, 7, 7, 1)]
+    direct = (D.load_double_images_by_offsets(path, pos, raw_latent=raw) if double else D.load_images_by_offsets(path, pos))
+    ds = D.SemiDataSet(str(roots / kind), input_size=90, is_image=True, is_double=double, raw_latent=raw)
+    for _ in range(2):          # second round: every record comes from the table
+        got = ds._load_features_by_positions(np.array(pos))
+        if double:
+            assert got[0].dtype == np.float32 and np.array_equal(got[0], direct[0]) and np.array_equal(got[1], direct[1])
+            assert got[1].dtype == np.float32
+        else:
+            assert got.dtype == np.float32 and np.array_equal(got, direct)
+    tab = ds._records
+    assert tab.usable and int(tab.have.sum()) == 5 and tab.images.dtype == np.uint8
+    exp = _expect(kind, pos)
+    assert np.array_equal(got[0] if double else got, exp[0])
+    # a whole seeded stream through the table equals the stream of a dataset whose table is disabled
+    a = D.SemiDataSet(str(roots / kind), input_size=90, is_image=True, is_double=double, raw_latent=raw, seed=7)
+    a._load_features_by_positions(np.array(pos[:1]))      # (the table is built at the first load: before the cap is set to 0)
+    monkeypatch.setenv('CFL_IMAGE_TABLE_MB', '0')
+    b = D.SemiDataSet(str(roots / kind), input_size=90, is_image=True, is_double=double, raw_latent=raw, seed=7)
+    for _ in range(6):
+        xa, xb = a.next_batch(3), b.next_batch(3)
+        assert len(xa) == len(xb) and all(np.array_equal(u, v) and u.dtype == v.dtype for u, v in zip(xa, xb))
+        ua, ub = a.next_unlabeled_batch(4), b.next_unlabeled_batch(4)
+        assert all(np.array_equal(u, v) for u, v in zip(ua, ub))
+    assert b._records is not None and not b._records.usable and a._records.usable
+    monkeypatch.delenv('CFL_IMAGE_TABLE_MB')
+    # unknown offset -> the table steps aside
+    assert tab.rows([pos[0] + 1]) is None
+
+
+def test_labeled_batches_without_images(roots):
+    """labeled_images = False: the image parts of a labeled double batch are zero placeholders of the right shape, the
+    latents and the seeded stream are those of the full batch."""
+    from cfl import input_data as D
+    a = D.SemiDataSet(str(roots / 'double_raw'), input_size=90, is_image=True, is_double=True, raw_latent=True, seed=11)
+    b = D.SemiDataSet(str(roots / 'double_raw'), input_size=90, is_image=True, is_double=True, raw_latent=True, seed=11)
+    b.labeled_images = False
+    for _ in range(5):
+        xa, xb = a.next_batch(3), b.next_batch(3)
+        assert len(xa) == len(xb) == 8
+        for i in range(0, 8, 2):
+            assert xb[i].shape == xa[i].shape and xb[i].dtype == np.float32 and not xb[i].any()
+            assert np.array_equal(xa[i + 1], xb[i + 1])
+        ua, ub = a.next_unlabeled_batch(4), b.next_unlabeled_batch(4)       # unlabeled batches keep their images
+        assert all(np.array_equal(u, v) for u, v in zip(ua, ub))
