@@ -779,6 +779,51 @@ class ResidentFeatures(object):
             yield self.table, self._h.IndexStreams([base, base + 4], 2, n, keep=[dev])
 
 
+class PinnedUploader(object):
+    """Host batches -> device tensors without stalling the host (new functionality).  `torch.from_numpy(x).to(device)` from
+    pageable memory is a synchronous copy on the CURRENT stream: it waits for everything enqueued there -- the previous
+    training step -- so host batch assembly and the GPU step take turns (measured on the MrCGAN post-epoch loop: 16.5 ms
+    per iteration for a 12.4 ms step and 3 ms of host work).  Here the rows are copied into a rotating pinned buffer
+    (one ring per shape) and uploaded asynchronously on a copy stream of the uploader's own; the consumer's stream waits
+    for the upload's event, the host does not wait at all unless a ring wraps onto an upload that has not left its buffer."""
+
+    NBUF = 8                   # pinned buffers per shape ...
+    RING_BYTES = 256 << 20     # ... within this many bytes per shape (at least two)
+    MAX_BYTES = 128 << 20      # larger arrays take the synchronous pageable copy
+
+    def __init__(self, device):
+        import torch
+        self.device = torch.device(device)
+        self.stream = torch.cuda.Stream(device=self.device)
+        self._rings = {}       # shape -> [next, [[pinned, event], ...]]
+
+    def upload(self, x):
+        """contiguous float32 device tensor with the values of the array `x` (ready on the CURRENT stream)"""
+        import torch
+        a = np.ascontiguousarray(x, dtype=np.float32)
+        if a.nbytes == 0 or a.nbytes > self.MAX_BYTES:      # (nothing to stage / not worth pinning: the plain copy)
+            return torch.from_numpy(a).to(self.device)
+        ring = self._rings.get(a.shape)
+        if ring is None:
+            nbuf = max(2, min(self.NBUF, self.RING_BYTES // a.nbytes))
+            ring = self._rings[a.shape] = [0, [[torch.empty(a.shape, dtype=torch.float32).pin_memory(), None]
+                                              for _ in range(nbuf)]]
+        slot = ring[1][ring[0]]
+        ring[0] = (ring[0] + 1) % len(ring[1])
+        if slot[1] is not None:
+            slot[1].synchronize()          # the previous upload from this pinned buffer has left it
+        np.copyto(slot[0].numpy(), a)
+        cur = torch.cuda.current_stream(self.device)
+        with torch.cuda.stream(self.stream):
+            dev = torch.empty(a.shape, dtype=torch.float32, device=self.device)
+            dev.copy_(slot[0], non_blocking=True)
+            slot[1] = torch.cuda.Event()
+            slot[1].record(self.stream)
+        cur.wait_event(slot[1])
+        dev.record_stream(cur)             # allocated on the copy stream, used (and eventually freed) under `cur`
+        return dev
+
+
 class StreamedFeatures(object):
     """A split whose ``features.b`` does NOT fit in HBM (or ``CFL_FEATURES=stream``): the file stays memory-mapped on the
     host and every batch's rows are gathered into pinned staging memory and copied to the device asynchronously --

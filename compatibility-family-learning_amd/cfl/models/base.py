@@ -7,6 +7,8 @@ HIP kernels (csrc/cfl_hip.hip), selected by (dist_type, weight_norm, has_bias,
 act_type).  Variables are addressed by the reference's TensorFlow names
  in checkpoints.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -71,13 +73,25 @@ class PairModel(object):
         return p
 
     # -- data plumbing ------------------------------------------------------
+    def upload(self, x):
+        """host array -> fp32 device tensor through the model's PinnedUploader (asynchronous; CFL_SYNC_UPLOAD=1: the
+        synchronous pageable copy)"""
+        dev = torch.device(self.device)
+        if dev.type != 'cuda' or os.environ.get('CFL_SYNC_UPLOAD', '0') not in ('0', ''):
+            return torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(dev)
+        up = getattr(self, '_uploader', None)
+        if up is None:
+            from ..input_data import PinnedUploader
+            up = self._uploader = PinnedUploader(dev)
+        return up.upload(x)
+
     def to_device(self, x):
         """[n, input_size] array or tensor -> contiguous fp32 device tensor padded to
         the kernels' multiple-of-64 feature width."""
         if isinstance(x, torch.Tensor):
             t = x.to(self.device, torch.float32)
         else:
-            t = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(self.device)
+            t = self.upload(x)
         if t.shape[1] != self.padded_size:
             t = torch.nn.functional.pad(t, (0, self.padded_size - t.shape[1]))
         return t.contiguous()

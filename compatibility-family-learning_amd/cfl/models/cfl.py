@@ -127,8 +127,9 @@ class CFL(PairModel):
     # -- MrCGAN post-epoch iteration (cfl/models/cfl.py:1487-1497) -----------------------
     def _dev(self, x):
         import torch
-        t = x if isinstance(x, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(x, np.float32))
-        return t.to(self.device, torch.float32).contiguous()
+        if not isinstance(x, torch.Tensor):
+            return self.upload(x)
+        return x.to(self.device, torch.float32).contiguous()
 
     def _enc_rows(self, x, side=0):
         """What the encoder heads read for raw input rows x: the padded rows themselves (linear model) or the
@@ -568,16 +569,21 @@ class CFL(PairModel):
         an unlabeled source / target batch (cfl/bin/train.py:29-40) and updates D and G."""
         t.set_description('post epoch {}'.format(e))
         tr = data.train
-        for i in t:
+
+        def fetch():
+            """the batches of one iteration, in the reference's order of draws (cfl/bin/train.py:29-40)"""
             labeled = tr.next_batch(self.batch_size)
             if self.cgan:
-                self.post_step(labeled)
-            else:
-                if self.directed or self.data_directed:
-                    unl_src, unl_dst = tr.next_source_batch(self.batch_size), tr.next_target_batch(self.batch_size)
-                else:
-                    unl_src = unl_dst = tr.next_unlabeled_batch(self.batch_size)
-                self.post_step(labeled, unl_src, unl_dst)
+                return (labeled,)
+            if self.directed or self.data_directed:
+                return labeled, tr.next_source_batch(self.batch_size), tr.next_target_batch(self.batch_size)
+            unl = tr.next_unlabeled_batch(self.batch_size)
+            return labeled, unl, unl
+        # (tried: the batches of iteration i + 1 assembled by a worker thread while this thread enqueues iteration i's ~500
+        # launches -- 15.3 -> 16.2 ms per iteration: both sides are interpreter-bound and take turns on its lock; not kept)
+        for i in t:
+            batches = fetch()
+            self.post_step(*batches)
             if save_iters and i > 0 and i % save_iters == 0 and saver is not None:
                 saver.save(self, os.path.join(checkpoint_dir, 'model'), global_step=nb_batch * e + i)
             if i % 20 == 0 or i == nb_batch - 1:

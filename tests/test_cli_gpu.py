@@ -282,6 +282,40 @@ def test_cfl_double_data_then_gan_post_epochs(tmp_path):
     assert Image.open(str(sdir / 'project_disc' / main_png)).size == (160, 16 * 2 * 2)
 
 
+def test_gan_post_epoch_loop_is_the_same_with_and_without_its_host_pipeline(tmp_path, monkeypatch):
+    """The post-epoch loop's host pipeline -- records decoded once into a table, labeled batches without their (unused)
+    images, asynchronous pinned uploads -- must not change a single draw or value: the scalars and the final weights equal
+    those of the plain loop (per-record decoding, synchronous uploads) bit for bit."""
+    import shutil
+    from cfl.bin import train
+    from cfl.synthetic import make_double_dataset
+    root = tmp_path / 'data'
+    make_double_dataset(str(root / 'dy'), image_shape=(16, 16, 3), latent_dim=64, n_items=120, n_pos=96, n_neg=96, k=2, seed=9)
+
+    def base(ck):
+        return ['--data-name', 'dy', '--data-root', str(root), '--checkpoint-root', str(ck), '--log-root', str(ck) + '_logs',
+                '--model-type', 'linear', '--data-type', 'tanh', '--data-mean', '0.5', '--data-norm', '0.5', '--data-directed',
+                '--latent-norm', '31.9098', '--data-is-image', '--data-is-double', '--raw-latent', '--latent-shape', '64',
+                '--input-shape', '16', '16', '3', '--dist-type', 'pcd', '--lambda-m', '0.5', '--use-threshold',
+                '--num-components', '2', '--latent-size', '8', '--batch-size', '16', '--lr', '0.01', '--seed', '3']
+    gan = ['--m-prj', '0.2', '--m-enc', '0.05', '--d-lr', '0.0002', '--d-beta1', '0.5', '--g-lr', '0.0002', '--g-beta1', '0.5',
+           '--gan', '--gan-type', 'srgan', '--lambda-gp', '0.5', '--z-dim', '6', '--load-pre-weights', '--epochs', '1',
+           '--post-epochs', '2', '--disable-eval']
+    train.main(base(tmp_path / 'a') + ['--epochs', '1', '--reset'])
+    shutil.copytree(str(tmp_path / 'a'), str(tmp_path / 'b'))
+    train.main(base(tmp_path / 'a') + gan)
+    for k, v in (('CFL_IMAGE_TABLE_MB', '0'), ('CFL_SYNC_UPLOAD', '1')):
+        monkeypatch.setenv(k, v)
+    train.main(base(tmp_path / 'b') + gan)
+    gname = 'cfl_pcd_linear_tanh_ls_8_nc_2_ut_norm_0.5_lm_0.5_gan_z_6_m_prj_0.2_m_enc_0.05_dra_0.5_0.5_srgan'
+    rows = [(tmp_path / (x + '_logs') / 'dy' / gname / 'gan_scalars.tsv').read_text() for x in 'ab']
+    assert rows[0] == rows[1] and len(rows[0].splitlines()) >= 3
+    nb = 96 // 16
+    va, vb = (torch.load(str(tmp_path / x / 'dy' / gname / 'model-{}.pt'.format(3 * nb)), weights_only=False)['variables']
+              for x in 'ab')
+    assert set(va) == set(vb) and all(np.array_equal(va[k], vb[k]) for k in va)
+
+
 def test_cfl_cgan_on_image_dataset(tmp_path):
     """experiments/mnist_30/run_cgan.sh in miniature: image-only dataset, linear encoder on the pixels, then the
     conditional-GAN baseline (--cgan, conv GAN type, gradient penalty), with and without --t-dim."""
