@@ -285,7 +285,7 @@ def roofline_eval(args, eng, pool, device):
             'pairs_per_s': round(B / per_call_s, 1), 'algorithmic_bytes_per_call': alg}
 
 
-def other_configs(device):
+def other_configs(device, args=None):
     """The other BASELINE.json configurations on the same kernels, measured by THIS run (so that the driver, not a
     builder-run probe, produces them): event-free step time over a pool larger than the Infinity Cache, median of 5
     repeats of 100 steps.  Weights are Xavier-uniform (RandomState(0)); inputs |N(0,1)| * 13.
@@ -397,7 +397,64 @@ def other_configs(device):
         torch.cuda.empty_cache()
     except Exception as e:
         out['config5_mrcgan_64x64_b100'] = {'error': repr(e)}
+    if 'error' not in out['config5_mrcgan_64x64_b100'] and not getattr(args, 'no_cli_loop', False):
+        try:
+            out['config5_mrcgan_64x64_b100']['cli_loop'] = gan_cli_loop()
+        except Exception as e:
+            out['config5_mrcgan_64x64_b100']['cli_loop'] = {'error': repr(e)}
     return out
+
+
+def gan_cli_loop(n_items=2000, n_pairs=3000):
+    """The MrCGAN post-epoch loop END TO END through the CLI (experiments/dyadic/run_gen.sh of the reference in synthetic form:
+    image + latent records, 64x64x3 PNGs + 1024-d latents, L = 64, K = 2, B = 100, srgan, lambda_gp 0.5): one distance epoch,
+    then two post epochs; ms per post-epoch iteration including batch assembly (record table, pinned uploads) and the
+    loop's read-backs (tools/gan_e2e_probe.py is the stand-alone form; profiles/r05_gan_e2e_loop.txt the ladder)."""
+    import contextlib
+    import shutil
+    import tempfile
+    import torch
+    from cfl.bin import train
+    from cfl.models import cfl as M
+    from cfl.synthetic import make_double_dataset
+    tmp = tempfile.mkdtemp(prefix='bench_gan_')
+    acc = {'epoch': 0.0, 'n': 0}
+    orig_epoch, orig_step = M.CFL._post_epoch, M.CFL.post_step
+
+    def post_step(self, *a, **k):
+        acc['n'] += 1
+        return orig_step(self, *a, **k)
+
+    def post_epoch(self, *a, **k):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        r = orig_epoch(self, *a, **k)
+        torch.cuda.synchronize()
+        acc['epoch'] += time.perf_counter() - t0
+        return r
+    try:
+        with contextlib.redirect_stdout(sys.stderr):       # (stdout carries the JSON line only)
+            root = os.path.join(tmp, 'data')
+            make_double_dataset(os.path.join(root, 'dy'), image_shape=(64, 64, 3), latent_dim=1024, n_items=n_items,
+                                n_pos=n_pairs, n_neg=n_pairs, k=2, seed=5)
+            base = ['--data-name', 'dy', '--data-root', root, '--checkpoint-root', os.path.join(tmp, 'ck'), '--log-root',
+                    os.path.join(tmp, 'logs'), '--model-type', 'linear', '--data-type', 'tanh', '--data-mean', '0.5',
+                    '--data-norm', '0.5', '--data-directed', '--latent-norm', '31.9098', '--data-is-image', '--data-is-double',
+                    '--raw-latent', '--latent-shape', '1024', '--input-shape', '64', '64', '3', '--dist-type', 'pcd',
+                    '--lambda-m', '0.5', '--use-threshold', '--num-components', '2', '--latent-size', '64', '--batch-size', '100',
+                    '--seed', '3']
+            train.main(base + ['--epochs', '1', '--reset'])
+            M.CFL._post_epoch, M.CFL.post_step = post_epoch, post_step
+            gan = ['--m-prj', '0.2', '--m-enc', '0.05', '--d-lr', '0.0002', '--d-beta1', '0.5', '--g-lr', '0.0002', '--g-beta1',
+                   '0.5', '--gan', '--gan-type', 'srgan', '--lambda-gp', '0.5']
+            train.main(base + gan + ['--load-pre-weights', '--epochs', '1', '--post-epochs', '2', '--disable-eval'])
+    finally:
+        M.CFL._post_epoch, M.CFL.post_step = orig_epoch, orig_step
+        shutil.rmtree(tmp, ignore_errors=True)
+    n = max(acc['n'], 1)
+    return {'ms_per_iteration': round(1e3 * acc['epoch'] / n, 3), 'iterations': acc['n'], 'images': n_items, 'pairs': 2 * n_pairs,
+            'what': 'cfl.bin.train --gan --post-epochs 2 on an image + latent dataset in the reference record format (batch '
+                    'assembly from the decoded-record table, pinned uploads, the GPU step, read-backs every 20 iterations)'}
 
 
 def cli_loop(args, device):
@@ -796,7 +853,7 @@ def main():
         if not args.no_other_configs and not args.no_kernel_profile:
             pool.clear()
             torch.cuda.empty_cache()
-            out['other_configs'] = other_configs(device)
+            out['other_configs'] = other_configs(device, args)
         if not args.no_cli_loop:
             pool.clear()
             torch.cuda.empty_cache()
