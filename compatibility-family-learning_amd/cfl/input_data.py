@@ -231,7 +231,8 @@ class DecodedRecords(object):
     the same values bit for bit, applied to the gathered rows instead of image by image.
 
     Records that are not uint8 images of one common shape make the table give up (`usable` False): the caller reads such a
-    file record by record as before.  CFL_IMAGE_TABLE_MB caps the tables (default 32768); 0 disables them."""
+    file record by record as before.  CFL_IMAGE_TABLE_MB caps the tables (default: 32768 or a quarter of the host's memory,
+    whichever is smaller); 0 disables them."""
 
     def __init__(self, path, offsets, is_double, raw_latent):
         self.path, self.is_double, self.raw_latent = path, is_double, raw_latent
@@ -246,10 +247,19 @@ class DecodedRecords(object):
 
     @staticmethod
     def cap_bytes():
+        """CFL_IMAGE_TABLE_MB, or by default the smaller of 32 GiB and a quarter of the host's physical memory"""
+        env = os.environ.get('CFL_IMAGE_TABLE_MB')
+        if env is not None:
+            try:
+                return int(float(env) * (1 << 20))
+            except ValueError:
+                pass
+        cap = 32768 << 20
         try:
-            return int(float(os.environ.get('CFL_IMAGE_TABLE_MB', '32768')) * (1 << 20))
-        except ValueError:
-            return 32768 << 20
+            cap = min(cap, os.sysconf('SC_PAGE_SIZE') * os.sysconf('SC_PHYS_PAGES') // 4)
+        except (ValueError, OSError, AttributeError):
+            pass
+        return cap
 
     def _decode(self, offsets):
         """[(uint8 pixels, latent or None)] of the records at `offsets`, or None when a record does not fit the tables"""
