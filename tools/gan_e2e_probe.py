@@ -42,6 +42,13 @@ def post_step(self, *a, **k):
 
 
 M.CFL.post_step = post_step
+if os.environ.get('E2E_SKIP_STEP'):          # host side alone: everything but the enqueue of the GAN step itself
+    from cfl.models import mrcgan
+    mrcgan.GanPhase.step = lambda self, *a, **k: self.scalars
+if os.environ.get('E2E_SKIP_INPUTS'):        # the step on constant inputs: no batch assembly / input preparation per iteration
+    _cache = {}
+    _orig_inputs = M.CFL.gan_inputs
+    M.CFL.gan_inputs = lambda self, *a, **k: _cache.setdefault('x', _orig_inputs(self, *a, **k))
 orig_epoch = M.CFL._post_epoch
 
 
