@@ -15,6 +15,12 @@ from cfl.bin import train  # noqa: E402
 from cfl.models import cfl as M  # noqa: E402
 from cfl.synthetic import make_double_dataset  # noqa: E402
 
+# (E2E_DUMMY=<n>: n streams created first -- the step time depends on how the runtime deals the step's streams to its 4 hardware
+# queues, and that on how many streams existed before them; LEDGER round 5 items 25-26)
+_dummies = [torch.cuda.Stream() for _ in range(int(os.environ.get('E2E_DUMMY', 0)))]
+for _s in _dummies:
+    with torch.cuda.stream(_s):
+        torch.zeros(1, device='cuda')
 n_items = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
 n_pairs = int(sys.argv[2]) if len(sys.argv) > 2 else 3000
 tmp = tempfile.mkdtemp(prefix='gan_e2e_')
