@@ -27,4 +27,14 @@ torch.cuda.synchronize(); t0 = time.perf_counter()
 n = 20
 for _ in range(n): ph.step(*batch)
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
-print('dummy streams %d: MrCGAN step %.2f ms' % (n_dummy, dt * 1e3))
+def sid(st):
+    return None if st is None else (st.stream_id >> 5, st.stream_id, hex(st.cuda_stream))
+
+
+names = {'gen.prep': getattr(ph.gen, '_prep_stream', None), 'disc.prep': getattr(ph.disc, '_prep_stream', None),
+         'gen.ws.side': ph.gen.ws.side_stream, 'disc.ws.side': ph.disc.ws.side_stream}
+for k, (st, ws) in enumerate(getattr(ph.disc, '_chains', [])):
+    names['chain%d' % (k + 1)] = st
+    names['chain%d.side' % (k + 1)] = ws.side_stream
+print('dummy streams %d: MrCGAN step %.2f ms   ' % (n_dummy, dt * 1e3) +
+      '  '.join('%s=%s' % (k, sid(v)[0] if v is not None else None) for k, v in names.items()))
