@@ -69,6 +69,59 @@ class GanPhase(object):
         acts, _ = self.gen.forward(G.concat_cols(z, c))
         return acts
 
+    # ---- stream placement (round 5) ---------------------------------------------------------------------------------------
+    # The HIP runtime deals every stream to one of its 4 hardware queues (least referenced queue at creation; torch hands out
+    # its 32 pooled streams in order), and streams on one queue serialise.  WHICH of the step's eight side streams share a
+    # queue -- with each other and with the critical chain's -- therefore follows from how many streams the process created
+    # before: measured 12.4 ... 14.8 ms per step for the same launches (tools/gan_streams_probe.py: period 4 in the number of
+    # earlier streams, worst when the d-loss chain lands on the critical chain's queue).  HIP has no call to place a stream,
+    # so the first step TRIES: four candidate stream sets, each one pool position further than the last, are timed on
+    # `apply=False` steps (no update: the trajectory is untouched) and the fastest set is kept.  CFL_GAN_TUNE_STREAMS=0: off.
+    tune_streams = os.environ.get('CFL_GAN_TUNE_STREAMS', '1') not in ('0', '')
+
+    def _stream_set(self):
+        from .gan_blocks import Workspace
+        if not Workspace.overlap:
+            return None
+        new = lambda: torch.cuda.Stream(device=self.device)
+        return {'gen_side': new(), 'disc_side': new(), 'chain': [new(), new()], 'chain_side': [new(), new()],
+                'prep': [new(), new()]}
+
+    def _install_streams(self, st):
+        torch.cuda.synchronize(self.device)          # nothing may be in flight on the streams that go
+        self.gen.ws.side_stream, self.disc.ws.side_stream = st['gen_side'], st['disc_side']
+        for k in (1, 2):
+            self.disc.chain(k)                        # (creates the chain workspaces on first use)
+        self.disc._chains = [(st['chain'][k], self.disc._chains[k][1]) for k in range(2)]
+        for k in range(2):
+            self.disc._chains[k][1].side_stream = st['chain_side'][k]
+        self.gen._prep_stream, self.disc._prep_stream = st['prep']
+        for net in (self.gen, self.disc):
+            net._prep_event = None
+
+    def _tune_streams(self, run, candidates=4, steps=3):
+        """run(): one non-applying step.  Returns the per-candidate step times (ms)."""
+        import time
+        times, sets, spacers = [], [], []
+        for c in range(candidates):
+            if c:
+                spacers.append(torch.cuda.Stream(device=self.device))    # one pool position further (8 streams per set: 8 = 0 mod 4)
+            st = self._stream_set()
+            if st is None:
+                return []
+            self._install_streams(st)
+            run(); run()
+            torch.cuda.synchronize(self.device)
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                run()
+            torch.cuda.synchronize(self.device)
+            times.append((time.perf_counter() - t0) / steps * 1e3)
+            sets.append(st)
+        self._install_streams(sets[int(np.argmin(times))])
+        self.stream_tuning = [round(t, 3) for t in times]
+        return times
+
     def step(self, real, enc_act, prj_c, neg_c, neg_tgt_act, z, eps, apply=True):
         """One post-epoch iteration.  All arguments are fp32 device tensors:
              real [B, prod(ae_shape)]  ae-normalised unlabeled target images
@@ -77,6 +130,9 @@ class GanPhase(object):
            Returns the scalars tensor (a view; read it after the step)."""
         B, Ld, sc = self.B, self.latent_size, self.scalars
         gen, disc = self.gen, self.disc
+        if GanPhase.tune_streams and not getattr(self, '_streams_tuned', False):
+            self._streams_tuned = True
+            self._tune_streams(lambda: self.step(real, enc_act, prj_c, neg_c, neg_tgt_act, z, eps, apply=False))
         marks = [] if self.timing is not None else None     # (diagnostic: CFL-event marks along the chains, tools/gan_chain_probe.py)
 
         def mark(name, stream=None):

@@ -36,5 +36,6 @@ names = {'gen.prep': getattr(ph.gen, '_prep_stream', None), 'disc.prep': getattr
 for k, (st, ws) in enumerate(getattr(ph.disc, '_chains', [])):
     names['chain%d' % (k + 1)] = st
     names['chain%d.side' % (k + 1)] = ws.side_stream
+print('tuning', getattr(ph, 'stream_tuning', None))
 print('dummy streams %d: MrCGAN step %.2f ms   ' % (n_dummy, dt * 1e3) +
       '  '.join('%s=%s' % (k, sid(v)[0] if v is not None else None) for k, v in names.items()))
