@@ -75,8 +75,9 @@ class GanPhase(object):
     # queue -- with each other and with the critical chain's -- therefore follows from how many streams the process created
     # before: measured 12.4 ... 14.8 ms per step for the same launches (tools/gan_streams_probe.py: period 4 in the number of
     # earlier streams, worst when the d-loss chain lands on the critical chain's queue).  HIP has no call to place a stream,
-    # so the first step TRIES: four candidate stream sets, each one pool position further than the last, are timed on
-    # `apply=False` steps (no update: the trajectory is untouched) and the fastest set is kept.  CFL_GAN_TUNE_STREAMS=0: off.
+    # so the first step TRIES: eight candidate stream sets, each one pool position further than the last, are timed on
+    # `apply=False` steps (no update: the trajectory is untouched; ~0.6 s once) and the fastest set is kept (four candidates left the
+    # step at 12.6-13.2 ms in half of the cases, eight at 12.1-12.9).  CFL_GAN_TUNE_STREAMS=0: off.
     tune_streams = os.environ.get('CFL_GAN_TUNE_STREAMS', '1') not in ('0', '')
 
     def _stream_set(self):
@@ -99,7 +100,7 @@ class GanPhase(object):
         for net in (self.gen, self.disc):
             net._prep_event = None
 
-    def _tune_streams(self, run, candidates=4, steps=3):
+    def _tune_streams(self, run, candidates=8, steps=4):
         """run(): one non-applying step.  Returns the per-candidate step times (ms)."""
         import time
         times, sets, spacers = [], [], []
