@@ -252,6 +252,40 @@ def test_post_epoch_step_matches_oracle(gan_type, shape, m_enc, m_prj, lambda_gp
             assert (diff <= 2e-4).mean() >= min(0.97, (diff32 <= 2e-4).mean() - 0.02), (k, diff.max(), (diff32 <= 2e-4).mean())
 
 
+def test_stream_placement_trial_leaves_the_trajectory_alone():
+    """GanPhase times candidate stream sets on NON-applying steps at its first step (mrcgan._tune_streams): three training steps
+    with the trial must equal three steps without it bit for bit -- scalars of every step, every variable and Adam slot -- and
+    the trial must have run (eight candidate timings recorded)."""
+    G, GB, M, GO, _ = _mods()
+    B, Ld, zd, shape = 4, 6, 5, (16, 16, 3)
+    rng = np.random.RandomState(5)
+    N = int(np.prod(shape))
+    batches = [[np.tanh(rng.randn(B, N)), 0.3 * rng.randn(B, Ld), 0.3 * rng.randn(B, Ld), 0.3 * rng.randn(B, Ld),
+                0.3 * rng.randn(B, Ld), rng.randn(B, zd), rng.rand(B, 1)] for _ in range(3)]
+    runs = []
+    before = M.GanPhase.tune_streams
+    try:
+        for tune in (False, True):
+            M.GanPhase.tune_streams = tune
+            ph = M.GanPhase('srgan', shape, 'tanh', zd, Ld, B, torch.device('cuda'), np.random.RandomState(0), lambda_gp=0.5,
+                            lambda_dra=0.5, m_enc=0.05, m_prj=0.2)
+            scal = []
+            for b in batches:
+                ph.step(*[_dev(x) for x in b])
+                scal.append(ph.scalars.detach().cpu().numpy().copy())
+            torch.cuda.synchronize()
+            runs.append((scal, ph.gen.state(), ph.disc.state(), getattr(ph, 'stream_tuning', None)))
+    finally:
+        M.GanPhase.tune_streams = before
+    (s0, g0, d0, t0), (s1, g1, d1, t1) = runs
+    assert t0 is None and t1 is not None and len(t1) == 8 and all(t > 0 for t in t1)
+    assert all(np.array_equal(a, b) for a, b in zip(s0, s1))
+    for a, b in ((g0, g1), (d0, d1)):
+        for part in ('variables', 'adam_m', 'adam_v'):
+            assert set(a[part]) == set(b[part]) and all(np.array_equal(a[part][k], b[part][k]) for k in a[part])
+        assert a['beta1_power'] == b['beta1_power']
+
+
 def test_conditional_discriminator_srgan_64():
     """SRDiscriminator with the cgan condition tiled in at stage 3 (64x64 images) and fc_t: forward, parameter
     and input gradients against the oracle."""
