@@ -315,6 +315,26 @@ class DecodedRecords(object):
             self.have[missing] = True
         return rows
 
+    def all_latents(self):
+        """(sorted byte offsets [n], latents [n, Dl]) of EVERY record of a double file -- only the latents are read, no image is
+        decoded (a seek past the image bytes) -- or None when the records' latents are ragged.  What ResidentFeatures keeps in
+        HBM for a model that trains on the latents of an image + latent dataset."""
+        if not self.is_double or self.n == 0:
+            return None
+        rows = []
+        with open(self.path, 'rb') as infile:
+            for offset in self._off_of:
+                infile.seek(int(offset) + ID_BYTES)
+                size1, size2 = struct.unpack('<ii', infile.read(8))
+                infile.seek(size1, 1)
+                if self.raw_latent:
+                    rows.append(np.frombuffer(infile.read(size2), dtype='<f4'))
+                else:
+                    rows.append(np.asarray(np.load(BytesIO(infile.read(size2)))['data'], dtype=np.float32).reshape(-1))
+        if len({r.shape[0] for r in rows}) != 1:
+            return None
+        return self._off_of, np.stack(rows).astype(np.float32, copy=False)
+
     def load(self, offsets):
         """what load_images_by_offsets / load_double_images_by_offsets return for `offsets`, or None"""
         rows = self.rows(offsets)
@@ -639,7 +659,21 @@ class ResidentFeatures(object):
         import torch
         from . import hipabi
         self._h = hipabi
-        x = dataset._file.all_features()
+        self._offsets = None       # image + latent datasets: sorted record offsets (positions are byte offsets there: _rows)
+        if dataset.is_image:
+            # An image + latent ("double") dataset whose consumer trains on the LATENTS (cfl.models.cfl: uses_latent): the
+            # latents of all records are the feature table.  The dataset's positions stay byte offsets (the reference's, and
+            # what the golden streams pin); they are translated to table rows where they cross to the device.
+            if not dataset.is_double:
+                raise ValueError('resident features of an image-only dataset: nothing to keep (the pixels are the input)')
+            if dataset._records is None:
+                dataset._records = DecodedRecords(dataset.feature_path, dataset.index_to_asins, True, dataset.raw_latent)
+            got = dataset._records.all_latents()
+            if got is None:
+                raise ValueError('ragged latents in ' + dataset.feature_path)
+            self._offsets, x = got
+        else:
+            x = dataset._file.all_features()
         D = x.shape[1]
         self.input_size = D
         self.padded_size = (D + 63) // 64 * 64
@@ -654,9 +688,16 @@ class ResidentFeatures(object):
         self._pairs = {}      # 'pos' / 'neg' -> (host array object that was uploaded, device int32 [n, 2])
         self._staging = {}    # 'pos' / 'neg' -> [pinned int32 [n, 2], event of the last upload from it]
 
+    def _rows(self, positions):
+        """table rows of dataset positions (identity for vector datasets; byte offset -> rank among the sorted offsets for
+        image + latent datasets)"""
+        if self._offsets is None:
+            return positions
+        return np.searchsorted(self._offsets, np.asarray(positions, dtype=np.int64))
+
     def gather(self, positions, out=None):
         import torch
-        idx = torch.as_tensor(np.ascontiguousarray(positions, dtype=np.int64)).to(self.device, non_blocking=True)
+        idx = torch.as_tensor(np.ascontiguousarray(self._rows(positions), dtype=np.int64)).to(self.device, non_blocking=True)
         return self._h.gather_rows(self.table, idx, out)
 
     def next_batch(self, batch_size, shard=None):
@@ -689,7 +730,10 @@ class ResidentFeatures(object):
             if st[1] is not None:
                 st[1].synchronize()
             ready = getattr(self.dataset, '_int32_of', {}).get(which)
-            host32 = ready[1] if (ready is not None and ready[0] is host) else host.astype(np.int32)
+            if self._offsets is not None:
+                host32 = self._rows(host).astype(np.int32)
+            else:
+                host32 = ready[1] if (ready is not None and ready[0] is host) else host.astype(np.int32)
             # one memcpy into the pinned buffer.  NOT tensor.copy_: torch splits a 400 k-element host copy over
             # its whole OpenMP pool, whose threads then spin at the team barrier (measured on a 256-core box: 0.8
             # CPU-seconds per call, enough to run the container into its CPU quota and stall the launch thread)
@@ -718,7 +762,7 @@ class ResidentFeatures(object):
                 # B > number of pairs: the reference oversamples with RandomState.choice (cfl/input_data.py:558-566);
                 # such a batch is not a window of the list -- upload its positions
                 import torch
-                dev = torch.from_numpy(np.ascontiguousarray(rows[lo:hi], dtype=np.int32)).to(self.device)
+                dev = torch.from_numpy(np.ascontiguousarray(self._rows(rows[lo:hi]), dtype=np.int32)).to(self.device)
                 base = dev.data_ptr()
             keep.append(dev)
             ptrs += [base + 4 * c[0], base + 4 * c[1]]
@@ -782,7 +826,7 @@ class ResidentFeatures(object):
         host = getattr(self.dataset, 'pairs_' + which)
         lo, hi = rows if rows is not None else (0, host.shape[0])
         host = host[lo:hi]
-        dev = torch.from_numpy(np.ascontiguousarray(host, dtype=np.int32)).to(self.device)
+        dev = torch.from_numpy(np.ascontiguousarray(self._rows(host), dtype=np.int32)).to(self.device)
         for i in range(0, host.shape[0], batch_size):
             n = min(batch_size, host.shape[0] - i)
             base = dev.data_ptr() + 8 * i
@@ -944,6 +988,8 @@ def feature_source(dataset, device='cuda'):
     CFL_FEATURES=resident|stream forces the choice; CFL_RESIDENT_FRACTION (default 0.6) is the share of the device's FREE
     memory a table may take (the table is uploaded once and stays)."""
     import torch
+    if dataset.is_image:
+        return ResidentFeatures(dataset, device)      # (image + latent dataset: the latents of all records; no streamed form)
     mode = os.environ.get('CFL_FEATURES', 'auto')
     if mode == 'stream':
         return StreamedFeatures(dataset, device)

@@ -487,6 +487,12 @@ class CFL(PairModel):
         if not data.train.is_image and self.trunk is None and self.train_data_transformer is None \
                 and self.val_data_transformer is None and self._explicit_norm is None:
             resident = (feature_source(data.train, self.device), feature_source(data.val, self.device))
+        elif data.train.is_image and data.train.is_double and self.uses_latent and self.trunk is None \
+                and os.environ.get('CFL_DOUBLE_RESIDENT', '1') not in ('0', ''):
+            # image + latent dataset, encoder on the latents: the latents of every record live in HBM and the distance epochs
+            # run on the indexed kernels as for a vector dataset (the same dataset object keeps driving the seeded streams, so
+            # the post epochs continue the reference's draw sequence)
+            resident = (feature_source(data.train, self.device), feature_source(data.val, self.device))
         shard = dp.shard_rows(self.batch_size) if dp.world_size() > 1 else None
         if shard is not None and resident is None:
             raise NotImplementedError('data-parallel training needs a vector dataset (resident features)')
@@ -509,6 +515,37 @@ class CFL(PairModel):
                 continue
             t.set_description('epoch {}'.format(e))
             train_avg = val_avg = 0.0
+            # Resident features + the linear encoder: a whole epoch goes through cfl.bin.train_dist.train_steps -- windows of the
+            # device pair lists through the fused multi-iteration library call, read-backs that do not stall the stream (the same
+            # iterations, 0, 50, 100, ... and the last, with the validation batch inside the step's launches where the library
+            # can) -- instead of one Python iteration per step (measured on the dyadic-generation shape: 0.47 ms of host time per
+            # 45 us step).  Same draws from the same seeded streams, same trajectory (step windows == single indexed steps bit for
+            # bit).  Not with --save-iters or when resuming inside an epoch (the cadence is counted from the epoch's first
+            # iteration); CFL_FUSED_EPOCHS=0: the per-iteration loop.
+            if (resident is not None and self.trunk is None and not save_iters and hasattr(self.engine, 'step_windows')
+                    and (start_iter % nb_batch == 0 or e != start_epoch)
+                    and os.environ.get('CFL_FUSED_EPOCHS', '1') not in ('0', '')):
+                from ..bin.train_dist import train_steps
+                bad, avgs = [], {}
+
+                def on_scalars(i, s, val_acc, e=e, t=t):
+                    if not np.isfinite(s['total']):
+                        bad.append(nb_batch * e + i)
+                    if writer is not None and chief:
+                        writer.add_scalars('scalars', nb_batch * e + i, s)
+                    avgs['train'] = self._ema_update('acc', s['accuracy'])
+                    avgs['val'] = self._ema_update('val_acc', val_acc)
+                    t.set_postfix(error=1. - avgs['train'], val_error=1. - avgs['val'],
+                                  pos_avg=self._ema_update('pos', s['dist_adapt_pos']),
+                                  neg_avg=self._ema_update('neg', s['dist_adapt_neg']))
+                train_steps(self, resident[0], resident[1], self.batch_size, shard, nb_batch, on_scalars, progress=t,
+                            scalar_every=50)
+                t.close()
+                if bad:
+                    # never checkpoint poisoned parameters: the last files written stay the latest ones
+                    raise FloatingPointError('non-finite training loss at iteration {}'.format(bad[0]))
+                train_avg, val_avg = avgs.get('train', 0.0), avgs.get('val', 0.0)
+                t = ()
             for i in t:
                 self.train_step(next_train())
                 if save_iters and i > 0 and i % save_iters == 0 and saver is not None:

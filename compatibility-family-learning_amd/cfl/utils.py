@@ -201,9 +201,15 @@ def _resident_ready(model, data):
     """The split's resident feature table when the in-place scoring path applies (vector dataset, linear encoder, no
     per-batch transformer, matching padded width), else None.  Cheap and side-effect free apart from the one-time
     upload, so that every rank of a data-parallel run can decide -- identically -- BEFORE the first collective."""
-    if getattr(data, 'is_image', True) or getattr(model, 'trunk', None) is not None or not hasattr(model, 'engine'):
+    if getattr(model, 'trunk', None) is not None or not hasattr(model, 'engine'):
         return None
-    if getattr(model, 'val_data_transformer', None) is not None or getattr(model, '_explicit_norm', None) is not None:
+    if getattr(data, 'is_image', True):
+        # image + latent dataset read through its latents: the latents of all records are the resident table
+        # (input_data.ResidentFeatures); the image transformers do not touch them (cfl.models.cfl: _prep)
+        if not (getattr(data, 'is_double', False) and getattr(model, 'uses_latent', False)) or \
+                os.environ.get('CFL_DOUBLE_RESIDENT', '1') in ('0', ''):
+            return None
+    elif getattr(model, 'val_data_transformer', None) is not None or getattr(model, '_explicit_norm', None) is not None:
         return None
     try:
         import torch

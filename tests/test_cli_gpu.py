@@ -87,6 +87,35 @@ def test_cfl_train_predict_linear(dataset, tmp_path):
         assert (pdir / f).exists()
 
 
+@pytest.mark.parametrize('extra', [
+    ['--dist-type', 'monomer', '--lambda-m', '0.5', '--data-switch'],
+    ['--dist-type', 'siamese', '--caffe-margin', '5.0'],
+    ['--dist-type', 'pcd'],
+])
+def test_cfl_epochs_through_the_fused_loop_equal_the_per_iteration_loop(dataset, tmp_path, monkeypatch, extra):
+    """cfl.bin.train's distance epochs on resident features go through cfl.bin.train_dist.train_steps (windows of the device pair
+    lists, non-stalling read-backs); CFL_FUSED_EPOCHS=0 is the one-Python-iteration-per-step loop.  Same seeded streams, same
+    trajectory: every variable and Adam slot after two epochs, and the best-model bookkeeping, must be equal."""
+    from cfl.bin import train
+    runs = []
+    for tag, env in (('f', '1'), ('p', '0')):
+        monkeypatch.setenv('CFL_FUSED_EPOCHS', env)
+        flags = ['--data-name', 'syn/toy', '--data-root', str(dataset), '--checkpoint-root', str(tmp_path / tag), '--log-root',
+                 str(tmp_path / (tag + '_logs')), '--batch-size', '20', '--model-type', 'linear', '--data-type', 'linear',
+                 '--data-norm', '16.0', '--input-shape', '200', '--pos-weight', '0.5', '--use-threshold', '--num-components', '3',
+                 '--latent-size', '8', '--lr', '0.01', '--seed', '1'] + extra
+        train.main(flags + ['--epochs', '2', '--reset'])
+        cks = sorted((tmp_path / tag).rglob('model-300.pt'))      # 3000 pairs / 20 = 150 iterations per epoch
+        assert len(cks) == 1
+        runs.append((torch.load(str(cks[0]), weights_only=False), (cks[0].parent / 'best_model' / 'best_accuracy').read_text()))
+    (a, ba), (b, bb) = runs
+    for part in ('variables', 'adam_m', 'adam_v'):
+        assert set(a[part]) == set(b[part])
+        for k in a[part]:
+            assert np.array_equal(a[part][k], b[part][k]), (part, k, float(np.abs(a[part][k] - b[part][k]).max()))
+    assert ba == bb
+
+
 def test_bad_flag_combinations_fail_loudly(dataset, tmp_path):
     from cfl.bin import train
     with pytest.raises(AssertionError):      # cfl/utils.py:70-71: the CD loss is for siamese only
@@ -314,6 +343,44 @@ def test_gan_post_epoch_loop_is_the_same_with_and_without_its_host_pipeline(tmp_
     va, vb = (torch.load(str(tmp_path / x / 'dy' / gname / 'model-{}.pt'.format(3 * nb)), weights_only=False)['variables']
               for x in 'ab')
     assert set(va) == set(vb) and all(np.array_equal(va[k], vb[k]) for k in va)
+
+
+def test_distance_epochs_on_resident_latents_equal_the_host_batches(tmp_path, monkeypatch):
+    """Image + latent dataset, encoder on the latents: by default the latents of all records live in HBM and the distance epochs
+    take the indexed kernels (ResidentFeatures over DecodedRecords.all_latents, byte offsets translated to table rows);
+    CFL_DOUBLE_RESIDENT=0 assembles host batches as the reference does.  Same seeded streams, same arithmetic: the checkpoints,
+    the best-model bookkeeping and -- the dataset object keeps its stream state across the phases -- the scalars of a
+    following MrCGAN post epoch must be equal."""
+    from cfl.bin import train
+    from cfl.synthetic import make_double_dataset
+    root = tmp_path / 'data'
+    make_double_dataset(str(root / 'dy'), image_shape=(16, 16, 3), latent_dim=64, n_items=120, n_pos=112, n_neg=96, k=2, seed=9)
+
+    def base(ck):
+        return ['--data-name', 'dy', '--data-root', str(root), '--checkpoint-root', str(ck), '--log-root', str(ck) + '_logs',
+                '--model-type', 'linear', '--data-type', 'tanh', '--data-mean', '0.5', '--data-norm', '0.5', '--data-directed',
+                '--latent-norm', '31.9098', '--data-is-image', '--data-is-double', '--raw-latent', '--latent-shape', '64',
+                '--input-shape', '16', '16', '3', '--dist-type', 'pcd', '--lambda-m', '0.5', '--use-threshold',
+                '--num-components', '2', '--latent-size', '8', '--batch-size', '16', '--lr', '0.01', '--seed', '3']
+    gan = ['--m-prj', '0.2', '--m-enc', '0.05', '--d-lr', '0.0002', '--d-beta1', '0.5', '--g-lr', '0.0002', '--g-beta1', '0.5',
+           '--gan', '--gan-type', 'srgan', '--lambda-gp', '0.5', '--z-dim', '6', '--load-pre-weights', '--epochs', '3',
+           '--post-epochs', '1', '--disable-eval']
+    for tag, env in (('a', '1'), ('b', '0')):
+        monkeypatch.setenv('CFL_DOUBLE_RESIDENT', env)
+        train.main(base(tmp_path / tag) + ['--epochs', '3', '--reset'])
+        train.main(base(tmp_path / tag) + gan)
+    name = 'cfl_pcd_linear_tanh_ls_8_nc_2_ut_norm_0.5_lm_0.5'
+    nb = 112 // 16
+    va, vb = (torch.load(str(tmp_path / x / 'dy' / name / 'model-{}.pt'.format(3 * nb)), weights_only=False) for x in 'ab')
+    for part in ('variables', 'adam_m', 'adam_v'):
+        assert set(va[part]) == set(vb[part])
+        for k in va[part]:
+            assert np.array_equal(va[part][k], vb[part][k]), (part, k, np.abs(va[part][k] - vb[part][k]).max())
+    best = [(tmp_path / x / 'dy' / name / 'best_model' / 'best_accuracy').read_text() for x in 'ab']
+    assert best[0] == best[1]
+    gname = name + '_gan_z_6_m_prj_0.2_m_enc_0.05_dra_0.5_0.5_srgan'
+    rows = [(tmp_path / (x + '_logs') / 'dy' / gname / 'gan_scalars.tsv').read_text() for x in 'ab']
+    assert rows[0] == rows[1] and len(rows[0].splitlines()) >= 2
 
 
 def test_cfl_cgan_on_image_dataset(tmp_path):
