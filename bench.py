@@ -397,12 +397,65 @@ def other_configs(device, args=None):
         torch.cuda.empty_cache()
     except Exception as e:
         out['config5_mrcgan_64x64_b100'] = {'error': repr(e)}
+    if 'error' not in out.get('config4_polyvore_pcd_k5', {'error': 1}) and not getattr(args, 'no_cli_loop', False):
+        try:
+            cl = cfl_cli_loop()
+            cl['vs_step'] = round(out['config4_polyvore_pcd_k5']['us_per_step'] / cl['us_per_iteration'], 4)
+            out['config4_polyvore_pcd_k5']['cli_loop'] = cl
+        except Exception as e:
+            out['config4_polyvore_pcd_k5']['cli_loop'] = {'error': repr(e)}
     if 'error' not in out['config5_mrcgan_64x64_b100'] and not getattr(args, 'no_cli_loop', False):
         try:
             out['config5_mrcgan_64x64_b100']['cli_loop'] = gan_cli_loop()
         except Exception as e:
             out['config5_mrcgan_64x64_b100']['cli_loop'] = {'error': repr(e)}
     return out
+
+
+def cfl_cli_loop(n_items=8192, n_pairs=204800):
+    """The distance epochs of `cfl.bin.train` -- the CFL model class of configs 3 / 4 and of every dyadic experiment of the reference
+    -- END TO END at the config-4 shape (2048-d vectors, pcd K = 5, L = 20, weight-norm heads, pos_weight 0.25, B = 1024) on a
+    synthetic vector dataset in the reference's format: three epochs through the CLI, us per training iteration of the LAST two
+    (the epoch loop itself: seeded index streams, windows of the device pair lists, the fused multi-iteration library call,
+    read-backs every 50 iterations; per-epoch checkpoints are outside the timed part).  tools/double_epoch_probe.py is the
+    image + latent form (profiles/r05_cfl_epoch_loop.txt)."""
+    import contextlib
+    import shutil
+    import tempfile
+    import torch
+    from cfl.bin import train, train_dist
+    from cfl.synthetic import make_dataset
+    tmp = tempfile.mkdtemp(prefix='bench_cfl_')
+    calls = []
+    orig = train_dist.train_steps
+
+    def timed(model, train_src, val_src, batch_size, shard, n_steps, *a, **k):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        r = orig(model, train_src, val_src, batch_size, shard, n_steps, *a, **k)
+        torch.cuda.synchronize()
+        calls.append((n_steps, time.perf_counter() - t0))
+        return r
+    try:
+        train_dist.train_steps = timed
+        with contextlib.redirect_stdout(sys.stderr):
+            root = os.path.join(tmp, 'data')
+            make_dataset(os.path.join(root, 'poly'), D=2048, n_items=n_items, n_pos=n_pairs, n_neg=n_pairs, k=5, latent=20, seed=7)
+            train.main(['--data-name', 'poly', '--data-root', root, '--checkpoint-root', os.path.join(tmp, 'ck'), '--log-root',
+                        os.path.join(tmp, 'logs'), '--model-type', 'linear', '--data-type', 'linear', '--data-norm', '58.388599',
+                        '--input-shape', '2048', '--dist-type', 'pcd', '--use-threshold', '--pos-weight', '0.25',
+                        '--num-components', '5', '--latent-size', '20', '--batch-size', '1024', '--seed', '3', '--disable-eval',
+                        '--reset', '--epochs', '3'])
+    finally:
+        train_dist.train_steps = orig
+        shutil.rmtree(tmp, ignore_errors=True)
+    if len(calls) < 2:
+        raise RuntimeError('cfl.bin.train did not take the fused epoch loop (%d calls)' % len(calls))
+    n = sum(c[0] for c in calls[1:])
+    return {'us_per_iteration': round(1e6 * sum(c[1] for c in calls[1:]) / n, 3), 'iterations': n,
+            'first_epoch_us_per_iteration': round(1e6 * calls[0][1] / calls[0][0], 3),
+            'what': 'cfl.bin.train (CFL model class) distance epochs through the fused multi-iteration loop on resident features: '
+                    'epochs 2 and 3 of a 3-epoch run, the epoch loop alone (checkpoints excluded)'}
 
 
 def gan_cli_loop(n_items=2000, n_pairs=3000):
