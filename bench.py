@@ -75,33 +75,62 @@ def parse():
     ap.add_argument('--no-dp-form', action='store_true', help='skip the one-rank RCCL leg (dp_form)')
     ap.add_argument('--cli-items', type=int, default=40000, help='items of the synthetic features.b of the cli_loop leg')
     ap.add_argument('--cli-pairs', type=int, default=200000)
+    ap.add_argument('--restore-steps', type=int, default=30, help='the timed repeats start from the training state after this '
+                    'many steps (restored before every repeat): the timed model is a model IN training, not a converged one')
+    ap.add_argument('--dp-leg', default='', help='(internal) N > 1: run only the named data-parallel leg and print its JSON '
+                    '(`oneshot`: the one-shot exchange at B = 512 and 2048 per GPU; started by rank 0 of the main job as a '
+                    'child job so that a failure of that path cannot take the headline line down)')
+    ap.add_argument('--no-dp-legs', action='store_true', help='N > 1: skip the extra data-parallel legs (dp_scaling)')
     return ap.parse_args()
 
 
 # ---------------------------------------------------------------------------------------------------------
 # N > 1 without a launcher: the parent starts the ranks and never initialises the GPU itself
 # ---------------------------------------------------------------------------------------------------------
-def launch_ranks(args):
+def spawn_ranks(gpus, argv, key='"metric"', timeout=None, extra_env=None):
+    """start `gpus` ranks of this script under torch.distributed.run (a fresh rendezvous port); returns (return code, the
+    JSON line containing `key` or None).  The child's other output goes to stderr.  On a timeout the whole process group of
+    the launcher is killed."""
+    import signal
     with socket.socket() as s:
         s.bind(('127.0.0.1', 0))
         port = s.getsockname()[1]
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
-           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + list(argv)
     env = dict(os.environ, MASTER_ADDR='127.0.0.1')
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_PORT', 'GROUP_RANK', 'LOCAL_WORLD_SIZE', 'ROLE_RANK', 'ROLE_WORLD_SIZE',
+              'TORCHELASTIC_RUN_ID', 'TORCHELASTIC_RESTART_COUNT', 'TORCHELASTIC_MAX_RESTARTS', 'TORCHELASTIC_USE_AGENT_STORE'):
+        env.pop(k, None)                                  # (a child job started BY a rank must not inherit that rank's identity)
     env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')     # dmabuf IPC: RCCL / cross-process tensor sharing needs it here
-    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    env.update(extra_env or {})
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, start_new_session=True)
+    try:
+        out, _ = proc.communicate(timeout=timeout)
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(proc.pid, signal.SIGKILL)          # exactly the process group this call started
+        except OSError:
+            pass
+        out, _ = proc.communicate()
+        print('bench.py: child job timed out after %s s' % timeout, file=sys.stderr)
+        return 124, None
     line = None
-    for ln in proc.stdout.splitlines():
-        if ln.startswith('{') and '"metric"' in ln:
+    for ln in out.splitlines():
+        if ln.startswith('{') and key in ln:
             line = ln
         else:
             print(ln, file=sys.stderr)
+    return proc.returncode, line
+
+
+def launch_ranks(args):
+    rc, line = spawn_ranks(args.gpus, sys.argv[1:])
     if line is not None:
         print(line, flush=True)
-    elif proc.returncode == 0:
+    elif rc == 0:
         print('bench.py: the ranks printed no result line', file=sys.stderr)
         return 1
-    return proc.returncode
+    return rc
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -178,6 +207,39 @@ def cpu_baseline(args, seconds):
             'sample': '%d steps of batch %d (%.1f s) of the same 4096-d K=%d L=%d step, '
                       'NumPy fp32 oracle (fwd+bwd+TF-Adam)' % (
                           n, B, el, args.num_components, args.latent_size)}
+
+
+def cpu_loader_baseline(args, seconds=3.0, n_items=6000):
+    """The reference's batch assembly timed beside the step (optional leg): next_labeled_batch reads every one
+    of its 4 * B vectors with a seek + fromfile on features.b (cfl/input_data.py:212-228 through :542-589 of the reference),
+    restated in oracle/loader_oracle.py.  Rows/s of that loader alone on a synthetic features.b (page cache warm: the best
+    case for it) -- the reference's real bottleneck at the throughput the GPU step reaches."""
+    import shutil
+    import tempfile
+    import numpy as np
+    from oracle import loader_oracle as LO
+    B, D = args.batch_size, args.input_size
+    tmp = tempfile.mkdtemp(prefix='bench_loader_')
+    try:
+        path = os.path.join(tmp, 'features.b')
+        rng = np.random.RandomState(0)
+        LO.write_features(path, rng, n_items, D)
+        pos = rng.randint(0, n_items, size=(64 * B, 2))
+        neg = rng.randint(0, n_items, size=(64 * B, 2))
+        LO.labeled_batch_by_seek(path, pos[:B], neg[:B], D)
+        n, t0 = 0, time.perf_counter()
+        while True:
+            k = n % 64
+            LO.labeled_batch_by_seek(path, pos[k * B:(k + 1) * B], neg[k * B:(k + 1) * B], D)
+            n += 1
+            el = time.perf_counter() - t0
+            if el >= seconds and n >= 2:
+                break
+        return {'value': round(n * B / el, 1), 'unit': 'triplets/s', 'cores': 1, 'kind': 'port',
+                'sample': '%d batches of %d rows (%.1f s): 4 x %d seek + read calls of %d bytes each per batch on a %d-item '
+                          'features.b (page cache warm), oracle/loader_oracle.py' % (n, B, el, B, 4 * D, n_items)}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def eval_auc(args, eng, device, teacher):
@@ -512,10 +574,15 @@ def gan_cli_loop(n_items=2000, n_pairs=3000):
                     'assembly from the decoded-record table, pinned uploads, the GPU step, read-backs every 20 iterations)'}
 
 
-def cli_loop(args, device):
+def cli_loop(args, device, B=None, K=None, L=None):
     """steps/s of the inner loop of `python -m cfl.bin.train_dist` (cfl.bin.train_dist.train_steps: the dataset's
     seeded index stream -> positions into the HBM-resident features.b -> one fused step, scalars every 25
-    iterations) on a synthetic dataset in the reference's on-disk format written for this run."""
+    iterations) on a synthetic dataset in the reference's on-disk format written for this run.  B / K / L override the
+    headline's batch size / prototypes / latent size (the reference's own scripts: B = 100, K = 4, L = 10)."""
+    import copy
+    args = copy.copy(args)
+    if B is not None:
+        args.batch_size, args.num_components, args.latent_size = B, K, L
     import shutil
     import tempfile
     import torch
@@ -577,6 +644,102 @@ def cli_loop(args, device):
         shutil.rmtree(root, ignore_errors=True)
 
 
+def make_engine(args, device, B):
+    from cfl import hipabi as H
+    from cfl.engine import PairEngine
+    D, K, L = args.input_size, args.num_components, args.latent_size
+    return PairEngine(D, L, K, 'pcd', weight_norm=False, has_bias=True, norm=H.make_norm(1.0 / NORMALIZE_VALUE),
+                      loss=H.make_loss(), lr=1e-3, device=device, params=init_params(D, L, K), batch_size=B)
+
+
+def make_pool(args, device, B, rank, teacher, pool_mib=None):
+    """this rank's row block of every global batch of a pool larger than the Infinity Cache"""
+    batch_bytes = 4 * B * args.input_size * 4
+    nb = max(2, ((pool_mib or args.pool_mib) * (1 << 20) + batch_bytes - 1) // batch_bytes)
+    return [make_block(B, args.input_size, device, block_seed(j, rank), teacher) for j in range(nb)]
+
+
+def snapshot(eng):
+    """the training state of an engine (parameters, Adam slots, kept planes, Adam powers): what `restore` puts back before
+    every timed repeat, so that the timed steps are those of a model IN training (197 k steps on a 12-batch
+    pool had driven the loss to 0.0 -- saturated dL/dY is not the state any user trains in)"""
+    return dict(theta=eng.theta.clone(), m=eng.m.clone(), v=eng.v.clone(), planes=eng.planes.buf.clone(),
+                valid=int(eng.planes.c.valid), b1=eng.beta1_power, b2=eng.beta2_power, gs=eng.global_step)
+
+
+def restore(eng, snap):
+    eng.theta.copy_(snap['theta']); eng.m.copy_(snap['m']); eng.v.copy_(snap['v'])
+    eng.planes.buf.copy_(snap['planes'])
+    eng.planes.c.valid = snap['valid']
+    eng.beta1_power, eng.beta2_power, eng.global_step = snap['b1'], snap['b2'], snap['gs']
+
+
+def dp_leg(args, device, rank, world, B, exchange, teacher, seconds=None, pool_mib=None):
+    """One data-parallel configuration, every rank: `exchange` = allreduce (RCCL's ncclAllReduce called by the library on the
+    launch stream) | oneshot (reduce-scatter fused into the weight-gradient launch, sharded Adam, all-gather) | none (the
+    same launches and the stand-alone Adam, NO collective: what a rank's step costs before a byte crosses a link).  Median of
+    >= 10 repeats of args.steps steps, each bracketed by barrier + synchronize, MAX over ranks; restored to the early-training
+    state before every repeat."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    seconds = float(os.environ.get('CFL_BENCH_LEG_SECONDS', '2.0')) if seconds is None else seconds
+    os.environ['CFL_DP_EXCHANGE'] = 'oneshot' if exchange == 'oneshot' else 'allreduce'
+    os.environ['CFL_DP_NO_COLLECTIVE'] = '1' if exchange == 'none' else '0'
+    try:
+        eng = make_engine(args, device, B)
+        pool = make_pool(args, device, B, rank, teacher, pool_mib)
+        nb = len(pool)
+
+        def sync_all():
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+                torch.cuda.synchronize()
+        for i in range(args.restore_steps):
+            eng.step(pool[i % nb])
+        snap = snapshot(eng)
+        for i in range(max(nb, 20)):
+            eng.step(pool[i % nb])
+        sync_all()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            eng.step(pool[i % nb])
+        sync_all()
+        est = max(time.perf_counter() - t0, 1e-6)
+        rt = torch.tensor([int(min(2000, max(10, np.ceil(seconds / est))))], device=device, dtype=torch.int64)
+        if world > 1:
+            dist.broadcast(rt, 0)
+        times, pos = [], 0
+        for _ in range(int(rt.item())):
+            restore(eng, snap)
+            sync_all()
+            t0 = time.perf_counter()
+            for i in range(args.steps):
+                eng.step(pool[(pos + i) % nb])
+            sync_all()
+            times.append(time.perf_counter() - t0)
+            pos += args.steps
+        tt = torch.tensor(times, device=device, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        el = float(np.median(tt.cpu().numpy()))
+        sc = eng.read_scalars()
+        lost = int(eng._oneshot.lost.item()) if eng._oneshot is not None else 0
+        native = eng.dp_native()
+        res = {'us_per_step': round(1e6 * el / args.steps, 3), 'triplets_per_s': round(args.steps * B * world / el, 1),
+               'rows_per_gpu': B, 'repeats': len(times), 'final_loss': round(sc['total'], 6),
+               'driven_by': 'library (one call per step)' if native is not None else 'python (torch.distributed.all_reduce)'}
+        if exchange == 'oneshot':
+            res['lost_handoffs'] = lost
+        del pool, eng
+        torch.cuda.empty_cache()
+        return res
+    finally:
+        os.environ['CFL_DP_EXCHANGE'] = 'allreduce'
+        os.environ['CFL_DP_NO_COLLECTIVE'] = '0'
+
+
 def dp_form(args, eng, pool, device, fused_us):
     """The DATA-PARALLEL form of the step on this one GPU, through a ONE-RANK RCCL process group (CFL_FORCE_DP=1): the
     same three launches as the fused step (projection on the bf16 matrix cores from the kept planes, row math, weight
@@ -626,6 +789,7 @@ def dp_form(args, eng, pool, device, fused_us):
         # without the collective: the same launches, no RCCL kernel between them
         eng_reduce = None
         eng_reduce, E.reduce_gradients = E.reduce_gradients, (lambda buf: 1.0)
+        os.environ['CFL_DP_NO_COLLECTIVE'] = '1'      # (the library-driven step: same launches, no ncclAllReduce between them)
         try:
             for i in range(20):
                 eng.step(pool[i % nb])
@@ -637,20 +801,56 @@ def dp_form(args, eng, pool, device, fused_us):
             t_nocoll = (time.perf_counter() - t0) / (5 * args.steps)
         finally:
             E.reduce_gradients = eng_reduce
+            os.environ['CFL_DP_NO_COLLECTIVE'] = '0'
         H.profile_enable(True)
         for i in range(50):
             eng.step(pool[i % nb])
         torch.cuda.synchronize()
         H.profile_enable(False)
         prof = H.profile_read()
+        # the ONE-SHOT exchange on the same one-rank group (round 6: the reduce-scatter rides in the weight-gradient launch; the
+        # step is proj, mid, grad(+push), cfl_dp_rs_adam, cfl_dp_rs_gather_planes = five launches, no collective library)
+        oneshot = None
+        try:
+            os.environ['CFL_DP_EXCHANGE'] = 'oneshot'
+            eng1 = make_engine(args, device, args.batch_size)
+            for i in range(50):
+                eng1.step(pool[i % nb])
+            torch.cuda.synchronize()
+            t1 = []
+            for r in range(10):
+                t0 = time.perf_counter()
+                for i in range(args.steps):
+                    eng1.step(pool[(r * args.steps + i) % nb])
+                torch.cuda.synchronize()
+                t1.append((time.perf_counter() - t0) / args.steps)
+            H.profile_enable(True)
+            for i in range(50):
+                eng1.step(pool[i % nb])
+            torch.cuda.synchronize()
+            H.profile_enable(False)
+            p1 = H.profile_read()
+            oneshot = {'us_per_step': round(float(np.median(t1)) * 1e6, 3),
+                       'launches_per_step': int(sum(c for _, c in p1.values()) // 50),
+                       'library_launches': {k: int(c) // 50 for k, (ms, c) in p1.items()},
+                       'lost_handoffs': int(eng1._oneshot.lost.item()),
+                       'what': 'CFL_DP_EXCHANGE=oneshot: proj_bx3 -> mid -> grad (finished entries pushed into the owner\'s slots, '
+                               'arrival flags raised by its last workgroup) -> cfl_dp_rs_adam -> cfl_dp_rs_gather_planes'}
+            del eng1
+        except Exception as e:          # noqa: BLE001
+            oneshot = {'error': repr(e)}
+        finally:
+            os.environ['CFL_DP_EXCHANGE'] = 'allreduce'
         return {'us_per_step': round(t * 1e6, 3), 'us_per_step_without_collective': round(t_nocoll * 1e6, 3),
                 'us_per_step_torch_all_reduce': round(t_torch * 1e6, 3),
                 'fused_us_per_step': round(fused_us, 3), 'vs_fused': round(fused_us / (t * 1e6), 4),
                 'library_launches_per_step': sorted(prof), 'backend': dist.get_backend(), 'world': dist.get_world_size(),
-                'exchange': os.environ.get('CFL_DP_EXCHANGE', 'allreduce'),
-                'what': 'PairEngine.step through its data-parallel branch on a one-rank RCCL group: proj_bx3 -> mid -> grad '
-                        '-> ncclAllReduce([gradient | scalars], %d floats, on the launch stream: cfl/rccl.py) -> '
-                        'cfl_adam_tf_planes' % eng.gradbuf.numel()}
+                'launches_per_step': int(sum(c for _, c in prof.values()) // 50) + 1,
+                'exchange': 'allreduce', 'oneshot': oneshot,
+                'driven_by': 'library: one cfl_pair_dp_step_planes call per step (ABI 6)' if eng.dp_native() is not None else 'python',
+                'what': 'PairEngine.step through its data-parallel branch on a one-rank RCCL group: ONE library call = proj_bx3 -> mid '
+                        '-> grad -> ncclAllReduce([gradient | scalars], %d floats, called by the library on the launch stream: '
+                        'cfl/rccl.py hands over the entry point) -> cfl_adam_tf_planes' % eng.gradbuf.numel()}
     finally:
         os.environ['CFL_FORCE_DP'] = '0'
         if own_group and dist.is_initialized():
@@ -702,18 +902,32 @@ def main():
 
     _trace('process group ready (backend %s, device %s)' % (backend if world > 1 else '-', device))
     from cfl import hipabi as H
-    from cfl.engine import PairEngine
 
     B, D, K, L = args.batch_size, args.input_size, args.num_components, args.latent_size
-    eng = PairEngine(D, L, K, 'pcd', weight_norm=False, has_bias=True,
-                     norm=H.make_norm(1.0 / NORMALIZE_VALUE), loss=H.make_loss(),
-                     lr=1e-3, device=device, params=init_params(D, L, K), batch_size=B)
-
-    batch_bytes = 4 * B * D * 4
-    nb = max(2, (args.pool_mib * (1 << 20) + batch_bytes - 1) // batch_bytes)
     teacher = teacher_of(D, device)
+    if args.dp_leg:
+        # child job of the main N-rank run (started by its rank 0): ONE risky leg, its own JSON line, nothing else
+        res = {'dp_leg': args.dp_leg}
+        if args.dp_leg == 'oneshot':
+            for b in (B, 2048):
+                try:
+                    res['b%d' % b] = dp_leg(args, device, rank, world, b, 'oneshot', teacher)
+                except Exception as e:          # noqa: BLE001
+                    res['b%d' % b] = {'error': repr(e)}
+        if rank == 0:
+            sys.stdout.flush()
+            os.write(real_stdout, (json.dumps(res) + '\n').encode())
+        if world > 1:
+            dist.barrier()
+            from cfl import rccl
+            rccl.shutdown()
+            dist.destroy_process_group()
+        return 0
+    eng = make_engine(args, device, B)
+    batch_bytes = 4 * B * D * 4
     # this rank's row block of every global batch of the pool
-    pool = [make_block(B, D, device, block_seed(j, rank), teacher) for j in range(nb)]
+    pool = make_pool(args, device, B, rank, teacher)
+    nb = len(pool)
 
     def run(nsteps, start):
         for i in range(nsteps):
@@ -726,8 +940,12 @@ def main():
             torch.cuda.synchronize()
 
     _trace('pool ready (%d batches)' % nb)
+    # the state every timed repeat starts from: `--restore-steps` steps into training (restored OUTSIDE the timed bracket)
+    run(args.restore_steps, 0)
+    snap = snapshot(eng)
+    loss_at_restore = eng.read_scalars()['total']
     warm = max(args.warmup, nb)          # every pool batch is touched before anything is timed
-    run(warm, 0)
+    run(warm, args.restore_steps)
     sync_all()
     _trace('warm-up done')
     # short calibration (untimed for the result): how many repeats make --timed-seconds (6 s) of timed work -- longer than the
@@ -744,6 +962,7 @@ def main():
     times = []
     pos = warm + args.steps
     for _ in range(repeats):
+        restore(eng, snap)               # (not timed: before the bracket's first barrier + synchronize)
         sync_all()
         t0 = time.perf_counter()
         run(args.steps, pos)
@@ -788,6 +1007,10 @@ def main():
                 'pool_mib_per_gpu': int(nb * batch_bytes >> 20),
                 'parallelism': 'dp%d' % world if world > 1 else 'single',
                 'final_loss': round(scal['total'], 6),
+                'loss_at_restore': round(loss_at_restore, 6),
+                'training_state': 'every timed repeat starts from the state %d steps into training (restored before the '
+                                  'bracket) and runs steps %d .. %d of that trajectory: final_loss is the loss of a model in '
+                                  'training' % (args.restore_steps, args.restore_steps, args.restore_steps + args.steps),
                 'timing': 'median of %d repeats of the %d-step region, each bracketed by barrier + synchronize and '
                           'reduced with MAX over ranks' % (repeats, args.steps),
                 'arithmetic': 'fp32 storage and accumulation everywhere; both contractions (projection of the fused '
@@ -878,6 +1101,12 @@ def main():
             'mfma_f32': {'achieved_tflops': round(alg_flops / raw_s / 1e12, 2),
                          'peak_tflops': FP32_MFMA_PEAK_TF,
                          'frac': round(alg_flops / raw_s / 1e12 / FP32_MFMA_PEAK_TF, 4)},
+            # the compute roof of the arithmetic the kernels actually ISSUE: every fp32 product is six bf16 partial products on
+            # v_mfma_f32_16x16x32_bf16, so the fp32-equivalent ceiling is the dense bf16 peak / 6 (2.5 PF / 6 = 416.7 TF)
+            'bf16x3': {'achieved_tflops': round(alg_flops / raw_s / 1e12, 2), 'peak_tflops': round(BF16X3_PEAK_TF, 1),
+                       'frac': round(alg_flops / raw_s / 1e12 / BF16X3_PEAK_TF, 4),
+                       'step_achieved_tflops': round(2.0 * alg_flops / (elapsed / args.steps) / 1e12, 2),
+                       'step_frac': round(2.0 * alg_flops / (elapsed / args.steps) / 1e12 / BF16X3_PEAK_TF, 4)},
             'step': {'hbm_frac': round(alg_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
                      'launches_per_step': len(step_kernels),
                      # x is read twice by design (projection, weight gradient): HBM traffic of a step vs its
@@ -898,6 +1127,10 @@ def main():
         if not args.no_cpu_baseline:
             out['eval_auc'] = eval_auc(args, eng, device, teacher)
             out['cpu_baseline'] = cpu_baseline(args, args.cpu_seconds)
+            try:
+                out['cpu_baseline']['loader'] = cpu_loader_baseline(args)
+            except Exception as e:          # noqa: BLE001
+                out['cpu_baseline']['loader'] = {'error': repr(e)}
         else:
             out['cpu_baseline'] = None
         if not args.no_dp_form:
@@ -916,8 +1149,66 @@ def main():
             cl['vs_value'] = round(cl['triplets_per_s'] / out['value'], 4)
             cl['vs_value_every1'] = round(cl['every1']['triplets_per_s'] / out['value'], 4)
             out['cli_loop'] = cl
+            # ... and at the shape every script of the reference runs (experiments/monomer/run.sh:3-53: --num-components 4
+            # --latent-size 10, batch 100), in the reference's own cadence: one validation fetch per iteration
+            try:
+                cr = cli_loop(args, device, B=100, K=4, L=10)
+                out['cli_loop_reference_shape_b100'] = {
+                    'us_per_step': cr['us_per_step'], 'triplets_per_s': cr['triplets_per_s'], 'every1': cr['every1'],
+                    'final_loss': cr['final_loss'], 'what': 'the same loop at B = 100, K = 4, L = 10 (experiments/monomer/run.sh of the '
+                    'reference); `every1` = --scalar-every 1, the reference\'s loop (cfl/bin/train_dist.py:79-86)'}
+            except Exception as e:          # noqa: BLE001
+                out['cli_loop_reference_shape_b100'] = {'error': repr(e)}
     elif rank == 0:
         out['cpu_baseline'] = None
+    if world > 1 and not args.no_dp_legs:
+        # ---- N > 1: the attribution of the scaling number, in the same line ------------------------------
+        # every rank runs the in-process legs (they contain collectives); the one-shot exchange -- peer memory mapped through
+        # hipIpc, kernels that poll flags other GPUs raise: never run on more than one GPU before -- goes into a CHILD job that
+        # rank 0 starts on the same GPUs while the ranks of this job wait on a CPU-side (gloo) barrier: if that path hangs or
+        # takes a process down, the child is killed and the line above survives with an `error` entry.
+        legs = {}
+        headline_us = 1e6 * elapsed / args.steps
+        try:
+            ctl = dist.new_group(backend='gloo')
+        except Exception:          # noqa: BLE001
+            ctl = None
+        pool.clear()
+        del eng
+        torch.cuda.empty_cache()
+        for name, b, exch in (('b%d_without_collective' % B, B, 'none'), ('b2048_allreduce', 2048, 'allreduce'),
+                              ('b2048_without_collective', 2048, 'none')):
+            try:
+                legs[name] = dp_leg(args, device, rank, world, b, exch, teacher)
+            except Exception as e:          # noqa: BLE001 (a side measurement must not take the headline line down)
+                legs[name] = {'error': repr(e)}
+        torch.cuda.synchronize()
+        if ctl is not None:
+            child = None
+            if rank == 0:
+                rc, line = spawn_ranks(world, ['--gpus', str(world), '--dp-leg', 'oneshot', '--steps', str(args.steps), '--warmup',
+                                               '10', '--pool-mib', str(args.pool_mib), '--restore-steps', str(args.restore_steps)],
+                                       key='"dp_leg"', timeout=600, extra_env={'CFL_DP_TIMEOUT_S': '20'})
+                try:
+                    child = json.loads(line) if line else {'error': 'the one-shot child job printed no line (rc %d)' % rc}
+                except ValueError:
+                    child = {'error': 'unparsable line from the one-shot child job (rc %d)' % rc}
+            import datetime
+            try:
+                dist.monitored_barrier(group=ctl, timeout=datetime.timedelta(seconds=900))
+            except Exception as e:          # noqa: BLE001
+                print('bench.py: control barrier: %r' % (e,), file=sys.stderr)
+            if rank == 0:
+                legs['oneshot'] = child
+        if rank == 0:
+            legs['b%d_allreduce' % B] = {'us_per_step': round(headline_us, 3), 'triplets_per_s': out['value'], 'rows_per_gpu': B,
+                                         'what': 'the headline of this line'}
+            legs['what'] = ('weak scaling, rows per GPU fixed: `allreduce` = RCCL ncclAllReduce of [gradient | scalars] called by the '
+                            'library on the launch stream between the weight-gradient launch and the Adam launch (default '
+                            'exchange); `oneshot` = reduce-scatter fused into the weight-gradient launch + sharded Adam + '
+                            'all-gather (csrc/cfl_dp.hip; measured by a child job on the same GPUs); `without_collective` = the '
+                            'same launches with no exchange at all (what a rank\'s step costs before a byte crosses a link)')
+            out['dp_scaling'] = legs
     if rank == 0:
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(out) + '\n').encode())

@@ -9,7 +9,9 @@ reference layout, so conversion is a name-for-name copy:
                                           + the directory's `checkpoint` file)
     --from-tf  in_prefix   model-N.pt     read a checkpoint written by the reference's tf.train.Saver
 
-The two TensorFlow directions need NO TensorFlow: cfl/tf_bundle.py reads and writes the bundle format itself (round 5).
+The two TensorFlow directions are EXPERIMENTAL: they need no TensorFlow -- cfl/tf_bundle.py reads and writes the bundle format
+itself (round 5) -- but neither the byte format nor the name mapping below has ever been read or written by a real TensorFlow
+(none is installable in the build image).  The .npz directions are the supported exchange.
 Names on the TensorFlow side follow what TF-1 creates for the reference's graph (cfl/models/dist.py:127-189,
 cfl/models/cfl.py:1065-1096 -- the optimisers are built INSIDE the model's variable scope):
     variables        <scope>/...                          as stored here
@@ -84,8 +86,11 @@ def _scope_of(name):
     return name.split('/', 1)[0]
 
 
-def to_tf_names(arrays, model_name=''):
-    """flat exchange names (<var>, <var>/Adam, <var>/Adam_1, beta*_power, gan powers) -> TF-1 checkpoint names"""
+def to_tf_names(arrays, model_name='', own_threshold_optimiser=None):
+    """flat exchange names (<var>, <var>/Adam, <var>/Adam_1, beta*_power, gan powers) -> TF-1 checkpoint names.
+    own_threshold_optimiser: does the graph have the separate `th_optim` Adam on the threshold (CFL without --use-threshold,
+    cfl/models/cfl.py:1076-1079)?  Stated by the checkpoint (state['graph']); None = checkpoints written before round 6:
+    inferred from the run name (`_ut` in get_name())."""
     out = {}
     scope = None
     for key, val in arrays.items():
@@ -100,7 +105,8 @@ def to_tf_names(arrays, model_name=''):
         out[key if base == key else _scope_of(base) + '/' + key] = val
     scope = scope or 'CFL'
     # power accumulators in the optimisers' creation order
-    own_threshold_optimiser = scope == 'CFL' and '_ut' not in ('_' + model_name + '_').replace('_reg', '_') and bool(model_name)
+    if own_threshold_optimiser is None:
+        own_threshold_optimiser = scope == 'CFL' and '_ut' not in ('_' + model_name + '_').replace('_reg', '_') and bool(model_name)
     chain = [('beta1_power', 'beta2_power')] * (2 if own_threshold_optimiser else 1)
     if 'gan_beta1_power_g' in arrays:
         chain += [('gan_beta1_power_g', 'gan_beta2_power_g'), ('gan_beta1_power_d', 'gan_beta2_power_d')]
@@ -108,6 +114,10 @@ def to_tf_names(arrays, model_name=''):
         sfx = '' if i == 0 else '_%d' % i
         out['%s/beta1_power%s' % (scope, sfx)] = np.float32(arrays.get(k1, 0.9))
         out['%s/beta2_power%s' % (scope, sfx)] = np.float32(arrays.get(k2, 0.999))
+    # the step counter of the run (the reference has no global_step variable of its own -- the Saver's global_step only names
+    # the file, cfl/utils.py:476-477 -- so this is an extra tensor a Saver(var_list=...) of the reference never asks for)
+    if 'global_step' in arrays:
+        out['global_step'] = np.int64(arrays['global_step'])
     return out
 
 
@@ -147,9 +157,9 @@ def from_tf_names(tensors):
     return out
 
 
-def to_tf(arrays, prefix, model_name=''):
+def to_tf(arrays, prefix, model_name='', own_threshold_optimiser=None):
     from .. import tf_bundle
-    tf_bundle.write_bundle(prefix, to_tf_names(arrays, model_name))
+    tf_bundle.write_bundle(prefix, to_tf_names(arrays, model_name, own_threshold_optimiser))
 
 
 def from_tf(prefix):
@@ -160,8 +170,11 @@ def from_tf(prefix):
 def main(argv=None):
     ap = argparse.ArgumentParser(description=__doc__.split('\n')[0])
     g = ap.add_mutually_exclusive_group(required=True)
-    for flag in ('--to-npz', '--from-npz', '--to-tf', '--from-tf'):
-        g.add_argument(flag, action='store_true')
+    for flag, what in (('--to-npz', 'native checkpoint -> NumPy archive under the TensorFlow variable names'),
+                       ('--from-npz', 'NumPy archive -> native checkpoint'),
+                       ('--to-tf', 'EXPERIMENTAL: native checkpoint -> TensorFlow tensor bundle (never read by a real TensorFlow)'),
+                       ('--from-tf', 'EXPERIMENTAL: TensorFlow tensor bundle -> native checkpoint (never fed a real TF file)')):
+        g.add_argument(flag, action='store_true', help=what)
     ap.add_argument('src')
     ap.add_argument('dst')
     ap.add_argument('--step', type=int, default=None)
@@ -174,7 +187,8 @@ def main(argv=None):
             torch.save(Saver._plain(arrays_to_state({k: z[k] for k in z.files}, a.step)), a.dst)
     elif a.to_tf:
         st = _load_pt(a.src)
-        to_tf(state_to_arrays(st), a.dst, st.get('name', ''))
+        graph = st.get('graph') or {}
+        to_tf(state_to_arrays(st), a.dst, st.get('name', ''), graph.get('own_threshold_optimiser'))
     else:
         import torch
         torch.save(Saver._plain(arrays_to_state(from_tf(a.src), a.step)), a.dst)

@@ -82,7 +82,11 @@ def parse_args(argv=None):
 
 
 def main(argv=None):
-    train_dist(**vars(parse_args(argv)))
+    try:
+        train_dist(**vars(parse_args(argv)))
+    finally:
+        if dp.world_size() > 1:
+            dp.finalize()       # the raw RCCL communicator of the exchange, then the process group (every rank)
 
 
 if __name__ == '__main__':

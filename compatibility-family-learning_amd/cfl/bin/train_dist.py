@@ -125,7 +125,8 @@ class DeferredScalars(object):
             rows = np.stack([g[1].numpy() for g in group]) if len(group) > 1 else group[0][1].numpy()[None]
             sc = rows[:, :H.S_COUNT]
             # a lost in-launch hand-off (sticky error word) raises here, one cadence after it happened at the latest
-            if sc[:, H.S_ERROR].any() or getattr(self.model.engine, '_oneshot', None) is not None:
+            # (the sticky error word is compared as the float it is: 0.0 healthy, anything else -- 1.0, a sum of them, NaN -- not)
+            if (sc[:, H.S_ERROR] != 0).any() or getattr(self.model.engine, '_oneshot', None) is not None:
                 for r in sc:
                     self.model.engine.check_health(r)
             # batch_accuracy (cfl/bin/train_dist.py:52-56 of the reference: mean of [s_pos > 0] and [s_neg <= 0])
@@ -141,11 +142,13 @@ class DeferredScalars(object):
 FUSED_CHUNK = 16    # iterations per library call at --scalar-every 1 (4 such calls fit the 64-slot pinned ring)
 
 
-def H_fusable(eng, batch_size):
+def H_fusable(eng, batch_size, rows=None):
+    """can a training step of `rows` rows per group (a rank's shard; default the whole batch) carry a validation batch of
+    `batch_size` pairs per group inside its own launches?"""
     from .. import hipabi as H
     if not hasattr(eng, 'step_windows_val'):
         return False
-    return H.train_val_fusable(eng.shape, batch_size, batch_size)
+    return H.train_val_fusable(eng.shape, rows if rows is not None else batch_size, batch_size)
 
 
 def train_steps(model, train_src, val_src, batch_size, shard, n_steps, on_scalars=None, progress=None,
@@ -166,8 +169,12 @@ def train_steps(model, train_src, val_src, batch_size, shard, n_steps, on_scalar
     # [scalars | validation scores] into the pinned ring themselves.  With --scalar-every 1 (the reference's cadence) up to
     # FUSED_CHUNK iterations go into one library call.  CFL_FUSED_VAL=0: the separate scoring call of rounds 3-4.
     eng = model.engine
-    fused = (deferred is not None and not dp.dp_active() and os.environ.get('CFL_FUSED_VAL', '1') not in ('0', '')
-             and shard is None and H_fusable(eng, batch_size))
+    # (data parallel, round 6: the same fused loop when the library drives the exchange itself -- PairEngine.dp_native: RCCL through
+    # the raw communicator or the one-shot exchange; every rank carries the whole validation batch, theta being replicated)
+    dp_ok = (not dp.dp_active()) or (hasattr(eng, 'dp_native') and eng.dp_native() is not None)
+    rows = (shard[1] - shard[0]) if shard is not None else batch_size
+    fused = (deferred is not None and dp_ok and os.environ.get('CFL_FUSED_VAL', '1') not in ('0', '')
+             and (shard is None or dp.dp_active()) and H_fusable(eng, batch_size, rows))
     while fused and i < n_steps:
         is_readback = lambda k: k % every == 0 or k == n_steps - 1
         # chunk [i, j): with a read-back every iteration, FUSED_CHUNK of them; otherwise up to and including the next one
@@ -218,21 +225,31 @@ def train_steps(model, train_src, val_src, batch_size, shard, n_steps, on_scalar
             progress.update(j - i)
         i = j
     while i < n_steps:
-        # the chunk ends with the next iteration whose scalars are read back (0, 25, 50, ..., and the last one)
+        # the chunk ends with the next iteration whose scalars are read back (0, 25, 50, ..., and the last one).  The validation
+        # batch of a read-back iteration is scored with the weights BEFORE that iteration's update, as the fused loop above does
+        # and as one sess.run of the reference fetches it (cfl/bin/train_dist.py:81-82): the iterations in front of it go first,
+        # then the scoring call, then the read-back iteration itself
         stop = min((i + every - 1) // every * every, n_steps - 1) + 1
-        win = train_src.next_windows(batch_size, stop - i, shard)
+        is_rb = lambda k: k % every == 0 or k == n_steps - 1
+        ahead = stop - i - 1 if (deferred is not None and is_rb(stop - 1)) else stop - i
+        win = train_src.next_windows(batch_size, ahead, shard) if ahead > 0 else None
         if win is not None:
             model.engine.step_windows(win)
             done = win.nsteps
         else:
-            model.engine.step(train_src.next_indexed(batch_size, shard))
+            last = i
+            slot = deferred.record_scores(val_src.next_indexed(batch_size)) if (deferred is not None and is_rb(last)) else None
+            win1 = train_src.next_windows(batch_size, 1, shard)
+            if win1 is not None:
+                model.engine.step_windows(win1)
+            else:
+                model.engine.step(train_src.next_indexed(batch_size, shard))
+            if slot is not None:
+                deferred.record_scalars(last, slot[0], slot[1])
             done = 1
-        last = i + done - 1
         i += done
         if progress is not None:
             progress.update(done)
-        if deferred is not None and (last % every == 0 or last == n_steps - 1):
-            deferred.record(last, val_src.next_indexed(batch_size))
     if deferred is not None:
         deferred.flush()
 
@@ -358,7 +375,11 @@ def parse_args(argv=None):
 def main(argv=None):
     args = parse_args(argv)
     log_args(args)
-    train_monomer(**vars(args))
+    try:
+        train_monomer(**vars(args))
+    finally:
+        if dp.world_size() > 1:
+            dp.finalize()       # the raw RCCL communicator of the exchange, then the process group (every rank)
 
 
 if __name__ == '__main__':

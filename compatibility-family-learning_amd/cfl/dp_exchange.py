@@ -12,6 +12,14 @@ point-to-point xGMI links -- every byte crosses exactly one link, every link car
                       stage buffer, raises its B flag there
     cfl_dp_rs_gather  waits for the peers' B flags, copies their slices from the local stage buffer into theta
 
+Round 6 (ABI 6): the PUSH IS FUSED into the weight-gradient launch -- its tile finishers store their finished entries of
+[gradient | scalars] straight into the owner's slot array and its last workgroup raises the A flags (csrc/pair_grad.h:
+GradFuse::dp_*) -- so a data-parallel step is proj, mid, grad(+push), cfl_dp_rs_adam, cfl_dp_rs_gather_planes: five launches,
+all of them behind ONE library call per K iterations (cfl_pair_dp_steps_idx_planes; PairEngine.step / step_windows).  This
+module owns the exchange memory and describes it to the library as a CflDpExchange (addresses of both parities, the device
+tables of the fused push, the step counter the library advances).  CFL_DP_PUSH_SEPARATE=1 keeps cfl_dp_rs_push as a launch of
+its own (A/B runs).
+
 The Adam slots are SHARDED: rank r keeps slice r of m and v current (Adam work / N); `sync_optimizer_state()` -- a
 collective every rank calls before the chief writes a checkpoint -- gathers them.  After a step every rank holds
 bit-identical parameters (one writer per slice), the global scalar sums, and ITS slice of the gradient sum.
@@ -56,8 +64,8 @@ class OneShotExchange(object):
     def __init__(self, engine):
         self.world = dist.get_world_size()
         self.rank = dist.get_rank()
-        if self.world > 16:
-            raise H.CflHipError('one-shot exchange supports up to 16 ranks')
+        if self.world > H.DP_MAX_WORLD:
+            raise H.CflHipError('one-shot exchange supports up to %d ranks' % H.DP_MAX_WORLD)
         dev = engine.device
         L = H.lib()
         self.n = int(engine.gradbuf.numel())
@@ -89,7 +97,6 @@ class OneShotExchange(object):
             H._check(L.cfl_dp_ipc_export(self.base, handle))
         except H.CflHipError as e:
             err = str(e)
-        self.ticket = torch.zeros(2, dtype=torch.int32, device=dev)    # [0] push launch, [1] Adam launch
         # the kernels' `lost` word lives in PINNED HOST memory (they write it only when a wait gives up): check() reads it
         # without touching the stream
         self.lost = torch.zeros(1, dtype=torch.int32).pin_memory()
@@ -115,9 +122,32 @@ class OneShotExchange(object):
         dist.all_gather_object(errs, err)
         self._raise_together(errs, 'mapping the peers\' exchange memory')
         self.local = torch.as_tensor(_Raw(self.base, self.total, '<f4'), device=dev)   # alias (diagnostics, tests)
+        # the library's view: every address of both parities, the device tables of the fused push, the step counter
+        c = self.c = H.CflDpExchange()
+        c.world, c.rank, c.n, c.n_adam, c.slice = self.world, self.rank, self.n, self.n_adam, self.slice
+        tables = []
+        for par in range(2):
+            c.slots[par] = self._slot_row(self.base, par, 0)
+            c.stage[par] = self._stage(self.base, par)
+            c.flags_a[par] = self._flag(self.base, self.o_flags_a, par, 0)
+            c.flags_b[par] = self._flag(self.base, self.o_flags_b, par, 0)
+            for r, b in enumerate(self._peer_base):
+                c.peer_rows[par][r] = self._slot_row(b, par, self.rank)
+                c.peer_stage[par][r] = self._stage(b, par)
+                c.peer_flag_a[par][r] = self._flag(b, self.o_flags_a, par, self.rank)
+                c.peer_flag_b[par][r] = self._flag(b, self.o_flags_b, par, self.rank)
+            pad = [0] * (H.DP_MAX_WORLD - self.world)
+            tables += [c.peer_rows[par][r] for r in range(self.world)] + pad
+            tables += [c.peer_flag_a[par][r] for r in range(self.world)] + pad
+        self._tables = torch.tensor(tables, dtype=torch.int64).to(dev)     # [2 parities][rows, A flags][DP_MAX_WORLD]
+        self._tickets = torch.zeros(4, dtype=torch.int32, device=dev)
+        c.dev_tables = self._tables.data_ptr()
+        c.tickets = self._tickets.data_ptr()
+        c.lost = self.lost.data_ptr()
+        c.timeout_s = self.timeout_s
+        c.step = 0
         torch.cuda.synchronize(dev)
         dist.barrier()                   # nobody pushes before everyone has mapped everyone
-        self.step = 0
         self.m_v_sharded = self.world > 1
         # True between a step and the next sync_optimizer_state(): this rank's m / v are current for its own slice only,
         # and a checkpoint written now would carry stale slots for (world - 1) / world of the parameters
@@ -138,36 +168,26 @@ class OneShotExchange(object):
     def _flag(self, base, off, par, r):
         return base + 4 * (off + par * 64 + r)
 
-    def exchange_and_adam(self, engine, lr_t):
-        """engine.gradbuf (this rank's [gradient | scalars]) -> every rank's theta updated with the mean gradient; this
-        rank's slice of m / v updated; engine.gradbuf = [this rank's slice of the gradient sum | the global scalar sums].
-        Returns the factor that turns the scalar sums into global-batch means."""
-        par, gen = self.step & 1, (self.step + 1) & 0xffffffff
-        if gen == 0:
-            gen = 1
-        W, me = self.world, self.rank
-        rows = (C.c_void_p * W)(*[self._slot_row(b, par, me) for b in self._peer_base])
-        flags_a = (C.c_void_p * W)(*[self._flag(b, self.o_flags_a, par, me) for b in self._peer_base])
-        stages = (C.c_void_p * W)(*[self._stage(b, par) for b in self._peer_base])
-        flags_b = (C.c_void_p * W)(*[self._flag(b, self.o_flags_b, par, me) for b in self._peer_base])
-        L = H.lib()
-        st = H._stream()
-        H._check(L.cfl_dp_rs_push(engine.gradbuf.data_ptr(), self.n, self.slice, rows, flags_a, W, gen,
-                                  self.ticket[0:].data_ptr(), st))
-        H._check(L.cfl_dp_rs_adam(engine.theta.data_ptr(), engine.m.data_ptr(), engine.v.data_ptr(),
-                                  self._slot_row(self.base, par, 0), self._flag(self.base, self.o_flags_a, par, 0), W, me,
-                                  self.n, self.n_adam, self.slice, engine.gradbuf.data_ptr(), stages, flags_b, float(lr_t),
-                                  float(engine.beta1), float(engine.beta2), float(engine.eps), gen, self.lost.data_ptr(),
-                                  self.timeout_s, self.ticket[1:].data_ptr(), st))
-        # (the gather also writes the kept bf16 planes of every weight -- peers' slices as it copies them, the own slice as
-        # it passes over it -- so the next projection runs from current planes, as after the fused single-GPU step)
-        H._check(L.cfl_dp_rs_gather_planes(C.byref(engine.shape), engine.theta.data_ptr(), engine.gradbuf.data_ptr(),
-                                           self._stage(self.base, par), self._flag(self.base, self.o_flags_b, par, 0), W, me,
-                                           self.n, self.n_adam, self.slice, gen, self.lost.data_ptr(), self.timeout_s,
-                                           H._planes(engine.planes), st))
-        self.step += 1
+    @property
+    def step(self):
+        """exchanges so far (the library advances the counter inside its calls)"""
+        return int(self.c.step)
+
+    def after_library_steps(self):
+        """bookkeeping behind a library call that ran exchanges (PairEngine): the Adam slots are sharded again"""
         self.slots_dirty = self.m_v_sharded
-        return 1.0 / W
+
+    def exchange_and_adam(self, engine, lr_t):
+        """engine.gradbuf (this rank's [gradient | scalars], already computed into the flat buffer) -> every rank's theta updated
+        with the mean gradient; this rank's slice of m / v updated; engine.gradbuf = [this rank's slice of the gradient sum |
+        the global scalar sums].  The separate-push form (cfl_dp_rs_push first): what PairEngine.fwd_bwd + this gives when the
+        step is not taken through the one-call entry points.  Returns the factor that turns the scalar sums into means."""
+        H._check(H.lib().cfl_dp_exchange_step(C.byref(engine.shape), C.byref(self.c), 0, engine.theta.data_ptr(),
+                                              engine.m.data_ptr(), engine.v.data_ptr(), engine.gradbuf.data_ptr(), float(lr_t),
+                                              float(engine.beta1), float(engine.beta2), float(engine.eps),
+                                              H._planes(engine.planes), None, H._stream()))
+        self.after_library_steps()
+        return 1.0 / self.world
 
     def owned(self):
         """[lo, hi) of the parameters whose Adam slots this rank keeps current"""

@@ -5,9 +5,14 @@ slots, the flat gradient, the scalar read-back buffer and the scratch workspace,
 and drives one training step as
 
     single GPU      cfl_pair_train_step[_idx]_planes             (3 launches, TF-Adam fused into the last one)
-    data parallel   cfl_pair_step_fwd_bwd[_idx]_planes  ->  RCCL all-reduce of [gradient | scalars]  ->  cfl_adam_tf_planes
-                    (the SAME 3 launches -- the projection on the bf16 matrix cores from the kept planes of theta, the fused
-                    weight-gradient tail emitting the flat gradient -- then the exchange and an Adam that re-writes the planes)
+    data parallel   cfl_pair_dp_step[s]_idx_planes (ABI 6): ONE library call per step / per K windowed steps runs
+                    proj -> mid -> grad -> exchange -> update, where the exchange is
+                      * RCCL's ncclAllReduce of [gradient | scalars], called BY the library on the launch stream between its
+                        weight-gradient launch and cfl_adam_tf_planes (default; cfl/rccl.py hands over the entry point), or
+                      * the one-shot exchange with the push fused into the weight-gradient launch (CFL_DP_EXCHANGE=oneshot:
+                        cfl/dp_exchange.py, csrc/cfl_dp.hip): 5 launches per step, no collective library in the loop.
+                    Without a raw RCCL communicator (gloo test mode, torch fallback): forward / backward, then
+                    torch.distributed.all_reduce and cfl_adam_tf_planes from Python (`_exchange_and_update`).
 
 which replaces the per-iteration ``sess.run([summary, [s_optim], ...])`` of
 cfl/bin/train_dist.py:81-82 and cfl/models/cfl.py:1399-1414.  Data parallelism
@@ -155,7 +160,7 @@ class PairEngine(object):
         # ONE flat buffer [gradient (layout of theta) | the step's loss / accuracy scalars | pad]: the kernels
         # write both parts, and the data-parallel exchange is a single all-reduce of it
         n = self.theta.numel()
-        self.gradbuf = torch.zeros(n + 64, dtype=torch.float32, device=self.device)
+        self.gradbuf = torch.zeros(n + H.GRADBUF_PAD, dtype=torch.float32, device=self.device)
         self.grad = self.gradbuf[:n]
         self.scalars = self.gradbuf[n:n + H.S_COUNT]
         self._scalar_scale = 1.0
@@ -173,21 +178,23 @@ class PairEngine(object):
         # (CFL_DP_EXCHANGE=oneshot: cfl/dp_exchange.py, csrc/cfl_dp.hip)
         self._oneshot = None
         import os
-        hot_communicator()           # (collective: created here, on every rank, not inside the first step)
-        if world_size() > 1 and os.environ.get('CFL_DP_EXCHANGE', 'allreduce') == 'oneshot':
+        self._comm = hot_communicator()    # (collective: created here, on every rank, not inside the first step)
+        if dp_active() and os.environ.get('CFL_DP_EXCHANGE', 'allreduce') == 'oneshot':
             from .dp_exchange import OneShotExchange
-            self._oneshot = OneShotExchange(self)
+            self._oneshot = OneShotExchange(self)   # (a one-rank group too: CFL_FORCE_DP, the one-GPU form of the same code)
 
     # -- plumbing ----------------------------------------------------------
-    def _workspace(self, rows, groups):
-        key = (int(rows), int(groups))
+    def _workspace(self, rows, groups, val_rows=0):
+        """val_rows: the call also carries a validation batch of that many pairs per group (larger than `rows` under data
+        parallelism: a rank trains its shard and scores the whole batch)"""
+        key = (int(rows), int(groups)) if val_rows <= rows else (int(rows), int(groups), int(val_rows))
         ws = self._ws.get(key)
         if ws is None:
-            n = H.workspace_bytes(self.shape, rows, groups)
+            n = H.workspace_bytes(self.shape, rows, groups) if val_rows <= rows else H.workspace_bytes_val(self.shape, rows, val_rows)
             ws = torch.empty(n // 4, dtype=torch.float32, device=self.device)
             # a few sizes per group count stay cached: under data parallelism the training step (rows = batch / world) and
             # the validation fetch (rows = batch) alternate, and evicting each other meant a reallocation per read-back
-            same = [k for k in self._ws if k[1] == groups]
+            same = [k for k in self._ws if k[1] == groups and len(k) == len(key)]
             for k in same[:max(0, len(same) - 2)]:
                 del self._ws[k]
             self._ws[key] = ws
@@ -245,6 +252,13 @@ class PairEngine(object):
             self._scalar_scale = 1.0
             self._advance()
             return
+        native = self.dp_native()
+        if native is not None:
+            # the whole step behind one library call: forward / backward, the exchange, the update
+            H.pair_dp_step(self.shape, self.norm, self.loss, batch, self.theta, self.m, self.v, self.gradbuf, ws, self.lr_t(),
+                           self.beta1, self.beta2, self.eps, planes=self.planes, **native)
+            self._after_native_steps(1, native)
+            return
         if indexed:
             H.pair_step_fwd_bwd_idx(self.shape, self.norm, self.loss, batch[0], batch[1], self.theta, self.grad,
                                     self.scalars, ws, planes=self.planes)
@@ -252,6 +266,36 @@ class PairEngine(object):
             H.pair_step_fwd_bwd(self.shape, self.norm, self.loss, batch, self.theta, self.grad, self.scalars, ws,
                                 planes=self.planes)
         self._exchange_and_update()
+
+    def dp_native(self):
+        """How the library itself runs the exchange of a data-parallel step (ABI 6), as keyword arguments of
+        hipabi.pair_dp_step / pair_dp_steps_idx: the one-shot exchange, or RCCL's all-reduce through the raw communicator;
+        None when the collective has to go through torch.distributed (gloo test mode, CFL_DP_ALLREDUCE=torch, RCCL not
+        loadable through ctypes) -- the step is then driven from Python (`_exchange_and_update`).  CFL_DP_NATIVE=0: never."""
+        import os
+        if not dp_active() or os.environ.get('CFL_DP_NATIVE', '1') in ('0', ''):
+            return None
+        if os.environ.get('CFL_DP_NO_COLLECTIVE', '0') == '1':
+            # measurements only (bench.py `without_collective`): the launches of a data-parallel step and its stand-alone Adam
+            # with NO exchange -- every rank trains on its own rows
+            return dict()
+        if self._oneshot is not None:
+            return dict(ex=self._oneshot.c)
+        if os.environ.get('CFL_DP_ALLREDUCE', 'direct') == 'torch':
+            return None
+        comm = hot_communicator()
+        return dict(ar=comm.c_struct()) if comm is not None else None
+
+    def _native_scale(self, native):
+        """factor that turns the scalars a library-driven step leaves behind into global-batch means"""
+        return 1.0 / world_size() if native else 1.0
+
+    def _after_native_steps(self, n, native):
+        self._scalar_scale = self._native_scale(native)
+        if self._oneshot is not None:
+            self._oneshot.after_library_steps()
+        for _ in range(n):
+            self._advance()
 
     def _exchange_and_update(self):
         """the ONE exchange of a data-parallel step + the replicated Adam apply"""
@@ -269,10 +313,21 @@ class PairEngine(object):
         (cfl.input_data.ResidentFeatures.next_windows): one library call, the launches of all steps are enqueued
         back to back."""
         ws = self._workspace(win.rows, 2)
+        native = self.dp_native() if dp_active() else None
+        if native is not None:
+            # data parallel: the same windows, every iteration forward / backward on this rank's rows, the exchange, the update --
+            # ONE library call for the iterations between two read-backs (cfl_pair_dp_steps_idx_planes)
+            b1p, b2p = H.pair_dp_steps_idx(self.shape, self.norm, self.loss, win, self.theta, self.m, self.v, self.gradbuf, ws,
+                                           np.float32(self.lr), self.beta1, self.beta2, self.eps, self.beta1_power,
+                                           self.beta2_power, planes=self.planes, **native)
+            self.beta1_power, self.beta2_power = np.float32(b1p), np.float32(b2p)
+            self.global_step += win.nsteps
+            self._scalar_scale = self._native_scale(native)
+            if self._oneshot is not None:
+                self._oneshot.after_library_steps()
+            return
         if dp_active():
-            # data parallel: the same windows, the exchange inside the loop -- every step is forward/backward on this
-            # rank's rows of the window, then the collective + Adam (one host call for the iterations between two
-            # read-backs; with the one-shot exchange nothing in the loop leaves the library's kernels)
+            # ... through torch.distributed (gloo test mode, torch fallback): the exchange inside a Python loop
             itemsize = 4
             if (win.nsteps <= 0 or win.pos_head < 0 or win.neg_head < 0
                     or win.pos_head + win.nsteps * win.batch_rows > win.pos_pairs.shape[0]
@@ -303,9 +358,24 @@ class PairEngine(object):
         steps with val_mask[i] set also score the next validation batch of `vwin` as extra rows of their own projection /
         row-math launches and write [scalars | scores of the positive, then the negative validation pairs] into the next
         of `slot_ptrs` (rows of a pinned host buffer: no copy command, no second launch pair per read-back)."""
+        ws = self._workspace(win.rows, 2, vwin.batch_rows)
         if dp_active():
-            raise H.CflHipError('step_windows_val is the single-GPU form; under data parallelism score separately')
-        ws = self._workspace(win.rows, 2)
+            native = self.dp_native()
+            if native is None:
+                raise H.CflHipError('step_windows_val under data parallelism needs the library-driven exchange '
+                                    '(PairEngine.dp_native); score separately')
+            # every rank scores the WHOLE validation batch (theta is replicated: identical scores on every rank); the ring slot
+            # receives the global scalar sums from the exchange's last kernel
+            b1p, b2p = H.pair_dp_steps_idx(self.shape, self.norm, self.loss, win, self.theta, self.m, self.v, self.gradbuf, ws,
+                                           np.float32(self.lr), self.beta1, self.beta2, self.eps, self.beta1_power,
+                                           self.beta2_power, planes=self.planes, vwin=vwin, val_mask=val_mask,
+                                           slot_ptrs=slot_ptrs, **native)
+            self.beta1_power, self.beta2_power = np.float32(b1p), np.float32(b2p)
+            self.global_step += win.nsteps
+            self._scalar_scale = self._native_scale(native)
+            if self._oneshot is not None:
+                self._oneshot.after_library_steps()
+            return
         b1p, b2p = H.pair_train_val_steps_idx(
             self.shape, self.norm, self.loss, win, vwin, val_mask, slot_ptrs, self.theta, self.m, self.v, self.grad,
             self.scalars, ws, np.float32(self.lr), self.beta1, self.beta2, self.eps, self.beta1_power, self.beta2_power,

@@ -66,6 +66,25 @@ class CflThetaPlanes(C.Structure):
     _fields_ = [('buf', C.c_void_p), ('valid', C.c_int32)]
 
 
+DP_MAX_WORLD = 16
+GRADBUF_PAD = 64      # gradbuf = [cfl_layout.total floats of gradient | 16 scalars | 48 pad] (include/cfl_hip.h, ABI 6)
+
+
+class CflDpExchange(C.Structure):
+    """one rank's view of the one-shot exchange memory (include/cfl_hip.h, ABI 6); filled by cfl.dp_exchange.OneShotExchange"""
+    _fields_ = [('world', C.c_int32), ('rank', C.c_int32), ('n', C.c_int64), ('n_adam', C.c_int64), ('slice', C.c_int64),
+                ('slots', C.c_void_p * 2), ('stage', C.c_void_p * 2), ('flags_a', C.c_void_p * 2), ('flags_b', C.c_void_p * 2),
+                ('peer_rows', (C.c_void_p * DP_MAX_WORLD) * 2), ('peer_stage', (C.c_void_p * DP_MAX_WORLD) * 2),
+                ('peer_flag_a', (C.c_void_p * DP_MAX_WORLD) * 2), ('peer_flag_b', (C.c_void_p * DP_MAX_WORLD) * 2),
+                ('dev_tables', C.c_void_p), ('tickets', C.c_void_p), ('lost', C.c_void_p), ('timeout_s', C.c_double),
+                ('step', C.c_uint64)]
+
+
+class CflAllReduce(C.Structure):
+    """a caller-supplied all-reduce with ncclAllReduce's signature (include/cfl_hip.h, ABI 6); cfl.rccl.Communicator.c_struct()"""
+    _fields_ = [('fn', C.c_void_p), ('comm', C.c_void_p), ('dtype', C.c_int32), ('op', C.c_int32), ('world', C.c_int32)]
+
+
 class CflPlanInfo(C.Structure):
     _fields_ = ([(n, C.c_char * 40) for n in ('proj', 'mid', 'grad', 'tail')] +
                 [(n, C.c_int32) for n in ('launches', 'per_call_plane_split', 'S', 'P', 'rows_padded', 'column_jobs',
@@ -89,9 +108,11 @@ EXPORTS = ('cfl_version', 'cfl_last_error', 'cfl_layout', 'cfl_workspace_bytes',
            'cfl_scalars_status', 'cfl_theta_planes_bytes', 'cfl_pair_train_step_planes', 'cfl_pair_train_step_idx_planes',
            'cfl_pair_train_steps_idx_planes', 'cfl_pair_step_fwd_bwd_planes', 'cfl_pair_step_fwd_bwd_idx_planes',
            'cfl_adam_tf_planes', 'cfl_dp_rs_gather_planes', 'cfl_plan_describe', 'cfl_crc32c',
-           'cfl_train_val_fusable', 'cfl_pair_train_val_steps_idx_planes')
+           'cfl_train_val_fusable', 'cfl_pair_train_val_steps_idx_planes',
+           'cfl_dp_exchange_step', 'cfl_dp_push_fusable', 'cfl_pair_dp_step_planes', 'cfl_pair_dp_step_idx_planes',
+           'cfl_pair_dp_steps_idx_planes', 'cfl_workspace_bytes_val')
 
-KERNEL_NAMES = ('colnorm', 'proj', 'mid', 'grad', 'finalize', 'adam', 'gather')
+KERNEL_NAMES = ('colnorm', 'proj', 'mid', 'grad', 'finalize', 'adam', 'gather', 'dp_exchange')
 K_COUNT = 8
 
 _lib = None
@@ -229,9 +250,33 @@ def lib():
     for f in (L.cfl_dp_alloc, L.cfl_dp_free, L.cfl_dp_ipc_export, L.cfl_dp_ipc_open, L.cfl_dp_ipc_close, L.cfl_dp_rs_push,
               L.cfl_dp_rs_adam, L.cfl_dp_rs_gather, L.cfl_dp_rs_gather_planes):
         f.restype = C.c_int
+    # ABI 6: the whole data-parallel step behind one call
+    DPX, ARP, TP = C.POINTER(CflDpExchange), C.POINTER(CflAllReduce), C.POINTER(CflThetaPlanes)
+    L.cfl_dp_exchange_step.argtypes = [C.POINTER(CflShape), DPX, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_float, C.c_float, C.c_float, C.c_float, TP, C.c_void_p, C.c_void_p]
+    L.cfl_dp_push_fusable.argtypes = [C.POINTER(CflShape), C.c_int64]
+    L.cfl_workspace_bytes_val.argtypes = [C.POINTER(CflShape), C.c_int64, C.c_int64]
+    L.cfl_workspace_bytes_val.restype = C.c_size_t
+    L.cfl_pair_dp_step_planes.argtypes = [
+        C.POINTER(CflShape), C.POINTER(CflNorm), C.POINTER(CflLossCfg), C.POINTER(C.c_void_p), C.c_int64, C.c_void_p, C.c_void_p,
+        C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, TP, DPX, ARP, C.c_void_p, C.c_size_t, C.c_void_p]
+    L.cfl_pair_dp_step_idx_planes.argtypes = [
+        C.POINTER(CflShape), C.POINTER(CflNorm), C.POINTER(CflLossCfg), C.c_void_p, C.c_int64, C.POINTER(C.c_void_p), C.c_int64,
+        C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, TP, DPX, ARP,
+        C.c_void_p, C.c_size_t, C.c_void_p]
+    L.cfl_pair_dp_steps_idx_planes.argtypes = [
+        C.POINTER(CflShape), C.POINTER(CflNorm), C.POINTER(CflLossCfg), C.c_void_p, C.c_int64,
+        C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_char_p, C.c_int64,
+        C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64,
+        C.c_char_p, C.c_char_p, C.POINTER(C.c_void_p),
+        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float,
+        C.POINTER(C.c_float), C.POINTER(C.c_float), TP, DPX, ARP, C.c_void_p, C.c_size_t, C.c_void_p]
+    for f in (L.cfl_dp_exchange_step, L.cfl_dp_push_fusable, L.cfl_pair_dp_step_planes, L.cfl_pair_dp_step_idx_planes,
+              L.cfl_pair_dp_steps_idx_planes):
+        f.restype = C.c_int
     L.cfl_profile_enable.argtypes = [C.c_int]
     L.cfl_profile_read.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_int64)]
-    if L.cfl_version() != 5:
+    if L.cfl_version() != 6:
         raise CflHipError('libcfl_hip.so ABI version mismatch')
     _lib = L
     return L
@@ -318,6 +363,14 @@ def workspace_bytes(shape, rows, groups):
     n = lib().cfl_workspace_bytes(C.byref(shape), int(rows), int(groups))
     if n == 0:
         raise CflHipError('cfl_workspace_bytes: ' + lib().cfl_last_error().decode())
+    return n
+
+
+def workspace_bytes_val(shape, rows, val_rows):
+    """workspace of a training call of `rows` rows per group that carries `val_rows` validation pairs per group"""
+    n = lib().cfl_workspace_bytes_val(C.byref(shape), int(rows), int(val_rows))
+    if n == 0:
+        raise CflHipError('cfl_workspace_bytes_val: ' + lib().cfl_last_error().decode())
     return n
 
 
@@ -485,6 +538,67 @@ def pair_train_val_steps_idx(shape, norm, loss, win, vwin, val_mask, slot_ptrs, 
         float(beta2), float(eps), C.byref(b1p), C.byref(b2p), _planes(planes), workspace.data_ptr(),
         workspace.numel() * workspace.element_size(), _stream()))
     return b1p.value, b2p.value
+
+
+# ---- ABI 6: one data-parallel step / K windowed steps behind ONE library call ------------------------------------------
+def _exchange_args(ex, ar):
+    """(CflDpExchange* | None, CflAllReduce* | None) for the C ABI; both None: no exchange"""
+    return (C.byref(ex) if ex is not None else None), (C.byref(ar) if ar is not None else None)
+
+
+def pair_dp_step(shape, norm, loss, batch, theta, m, v, gradbuf, workspace, lr_t, beta1, beta2, eps=1e-8, planes=None, ex=None,
+                 ar=None):
+    """forward / backward of this rank's rows, the gradient exchange (ex: one-shot exchange with the push fused into the
+    weight-gradient launch; ar: a caller-supplied all-reduce enqueued on the launch stream) and TF-Adam + planes: one call.
+    batch = 4 dense device tensors or (table, IndexStreams)."""
+    if gradbuf.numel() != theta.numel() + GRADBUF_PAD:
+        raise CflHipError('gradbuf must hold the parameter count + %d floats' % GRADBUF_PAD)
+    exp, arp = _exchange_args(ex, ar)
+    wsb = workspace.numel() * workspace.element_size()
+    if isinstance(batch[1], IndexStreams):
+        tp, rows = _table(batch[0])
+        st = batch[1]
+        _check(lib().cfl_pair_dp_step_idx_planes(
+            C.byref(shape), C.byref(norm), C.byref(loss), tp, rows, st.arr, st.stride, st.n, _dev(theta), _dev(m), _dev(v),
+            _dev(gradbuf), float(lr_t), float(beta1), float(beta2), float(eps), _planes(planes), exp, arp,
+            workspace.data_ptr(), wsb, _stream()))
+    else:
+        arr = (C.c_void_p * 4)(*[_dev(x) for x in batch])
+        _check(lib().cfl_pair_dp_step_planes(
+            C.byref(shape), C.byref(norm), C.byref(loss), arr, batch[0].shape[0], _dev(theta), _dev(m), _dev(v), _dev(gradbuf),
+            float(lr_t), float(beta1), float(beta2), float(eps), _planes(planes), exp, arp, workspace.data_ptr(), wsb,
+            _stream()))
+
+
+def pair_dp_steps_idx(shape, norm, loss, win, theta, m, v, gradbuf, workspace, lr, beta1, beta2, eps, beta1_power, beta2_power,
+                      planes=None, ex=None, ar=None, vwin=None, val_mask=None, slot_ptrs=None):
+    """win.nsteps data-parallel iterations over windows of the device pair lists in ONE call (cfl_pair_dp_steps_idx_planes); with
+    vwin / val_mask / slot_ptrs the masked iterations carry the validation fetch.  Returns the advanced Adam powers."""
+    if gradbuf.numel() != theta.numel() + GRADBUF_PAD:
+        raise CflHipError('gradbuf must hold the parameter count + %d floats' % GRADBUF_PAD)
+    tp, trows = _table(win.table)
+    b1p, b2p = C.c_float(beta1_power), C.c_float(beta2_power)
+    exp, arp = _exchange_args(ex, ar)
+    if vwin is not None:
+        vp, vrows = _table(vwin.table)
+        slots = (C.c_void_p * max(1, len(slot_ptrs)))(*[int(p) for p in slot_ptrs])
+        val = (vp, vrows, _dev(vwin.pos_pairs, torch.int32), int(vwin.pos_pairs.shape[0]), _dev(vwin.neg_pairs, torch.int32),
+               int(vwin.neg_pairs.shape[0]), int(vwin.pos_head), int(vwin.neg_head), int(vwin.batch_rows), _flags(vwin.switched),
+               _flags(val_mask), slots)
+    else:
+        val = (None, 0, None, 0, None, 0, 0, 0, 0, None, None, None)
+    _check(lib().cfl_pair_dp_steps_idx_planes(
+        C.byref(shape), C.byref(norm), C.byref(loss), tp, trows, _dev(win.pos_pairs, torch.int32), int(win.pos_pairs.shape[0]),
+        _dev(win.neg_pairs, torch.int32), int(win.neg_pairs.shape[0]), int(win.pos_head), int(win.neg_head),
+        int(win.batch_rows), int(win.shard_lo), int(win.rows), _flags(win.switched), int(win.nsteps), *val,
+        _dev(theta), _dev(m), _dev(v), _dev(gradbuf), float(lr), float(beta1), float(beta2), float(eps), C.byref(b1p),
+        C.byref(b2p), _planes(planes), exp, arp, workspace.data_ptr(), workspace.numel() * workspace.element_size(), _stream()))
+    return b1p.value, b2p.value
+
+
+def dp_push_fusable(shape, rows):
+    """does a training call of this shape push its gradient from inside the weight-gradient launch (fused-tail plans)?"""
+    return lib().cfl_dp_push_fusable(C.byref(shape), int(rows)) == 1
 
 
 def mt19937_reshuffle(state, rows, want32=False):

@@ -158,7 +158,12 @@ class PairModel(object):
         state = {'variables': self._named(eng.theta),
                  'adam_m': self._named(eng.m), 'adam_v': self._named(eng.v),
                  'beta1_power': float(eng.beta1_power), 'beta2_power': float(eng.beta2_power),
-                 'global_step': eng.global_step, 'name': self.get_name()}
+                 'global_step': eng.global_step, 'name': self.get_name(),
+                 # what the TensorFlow-side names of a converted checkpoint depend on (cfl.bin.convert_checkpoint --to-tf):
+                 # stated by the model instead of being parsed out of its name
+                 'graph': {'own_threshold_optimiser': bool(getattr(self, 'MODEL_SCOPE', '') == 'CFL'
+                                                           and not getattr(self, 'use_threshold', True)),
+                           'has_gan': getattr(self, 'gan_phase', None) is not None}}
         return state
 
     def _pack(self, named):

@@ -42,7 +42,10 @@ class CFL(PairModel):
                  unlabeled_batches=None, train_data_transformer=None, val_data_transformer=None,
                  ae_transformer=None, data_normalizer=None, data_unnormalizer=None,
                  ae_normalizer=None, ae_unnormalizer=None, latent_normalizer=None, run_tag=None,
-                 name='CFL', reuse=False, seed=0, device=None):
+                 name='CFL', reuse=False, seed=0, device=None, layer_sizes=None):
+        # layer_sizes: the hidden weight-normalised fc_i + lrelu layers of FCPCD (cfl/models/blocks.py:509-527; linear model only).
+        # No command line of the reference sets it (its CFL class builds FCPCD without it, cfl/models/cfl.py:576-612); kept as a
+        # constructor argument for callers of the model classes.
         for k, v in list(locals().items()):
             if k not in ('self', 'name', 'reuse', 'batches', 'val_batches', 'unlabeled_batches'):
                 setattr(self, k, v)
@@ -82,6 +85,17 @@ class CFL(PairModel):
             self.trunk_dst = ConvTrunk(shape3, 4 * batch_size, enc_norm, reg_const, lr, beta1, beta2, 1e-8,
                                        np.random.RandomState(seed + 5), dev) if directed else self.trunk
             self._explicit_norm = None     # the trunk applies the data normaliser itself
+            head_inputs, norm = self.trunk.feature_size, H.make_norm()
+        elif layer_sizes:
+            # FCPCD(layer_sizes=...): hidden fc_i layers in front of the heads, the same trunk plumbing as the conv encoder
+            from .conv_encoder import FCTrunk
+            import torch
+            dev = torch.device(device if device is not None else 'cuda')
+            mk = lambda sd: FCTrunk(head_inputs, layer_sizes, 4 * batch_size, enc_norm, reg_const, lr, beta1, beta2, 1e-8,
+                                    np.random.RandomState(sd), dev)
+            self.trunk = mk(seed + 1)
+            self.trunk_dst = mk(seed + 5) if directed else self.trunk
+            self._explicit_norm = None
             head_inputs, norm = self.trunk.feature_size, H.make_norm()
         self._setup_engine(
             head_inputs, latent_size, num_components, dist_type,
@@ -355,7 +369,7 @@ class CFL(PairModel):
         PairModel.assign_trainable(self, state, ignore_missing)
         for i, tr in enumerate(self._trunks()):
             pre = 'CFL/' + self.ENCODER_SCOPES[i] + '/'
-            tr.load_named({k[len(pre):]: v for k, v in state['variables'].items() if k.startswith(pre + 'conv')})
+            tr.load_named({k[len(pre):]: v for k, v in state['variables'].items() if k.startswith(pre + tr.PREFIX)})
 
     def _trunks(self):
         if self.trunk is None:
@@ -392,7 +406,7 @@ class CFL(PairModel):
         for i, tr in enumerate(self._trunks()):
             pre = 'CFL/' + self.ENCODER_SCOPES[i] + '/'
             for key, base in (('variables', None), ('adam_m', tr.m), ('adam_v', tr.v)):
-                tr.load_named({k[len(pre):]: v for k, v in state[key].items() if k.startswith(pre + 'conv')}, base)
+                tr.load_named({k[len(pre):]: v for k, v in state[key].items() if k.startswith(pre + tr.PREFIX)}, base)
         if self.gan_phase is not None and 'gan_powers' in state:
             for n, net in (('g', self.gan_phase.gen), ('d', self.gan_phase.disc)):
                 strip = lambda d: {k[4:]: v for k, v in d.items() if k.startswith('CFL/')}
@@ -547,12 +561,17 @@ class CFL(PairModel):
                 train_avg, val_avg = avgs.get('train', 0.0), avgs.get('val', 0.0)
                 t = ()
             for i in t:
-                self.train_step(next_train())
+                rb = i % 50 == 0 or i == nb_batch - 1
+                batch = next_train()
+                # the validation batch of a read-back iteration is scored with the weights BEFORE that iteration's update -- what the
+                # fused epochs above do, and what one sess.run of the reference fetches (cfl/models/cfl.py:1399-1414): ONE semantics
+                val_acc = self.batch_accuracy(next_val()) if rb else None
+                self.train_step(batch)
                 if save_iters and i > 0 and i % save_iters == 0 and saver is not None:
                     self.engine.sync_state()      # collective when the Adam slots are sharded (one-shot exchange)
                     if chief:
                         saver.save(self, os.path.join(checkpoint_dir, 'model'), global_step=nb_batch * e + i)
-                if i % 50 == 0 or i == nb_batch - 1:      # host read-back only now and then
+                if rb:                                    # host read-back only now and then
                     s = self.scalars()                    # (raises CflHipError on a lost in-launch hand-off)
                     if not np.isfinite(s['total']):
                         # never checkpoint poisoned parameters: the last files written stay the latest ones
@@ -560,7 +579,7 @@ class CFL(PairModel):
                     if writer is not None and chief:
                         writer.add_scalars('scalars', nb_batch * e + i, s)
                     train_avg = self._ema_update('acc', s['accuracy'])
-                    val_avg = self._ema_update('val_acc', self.batch_accuracy(next_val()))
+                    val_avg = self._ema_update('val_acc', val_acc)
                     t.set_postfix(error=1. - train_avg, val_error=1. - val_avg,
                                   pos_avg=self._ema_update('pos', s['dist_adapt_pos']),
                                   neg_avg=self._ema_update('neg', s['dist_adapt_neg']))
@@ -644,8 +663,9 @@ def construct_model(is_double, disable_double, latent_shape, source_shape, input
                     train_data_transformer=None, val_data_transformer=None, ae_transformer=None,
                     data_normalizer=None, data_unnormalizer=None, ae_normalizer=None,
                     ae_unnormalizer=None, latent_normalizer=None, enable_input_producer=False,
-                    seed=0, device=None):
-    """(model, aux) with the argument list of cfl/models/cfl.py:1514-1523."""
+                    seed=0, device=None, layer_sizes=None):
+    """(model, aux) with the argument list of cfl/models/cfl.py:1514-1523 (+ layer_sizes: FCPCD's hidden layers,
+    cfl/models/blocks.py:492,509-524, which the reference's construct_model leaves at None)."""
     from argparse import Namespace
     kw = dict(locals())
     for k in ('data', 'enable_input_producer', 'Namespace'):

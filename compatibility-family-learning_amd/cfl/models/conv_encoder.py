@@ -1,4 +1,12 @@
-"""ConvPCD trunk on the GPU (cfl/models/blocks.py:530-590): reshape to NHWC, then
+"""Encoder trunks on the GPU: weight-normalised layers in front of the pair-distance heads.
+
+* ConvTrunk -- ConvPCD (cfl/models/blocks.py:530-590);
+* FCTrunk   -- the hidden `fc_i` stack of FCPCD(layer_sizes=...) (cfl/models/blocks.py:509-527: weight-normalised fully
+  connected layers with lrelu, zero-initialised biases, L2 term on V only), run as 1x1 convolutions on 1x1 images through the
+  same cfl_conv2d_wn_{fwd,bwd} entry points (round 6: no command line of the reference sets layer_sizes, the constructor
+  argument is kept for callers of the model classes).
+
+ConvPCD trunk on the GPU (cfl/models/blocks.py:530-590): reshape to NHWC, then
 [5x5 stride-2 weight-normalised conv + lrelu] while the side is even and > 4, flatten.
 The flattened features feed the pair-distance heads (the fused HIP pair kernels with
 D = flattened size); the trunk's gradient comes back through cfl_pair_input_grad and the
@@ -27,29 +35,41 @@ def trunk_layers(input_shape, dim=64, max_dim=512, min_dim=4):
 
 
 class ConvTrunk(object):
+    KSIZE, STRIDE = 5, 2                  # 5x5 stride-2 convolutions (cfl/models/blocks.py:571-586)
+    SCOPE, FIRST = 'conv%d/Conv/', 1      # variable scopes conv1/Conv/{V,g,biases}, ...
+    PREFIX = 'conv'                       # what this trunk's variables start with inside an encoder scope
+
+    def _layers(self):
+        return trunk_layers(self.input_shape)
+
+    def _vshape(self, ci, co):
+        return (self.KSIZE, self.KSIZE, ci, co)
+
     def __init__(self, input_shape, batch_rows, norm, reg_const, lr, beta1, beta2, eps, rng, device):
         self.input_shape = tuple(input_shape)
         self.device = device
         self.norm, self.reg_const = norm, float(reg_const or 0.0)
         self.lr, self.beta1, self.beta2, self.eps = lr, beta1, beta2, eps
-        self.layers, out = trunk_layers(self.input_shape)
+        self.layers, out = self._layers()
         if not self.layers:
-            raise ValueError('input shape %r leaves no convolution layer' % (self.input_shape,))
+            raise ValueError('input shape %r leaves no trunk layer' % (self.input_shape,))
         self.feat_shape = out
         self.feature_size = out[0] * out[1] * out[2]
         if self.feature_size % 64:
-            raise H.CflHipError('flattened conv features (%d) must be a multiple of 64' % self.feature_size)
+            raise H.CflHipError('flattened trunk features (%d) must be a multiple of 64' % self.feature_size)
+        k2 = self.KSIZE * self.KSIZE
         # flat parameter buffer [V1 g1 b1 V2 g2 b2 ...], each segment 64-float aligned
         self.slices, off = [], 0
         for (h, w, ci, co) in self.layers:
             seg = {}
-            for name, n in (('V', 25 * ci * co), ('g', co), ('b', co)):
+            for name, n in (('V', k2 * ci * co), ('g', co), ('b', co)):
                 seg[name] = (off, n)
                 off += (n + 63) // 64 * 64
             self.slices.append(seg)
         self.theta = torch.zeros(off, dtype=torch.float32, device=device)
         for seg, (h, w, ci, co) in zip(self.slices, self.layers):
-            V = np.asarray(rng.uniform(-1, 1, size=(5, 5, ci, co)) * np.sqrt(6.0 / (25 * ci + 25 * co)),
+            # xavier_initializer: uniform +-sqrt(6 / (fan_in + fan_out)), fans include the receptive field
+            V = np.asarray(rng.uniform(-1, 1, size=self._vshape(ci, co)) * np.sqrt(6.0 / (k2 * ci + k2 * co)),
                            np.float32)
             self._view(seg, 'V').copy_(torch.from_numpy(V).reshape(-1))
             self._view(seg, 'g').fill_(1.0)
@@ -67,7 +87,7 @@ class ConvTrunk(object):
         if plan is None:
             convs, acts, wss = [], [], []
             for (h, w, ci, co) in self.layers:
-                conv = H.make_conv(rows, h, w, ci, co, 5, 5, 2, 'lrelu')
+                conv = H.make_conv(rows, h, w, ci, co, self.KSIZE, self.KSIZE, self.STRIDE, 'lrelu')
                 oh, ow = H.conv_out_hw(conv)
                 convs.append(conv)
                 acts.append(torch.empty(rows, oh, ow, co, dtype=torch.float32, device=self.device))
@@ -86,7 +106,7 @@ class ConvTrunk(object):
         cur = x_rows.reshape((rows,) + self.input_shape)
         self._inputs = [cur]
         for i, (conv, y, ws, seg) in enumerate(zip(convs, acts, wss, self.slices)):
-            V = self._view(seg, 'V').view(5, 5, conv.Ci, conv.Co)
+            V = self._view(seg, 'V').view(self.KSIZE, self.KSIZE, conv.Ci, conv.Co)
             H.conv2d_wn_fwd(conv, cur, V, self._view(seg, 'g'), self._view(seg, 'b'), ws, y)
             cur = y
             self._inputs.append(cur)
@@ -99,7 +119,7 @@ class ConvTrunk(object):
         dy = dfeat.reshape(acts[-1].shape)
         for i in reversed(range(len(convs))):
             conv, seg = convs[i], self.slices[i]
-            V = self._view(seg, 'V').view(5, 5, conv.Ci, conv.Co)
+            V = self._view(seg, 'V').view(self.KSIZE, self.KSIZE, conv.Ci, conv.Co)
             dx, dV, dg, db = H.conv2d_wn_bwd(conv, self._inputs[i], V, self._view(seg, 'g'),
                                              self._inputs[i + 1], dy.contiguous(), wss[i],
                                              reg_const=self.reg_const, need_dx=i > 0, need_db=True)
@@ -129,8 +149,8 @@ class ConvTrunk(object):
     def named(self, base=None):
         out = {}
         for i, (seg, (h, w, ci, co)) in enumerate(zip(self.slices, self.layers)):
-            scope = 'conv%d/Conv/' % (i + 1)
-            out[scope + 'V'] = self._view(seg, 'V', base).view(5, 5, ci, co).cpu().numpy().copy()
+            scope = self.SCOPE % (i + self.FIRST)
+            out[scope + 'V'] = self._view(seg, 'V', base).view(self._vshape(ci, co)).cpu().numpy().copy()
             out[scope + 'g'] = self._view(seg, 'g', base).cpu().numpy().copy()
             out[scope + 'biases'] = self._view(seg, 'b', base).cpu().numpy().copy()
         return out
@@ -139,8 +159,34 @@ class ConvTrunk(object):
         if base is None:
             self._reg_sum = None
         for i, seg in enumerate(self.slices):
-            scope = 'conv%d/Conv/' % (i + 1)
+            scope = self.SCOPE % (i + self.FIRST)
             for leaf, key in (('V', 'V'), ('g', 'g'), ('biases', 'b')):
                 if scope + leaf in named:
                     self._view(seg, key, base).copy_(torch.as_tensor(
                         np.asarray(named[scope + leaf], np.float32)).reshape(-1))
+
+
+class FCTrunk(ConvTrunk):
+    """The hidden layers of FCPCD(layer_sizes=[...]) (cfl/models/blocks.py:509-527): `fc_i` = weight-normalised fully connected
+    layer + lrelu (cfl/layers.py:28-97: y = (x . V) * g / ||V_col|| + b), variables fc_<i>/fully_connected/{V [Ci, Co], g, biases},
+    L2 term on V only (weights_regularizer; the biases have none).  A fully connected layer IS a 1x1 convolution on a 1x1
+    image: the layers run through the same weight-normalised convolution kernels as the conv trunk, rows as the batch."""
+    KSIZE, STRIDE = 1, 1
+    SCOPE, FIRST = 'fc_%d/fully_connected/', 0
+    PREFIX = 'fc_'
+
+    def __init__(self, input_size, layer_sizes, batch_rows, norm, reg_const, lr, beta1, beta2, eps, rng, device):
+        self.layer_sizes = [int(n) for n in layer_sizes]
+        if not self.layer_sizes or min(self.layer_sizes) <= 0:
+            raise ValueError('layer_sizes %r' % (layer_sizes,))
+        ConvTrunk.__init__(self, (1, 1, int(input_size)), batch_rows, norm, reg_const, lr, beta1, beta2, eps, rng, device)
+
+    def _layers(self):
+        layers, ci = [], self.input_shape[2]
+        for co in self.layer_sizes:
+            layers.append((1, 1, ci, co))
+            ci = co
+        return layers, (1, 1, ci)
+
+    def _vshape(self, ci, co):
+        return (ci, co)

@@ -50,7 +50,7 @@ class ParamPool(object):
         self.theta = None
         self.version = 0     # bumped whenever theta changes (Adam, load): per-layer weight caches key on it
         self.layers = []     # the WNLayers whose variables live here (cache preparation behind the optimizer step)
-        self._views = {}     # (name, buffer address) -> view
+        self._views = {}     # id(buffer) -> (weak reference to the buffer, {name: view})
 
     def add(self, name, value):
         value = np.asarray(value, np.float32)
@@ -76,11 +76,24 @@ class ParamPool(object):
         (name, buffer): a post-epoch step asks for ~600 of them, and slicing + reshaping each time was a fifth of the
         host time of the step (tools/gan_host_profile.py)."""
         base = self.theta if base is None else base
-        key = (name, base.data_ptr())
-        v = self._views.get(key)
+        # keyed by the buffer OBJECT (ADVICE r5): an address says nothing about dtype / length, and a cache keyed by it would keep
+        # every buffer that was ever passed alive.  The pool's own buffers (theta, m, v, grad, grad2) live as long as the pool;
+        # anything else -- a caller's scratch buffer -- is evicted when a new buffer object shows up.
+        if base.dtype != torch.float32 or base.numel() < self.total:
+            raise ValueError('ParamPool.view: buffer of %d %s elements for a pool of %d floats' % (base.numel(), base.dtype, self.total))
+        bid = id(base)
+        cache = self._views.get(bid)
+        if cache is None or cache[0]() is not base:
+            own = {id(b) for b in (self.theta, getattr(self, 'm', None), getattr(self, 'v', None), getattr(self, 'grad', None),
+                                   getattr(self, 'grad2', None)) if b is not None}
+            for k in [k for k, c in self._views.items() if k not in own or c[0]() is None]:
+                del self._views[k]
+            import weakref
+            cache = self._views[bid] = (weakref.ref(base), {})
+        v = cache[1].get(name)
         if v is None:
             o, shp = self.specs[name]
-            v = self._views[key] = base[o:o + int(np.prod(shp))].view(shp)
+            v = cache[1][name] = base[o:o + int(np.prod(shp))].view(shp)
         return v
 
     def named(self, base=None):
@@ -263,10 +276,27 @@ class _Net(object):
             self._prep_stream = torch.cuda.Stream(device=self.device)
         self._prep_stream.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(self._prep_stream):
+            complete = True
             for layer in self.pool.layers:
                 layer.prepare()
+                complete = complete and (layer._cache is None or layer._prep_desc is not None)
             self._prep_event = torch.cuda.Event()
             self._prep_event.record()
+        # every cache was rebuilt for THIS version of the weights behind `_prep_event` (caches_prepared)
+        self._prepared_version = self.pool.version if complete else -1
+
+    def caches_prepared(self):
+        """Were ALL layer caches rebuilt ahead (prepare_caches) for the current weights?  Then their host validity bits are
+        set and every kernel that filled them sits behind `_prep_event`, which every consumer waits for on its own stream
+        (join_prepare): forward passes may run on several streams at once.  Otherwise the first stream to touch a layer
+        builds its cache and sets the HOST bits at once -- a second stream would read scale / planes with no dependency on
+        the kernels that write them -- so concurrent forwards are only allowed when this returns True (GanPhase.step)."""
+        if not (_Net.prep_ahead and Workspace.overlap and G.ConvCache.enabled):
+            return False
+        if getattr(self, '_prep_event', None) is None or getattr(self, '_prepared_version', -1) != self.pool.version:
+            return False
+        return all(l._cache is None or (l._cache_version == self.pool.version and l._cache.flags.value != 0)
+                   for l in self.pool.layers)
 
     def join_prepare(self):
         """every entry point that reads a layer's cache waits -- on whatever stream it runs -- for the last preparation"""

@@ -111,7 +111,11 @@ class GanPhase(object):
             if st is None:
                 return []
             self._install_streams(st)
-            run(); run()
+            run()
+            # the timed steps must take the form the training steps take -- gradient-penalty chain forked at the top of the
+            # step -- which needs every cache marked as prepared ahead (nothing is rebuilt here: the weights have not moved)
+            self.disc.prepare_caches(); self.gen.prepare_caches()
+            run()
             torch.cuda.synchronize(self.device)
             t0 = time.perf_counter()
             for _ in range(steps):
@@ -120,6 +124,7 @@ class GanPhase(object):
             times.append((time.perf_counter() - t0) / steps * 1e3)
             sets.append(st)
         self._install_streams(sets[int(np.argmin(times))])
+        self.disc.prepare_caches(); self.gen.prepare_caches()
         self.stream_tuning = [round(t, 3) for t in times]
         return times
 
@@ -148,7 +153,11 @@ class GanPhase(object):
         # backward -- depends on nothing the generator produces: it starts HERE, on its own stream and workspace, beside the
         # generator forward (2 ms of layers far too small to fill 256 CUs) instead of behind the batched discriminator
         # forward, which then carries 4 B rows instead of 5 B.  (Round 5; CFL_GAN_GP_EARLY=0: X_hat rides in the batched forward)
-        gp_early = bool(self.lambda_gp) and c2 is not None and GanPhase.gp_early
+        # ... but only when every discriminator layer's cache (weight-norm scale, filter planes) was prepared ahead for the
+        # current weights: the caches' validity bits are HOST state shared by all streams, so a cache built lazily by this
+        # chain's forward would be read by the main stream's forward with no dependency on the kernels that fill it (first
+        # step after construction / load_state, CFL_GAN_PREP_AHEAD=0: X_hat rides in the batched forward for that step)
+        gp_early = bool(self.lambda_gp) and c2 is not None and GanPhase.gp_early and disc.caches_prepared()
         if gp_early:
             start_ev = torch.cuda.Event()
             start_ev.record(main)

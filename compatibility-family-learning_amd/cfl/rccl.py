@@ -57,24 +57,14 @@ def _check(rc, what):
 
 
 class Communicator(object):
-    """One RCCL communicator over the ranks of the default torch process group (COLLECTIVE constructor: every rank
-    calls it; the current device must be this rank's GPU)."""
+    """One RCCL communicator over the ranks of the default torch process group.  Built by `default_communicator()` in
+    PHASES with an agreement step after each: a constructor that is one collective from end to end cannot
+    fail symmetrically -- a rank whose librccl does not load would sit in the agreement all-reduce while the others sit in
+    the broadcast of the unique id."""
 
-    def __init__(self):
-        if not dist.is_initialized():
-            raise RcclError('a torch.distributed process group must exist (the unique id travels over it)')
-        L = lib()
-        self.rank, self.world = dist.get_rank(), dist.get_world_size()
-        uid = _UniqueId()
-        if self.rank == 0:
-            _check(L.ncclGetUniqueId(C.byref(uid)), 'ncclGetUniqueId')
-        # (the raw 128 bytes: ctypes truncates a c_char array at the first NUL when it is read as bytes)
-        box = [C.string_at(C.addressof(uid), 128) if self.rank == 0 else None]
-        dist.broadcast_object_list(box, src=0)
-        C.memmove(C.addressof(uid), box[0], 128)
-        comm = C.c_void_p()
-        _check(L.ncclCommInitRank(C.byref(comm), self.world, uid, self.rank), 'ncclCommInitRank')
-        self.comm = comm
+    def __init__(self, comm, rank, world):
+        self.comm, self.rank, self.world = comm, rank, world
+        self._c = None
 
     def all_reduce_sum_(self, tensor, stream=None):
         """in-place fp32 sum over the ranks, enqueued on `stream` (default: torch's current stream)"""
@@ -84,6 +74,16 @@ class Communicator(object):
         p = tensor.data_ptr()
         _check(lib().ncclAllReduce(p, p, tensor.numel(), NCCL_FLOAT32, NCCL_SUM, self.comm, st), 'ncclAllReduce')
 
+    def c_struct(self):
+        """CflAllReduce for libcfl_hip's data-parallel entry points (include/cfl_hip.h, ABI 6): RCCL's own ncclAllReduce and
+        this communicator -- the library calls it between its weight-gradient launch and the update, on the launch stream"""
+        if self._c is None:
+            from .hipabi import CflAllReduce
+            fn = C.cast(lib().ncclAllReduce, C.c_void_p).value
+            self._c = CflAllReduce(fn, self.comm.value if isinstance(self.comm, C.c_void_p) else int(self.comm),
+                                   NCCL_FLOAT32, NCCL_SUM, self.world)
+        return self._c
+
     def close(self):
         if getattr(self, 'comm', None):
             torch.cuda.synchronize()
@@ -91,36 +91,93 @@ class Communicator(object):
             self.comm = None
 
 
-
 _default = None
-
-
 _unavailable = False
 
 
+def _all_ok(ok):
+    """agreement over the torch process group: did the phase succeed on EVERY rank?  (MIN all-reduce of a flag; with one rank
+    nothing to agree on)"""
+    if dist.get_world_size() == 1:
+        return bool(ok)
+    t = torch.tensor([1 if ok else 0], dtype=torch.int32, device='cuda' if dist.get_backend() == 'nccl' else 'cpu')
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return int(t.item()) == 1
+
+
+def _warn_fallback(phase, err):
+    import logging
+    logging.getLogger(__name__).warning('direct RCCL all-reduce unavailable (%s: %s): the gradient exchange goes through '
+                                        'torch.distributed.all_reduce', phase, err or 'failed on another rank')
+
+
 def default_communicator():
-    """The process-wide communicator of the hot exchange, created on first use (COLLECTIVE), or None when it cannot be
-    created on EVERY rank -- librccl not loadable through ctypes, ncclCommInitRank failing somewhere: the ranks agree on the
-    outcome over the torch process group (a MIN all-reduce of a success flag), so that either all of them enqueue
-    ncclAllReduce on their launch streams or all of them fall back to torch.distributed.all_reduce; a split would hang."""
+    """The process-wide communicator of the hot exchange, created on first use (COLLECTIVE: every rank calls it), or None when it
+    cannot be created on EVERY rank; the ranks then ALL fall back to torch.distributed.all_reduce (a split would hang).  Three
+    phases, each followed by an agreement over the torch process group, so that a failure in one of them is seen by every
+    rank BEFORE anybody enters the next collective:
+      1. load librccl through ctypes and resolve the symbols                      -> MIN all-reduce
+      2. rank 0 draws the unique id; (ok, id) is broadcast                        -> every rank reads `ok` from the broadcast
+      3. ncclCommInitRank (collective inside RCCL: every rank enters it)          -> MIN all-reduce
+    CFL_RCCL_FAIL_PHASE=<n>[:<rank>] makes phase n fail (on that rank; tests)."""
     global _default, _unavailable
-    if _default is None and not _unavailable:
-        comm, err = None, None
+    if _default is not None or _unavailable:
+        return _default
+    if not dist.is_initialized():
+        raise RcclError('a torch.distributed process group must exist (the unique id travels over it)')
+    rank, world = dist.get_rank(), dist.get_world_size()
+    fail = os.environ.get('CFL_RCCL_FAIL_PHASE', '')
+    fail_phase, _, fail_rank = fail.partition(':')
+
+    def injected(phase):
+        return fail_phase == str(phase) and (fail_rank == '' or int(fail_rank) == rank)
+
+    # phase 1: the library
+    L, err = None, None
+    try:
+        if injected(1):
+            raise OSError('injected failure (CFL_RCCL_FAIL_PHASE)')
+        L = lib()
+    except Exception as e:          # noqa: BLE001 (OSError from ctypes, AttributeError of a missing symbol)
+        err = e
+    if not _all_ok(L is not None):
+        _unavailable = True
+        _warn_fallback('loading librccl', err)
+        return None
+    # phase 2: the unique id (rank 0 draws it; its success travels WITH the id)
+    uid, err = _UniqueId(), None
+    box = [None]
+    if rank == 0:
         try:
-            comm = Communicator()
-        except Exception as e:          # noqa: BLE001 (anything: OSError from ctypes, RcclError, AttributeError of a missing symbol)
+            if injected(2):
+                raise RcclError('injected failure (CFL_RCCL_FAIL_PHASE)')
+            _check(L.ncclGetUniqueId(C.byref(uid)), 'ncclGetUniqueId')
+            # (the raw 128 bytes: ctypes truncates a c_char array at the first NUL when it is read as bytes)
+            box = [C.string_at(C.addressof(uid), 128)]
+        except Exception as e:      # noqa: BLE001
             err = e
-        ok = torch.tensor([0 if comm is None else 1], dtype=torch.int32, device='cuda')
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-        if int(ok.item()) == 1:
-            _default = comm
-        else:
-            _unavailable = True
-            if comm is not None:
-                comm.close()
-            import logging
-            logging.getLogger(__name__).warning('direct RCCL all-reduce unavailable (%s on this rank): the gradient exchange goes '
-                                                'through torch.distributed.all_reduce', err or 'failed on another rank')
+    if world > 1:
+        dist.broadcast_object_list(box, src=0)
+    if box[0] is None:
+        _unavailable = True
+        _warn_fallback('ncclGetUniqueId on rank 0', err)
+        return None
+    C.memmove(C.addressof(uid), box[0], 128)
+    # phase 3: the communicator (every rank enters ncclCommInitRank: the failures that remain are RCCL's own, symmetric or not)
+    comm, err = C.c_void_p(), None
+    try:
+        if injected(3):
+            raise RcclError('injected failure (CFL_RCCL_FAIL_PHASE)')
+        _check(L.ncclCommInitRank(C.byref(comm), world, uid, rank), 'ncclCommInitRank')
+    except Exception as e:          # noqa: BLE001
+        err, comm = e, None
+    if not _all_ok(comm is not None):
+        _unavailable = True
+        if comm is not None:
+            Communicator(comm, rank, world).close()
+        _warn_fallback('ncclCommInitRank', err)
+        return None
+    _default = Communicator(comm, rank, world)
     return _default
 
 

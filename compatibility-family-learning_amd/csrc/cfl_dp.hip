@@ -36,10 +36,15 @@
 #include "theta_planes.h"
 
 extern int cfl_set_err(int code, const char *fmt, ...);
+extern void *cfl_prof_scope_begin(void *stream, int kind);   // cfl_profile_enable's event pairs (cfl_hip.hip)
+extern void cfl_prof_scope_end(void *scope);
+struct DpProf {
+    void *h;
+    DpProf(cfl_stream_t st) : h(cfl_prof_scope_begin(st, CFL_K_DP)) {}
+    ~DpProf() { if (h) cfl_prof_scope_end(h); }
+};
 
 typedef float dp_f32x4 __attribute__((ext_vector_type(4)));
-
-#define CFL_DP_MAX_WORLD 16
 
 struct DpPeers {
     float *slot[CFL_DP_MAX_WORLD];        // per peer: where this rank writes (row of the slot array / stage buffer, current parity)
@@ -164,13 +169,17 @@ __global__ __launch_bounds__(256) void cfl_dp_rs_adam_kernel(float *theta, float
 __global__ __launch_bounds__(256) void cfl_dp_rs_gather_kernel(float *theta, float *sum_out, const float *stage,
                                                                const unsigned *flags, int world, int rank, long long n4,
                                                                long long nadam4, long long slice4, unsigned gen, int *lost,
-                                                               unsigned long long ticks, ThetaPlaneRegions pr) {
+                                                               unsigned long long ticks, ThetaPlaneRegions pr, float *scalars_copy) {
     const bool ok = dp_wait_flags(flags, world, rank, gen, ticks, lost);
     const long long lo = (long long)rank * slice4, hi = lo + slice4;
     const long long stride = (long long)gridDim.x * 256;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+        // the step's global scalar SUMS (the 16 floats behind the parameters) also go to the caller's second destination -- a
+        // pinned host ring slot of the training loop: no copy command on the stream
+        const bool sc = scalars_copy && i >= nadam4 && i < nadam4 + 4;
         if (i >= lo && i < hi) {            // own slice: written by cfl_dp_rs_adam_kernel (the launch before this one)
             if (pr.planes && i < nadam4) theta_planes_store4(pr, i * 4, ((const dp_f32x4 *)theta)[i]);
+            if (sc) ((dp_f32x4 *)scalars_copy)[i - nadam4] = ((const dp_f32x4 *)sum_out)[i];
             continue;
         }
         dp_f32x4 x = load_sys16(stage + i * 4);
@@ -178,7 +187,10 @@ __global__ __launch_bounds__(256) void cfl_dp_rs_gather_kernel(float *theta, flo
         if (i < nadam4) {
             ((dp_f32x4 *)theta)[i] = x;
             theta_planes_store4(pr, i * 4, x);
-        } else ((dp_f32x4 *)sum_out)[i] = x;
+        } else {
+            ((dp_f32x4 *)sum_out)[i] = x;
+            if (sc) ((dp_f32x4 *)scalars_copy)[i - nadam4] = x;
+        }
     }
 }
 
@@ -271,8 +283,11 @@ extern "C" int cfl_dp_rs_push(const float *src, int64_t n, int64_t slice, float 
     const long long n4 = n / 4;
     int blocks = (int)((n4 + 255) / 256);
     if (blocks > 256) blocks = 256;
-    hipLaunchKernelGGL(cfl_dp_rs_push_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, n4, (long long)(slice / 4), p,
-                       generation, ticket);
+    {
+        DpProf prof(stream);
+        hipLaunchKernelGGL(cfl_dp_rs_push_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, n4, (long long)(slice / 4), p,
+                           generation, ticket);
+    }
     return hipGetLastError() == hipSuccess ? CFL_OK : cfl_set_err(CFL_E_HIP, "cfl_dp_rs_push launch failed");
 }
 
@@ -294,16 +309,19 @@ extern "C" int cfl_dp_rs_adam(float *theta, float *m, float *v, const float *gsl
     // other of compute units while they wait
     int blocks = (int)((slice / 4 + 255) / 256);
     if (blocks > 64) blocks = 64;
-    hipLaunchKernelGGL(cfl_dp_rs_adam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, theta, m, v, gslots, flags,
-                       world, rank, (long long)(n / 4), (long long)(n_adam / 4), (long long)(slice / 4), sum_out, p, lr_t, beta1,
-                       beta2, eps, generation, (int *)lost, dp_ticks(timeout_s), ticket);
+    {
+        DpProf prof(stream);
+        hipLaunchKernelGGL(cfl_dp_rs_adam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, theta, m, v, gslots, flags,
+                           world, rank, (long long)(n / 4), (long long)(n_adam / 4), (long long)(slice / 4), sum_out, p, lr_t, beta1,
+                           beta2, eps, generation, (int *)lost, dp_ticks(timeout_s), ticket);
+    }
     return hipGetLastError() == hipSuccess ? CFL_OK : cfl_set_err(CFL_E_HIP, "cfl_dp_rs_adam launch failed");
 }
 
-extern "C" int cfl_dp_rs_gather_planes(const CflShape *shape, float *theta, float *sum_out, const float *stage,
-                                       const uint32_t *flags, int32_t world, int32_t rank, int64_t n, int64_t n_adam,
-                                       int64_t slice, uint32_t generation, int32_t *lost, double timeout_s,
-                                       CflThetaPlanes *planes, cfl_stream_t stream) {
+static int dp_gather_launch(const CflShape *shape, float *theta, float *sum_out, const float *stage,
+                            const uint32_t *flags, int32_t world, int32_t rank, int64_t n, int64_t n_adam,
+                            int64_t slice, uint32_t generation, int32_t *lost, double timeout_s,
+                            CflThetaPlanes *planes, float *scalars_copy, cfl_stream_t stream) {
     ThetaPlaneRegions pr;
     memset(&pr, 0, sizeof(pr));
     if (planes) {
@@ -325,11 +343,61 @@ extern "C" int cfl_dp_rs_gather_planes(const CflShape *shape, float *theta, floa
     if (rc) return rc;
     int blocks = (int)((n / 4 + 255) / 256);
     if (blocks > 128) blocks = 128;
-    hipLaunchKernelGGL(cfl_dp_rs_gather_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, theta, sum_out, stage, flags,
-                       world, rank, (long long)(n / 4), (long long)(n_adam / 4), (long long)(slice / 4), generation, (int *)lost,
-                       dp_ticks(timeout_s), pr);
+    {
+        DpProf prof(stream);
+        hipLaunchKernelGGL(cfl_dp_rs_gather_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, theta, sum_out, stage, flags,
+                           world, rank, (long long)(n / 4), (long long)(n_adam / 4), (long long)(slice / 4), generation, (int *)lost,
+                           dp_ticks(timeout_s), pr, scalars_copy);
+    }
     if (hipGetLastError() != hipSuccess) return cfl_set_err(CFL_E_HIP, "cfl_dp_rs_gather launch failed");
     if (planes) planes->valid = 1;
+    return CFL_OK;
+}
+
+extern "C" int cfl_dp_rs_gather_planes(const CflShape *shape, float *theta, float *sum_out, const float *stage,
+                                       const uint32_t *flags, int32_t world, int32_t rank, int64_t n, int64_t n_adam,
+                                       int64_t slice, uint32_t generation, int32_t *lost, double timeout_s,
+                                       CflThetaPlanes *planes, cfl_stream_t stream) {
+    return dp_gather_launch(shape, theta, sum_out, stage, flags, world, rank, n, n_adam, slice, generation, lost, timeout_s,
+                            planes, nullptr, stream);
+}
+
+// ---- ABI 6: the exchange + update of one step from a CflDpExchange ------------------------------------------------------
+static int dp_check_exchange(const CflDpExchange *ex, const char *who) {
+    if (!ex) return cfl_set_err(CFL_E_SHAPE, "%s: exchange is NULL", who);
+    if (ex->world < 1 || ex->world > CFL_DP_MAX_WORLD || ex->rank < 0 || ex->rank >= ex->world)
+        return cfl_set_err(CFL_E_SHAPE, "%s: rank %d of %d", who, ex->rank, ex->world);
+    if (!ex->tickets || !ex->lost) return cfl_set_err(CFL_E_SHAPE, "%s: tickets / lost is NULL", who);
+    for (int p = 0; p < 2; ++p)
+        if (!ex->slots[p] || !ex->stage[p] || !ex->flags_a[p] || !ex->flags_b[p])
+            return cfl_set_err(CFL_E_SHAPE, "%s: local slots / stage / flags of parity %d are NULL", who, p);
+    return dp_check_sizes(who, ex->n, ex->n_adam, ex->slice, ex->world, ex->rank);
+}
+
+extern "C" uint32_t cfl_dp_generation(uint64_t step) {   // never 0 (the flag words start at 0)
+    const uint32_t g = (uint32_t)((step + 1) & 0xffffffffu);
+    return g ? g : 1u;
+}
+
+extern "C" int cfl_dp_exchange_step(const CflShape *shape, CflDpExchange *ex, int32_t pushed, float *theta, float *m, float *v,
+                                    float *gradbuf, float lr_t, float beta1, float beta2, float eps, CflThetaPlanes *planes,
+                                    float *scalars_copy, cfl_stream_t stream) {
+    int rc = dp_check_exchange(ex, "cfl_dp_exchange_step");
+    if (rc) return rc;
+    const int par = (int)(ex->step & 1);
+    const uint32_t gen = cfl_dp_generation(ex->step);
+    if (!pushed) {
+        rc = cfl_dp_rs_push(gradbuf, ex->n, ex->slice, ex->peer_rows[par], ex->peer_flag_a[par], ex->world, gen, ex->tickets, stream);
+        if (rc) return rc;
+    }
+    rc = cfl_dp_rs_adam(theta, m, v, ex->slots[par], ex->flags_a[par], ex->world, ex->rank, ex->n, ex->n_adam, ex->slice, gradbuf,
+                        ex->peer_stage[par], ex->peer_flag_b[par], lr_t, beta1, beta2, eps, gen, ex->lost, ex->timeout_s,
+                        ex->tickets + 1, stream);
+    if (rc) return rc;
+    rc = dp_gather_launch(shape, theta, gradbuf, ex->stage[par], ex->flags_b[par], ex->world, ex->rank, ex->n, ex->n_adam, ex->slice,
+                          gen, ex->lost, ex->timeout_s, planes, scalars_copy, stream);
+    if (rc) return rc;
+    ex->step += 1;
     return CFL_OK;
 }
 

@@ -115,6 +115,10 @@ struct ProfScope {
     }
 };
 
+// (the kernels of cfl_dp.hip are timed through these: one record list for the whole library)
+void *cfl_prof_scope_begin(void *stream, int kind) { return g_prof_on ? new ProfScope((hipStream_t)stream, kind) : nullptr; }
+void cfl_prof_scope_end(void *scope) { delete (ProfScope *)scope; }
+
 extern "C" int cfl_profile_enable(int on) { g_prof_on = on != 0; return CFL_OK; }
 
 extern "C" int cfl_profile_read(double *ms_sum, int64_t *launches) {
@@ -802,6 +806,20 @@ extern "C" size_t cfl_workspace_bytes(const CflShape *s, int64_t rows, int32_t g
     return need * sizeof(float);
 }
 
+// ... of a training call of `rows` rows per group that carries a validation batch of `val_rows` pairs per group as extra scoring
+// rows (under data parallelism a rank trains its shard but scores the WHOLE validation batch: val_rows > rows)
+extern "C" size_t cfl_workspace_bytes_val(const CflShape *s, int64_t rows, int64_t val_rows) {
+    size_t need = cfl_workspace_bytes(s, rows, 2);
+    if (!need) return 0;
+    need /= sizeof(float);
+    for (int kept = 0; kept < 2; ++kept) {
+        Plan pl;
+        if (make_plan(s, rows, 2, true, kept != 0, &pl, 2 * val_rows)) return 0;
+        if (pl.total_floats > need) need = pl.total_floats;
+    }
+    return need * sizeof(float);
+}
+
 extern "C" size_t cfl_theta_planes_bytes(const CflShape *s) {
     CflLayout lay;
     if (cfl_layout(s, &lay)) return 0;
@@ -894,11 +912,27 @@ static int cached_plan(const CflShape *s, int64_t rows, int groups, bool train, 
     return CFL_OK;
 }
 
+// Fused push of the data-parallel one-shot exchange (GradFuse::dp_*): the weight-gradient launch stores [gradient | scalars]
+// into the owners' slot arrays.  rows_tab / flags_tab: DEVICE tables [world]; scalars_remote: where the step's 16 scalars live
+// in their owner's slot row (resolved on the host: their offset is static).  Honoured by plans with the fused tail only
+// (*pushed tells the caller); without it the caller runs cfl_dp_rs_push on the flat buffer.
+struct DpPush {
+    float *const *rows_tab;
+    unsigned *const *flags_tab;
+    long long slice;
+    int world;
+    unsigned gen;
+    unsigned *ticket;
+    float *scalars_remote;
+};
+
 static int run_pairs(const CflShape *s, const CflNorm *norm, const CflLossCfg *loss,
                      const float *const *x, int groups, int64_t rows, const float *theta,
                      float *grad, float *scalars, float *scores, float *dists, void *workspace,
                      size_t workspace_bytes, hipStream_t st, const AdamFuse *adam = nullptr,
-                     const IndexSrc *isrc = nullptr, CflThetaPlanes *kept = nullptr, const ExtraSrc *xs = nullptr) {
+                     const IndexSrc *isrc = nullptr, CflThetaPlanes *kept = nullptr, const ExtraSrc *xs = nullptr,
+                     const DpPush *dpp = nullptr, bool *pushed = nullptr) {
+    if (pushed) *pushed = false;
     const bool train = grad != nullptr;
     Plan pl;
     if (kept && (!kept->buf || ((uintptr_t)kept->buf & 15))) return set_err(CFL_E_SHAPE, "theta planes buffer NULL or misaligned");
@@ -1377,6 +1411,13 @@ static int run_pairs(const CflShape *s, const CflNorm *norm, const CflLossCfg *l
             f.pos_weight = loss->pos_weight; f.caffe_margin = loss->caffe_margin; f.lambda_m = loss->lambda_m;
             f.scalars = scalars; f.thr_copy = ws + pl.thr_copy;
             f.scalars2 = xs ? xs->scalars_copy : nullptr;
+            if (dpp && !adam) {
+                // data parallel, one-shot exchange: the finished entries go straight to their owner ranks (GradFuse::dp_*)
+                f.dp_rows = dpp->rows_tab; f.dp_flags = dpp->flags_tab; f.dp_slice = dpp->slice; f.dp_world = dpp->world;
+                f.dp_gen = dpp->gen; f.dp_ticket = dpp->ticket;
+                f.scalars = dpp->scalars_remote;
+                if (pushed) *pushed = true;
+            }
         }
         ga.tps = pl.xcd ? (s->D / (pl.grad_half ? 32 : 64)) / pl.S : 0;
         dim3 grid(s->D / 64, pl.P, nj + 1);
@@ -1892,9 +1933,9 @@ extern "C" int cfl_adam_tf(float *theta, float *m, float *v, const float *grad, 
     return CFL_OK;
 }
 
-extern "C" int cfl_adam_tf_planes(const CflShape *shape, float *theta, float *m, float *v, const float *grad,
-                                  float lr_t, float beta1, float beta2, float eps, float grad_scale,
-                                  CflThetaPlanes *planes, cfl_stream_t stream) {
+static int adam_tf_planes_impl(const CflShape *shape, float *theta, float *m, float *v, const float *grad,
+                              float lr_t, float beta1, float beta2, float eps, float grad_scale,
+                              CflThetaPlanes *planes, const float *scal_src, float *scal_dst, cfl_stream_t stream) {
     if (!theta || !m || !v || !grad) return set_err(CFL_E_SHAPE, "NULL pointer");
     if (planes && (!planes->buf || ((uintptr_t)planes->buf & 15))) return set_err(CFL_E_SHAPE, "theta planes buffer NULL or misaligned");
     ThetaPlaneRegions pr;
@@ -1909,10 +1950,165 @@ extern "C" int cfl_adam_tf_planes(const CflShape *shape, float *theta, float *m,
     {
         ProfScope ps((hipStream_t)stream, CFL_K_ADAM);
         hipLaunchKernelGGL(cfl_adam_planes_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, theta, m,
-                           v, grad, n4, lr_t, beta1, beta2, eps, grad_scale, pr);
+                           v, grad, n4, lr_t, beta1, beta2, eps, grad_scale, pr, scal_src, scal_dst);
     }
     HIP_TRY(hipGetLastError());
     if (planes) planes->valid = 1;
+    return CFL_OK;
+}
+
+extern "C" int cfl_adam_tf_planes(const CflShape *shape, float *theta, float *m, float *v, const float *grad,
+                                  float lr_t, float beta1, float beta2, float eps, float grad_scale,
+                                  CflThetaPlanes *planes, cfl_stream_t stream) {
+    return adam_tf_planes_impl(shape, theta, m, v, grad, lr_t, beta1, beta2, eps, grad_scale, planes, nullptr, nullptr, stream);
+}
+
+// ===========================================================================================================================
+// ABI 6: the whole data-parallel step behind one call (include/cfl_hip.h)
+// ===========================================================================================================================
+#define CFL_GRADBUF_PAD 64    // gradbuf = [cfl_layout.total floats of gradient | 16 scalars | 48 pad]
+
+static int dp_check(const CflShape *shape, const CflLossCfg *loss, const float *theta, const float *m, const float *v,
+                    const float *gradbuf, const CflDpExchange *ex, const CflAllReduce *ar, CflLayout *lay) {
+    if (!loss || !theta || !m || !v || !gradbuf) return set_err(CFL_E_SHAPE, "NULL pointer");
+    if (loss->caffe_margin != 0.f && loss->lambda_m != 0.f)
+        return set_err(CFL_E_SHAPE, "caffe_margin and lambda_m are exclusive (cfl/utils.py:72-73)");
+    if (ex && ar) return set_err(CFL_E_SHAPE, "one exchange at most: CflDpExchange or CflAllReduce");
+    int rc = cfl_layout(shape, lay);
+    if (rc) return rc;
+    if (ex && (ex->n_adam != lay->total || ex->n != lay->total + CFL_GRADBUF_PAD))
+        return set_err(CFL_E_SHAPE, "CflDpExchange: n_adam=%lld n=%lld do not match the shape (%lld parameters + %d)",
+                       (long long)ex->n_adam, (long long)ex->n, (long long)lay->total, CFL_GRADBUF_PAD);
+    if (ar && (!ar->fn || !ar->comm || ar->world < 1)) return set_err(CFL_E_SHAPE, "CflAllReduce: NULL entry point / communicator");
+    return CFL_OK;
+}
+
+// forward / backward of this rank's rows (+ the fused push when the exchange has device tables and the plan a fused tail),
+// the exchange, the update.  xs: extra scoring rows (their scalars copy is written by the exchange's LAST kernel: global sums)
+static int dp_one_step(const CflShape *shape, const CflNorm *norm, const CflLossCfg *loss, const float *const *x4,
+                       const IndexSrc *isrc, int64_t rows, const CflLayout &lay, float *theta, float *m, float *v, float *gradbuf,
+                       float lr_t, float beta1, float beta2, float eps, CflThetaPlanes *planes, CflDpExchange *ex,
+                       const CflAllReduce *ar, void *workspace, size_t workspace_bytes, const ExtraSrc *xs, hipStream_t st) {
+    float *scalars = gradbuf + lay.total;
+    DpPush dpp;
+    const DpPush *use = nullptr;
+    if (ex && ex->dev_tables && debug_env("CFL_DP_PUSH_SEPARATE") <= 0) {
+        const int par = (int)(ex->step & 1);
+        void *const *tab = (void *const *)ex->dev_tables;
+        dpp.rows_tab = (float *const *)(tab + (size_t)(par * 2 + 0) * CFL_DP_MAX_WORLD);
+        dpp.flags_tab = (unsigned *const *)(tab + (size_t)(par * 2 + 1) * CFL_DP_MAX_WORLD);
+        dpp.slice = ex->slice; dpp.world = ex->world;
+        const uint32_t g = (uint32_t)((ex->step + 1) & 0xffffffffu);
+        dpp.gen = g ? g : 1u;
+        dpp.ticket = ex->tickets;
+        const int64_t owner = lay.total / ex->slice;          // (n > total: the scalars always have an owner)
+        dpp.scalars_remote = ex->peer_rows[par][owner] + (lay.total - owner * ex->slice);
+        use = &dpp;
+    }
+    ExtraSrc xl;
+    float *scalars_copy = nullptr;
+    if (xs) { xl = *xs; scalars_copy = xl.scalars_copy; xl.scalars_copy = nullptr; }
+    bool pushed = false;
+    int rc = run_pairs(shape, norm, loss, x4, 2, rows, theta, gradbuf, scalars, nullptr, nullptr, workspace, workspace_bytes, st,
+                       nullptr, isrc, planes, xs ? &xl : nullptr, use, &pushed);
+    if (rc) return rc;
+    if (ex) return cfl_dp_exchange_step(shape, ex, pushed ? 1 : 0, theta, m, v, gradbuf, lr_t, beta1, beta2, eps, planes,
+                                        scalars_copy, (cfl_stream_t)st);
+    float scale = 1.f;
+    if (ar) {
+        const int nrc = ar->fn(gradbuf, gradbuf, (size_t)(lay.total + CFL_GRADBUF_PAD), ar->dtype, ar->op, ar->comm, (void *)st);
+        if (nrc) return set_err(CFL_E_HIP, "the caller's all-reduce returned %d", nrc);
+        scale = 1.f / (float)ar->world;
+    }
+    return adam_tf_planes_impl(shape, theta, m, v, gradbuf, lr_t, beta1, beta2, eps, scale, planes,
+                               scalars_copy ? scalars : nullptr, scalars_copy, (cfl_stream_t)st);
+}
+
+extern "C" int cfl_dp_push_fusable(const CflShape *shape, int64_t rows) {
+    Plan pl;
+    if (make_plan(shape, rows, 2, true, true, &pl)) return 0;
+    return pl.fused ? 1 : 0;
+}
+
+extern "C" int cfl_pair_dp_step_planes(const CflShape *shape, const CflNorm *norm, const CflLossCfg *loss, const float *const x4[4],
+                                       int64_t B, float *theta, float *m, float *v, float *gradbuf, float lr_t, float beta1,
+                                       float beta2, float eps, CflThetaPlanes *planes, CflDpExchange *ex, const CflAllReduce *ar,
+                                       void *workspace, size_t workspace_bytes, cfl_stream_t stream) {
+    CflLayout lay;
+    int rc = dp_check(shape, loss, theta, m, v, gradbuf, ex, ar, &lay);
+    if (rc) return rc;
+    if (!x4) return set_err(CFL_E_SHAPE, "x4 is NULL");
+    return dp_one_step(shape, norm, loss, x4, nullptr, B, lay, theta, m, v, gradbuf, lr_t, beta1, beta2, eps, planes, ex, ar,
+                       workspace, workspace_bytes, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int cfl_pair_dp_step_idx_planes(const CflShape *shape, const CflNorm *norm, const CflLossCfg *loss, const float *table,
+                                           int64_t table_rows, const int32_t *const idx4[4], int64_t idx_stride, int64_t B,
+                                           float *theta, float *m, float *v, float *gradbuf, float lr_t, float beta1, float beta2,
+                                           float eps, CflThetaPlanes *planes, CflDpExchange *ex, const CflAllReduce *ar,
+                                           void *workspace, size_t workspace_bytes, cfl_stream_t stream) {
+    CflLayout lay;
+    int rc = dp_check(shape, loss, theta, m, v, gradbuf, ex, ar, &lay);
+    if (rc) return rc;
+    IndexSrc is = {table, table_rows, idx4, idx_stride};
+    return dp_one_step(shape, norm, loss, nullptr, &is, B, lay, theta, m, v, gradbuf, lr_t, beta1, beta2, eps, planes, ex, ar,
+                       workspace, workspace_bytes, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int cfl_pair_dp_steps_idx_planes(
+    const CflShape *shape, const CflNorm *norm, const CflLossCfg *loss, const float *table, int64_t table_rows,
+    const int32_t *pos_pairs, int64_t n_pos, const int32_t *neg_pairs, int64_t n_neg, int64_t pos_head, int64_t neg_head,
+    int64_t batch_rows, int64_t shard_lo, int64_t rows, const uint8_t *switched, int64_t nsteps,
+    const float *val_table, int64_t val_table_rows, const int32_t *val_pos_pairs, int64_t n_val_pos,
+    const int32_t *val_neg_pairs, int64_t n_val_neg, int64_t val_pos_head, int64_t val_neg_head, int64_t val_batch_rows,
+    const uint8_t *val_switched, const uint8_t *val_mask, float *const *ring_slots,
+    float *theta, float *m, float *v, float *gradbuf, float lr, float beta1, float beta2, float eps,
+    float *beta1_power, float *beta2_power, CflThetaPlanes *planes, CflDpExchange *ex, const CflAllReduce *ar,
+    void *workspace, size_t workspace_bytes, cfl_stream_t stream) {
+    CflLayout lay;
+    int rc = dp_check(shape, loss, theta, m, v, gradbuf, ex, ar, &lay);
+    if (rc) return rc;
+    if (!pos_pairs || !neg_pairs || !beta1_power || !beta2_power) return set_err(CFL_E_SHAPE, "NULL pointer");
+    if (nsteps <= 0 || batch_rows <= 0 || rows <= 0 || shard_lo < 0 || shard_lo + rows > batch_rows || pos_head < 0 || neg_head < 0)
+        return set_err(CFL_E_SHAPE, "bad step window");
+    int64_t nval = 0;
+    if (val_mask) {
+        if (!ring_slots || !val_pos_pairs || !val_neg_pairs || !val_table || val_batch_rows <= 0 || val_pos_head < 0 || val_neg_head < 0)
+            return set_err(CFL_E_SHAPE, "validation fetch: NULL pointer / bad window");
+        for (int64_t i = 0; i < nsteps; ++i) nval += val_mask[i] ? 1 : 0;
+        for (int64_t k = 0; k < nval; ++k)
+            if (!ring_slots[k]) return set_err(CFL_E_SHAPE, "ring slot %lld is NULL", (long long)k);
+    }
+    if (nsteps > (1ll << 40) / batch_rows || pos_head + nsteps * batch_rows > n_pos || neg_head + nsteps * batch_rows > n_neg ||
+        (nval && (val_pos_head + nval * val_batch_rows > n_val_pos || val_neg_head + nval * val_batch_rows > n_val_neg)))
+        return set_err(CFL_E_SHAPE, "step window runs past the pair lists");
+    float b1p = *beta1_power, b2p = *beta2_power;
+    int64_t k = 0;
+    for (int64_t i = 0; i < nsteps; ++i) {
+        const int32_t *ps = pos_pairs + 2 * (pos_head + i * batch_rows + shard_lo);
+        const int32_t *ng = neg_pairs + 2 * (neg_head + i * batch_rows + shard_lo);
+        const int c0 = (switched && switched[i]) ? 1 : 0;
+        const int32_t *idx4[4] = {ps + c0, ps + (1 - c0), ng + c0, ng + (1 - c0)};
+        const float lr_t = lr * sqrtf(1.f - b2p) / (1.f - b1p);
+        IndexSrc is = {table, table_rows, idx4, 2};
+        ExtraSrc xs;
+        const bool val = val_mask && val_mask[i];
+        if (val) {
+            const int32_t *vp = val_pos_pairs + 2 * (val_pos_head + k * val_batch_rows);
+            const int32_t *vn = val_neg_pairs + 2 * (val_neg_head + k * val_batch_rows);
+            const int v0 = (val_switched && val_switched[k]) ? 1 : 0;
+            xs = {val_table, val_table_rows, {vp + v0, vp + (1 - v0), vn + v0, vn + (1 - v0)}, 2, val_batch_rows,
+                  ring_slots[k] + CFL_S_COUNT, ring_slots[k]};
+            ++k;
+        }
+        rc = dp_one_step(shape, norm, loss, nullptr, &is, rows, lay, theta, m, v, gradbuf, lr_t, beta1, beta2, eps, planes, ex, ar,
+                         workspace, workspace_bytes, val ? &xs : nullptr, (hipStream_t)stream);
+        if (rc) return rc;
+        b1p *= beta1;
+        b2p *= beta2;
+    }
+    *beta1_power = b1p;
+    *beta2_power = b2p;
     return CFL_OK;
 }
 

@@ -229,7 +229,11 @@ extern "C" __global__ __launch_bounds__(256) void cfl_adam_kernel(float *theta, 
 extern "C" __global__ __launch_bounds__(256) void cfl_adam_planes_kernel(float *theta, float *m, float *v,
                                                                         const float *grad, long long n4,
                                                                         float lr_t, float b1, float b2,
-                                                                        float eps, float gscale, ThetaPlaneRegions pr) {
+                                                                        float eps, float gscale, ThetaPlaneRegions pr,
+                                                                        const float *scal_src, float *scal_dst) {
+    // (data-parallel loop with the validation fetch inside: the 16 global scalar sums behind the gradient also go to the caller's
+    // pinned ring slot -- no copy command on the stream; both NULL everywhere else)
+    if (scal_dst && blockIdx.x == 0 && threadIdx.x < 16) scal_dst[threadIdx.x] = scal_src[threadIdx.x];
     long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     const long long stride = (long long)gridDim.x * 256;
     for (; i < n4; i += stride) {

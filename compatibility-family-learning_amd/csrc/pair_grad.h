@@ -100,7 +100,42 @@ struct GradFuse {
     float *scalars;
     float *scalars2;             // a second destination of the step's scalars (nullptr: none)
     const float *thr_copy;
+    // DATA-PARALLEL one-shot exchange with the reduce-scatter FUSED into this launch (round 6; csrc/cfl_dp.hip): every finished
+    // entry of [gradient | scalars] goes straight into the OWNER rank's slot array instead of the local flat buffer -- element
+    // `off` belongs to rank off / dp_slice, and dp_rows[r] (a table in DEVICE memory: a dynamically indexed array inside this
+    // argument block would send the whole block to scratch) is where THIS rank's row of rank r's slot array is mapped.  Every
+    // workgroup of the launch ends with grad_dp_block_done(): system-scope fence, one count on dp_ticket; the last one raises
+    // this rank's arrival flag in every peer (dp_flags[r], generation dp_gen).  dp_slice == 0: off (every other caller).
+    float *const *dp_rows;
+    unsigned *const *dp_flags;
+    long long dp_slice;
+    int dp_world;
+    unsigned dp_gen;
+    unsigned *dp_ticket;
 };
+
+// where gradient entry `off` (and, past the parameters, the step's scalars) is stored: the flat buffer, or the owner's slot
+__device__ __forceinline__ float *fuse_grad_ptr(const GradFuse &f, long long off) {
+    if (f.dp_slice == 0) return f.grad + off;
+    const unsigned s = (unsigned)off / (unsigned)f.dp_slice;       // (off < 2^31: make_plan rejects larger layouts)
+    return f.dp_rows[s] + (off - (long long)s * f.dp_slice);
+}
+
+// end of EVERY workgroup of a weight-gradient launch with the fused push (no-op otherwise; uniform branch)
+__device__ __forceinline__ void grad_dp_block_done(const GradFuse &f) {
+    if (f.dp_slice == 0) return;
+    __threadfence_system();            // this thread's stores into the peers' slots are visible system-wide before the count
+    __syncthreads();
+    __shared__ unsigned dp_last;
+    if (threadIdx.x == 0) dp_last = atomicAdd(f.dp_ticket, 1u) == gridDim.x * gridDim.y * gridDim.z - 1u ? 1u : 0u;
+    __syncthreads();
+    if (dp_last) {
+        __threadfence_system();
+        if ((int)threadIdx.x < f.dp_world)
+            __hip_atomic_store(f.dp_flags[threadIdx.x], f.dp_gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (threadIdx.x == 0) *f.dp_ticket = 0;   // the next launch on this stream starts from zero
+    }
+}
 
 struct GradArgs {
     GradJob job[CFL_MAX_JOBS];
@@ -215,7 +250,7 @@ __device__ __forceinline__ void fuse_apply(const GradFuse &f, long long off, f32
 #pragma unroll
         for (int e = 0; e < 4; ++e) gr[e] = fmaf(f.reg_const, th[e], gr[e]);
     }
-    *(f32x4 *)(f.grad + off) = gr;
+    *(f32x4 *)fuse_grad_ptr(f, off) = gr;
     if (f.m) {
         adam4(th, mm, vv, gr, f.lr_t, f.b1, f.b2, f.eps);
         *(f32x4 *)(f.m + off) = mm;
@@ -522,7 +557,7 @@ __device__ __forceinline__ void write_scalars(float *o, const float *sc, float r
 __device__ __forceinline__ void fuse_apply1(const GradFuse &f, long long off, float gr, bool reg) {
     float th = f.theta[off];
     if (reg && f.reg_const != 0.f) gr = fmaf(f.reg_const, th, gr);
-    f.grad[off] = gr;
+    *fuse_grad_ptr(f, off) = gr;
     if (f.m) {
         float mm = f.m[off], vv = f.v[off];
         adam1(th, mm, vv, gr, f.lr_t, f.b1, f.b2, f.eps);
@@ -678,7 +713,7 @@ __device__ __forceinline__ void grad_red_block(const GradArgs &a, float *lds) { 
 #pragma unroll
                         for (int e = 0; e < 4; ++e) gr[e] = fmaf(f.reg_const, th[e], gr[e]);
                     }
-                    *(f32x4 *)(f.grad + off) = gr;
+                    *(f32x4 *)fuse_grad_ptr(f, off) = gr;
                     if (f.m) {
                         f32x4 mm = *(const f32x4 *)(f.m + off), vv = *(const f32x4 *)(f.v + off), tn = th;
                         adam4(tn, mm, vv, gr, f.lr_t, f.b1, f.b2, f.eps);
@@ -755,7 +790,7 @@ extern "C" __global__ __launch_bounds__(256) void cfl_grad_kernel(GradArgs a_) {
     CFL_KERNARG_IN_PLACE(GradArgs, a, a_);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     f32x4 *lds = (f32x4 *)smem;
-    if (blockIdx.z == 0) { grad_red_block(a, (float *)smem); return; }
+    if (blockIdx.z == 0) { grad_red_block(a, (float *)smem); grad_dp_block_done(a.fuse); return; }
     const GradJob &jb = a.job[blockIdx.z - 1];
     switch (jb.nt) {
         case 1: grad_body<1>(jb, a, lds); break;
@@ -763,6 +798,7 @@ extern "C" __global__ __launch_bounds__(256) void cfl_grad_kernel(GradArgs a_) {
         case 3: grad_body<3>(jb, a, lds); break;
         default: grad_body<4>(jb, a, lds); break;
     }
+    grad_dp_block_done(a.fuse);
 }
 
 // ---------------------------------------------------------------------------
@@ -1148,7 +1184,7 @@ extern "C" __global__ __launch_bounds__(256) void cfl_grad_x3_half_kernel(GradAr
     CFL_KERNARG_IN_PLACE(GradArgs, a, a_);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     f32x4 *lds = (f32x4 *)smem;
-    if (blockIdx.z == 0) { grad_red_block(a, (float *)smem); return; }
+    if (blockIdx.z == 0) { grad_red_block(a, (float *)smem); grad_dp_block_done(a.fuse); return; }
     const GradJob &jb = a.job[blockIdx.z - 1];
     const int job = (int)blockIdx.z - 1, dt = grad_dtile(a.tps);
     switch (jb.nt) {
@@ -1157,6 +1193,7 @@ extern "C" __global__ __launch_bounds__(256) void cfl_grad_x3_half_kernel(GradAr
         case 3: grad_body_x3_half<3, false>(jb, a, lds, job, dt, 0); break;
         default: grad_body_x3_half<4, false>(jb, a, lds, job, dt, 0); break;
     }
+    grad_dp_block_done(a.fuse);
 }
 
 // the same tile with EIGHT waves (two per SIMD, half the rows each): the headline plan (CFL_DEBUG_GRAD_W8=-1: four waves)
@@ -1167,6 +1204,7 @@ extern "C" __global__ __launch_bounds__(512) void cfl_grad_x3_half_w8_kernel(Gra
     if (blockIdx.z == 0) {
         if (threadIdx.x >= 256) return;   // (the reduction blocks are written for four waves; a finished wave does not count at a barrier)
         grad_red_block(a, (float *)smem);
+        grad_dp_block_done(a.fuse);
         return;
     }
     const GradJob &jb = a.job[blockIdx.z - 1];
@@ -1177,6 +1215,7 @@ extern "C" __global__ __launch_bounds__(512) void cfl_grad_x3_half_w8_kernel(Gra
         case 3: grad_body_x3_half<3, false, 8>(jb, a, lds, job, dt, 0); break;
         default: grad_body_x3_half<4, false, 8>(jb, a, lds, job, dt, 0); break;
     }
+    grad_dp_block_done(a.fuse);
 }
 
 // ... with a row split (grid y = P row ranges) and / or the siamese pairing: hand-off tail
@@ -1184,7 +1223,7 @@ extern "C" __global__ __launch_bounds__(256) void cfl_grad_x3_half_split_kernel(
     CFL_KERNARG_IN_PLACE(GradArgs, a, a_);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     f32x4 *lds = (f32x4 *)smem;
-    if (blockIdx.z == 0) { grad_red_block(a, (float *)smem); return; }
+    if (blockIdx.z == 0) { grad_red_block(a, (float *)smem); grad_dp_block_done(a.fuse); return; }
     const GradJob &jb = a.job[blockIdx.z - 1];
     const int job = (int)blockIdx.z - 1, dt = grad_dtile(a.tps);
     switch (jb.nt) {
@@ -1193,6 +1232,7 @@ extern "C" __global__ __launch_bounds__(256) void cfl_grad_x3_half_split_kernel(
         case 3: grad_body_x3_half<3, true>(jb, a, lds, job, dt, (int)blockIdx.y); break;
         default: grad_body_x3_half<4, true>(jb, a, lds, job, dt, (int)blockIdx.y); break;
     }
+    grad_dp_block_done(a.fuse);
 }
 
 // Two kernels rather than one with both bodies: eight inlined instantiations make the compiler keep `a` on the
@@ -1200,7 +1240,7 @@ extern "C" __global__ __launch_bounds__(256) void cfl_grad_x3_half_split_kernel(
 template <bool STAGED>
 __device__ __forceinline__ void grad_x3_kernel_body(const GradArgs &a, char *smem) {
     f32x4 *lds = (f32x4 *)smem;
-    if (blockIdx.z == 0) { grad_red_block(a, (float *)smem); return; }
+    if (blockIdx.z == 0) { grad_red_block(a, (float *)smem); grad_dp_block_done(a.fuse); return; }
     const GradJob &jb = a.job[blockIdx.z - 1];
     switch (jb.nt) {
         case 1: grad_body_x3<1, STAGED>(jb, a, lds); break;
@@ -1208,6 +1248,7 @@ __device__ __forceinline__ void grad_x3_kernel_body(const GradArgs &a, char *sme
         case 3: grad_body_x3<3, STAGED>(jb, a, lds); break;
         default: grad_body_x3<4, STAGED>(jb, a, lds); break;
     }
+    grad_dp_block_done(a.fuse);
 }
 
 extern "C" __global__ __launch_bounds__(256) void cfl_grad_x3_kernel(GradArgs a_) {   // Rpad / P <= 8192

@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define CFL_ABI_VERSION 5
+#define CFL_ABI_VERSION 6
 
 /* error codes */
 #define CFL_OK 0
@@ -570,7 +570,7 @@ int cfl_auc(const float *scores_pos, int64_t n_pos, const float *scores_neg, int
  * CFL_K_COUNT entries and clears the record list.  Not for production steps.   */
 enum {
     CFL_K_COLNORM = 0, CFL_K_PROJ, CFL_K_MID, CFL_K_GRAD, CFL_K_FINALIZE,
-    CFL_K_ADAM, CFL_K_GATHER, CFL_K_COUNT = 8
+    CFL_K_ADAM, CFL_K_GATHER, CFL_K_DP /* the kernels of the one-shot exchange (ABI 6) */, CFL_K_COUNT = 8
 };
 int cfl_profile_enable(int on);
 int cfl_profile_read(double *ms_sum, int64_t *launches);
@@ -623,6 +623,94 @@ int cfl_dp_rs_gather(float *theta, float *sum_out, const float *stage, const uin
 int cfl_dp_rs_gather_planes(const CflShape *shape, float *theta, float *sum_out, const float *stage, const uint32_t *flags,
                             int32_t world, int32_t rank, int64_t n, int64_t n_adam, int64_t slice, uint32_t generation,
                             int32_t *lost, double timeout_s, CflThetaPlanes *planes, cfl_stream_t stream);
+
+/* ---- ABI 6: the WHOLE data-parallel step behind one call ------------------------------------------------------------
+ * Round 6.  The reference is single-device; SURVEY 8(e) / BASELINE north_star ask for row shards + one
+ * gradient exchange per step.  Until ABI 5 the host drove that step as 3-5 separate calls per iteration; from ABI 6 one call
+ * runs K iterations of
+ *
+ *   proj -> mid -> grad (fused tail emits [gradient | scalars])  ->  exchange  ->  TF-Adam (+ planes)
+ *
+ * with either exchange:
+ *   CflDpExchange  the one-shot exchange above with its reduce-scatter FUSED into the weight-gradient launch: the tile
+ *                  finishers store their finished gradient entries straight into the owner rank's slot array (peer memory)
+ *                  and the launch's last workgroup raises this rank's arrival flags -- no cfl_dp_rs_push launch, no flat
+ *                  gradient round trip: proj, mid, grad(+push), cfl_dp_rs_adam, cfl_dp_rs_gather_planes = 5 launches;
+ *   CflAllReduce   a caller-supplied all-reduce (signature of ncclAllReduce: the caller passes RCCL's entry point and its
+ *                  communicator, the library does not link RCCL) enqueued on the launch stream between the weight-gradient
+ *                  launch and cfl_adam_tf_planes: 3 launches + the collective + 1;
+ *   neither        no exchange at all (a one-rank group; "step without collective" measurements).
+ */
+#define CFL_DP_MAX_WORLD 16
+typedef struct {
+    int32_t world, rank;
+    int64_t n, n_adam, slice;                      /* floats: exchanged buffer, parameters (cfl_layout.total), per-rank slice */
+    /* everything below is per step parity p = step & 1 (double buffering, csrc/cfl_dp.hip) */
+    float *slots[2];                               /* LOCAL slot array [world][slice] */
+    float *stage[2];                               /* LOCAL stage buffer [n] */
+    uint32_t *flags_a[2], *flags_b[2];             /* LOCAL flag words [world] */
+    float *peer_rows[2][CFL_DP_MAX_WORLD];         /* row `rank` of rank r's slot array, mapped here ([rank] = the local one) */
+    float *peer_stage[2][CFL_DP_MAX_WORLD];        /* rank r's stage buffer, mapped here */
+    uint32_t *peer_flag_a[2][CFL_DP_MAX_WORLD];    /* word `rank` of rank r's A / B flag arrays, mapped here */
+    uint32_t *peer_flag_b[2][CFL_DP_MAX_WORLD];
+    /* DEVICE copy of {peer_rows[p], peer_flag_a[p]} for the fused push: void *[2 parities][2 kinds][CFL_DP_MAX_WORLD],
+     * kind 0 = rows, kind 1 = A flags (512 bytes; the caller fills it once).  NULL: the push stays a launch of its own */
+    void *dev_tables;
+    uint32_t *tickets;                             /* device, 4 zeroed words ([0] push / fused push, [1] Adam) */
+    int32_t *lost;                                 /* set to 1 by a kernel whose bounded wait gave up (pinned host or device) */
+    double timeout_s;
+    uint64_t step;                                 /* exchanges so far (parity / generation); ADVANCED BY THE LIBRARY */
+} CflDpExchange;
+
+typedef int (*cfl_allreduce_fn)(const void *sendbuf, void *recvbuf, size_t count, int dtype, int op, void *comm, void *stream);
+typedef struct {
+    cfl_allreduce_fn fn;                           /* ncclAllReduce of the librccl.so the process already uses */
+    void *comm;                                    /* ncclComm_t */
+    int32_t dtype, op;                             /* ncclFloat32 (7), ncclSum (0) */
+    int32_t world;                                 /* ranks (the gradient / scalar sums are divided by it) */
+} CflAllReduce;
+
+/* The exchange + update of ONE step on `gradbuf` = this rank's [gradient | scalars | pad] (n floats): with `pushed` != 0 the
+ * weight-gradient launch has already stored it into the owners' slots (fused push); otherwise cfl_dp_rs_push runs first.
+ * Then cfl_dp_rs_adam and cfl_dp_rs_gather_planes.  scalars_copy (nullable, device-accessible, 16 floats): a second copy of
+ * the global scalar SUMS (divide by world).  Advances ex->step.                                                        */
+int cfl_dp_exchange_step(const CflShape *shape, CflDpExchange *ex, int32_t pushed, float *theta, float *m, float *v,
+                         float *gradbuf, float lr_t, float beta1, float beta2, float eps, CflThetaPlanes *planes,
+                         float *scalars_copy, cfl_stream_t stream);
+/* workspace of a training call of `rows` rows per group that carries a validation batch of `val_rows` pairs per group
+ * (cfl_pair_train_val_steps_idx_planes / cfl_pair_dp_steps_idx_planes: a data-parallel rank trains its shard but scores the
+ * whole validation batch, val_rows > rows); >= cfl_workspace_bytes(shape, rows, 2).  0 on error.                         */
+size_t cfl_workspace_bytes_val(const CflShape *shape, int64_t rows, int64_t val_rows);
+/* can a training call of this shape / row count push from inside its weight-gradient launch (fused tail plans)? */
+int cfl_dp_push_fusable(const CflShape *shape, int64_t rows);
+
+/* One data-parallel step on dense row blocks / on rows of a resident table (cfl_pair_step_fwd_bwd[_idx]_planes + exchange +
+ * update).  gradbuf: [cfl_layout.total floats of gradient | 16 scalars | pad to n]; theta / m / v as cfl_pair_train_step.
+ * Exactly one of ex / ar may be non-NULL (both NULL: no exchange, plain cfl_adam_tf_planes).                           */
+int cfl_pair_dp_step_planes(const CflShape *shape, const CflNorm *norm, const CflLossCfg *loss, const float *const x4[4],
+                            int64_t B, float *theta, float *m, float *v, float *gradbuf, float lr_t, float beta1,
+                            float beta2, float eps, CflThetaPlanes *planes, CflDpExchange *ex, const CflAllReduce *ar,
+                            void *workspace, size_t workspace_bytes, cfl_stream_t stream);
+int cfl_pair_dp_step_idx_planes(const CflShape *shape, const CflNorm *norm, const CflLossCfg *loss, const float *table,
+                                int64_t table_rows, const int32_t *const idx4[4], int64_t idx_stride, int64_t B,
+                                float *theta, float *m, float *v, float *gradbuf, float lr_t, float beta1, float beta2,
+                                float eps, CflThetaPlanes *planes, CflDpExchange *ex, const CflAllReduce *ar,
+                                void *workspace, size_t workspace_bytes, cfl_stream_t stream);
+/* K data-parallel iterations over windows of the device pair lists: cfl_pair_train_val_steps_idx_planes with the exchange
+ * inside every iteration (this rank trains rows [shard_lo, shard_lo + rows) of every window).  val_mask == NULL: no
+ * validation fetch (the val_* arguments are ignored); otherwise the masked iterations score the next validation batch as
+ * extra rows of their own launches -- EVERY rank scores the whole batch (theta is replicated: identical scores) -- and
+ * ring_slots[k] receives [global scalar SUMS (x 1/world on the host) | scores].                                         */
+int cfl_pair_dp_steps_idx_planes(
+    const CflShape *shape, const CflNorm *norm, const CflLossCfg *loss, const float *table, int64_t table_rows,
+    const int32_t *pos_pairs, int64_t n_pos, const int32_t *neg_pairs, int64_t n_neg, int64_t pos_head, int64_t neg_head,
+    int64_t batch_rows, int64_t shard_lo, int64_t rows, const uint8_t *switched, int64_t nsteps,
+    const float *val_table, int64_t val_table_rows, const int32_t *val_pos_pairs, int64_t n_val_pos,
+    const int32_t *val_neg_pairs, int64_t n_val_neg, int64_t val_pos_head, int64_t val_neg_head, int64_t val_batch_rows,
+    const uint8_t *val_switched, const uint8_t *val_mask, float *const *ring_slots,
+    float *theta, float *m, float *v, float *gradbuf, float lr, float beta1, float beta2, float eps,
+    float *beta1_power, float *beta2_power, CflThetaPlanes *planes, CflDpExchange *ex, const CflAllReduce *ar,
+    void *workspace, size_t workspace_bytes, cfl_stream_t stream);
 
 #ifdef __cplusplus
 }

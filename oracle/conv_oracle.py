@@ -8,6 +8,7 @@ convolution layers and of the ConvPCD encoder, following
     conv2d_transpose_weight_norm  cfl/layers.py:253-361
     lrelu                         cfl/ops.py:10-12
     ConvPCD                       cfl/models/blocks.py:530-590
+    FCPCD hidden fc_i layers      cfl/models/blocks.py:509-524, cfl/layers.py:28-97
 
 PARITY: composition pinned, TensorFlow kernels unpinned (see oracle/cfl_oracle.py): the ConvPCD trunk + heads
 + losses + Adam reproduce, to float64 round-off, golden vectors produced by the reference's own CFL / ConvPCD
@@ -110,6 +111,17 @@ def init_convpcd(input_shape, rng, dtype=np.float64):
         p['conv%d/g' % (i + 1)] = np.ones(co, dtype)
         p['conv%d/b' % (i + 1)] = np.zeros(co, dtype)
     return p, feat
+
+
+def fcpcd_hidden(x, p):
+    """The hidden layers of FCPCD(layer_sizes=[...]) (cfl/models/blocks.py:516-524): fc_i = lrelu(fully_connected_weight_norm(x)),
+    y = (x . V) * (g / sqrt(sum_rows V^2)) + b  (cfl/layers.py:80-94; no epsilon), parameters fc_<i>/{V [Ci, Co], g, b}."""
+    y, i = x, 0
+    while 'fc_%d/V' % i in p:
+        V, g, b = p['fc_%d/V' % i], p['fc_%d/g' % i], p['fc_%d/b' % i]
+        y = lrelu((y @ V) * (g / torch.sqrt((V * V).sum(dim=0))) + b)
+        i += 1
+    return y
 
 
 def convpcd_features(x_flat, input_shape, p):

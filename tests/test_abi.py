@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol(H):
     lib = hipgan.lib()
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.cfl_version() == 5
+    assert lib.cfl_version() == 6
 
 
 def test_layout_is_consistent(H):

@@ -47,6 +47,41 @@ class MaskFeeder(object):
             assert left == 0, '%d masks were not consumed' % left
 
 
+class MaskedConvRun(object):
+    """the ConvPCD oracle graph (conv trunk of oracle/conv_oracle.py + heads / distance / loss of tests/test_oracle.py + TF-Adam of
+    oracle/cfl_oracle.py) in one precision, stepped with the HIP run's lrelu slope patterns imposed: parameters, Adam state, one
+    masked step.  Shared by tests/test_conv_gpu.py::test_convpcd_model_matches_oracle (the strict variable comparison)."""
+
+    def __init__(self, model, hp, thr, cfg, lcfg, shape, reg, B, dtype):
+        self.dtype, self.cfg, self.lcfg, self.shape, self.reg, self.B = dtype, cfg, lcfg, shape, reg, B
+        self.params = {'head/' + k: v.astype(dtype) for k, v in hp.items()}
+        for k, v in model.trunk.named().items():
+            self.params['conv/' + k] = v.astype(dtype)
+        self.params['thr'] = dtype(thr)
+        self.adam = O.AdamState(1e-3)
+
+    def step(self, batch, acts):
+        import tests.test_oracle as TO
+        B, shape, reg = self.B, self.shape, self.reg
+        td = torch.float64 if self.dtype is np.float64 else torch.float32
+        with MaskFeeder() as mf:
+            for part in (0, 2, 1, 3):                    # oracle order: pos_src, pos_dst, neg_src, neg_dst
+                for a in acts:
+                    mf.push('lrelu', a[part * B:(part + 1) * B])
+            tp = {k: torch.tensor(v, dtype=td, requires_grad=True) for k, v in self.params.items()}
+            cp = {k.split('/', 1)[1].replace('/Conv/', '/').replace('biases', 'b'): v
+                  for k, v in tp.items() if k.startswith('conv/')}
+            feats = [CO.convpcd_features(torch.clamp(torch.tensor(b, dtype=td), 0., 1.), shape, cp)
+                     for b in batch]
+            head = {k.split('/', 1)[1]: v for k, v in tp.items() if k.startswith('head/')}
+            total, _, _ = TO._torch_forward(self.cfg, self.lcfg, head, tp['thr'], tuple(feats))
+            total = total + sum(0.5 * reg * (v * v).sum() for k, v in cp.items() if k.endswith('/V'))
+            total.backward()
+        self.adam.apply(self.params, {k: (v.grad.numpy() if v.grad is not None else np.zeros_like(self.params[k]))
+                                      for k, v in tp.items()})
+        return float(total.detach())
+
+
 def test_convpcd_trajectory_with_equal_masks():
     """BASELINE config 0 shape (28x28x1 conv encoder, PCD K=1, latent 30, sigmoid data, reg 5e-4), 8 steps.
     With the masks of the HIP run imposed, the float64 oracle and an fp32 CPU evaluation of the SAME graph (the
@@ -73,37 +108,8 @@ def test_convpcd_trajectory_with_equal_masks():
     cfg = O.EncoderCfg(D=6272, L=L, K=K, dist_type='pcd', style='cfl')
     lcfg = O.LossCfg(reg_const=reg)
 
-    class Run(object):
-        """the oracle graph in one precision: parameters, Adam state, one masked step"""
-
-        def __init__(self, dtype):
-            self.dtype = dtype
-            self.params = {'head/' + k: v.astype(dtype) for k, v in hp.items()}
-            for k, v in model.trunk.named().items():
-                self.params['conv/' + k] = v.astype(dtype)
-            self.params['thr'] = dtype(thr)
-            self.adam = O.AdamState(1e-3)
-
-        def step(self, batch, acts):
-            td = torch.float64 if self.dtype is np.float64 else torch.float32
-            with MaskFeeder() as mf:
-                for part in (0, 2, 1, 3):                    # oracle order: pos_src, pos_dst, neg_src, neg_dst
-                    for a in acts:
-                        mf.push('lrelu', a[part * B:(part + 1) * B])
-                tp = {k: torch.tensor(v, dtype=td, requires_grad=True) for k, v in self.params.items()}
-                cp = {k.split('/', 1)[1].replace('/Conv/', '/').replace('biases', 'b'): v
-                      for k, v in tp.items() if k.startswith('conv/')}
-                feats = [CO.convpcd_features(torch.clamp(torch.tensor(b, dtype=td), 0., 1.), shape, cp)
-                         for b in batch]
-                head = {k.split('/', 1)[1]: v for k, v in tp.items() if k.startswith('head/')}
-                total, _, _ = TO._torch_forward(cfg, lcfg, head, tp['thr'], tuple(feats))
-                total = total + sum(0.5 * reg * (v * v).sum() for k, v in cp.items() if k.endswith('/V'))
-                total.backward()
-            self.adam.apply(self.params, {k: (v.grad.numpy() if v.grad is not None else np.zeros_like(self.params[k]))
-                                          for k, v in tp.items()})
-            return float(total.detach())
-
-    o64, o32 = Run(np.float64), Run(np.float32)
+    mk = lambda dtype: MaskedConvRun(model, hp, thr, cfg, lcfg, shape, reg, B, dtype)
+    o64, o32 = mk(np.float64), mk(np.float32)
     hip_err, cpu32_err = [], []
     for step in range(steps):
         batch = tuple(rng.rand(B, 784).astype(np.float32) * 1.2 - 0.1 for _ in range(4))

@@ -194,6 +194,12 @@ def test_convpcd_model_matches_oracle(B):
     params32 = {k: np.asarray(v, np.float32) for k, v in params.items()}
     lcfg = O.LossCfg(reg_const=reg)
     ser = ParitySeries('convpcd_config0_b%d' % B, floor=2e-5, meta=dict(shape=shape, B=B, steps=6, L=L, K=K, reg=reg))
+    # the STRICT comparison: a second float64 oracle is stepped beside the free-running one with the HIP
+    # run's lrelu slope patterns imposed (tests/test_activation_masks_gpu.py) -- it differs from the HIP trajectory by rounding
+    # only, not by kink flips, and the variables are held against IT entry by entry below
+    from test_activation_masks_gpu import MaskedConvRun
+    masked = MaskedConvRun(model, hp, thr, cfg, lcfg, shape, reg, B, np.float64)
+    masked_err = []
 
     def oracle_loss(p, batch, dtype=torch.float64):
         tp = {k: torch.tensor(v, dtype=dtype, requires_grad=True) for k, v in p.items()}
@@ -214,6 +220,9 @@ def test_convpcd_model_matches_oracle(B):
         ref32, grads32 = oracle_loss(params32, batch, torch.float32)
         model.train_step(batch)
         got = model.scalars()['total']
+        acts = [a.clone() for a in model.trunk._inputs[1:]]  # post-lrelu, rows [pos_src | neg_src | pos_dst | neg_dst]
+        ref_masked = masked.step(batch, acts)
+        masked_err.append(abs(got - ref_masked) / max(1.0, abs(ref_masked)))
         # fp32-vs-fp64 sign flips of near-zero lrelu pre-activations change single slopes (0.2 <-> 1), for the fp32 CPU
         # evaluation exactly as here: the free-running trajectory is held to twice the fp32 CPU twin's distance from float64
         # (tests/test_activation_masks_gpu.py: with the masks held equal the same steps agree to < 1e-4)
@@ -231,8 +240,19 @@ def test_convpcd_model_matches_oracle(B):
     ser.check()
     # variables after 6 Adam steps
     hp, _, thr = model.engine.named_variables()
+    # STRICT: against the equal-mask float64 oracle -- losses of every step within 1e-4 (fp32 rounding amplified by Adam's lr-sized
+    # first steps; the free-running bar is 5e-4), and >= 99 % of the entries of EVERY variable within 2e-5 of the tensor's scale
+    # (the rest: entries whose gradient sits at the fp32 noise level, which Adam moves by ~lr either way), none further than
+    # one Adam step per iteration
+    assert max(masked_err) <= 1e-4 and masked_err[0] <= 2e-6, ['%.1e' % e for e in masked_err]
+    for got_v, ref_v, k in [(v, masked.params['head/' + k], k) for k, v in hp.items()] + \
+                           [(v, masked.params['conv/' + k], k) for k, v in model.trunk.named().items()]:
+        d = np.abs(got_v - ref_v)
+        assert (d <= 2e-5 * max(1.0, np.abs(ref_v).max())).mean() >= 0.99, (k, float(d.max()), float((d <= 2e-5).mean()))
+        assert d.max() <= 6 * 1e-3 * 1.05, (k, float(d.max()))
+    # free-running SANITY bound (the oracle without the masks; kink flips included):
     # Adam's first steps move every weight by ~lr * sign(g): one flipped lrelu slope changes the
-    # sign of a few tiny gradients of one channel, hence a robust comparison (>= 99 % of the
+    # sign of a few tiny gradients of one channel, hence a robust comparison (>= 97 % of the
     # entries agree to 1e-4 of the tensor scale; nothing is off by more than 2 * steps * lr)
     def close(v, ref, k):
         diff, scale = np.abs(v - ref), max(1e-2, np.abs(ref).max())
@@ -246,6 +266,86 @@ def test_convpcd_model_matches_oracle(B):
     st = model.checkpoint_state()['variables']
     assert st['CFL/DistEncoder/conv2/Conv/V'].shape == (5, 5, 64, 128)
     assert st['CFL/DistEncoder/outputs/fully_connected/V'].shape == (6272, 30)
+
+
+def test_fcpcd_hidden_layers_match_oracle():
+    """FCPCD(layer_sizes=[...]) -- hidden weight-normalised fc_i + lrelu layers in front of the heads
+    (cfl/models/blocks.py:509-524; no command line of the reference sets them, the model classes take the argument).  CFL linear
+    model, D = 256, layer_sizes [128, 64], pcd K = 3, L = 10, reg 5e-4 (V of the hidden layers regularised, their biases not),
+    4 training steps on identical batches against the float64 torch-autograd oracle (oracle/conv_oracle.py::fcpcd_hidden + heads /
+    distance / loss of tests/test_oracle.py + TF-Adam): loss of step 0 within 2e-5, every step within twice the fp32 CPU
+    evaluation's distance (lrelu kinks), variables after the steps, and the checkpoint names / shapes of SURVEY App. D."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from parity_series import ParitySeries
+    import tests.test_oracle as TO
+    from cfl import ops
+    from cfl.models.cfl import construct_model
+    rng = np.random.RandomState(8)
+    D, L, K, B, reg, sizes, steps = 256, 10, 3, 16, 5e-4, [128, 64], 4
+    dn = ops.dist_normalizer((D,), None, None, None, [4.0], None, 'linear')
+    kw = dict(is_double=False, disable_double=False, latent_shape=None, source_shape=None, input_shape=(D,),
+              ae_shape=None, batch_size=B, data_norm=[4.0], data_type='linear', model_type='linear',
+              gan_type='conv', num_components=K, latent_size=L, pos_weight=0.25, caffe_margin=None, gan=False,
+              cgan=False, t_dim=None, dist_type='pcd', act_type=None, use_threshold=True, lr=1e-3, beta1=0.9,
+              beta2=0.999, z_dim=20, z_stddev=1., g_dim=64, g_lr=2e-4, g_beta1=.5, g_beta2=.999, m_prj=None,
+              m_enc=None, d_dim=64, d_lr=2e-4, d_beta1=.5, d_beta2=.999, lambda_dra=.5, lambda_gp=None,
+              lambda_m=0.0, directed=False, data_directed=False, reg_const=reg, data_normalizer=dn[0],
+              data_unnormalizer=dn[1], seed=2, layer_sizes=sizes)
+    model, _ = construct_model(**kw)
+    assert model.trunk is not None and model.trunk.feature_size == 64 and model.engine.shape.D == 64
+    model.engine.theta[model.engine.layout.thr] = 0.3
+    hp, _, thr = model.engine.named_variables()
+    cfg = O.EncoderCfg(D=64, L=L, K=K, dist_type='pcd', style='cfl')
+    lcfg = O.LossCfg(reg_const=reg, pos_weight=0.25)
+    params = {'head/' + k: v.astype(np.float64) for k, v in hp.items()}
+    for k, v in model.trunk.named().items():
+        params['fc/' + k] = v.astype(np.float64)
+    params['thr'] = np.float64(thr)
+    params32 = {k: np.asarray(v, np.float32) for k, v in params.items()}
+    adam, adam32 = O.AdamState(1e-3), O.AdamState(1e-3)
+    ser = ParitySeries('fcpcd_hidden_layers', floor=2e-5, meta=dict(D=D, B=B, steps=steps, L=L, K=K, reg=reg, layer_sizes=sizes))
+
+    def oracle_loss(p, batch, dtype=torch.float64):
+        tp = {k: torch.tensor(v, dtype=dtype, requires_grad=True) for k, v in p.items()}
+        fp = {k.split('/', 1)[1].replace('/fully_connected/', '/').replace('biases', 'b'): v
+              for k, v in tp.items() if k.startswith('fc/')}
+        feats = [CO.fcpcd_hidden(torch.tensor(b, dtype=dtype) / 4.0, fp) for b in batch]
+        head = {k.split('/', 1)[1]: v for k, v in tp.items() if k.startswith('head/')}
+        total, _, _ = TO._torch_forward(cfg, lcfg, head, tp['thr'], tuple(feats))
+        total = total + sum(0.5 * reg * (v * v).sum() for k, v in fp.items() if k.endswith('/V'))
+        total.backward()
+        return float(total), {k: (v.grad.numpy() if v.grad is not None else np.zeros_like(p[k])) for k, v in tp.items()}
+
+    for step in range(steps):
+        batch = tuple((rng.randn(B, D) * 2.0).astype(np.float32) for _ in range(4))
+        ref, grads = oracle_loss(params, batch)
+        ref32, grads32 = oracle_loss(params32, batch, torch.float32)
+        model.train_step(batch)
+        got = model.scalars()['total']
+        ser.add(step, 'total', got, ref, ref32)
+        if step == 0:
+            assert abs(got - ref) <= 2e-5 * max(1.0, abs(ref)), (got, ref)
+        adam.apply(params, grads)
+        adam32.apply(params32, {k: np.asarray(v, np.float32) for k, v in grads32.items()})
+    ser.check()
+    hp, _, _ = model.engine.named_variables()
+    for got_v, ref_v, k in [(v, params['head/' + k], k) for k, v in hp.items()] + \
+                           [(v, params['fc/' + k], k) for k, v in model.trunk.named().items()]:
+        d = np.abs(got_v - ref_v)
+        tol = max(1e-4 * max(1e-2, np.abs(ref_v).max()), 0.05 * steps * 1e-3)
+        assert np.mean(d <= tol) >= 0.97 and d.max() <= 2 * steps * 1e-3, (k, float(d.max()), float(np.mean(d <= tol)))
+    st = model.checkpoint_state()['variables']
+    assert st['CFL/DistEncoder/fc_0/fully_connected/V'].shape == (256, 128)
+    assert st['CFL/DistEncoder/fc_1/fully_connected/V'].shape == (128, 64)
+    assert st['CFL/DistEncoder/fc_1/fully_connected/biases'].shape == (64,)
+    assert st['CFL/DistEncoder/outputs/fully_connected/V'].shape == (64, 10)
+    # a checkpoint round trip restores the hidden layers too
+    st_all = model.checkpoint_state()
+    model.trunk.theta.zero_()
+    model.load_checkpoint_state(st_all)
+    assert np.array_equal(model.trunk.named()['fc_0/fully_connected/V'], st['CFL/DistEncoder/fc_0/fully_connected/V'])
 
 
 def test_exact_fp32_gemm_path_in_a_fresh_process():

@@ -193,7 +193,7 @@ def _oneshot_worker(rank, world, port, out):
         table = torch.tensor(np.abs(rng.randn(500, D)).astype(np.float32), device='cuda')
         lo, hi = engine.shard_rows(B)
         worst = 0.0
-        for it in range(100):
+        for it in range(100 if world == 2 else 24):
             idx = [torch.tensor(rng.randint(0, 500, size=B).astype(np.int32), device='cuda') for _ in range(4)]
             batch = (table, H.IndexStreams.from_tensors([i[lo:hi].contiguous() for i in idx]))
             a.step(batch)
@@ -230,6 +230,22 @@ def _oneshot_worker(rank, world, port, out):
                                                    neg[nh:nh + hi - lo, cols[0]].contiguous(), neg[nh:nh + hi - lo, cols[1]].contiguous()])
             c.step((table, streams))
         windows_equal = bool(torch.equal(b.theta, c.theta)) and b.global_step == c.global_step
+        # ... and with the validation fetch inside the iterations (round 6: every rank carries the whole validation batch as extra
+        # rows of its own launches; the ring slot gets the GLOBAL scalar sums from the exchange's last kernel): the same
+        # parameters as the plain windows, scores equal to a scoring call with the pre-update weights, scalars equal on every rank
+        vwin = Namespace(table=table, pos_pairs=neg, neg_pairs=pos, pos_head=0, neg_head=B, batch_rows=B, switched=None)
+        ring = torch.zeros(2, H.S_COUNT + 2 * B).pin_memory()
+        pre = b.scores_pos_neg(table, H.IndexStreams.from_tensors([neg[0:B, 0].contiguous(), neg[0:B, 1].contiguous(),
+                                                                   pos[B:2 * B, 0].contiguous(), pos[B:2 * B, 1].contiguous()])).cpu()
+        b.step_windows_val(win, vwin, [True, False, True], [ring[0].data_ptr(), ring[1].data_ptr()])
+        c.step_windows(win)
+        torch.cuda.synchronize()
+        val_ok = bool(torch.equal(b.theta, c.theta)) and \
+            float((ring[0, H.S_COUNT:] - pre).abs().max()) < 1e-4 * max(1.0, float(pre.abs().max()))
+        sums = ring[:, :H.S_COUNT].clone()
+        dist.all_reduce(sums, op=dist.ReduceOp.MAX)
+        val_ok = val_ok and bool(torch.equal(sums, ring[:, :H.S_COUNT])) and float(ring[1, 0]) != 0.0
+        windows_equal = windows_equal and val_ok
         th = b.theta.clone()
         dist.all_reduce(th, op=dist.ReduceOp.MAX)
         same = bool(torch.equal(th, b.theta))                 # every rank holds the same weights, bit for bit
@@ -256,6 +272,28 @@ def test_oneshot_exchange_equals_allreduce_and_windows_equal_single_steps():
         p.start()
     for p in procs:
         p.join(300)
+        assert p.exitcode == 0
+    worst, same, windows_equal, lost = out.get()
+    assert lost == 0
+    assert same and windows_equal
+    assert worst < 1e-6, worst
+
+
+def test_eight_ranks_share_one_gpu():
+    """EIGHT ranks (the size of the node the scaling bench runs on) on the one GPU -- IPC-handle fan-out to
+    seven peers, slice boundaries at n / 8 (not multiples of a weight tile), eight rows per rank, the fused push of eight
+    processes' weight-gradient launches into one another's slots, flag fan-in of eight -- against the all-reduce path: same
+    parameters / owned gradient sums / scalars to 1e-6, identical parameters on every rank, no lost hand-off, windowed
+    iterations (with the validation fetch) equal to single steps."""
+    world = 8
+    ctx = mp.get_context('spawn')
+    out = ctx.SimpleQueue()
+    port = 37500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_oneshot_worker, args=(r, world, port, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(900)
         assert p.exitcode == 0
     worst, same, windows_equal, lost = out.get()
     assert lost == 0

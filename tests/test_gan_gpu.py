@@ -286,6 +286,47 @@ def test_stream_placement_trial_leaves_the_trajectory_alone():
         assert a['beta1_power'] == b['beta1_power']
 
 
+def test_gradient_penalty_chain_forks_only_behind_prepared_caches():
+    """the gradient-penalty chain may run its own discriminator forward beside the main stream's only when
+    every layer cache was rebuilt AHEAD for the current weights (_Net.caches_prepared) -- the caches' validity bits are host
+    state shared by all streams.  First step after construction and after load_state: not prepared, X_hat rides in the batched
+    forward; from the second step on: prepared.  Both forms give the same step bit for bit (three steps, every scalar, every
+    variable and Adam slot)."""
+    G, GB, M, GO, _ = _mods()
+    B, Ld, zd, shape = 4, 6, 5, (16, 16, 3)
+    rng = np.random.RandomState(7)
+    N = int(np.prod(shape))
+    batches = [[np.tanh(rng.randn(B, N)), 0.3 * rng.randn(B, Ld), 0.3 * rng.randn(B, Ld), 0.3 * rng.randn(B, Ld),
+                0.3 * rng.randn(B, Ld), rng.randn(B, zd), rng.rand(B, 1)] for _ in range(3)]
+    runs = []
+    before = (M.GanPhase.tune_streams, M.GanPhase.gp_early)
+    try:
+        M.GanPhase.tune_streams = False
+        for early in (False, True):
+            M.GanPhase.gp_early = early
+            ph = M.GanPhase('srgan', shape, 'tanh', zd, Ld, B, torch.device('cuda'), np.random.RandomState(0), lambda_gp=0.5,
+                            lambda_dra=0.5, m_enc=0.05, m_prj=0.2)
+            assert not ph.disc.caches_prepared()                 # nothing was ever built
+            scal, prepared = [], []
+            for b in batches:
+                prepared.append(ph.disc.caches_prepared())
+                ph.step(*[_dev(x) for x in b])
+                scal.append(ph.scalars.detach().cpu().numpy().copy())
+            torch.cuda.synchronize()
+            assert prepared == [False, True, True], prepared     # (the optimizer step prepares the next step's caches)
+            st = ph.state()
+            ph.load_state(st)                                    # weights replaced: stale until the next preparation
+            assert not ph.disc.caches_prepared()
+            runs.append((scal, st))
+    finally:
+        M.GanPhase.tune_streams, M.GanPhase.gp_early = before
+    (s0, st0), (s1, st1) = runs
+    assert all(np.array_equal(a, b) for a, b in zip(s0, s1))
+    for net in ('generator', 'discriminator'):
+        for part in ('variables', 'adam_m', 'adam_v'):
+            assert all(np.array_equal(st0[net][part][k], st1[net][part][k]) for k in st0[net][part])
+
+
 def test_conditional_discriminator_srgan_64():
     """SRDiscriminator with the cgan condition tiled in at stage 3 (64x64 images) and fc_t: forward, parameter
     and input gradients against the oracle."""

@@ -136,14 +136,16 @@ STEP_CASES = [
 ]
 
 
-# Per-case gradient bars (round 4): the worst per-tensor error of every STEP_CASE (relative to the tensor's scale as
-# defined in the test) is recorded in profiles/r04_step_grad_errors.json by a run with CFL_RECORD_GRAD_ERRORS=<path>;
-# the test caps each case at twice its recorded worst, floored at GRAD_FLOOR (the kernels are bit-reproducible run to
-# run, so the factor 2 only covers compiler / plan changes).  A case without a record fails: record it first.
-GRAD_ERR_FILE = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'profiles',
-                             'r04_step_grad_errors.json')
+# Gradient bars.  TWO assertions per STEP_CASE and tensor:
+#  * HARD_GRAD_CEILING -- a FIXED fp32-level ceiling (5e-6 of the tensor's scale), independent of anything the path under test
+#    has ever produced: this is the parity bar.  Every case is held to it whatever the recorded file says.
+#  * a regression guard: twice the case's worst error as recorded ONCE in tests/golden/step_grad_errors.json (commit 8ef9e1b,
+#    round 4; 2.5e-7 ... 1.5e-6, floor GRAD_FLOOR).  The kernels are bit-reproducible run to run, so the factor 2 only covers
+#    compiler / plan changes; re-recording the file can loosen THIS bar, never the ceiling.
+GRAD_ERR_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'step_grad_errors.json')
 GRAD_FLOOR = 1e-6
-UNRECORDED_GRAD_CAP = 5e-6      # a STEP_CASE without an entry in the recorded-error file (profiles/r04_step_grad_errors.json)
+HARD_GRAD_CEILING = 5e-6
+UNRECORDED_GRAD_CAP = HARD_GRAD_CEILING      # a STEP_CASE without a recorded entry: the ceiling alone
 
 
 def _case_id(style, dist, D, L, K, act, B, lkw, directed):
@@ -223,7 +225,9 @@ def test_step_fwd_bwd(style, dist, D, L, K, act, B, nv, lkw, directed):
     # CFL_RECORD_GRAD_ERRORS=<file> to get its own bar (2 x observed)
     cap = max(2.0 * caps[cid]['worst'], GRAD_FLOOR) if cid in caps else UNRECORDED_GRAD_CAP
     for k, e in observed.items():
-        assert e <= cap, (cid, k, e, cap)
+        if not fuzz_cap:
+            assert e <= HARD_GRAD_CEILING, (cid, k, e, 'fixed fp32-level ceiling')     # the parity bar: independent of the path under test
+        assert e <= cap, (cid, k, e, cap)                                               # regression guard (recorded once)
 
 
 def test_full_size_properties():

@@ -260,7 +260,7 @@ def test_scalar_every_flag_and_read_back_cadence():
             self.steps += win.nsteps
 
     for every, n_steps in ((25, 60), (1, 7), (10, 10), (4, 1)):
-        recorded = []
+        recorded, scored = [], []
         train, val, model = Src(), Src(), Namespace(engine=Engine())
         orig = train_dist.DeferredScalars
 
@@ -268,7 +268,11 @@ def test_scalar_every_flag_and_read_back_cadence():
             def __init__(self, model, on_scalars):
                 pass
 
-            def record(self, step, val_batch):
+            def record_scores(self, val_batch):       # (the validation batch is scored BEFORE the read-back iteration's update)
+                scored.append(model.engine.steps)
+                return ('slot', 8)
+
+            def record_scalars(self, step, host, n):
                 recorded.append(step)
 
             def flush(self):
@@ -280,5 +284,6 @@ def test_scalar_every_flag_and_read_back_cadence():
             train_dist.DeferredScalars = orig
         want = sorted(set(list(range(0, n_steps, every)) + [n_steps - 1]))
         assert recorded == want, (every, n_steps, recorded)
+        assert scored == want, (every, n_steps, scored)      # scored when exactly `step` iterations had been taken: pre-update
         assert model.engine.steps == n_steps and sum(train.windows) == n_steps
         assert val.singles == len(want)            # one validation batch per read-back: at N = 1 the reference's stream

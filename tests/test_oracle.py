@@ -6,6 +6,7 @@ float64 finite differences of every analytic gradient, and an independent
 torch-autograd float64 restatement of the same forward.
 """
 import itertools
+import os
 
 import numpy as np
 import pytest
@@ -262,3 +263,22 @@ def test_oracle_trainer_learns():
     assert last < first
     ev = O.dist_eval(tr.scores(*pos), tr.scores(*neg))
     assert ev['auc'] > 0.8
+
+
+def test_loader_oracle_reads_what_the_product_reader_reads(tmp_path):
+    """oracle/loader_oracle.py (the reference's per-row seek + read, cfl/input_data.py:212-228; bench.py's cpu_baseline.loader leg)
+    against the product's reader of the same file -- itself pinned to goldens captured from the reference's own module
+    (tests/test_input_data.py): same bytes, and the file it writes has the reference's record grammar."""
+    from cfl import input_data
+    from oracle import loader_oracle as LO
+    rng = np.random.RandomState(3)
+    path = str(tmp_path / 'features.b')
+    D, n = 24, 17
+    LO.write_features(path, rng, n, D)
+    assert os.path.getsize(path) == n * (10 + 4 * D)
+    pos = np.array([[0, 16], [5, 5], [16, 1], [3, 9]])
+    got = LO.labeled_batch_by_seek(path, pos, pos[::-1], D)
+    for g, want_pos in zip(got, (pos[:, 0], pos[:, 1], pos[::-1][:, 0], pos[::-1][:, 1])):
+        want = input_data.load_features_by_positions(path, want_pos, D)
+        assert g.dtype == np.float32 and np.array_equal(g, want)
+    assert input_data.load_asins_by_positions(path, [0, 16], D) == ['0000000000', '0000000016']
