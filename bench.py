@@ -75,11 +75,13 @@ def parse():
     ap.add_argument('--no-dp-form', action='store_true', help='skip the one-rank RCCL leg (dp_form)')
     ap.add_argument('--cli-items', type=int, default=40000, help='items of the synthetic features.b of the cli_loop leg')
     ap.add_argument('--cli-pairs', type=int, default=200000)
-    ap.add_argument('--restore-steps', type=int, default=30, help='the timed repeats start from the training state after this '
+    ap.add_argument('--restore-steps', type=int, default=1500, help='the timed repeats start from the training state after this '
                     'many steps (restored before every repeat): the timed model is a model IN training, not a converged one')
     ap.add_argument('--dp-leg', default='', help='(internal) N > 1: run only the named data-parallel leg and print its JSON '
                     '(`oneshot`: the one-shot exchange at B = 512 and 2048 per GPU; started by rank 0 of the main job as a '
                     'child job so that a failure of that path cannot take the headline line down)')
+    ap.add_argument('--no-live-traffic', action='store_true', help='quote profiles/traffic.json instead of measuring the HBM '
+                    'traffic of the step with two rocprofv3 --pmc child runs')
     ap.add_argument('--no-dp-legs', action='store_true', help='N > 1: skip the extra data-parallel legs (dp_scaling)')
     return ap.parse_args()
 
@@ -281,6 +283,46 @@ def _rocprof_avg_us(kernel_name):
     except Exception:
         return None
     return None
+
+
+def traffic_live(args, timeout=240):
+    """HBM traffic per launch of the step's kernels MEASURED IN THIS RUN: two child runs of
+    tools/kernel_probe.py (the same step on the same shapes) under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` -- separate
+    passes, the program directly after `--`, no trace domains -- reduced as MI355X_MICROARCH.md's HBM section prescribes
+    (2 x FETCH_SIZE + WRITE_SIZE in KiB: gfx950 tallies the 128-byte read requests at 64 bytes).  None when rocprofv3 is missing
+    or a pass fails (the committed builder-box file is quoted then)."""
+    import shutil
+    import tempfile
+    prof = shutil.which('rocprofv3') or ('/opt/rocm/bin/rocprofv3' if os.path.exists('/opt/rocm/bin/rocprofv3') else None)
+    if prof is None:
+        return None
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import pmc_traffic
+    tmp = tempfile.mkdtemp(prefix='bench_pmc_', dir='/tmp')
+    try:
+        dirs = {}
+        for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
+            d = os.path.join(tmp, counter)
+            cmd = [prof, '--pmc', counter, '--output-format', 'csv', '-d', d, '-o', 'run', '--', sys.executable,
+                   os.path.join(ROOT, 'tools', 'kernel_probe.py'), '--steps', '40', '--batch-size', str(args.batch_size),
+                   '--input-size', str(args.input_size), '--num-components', str(args.num_components), '--latent-size',
+                   str(args.latent_size)]
+            r = subprocess.run(cmd, cwd='/tmp', env=dict(os.environ, TMPDIR='/tmp'), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                               timeout=timeout)
+            if r.returncode != 0:
+                print('bench.py: rocprofv3 --pmc %s failed (rc %d): %s' % (counter, r.returncode, r.stderr[-300:]), file=sys.stderr)
+                return None
+            dirs[counter] = d
+        fetch, nf = pmc_traffic.collect(dirs['FETCH_SIZE'], 'FETCH_SIZE')
+        write, _ = pmc_traffic.collect(dirs['WRITE_SIZE'], 'WRITE_SIZE')
+        if not fetch:
+            return None
+        return {k: int(round((2.0 * fetch[k] + write.get(k, 0.0)) * 1024)) for k in fetch}
+    except Exception as e:          # noqa: BLE001 (a side measurement must not take the headline line down)
+        print('bench.py: live PMC traffic: %r' % (e,), file=sys.stderr)
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def _eval_traffic():
@@ -696,7 +738,7 @@ def dp_leg(args, device, rank, world, B, exchange, teacher, seconds=None, pool_m
             if world > 1:
                 dist.barrier()
                 torch.cuda.synchronize()
-        for i in range(args.restore_steps):
+        for i in range(min(args.restore_steps, 300)):     # (side legs: a shorter run-in)
             eng.step(pool[i % nb])
         snap = snapshot(eng)
         for i in range(max(nb, 20)):
@@ -1050,8 +1092,16 @@ def main():
         alg_bytes = 16.0 * D * B                       # 4 fp32 vectors per row, read once
         alg_flops = 4.0 * D * L * (K + 1) * B          # one of fwd / dW: half of 8*D*L*(K+1)
         traffic, traffic_all = None, {}
+        traffic_src = ('profiles/traffic.json: builder box, separate `rocprofv3 --pmc FETCH_SIZE` / `WRITE_SIZE` passes '
+                       'of this command (2 * FETCH_SIZE + WRITE_SIZE, gfx950 half-count correction); NOT measured in this run')
+        live = traffic_live(args) if (world == 1 and not args.no_live_traffic) else None
+        if live:
+            traffic_all, traffic = live, live.get(dom)
+            traffic_src = ('MEASURED IN THIS RUN: two child runs of tools/kernel_probe.py (the same step, same shapes) under '
+                           '`rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes), per launch = '
+                           '(2 * FETCH_SIZE + WRITE_SIZE) KiB: gfx950 tallies 128-byte read requests at 64 bytes (MI355X_MICROARCH.md)')
         tp = os.path.join(ROOT, 'profiles', 'traffic.json')
-        if os.path.exists(tp):
+        if not live and os.path.exists(tp):
             try:
                 traffic_all = json.load(open(tp))
                 traffic = traffic_all.get(dom)
@@ -1089,9 +1139,8 @@ def main():
             'unit': 'GB/s',
             'frac': round(hbm_frac_dom, 4),
             'traffic': traffic,
-            'traffic_source': 'profiles/traffic.json: builder box, separate `rocprofv3 --pmc FETCH_SIZE` / `WRITE_SIZE` passes '
-                              'of this command (2 * FETCH_SIZE + WRITE_SIZE, gfx950 half-count correction); NOT measured in '
-                              'this run',
+            'traffic_all_kernels': {k: v for k, v in traffic_all.items() if isinstance(v, (int, float))},
+            'traffic_source': traffic_src,
             'avg_launch_us': round(raw_s * 1e6, 3),
             'algorithmic_bytes_per_launch': alg_bytes,
             'event_corrected': {'avg_launch_us': round(corr_s * 1e6, 3),
@@ -1113,7 +1162,7 @@ def main():
                      # algorithmic bytes 16*D*B + 32*P (inputs once + parameters / Adam slots / gradient)
                      'traffic_bytes': step_traffic,
                      'algorithmic_bytes': 16.0 * D * B + 32.0 * P_params,
-                     'traffic_source': 'profiles/traffic.json (builder box)'},
+                     'traffic_source': 'measured in this run' if live else 'profiles/traffic.json (builder box)'},
             'kernels': kern,
             'timing': 'hipEvent pairs around every launch on the launch stream, separate pass of %d steps (`kernels` '
                       'lists the raw intervals; `achieved` / `frac` use the raw interval of the dominant kernel).  '
@@ -1125,7 +1174,13 @@ def main():
         if not args.no_kernel_profile:
             out['roofline_eval'] = roofline_eval(args, eng, pool, device)
         if not args.no_cpu_baseline:
+            # the AUC half of the metric on a TRAINED model: the timed repeats were restored to an early state, so train on
+            # (untimed) before scoring held-out pairs with the HIP path and with the fp64 oracle
+            run(6000, 0)
+            torch.cuda.synchronize()
             out['eval_auc'] = eval_auc(args, eng, device, teacher)
+            out['eval_auc']['trained_steps'] = int(eng.global_step)
+            out['eval_auc']['train_loss'] = round(eng.read_scalars()['total'], 6)
             out['cpu_baseline'] = cpu_baseline(args, args.cpu_seconds)
             try:
                 out['cpu_baseline']['loader'] = cpu_loader_baseline(args)

@@ -30,6 +30,7 @@
 
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 
 #include "../../include/cfl_hip.h"
@@ -256,6 +257,16 @@ static int dp_fill_peers(DpPeers *p, float *const *slots, uint32_t *const *flags
     return CFL_OK;
 }
 
+// Workgroups of the polling kernels.  Every block of cfl_dp_rs_adam / cfl_dp_rs_gather polls flags before it works, so ranks that
+// SHARE a GPU (the functional tests: 2 or 8 processes on one device) must not fill it with waiting blocks: CFL_DP_MAX_BLOCKS caps
+// the launches (the tests set 64).  One rank per GPU (the default, 512): one float4 per thread wherever the slice allows -- a
+// thread's loads are system-scope round trips, and every extra trip of the loop is one more of them in series.
+static int dp_max_blocks(void) {
+    const char *v = getenv("CFL_DP_MAX_BLOCKS");
+    const int n = v ? atoi(v) : 0;
+    return n > 0 ? n : 512;
+}
+
 static unsigned long long dp_ticks(double timeout_s) {
     if (!(timeout_s > 0.0)) timeout_s = 30.0;
     return (unsigned long long)(timeout_s * 1e8);   // s_memrealtime counts at 100 MHz
@@ -305,10 +316,8 @@ extern "C" int cfl_dp_rs_adam(float *theta, float *m, float *v, const float *gsl
     if (rc) return rc;
     rc = dp_check_sizes("cfl_dp_rs_adam", n, n_adam, slice, world, rank);
     if (rc) return rc;
-    // few blocks on purpose: every block polls, and ranks that share a GPU (the functional tests) must never starve each
-    // other of compute units while they wait
     int blocks = (int)((slice / 4 + 255) / 256);
-    if (blocks > 64) blocks = 64;
+    if (blocks > dp_max_blocks()) blocks = dp_max_blocks();
     {
         DpProf prof(stream);
         hipLaunchKernelGGL(cfl_dp_rs_adam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, theta, m, v, gslots, flags,
@@ -342,7 +351,7 @@ static int dp_gather_launch(const CflShape *shape, float *theta, float *sum_out,
     int rc = dp_check_sizes("cfl_dp_rs_gather", n, n_adam, slice, world, rank);
     if (rc) return rc;
     int blocks = (int)((n / 4 + 255) / 256);
-    if (blocks > 128) blocks = 128;
+    if (blocks > dp_max_blocks()) blocks = dp_max_blocks();
     {
         DpProf prof(stream);
         hipLaunchKernelGGL(cfl_dp_rs_gather_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, theta, sum_out, stage, flags,

@@ -318,6 +318,20 @@ __device__ __forceinline__ void split_frag(const float (&v)[8], bf16x8 (&f)[3]) 
     f[2] = __builtin_bit_cast(bf16x8, pl);
 }
 
+// split of an X operand (rows of the feature table / the batch).  ABL_X_NOSPLIT (ablation build, tools/r06_xsplit_ab.sh): the three
+// fragments are the truncated high halves only (one v_perm per pair, no subtract / mask chains) -- WRONG numbers, the instruction
+// count of a kernel whose x arrives already split (round 6: what resident bf16 planes of the feature table could save at most)
+__device__ __forceinline__ void split_frag_x(const float (&v)[8], bf16x8 (&f)[3]) {
+#ifdef ABL_X_NOSPLIT
+    u32x4 ph;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ph[i] = pack_hi16(v[2 * i], v[2 * i + 1]);
+    f[0] = f[1] = f[2] = __builtin_bit_cast(bf16x8, ph);
+#else
+    split_frag(v, f);
+#endif
+}
+
 // ---------------------------------------------------------------------------
 // colnorm (weight-norm): n2[c] = sum_d V[d][c]^2   (cfl/layers.py:81) + gain snapshot.
 // The blocks ride in the projection launch as an extra z-slice (the projection uses the raw V; `mid`, the next

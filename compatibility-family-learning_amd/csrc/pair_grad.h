@@ -116,6 +116,9 @@ struct GradFuse {
 
 // where gradient entry `off` (and, past the parameters, the step's scalars) is stored: the flat buffer, or the owner's slot
 __device__ __forceinline__ float *fuse_grad_ptr(const GradFuse &f, long long off) {
+#ifdef ABL_NO_DP_PUSH      // ablation build (tools/r06_dp_ab.sh): what the fused-push hooks cost the single-GPU step
+    return f.grad + off;
+#endif
     if (f.dp_slice == 0) return f.grad + off;
     const unsigned s = (unsigned)off / (unsigned)f.dp_slice;       // (off < 2^31: make_plan rejects larger layouts)
     return f.dp_rows[s] + (off - (long long)s * f.dp_slice);
@@ -123,6 +126,9 @@ __device__ __forceinline__ float *fuse_grad_ptr(const GradFuse &f, long long off
 
 // end of EVERY workgroup of a weight-gradient launch with the fused push (no-op otherwise; uniform branch)
 __device__ __forceinline__ void grad_dp_block_done(const GradFuse &f) {
+#ifdef ABL_NO_DP_PUSH
+    return;
+#endif
     if (f.dp_slice == 0) return;
     __threadfence_system();            // this thread's stores into the peers' slots are visible system-wide before the count
     __syncthreads();
@@ -898,7 +904,7 @@ __device__ __forceinline__ void grad_body_x3(const GradJob &jb, const GradArgs &
 #pragma unroll
                 for (int jj = 0; jj < 8; ++jj) v[jj] = xr[r2][jj][t];
                 bf16x8 af[3];
-                split_frag(v, af);
+                split_frag_x(v, af);
                 // small terms first; consecutive MFMAs hit different accumulators
 #define CFL_X3(LA, LB)                                                                               \
     _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) acc[t][nt] =                                   \
@@ -1041,7 +1047,7 @@ __device__ __forceinline__ void grad_body_x3_half(const GradJob &jb, const GradA
 #pragma unroll
                 for (int jj = 0; jj < 8; ++jj) v[jj] = xr[r2][jj][t];
                 bf16x8 af[3];
-                split_frag(v, af);
+                split_frag_x(v, af);
 #define CFL_X3(LA, LB)                                                                               \
     _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) acc[t][nt] =                                   \
         __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[LA], bf[nt][LB], acc[t][nt], 0, 0, 0);

@@ -292,7 +292,7 @@ __device__ __forceinline__ void proj_body_bx3(const ProjJob &jb, const ProjArgs 
 #ifdef CFL_BX3_A_RNE
                 split_frag_rne(v, af[mt]);
 #else
-                split_frag(v, af[mt]);
+                split_frag_x(v, af[mt]);
 #endif
             }
             // six partial products, small terms first; consecutive MFMAs hit different accumulators
@@ -654,7 +654,7 @@ __device__ __forceinline__ void px3_unit(const Px3Args &a, const ProjJob &jb, in
                 const int row = mt * 16 + i16;
                 const f32x4 c0 = xt[row * 8 + ((2 * kq) ^ xt_sw2(row))], c1 = xt[row * 8 + ((2 * kq + 1) ^ xt_sw2(row))];
                 float v[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
-                split_frag(v, af[mt]);
+                split_frag_x(v, af[mt]);
             }
             const bf16x8 *ws = (const bf16x8 *)(smem + (size_t)(q % PX3_SLOTS) * PX3_SLOT_USHORTS * 2) + lane;
             bf16x8 bf[NT][3];

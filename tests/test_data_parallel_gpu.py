@@ -148,7 +148,7 @@ def test_sharded_evaluation_equals_the_single_gpu_evaluation(tmp_path):
 
 
 def test_bench_starts_its_own_ranks():
-    env = dict(os.environ, CFL_DIST_BACKEND='gloo')
+    env = dict(os.environ, CFL_DIST_BACKEND='gloo', CFL_BENCH_LEG_SECONDS='0.2', CFL_DP_MAX_BLOCKS='64')
     env.pop('WORLD_SIZE', None)
     env.pop('RANK', None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '5', '--warmup', '2',
@@ -161,6 +161,17 @@ def test_bench_starts_its_own_ranks():
     assert out['n_gpus'] == 2 and out['ranks_seen'] == 2 and out['config']['global_batch_rows'] == 1024
     assert out['config']['parallelism'] == 'dp2' and out['scaling'] == 'weak' and out['value'] > 0
     assert np.isfinite(out['config']['final_loss'])
+    # round 6: the attribution of the scaling number travels in the same line -- both exchanges, two batch sizes per GPU, the
+    # step without any collective; the one-shot legs come from a CHILD job started by rank 0 (isolation: a failure of that path
+    # must not take the line down)
+    legs = out['dp_scaling']
+    for k in ('b512_allreduce', 'b512_without_collective', 'b2048_allreduce', 'b2048_without_collective'):
+        assert legs[k]['us_per_step'] > 0, (k, legs[k])
+    one = legs['oneshot']
+    assert one.get('dp_leg') == 'oneshot', one
+    for k in ('b512', 'b2048'):
+        assert one[k]['us_per_step'] > 0 and one[k]['lost_handoffs'] == 0, one
+        assert one[k]['driven_by'].startswith('library'), one
     # a mismatching launcher is an error, not a silent single-GPU run
     env2 = dict(env, WORLD_SIZE='1', RANK='0')
     r2 = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup',
@@ -172,7 +183,8 @@ def _oneshot_worker(rank, world, port, out):
     for p in (ROOT, os.path.join(ROOT, 'compatibility-family-learning_amd')):
         if p not in sys.path:
             sys.path.insert(0, p)
-    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0',
+                      CFL_DP_MAX_BLOCKS='64')     # (the ranks share ONE GPU here: few polling blocks per rank, csrc/cfl_dp.hip)
     torch.cuda.set_device(0)
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:

@@ -18,7 +18,7 @@ for B in (256, 512, 1024, 2048, 4096, 8192):
     batch_mib = 4 * B * 4096 * 4 >> 20
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--batch-size', str(B), '--steps', '20',
                         '--warmup', '5', '--pool-mib', str(max(384, 3 * batch_mib)), '--no-cpu-baseline',
-                        '--no-cli-loop', '--no-other-configs'], capture_output=True, text=True, cwd=ROOT)
+                        '--no-cli-loop', '--no-other-configs', '--no-live-traffic', '--no-dp-form'], capture_output=True, text=True, cwd=ROOT)
     line = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
     if not line:
         print('B=%d failed: %s' % (B, r.stderr[-500:]), file=sys.stderr)
