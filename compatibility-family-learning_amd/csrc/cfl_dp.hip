@@ -53,17 +53,32 @@ struct DpPeers {
     int world;
 };
 
-// last block of a launch: every block has fenced its stores at system scope; release and raise this rank's flag in every peer
+// Memory model of the exchange (round 6: no __threadfence_system() anywhere -- on gfx950 it writes back / invalidates the whole L2
+// per calling wave, and hundreds of workgroups doing that at the end of a launch cost a step tens of microseconds, measured).
+//  * every byte handed to another rank is stored with a SYSTEM-SCOPE WRITE-THROUGH store (sc0 sc1) into fine-grained memory --
+//    never dirty in an L2 -- and every storing wave drains its stores (s_waitcnt vmcnt(0): acknowledged by the memory system)
+//    before its workgroup counts itself on the launch's ticket;
+//  * the workgroup that sees the last count raises this rank's flag word in every peer (system-scope store): the flag leaves the
+//    GPU behind every data store of the launch, and stores of one GPU to one peer are delivered in order;
+//  * the receiver polls its flag words with system-scope loads and reads the handed-off bytes with system-scope (sc0 sc1) loads
+//    to registers: nothing it reads can come from a stale line of its own caches.
+// The in-launch hand-offs of the weight-gradient kernels use the same form one scope further in (sc1; MI355X_MICROARCH.md).
+__device__ __forceinline__ void dp_store_sys16(float *p, dp_f32x4 v) {
+    // (one asm statement, with the wait states a VALU write to the data registers of a > 64-bit store needs behind it: the
+    // compiler's hazard recogniser does not see inside inline asm)
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" :: "v"(p), "v"(v) : "memory");
+}
+
+// last block of a launch: every block drained its stores before it counted; raise this rank's flag in every peer
 __device__ __forceinline__ void dp_signal_peers(const DpPeers &p, unsigned gen, unsigned *ticket) {
-    __threadfence_system();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     __shared__ unsigned last;
-    if (threadIdx.x == 0) last = atomicAdd(ticket, 1u) == gridDim.x - 1 ? 1u : 0u;
+    if (threadIdx.x == 0) last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1u : 0u;
     __syncthreads();
     if (last) {
-        __threadfence_system();
         if ((int)threadIdx.x < p.world)
-            __hip_atomic_store(p.flag[threadIdx.x], gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(p.flag[threadIdx.x], gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         if (threadIdx.x == 0) *ticket = 0;  // the next launch on this stream starts from zero
     }
 }
@@ -84,7 +99,6 @@ __device__ __forceinline__ bool dp_wait_flags(const unsigned *flags, int world, 
             if (__builtin_amdgcn_s_memrealtime() - t0 > ticks) { ok = 0; break; }
             __builtin_amdgcn_s_sleep(8);
         }
-        __threadfence_system();
         if (lane == 0) {
             ok_s = ok;
             if (!ok) *lost = 1;
@@ -118,7 +132,7 @@ __global__ __launch_bounds__(256) void cfl_dp_rs_push_kernel(const float *src, l
     const long long stride = (long long)gridDim.x * 256;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
         const int s = (int)(i / slice4);                       // owner of element i
-        ((dp_f32x4 *)p.slot[s])[i - (long long)s * slice4] = ((const dp_f32x4 *)src)[i];
+        dp_store_sys16(p.slot[s] + 4 * (i - (long long)s * slice4), ((const dp_f32x4 *)src)[i]);
     }
     dp_signal_peers(p, gen, ticket);
 }
@@ -162,7 +176,7 @@ __global__ __launch_bounds__(256) void cfl_dp_rs_adam_kernel(float *theta, float
             out = th;
         }
         for (int r = 0; r < world; ++r)
-            if (r != rank) ((dp_f32x4 *)p.slot[r])[i] = out;   // all-gather, send side: one store per link
+            if (r != rank) dp_store_sys16(p.slot[r] + 4 * i, out);   // all-gather, send side: one store per link
     }
     dp_signal_peers(p, gen, ticket);
 }

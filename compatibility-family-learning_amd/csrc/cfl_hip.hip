@@ -1425,8 +1425,11 @@ static int run_pairs(const CflShape *s, const CflNorm *norm, const CflLossCfg *l
             f.pos_weight = loss->pos_weight; f.caffe_margin = loss->caffe_margin; f.lambda_m = loss->lambda_m;
             f.scalars = scalars; f.thr_copy = ws + pl.thr_copy;
             f.scalars2 = xs ? xs->scalars_copy : nullptr;
-            if (dpp && !adam) {
-                // data parallel, one-shot exchange: the finished entries go straight to their owner ranks (GradFuse::dp_*)
+            const bool dp_kernel = pl.grad_kernel == GK_HALF_W8 || pl.grad_kernel == GK_HALF || pl.grad_kernel == GK_HALF_SPLIT;
+            if (dpp && !adam && dp_kernel) {
+                // data parallel, one-shot exchange: the finished entries go straight to their owner ranks (GradFuse::dp_*).  The
+                // half-tile kernels have a fused-push form; the other plans emit the flat gradient and the caller pushes it
+                // with cfl_dp_rs_push (*pushed stays false)
                 f.dp_rows = dpp->rows_tab; f.dp_flags = dpp->flags_tab; f.dp_slice = dpp->slice; f.dp_world = dpp->world;
                 f.dp_gen = dpp->gen; f.dp_ticket = dpp->ticket;
                 f.scalars = dpp->scalars_remote;
@@ -1438,10 +1441,20 @@ static int run_pairs(const CflShape *s, const CflNorm *norm, const CflLossCfg *l
         ProfScope ps(st, CFL_K_GRAD);
         const size_t glds = 4 * 4 * 4 * 64 * sizeof(f32x4);
         const dim3 hgrid(s->D / 32, pl.P, nj + 1);
+        const bool push = ga.fuse.dp_slice != 0;      // (set above for the half-tile kernels only)
         switch (pl.grad_kernel) {
-            case GK_HALF_W8: hipLaunchKernelGGL(cfl_grad_x3_half_w8_kernel, hgrid, dim3(512), glds, st, ga); break;
-            case GK_HALF: hipLaunchKernelGGL(cfl_grad_x3_half_kernel, hgrid, dim3(256), glds, st, ga); break;
-            case GK_HALF_SPLIT: hipLaunchKernelGGL(cfl_grad_x3_half_split_kernel, hgrid, dim3(256), glds, st, ga); break;
+            case GK_HALF_W8:
+                if (push) hipLaunchKernelGGL(cfl_grad_x3_half_w8_dp_kernel, hgrid, dim3(512), glds, st, ga);
+                else hipLaunchKernelGGL(cfl_grad_x3_half_w8_kernel, hgrid, dim3(512), glds, st, ga);
+                break;
+            case GK_HALF:
+                if (push) hipLaunchKernelGGL(cfl_grad_x3_half_dp_kernel, hgrid, dim3(256), glds, st, ga);
+                else hipLaunchKernelGGL(cfl_grad_x3_half_kernel, hgrid, dim3(256), glds, st, ga);
+                break;
+            case GK_HALF_SPLIT:
+                if (push) hipLaunchKernelGGL(cfl_grad_x3_half_split_dp_kernel, hgrid, dim3(256), glds, st, ga);
+                else hipLaunchKernelGGL(cfl_grad_x3_half_split_kernel, hgrid, dim3(256), glds, st, ga);
+                break;
             case GK_X3: hipLaunchKernelGGL(cfl_grad_x3_kernel, grid, dim3(256), glds, st, ga); break;
             case GK_X3_LONGRANGE: hipLaunchKernelGGL(cfl_grad_x3_longrange_kernel, grid, dim3(256), glds, st, ga); break;
             default: hipLaunchKernelGGL(cfl_grad_kernel, grid, dim3(256), glds, st, ga); break;
@@ -2041,7 +2054,7 @@ static int dp_one_step(const CflShape *shape, const CflNorm *norm, const CflLoss
 extern "C" int cfl_dp_push_fusable(const CflShape *shape, int64_t rows) {
     Plan pl;
     if (make_plan(shape, rows, 2, true, true, &pl)) return 0;
-    return pl.fused ? 1 : 0;
+    return (pl.fused && (pl.grad_kernel == GK_HALF_W8 || pl.grad_kernel == GK_HALF || pl.grad_kernel == GK_HALF_SPLIT)) ? 1 : 0;
 }
 
 extern "C" int cfl_pair_dp_step_planes(const CflShape *shape, const CflNorm *norm, const CflLossCfg *loss, const float *const x4[4],

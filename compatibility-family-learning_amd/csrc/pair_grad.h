@@ -104,7 +104,7 @@ struct GradFuse {
     // entry of [gradient | scalars] goes straight into the OWNER rank's slot array instead of the local flat buffer -- element
     // `off` belongs to rank off / dp_slice, and dp_rows[r] (a table in DEVICE memory: a dynamically indexed array inside this
     // argument block would send the whole block to scratch) is where THIS rank's row of rank r's slot array is mapped.  Every
-    // workgroup of the launch ends with grad_dp_block_done(): system-scope fence, one count on dp_ticket; the last one raises
+    // workgroup of the launch ends with grad_dp_block_done(): its stores drained, one count on dp_ticket; the last one raises
     // this rank's arrival flag in every peer (dp_flags[r], generation dp_gen).  dp_slice == 0: off (every other caller).
     float *const *dp_rows;
     unsigned *const *dp_flags;
@@ -114,31 +114,36 @@ struct GradFuse {
     unsigned *dp_ticket;
 };
 
-// where gradient entry `off` (and, past the parameters, the step's scalars) is stored: the flat buffer, or the owner's slot
-__device__ __forceinline__ float *fuse_grad_ptr(const GradFuse &f, long long off) {
-#ifdef ABL_NO_DP_PUSH      // ablation build (tools/r06_dp_ab.sh): what the fused-push hooks cost the single-GPU step
-    return f.grad + off;
-#endif
-    if (f.dp_slice == 0) return f.grad + off;
+// where gradient entry `off` (and, past the parameters, the step's scalars) lives in its OWNER's slot array (DP kernels only)
+__device__ __forceinline__ float *dp_grad_ptr(const GradFuse &f, long long off) {
     const unsigned s = (unsigned)off / (unsigned)f.dp_slice;       // (off < 2^31: make_plan rejects larger layouts)
     return f.dp_rows[s] + (off - (long long)s * f.dp_slice);
 }
+// Stores into the peers' slots are SYSTEM-SCOPE WRITE-THROUGH stores (sc0 sc1: the slots are fine-grained memory of this or another
+// GPU, never held dirty in an L2), drained by every storing wave with s_waitcnt vmcnt(0) before the workgroup's arrival count --
+// the hand-off form this library uses inside a launch (grad_fused_tail), one scope further out.  No __threadfence_system():
+// on gfx950 that is a write-back of the whole L2 per calling wave; 257 workgroups doing it at the end of the launch cost the
+// step tens of microseconds (measured on a one-rank group, round 6).
+// (one asm statement per store, with the wait states a VALU write to the data registers of a > 64-bit store needs behind it: the
+// compiler's hazard recogniser does not see inside inline asm)
+__device__ __forceinline__ void dp_store16(float *p, f32x4 v) {
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" :: "v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void dp_store4(float *p, float v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 
-// end of EVERY workgroup of a weight-gradient launch with the fused push (no-op otherwise; uniform branch)
+// end of EVERY workgroup of a weight-gradient launch with the fused push
 __device__ __forceinline__ void grad_dp_block_done(const GradFuse &f) {
-#ifdef ABL_NO_DP_PUSH
-    return;
-#endif
-    if (f.dp_slice == 0) return;
-    __threadfence_system();            // this thread's stores into the peers' slots are visible system-wide before the count
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pushes have been acknowledged by the memory system
     __syncthreads();
     __shared__ unsigned dp_last;
-    if (threadIdx.x == 0) dp_last = atomicAdd(f.dp_ticket, 1u) == gridDim.x * gridDim.y * gridDim.z - 1u ? 1u : 0u;
+    if (threadIdx.x == 0)
+        dp_last = __hip_atomic_fetch_add(f.dp_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x * gridDim.y * gridDim.z - 1u ? 1u : 0u;
     __syncthreads();
     if (dp_last) {
-        __threadfence_system();
-        if ((int)threadIdx.x < f.dp_world)
-            __hip_atomic_store(f.dp_flags[threadIdx.x], f.dp_gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        // every workgroup of the launch drained its stores before it counted: raise this rank's arrival flag in every peer
+        if ((int)threadIdx.x < f.dp_world) __hip_atomic_store(f.dp_flags[threadIdx.x], f.dp_gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         if (threadIdx.x == 0) *f.dp_ticket = 0;   // the next launch on this stream starts from zero
     }
 }
@@ -251,12 +256,14 @@ __device__ __forceinline__ void adam4(f32x4 &th, f32x4 &mm, f32x4 &vv, const f32
 }
 
 // gradient entry -> flat gradient (+ L2 term) -> optional TF-Adam, 4 consecutive parameters at `off`
+template <bool DP = false>   // DP: the entry goes to its owner rank's slot (fused push of the one-shot exchange) instead of the flat gradient
 __device__ __forceinline__ void fuse_apply(const GradFuse &f, long long off, f32x4 gr, f32x4 &th, f32x4 mm, f32x4 vv) {   // th: updated in place (the planes are split from it)
     if (f.reg_const != 0.f) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) gr[e] = fmaf(f.reg_const, th[e], gr[e]);
     }
-    *(f32x4 *)fuse_grad_ptr(f, off) = gr;
+    if (DP) dp_store16(dp_grad_ptr(f, off), gr);
+    else *(f32x4 *)(f.grad + off) = gr;
     if (f.m) {
         adam4(th, mm, vv, gr, f.lr_t, f.b1, f.b2, f.eps);
         *(f32x4 *)(f.m + off) = mm;
@@ -560,10 +567,12 @@ __device__ __forceinline__ void write_scalars(float *o, const float *sc, float r
 }
 
 // one parameter: flat gradient (+ L2 term) and optional TF-Adam (fused mode, bias / threshold entries)
+template <bool DP = false>
 __device__ __forceinline__ void fuse_apply1(const GradFuse &f, long long off, float gr, bool reg) {
     float th = f.theta[off];
     if (reg && f.reg_const != 0.f) gr = fmaf(f.reg_const, th, gr);
-    *fuse_grad_ptr(f, off) = gr;
+    if (DP) dp_store4(dp_grad_ptr(f, off), gr);
+    else f.grad[off] = gr;
     if (f.m) {
         float mm = f.m[off], vv = f.v[off];
         adam1(th, mm, vv, gr, f.lr_t, f.b1, f.b2, f.eps);
@@ -622,6 +631,7 @@ __device__ __forceinline__ float tile_colsum(const float *buf, int idx, int RG, 
     return cs;
 }
 
+template <bool DP = false>
 __device__ __forceinline__ void grad_red_block(const GradArgs &a, float *lds) {   // (forceinline: an out-of-line call takes the address of the argument block, which then lives in scratch)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nblk = gridDim.x * gridDim.y;
@@ -663,14 +673,20 @@ __device__ __forceinline__ void grad_red_block(const GradArgs &a, float *lds) { 
                     if (wave == 0) {
                         if (lane == 0) {
                             const float th = f.theta[f.thr_off];
-                            fuse_apply1(f, f.thr_off, th >= CFL_THR_FLOOR ? lds[64 + P_DTHR] : 0.f, false);
+                            fuse_apply1<DP>(f, f.thr_off, th >= CFL_THR_FLOOR ? lds[64 + P_DTHR] : 0.f, false);
                         } else {
-                            fuse_apply1(f, f.thr_off + lane, 0.f, false);   // rest of the 64-float threshold slot
+                            fuse_apply1<DP>(f, f.thr_off + lane, 0.f, false);   // rest of the 64-float threshold slot
                         }
                         float rs = 0.f;
                         for (int b = lane; b < f.nregblocks; b += 64) rs += f.regpart[b];
                         rs = wave_sum(rs);
-                        if (lane == 0) {
+                        if (lane == 0 && DP) {
+                            // (the step's scalars live in their owner's slot row: staged in LDS, then system-scope stores)
+                            float *stg = lds + 128;
+                            write_scalars(stg, lds + 64, 0.5f * f.reg_const * rs, f.B, f.use_threshold,
+                                          f.pos_weight, f.caffe_margin, f.lambda_m, f.thr_copy[0]);
+                            for (int q = 0; q < CFL_S_ERROR; ++q) dp_store4(f.scalars + q, stg[q]);
+                        } else if (lane == 0) {
                             write_scalars(f.scalars, lds + 64, 0.5f * f.reg_const * rs, f.B, f.use_threshold,
                                           f.pos_weight, f.caffe_margin, f.lambda_m, f.thr_copy[0]);
                             if (f.scalars2) {   // the caller's second copy (a pinned host ring slot: no copy command on the stream)
@@ -683,11 +699,11 @@ __device__ __forceinline__ void grad_red_block(const GradArgs &a, float *lds) { 
                 } else if (f.red_b[k] >= 0 && wave == 0) {
                     const int c = idx * 16 + lane;
                     if (lane < 16) {
-                        fuse_apply1(f, f.red_b[k] + c, c < f.red_n[k] ? csum : 0.f, true);
+                        fuse_apply1<DP>(f, f.red_b[k] + c, c < f.red_n[k] ? csum : 0.f, true);
                     } else if (idx == 0) {
                         // pad of the bias array up to its 64-float slot: zero gradient
                         const int cp = f.red_npad[k] + lane - 16;
-                        if (cp < ((f.red_npad[k] + 63) & ~63)) fuse_apply1(f, f.red_b[k] + cp, 0.f, true);
+                        if (cp < ((f.red_npad[k] + 63) & ~63)) fuse_apply1<DP>(f, f.red_b[k] + cp, 0.f, true);
                     }
                 } else if (f.wn && f.red_g[k] >= 0 && wave == 0) {
                     // gain entries: dg_j = c_j / n_j (the RK_GAIN branch of the finalize kernel; no L2 term)
@@ -698,10 +714,10 @@ __device__ __forceinline__ void grad_red_block(const GradArgs &a, float *lds) { 
                             const float n2 = f.red_n2[k][c];
                             gr = n2 > 0.f ? csum / sqrtf(n2) : 0.f;
                         }
-                        fuse_apply1(f, f.red_g[k] + c, gr, false);
+                        fuse_apply1<DP>(f, f.red_g[k] + c, gr, false);
                     } else if (idx == 0) {
                         const int cp = f.red_npad[k] + lane - 16;
-                        if (cp < ((f.red_npad[k] + 63) & ~63)) fuse_apply1(f, f.red_g[k] + cp, 0.f, false);
+                        if (cp < ((f.red_npad[k] + 63) & ~63)) fuse_apply1<DP>(f, f.red_g[k] + cp, 0.f, false);
                     }
                 }
             }
@@ -719,7 +735,8 @@ __device__ __forceinline__ void grad_red_block(const GradArgs &a, float *lds) { 
 #pragma unroll
                         for (int e = 0; e < 4; ++e) gr[e] = fmaf(f.reg_const, th[e], gr[e]);
                     }
-                    *(f32x4 *)fuse_grad_ptr(f, off) = gr;
+                    if (DP) dp_store16(dp_grad_ptr(f, off), gr);
+                    else *(f32x4 *)(f.grad + off) = gr;
                     if (f.m) {
                         f32x4 mm = *(const f32x4 *)(f.m + off), vv = *(const f32x4 *)(f.v + off), tn = th;
                         adam4(tn, mm, vv, gr, f.lr_t, f.b1, f.b2, f.eps);
@@ -767,10 +784,10 @@ __device__ __forceinline__ void grad_red_block(const GradArgs &a, float *lds) { 
                             if (threadIdx.x == 0 && n2 > 0.f)
                                 g1 = fmaf(-(f.mono_gcopy[kk] * cw / (n2 * n)), f.theta[f.mono_w + (long long)idx * rr.kpad + kk], g1);
                         }
-                        if (threadIdx.x == 0) fuse_apply1(f, f.mono_w + (long long)idx * rr.kpad + kk, g1, f.mono_reg != 0);
+                        if (threadIdx.x == 0) fuse_apply1<DP>(f, f.mono_w + (long long)idx * rr.kpad + kk, g1, f.mono_reg != 0);
                     } else if (threadIdx.x == 0) {
                         const float n2 = f.mono_n2[kk];
-                        fuse_apply1(f, f.mono_g + kk, n2 > 0.f ? tot / sqrtf(n2) : 0.f, false);
+                        fuse_apply1<DP>(f, f.mono_g + kk, n2 > 0.f ? tot / sqrtf(n2) : 0.f, false);
                     }
                 }
             }
@@ -779,13 +796,13 @@ __device__ __forceinline__ void grad_red_block(const GradArgs &a, float *lds) { 
                 // rest of the region up to its 64-float boundary: zero gradient (+ L2 of a zero weight)
                 const GradFuse &f = a.fuse;
                 if (rr.kind == 1) {
-                    for (int kk = rr.K + lane; kk < rr.kpad; kk += 64) fuse_apply1(f, f.mono_w + (long long)idx * rr.kpad + kk, 0.f, f.mono_reg != 0);
+                    for (int kk = rr.K + lane; kk < rr.kpad; kk += 64) fuse_apply1<DP>(f, f.mono_w + (long long)idx * rr.kpad + kk, 0.f, f.mono_reg != 0);
                     if (idx == f.mono_L - 1) {
                         const long long used = (long long)f.mono_L * rr.kpad, end = (used + 63) / 64 * 64;
-                        for (long long o = used + lane; o < end; o += 64) fuse_apply1(f, f.mono_w + o, 0.f, f.mono_reg != 0);
+                        for (long long o = used + lane; o < end; o += 64) fuse_apply1<DP>(f, f.mono_w + o, 0.f, f.mono_reg != 0);
                     }
                 } else {
-                    for (int kk = rr.K + lane; kk < ((rr.kpad + 63) & ~63); kk += 64) fuse_apply1(f, f.mono_g + kk, 0.f, false);
+                    for (int kk = rr.K + lane; kk < ((rr.kpad + 63) & ~63); kk += 64) fuse_apply1<DP>(f, f.mono_g + kk, 0.f, false);
                 }
             }
         }
@@ -796,7 +813,7 @@ extern "C" __global__ __launch_bounds__(256) void cfl_grad_kernel(GradArgs a_) {
     CFL_KERNARG_IN_PLACE(GradArgs, a, a_);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     f32x4 *lds = (f32x4 *)smem;
-    if (blockIdx.z == 0) { grad_red_block(a, (float *)smem); grad_dp_block_done(a.fuse); return; }
+    if (blockIdx.z == 0) { grad_red_block(a, (float *)smem); return; }
     const GradJob &jb = a.job[blockIdx.z - 1];
     switch (jb.nt) {
         case 1: grad_body<1>(jb, a, lds); break;
@@ -804,7 +821,6 @@ extern "C" __global__ __launch_bounds__(256) void cfl_grad_kernel(GradArgs a_) {
         case 3: grad_body<3>(jb, a, lds); break;
         default: grad_body<4>(jb, a, lds); break;
     }
-    grad_dp_block_done(a.fuse);
 }
 
 // ---------------------------------------------------------------------------
@@ -955,7 +971,7 @@ __device__ __forceinline__ void grad_body_x3(const GradJob &jb, const GradArgs &
 // ---------------------------------------------------------------------------
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-template <int NT, bool HO, int NW = 4>   // NW: waves per workgroup (8: two waves per SIMD); HO: row split and / or siamese pairing (hand-off tail); false: the tile is complete in the workgroup
+template <int NT, bool HO, int NW = 4, bool DP = false>   // NW: waves per workgroup (8: two waves per SIMD); HO: row split and / or siamese pairing (hand-off tail); false: the tile is complete in the workgroup; DP: fused push of the one-shot exchange
 __device__ __forceinline__ void grad_body_x3_half(const GradJob &jb, const GradArgs &a, f32x4 *lds, int job, int dtile,
                                                   int p) {
     const int lane = threadIdx.x & 63;
@@ -1125,7 +1141,7 @@ __device__ __forceinline__ void grad_body_x3_half(const GradJob &jb, const GradA
                 }
             }
             ((int *)lds)[0] = ok;
-            if (!ok) f.scalars[CFL_S_ERROR] = 1.f;   // sticky error word (see CFL_HANDOFF_SPIN_LIMIT)
+            if (!ok) { if (DP) dp_store4(f.scalars + CFL_S_ERROR, 1.f); else f.scalars[CFL_S_ERROR] = 1.f; }   // sticky error word (see CFL_HANDOFF_SPIN_LIMIT)
         }
         __syncthreads();
         lost = lost || ((int *)lds)[0] == 0;
@@ -1171,7 +1187,7 @@ __device__ __forceinline__ void grad_body_x3_half(const GradJob &jb, const GradA
 #pragma unroll
                 for (int i = 0; i < 4; ++i) gr[i] = fmaf(-s2, th[h][i], gr[i]);
             }
-            fuse_apply(f, base + h * 64, gr, th[h], mm[h], vv[h]);
+            fuse_apply<DP>(f, base + h * 64, gr, th[h], mm[h], vv[h]);
         }
         if (f.planes && f.m) {
             // kept bf16 planes of the updated weights: this lane holds d = 32 dtile + 8 kq + (0 .. 7) of column i16 -- exactly
@@ -1190,7 +1206,7 @@ extern "C" __global__ __launch_bounds__(256) void cfl_grad_x3_half_kernel(GradAr
     CFL_KERNARG_IN_PLACE(GradArgs, a, a_);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     f32x4 *lds = (f32x4 *)smem;
-    if (blockIdx.z == 0) { grad_red_block(a, (float *)smem); grad_dp_block_done(a.fuse); return; }
+    if (blockIdx.z == 0) { grad_red_block(a, (float *)smem); return; }
     const GradJob &jb = a.job[blockIdx.z - 1];
     const int job = (int)blockIdx.z - 1, dt = grad_dtile(a.tps);
     switch (jb.nt) {
@@ -1199,7 +1215,6 @@ extern "C" __global__ __launch_bounds__(256) void cfl_grad_x3_half_kernel(GradAr
         case 3: grad_body_x3_half<3, false>(jb, a, lds, job, dt, 0); break;
         default: grad_body_x3_half<4, false>(jb, a, lds, job, dt, 0); break;
     }
-    grad_dp_block_done(a.fuse);
 }
 
 // the same tile with EIGHT waves (two per SIMD, half the rows each): the headline plan (CFL_DEBUG_GRAD_W8=-1: four waves)
@@ -1210,7 +1225,6 @@ extern "C" __global__ __launch_bounds__(512) void cfl_grad_x3_half_w8_kernel(Gra
     if (blockIdx.z == 0) {
         if (threadIdx.x >= 256) return;   // (the reduction blocks are written for four waves; a finished wave does not count at a barrier)
         grad_red_block(a, (float *)smem);
-        grad_dp_block_done(a.fuse);
         return;
     }
     const GradJob &jb = a.job[blockIdx.z - 1];
@@ -1221,7 +1235,6 @@ extern "C" __global__ __launch_bounds__(512) void cfl_grad_x3_half_w8_kernel(Gra
         case 3: grad_body_x3_half<3, false, 8>(jb, a, lds, job, dt, 0); break;
         default: grad_body_x3_half<4, false, 8>(jb, a, lds, job, dt, 0); break;
     }
-    grad_dp_block_done(a.fuse);
 }
 
 // ... with a row split (grid y = P row ranges) and / or the siamese pairing: hand-off tail
@@ -1229,7 +1242,7 @@ extern "C" __global__ __launch_bounds__(256) void cfl_grad_x3_half_split_kernel(
     CFL_KERNARG_IN_PLACE(GradArgs, a, a_);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     f32x4 *lds = (f32x4 *)smem;
-    if (blockIdx.z == 0) { grad_red_block(a, (float *)smem); grad_dp_block_done(a.fuse); return; }
+    if (blockIdx.z == 0) { grad_red_block(a, (float *)smem); return; }
     const GradJob &jb = a.job[blockIdx.z - 1];
     const int job = (int)blockIdx.z - 1, dt = grad_dtile(a.tps);
     switch (jb.nt) {
@@ -1237,6 +1250,62 @@ extern "C" __global__ __launch_bounds__(256) void cfl_grad_x3_half_split_kernel(
         case 2: grad_body_x3_half<2, true>(jb, a, lds, job, dt, (int)blockIdx.y); break;
         case 3: grad_body_x3_half<3, true>(jb, a, lds, job, dt, (int)blockIdx.y); break;
         default: grad_body_x3_half<4, true>(jb, a, lds, job, dt, (int)blockIdx.y); break;
+    }
+}
+
+// ---- the half-tile kernels with the FUSED PUSH of the data-parallel one-shot exchange (round 6; GradFuse::dp_*) ------------------
+// Kernels of their own, so that the single-GPU kernels above stay what they were instruction for instruction (a run-time switch
+// inside them measured +0.5 us per headline step, profiles/r06_nodp_ab_first.txt).  Same bodies, template parameter DP: every
+// finished entry of [gradient | scalars] goes to its owner rank's slot, every workgroup ends with grad_dp_block_done().
+extern "C" __global__ __launch_bounds__(256) void cfl_grad_x3_half_dp_kernel(GradArgs a_) {
+    CFL_KERNARG_IN_PLACE(GradArgs, a, a_);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    f32x4 *lds = (f32x4 *)smem;
+    if (blockIdx.z == 0) { grad_red_block<true>(a, (float *)smem); grad_dp_block_done(a.fuse); return; }
+    const GradJob &jb = a.job[blockIdx.z - 1];
+    const int job = (int)blockIdx.z - 1, dt = grad_dtile(a.tps);
+    switch (jb.nt) {
+        case 1: grad_body_x3_half<1, false, 4, true>(jb, a, lds, job, dt, 0); break;
+        case 2: grad_body_x3_half<2, false, 4, true>(jb, a, lds, job, dt, 0); break;
+        case 3: grad_body_x3_half<3, false, 4, true>(jb, a, lds, job, dt, 0); break;
+        default: grad_body_x3_half<4, false, 4, true>(jb, a, lds, job, dt, 0); break;
+    }
+    grad_dp_block_done(a.fuse);
+}
+
+extern "C" __global__ __launch_bounds__(512) void cfl_grad_x3_half_w8_dp_kernel(GradArgs a_) {
+    CFL_KERNARG_IN_PLACE(GradArgs, a, a_);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    f32x4 *lds = (f32x4 *)smem;
+    if (blockIdx.z == 0) {
+        if (threadIdx.x >= 256) return;   // (four-wave reduction blocks; a finished wave does not count at a barrier)
+        grad_red_block<true>(a, (float *)smem);
+        grad_dp_block_done(a.fuse);
+        return;
+    }
+    const GradJob &jb = a.job[blockIdx.z - 1];
+    const int job = (int)blockIdx.z - 1, dt = grad_dtile(a.tps);
+    switch (jb.nt) {
+        case 1: grad_body_x3_half<1, false, 8, true>(jb, a, lds, job, dt, 0); break;
+        case 2: grad_body_x3_half<2, false, 8, true>(jb, a, lds, job, dt, 0); break;
+        case 3: grad_body_x3_half<3, false, 8, true>(jb, a, lds, job, dt, 0); break;
+        default: grad_body_x3_half<4, false, 8, true>(jb, a, lds, job, dt, 0); break;
+    }
+    grad_dp_block_done(a.fuse);
+}
+
+extern "C" __global__ __launch_bounds__(256) void cfl_grad_x3_half_split_dp_kernel(GradArgs a_) {
+    CFL_KERNARG_IN_PLACE(GradArgs, a, a_);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    f32x4 *lds = (f32x4 *)smem;
+    if (blockIdx.z == 0) { grad_red_block<true>(a, (float *)smem); grad_dp_block_done(a.fuse); return; }
+    const GradJob &jb = a.job[blockIdx.z - 1];
+    const int job = (int)blockIdx.z - 1, dt = grad_dtile(a.tps);
+    switch (jb.nt) {
+        case 1: grad_body_x3_half<1, true, 4, true>(jb, a, lds, job, dt, (int)blockIdx.y); break;
+        case 2: grad_body_x3_half<2, true, 4, true>(jb, a, lds, job, dt, (int)blockIdx.y); break;
+        case 3: grad_body_x3_half<3, true, 4, true>(jb, a, lds, job, dt, (int)blockIdx.y); break;
+        default: grad_body_x3_half<4, true, 4, true>(jb, a, lds, job, dt, (int)blockIdx.y); break;
     }
     grad_dp_block_done(a.fuse);
 }
@@ -1246,7 +1315,7 @@ extern "C" __global__ __launch_bounds__(256) void cfl_grad_x3_half_split_kernel(
 template <bool STAGED>
 __device__ __forceinline__ void grad_x3_kernel_body(const GradArgs &a, char *smem) {
     f32x4 *lds = (f32x4 *)smem;
-    if (blockIdx.z == 0) { grad_red_block(a, (float *)smem); grad_dp_block_done(a.fuse); return; }
+    if (blockIdx.z == 0) { grad_red_block(a, (float *)smem); return; }
     const GradJob &jb = a.job[blockIdx.z - 1];
     switch (jb.nt) {
         case 1: grad_body_x3<1, STAGED>(jb, a, lds); break;
@@ -1254,7 +1323,6 @@ __device__ __forceinline__ void grad_x3_kernel_body(const GradArgs &a, char *sme
         case 3: grad_body_x3<3, STAGED>(jb, a, lds); break;
         default: grad_body_x3<4, STAGED>(jb, a, lds); break;
     }
-    grad_dp_block_done(a.fuse);
 }
 
 extern "C" __global__ __launch_bounds__(256) void cfl_grad_x3_kernel(GradArgs a_) {   // Rpad / P <= 8192
