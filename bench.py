@@ -877,7 +877,8 @@ def dp_form(args, eng, pool, device, fused_us):
                        'library_launches': {k: int(c) // 50 for k, (ms, c) in p1.items()},
                        'lost_handoffs': int(eng1._oneshot.lost.item()),
                        'what': 'CFL_DP_EXCHANGE=oneshot: proj_bx3 -> mid -> grad (finished entries pushed into the owner\'s slots, '
-                               'arrival flags raised by its last workgroup) -> cfl_dp_rs_adam -> cfl_dp_rs_gather_planes'}
+                               'arrival flags raised by its last workgroup) -> sharded Adam + all-gather + planes in one launch '
+                               '(cfl_dp_adam_gather_kernel)'}
             del eng1
         except Exception as e:          # noqa: BLE001
             oneshot = {'error': repr(e)}

@@ -5,8 +5,8 @@
 // every link carries 1/N of the buffer twice, and every rank applies Adam to 1/N of the parameters:
 //
 //   cfl_dp_rs_push    (reduce-scatter, send side) slice s of this rank's buffer -> row `rank` of rank s's slot array,
-//                     all N - 1 links at once; __threadfence_system() by every block; the last block (device-scope
-//                     ticket) releases at system scope and raises flag A[rank] = generation in every peer;
+//                     all N - 1 links at once; every block drains its stores, the last block (device-scope ticket)
+//                     raises flag A[rank] = generation in every peer;
 //   cfl_dp_rs_adam    waits (bounded by wall-clock time) until the N local A flags carry the generation, sums the N rows
 //                     of ITS slice in rank order (system-scope loads; deterministic, no reduction tree), applies TF-Adam
 //                     to its slice of theta / m / v -- the Adam slots are sharded, each rank keeps 1/N of them current --
@@ -14,6 +14,11 @@
 //                     peer's stage buffer; the last block raises flag B[rank] in every peer;
 //   cfl_dp_rs_gather  (all-gather, receive side) waits for the N - 1 B flags and copies the peers' slices from the local
 //                     stage buffer into theta (and the scalar sums into the caller's buffer).
+// Round 6: (1) the push is FUSED into the weight-gradient launch (csrc/pair_grad.h: the tile finishers store their entries into
+// the owners' slots, the launch's last workgroup raises the A flags) -- cfl_dp_rs_push stays for plans without that form; (2) the
+// sharded Adam and the all-gather run in ONE launch (cfl_dp_adam_gather_kernel; CFL_DP_SPLIT_ADAM=1: the two launches below);
+// (3) no __threadfence_system() anywhere: write-through system-scope stores + drains (see "Memory model" below).  A step is
+// proj, mid, grad(+push), adam_gather: FOUR launches behind one library call (cfl_pair_dp_step[s]_idx_planes, cfl_hip.hip).
 // Every rank ends the step with bit-identical parameters by construction (each slice has ONE writer; the others copy).
 // Per step and link: 2 x (n / N) floats (0.39 MB at the headline shape and N = 8, against 1.57 MB for the push-everything
 // form of round 3 and 2 x 7/8 x 1.57 MB around a ring).
@@ -205,6 +210,77 @@ __global__ __launch_bounds__(256) void cfl_dp_rs_gather_kernel(float *theta, flo
         } else {
             ((dp_f32x4 *)sum_out)[i] = x;
             if (sc) ((dp_f32x4 *)scalars_copy)[i - nadam4] = x;
+        }
+    }
+}
+
+// cfl_dp_rs_adam + cfl_dp_rs_gather in ONE launch (round 6).  The two phases of a rank do not depend on each other -- the gather of
+// rank r reads what the OTHER ranks' Adam phases pushed -- so no grid barrier is needed between them: a workgroup does its share
+// of the sharded Adam (waits for the A flags only if it has a share), counts itself (the last one raises this rank's B flags),
+// then waits for the peers' B flags and copies its share of their slices.  No deadlock: phase 1 of every rank waits only for
+// weight-gradient launches (A flags), phase 2 only for peers' phase 1.  One launch and one dispatch less per step.
+__global__ __launch_bounds__(256) void cfl_dp_adam_gather_kernel(float *theta, float *m, float *v, const float *gslots,
+                                                                 const unsigned *flags_a, const unsigned *flags_b, const float *stage,
+                                                                 int world, int rank, long long n4, long long nadam4, long long slice4,
+                                                                 float *sum_out, DpPeers p, float lr_t, float b1, float b2, float eps,
+                                                                 unsigned gen, int *lost, unsigned long long ticks, unsigned *ticket,
+                                                                 ThetaPlaneRegions pr, float *scalars_copy) {
+    const long long lo = (long long)rank * slice4, hi = lo + slice4 < n4 ? lo + slice4 : n4;
+    const long long stride = (long long)gridDim.x * 256;
+    // ---- phase 1: this rank's slice -- rank-ordered sum of the pushed rows, TF-Adam, planes, push of the updated slice ----------
+    if (lo + (long long)blockIdx.x * 256 < hi) {        // (uniform per workgroup: it owns part of the slice)
+        const bool ok = dp_wait_flags(flags_a, world, -1, gen, ticks, lost);
+        const float scale = 1.f / (float)world;
+        for (long long i = lo + (long long)blockIdx.x * 256 + threadIdx.x; i < hi; i += stride) {
+            dp_f32x4 g = {0.f, 0.f, 0.f, 0.f};
+            for (int r0 = 0; r0 < world; r0 += 4) {
+                dp_f32x4 s4[4];
+                const float *q[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) q[k] = gslots + ((long long)(r0 + k < world ? r0 + k : 0) * slice4 + (i - lo)) * 4;
+                load_sys16x4(q[0], q[1], q[2], q[3], s4);
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (r0 + k < world) g = (r0 + k == 0) ? s4[k] : g + s4[k];
+            }
+            if (!ok) g = (dp_f32x4){NAN, NAN, NAN, NAN};
+            ((dp_f32x4 *)sum_out)[i] = g;
+            if (scalars_copy && i >= nadam4 && i < nadam4 + 4) ((dp_f32x4 *)scalars_copy)[i - nadam4] = g;
+            dp_f32x4 out = g;
+            if (i < nadam4) {
+                g *= scale;
+                dp_f32x4 mm = ((dp_f32x4 *)m)[i], vv = ((dp_f32x4 *)v)[i], th = ((dp_f32x4 *)theta)[i];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {   // TF-1.x Adam, the same operations as adam1() of cfl_hip.hip
+                    mm[e] = fmaf(b1, mm[e], (1.f - b1) * g[e]);
+                    vv[e] = fmaf(b2, vv[e], ((1.f - b2) * g[e]) * g[e]);
+                    th[e] -= lr_t * mm[e] / (sqrtf(vv[e]) + eps);
+                }
+                ((dp_f32x4 *)m)[i] = mm;
+                ((dp_f32x4 *)v)[i] = vv;
+                ((dp_f32x4 *)theta)[i] = th;
+                theta_planes_store4(pr, i * 4, th);
+                out = th;
+            }
+            for (int r = 0; r < world; ++r)
+                if (r != rank) dp_store_sys16(p.slot[r] + 4 * i, out);
+        }
+    }
+    dp_signal_peers(p, gen, ticket);                    // every workgroup counts; the last one raises this rank's B flags
+    // ---- phase 2: the peers' slices, from the local stage buffer -------------------------------------------------------------
+    if (world > 1) {
+        const bool ok = dp_wait_flags(flags_b, world, rank, gen, ticks, lost);
+        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+            if (i >= lo && i < hi) continue;
+            dp_f32x4 x = load_sys16(stage + i * 4);
+            if (!ok) x = (dp_f32x4){NAN, NAN, NAN, NAN};
+            if (i < nadam4) {
+                ((dp_f32x4 *)theta)[i] = x;
+                theta_planes_store4(pr, i * 4, x);
+            } else {
+                ((dp_f32x4 *)sum_out)[i] = x;
+                if (scalars_copy && i < nadam4 + 4) ((dp_f32x4 *)scalars_copy)[i - nadam4] = x;
+            }
         }
     }
 }
@@ -412,6 +488,36 @@ extern "C" int cfl_dp_exchange_step(const CflShape *shape, CflDpExchange *ex, in
     if (!pushed) {
         rc = cfl_dp_rs_push(gradbuf, ex->n, ex->slice, ex->peer_rows[par], ex->peer_flag_a[par], ex->world, gen, ex->tickets, stream);
         if (rc) return rc;
+    }
+    const char *split = getenv("CFL_DP_SPLIT_ADAM");
+    if (!(split && atoi(split) > 0)) {
+        // default: the sharded Adam and the all-gather in ONE launch (cfl_dp_adam_gather_kernel)
+        ThetaPlaneRegions pr;
+        memset(&pr, 0, sizeof(pr));
+        if (planes) {
+            if (!planes->buf || ((uintptr_t)planes->buf & 15)) return cfl_set_err(CFL_E_SHAPE, "cfl_dp_exchange_step: theta planes buffer NULL or misaligned");
+            rc = theta_plane_regions(shape, planes->buf, &pr);
+            if (rc) return rc;
+        }
+        if (!theta || !m || !v || !gradbuf) return cfl_set_err(CFL_E_SHAPE, "cfl_dp_exchange_step: NULL pointer");
+        if (((uintptr_t)theta | (uintptr_t)m | (uintptr_t)v | (uintptr_t)gradbuf) & 15)
+            return cfl_set_err(CFL_E_SHAPE, "cfl_dp_exchange_step: theta / m / v / gradbuf must be 16-byte aligned");
+        DpPeers p;
+        rc = dp_fill_peers(&p, ex->peer_stage[par], ex->peer_flag_b[par], ex->world, "cfl_dp_exchange_step");
+        if (rc) return rc;
+        int blocks = (int)((ex->n / 4 + 255) / 256);
+        if (blocks > dp_max_blocks()) blocks = dp_max_blocks();
+        {
+            DpProf prof(stream);
+            hipLaunchKernelGGL(cfl_dp_adam_gather_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, theta, m, v, ex->slots[par],
+                               ex->flags_a[par], ex->flags_b[par], ex->stage[par], ex->world, ex->rank, (long long)(ex->n / 4),
+                               (long long)(ex->n_adam / 4), (long long)(ex->slice / 4), gradbuf, p, lr_t, beta1, beta2, eps, gen,
+                               (int *)ex->lost, dp_ticks(ex->timeout_s), ex->tickets + 1, pr, scalars_copy);
+        }
+        if (hipGetLastError() != hipSuccess) return cfl_set_err(CFL_E_HIP, "cfl_dp_adam_gather launch failed");
+        if (planes) planes->valid = 1;
+        ex->step += 1;
+        return CFL_OK;
     }
     rc = cfl_dp_rs_adam(theta, m, v, ex->slots[par], ex->flags_a[par], ex->world, ex->rank, ex->n, ex->n_adam, ex->slice, gradbuf,
                         ex->peer_stage[par], ex->peer_flag_b[par], lr_t, beta1, beta2, eps, gen, ex->lost, ex->timeout_s,

@@ -169,6 +169,7 @@ worst, same = 0.0, True
 def dp_step(e, batch, separate=False):
     os.environ['CFL_FORCE_DP'] = '1'
     os.environ['CFL_DP_PUSH_SEPARATE'] = '1' if separate else '0'
+    os.environ['CFL_DP_SPLIT_ADAM'] = '1' if separate else '0'      # (the three-kernel form: push | sharded Adam | gather)
     e.step(batch)
     os.environ['CFL_FORCE_DP'] = '0'
 for i in range(%(steps)d):
@@ -178,8 +179,8 @@ for i in range(%(steps)d):
     else:
         batch = pool[i %% 3]
     dp_step(dp, batch)                   # proj_bx3 -> mid -> grad | ncclAllReduce of gradbuf, called by the library | Adam + planes
-    dp_step(dpo, batch)                  # proj_bx3 -> mid -> grad (+ push into the slots) | rs_adam | rs_gather (+ planes)
-    dp_step(dps, batch, separate=True)   # ... with cfl_dp_rs_push as a launch of its own
+    dp_step(dpo, batch)                  # proj_bx3 -> mid -> grad (+ push into the slots) | sharded Adam + all-gather (+ planes) in one launch
+    dp_step(dps, batch, separate=True)   # ... with cfl_dp_rs_push, cfl_dp_rs_adam and cfl_dp_rs_gather as launches of their own
     one.step(batch)                      # the fused single-GPU step
     assert dp.planes.valid and one.planes.valid and dpo.planes.valid
     for e in (dp, dpo, dps):
@@ -217,6 +218,7 @@ os.environ['CFL_FORCE_DP'] = '1'
 prof = {}
 for name, e, sep in (('allreduce', dp, False), ('oneshot', dpo, False), ('oneshot_separate_push', dps, True)):
     os.environ['CFL_DP_PUSH_SEPARATE'] = '1' if sep else '0'
+    os.environ['CFL_DP_SPLIT_ADAM'] = '1' if sep else '0'
     H.profile_enable(True)
     for i in range(20):
         e.step(pool[i %% 3])
@@ -250,9 +252,10 @@ def test_dp_branch_on_a_one_rank_rccl_group_equals_the_fused_step():
     assert same, 'a one-rank data-parallel step differs from the fused single-GPU step'
     assert wins_same, 'windowed data-parallel iterations differ from the single-GPU windows'
     # launches per step, from the library's own profile hooks: 3 compute + the stand-alone Adam (+ RCCL's kernel);
-    # one-shot exchange: 3 compute (the push rides in grad) + sharded Adam + gather = FIVE; six with the push as its own launch
+    # one-shot exchange: 3 compute (the push rides in grad) + ONE launch for the sharded Adam and the all-gather = FOUR; six in the
+    # separate form (push | Adam | gather)
     assert prof['allreduce'] == {'proj': 1, 'mid': 1, 'grad': 1, 'adam': 1}, prof
-    assert prof['oneshot'] == {'proj': 1, 'mid': 1, 'grad': 1, 'dp_exchange': 2}, prof
+    assert prof['oneshot'] == {'proj': 1, 'mid': 1, 'grad': 1, 'dp_exchange': 1}, prof
     assert prof['oneshot_separate_push'] == {'proj': 1, 'mid': 1, 'grad': 1, 'dp_exchange': 3}, prof
 
 
