@@ -950,6 +950,8 @@ def main():
     teacher = teacher_of(D, device)
     if args.dp_leg:
         # child job of the main N-rank run (started by its rank 0): ONE risky leg, its own JSON line, nothing else
+        if os.environ.get('CFL_BENCH_FAIL_DP_LEG') == '1':      # (tests: a child job that dies must cost an `error` entry, not the line)
+            os._exit(3)
         res = {'dp_leg': args.dp_leg}
         if args.dp_leg == 'oneshot':
             for b in (B, 2048):

@@ -179,6 +179,24 @@ def test_bench_starts_its_own_ranks():
     assert r2.returncode != 0 and '--gpus 2 but WORLD_SIZE 1' in r2.stderr
 
 
+def test_bench_line_survives_a_dying_one_shot_child_job():
+    """The one-shot exchange has never run on more than one GPU: `bench.py --gpus N` measures it in a CHILD job so that a crash or a
+    hang there cannot take the headline line down.  Injected: the child's ranks die at once."""
+    env = dict(os.environ, CFL_DIST_BACKEND='gloo', CFL_BENCH_LEG_SECONDS='0.1', CFL_DP_MAX_BLOCKS='64', CFL_BENCH_FAIL_DP_LEG='1')
+    env.pop('WORLD_SIZE', None)
+    env.pop('RANK', None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '5', '--warmup', '2',
+                        '--repeats', '3', '--pool-mib', '64', '--restore-steps', '20', '--no-cpu-baseline', '--no-kernel-profile',
+                        '--no-cli-loop'], env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['value'] > 0
+    assert 'error' in out['dp_scaling']['oneshot'], out['dp_scaling']['oneshot']
+    assert out['dp_scaling']['b2048_allreduce']['us_per_step'] > 0
+
+
 def _oneshot_worker(rank, world, port, out):
     for p in (ROOT, os.path.join(ROOT, 'compatibility-family-learning_amd')):
         if p not in sys.path:
