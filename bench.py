@@ -1179,7 +1179,7 @@ def main():
         if not args.no_cpu_baseline:
             # the AUC half of the metric on a TRAINED model: the timed repeats were restored to an early state, so train on
             # (untimed) before scoring held-out pairs with the HIP path and with the fp64 oracle
-            run(6000, 0)
+            run(40000, 0)
             torch.cuda.synchronize()
             out['eval_auc'] = eval_auc(args, eng, device, teacher)
             out['eval_auc']['trained_steps'] = int(eng.global_step)
