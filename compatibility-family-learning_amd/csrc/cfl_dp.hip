@@ -132,6 +132,23 @@ __device__ __forceinline__ void load_sys16x4(const float *p0, const float *p1, c
         : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]) : "v"(p0), "v"(p1), "v"(p2), "v"(p3) : "memory");
 }
 
+// ... eight rows in ONE round trip (the merged Adam + gather kernel: a rank of an 8-GPU job sums eight rows per element; two
+// statements of four were two dependent system-scope round trips)
+__device__ __forceinline__ void load_sys16x8(const float *const (&p)[8], dp_f32x4 (&o)[8]) {
+    asm volatile(
+        "global_load_dwordx4 %0, %8, off sc0 sc1\n\t"
+        "global_load_dwordx4 %1, %9, off sc0 sc1\n\t"
+        "global_load_dwordx4 %2, %10, off sc0 sc1\n\t"
+        "global_load_dwordx4 %3, %11, off sc0 sc1\n\t"
+        "global_load_dwordx4 %4, %12, off sc0 sc1\n\t"
+        "global_load_dwordx4 %5, %13, off sc0 sc1\n\t"
+        "global_load_dwordx4 %6, %14, off sc0 sc1\n\t"
+        "global_load_dwordx4 %7, %15, off sc0 sc1\n\t"
+        "s_waitcnt vmcnt(0)"
+        : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7])
+        : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]), "v"(p[4]), "v"(p[5]), "v"(p[6]), "v"(p[7]) : "memory");
+}
+
 __global__ __launch_bounds__(256) void cfl_dp_rs_push_kernel(const float *src, long long n4, long long slice4, DpPeers p,
                                                              unsigned gen, unsigned *ticket) {
     const long long stride = (long long)gridDim.x * 256;
@@ -232,24 +249,40 @@ __global__ __launch_bounds__(256) void cfl_dp_adam_gather_kernel(float *theta, f
         const bool ok = dp_wait_flags(flags_a, world, -1, gen, ticks, lost);
         const float scale = 1.f / (float)world;
         for (long long i = lo + (long long)blockIdx.x * 256 + threadIdx.x; i < hi; i += stride) {
+            // the local operands first (ordinary loads, in flight while the system-scope row loads below wait for theirs)
+            const bool upd = i < nadam4;
+            dp_f32x4 mm = {0.f, 0.f, 0.f, 0.f}, vv = mm, th = mm;
+            if (upd) { mm = ((dp_f32x4 *)m)[i]; vv = ((dp_f32x4 *)v)[i]; th = ((dp_f32x4 *)theta)[i]; }
             dp_f32x4 g = {0.f, 0.f, 0.f, 0.f};
-            for (int r0 = 0; r0 < world; r0 += 4) {
+            if (world > 4) {
+                for (int r0 = 0; r0 < world; r0 += 8) {   // eight rows per round trip, added in rank order
+                    dp_f32x4 s8[8];
+                    const float *q[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) q[k] = gslots + ((long long)(r0 + k < world ? r0 + k : 0) * slice4 + (i - lo)) * 4;
+                    load_sys16x8(q, s8);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k)
+                        if (r0 + k < world) g = (r0 + k == 0) ? s8[k] : g + s8[k];
+                }
+            } else if (world == 1) {              // (a one-rank group: one row, no padding loads of uncached memory)
+                g = load_sys16(gslots + (i - lo) * 4);
+            } else {
                 dp_f32x4 s4[4];
                 const float *q[4];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) q[k] = gslots + ((long long)(r0 + k < world ? r0 + k : 0) * slice4 + (i - lo)) * 4;
+                for (int k = 0; k < 4; ++k) q[k] = gslots + ((long long)(k < world ? k : 0) * slice4 + (i - lo)) * 4;
                 load_sys16x4(q[0], q[1], q[2], q[3], s4);
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
-                    if (r0 + k < world) g = (r0 + k == 0) ? s4[k] : g + s4[k];
+                    if (k < world) g = (k == 0) ? s4[k] : g + s4[k];
             }
             if (!ok) g = (dp_f32x4){NAN, NAN, NAN, NAN};
             ((dp_f32x4 *)sum_out)[i] = g;
             if (scalars_copy && i >= nadam4 && i < nadam4 + 4) ((dp_f32x4 *)scalars_copy)[i - nadam4] = g;
             dp_f32x4 out = g;
-            if (i < nadam4) {
+            if (upd) {
                 g *= scale;
-                dp_f32x4 mm = ((dp_f32x4 *)m)[i], vv = ((dp_f32x4 *)v)[i], th = ((dp_f32x4 *)theta)[i];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {   // TF-1.x Adam, the same operations as adam1() of cfl_hip.hip
                     mm[e] = fmaf(b1, mm[e], (1.f - b1) * g[e]);
