@@ -166,6 +166,8 @@ assert H.dp_push_fusable(dp.shape, B)
 pool = [[torch.from_numpy((np.abs(rng.randn(B, D)) * 13.0).astype(np.float32)).cuda() for _ in range(4)] for _ in range(3)]
 table = torch.cat([x for b in pool for x in b])
 worst, same = 0.0, True
+_lay = H.layout(dp.shape)
+_heads = (_lay.enc[0].proto, _lay.enc[0].outputs)             # (the plane regions of the two weight matrices; the rest of the buffer is never written)
 def dp_step(e, batch, separate=False):
     os.environ['CFL_FORCE_DP'] = '1'
     os.environ['CFL_DP_PUSH_SEPARATE'] = '1' if separate else '0'
@@ -185,7 +187,8 @@ for i in range(%(steps)d):
     assert dp.planes.valid and one.planes.valid and dpo.planes.valid
     for e in (dp, dpo, dps):
         worst = max(worst, float((e.theta - one.theta).abs().max()))
-        same = same and bool(torch.equal(e.theta, one.theta)) and bool(torch.equal(e.planes.buf, one.planes.buf))
+        same = same and bool(torch.equal(e.theta, one.theta)) and all(
+            bool(torch.equal(e.planes.buf[3 * h.w:3 * (h.w + h.npad * D)], one.planes.buf[3 * h.w:3 * (h.w + h.npad * D)])) for h in _heads)
         a, b = e.read_scalars(), one.read_scalars()
         worst = max(worst, max(abs(a[k] - b[k]) / max(1.0, abs(b[k])) for k in a))
 assert int(dpo._oneshot.lost.item()) == 0 and dpo._oneshot.step == %(steps)d
@@ -257,6 +260,91 @@ def test_dp_branch_on_a_one_rank_rccl_group_equals_the_fused_step():
     assert prof['allreduce'] == {'proj': 1, 'mid': 1, 'grad': 1, 'adam': 1}, prof
     assert prof['oneshot'] == {'proj': 1, 'mid': 1, 'grad': 1, 'dp_exchange': 1}, prof
     assert prof['oneshot_separate_push'] == {'proj': 1, 'mid': 1, 'grad': 1, 'dp_exchange': 3}, prof
+
+
+_FAMILIES = r'''
+import os, sys
+sys.path[:0] = [%(root)r, os.path.join(%(root)r, 'compatibility-family-learning_amd')]
+os.environ.update(CFL_FORCE_DP='1', MASTER_PORT=%(port)r, MASTER_ADDR='127.0.0.1', CFL_DIST_BACKEND='gloo', CFL_DP_EXCHANGE='oneshot')
+import numpy as np, torch
+import torch.distributed as dist
+from cfl import engine, hipabi as H
+from cfl.engine import PairEngine
+from oracle import cfl_oracle as O
+assert engine.init_from_env() == 1 and dist.get_backend() == 'gloo'
+CASES = %(cases)r
+out = []
+for style, dtype, D, L, K, B, lkw, directed, steps in CASES:
+    rng = np.random.RandomState(3)
+    cfg = O.EncoderCfg(D=D, L=L, K=K, dist_type=dtype, style=style)
+    def params():
+        p = O.init_encoder_params(cfg, rng, np.float32)
+        for k in p:
+            p[k] = (p[k] + 0.05 * rng.randn(*p[k].shape).astype(np.float32) * (0.1 if k.endswith('/W') else 1.0)).astype(np.float32)
+        return p
+    p0 = params()
+    p1 = params() if directed else None
+    def mk():
+        return PairEngine(D, L, K, dtype, weight_norm=cfg.weight_norm, has_bias=cfg.has_bias, directed=directed,
+                          norm=H.make_norm(1.0 / 31.9098), loss=H.make_loss(**lkw), lr=1e-3, device='cuda', params=p0, params_dst=p1,
+                          thr=40.0 if dtype == 'siamese' else 0.5, batch_size=B)
+    os.environ['CFL_FORCE_DP'] = '1'
+    dp = mk()
+    os.environ['CFL_FORCE_DP'] = '0'
+    one = mk()
+    assert dp._oneshot is not None and one._oneshot is None
+    pool = [[torch.from_numpy((np.abs(rng.randn(B, D)) * 8.0).astype(np.float32)).cuda() for _ in range(4)] for _ in range(3)]
+    pushed = H.dp_push_fusable(dp.shape, B)
+    same, worst = True, 0.0
+    for i in range(steps):
+        os.environ['CFL_FORCE_DP'] = '1'
+        dp.step(pool[i %% 3])
+        os.environ['CFL_FORCE_DP'] = '0'
+        one.step(pool[i %% 3])
+        same = same and bool(torch.equal(dp.theta, one.theta)) and bool(torch.equal(dp.m, one.m))
+        worst = max(worst, float((dp.theta - one.theta).abs().max()))
+    a, b = dp.read_scalars(), one.read_scalars()
+    worst = max(worst, max(abs(a[k] - b[k]) / max(1.0, abs(b[k])) for k in a))
+    # the planes of every head a side projects through (the rest of the buffer is never written by the fused tail)
+    lay = H.layout(dp.shape)
+    heads = {'pcd': (lay.enc[0].proto, lay.enc[1].outputs), 'monomer': (lay.enc[0].outputs, lay.enc[1].proto),
+             'siamese': (lay.enc[0].outputs, lay.enc[1].outputs)}[dtype]
+    planes_same = None
+    if dp.planes.valid and one.planes.valid:
+        planes_same = all(bool(torch.equal(dp.planes.buf[3 * h.w:3 * (h.w + h.npad * D)], one.planes.buf[3 * h.w:3 * (h.w + h.npad * D)]))
+                          for h in heads)
+    out.append((style, dtype, K, directed, pushed, same, worst, planes_same, int(dp._oneshot.lost.item())))
+print('RESULT', repr(out), flush=True)
+engine.finalize()
+'''
+
+
+def test_one_shot_exchange_on_every_model_family_equals_the_fused_step():
+    # Round 6: the fused push writes EVERY kind of gradient entry into the owner's slot -- weight tiles from the tile finishers, bias /
+    # gain / threshold / gate-head / unused-head entries and the scalars from the reduction blocks (fuse_apply1<DP>, the kind-1/2/3
+    # blocks) -- so every model family goes through it on a one-rank group (gloo for the control plane) and must equal the fused
+    # single-GPU step bit for bit: parameters, Adam slots, planes, scalars.  Families whose plan has no half-tile weight gradient
+    # take the separate push kernel (pushed == False) and must agree as well.
+    cases = [
+        ('cfl', 'pcd', 2048, 20, 5, 1024, dict(pos_weight=0.25), False, 12),                       # config 4: weight norm
+        ('cfl', 'siamese', 1024, 256, 1, 512, dict(use_threshold=False, caffe_margin=100.0, pos_weight=0.0625), False, 12),   # config 3: paired hand-off
+        ('cfl', 'monomer', 2048, 32, 3, 1024, dict(reg_const=1e-3), False, 12),                     # gate head + gains
+        ('cfl', 'pcd', 512, 12, 3, 256, dict(reg_const=1e-3), True, 12),                            # directed: unused heads (kind 3)
+        ('cfl', 'monomer', 512, 12, 3, 256, dict(), True, 8),
+        ('dist', 'pcd', 1088, 7, 2, 100, dict(), False, 12),                                        # D % 128 != 0: exact-fp32 projection
+        ('dist', 'pcd', 4096, 20, 3, 4096, dict(), False, 4),                                       # rows > 7680: no half-tile kernel -> separate push
+    ]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK'):
+        env.pop(k, None)
+    code = _FAMILIES % dict(root=ROOT, port=str(38500 + os.getpid() % 2000), cases=cases)
+    r = subprocess.run([sys.executable, '-c', code], env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    res = eval([ln for ln in r.stdout.splitlines() if ln.startswith('RESULT')][-1][len('RESULT '):])
+    assert len(res) == len(cases)
+    assert any(not x[4] for x in res) and any(x[4] for x in res), res          # both push forms were exercised
+    for style, dtype, K, directed, pushed, same, worst, planes_same, lost in res:
+        assert lost == 0 and same and worst <= 2e-6 and planes_same in (True, None), (style, dtype, K, directed, pushed, same, worst, planes_same)
 
 
 @pytest.mark.parametrize('phase', ['1', '2', '3'])
