@@ -15,7 +15,8 @@ EXPORTS = ('cfl_conv_transpose_workspace_bytes', 'cfl_conv2d_transpose_wn_fwd', 
            'cfl_rowdist_loss', 'cfl_perturb_workspace_bytes', 'cfl_perturb', 'cfl_grad_penalty', 'cfl_copy_cols',
            'cfl_tile_concat_channels', 'cfl_tile_concat_channels_bwd', 'cfl_auc_workspace_bytes', 'cfl_auc', 'cfl_image_transform',
            'cfl_ew_affine_clip_channels', 'cfl_conv_cache_bytes', 'cfl_conv2d_wn_fwd_cached', 'cfl_conv2d_wn_bwd_cached', 'cfl_conv2d_wn_fwd_fused', 'cfl_conv2d_wn_bwd_fused',
-           'cfl_conv_bwd_takes_subpixel', 'cfl_conv_prepare_cached')
+           'cfl_conv_bwd_takes_subpixel', 'cfl_conv_prepare_cached', 'cfl_conv_wgrad_slab_bytes', 'cfl_conv2d_wn_wgrad_slabs',
+           'cfl_conv_wfinal_many')
 
 EW = {None: 0, 'linear': 0, 'lrelu': 1, 'relu': 2, 'tanh': 3, 'sigmoid': 4}
 
@@ -68,9 +69,13 @@ def lib():
                                           [sz, vp, sz, C.POINTER(C.c_int32), vp])
     L.cfl_conv_bwd_takes_subpixel.argtypes = [C.POINTER(CflConv)]
     L.cfl_conv_prepare_cached.argtypes = [C.POINTER(CflConv), vp, vp, vp, sz, C.POINTER(C.c_int32), vp]
+    L.cfl_conv_wgrad_slab_bytes.argtypes = [C.POINTER(CflConv)]
+    L.cfl_conv_wgrad_slab_bytes.restype = sz
+    L.cfl_conv2d_wn_wgrad_slabs.argtypes = [C.POINTER(CflConv), vp, vp, vp, C.c_int32, vp, sz, vp]
+    L.cfl_conv_wfinal_many.argtypes = [C.c_int32, C.POINTER(CflConv)] + [C.POINTER(vp)] * 4 + [f32] + [C.POINTER(vp)] * 3 + [vp]
     for n in EXPORTS:
         if n not in ('cfl_conv_transpose_workspace_bytes', 'cfl_perturb_workspace_bytes', 'cfl_auc_workspace_bytes',
-                     'cfl_conv_cache_bytes'):
+                     'cfl_conv_cache_bytes', 'cfl_conv_wgrad_slab_bytes'):
             getattr(L, n).restype = C.c_int
     _ready = True
     return L
@@ -156,6 +161,34 @@ def conv_prepare(conv, V, g, cache):
     cache.ensure(conv, V.device)
     _check(lib().cfl_conv_prepare_cached(C.byref(conv), _dev(V), _opt(g), cache.buf.data_ptr(), cache.buf.numel() * 4,
                                          C.byref(cache.flags), _stream()))
+
+
+def conv_wgrad_slab_bytes(conv):
+    n = lib().cfl_conv_wgrad_slab_bytes(C.byref(conv))
+    if n == 0:
+        raise H.CflHipError('cfl_conv_wgrad_slab_bytes: ' + lib().cfl_last_error().decode())
+    return n
+
+
+def conv_wgrad_slabs(conv, x, y, dy, slab, dy_subpixel=False):
+    """ONLY the weight-gradient contraction of a layer, as split-K slabs in `slab` (cfl_conv2d_wn_wgrad_slabs); the slabs are
+    finished later, many layers at once, by conv_wfinal_many."""
+    _count_flops(conv, False, 1)
+    _check(lib().cfl_conv2d_wn_wgrad_slabs(C.byref(conv), _dev(x), _opt(y), _dev(dy), int(bool(dy_subpixel)), slab.data_ptr(),
+                                           slab.numel() * 4, _stream()))
+
+
+def conv_wfinal_many(jobs, reg_const=0.0):
+    """jobs: [(conv, slab, V, g, cache, dV, dg, db)] -- the layers of one backward chain, finished by one slab-sum launch and one
+    finalisation launch (cfl_conv_wfinal_many)"""
+    n = len(jobs)
+    if not n:
+        return
+    convs = (CflConv * n)(*[j[0] for j in jobs])
+    arr = lambda k, f: (C.c_void_p * n)(*[f(j[k]) for j in jobs])
+    ptr = lambda t: t.data_ptr() if t is not None else None
+    _check(lib().cfl_conv_wfinal_many(n, convs, arr(1, ptr), arr(2, ptr), arr(3, ptr), arr(4, lambda c: c.buf.data_ptr()),
+                                      float(reg_const), arr(5, ptr), arr(6, ptr), arr(7, ptr), _stream()))
 
 
 def conv_bwd_takes_subpixel(conv):

@@ -133,6 +133,7 @@ class WNLayer(object):
         self._cache = G.ConvCache() if kind != 'convt' else None
         self._cache_version = -1
         self._prep_desc = None       # shape of the layer's first forward call: what `prepare` rebuilds the cache for
+        self._slabs = {}             # (workspace, call shape) -> split-K slab region of the deferred weight-gradient finalisation
         pool.layers.append(self)
 
     def cache(self):
@@ -206,8 +207,16 @@ class WNLayer(object):
             return dx
         side.wait_stream(torch.cuda.current_stream())          # x, y, dy were produced on the main stream
         with torch.cuda.stream(side):
-            G.conv_bwd(d, x, self.p('V'), self.p('g'), y, dy, ws.side_ws.get(d, t), dx=None, dV=dV, dg=dg, db=db,
-                       transposed=t, cache=cache, **sp)
+            if Workspace.defer_wfinal:
+                # only the contraction now, into this layer's own slab region; the slab sums and the weight-norm finalisation of
+                # ALL the layers of this backward chain run as one launch pair at Workspace.join() (cfl_conv_wfinal_many:
+                # ~80 launches of 5-16 us per MrCGAN step before)
+                slab = self._slab(ws, d)
+                G.conv_wgrad_slabs(d, x, y, dy, slab, dy_subpixel=dy_subpixel)
+                ws.pending.append((d, slab, self.p('V'), self.p('g'), cache, dV, dg, db))
+            else:
+                G.conv_bwd(d, x, self.p('V'), self.p('g'), y, dy, ws.side_ws.get(d, t), dx=None, dV=dV, dg=dg, db=db,
+                           transposed=t, cache=cache, **sp)
         for tt in (x, y, dy):
             if tt is not None:
                 tt.record_stream(side)                          # the allocator must not recycle them under the side stream
@@ -217,6 +226,15 @@ class WNLayer(object):
                        transposed=t, cache=cache, **sp)
         return dx
 
+    def _slab(self, ws, d):
+        """this layer's split-K slab region for weight gradients taken through workspace `ws` at call shape `d` (kept: a layer is
+        differentiated by up to three backward chains per step, each with its own workspace, on its own stream)"""
+        key = (id(ws), d.B, d.H, d.W, d.act)
+        slab = self._slabs.get(key)
+        if slab is None:
+            slab = self._slabs[key] = torch.empty(G.conv_wgrad_slab_bytes(d) // 4, dtype=torch.float32, device=self.pool.device)
+        return slab
+
     def bwd_takes_subpixel(self, B, Hh, W):
         """can bwd(..., dy_subpixel=True) be used for an input of this shape (see hipgan.conv_bwd_takes_subpixel)?"""
         return self.kind == 'conv' and G.conv_bwd_takes_subpixel(self.desc(B, Hh, W, None))
@@ -225,6 +243,8 @@ class WNLayer(object):
 class Workspace(object):
     # CFL_GAN_OVERLAP=0 keeps every launch of a network on one stream (A/B runs, debugging)
     overlap = os.environ.get('CFL_GAN_OVERLAP', '1') not in ('0', '')
+    # CFL_GAN_DEFER_WFINAL=0: every weight gradient finishes itself (slab sums + finalisation per layer: the form of rounds 4-5)
+    defer_wfinal = os.environ.get('CFL_GAN_DEFER_WFINAL', '1') not in ('0', '')
 
     def __init__(self, device, side=True):
         self.device = device
@@ -234,10 +254,16 @@ class Workspace(object):
         self.side_stream = torch.cuda.Stream(device=device) if (side and Workspace.overlap) else None
         self.side_ws = Workspace(device, side=False) if self.side_stream is not None else None
         self.side_used = False
+        self.pending = []            # deferred weight-gradient finalisations of the backward chain in flight (WNLayer.bwd)
 
     def join(self):
-        """order the side stream's work (weight gradients) before whatever the current stream does next"""
+        """finish the deferred weight gradients (one launch pair for all layers of the chain) and order the side stream's work
+        before whatever the current stream does next"""
         if self.side_stream is not None and self.side_used:
+            if self.pending:
+                with torch.cuda.stream(self.side_stream):
+                    G.conv_wfinal_many(self.pending)
+                self.pending = []
             torch.cuda.current_stream().wait_stream(self.side_stream)
             self.side_used = False
 

@@ -1008,6 +1008,208 @@ extern "C" int cfl_conv2d_wn_bwd_fused(const CflConv *c, const float *x, const f
     return hipGetLastError() == hipSuccess ? CFL_OK : cfl_set_err(CFL_E_HIP, "conv bwd launch failed");
 }
 
+// ---- deferred weight-gradient finalisation (round 6) -----------------------------------------------------------------------------
+// cfl_conv2d_wn_bwd_* ends every weight gradient with its own small launches: slab sums (slab_sum_kernel) and the per-channel
+// weight-norm finalisation (conv_wfinal_kernel) -- ~80 launches of 5-16 us per MrCGAN step, one pair per layer and backward chain.
+// The two entry points below split that work: cfl_conv2d_wn_wgrad_slabs runs ONLY the contraction of a layer into slabs the
+// caller keeps (one region per layer), and cfl_conv_wfinal_many finishes the layers of a whole backward chain at once -- one
+// slab-sum launch and one finalisation launch for all of them (job tables in the kernel arguments; the same per-element code in
+// the same order as the per-layer kernels: bit-identical), the few large filters on their coalesced three-launch form as before.
+extern "C" size_t cfl_conv_wgrad_slab_bytes(const CflConv *c) {
+    ConvGeom g;
+    if (make_geom(c, &g)) return 0;
+    return (size_t)wgrad_splits(g) * ((size_t)g.KH * g.KW * g.Ci + 4) * g.Co * sizeof(float);
+}
+
+extern "C" int cfl_conv2d_wn_wgrad_slabs(const CflConv *c, const float *x, const float *y, const float *dy, int32_t dy_subpixel,
+                                         float *slab, size_t slab_bytes, cfl_stream_t stream) {
+    ConvGeom g;
+    int rc = make_geom(c, &g);
+    if (rc) return rc;
+    if (dy_subpixel && cfl_conv_bwd_takes_subpixel(c) != 1)
+        return cfl_set_err(CFL_E_SHAPE, "conv wgrad: a shuffled dy needs the halo-tile kernels (cfl_conv_bwd_takes_subpixel)");
+    if (!x || !dy || !slab) return cfl_set_err(CFL_E_SHAPE, "NULL pointer");
+    if (!y) {
+        if (g.act != 0) return cfl_set_err(CFL_E_SHAPE, "conv wgrad: y is required when act != 0");
+        y = dy;
+    }
+    if (slab_bytes < cfl_conv_wgrad_slab_bytes(c) || ((uintptr_t)slab & 15)) return cfl_set_err(CFL_E_WORKSPACE, "conv wgrad slabs too small / misaligned");
+    hipStream_t st = (hipStream_t)stream;
+    const int dy_cq = dy_subpixel ? g.Co / 4 : 0;
+    const int rows = g.KH * g.KW * g.Ci;
+    const int npix = g.B * g.OH * g.OW;
+    const bool vec = (g.Ci % 4 == 0) && (g.Co % 4 == 0);
+    const size_t sstride = (size_t)(rows + 4) * g.Co;
+    const HaloWPlan hw = halo_wgrad_plan_of(g);
+    // (the dispatch of cfl_conv2d_wn_bwd_fused's weight-gradient branch, slabs in the caller's region)
+    if (hw.ok)
+        halo_wgrad(hw, g.B, g.H, g.W, g.Ci, g.Co, x, dy, y, g.act, slab, sstride, st, dy_cq);
+    else if (stem_shape(g))
+        stem_dw(g.B, g.H, g.W, g.Co, x, dy, y, g.act, slab, sstride, st);
+    else if (vec)
+        gemm_gather_modes<GG_VEC_MN, GG_VEC_MN>(rows + 4, g.Co, npix, wgrad_klen(g), Im2colXT{Im2colX{x, g}, rows},
+                                                DyPre{dy, y, g.Co, g.act}, StoreSlab{slab, sstride, g.Co}, st);
+    else
+        gemm_gather(rows + 4, g.Co, npix, wgrad_klen(g), Im2colXT{Im2colX{x, g}, rows}, DyPre{dy, y, g.Co, g.act},
+                    StoreSlab{slab, sstride, g.Co}, st);
+    return hipGetLastError() == hipSuccess ? CFL_OK : cfl_set_err(CFL_E_HIP, "conv wgrad launch failed");
+}
+
+#define CFL_WFINAL_MAX_JOBS 32
+struct SlabSumJob { float *slab; size_t stride, n; int splits, gsz, bx, block0, nblocks, vec; };
+struct SlabSumManyArgs { SlabSumJob job[CFL_WFINAL_MAX_JOBS]; int njobs; };
+struct WFinalJob { const float *slab, *V, *scale, *n2; float *dV, *dg, *db; size_t stride; int splits, rows, Co, block0; };
+struct WFinalManyArgs { WFinalJob job[CFL_WFINAL_MAX_JOBS]; int njobs; float reg; };
+
+// slab_sum_kernel for many layers: block b belongs to the job whose [block0, block0 + nblocks) holds it; inside the job the grid
+// is (bx, groups) linearised x fastest -- the same element, the same slabs in the same order as the per-layer launch
+__global__ __launch_bounds__(256) void slab_sum_many_kernel(SlabSumManyArgs a) {
+    int j = 0;
+    while (j < a.njobs - 1 && (int)blockIdx.x >= a.job[j].block0 + a.job[j].nblocks) ++j;
+    const SlabSumJob &jb = a.job[j];
+    const int lb = (int)blockIdx.x - jb.block0, bxi = lb % jb.bx, gy = lb / jb.bx;
+    const int z0 = gy * jb.gsz, z1 = z0 + jb.gsz < jb.splits ? z0 + jb.gsz : jb.splits;
+    if (jb.vec) {
+        const size_t e = ((size_t)bxi * 256 + threadIdx.x) * 4;
+        if (e >= jb.n) return;
+        float *base = jb.slab + e;
+        gg_f32x4 acc = *(const gg_f32x4 *)(base + (size_t)z0 * jb.stride);
+        for (int z = z0 + 1; z < z1; z += 16) {
+            gg_f32x4 v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+                if (z + u < z1) v[u] = *(const gg_f32x4 *)(base + (size_t)(z + u) * jb.stride);
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+                if (z + u < z1) acc += v[u];
+        }
+        *(gg_f32x4 *)(base + (size_t)z0 * jb.stride) = acc;
+    } else {
+        const size_t e = (size_t)bxi * 256 + threadIdx.x;
+        if (e >= jb.n) return;
+        float *base = jb.slab + e;
+        float acc = base[(size_t)z0 * jb.stride];
+        for (int z = z0 + 1; z < z1; z += 16) {
+            float v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+                if (z + u < z1) v[u] = base[(size_t)(z + u) * jb.stride];
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+                if (z + u < z1) acc += v[u];
+        }
+        base[(size_t)z0 * jb.stride] = acc;
+    }
+}
+
+// conv_wfinal_kernel for many layers: one block per output channel of every job
+__global__ __launch_bounds__(256) void conv_wfinal_many_kernel(WFinalManyArgs a) {
+    int j = 0;
+    while (j < a.njobs - 1 && (int)blockIdx.x >= a.job[j + 1].block0) ++j;
+    const WFinalJob &jb = a.job[j];
+    const int co = (int)blockIdx.x - jb.block0, rows = jb.rows, Co = jb.Co, splits = jb.splits;
+    const float *slab = jb.slab, *V = jb.V;
+    float *dV = jb.dV;
+    const size_t stride = jb.stride;
+    float acc = 0.f;
+    for (int r = threadIdx.x; r < rows; r += 256) {
+        const size_t o = (size_t)r * Co + co;
+        float dw = 0.f;
+        for (int z = 0; z < splits; ++z) dw += slab[z * stride + o];
+        dV[o] = dw;   // parked; rewritten below
+        acc = fmaf(dw, V[o], acc);
+    }
+    __shared__ float red[256];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    const float c = red[0], s = jb.scale[co], nn = jb.n2[co];
+    if (threadIdx.x == 0) {
+        if (jb.dg) jb.dg[co] = c * rsqrtf(nn);
+        if (jb.db) {
+            float t = 0.f;
+            for (int z = 0; z < splits; ++z) t += slab[z * stride + (size_t)rows * Co + co];
+            jb.db[co] = t;
+        }
+    }
+    for (int r = threadIdx.x; r < rows; r += 256) {
+        const size_t o = (size_t)r * Co + co;
+        dV[o] = s * dV[o] - (s / nn) * c * V[o] + a.reg * V[o];
+    }
+}
+
+extern "C" int cfl_conv_wfinal_many(int32_t n, const CflConv *convs, float *const *slabs, const float *const *V,
+                                    const float *const *gain, void *const *caches, float reg_const, float *const *dV,
+                                    float *const *dg, float *const *db, cfl_stream_t stream) {
+    if (n <= 0 || !convs || !slabs || !V || !gain || !caches || !dV || !dg || !db) return cfl_set_err(CFL_E_SHAPE, "cfl_conv_wfinal_many: NULL pointer / no jobs");
+    hipStream_t st = (hipStream_t)stream;
+    SlabSumManyArgs sa;
+    WFinalManyArgs wa;
+    memset(&sa, 0, sizeof(sa));
+    memset(&wa, 0, sizeof(wa));
+    wa.reg = reg_const;
+    int sblocks = 0, wblocks = 0;
+    auto flush = [&]() {
+        if (sa.njobs) hipLaunchKernelGGL(slab_sum_many_kernel, dim3(sblocks), dim3(256), 0, st, sa);
+        if (wa.njobs) hipLaunchKernelGGL(conv_wfinal_many_kernel, dim3(wblocks), dim3(256), 0, st, wa);
+        sa.njobs = wa.njobs = 0;
+        sblocks = wblocks = 0;
+    };
+    for (int i = 0; i < n; ++i) {
+        ConvGeom g;
+        int rc = make_geom(&convs[i], &g);
+        if (rc) return rc;
+        if (!slabs[i] || !V[i] || !caches[i] || !dV[i]) return cfl_set_err(CFL_E_SHAPE, "cfl_conv_wfinal_many: job %d has a NULL pointer", i);
+        const int rows = g.KH * g.KW * g.Ci, splits = wgrad_splits(g);
+        const size_t sstride = (size_t)(rows + 4) * g.Co;
+        float *scale = (float *)caches[i], *n2 = scale + g.Co;       // (the layer cache's header: valid -- CFL_CONV_CACHE_SCALE -- by contract)
+        float *slab = slabs[i];
+        if (conv_big_filter(rows, g.Co)) {
+            // the large filters: coalesced three-launch form, as cfl_conv2d_wn_bwd_fused
+            size_t gstride;
+            const int groups = slab_presum(slab, splits, sstride, (size_t)(rows + 1) * g.Co, &gstride, st);
+            float *part = n2 + g.Co;
+            const int rpc = conv_col_rpc(rows), chunks = (rows + rpc - 1) / rpc;
+            hipLaunchKernelGGL(conv_wdot_partial_kernel, dim3((g.Co + 63) / 64, chunks), dim3(256), 0, st, slab, groups, gstride, V[i],
+                               rows, g.Co, rpc, dV[i], part);
+            hipLaunchKernelGGL(conv_wdot_final_kernel, dim3((g.Co + 255) / 256), dim3(256), 0, st, part, chunks, slab, groups, gstride,
+                               scale, n2, rows, g.Co, reg_const, gain[i] ? dg[i] : nullptr, db[i]);
+            const size_t n4 = (size_t)rows * g.Co / 4;
+            hipLaunchKernelGGL(conv_wapply_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, V[i], scale, part, n4, g.Co, dV[i]);
+            continue;
+        }
+        if (wa.njobs == CFL_WFINAL_MAX_JOBS || sa.njobs == CFL_WFINAL_MAX_JOBS) flush();
+        // slab_presum's grouping, as a job of the batched slab-sum launch
+        int groups = splits;
+        size_t gstride = sstride;
+        if (splits > 4) {
+            const size_t nsum = (size_t)(rows + 1) * g.Co;
+            const bool v4 = sstride % 4 == 0 && nsum % 4 == 0 && ((uintptr_t)slab & 15) == 0;
+            const size_t threads = v4 ? nsum / 4 : nsum;
+            groups = (int)((16384 + threads - 1) / threads);
+            if (groups > splits / 8) groups = splits / 8;
+            if (groups > 16) groups = 16;
+            if (groups < 1) groups = 1;
+            const int gsz = (splits + groups - 1) / groups;
+            groups = (splits + gsz - 1) / gsz;
+            SlabSumJob &sj = sa.job[sa.njobs++];
+            sj.slab = slab; sj.stride = sstride; sj.n = nsum; sj.splits = splits; sj.gsz = gsz; sj.vec = v4 ? 1 : 0;
+            sj.bx = (int)((threads + 255) / 256); sj.block0 = sblocks; sj.nblocks = sj.bx * groups;
+            sblocks += sj.nblocks;
+            gstride = (size_t)gsz * sstride;
+        }
+        WFinalJob &wj = wa.job[wa.njobs++];
+        wj.slab = slab; wj.V = V[i]; wj.scale = scale; wj.n2 = n2; wj.dV = dV[i]; wj.dg = gain[i] ? dg[i] : nullptr; wj.db = db[i];
+        wj.stride = gstride; wj.splits = groups; wj.rows = rows; wj.Co = g.Co; wj.block0 = wblocks;
+        wblocks += g.Co;
+    }
+    flush();
+    return hipGetLastError() == hipSuccess ? CFL_OK : cfl_set_err(CFL_E_HIP, "conv wfinal launch failed");
+}
+
 // =============================================================================================
 // Weight-normalised TRANSPOSED convolution (cfl/layers.py:253-361): x [B,H,W,Ci], V [KH,KW,Co,Ci],
 // y [B,H*S,W*S,Co] = act( conv2d_transpose(x, g[co] * V / ||V[:,:,co,:]||) + b ), 'SAME'.

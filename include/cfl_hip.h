@@ -464,6 +464,23 @@ int cfl_conv2d_wn_bwd_fused(const CflConv *conv, const float *x, const float *V,
                             const float *dy, int32_t dy_subpixel, float reg_const, float *dx, float *dV, float *dg, float *db,
                             void *workspace, size_t workspace_bytes, void *cache, size_t cache_bytes, int32_t *cache_flags,
                             cfl_stream_t stream);
+/* Deferred weight-gradient finalisation (round 6).  cfl_conv2d_wn_bwd_* ends every weight gradient with launches of its own (slab
+ * sums + the per-channel weight-norm finalisation): ~80 launches of 5-16 us per MrCGAN step.  These two entry points split the work:
+ *   cfl_conv2d_wn_wgrad_slabs   ONLY the contraction dW = x^T (dy * act'(y)) of a layer (+ the bias-gradient row), as split-K slabs in
+ *                               the caller's region `slab` (cfl_conv_wgrad_slab_bytes(conv) bytes, 16-byte aligned, one region per
+ *                               layer and backward chain; the caller keeps it until the chain is finished)
+ *   cfl_conv_wfinal_many        finishes n such layers at once: dV = s dW - (s / n^2)(dW . V) V + reg V, dg = (dW . V) / n, db -- ONE
+ *                               slab-sum launch and ONE finalisation launch for all of them (up to 32 layers per launch pair; the few
+ *                               filters of >= 2^20 elements keep their coalesced three-launch form).  caches[i] = the layer's cache
+ *                               buffer with CFL_CONV_CACHE_SCALE valid (its header holds scale and n^2); dg[i] / db[i] nullable.
+ * Bit-identical to the per-layer path (the same per-element code in the same order).                                              */
+size_t cfl_conv_wgrad_slab_bytes(const CflConv *conv);
+int cfl_conv2d_wn_wgrad_slabs(const CflConv *conv, const float *x, const float *y, const float *dy, int32_t dy_subpixel,
+                              float *slab, size_t slab_bytes, cfl_stream_t stream);
+int cfl_conv_wfinal_many(int32_t n, const CflConv *convs, float *const *slabs, const float *const *V, const float *const *g,
+                         void *const *caches, float reg_const, float *const *dV, float *const *dg, float *const *db,
+                         cfl_stream_t stream);
+
 /* The forward with two store epilogues of the MrCGAN stacks folded in (cache nullable as above):
  *   residual  dev [B,OH,OW,Co] or NULL: y = act(conv + b + residual) -- the join of a residual block
  *             (cfl/models/blocks.py:150-170: lrelu(conv_b(...) + h)) as the epilogue of its second convolution

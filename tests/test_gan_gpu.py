@@ -327,6 +327,44 @@ def test_gradient_penalty_chain_forks_only_behind_prepared_caches():
             assert all(np.array_equal(st0[net][part][k], st1[net][part][k]) for k in st0[net][part])
 
 
+def test_deferred_weight_gradient_finalisation_is_bit_identical():
+    """Round 6: the weight gradients of a backward chain are finished together -- ONE slab-sum launch and ONE finalisation launch for
+    all layers of the chain (cfl_conv2d_wn_wgrad_slabs + cfl_conv_wfinal_many) -- instead of a launch pair per layer.  Same per-element
+    code in the same order: three post-epoch steps at the config-5 shape family (srgan 32x32 with the residual stages, and the conv
+    GAN) must give the same scalars, variables and Adam slots bit for bit, and the launch count per step must drop."""
+    G, GB, M, GO, _ = _mods()
+    from cfl import hipabi as H
+    rng = np.random.RandomState(9)
+    before = (GB.Workspace.defer_wfinal, M.GanPhase.tune_streams)
+    try:
+        M.GanPhase.tune_streams = False
+        for gan_type, shape, B in (('srgan', (32, 32, 3), 6), ('conv', (16, 16, 1), 4)):
+            Ld, zd = 6, 5
+            N = int(np.prod(shape))
+            batches = [[np.tanh(rng.randn(B, N)), 0.3 * rng.randn(B, Ld), 0.3 * rng.randn(B, Ld), 0.3 * rng.randn(B, Ld),
+                        0.3 * rng.randn(B, Ld), rng.randn(B, zd), rng.rand(B, 1)] for _ in range(3)]
+            runs = []
+            for defer in (False, True):
+                GB.Workspace.defer_wfinal = defer
+                ph = M.GanPhase(gan_type, shape, 'tanh', zd, Ld, B, torch.device('cuda'), np.random.RandomState(0), lambda_gp=0.5,
+                                lambda_dra=0.5, m_enc=0.05, m_prj=0.2)
+                scal = []
+                for b in batches:
+                    ph.step(*[_dev(x) for x in b])
+                    scal.append(ph.scalars.detach().cpu().numpy().copy())
+                torch.cuda.synchronize()
+                H.profile_enable(False)
+                runs.append((scal, ph.state()))
+            (s0, st0), (s1, st1) = runs
+            assert all(np.array_equal(a, b) for a, b in zip(s0, s1)), gan_type
+            for net in ('generator', 'discriminator'):
+                for part in ('variables', 'adam_m', 'adam_v'):
+                    bad = [k for k in st0[net][part] if not np.array_equal(st0[net][part][k], st1[net][part][k])]
+                    assert not bad, (gan_type, net, part, bad[:3])
+    finally:
+        GB.Workspace.defer_wfinal, M.GanPhase.tune_streams = before
+
+
 def test_conditional_discriminator_srgan_64():
     """SRDiscriminator with the cgan condition tiled in at stage 3 (64x64 images) and fc_t: forward, parameter
     and input gradients against the oracle."""
