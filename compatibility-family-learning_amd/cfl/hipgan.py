@@ -16,7 +16,7 @@ EXPORTS = ('cfl_conv_transpose_workspace_bytes', 'cfl_conv2d_transpose_wn_fwd', 
            'cfl_tile_concat_channels', 'cfl_tile_concat_channels_bwd', 'cfl_auc_workspace_bytes', 'cfl_auc', 'cfl_image_transform',
            'cfl_ew_affine_clip_channels', 'cfl_conv_cache_bytes', 'cfl_conv2d_wn_fwd_cached', 'cfl_conv2d_wn_bwd_cached', 'cfl_conv2d_wn_fwd_fused', 'cfl_conv2d_wn_bwd_fused',
            'cfl_conv_bwd_takes_subpixel', 'cfl_conv_prepare_cached', 'cfl_conv_wgrad_slab_bytes', 'cfl_conv2d_wn_wgrad_slabs',
-           'cfl_conv_wfinal_many')
+           'cfl_conv_wfinal_many', 'cfl_conv_prepare_cached_many')
 
 EW = {None: 0, 'linear': 0, 'lrelu': 1, 'relu': 2, 'tanh': 3, 'sigmoid': 4}
 
@@ -69,6 +69,8 @@ def lib():
                                           [sz, vp, sz, C.POINTER(C.c_int32), vp])
     L.cfl_conv_bwd_takes_subpixel.argtypes = [C.POINTER(CflConv)]
     L.cfl_conv_prepare_cached.argtypes = [C.POINTER(CflConv), vp, vp, vp, sz, C.POINTER(C.c_int32), vp]
+    L.cfl_conv_prepare_cached_many.argtypes = [C.c_int32, C.POINTER(CflConv), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp),
+                                               C.POINTER(sz), C.POINTER(C.POINTER(C.c_int32)), vp]
     L.cfl_conv_wgrad_slab_bytes.argtypes = [C.POINTER(CflConv)]
     L.cfl_conv_wgrad_slab_bytes.restype = sz
     L.cfl_conv2d_wn_wgrad_slabs.argtypes = [C.POINTER(CflConv), vp, vp, vp, C.c_int32, vp, sz, vp]
@@ -189,6 +191,25 @@ def conv_wfinal_many(jobs, reg_const=0.0):
     ptr = lambda t: t.data_ptr() if t is not None else None
     _check(lib().cfl_conv_wfinal_many(n, convs, arr(1, ptr), arr(2, ptr), arr(3, ptr), arr(4, lambda c: c.buf.data_ptr()),
                                       float(reg_const), arr(5, ptr), arr(6, ptr), arr(7, ptr), _stream()))
+
+
+def conv_prepare_many(layers):
+    """layers: [(conv, V, g, cache)] -- rebuild what is missing in the caches of ALL of them with one launch for the weight-norm
+    scales and one for the filter planes (cfl_conv_prepare_cached_many)"""
+    if not ConvCache.enabled:
+        return
+    layers = [l for l in layers if l[3] is not None]
+    n = len(layers)
+    if not n:
+        return
+    for conv, V, g, cache in layers:
+        cache.ensure(conv, V.device)
+    convs = (CflConv * n)(*[l[0] for l in layers])
+    vps = lambda f: (C.c_void_p * n)(*[f(l) for l in layers])
+    flags = (C.POINTER(C.c_int32) * n)(*[C.pointer(l[3].flags) for l in layers])
+    sizes = (C.c_size_t * n)(*[l[3].buf.numel() * 4 for l in layers])
+    _check(lib().cfl_conv_prepare_cached_many(n, convs, vps(lambda l: l[1].data_ptr()), vps(lambda l: l[2].data_ptr() if l[2] is not None else None),
+                                              vps(lambda l: l[3].buf.data_ptr()), sizes, flags, _stream()))
 
 
 def conv_bwd_takes_subpixel(conv):

@@ -214,6 +214,11 @@ class WNLayer(object):
                 slab = self._slab(ws, d)
                 G.conv_wgrad_slabs(d, x, y, dy, slab, dy_subpixel=dy_subpixel)
                 ws.pending.append((d, slab, self.p('V'), self.p('g'), cache, dV, dg, db))
+                if len(ws.pending) >= Workspace.defer_group:
+                    # finished in groups along the chain, not all at its end: a backward pass meets the wide layers first, and one
+                    # launch for all 23 layers at the join put their 0.2 ms of per-channel walks on the chain's tail (+0.4 ms per step)
+                    G.conv_wfinal_many(ws.pending)
+                    ws.pending = []
             else:
                 G.conv_bwd(d, x, self.p('V'), self.p('g'), y, dy, ws.side_ws.get(d, t), dx=None, dV=dV, dg=dg, db=db,
                            transposed=t, cache=cache, **sp)
@@ -243,8 +248,13 @@ class WNLayer(object):
 class Workspace(object):
     # CFL_GAN_OVERLAP=0 keeps every launch of a network on one stream (A/B runs, debugging)
     overlap = os.environ.get('CFL_GAN_OVERLAP', '1') not in ('0', '')
-    # CFL_GAN_DEFER_WFINAL=0: every weight gradient finishes itself (slab sums + finalisation per layer: the form of rounds 4-5)
-    defer_wfinal = os.environ.get('CFL_GAN_DEFER_WFINAL', '1') not in ('0', '')
+    # CFL_GAN_DEFER_WFINAL=1 (opt-in): the slab sums + weight-norm finalisations of a backward chain's layers in grouped launch pairs
+    # (cfl_conv_wfinal_many) instead of a pair per layer.  Built and measured in round 6 (tools/r06_gan_ab.sh, stream tuner off, same
+    # box, three alternations): 83 launches fewer per step but the step is 0.2-0.4 ms SLOWER (12.2-12.3 -> 12.4-12.7 ms, groups of
+    # 3 ... all layers) -- the per-layer finalisations fill gaps of the side stream as they come, a grouped launch serialises the
+    # wide layers' per-channel walks behind the chain.  The step is GPU-bound: launch count is not what it pays for.  Default off.
+    defer_wfinal = os.environ.get('CFL_GAN_DEFER_WFINAL', '0') not in ('0', '')
+    defer_group = int(os.environ.get('CFL_GAN_DEFER_GROUP', '6'))     # layers per finalisation launch pair
 
     def __init__(self, device, side=True):
         self.device = device
@@ -291,6 +301,8 @@ class _Net(object):
 
     # CFL_GAN_PREP_AHEAD=0: leave every layer's cache to its first convolution of the next step (A/B runs)
     prep_ahead = os.environ.get('CFL_GAN_PREP_AHEAD', '1') not in ('0', '')
+    # CFL_GAN_PREP_BATCHED=0: one preparation call per layer (the form of round 5; A/B runs)
+    prep_batched = os.environ.get('CFL_GAN_PREP_BATCHED', '1') not in ('0', '')
 
     def prepare_caches(self):
         """Right behind the optimizer step: rebuild every layer's weight-norm scale and filter planes on a side stream, so
@@ -303,9 +315,18 @@ class _Net(object):
         self._prep_stream.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(self._prep_stream):
             complete = True
+            many = []
             for layer in self.pool.layers:
-                layer.prepare()
                 complete = complete and (layer._cache is None or layer._prep_desc is not None)
+                if layer._cache is not None and layer._prep_desc is not None:
+                    many.append((layer._prep_desc, layer.p('V'), layer.p('g'), layer.cache()))
+            # every layer's weight-norm scale in ONE launch, every layer's filter planes in another (round 6: ~65 launches in a
+            # row before, which the next step's first layers waited for)
+            if _Net.prep_batched:
+                G.conv_prepare_many(many)
+            else:
+                for layer in self.pool.layers:
+                    layer.prepare()
             self._prep_event = torch.cuda.Event()
             self._prep_event.record()
         # every cache was rebuilt for THIS version of the weights behind `_prep_event` (caches_prepared)

@@ -854,6 +854,149 @@ extern "C" int cfl_conv_prepare_cached(const CflConv *c, const float *V, const f
     return hipGetLastError() == hipSuccess ? CFL_OK : cfl_set_err(CFL_E_HIP, "conv prepare launch failed");
 }
 
+// ... for ALL the layers of a network in a handful of launches (round 6): behind the optimizer step of the MrCGAN post epochs the
+// per-layer form above is ~65 launches of ~6 us in a row on the preparation stream -- 0.4 ms that the next step's first layers wait
+// for.  Here the weight-norm scales of all layers are ONE launch (one workgroup per output channel of every layer, job table in the
+// kernel arguments) and the filter planes of all layers another; the per-element code is that of conv_scale_kernel /
+// conv_halo_prep_kernel (bit-identical caches).  The few filters of >= 2^20 elements keep their coalesced two-launch scale.
+#define CFL_PREP_MAX_JOBS 48
+struct ScaleJob { const float *V, *g; float *scale, *n2; int rows, Co, block0; };
+struct ScaleManyArgs { ScaleJob job[CFL_PREP_MAX_JOBS]; int njobs; };
+struct PlanesJob { const float *V, *scale; unsigned short *wp; int Ci, Co, dgrad, K, N, Npad, block0, nblocks; };
+struct PlanesManyArgs { PlanesJob job[CFL_PREP_MAX_JOBS]; int njobs; };
+
+__global__ __launch_bounds__(256) void conv_scale_many_kernel(ScaleManyArgs a) {
+    int j = 0;
+    while (j < a.njobs - 1 && (int)blockIdx.x >= a.job[j + 1].block0) ++j;
+    const ScaleJob &jb = a.job[j];
+    const int co = (int)blockIdx.x - jb.block0, rows = jb.rows, Co = jb.Co;
+    const float *V = jb.V;
+    float acc = 0.f;
+    for (int r = threadIdx.x; r < rows; r += 256) {
+        const float v = V[(size_t)r * Co + co];
+        acc = fmaf(v, v, acc);
+    }
+    __shared__ float red[256];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float n2 = fmaxf(red[0], 1e-12f);
+        jb.n2[co] = n2;
+        jb.scale[co] = (jb.g ? jb.g[co] : 1.f) * rsqrtf(n2);
+    }
+}
+
+__global__ __launch_bounds__(256) void conv_halo_prep_many_kernel(PlanesManyArgs a) {
+    int j = 0;
+    while (j < a.njobs - 1 && (int)blockIdx.x >= a.job[j + 1].block0) ++j;
+    const PlanesJob &jb = a.job[j];
+    const int K = jb.K, N = jb.N, Npad = jb.Npad, Ci = jb.Ci, Co = jb.Co, dgrad = jb.dgrad;
+    const float *V = jb.V, *scale = jb.scale;
+    const int nchunks = K >> 5;
+    const long long total = 9ll * nchunks * Npad * 4;
+    const long long i = (long long)((int)blockIdx.x - jb.block0) * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int oct = (int)(i & 3);
+    long long r = i >> 2;
+    const int n = (int)(r % Npad); r /= Npad;
+    const int kc = (int)(r % nchunks);
+    const int t = (int)(r / nchunks);
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int k = kc * 32 + oct * 8 + e;
+        float x = 0.f;
+        if (n < N) {
+            if (dgrad) x = V[((size_t)(8 - t) * Ci + n) * Co + k] * scale[k];
+            else x = V[((size_t)t * Ci + k) * Co + n] * scale[n];
+        }
+        v[e] = x;
+    }
+    float h[8], m[8], l[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) gg_split3(v[e], h[e], m[e], l[e]);
+    gg_u32x4 ph, pm, pl;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        ph[e] = gg_pack(h[2 * e], h[2 * e + 1]);
+        pm[e] = gg_pack(m[2 * e], m[2 * e + 1]);
+        pl[e] = gg_pack(l[2 * e], l[2 * e + 1]);
+    }
+    const size_t blk = (size_t)(t * nchunks + kc) * 3;
+    unsigned short *d = jb.wp + ((blk * Npad + n) * 32 + oct * 8);
+    const size_t plane = (size_t)Npad * 32;
+    *(gg_u32x4 *)d = ph;
+    *(gg_u32x4 *)(d + plane) = pm;
+    *(gg_u32x4 *)(d + 2 * plane) = pl;
+}
+
+extern "C" int cfl_conv_prepare_cached_many(int32_t n, const CflConv *convs, const float *const *V, const float *const *gain,
+                                            void *const *caches, const size_t *cache_bytes, int32_t *const *cache_flags,
+                                            cfl_stream_t stream) {
+    if (n <= 0 || !convs || !V || !gain || !caches || !cache_bytes || !cache_flags) return cfl_set_err(CFL_E_SHAPE, "cfl_conv_prepare_cached_many: NULL pointer / no layers");
+    hipStream_t st = (hipStream_t)stream;
+    ScaleManyArgs sa;
+    PlanesManyArgs pa;
+    memset(&sa, 0, sizeof(sa));
+    memset(&pa, 0, sizeof(pa));
+    int sblocks = 0, pblocks = 0;
+    // pass 1: the scales (the planes fold them in: every scale launch goes in front of every plane launch on the stream)
+    for (int i = 0; i < n; ++i) {
+        ConvGeom g;
+        int rc = make_geom(&convs[i], &g);
+        if (rc) return rc;
+        if (!V[i] || !caches[i] || !cache_flags[i]) return cfl_set_err(CFL_E_SHAPE, "cfl_conv_prepare_cached_many: layer %d has a NULL pointer", i);
+        if (cache_bytes[i] < cfl_conv_cache_bytes(&convs[i]) || ((uintptr_t)caches[i] & 15))
+            return cfl_set_err(CFL_E_WORKSPACE, "conv cache of layer %d too small / misaligned", i);
+        if (*cache_flags[i] & CFL_CONV_CACHE_SCALE) continue;
+        const int rows = g.KH * g.KW * g.Ci;
+        float *scale = (float *)caches[i], *n2 = scale + g.Co;
+        if (conv_big_filter(rows, g.Co)) {
+            conv_scale(V[i], gain[i], rows, g.Co, scale, n2, n2 + g.Co, st);
+        } else {
+            if (sa.njobs == CFL_PREP_MAX_JOBS) {
+                hipLaunchKernelGGL(conv_scale_many_kernel, dim3(sblocks), dim3(256), 0, st, sa);
+                sa.njobs = 0; sblocks = 0;
+            }
+            ScaleJob &sj = sa.job[sa.njobs++];
+            sj.V = V[i]; sj.g = gain[i]; sj.scale = scale; sj.n2 = n2; sj.rows = rows; sj.Co = g.Co; sj.block0 = sblocks;
+            sblocks += g.Co;
+        }
+        *cache_flags[i] |= CFL_CONV_CACHE_SCALE;
+    }
+    if (sa.njobs) hipLaunchKernelGGL(conv_scale_many_kernel, dim3(sblocks), dim3(256), 0, st, sa);
+    // pass 2: the filter planes of the halo kernels (forward, input gradient)
+    for (int i = 0; i < n; ++i) {
+        ConvGeom g;
+        (void)make_geom(&convs[i], &g);
+        const float *scale = (const float *)caches[i];
+        for (int dgrad = 0; dgrad < 2; ++dgrad) {
+            const int bit = dgrad ? CFL_CONV_CACHE_PLANES_DX : CFL_CONV_CACHE_PLANES_FWD;
+            if (*cache_flags[i] & bit) continue;
+            const HaloPlan hp = dgrad ? halo_dx_prep_plan(g) : halo_fwd_prep_plan(g);
+            if (!hp.ok) continue;
+            if (pa.njobs == CFL_PREP_MAX_JOBS) {
+                hipLaunchKernelGGL(conv_halo_prep_many_kernel, dim3(pblocks), dim3(256), 0, st, pa);
+                pa.njobs = 0; pblocks = 0;
+            }
+            PlanesJob &pj = pa.job[pa.njobs++];
+            pj.V = V[i]; pj.scale = scale; pj.Ci = g.Ci; pj.Co = g.Co; pj.dgrad = dgrad;
+            pj.K = dgrad ? g.Co : g.Ci; pj.N = dgrad ? g.Ci : g.Co; pj.Npad = hp.Npad;
+            pj.wp = (unsigned short *)((char *)caches[i] + conv_cache_planes_off(g) + (dgrad ? conv_cache_fwd_bytes(g) : 0));
+            const long long prep = 9ll * hp.nchunks * hp.Npad * 4;
+            pj.block0 = pblocks; pj.nblocks = (int)((prep + 255) / 256);
+            pblocks += pj.nblocks;
+            *cache_flags[i] |= bit;
+        }
+    }
+    if (pa.njobs) hipLaunchKernelGGL(conv_halo_prep_many_kernel, dim3(pblocks), dim3(256), 0, st, pa);
+    return hipGetLastError() == hipSuccess ? CFL_OK : cfl_set_err(CFL_E_HIP, "conv prepare launch failed");
+}
+
 extern "C" int cfl_conv2d_wn_fwd_cached(const CflConv *c, const float *x, const float *V, const float *gain,
                                         const float *bias, float *y, void *workspace, size_t workspace_bytes,
                                         void *cache, size_t cache_bytes, int32_t *cache_flags, cfl_stream_t stream) {

@@ -453,6 +453,12 @@ int cfl_conv2d_wn_bwd_cached(const CflConv *conv, const float *x, const float *V
  * batch size serves calls with another. */
 int cfl_conv_prepare_cached(const CflConv *conv, const float *V, const float *g, void *cache, size_t cache_bytes,
                             int32_t *cache_flags, cfl_stream_t stream);
+/* ... for n layers at once (round 6): ONE launch for the weight-norm scales of all of them and ONE for their filter planes
+ * (up to 48 jobs per launch; filters of >= 2^20 elements keep their coalesced two-launch scale) -- instead of ~65 launches in a row
+ * behind every optimizer step of the MrCGAN post epochs.  Arrays of n entries; bit-identical to n calls of the function above.   */
+int cfl_conv_prepare_cached_many(int32_t n, const CflConv *convs, const float *const *V, const float *const *g,
+                                 void *const *caches, const size_t *cache_bytes, int32_t *const *cache_flags, cfl_stream_t stream);
+
 /* The backward with the sub-pixel un-shuffle folded into its dy loaders (round 4; cache nullable as above):
  *   dy_subpixel != 0: dy -- and y, the layer's activated output, when conv->act != 0 -- arrive 2x sub-pixel shuffled,
  *             [B, 2 OH, 2 OW, Co/4], exactly as cfl_conv2d_wn_fwd_fused(subpixel = 1) stored y; equal bit for bit to

@@ -335,7 +335,7 @@ def test_deferred_weight_gradient_finalisation_is_bit_identical():
     G, GB, M, GO, _ = _mods()
     from cfl import hipabi as H
     rng = np.random.RandomState(9)
-    before = (GB.Workspace.defer_wfinal, M.GanPhase.tune_streams)
+    before = (GB.Workspace.defer_wfinal, M.GanPhase.tune_streams, GB._Net.prep_batched)
     try:
         M.GanPhase.tune_streams = False
         for gan_type, shape, B in (('srgan', (32, 32, 3), 6), ('conv', (16, 16, 1), 4)):
@@ -346,6 +346,7 @@ def test_deferred_weight_gradient_finalisation_is_bit_identical():
             runs = []
             for defer in (False, True):
                 GB.Workspace.defer_wfinal = defer
+                GB._Net.prep_batched = defer      # ... and the cache preparation of all layers in two launches (cfl_conv_prepare_cached_many)
                 ph = M.GanPhase(gan_type, shape, 'tanh', zd, Ld, B, torch.device('cuda'), np.random.RandomState(0), lambda_gp=0.5,
                                 lambda_dra=0.5, m_enc=0.05, m_prj=0.2)
                 scal = []
@@ -362,7 +363,7 @@ def test_deferred_weight_gradient_finalisation_is_bit_identical():
                     bad = [k for k in st0[net][part] if not np.array_equal(st0[net][part][k], st1[net][part][k])]
                     assert not bad, (gan_type, net, part, bad[:3])
     finally:
-        GB.Workspace.defer_wfinal, M.GanPhase.tune_streams = before
+        GB.Workspace.defer_wfinal, M.GanPhase.tune_streams, GB._Net.prep_batched = before
 
 
 def test_conditional_discriminator_srgan_64():
