@@ -82,6 +82,8 @@ def parse():
                     'child job so that a failure of that path cannot take the headline line down)')
     ap.add_argument('--no-live-traffic', action='store_true', help='quote profiles/traffic.json instead of measuring the HBM '
                     'traffic of the step with two rocprofv3 --pmc child runs')
+    ap.add_argument('--dp-legs-timeout', type=int, default=900, help='N > 1: seconds after which the line is printed without '
+                    'the dp_scaling legs (they wedged)')
     ap.add_argument('--no-dp-legs', action='store_true', help='N > 1: skip the extra data-parallel legs (dp_scaling)')
     return ap.parse_args()
 
@@ -89,6 +91,9 @@ def parse():
 # ---------------------------------------------------------------------------------------------------------
 # N > 1 without a launcher: the parent starts the ranks and never initialises the GPU itself
 # ---------------------------------------------------------------------------------------------------------
+_live_children = []      # process groups started by spawn_ranks (the watchdog of the dp_scaling legs kills what is left of them)
+
+
 def spawn_ranks(gpus, argv, key='"metric"', timeout=None, extra_env=None):
     """start `gpus` ranks of this script under torch.distributed.run (a fresh rendezvous port); returns (return code, the
     JSON line containing `key` or None).  The child's other output goes to stderr.  On a timeout the whole process group of
@@ -106,6 +111,7 @@ def spawn_ranks(gpus, argv, key='"metric"', timeout=None, extra_env=None):
     env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')     # dmabuf IPC: RCCL / cross-process tensor sharing needs it here
     env.update(extra_env or {})
     proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, start_new_session=True)
+    _live_children.append(proc.pid)
     try:
         out, _ = proc.communicate(timeout=timeout)
     except subprocess.TimeoutExpired:
@@ -114,8 +120,10 @@ def spawn_ranks(gpus, argv, key='"metric"', timeout=None, extra_env=None):
         except OSError:
             pass
         out, _ = proc.communicate()
+        _live_children.remove(proc.pid)
         print('bench.py: child job timed out after %s s' % timeout, file=sys.stderr)
         return 124, None
+    _live_children.remove(proc.pid)
     line = None
     for ln in out.splitlines():
         if ln.startswith('{') and key in ln:
@@ -952,6 +960,9 @@ def main():
         # child job of the main N-rank run (started by its rank 0): ONE risky leg, its own JSON line, nothing else
         if os.environ.get('CFL_BENCH_FAIL_DP_LEG') == '1':      # (tests: a child job that dies must cost an `error` entry, not the line)
             os._exit(3)
+        if os.environ.get('CFL_BENCH_FAIL_DP_LEG') == 'hang':   # (tests: a child job that wedges -- the parent's watchdog prints the line)
+            time.sleep(25)
+            os._exit(3)
         res = {'dp_leg': args.dp_leg}
         if args.dp_leg == 'oneshot':
             for b in (B, 2048):
@@ -1227,6 +1238,27 @@ def main():
         # takes a process down, the child is killed and the line above survives with an `error` entry.
         legs = {}
         headline_us = 1e6 * elapsed / args.steps
+        # last resort: these legs are side measurements on paths no multi-GPU box has run.  If they wedge (a collective that
+        # never returns cannot be interrupted from Python), every rank's timer fires, rank 0 prints the line it already has --
+        # the headline was measured above -- and the processes leave without the teardown collectives.
+        import threading
+
+        def give_up():
+            import signal
+            for pid in _live_children:          # exactly the process groups this process started
+                try:
+                    os.killpg(pid, signal.SIGKILL)
+                except OSError:
+                    pass
+            if rank == 0:
+                out['dp_scaling'] = dict(legs, error='the data-parallel legs did not finish within %d s; the line carries the '
+                                                     'headline only' % args.dp_legs_timeout)
+                os.write(real_stdout, (json.dumps(out) + '\n').encode())
+            os._exit(0)
+
+        watchdog = threading.Timer(args.dp_legs_timeout, give_up)
+        watchdog.daemon = True
+        watchdog.start()
         try:
             ctl = dist.new_group(backend='gloo')
         except Exception:          # noqa: BLE001
@@ -1246,14 +1278,14 @@ def main():
             if rank == 0:
                 rc, line = spawn_ranks(world, ['--gpus', str(world), '--dp-leg', 'oneshot', '--steps', str(args.steps), '--warmup',
                                                '10', '--pool-mib', str(args.pool_mib), '--restore-steps', str(args.restore_steps)],
-                                       key='"dp_leg"', timeout=600, extra_env={'CFL_DP_TIMEOUT_S': '20'})
+                                       key='"dp_leg"', timeout=360, extra_env={'CFL_DP_TIMEOUT_S': '20'})
                 try:
                     child = json.loads(line) if line else {'error': 'the one-shot child job printed no line (rc %d)' % rc}
                 except ValueError:
                     child = {'error': 'unparsable line from the one-shot child job (rc %d)' % rc}
             import datetime
             try:
-                dist.monitored_barrier(group=ctl, timeout=datetime.timedelta(seconds=900))
+                dist.monitored_barrier(group=ctl, timeout=datetime.timedelta(seconds=480))
             except Exception as e:          # noqa: BLE001
                 print('bench.py: control barrier: %r' % (e,), file=sys.stderr)
             if rank == 0:
@@ -1267,6 +1299,7 @@ def main():
                             'all-gather (csrc/cfl_dp.hip; measured by a child job on the same GPUs); `without_collective` = the '
                             'same launches with no exchange at all (what a rank\'s step costs before a byte crosses a link)')
             out['dp_scaling'] = legs
+        watchdog.cancel()
     if rank == 0:
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(out) + '\n').encode())

@@ -11,6 +11,7 @@ functional coverage of exactly the code the RCCL ranks run, not a measurement):
 import json
 import os
 import subprocess
+import time
 import sys
 
 import numpy as np
@@ -195,6 +196,23 @@ def test_bench_line_survives_a_dying_one_shot_child_job():
     assert out['n_gpus'] == 2 and out['value'] > 0
     assert 'error' in out['dp_scaling']['oneshot'], out['dp_scaling']['oneshot']
     assert out['dp_scaling']['b2048_allreduce']['us_per_step'] > 0
+
+
+def test_bench_line_survives_wedged_data_parallel_legs():
+    """Last resort of `bench.py --gpus N`: when the dp_scaling legs do not come back (injected: the child job sleeps), every rank's
+    watchdog fires, rank 0 prints the line with the headline it has already measured, and the job ends with exit code 0."""
+    env = dict(os.environ, CFL_DIST_BACKEND='gloo', CFL_BENCH_LEG_SECONDS='0.1', CFL_DP_MAX_BLOCKS='64', CFL_BENCH_FAIL_DP_LEG='hang')
+    env.pop('WORLD_SIZE', None)
+    env.pop('RANK', None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '5', '--warmup', '2',
+                        '--repeats', '3', '--pool-mib', '64', '--restore-steps', '20', '--no-cpu-baseline', '--no-kernel-profile',
+                        '--no-cli-loop', '--dp-legs-timeout', '8'], env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['value'] > 0
+    assert 'did not finish' in out['dp_scaling']['error'], out['dp_scaling']
 
 
 def _oneshot_worker(rank, world, port, out):
