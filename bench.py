@@ -790,6 +790,54 @@ def dp_leg(args, device, rank, world, B, exchange, teacher, seconds=None, pool_m
         os.environ['CFL_DP_NO_COLLECTIVE'] = '0'
 
 
+def gan_dp_leg(device, rank, world, n=10):
+    """MrCGAN post-epoch step (config 5: 64x64x3, L = 64, z = 20, srgan) under data parallelism, weak scaling: every rank runs the
+    G / D step on ITS 100 rows of a global batch of 100 x world, then ONE all-reduce of [d gradient | g gradient | scalars] in front
+    of the two Adams (cfl.models.mrcgan.GanPhase.shard_over) -- and the same step without the collective beside it."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from cfl import engine
+    from cfl.models.mrcgan import GanPhase
+    B, L, zd, shape = 100, 64, 20, (64, 64, 3)
+    g = torch.Generator(device=device)
+    g.manual_seed(77 + rank)
+    ph = GanPhase('srgan', shape, 'tanh', zd, L, B, device, np.random.RandomState(0), lambda_gp=0.5, lambda_dra=0.5, m_enc=0.05,
+                  m_prj=0.2)
+    N = int(np.prod(shape))
+    batch = [torch.tanh(torch.randn(B, N, device=device, generator=g))] + \
+            [0.3 * torch.randn(B, L, device=device, generator=g) for _ in range(4)] + \
+            [torch.randn(B, zd, device=device, generator=g), torch.rand(B, 1, device=device, generator=g)]
+
+    def timed():
+        def sync_all():
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+                torch.cuda.synchronize()
+        for _ in range(3):
+            ph.step(*batch)
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            ph.step(*batch)
+        sync_all()
+        tt = torch.tensor([time.perf_counter() - t0], device=device, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return float(tt.item()) / n
+    alone = timed()
+    ph.shard_over(engine.reduce_gradients)
+    dt = timed()
+    sc = ph.read_scalars()
+    res = {'ms_per_step': round(dt * 1e3, 3), 'images_per_s': round(B * world / dt, 1), 'rows_per_gpu': B,
+           'ms_per_step_without_collective': round(alone * 1e3, 3), 'all_reduce_mb': round(ph._flat.numel() * 4 / 1e6, 2),
+           'd_total_loss': round(sc['d_total_loss'], 5), 'direct_rccl': engine.hot_communicator() is not None}
+    del ph
+    torch.cuda.empty_cache()
+    return res
+
+
 def dp_form(args, eng, pool, device, fused_us):
     """The DATA-PARALLEL form of the step on this one GPU, through a ONE-RANK RCCL process group (CFL_FORCE_DP=1): the
     same three launches as the fused step (projection on the bf16 matrix cores from the kept planes, row math, weight
@@ -1272,6 +1320,10 @@ def main():
                 legs[name] = dp_leg(args, device, rank, world, b, exch, teacher)
             except Exception as e:          # noqa: BLE001 (a side measurement must not take the headline line down)
                 legs[name] = {'error': repr(e)}
+        try:
+            legs['config5_mrcgan_b100_per_gpu'] = gan_dp_leg(device, rank, world)
+        except Exception as e:          # noqa: BLE001
+            legs['config5_mrcgan_b100_per_gpu'] = {'error': repr(e)}
         torch.cuda.synchronize()
         if ctl is not None:
             child = None
@@ -1297,7 +1349,9 @@ def main():
                             'library on the launch stream between the weight-gradient launch and the Adam launch (default '
                             'exchange); `oneshot` = reduce-scatter fused into the weight-gradient launch + sharded Adam + '
                             'all-gather (csrc/cfl_dp.hip; measured by a child job on the same GPUs); `without_collective` = the '
-                            'same launches with no exchange at all (what a rank\'s step costs before a byte crosses a link)')
+                            'same launches with no exchange at all (what a rank\'s step costs before a byte crosses a link); '
+                            '`config5_mrcgan_b100_per_gpu` = the MrCGAN post-epoch step on 100 rows per GPU of a global batch of '
+                            '100 x N, one all-reduce of [d gradient | g gradient | scalars] per step')
             out['dp_scaling'] = legs
         watchdog.cancel()
     if rank == 0:

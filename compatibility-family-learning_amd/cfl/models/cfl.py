@@ -105,15 +105,32 @@ class CFL(PairModel):
         self._ema = {}
         self._np_rng = np.random.RandomState(int(seed) + 4)    # random crops / mirrors
         self.gan_phase = None
+        self._gan_shard = None
         if gan:
             from .mrcgan import GanPhase
+            from .. import engine as E
+            # Data-parallel post epochs: every rank builds the inputs of the GLOBAL batch (encoder heads on B rows:
+            # microseconds) and runs the G / D step on its rows -- `batch_size / world` of them -- then ONE all-reduce of
+            # [d gradient | g gradient | scalars] in front of the two Adams.  Needs equal shares (--cgan: of each HALF of the batch,
+            # its interpolation pairs row i with row i + B/2); otherwise every rank runs the whole batch (replicas, as round 5).
+            # CFL_GAN_DP_SHARD=0: replicas.
+            gan_rows = batch_size
+            if E.dp_active() and os.environ.get('CFL_GAN_DP_SHARD', '1') not in ('0', ''):
+                w = E.world_size()
+                if batch_size % ((2 if cgan else 1) * w) == 0:
+                    self._gan_shard, gan_rows = (E.rank(), w), batch_size // w
+                else:
+                    logger.warning('post epochs: batch size %d is not a multiple of %d: every rank runs the whole batch',
+                                   batch_size, (2 if cgan else 1) * w)
             self.gan_phase = GanPhase(
                 gan_type, self.ae_shape if len(self.ae_shape) == 3 else self.ae_shape + (1,), data_type, z_dim,
-                latent_size, batch_size, self.device, np.random.RandomState(seed + 2), g_lr=g_lr, g_beta1=g_beta1,
+                latent_size, gan_rows, self.device, np.random.RandomState(seed + 2), g_lr=g_lr, g_beta1=g_beta1,
                 g_beta2=g_beta2, d_lr=d_lr, d_beta1=d_beta1, d_beta2=d_beta2, lambda_gp=lambda_gp,
                 lambda_dra=lambda_dra, m_enc=m_enc, m_prj=m_prj, cgan=cgan,
                 c_dim=((reduce_product(self.input_shape) if self.trunk is not None else head_inputs) if t_dim
                        else latent_size) if cgan else None, t_dim=t_dim if cgan else None)
+            if self._gan_shard is not None:
+                self.gan_phase.shard_over(E.reduce_gradients)
             self._heads = None
             import torch
             self._gen = torch.Generator(device=self.device)
@@ -217,11 +234,32 @@ class CFL(PairModel):
             return self._pixels(a, True)
         return hd.normalize(self.to_device(self._prep(a, True)))[:, :self.input_size].contiguous()
 
-    def post_step(self, labeled, unl_src=None, unl_dst=None, draws=None):
-        if self.cgan:
-            self.gan_phase.step_cgan(*self.cgan_inputs(labeled, draws))
+    def _gan_rows(self, ins):
+        """this rank's rows of the global batch's GanPhase inputs (+ X_hat, whose std is a statistic of the GLOBAL batch)"""
+        import torch
+        from .. import hipgan as G
+        gp, (r, w), B = self.gan_phase, self._gan_shard, self.batch_size
+        x_hat = G.perturb(ins[0], ins[-1], gp.lambda_dra) if gp.lambda_gp else None
+        if self.cgan:       # rows [r hs, (r+1) hs) of BOTH halves: the interpolated conditions pair row i with row i + B/2
+            hs = B // 2 // w
+            if getattr(self, '_gan_idx', None) is None:
+                a = torch.arange(r * hs, (r + 1) * hs, device=self.device)
+                self._gan_idx = torch.cat([a, a + B // 2])
+            take = lambda t: t.index_select(0, self._gan_idx)
         else:
-            self.gan_phase.step(*self.gan_inputs(labeled, unl_src, unl_dst, draws))
+            lo, hi = r * (B // w), (r + 1) * (B // w)
+            take = lambda t: t[lo:hi].contiguous()
+        return tuple(take(t) for t in ins), (take(x_hat) if x_hat is not None else None)
+
+    def post_step(self, labeled, unl_src=None, unl_dst=None, draws=None):
+        ins = self.cgan_inputs(labeled, draws) if self.cgan else self.gan_inputs(labeled, unl_src, unl_dst, draws)
+        x_hat = None
+        if self._gan_shard is not None:
+            ins, x_hat = self._gan_rows(ins)
+        if self.cgan:
+            self.gan_phase.step_cgan(*ins, x_hat=x_hat)
+        else:
+            self.gan_phase.step(*ins, x_hat=x_hat)
 
     # -- sampling (cfl/models/cfl.py:808-860: s_encoder_sample, g_target, g_prototypes, d_prototypes) --------
     def _sample_heads(self):

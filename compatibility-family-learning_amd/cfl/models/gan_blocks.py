@@ -351,9 +351,9 @@ class _Net(object):
         if ev is not None:
             torch.cuda.current_stream().wait_event(ev)
 
-    def adam(self):
+    def adam(self, grad_scale=1.0):
         p = self.pool
-        H.adam_tf(p.theta, p.m, p.v, p.grad, self.lr_t(), self.beta1, self.beta2, self.eps)
+        H.adam_tf(p.theta, p.m, p.v, p.grad, self.lr_t(), self.beta1, self.beta2, self.eps, grad_scale)
         p.touch()
         self.prepare_caches()
         self.beta1_power = np.float32(self.beta1_power * np.float32(self.beta1))

@@ -56,13 +56,35 @@ class GanPhase(object):
             self.gen = Generator(gan_type, ae_shape, z_dim + latent_size, data_type, rng, device, g_lr, g_beta1,
                                  g_beta2)
             self.disc = Discriminator(gan_type, ae_shape, latent_size, rng, device, d_lr, d_beta1, d_beta2)
-        self.scalars = torch.zeros(16, dtype=torch.float32, device=device)
+        # ONE flat buffer [discriminator gradient | generator gradient | 16 scalars (+ pad)]: under data parallelism the whole
+        # exchange of a post-epoch iteration is one all-reduce of it (shard_over)
+        nd, ng = self.disc.pool.total, self.gen.pool.total
+        self._flat = torch.zeros(nd + ng + 64, dtype=torch.float32, device=device)
+        self.disc.pool.grad, self.gen.pool.grad = self._flat[:nd], self._flat[nd:nd + ng]
+        self.scalars = self._flat[nd + ng:nd + ng + 16]
+        self.reduce = None      # data parallelism: flat buffer -> factor that turns the sums over the ranks into global-batch means
         self.ae_size = int(np.prod(self.ae_shape))
         # diagnostics: keep the (generator, discriminator) tapes of the last step alive (tests read the activation
         # signs from them); off by default so that a step's activations are released when it returns
         self.keep_tapes = False
         self.last_tapes = None
         self.timing = None      # set to {} to have step() record where its chains end (ms from the start of the step)
+
+    def shard_over(self, reduce):
+        """Data-parallel post epochs (rows are independent given the weights): this GanPhase was built with the
+        rank's share B / world of the global batch, the caller hands every step the rank's ROWS of the global batch's inputs (and
+        X_hat computed from the GLOBAL batch: its std is a statistic of all elements, cfl/models/cfl.py:742-745), and before the
+        two Adams `reduce(flat)` sums [d gradient | g gradient | scalars] over the ranks in ONE collective and returns
+        1 / world: every loss is a mean over equal shares, so the mean of the ranks' gradients is the global-batch gradient."""
+        self.reduce = reduce
+
+    def _exchange(self):
+        """-> gradient scale of the two Adams (1.0 without data parallelism)"""
+        if self.reduce is None:
+            return 1.0
+        scale = float(self.reduce(self._flat))
+        self.scalars.mul_(scale)        # (16 floats: the logged losses / accuracies become global-batch means)
+        return scale
 
     def generate(self, z, c):
         """Generator activations for display / sampling (cfl.bin.sample)."""
@@ -128,17 +150,19 @@ class GanPhase(object):
         self.stream_tuning = [round(t, 3) for t in times]
         return times
 
-    def step(self, real, enc_act, prj_c, neg_c, neg_tgt_act, z, eps, apply=True):
+    def step(self, real, enc_act, prj_c, neg_c, neg_tgt_act, z, eps, apply=True, x_hat=None):
         """One post-epoch iteration.  All arguments are fp32 device tensors:
              real [B, prod(ae_shape)]  ae-normalised unlabeled target images
              enc_act, prj_c, neg_c, neg_tgt_act [B, L]  encoder-side constants (see module docstring)
              z [B, z_dim], eps [B, 1]
+             x_hat [B, prod(ae_shape)] or None: the perturbed images, when the caller has them (data parallelism: computed from
+             the global batch); default: real + lambda_dra * std(real) * eps of THIS batch
            Returns the scalars tensor (a view; read it after the step)."""
         B, Ld, sc = self.B, self.latent_size, self.scalars
         gen, disc = self.gen, self.disc
         if GanPhase.tune_streams and not getattr(self, '_streams_tuned', False):
             self._streams_tuned = True
-            self._tune_streams(lambda: self.step(real, enc_act, prj_c, neg_c, neg_tgt_act, z, eps, apply=False))
+            self._tune_streams(lambda: self.step(real, enc_act, prj_c, neg_c, neg_tgt_act, z, eps, apply=False, x_hat=x_hat))
         marks = [] if self.timing is not None else None     # (diagnostic: CFL-event marks along the chains, tools/gan_chain_probe.py)
 
         def mark(name, stream=None):
@@ -167,8 +191,8 @@ class GanPhase(object):
             # first launches must not wait for that -- but ordered only behind the start of the step)
             c2[0].wait_event(start_ev)
             with torch.cuda.stream(c2[0]):
-                x_hat = G.perturb(real, eps, self.lambda_dra)
-                _, _, tape = disc.forward(x_hat, ws=c2[1])
+                xh = G.perturb(real, eps, self.lambda_dra) if x_hat is None else x_hat
+                _, _, tape = disc.forward(xh, ws=c2[1])
                 disc.gp_grads(tape, 0, B, self.lambda_gp, sc[S_D_GP:S_D_GP + 1], disc.pool.grad2, ws=c2[1])
                 mark('chain2_gradient_penalty')
                 return tape if self.keep_tapes else None
@@ -185,7 +209,10 @@ class GanPhase(object):
         x_all[:B].copy_(real)
         x_all[B:4 * B].copy_(fake)
         if self.lambda_gp and not gp_early:
-            G.perturb(real, eps, self.lambda_dra, out=x_all[4 * B:5 * B])
+            if x_hat is None:
+                G.perturb(real, eps, self.lambda_dra, out=x_all[4 * B:5 * B])
+            else:
+                x_all[4 * B:5 * B].copy_(x_hat)
         d_logit, d_lat, d_tape = disc.forward(x_all)
         mark('d_forward')
 
@@ -244,8 +271,9 @@ class GanPhase(object):
             self.last_tapes = (g_tape, d_tape, gp_tape if gp_early else None)
 
         if apply:
-            disc.adam()
-            gen.adam()
+            scale = self._exchange()
+            disc.adam(scale)
+            gen.adam(scale)
         mark('end')
         if marks is not None:
             torch.cuda.synchronize()
@@ -253,7 +281,7 @@ class GanPhase(object):
             self.timing = {name: t0.elapsed_time(ev) for name, ev in marks}
         return sc
 
-    def step_cgan(self, real_pos, real_neg, pos_c, neg_c, z, eps, apply=True):
+    def step_cgan(self, real_pos, real_neg, pos_c, neg_c, z, eps, apply=True, x_hat=None):
         """One post-epoch iteration of the --cgan branch.  real_pos / real_neg: ae-normalised positive / negative
         TARGET images [B, prod(ae_shape)]; pos_c / neg_c [B, c_dim]: the conditions (source side)."""
         B, sc, hb = self.B, self.scalars, self.B // 2
@@ -282,7 +310,10 @@ class GanPhase(object):
         x_all[2 * B:3 * B].copy_(real_neg)
         x_all[3 * B:3 * B + hb].copy_(fake[B:])
         if self.lambda_gp:
-            G.perturb(real_pos, eps, self.lambda_dra, out=x_all[3 * B + hb:])
+            if x_hat is None:
+                G.perturb(real_pos, eps, self.lambda_dra, out=x_all[3 * B + hb:])
+            else:
+                x_all[3 * B + hb:].copy_(x_hat)
         d_logit, _, d_tape = disc.forward(x_all, t_all)
 
         dd = torch.zeros(3 * B, 1, dtype=torch.float32, device=self.device)
@@ -303,8 +334,9 @@ class GanPhase(object):
         d_img[B:].copy_(disc.backward(d_tape, 3 * B, 3 * B + hb, gd2, None, need_dx=True, need_dw=False))
         gen.backward(g_tape, d_img)
         if apply:
-            disc.adam()
-            gen.adam()
+            scale = self._exchange()
+            disc.adam(scale)
+            gen.adam(scale)
         return sc
 
     def read_scalars(self):

@@ -1,0 +1,114 @@
+"""The command lines of the reference's scripts under `torch.distributed.run` with TWO ranks (the box has one GPU: the ranks
+share it and talk over gloo -- the code the RCCL ranks of an N-GPU job run, end to end through the CLI):
+
+* `cfl.bin.train_dist` / `predict_dist`: every rank trains its rows of each seeded global batch, evaluation is collective,
+  rank 0 alone writes checkpoints / best-model files / predict files; the run lands where the one-process run of the same
+  command line lands (same batches; the summation order of the gradient differs);
+* `cfl.bin.train --gan ... --post-epochs`: the MrCGAN post epochs sharded over the ranks (round 6: one all-reduce of
+  [d gradient | g gradient | scalars] per iteration) against the one-process run.
+"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(module, flags, ranks, port=None, timeout=900):
+    env = dict(os.environ, CFL_DIST_BACKEND='gloo', CFL_DP_MAX_BLOCKS='64', CFL_GAN_TUNE_STREAMS='0',
+               PYTHONPATH=os.pathsep.join([ROOT, os.path.join(ROOT, 'compatibility-family-learning_amd')]))
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT'):
+        env.pop(k, None)
+    if ranks == 1:
+        cmd = [sys.executable, '-m', module] + flags
+    else:
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(ranks), '--master-addr',
+               '127.0.0.1', '--master-port', str(port), '-m', module] + flags
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    return r
+
+
+def _flags(data_root, out, data_name):
+    return ['--data-name', data_name, '--data-root', data_root, '--checkpoint-root', os.path.join(out, 'ck'),
+            '--log-root', os.path.join(out, 'logs')]
+
+
+def test_train_dist_and_predict_under_two_ranks(tmp_path):
+    from cfl.synthetic import make_dataset
+    root = str(tmp_path / 'data')
+    make_dataset(os.path.join(root, 'syn', 'toy'), D=200, n_items=600, n_pos=3000, n_neg=3000, k=3, latent=8, seed=1, scale=4.0)
+    port = 31000 + os.getpid() % 2000
+    model = ['--input-shape', '200', '--num-components', '3', '--latent-size', '10', '--normalize-value', '16.0', '--seed', '0',
+             '--batch-size', '100', '--lr', '0.01']
+    name = 'linear_dist_ls_10_nc_3_reg_0.0_norm_16.0'
+    got = {}
+    for tag, ranks in (('one', 1), ('two', 2)):
+        out = str(tmp_path / tag)
+        fl = _flags(root, out, 'syn/toy') + model
+        _run('cfl.bin.train_dist', fl + ['--epochs', '2', '--reset'], ranks, port)
+        _run('cfl.bin.predict_dist', fl + ['--predict-root', os.path.join(out, 'pred')], ranks, port + 1)
+        ck = os.path.join(out, 'ck', 'syn', 'toy', name)
+        st = torch.load(os.path.join(ck, 'model-1.pt'), weights_only=False)
+        epoch, acc, auc = open(os.path.join(ck, 'best_acc_model', 'best_accuracy')).read().split('\t')
+        lines = open(os.path.join(out, 'pred', 'syn', 'toy', name, 'predict_acc.txt')).read().splitlines()
+        got[tag] = (st, float(acc), float(auc), lines)
+    (s1, acc1, auc1, l1), (s2, acc2, auc2, l2) = got['one'], got['two']
+    assert s1['global_step'] == s2['global_step'] == 60
+    # same batches, same initialisation: after 60 Adam steps (lr 0.01) the two runs differ by what the summation order of two partial
+    # gradient sums does to a trajectory -- small against the weights' own scale -- and they evaluate alike
+    for k, v in s1['variables'].items():
+        v, w = np.asarray(v), np.asarray(s2['variables'][k])
+        d = np.abs(v - w).max()
+        assert d <= 2e-3 * max(1.0, np.abs(v).max()), (k, d)
+    assert auc1 > 0.8 and abs(auc1 - auc2) < 5e-3 and abs(acc1 - acc2) < 2e-2, (acc1, auc1, acc2, auc2)
+    # the predict file of the two-rank run: rank 0 wrote every pair once, in the same order, with scores of the same model
+    assert len(l1) == len(l2) and [ln.split()[:3] for ln in l1] == [ln.split()[:3] for ln in l2]
+    sc1, sc2 = np.array([float(ln.split()[3]) for ln in l1]), np.array([float(ln.split()[3]) for ln in l2])
+    assert np.abs(sc1 - sc2).max() < 5e-2 * max(1.0, np.abs(sc1).max())
+    assert np.mean(np.sign(sc1) == np.sign(sc2)) > 0.97
+
+
+def test_gan_post_epochs_under_two_ranks(tmp_path):
+    from cfl.synthetic import make_double_dataset
+    root = str(tmp_path / 'data')
+    make_double_dataset(os.path.join(root, 'dy'), image_shape=(16, 16, 3), latent_dim=64, n_items=120, n_pos=160, n_neg=160, k=2, seed=5)
+    port = 33000 + os.getpid() % 2000
+    base = ['--model-type', 'linear', '--data-type', 'tanh', '--data-mean', '0.5', '--data-norm', '0.5', '--data-directed',
+            '--latent-norm', '31.9098', '--data-is-image', '--data-is-double', '--raw-latent', '--latent-shape', '64',
+            '--input-shape', '16', '16', '3', '--dist-type', 'pcd', '--lambda-m', '0.5', '--use-threshold', '--num-components',
+            '2', '--latent-size', '8', '--batch-size', '16', '--lr', '0.01', '--seed', '3']
+    gan = ['--m-prj', '0.2', '--m-enc', '0.05', '--d-lr', '0.0002', '--d-beta1', '0.5', '--g-lr', '0.0002', '--g-beta1', '0.5',
+           '--gan', '--gan-type', 'srgan', '--lambda-gp', '0.5', '--z-dim', '6']
+    name = 'cfl_pcd_linear_tanh_ls_8_nc_2_ut_norm_0.5_lm_0.5'
+    gname = name + '_gan_z_6_m_prj_0.2_m_enc_0.05_dra_0.5_0.5_srgan'
+    rows = {}
+    for tag, ranks in (('one', 1), ('two', 2)):
+        out = str(tmp_path / tag)
+        fl = _flags(root, out, 'dy') + base
+        _run('cfl.bin.train', fl + ['--epochs', '2', '--reset'], ranks, port)
+        _run('cfl.bin.train', fl + gan + ['--load-pre-weights', '--epochs', '2', '--post-epochs', '1', '--disable-eval'], ranks, port + 1)
+        gck = os.path.join(out, 'ck', 'dy', gname)
+        st = torch.load(os.path.join(gck, 'model-{}.pt'.format(3 * (160 // 16))), weights_only=False)
+        assert all(np.isfinite(np.asarray(v)).all() for v in st['variables'].values())
+        m = np.asarray(st['adam_m']['CFL/Generator/outputs/Conv/V'])
+        assert np.isfinite(m).all() and np.abs(m).max() > 0
+        tsv = open(os.path.join(out, 'logs', 'dy', gname, 'gan_scalars.tsv')).read().splitlines()
+        head, first = tsv[0].split('\t'), [float(c) for c in tsv[1].split('\t')]
+        assert all(np.isfinite(first)) and len(tsv) >= 2
+        rows[tag] = (dict(zip(head, first)), st)
+    (r1, s1), (r2, s2) = rows['one'], rows['two']
+    # first logged iteration of the post epoch: the generator / discriminator start from the same seeded initialisation, the encoder
+    # from distance epochs that differ by the summation order only -- the global-batch means of the two-rank run sit beside the
+    # one-process run's
+    for k in ('d_total_loss', 'g_total_loss', 'd_loss_real', 'd_grad_loss'):
+        assert abs(r1[k] - r2[k]) <= 2e-2 * max(1.0, abs(r1[k])), (k, r1[k], r2[k])
+    k = 'CFL/Discriminator/conv2/Conv_4/V'
+    d = np.abs(np.asarray(s1['variables'][k]) - np.asarray(s2['variables'][k]))
+    assert np.mean(d <= 2e-3) > 0.99, float(np.mean(d <= 2e-3))      # 10 Adam steps of lr 2e-4

@@ -168,6 +168,8 @@ def test_bench_starts_its_own_ranks():
     legs = out['dp_scaling']
     for k in ('b512_allreduce', 'b512_without_collective', 'b2048_allreduce', 'b2048_without_collective'):
         assert legs[k]['us_per_step'] > 0, (k, legs[k])
+    g5 = legs['config5_mrcgan_b100_per_gpu']
+    assert g5['ms_per_step'] > 0 and g5['rows_per_gpu'] == 100 and np.isfinite(g5['d_total_loss']), g5
     one = legs['oneshot']
     assert one.get('dp_leg') == 'oneshot', one
     for k in ('b512', 'b2048'):
@@ -213,6 +215,88 @@ def test_bench_line_survives_wedged_data_parallel_legs():
     out = json.loads(lines[0])
     assert out['n_gpus'] == 2 and out['value'] > 0
     assert 'did not finish' in out['dp_scaling']['error'], out['dp_scaling']
+
+
+def _gan_worker(rank, world, port, out):
+    for p in (ROOT, os.path.join(ROOT, 'compatibility-family-learning_amd')):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), CFL_GAN_TUNE_STREAMS='0', CFL_DP_MAX_BLOCKS='64')
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        import tests.test_arith_goldens as T
+        res = {}
+        for name in ('gan_sr_double', 'gan_conv_mnist', 'cgan_conv_t', 'cgan_sr'):
+            case = T.R.case_by_name(name)
+            models = {}
+            for kind in ('sharded', 'replica'):
+                os.environ['CFL_GAN_DP_SHARD'] = '1' if kind == 'sharded' else '0'
+                m = T.build_product_model(case)
+                T.load_initial(m, case)
+                models[kind] = m
+            sh, rep = models['sharded'], models['replica']
+            assert sh._gan_shard == (rank, world) and sh.gan_phase.B == case['batch_size'] // world
+            assert rep._gan_shard is None and rep.gan_phase.B == case['batch_size']
+            df = T._Diffs(case)
+            worst_s = 0.0
+            for step in range(case['steps']):
+                inp = T.R.inputs(case, step)
+                lab = T.labeled(case, inp['batch'])
+                draws = (inp['z'], inp['eps'], inp['c'])
+                for m in (sh, rep):
+                    if case.get('cgan'):
+                        m.post_step(lab, draws=draws)
+                    else:
+                        m.post_step(lab, T.unl(case, inp['unlabeled'][0]), T.unl(case, inp['unlabeled'][1]), draws=draws)
+                s, sr = sh.gan_phase.read_scalars(), rep.gan_phase.read_scalars()
+                for k in s:      # the logged numbers are GLOBAL-batch means on every rank
+                    worst_s = max(worst_s, abs(s[k] - sr[k]) / max(1.0, abs(sr[k])))
+                # ... and they sit where the goldens of the reference's own graph put them (the bars of test_hip_matches_reference_graph)
+                for k in ('d_total_loss', 'g_total_loss', 'd_loss_real', 'd_loss_fake', 'd_loss_neg', 'd_grad_loss', 'd_loss_d',
+                          'g_loss', 'g_loss_d', 'g_loss_d_neg', 'g_loss_int'):
+                    if k in s:
+                        df.scalar(step, k, s[k], 2e-3 if step else 5e-5)
+            df.finish()
+            # variables after the case's steps: sharded == whole batch up to the summation order (two partial sums instead of
+            # one; Adam's early steps move every entry by ~lr whatever the gradient's size, so an entry whose tiny gradient
+            # changes sign between the two orders differs by up to 2 lr per step: counted, not maxed)
+            frac, worst_w, same = 1.0, 0.0, True
+            for a, b in ((sh.gan_phase.disc, rep.gan_phase.disc), (sh.gan_phase.gen, rep.gan_phase.gen)):
+                d = (a.pool.theta - b.pool.theta).abs()
+                frac = min(frac, float((d <= 2e-6).float().mean()))
+                worst_w = max(worst_w, float(d.max()))
+                th = a.pool.theta.clone()
+                dist.all_reduce(th, op=dist.ReduceOp.MAX)
+                same = same and bool(torch.equal(th, a.pool.theta))
+            res[name] = (worst_s, frac, worst_w, same, 2 * case['steps'] * 1e-3)
+        if rank == 0:
+            out.put(res)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_post_epoch_step_sharded_over_two_ranks_equals_the_whole_batch():
+    """MrCGAN post epochs under data parallelism (round 6): every rank runs the G / D step on ITS rows of the global batch (X_hat's
+    std from the global batch; --cgan: its rows of both halves), one all-reduce of [d gradient | g gradient | scalars], two Adams.
+    Against a replica model running the whole batch in the same process, on the four GAN golden cases, with the reference
+    graph's golden scalars as the third witness; every rank ends with the same weights bit for bit."""
+    ctx = mp.get_context('spawn')
+    out = ctx.SimpleQueue()
+    port = 29500 + (os.getpid() + 977) % 2000
+    procs = [ctx.Process(target=_gan_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+        assert p.exitcode == 0
+    res = out.get()
+    assert set(res) == {'gan_sr_double', 'gan_conv_mnist', 'cgan_conv_t', 'cgan_sr'}
+    for name, (worst_s, frac, worst_w, same, cap) in res.items():
+        assert same, name
+        assert worst_s < 2e-5, (name, worst_s)
+        assert frac > 0.995 and worst_w <= cap, (name, frac, worst_w)
 
 
 def _oneshot_worker(rank, world, port, out):

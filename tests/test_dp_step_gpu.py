@@ -428,3 +428,55 @@ def test_validation_fetch_inside_the_training_step_equals_separate_scoring(tmp_p
         assert abs(acc - a0) <= (0.5 / B if margin < 1e-4 else 0.0) + 1e-12, (i, acc, a0, margin)
         worst = max(worst, abs(acc - a0))
     assert torch.equal(e.theta, ea.theta)
+
+
+_GAN_ONE_RANK = r"""
+import os, sys
+sys.path[:0] = [%(root)r, os.path.join(%(root)r, 'compatibility-family-learning_amd')]
+os.environ.update(CFL_FORCE_DP='1', MASTER_PORT=%(port)r, MASTER_ADDR='127.0.0.1', CFL_GAN_TUNE_STREAMS='0')
+import numpy as np, torch
+import torch.distributed as dist
+from cfl import engine
+import tests.test_arith_goldens as T
+assert engine.init_from_env() == 1 and dist.get_backend() == 'nccl' and engine.dp_active()
+out = {}
+for name in ('gan_sr_double', 'cgan_conv_t'):
+    case = T.R.case_by_name(name)
+    ms = []
+    for shard in ('1', '0'):
+        os.environ['CFL_GAN_DP_SHARD'] = shard
+        m = T.build_product_model(case)
+        T.load_initial(m, case)
+        ms.append(m)
+    sh, rep = ms
+    assert sh._gan_shard == (0, 1) and rep._gan_shard is None and sh.gan_phase.reduce is not None
+    for step in range(case['steps']):
+        inp = T.R.inputs(case, step)
+        lab = T.labeled(case, inp['batch'])
+        draws = (inp['z'], inp['eps'], inp['c'])
+        for m in ms:
+            if case.get('cgan'):
+                m.post_step(lab, draws=draws)
+            else:
+                m.post_step(lab, T.unl(case, inp['unlabeled'][0]), T.unl(case, inp['unlabeled'][1]), draws=draws)
+    same = all(torch.equal(getattr(sh.gan_phase, n).pool.theta, getattr(rep.gan_phase, n).pool.theta) for n in ('gen', 'disc'))
+    same = same and torch.equal(sh.gan_phase.scalars, rep.gan_phase.scalars)
+    out[name] = (bool(same), engine.hot_communicator() is not None)
+print('RESULT', out)
+engine.finalize()
+"""
+
+
+def test_gan_step_on_a_one_rank_rccl_group_equals_the_plain_step():
+    """The data-parallel form of the MrCGAN post-epoch step -- rows of the global batch's inputs, X_hat from the global batch, ONE
+    ncclAllReduce of [d gradient | g gradient | scalars] on the launch stream through the raw communicator, Adam with the
+    1 / world scale -- on a one-rank RCCL group: bit-identical to the plain step (a one-rank sum changes nothing)."""
+    env = dict(os.environ)
+    code = _GAN_ONE_RANK % dict(root=ROOT, port=str(33500 + os.getpid() % 2000))
+    r = subprocess.run([sys.executable, '-c', code], env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith('RESULT')][-1]
+    res = eval(line[len('RESULT '):])
+    for name, (same, direct) in res.items():
+        assert same, name
+        assert direct, 'the exchange did not go through the raw RCCL communicator'
