@@ -104,6 +104,8 @@ class CFL(PairModel):
             batch_size=batch_size, seed=seed, device=device)
         self._ema = {}
         self._np_rng = np.random.RandomState(int(seed) + 4)    # random crops / mirrors
+        self._np_rng_shard = None                               # ... of a rank's rows of a host batch (data parallelism: train())
+        self.seed = seed
         self.gan_phase = None
         self._gan_shard = None
         if gan:
@@ -344,6 +346,15 @@ class CFL(PairModel):
     def train_step(self, batch):
         if self.is_indexed(batch):
             return PairModel.train_step(self, batch)
+        if self._np_rng_shard is None:
+            return self._train_step_host(batch)
+        shared, self._np_rng = self._np_rng, self._np_rng_shard
+        try:
+            return self._train_step_host(batch)
+        finally:
+            self._np_rng = shared
+
+    def _train_step_host(self, batch):
         batch = self.select_batch(batch)
         if self.trunk is None:
             return PairModel.train_step(self, [self._prep(b, True) for b in batch])
@@ -546,12 +557,18 @@ class CFL(PairModel):
             # the post epochs continue the reference's draw sequence)
             resident = (feature_source(data.train, self.device), feature_source(data.val, self.device))
         shard = dp.shard_rows(self.batch_size) if dp.world_size() > 1 else None
-        if shard is not None and resident is None:
-            raise NotImplementedError('data-parallel training needs a vector dataset (resident features)')
         chief = dp.rank() == 0
+        if shard is not None and resident is None and self._np_rng_shard is None:
+            # host batches (image data, conv trunk, per-batch transformers) under data parallelism: every rank draws the SAME
+            # global batch from the seeded streams and trains on its rows of it; the random crops / mirrors of those rows come
+            # from a stream of the rank's own (the ranks' rows must not share their crop offsets)
+            self._np_rng_shard = np.random.RandomState((int(self.seed) + 4 + 7919 * (dp.rank() + 1)) % (2 ** 31))
 
         def next_train():
-            return resident[0].next_indexed(self.batch_size, shard) if resident else data.train.next_batch(self.batch_size)
+            if resident:
+                return resident[0].next_indexed(self.batch_size, shard)
+            b = data.train.next_batch(self.batch_size)
+            return b if shard is None else [x[shard[0]:shard[1]] for x in b]
 
         def next_val():
             return resident[1].next_indexed(self.batch_size) if resident else data.val.next_batch(self.batch_size)

@@ -112,3 +112,68 @@ def test_gan_post_epochs_under_two_ranks(tmp_path):
     k = 'CFL/Discriminator/conv2/Conv_4/V'
     d = np.abs(np.asarray(s1['variables'][k]) - np.asarray(s2['variables'][k]))
     assert np.mean(d <= 2e-3) > 0.99, float(np.mean(d <= 2e-3))      # 10 Adam steps of lr 2e-4
+
+
+def test_conv_encoder_epochs_under_two_ranks(tmp_path):
+    """--model-type conv (ConvPCD trunk in front of the heads): under two ranks the trunk's gradient is exchanged beside the heads'
+    [gradient | scalars]; the run of experiments/fashion_30/run.sh's command line lands beside the one-process run."""
+    from cfl.synthetic import make_dataset
+    root = str(tmp_path / 'data')
+    make_dataset(os.path.join(root, 'syn', 'img'), D=64, n_items=400, n_pos=1500, n_neg=1500, k=2, latent=6, seed=3, scale=0.25)
+    port = 35000 + os.getpid() % 2000
+    model = ['--model-type', 'conv', '--data-type', 'sigmoid', '--dist-type', 'pcd', '--use-threshold', '--reg-const', '5e-4',
+             '--num-components', '2', '--latent-size', '8', '--input-shape', '8', '8', '1', '--lr', '0.005', '--seed', '10',
+             '--batch-size', '100']
+    name = 'cfl_pcd_conv_sigmoid_ls_8_nc_2_ut_reg_0.0005'
+    got = {}
+    for tag, ranks in (('one', 1), ('two', 2)):
+        out = str(tmp_path / tag)
+        _run('cfl.bin.train', _flags(root, out, 'syn/img') + model + ['--epochs', '2', '--reset'], ranks, port)
+        ck = os.path.join(out, 'ck', 'syn', 'img', name)
+        st = torch.load(os.path.join(ck, 'model-30.pt'), weights_only=False)
+        auc = float(open(os.path.join(ck, 'best_model', 'best_accuracy')).read().split('\t')[2])
+        got[tag] = (st, auc)
+    (s1, auc1), (s2, auc2) = got['one'], got['two']
+    assert s1['global_step'] == s2['global_step'] == 30
+    assert auc1 > 0.6 and abs(auc1 - auc2) < 2e-2, (auc1, auc2)
+    # 30 Adam steps of lr 0.005 behind a leaky-relu trunk: entries whose tiny gradients change sign with the summation order drift
+    # by up to 2 lr per step; the bulk of every variable stays together
+    for k in ('CFL/DistEncoder/conv1/Conv/V', 'CFL/DistEncoder/outputs/fully_connected/V'):
+        v, w = np.asarray(s1['variables'][k]), np.asarray(s2['variables'][k])
+        assert np.mean(np.abs(v - w) <= 5e-3 * max(1.0, np.abs(v).max())) > 0.98, k
+
+
+def test_cgan_on_an_image_dataset_under_two_ranks(tmp_path):
+    """experiments/mnist_30/run_cgan.sh in miniature under two ranks: the distance epochs read HOST batches (image dataset: every rank
+    draws the global batch and trains on its rows), the --cgan post epoch shards each HALF of the batch (the interpolation pairs row i
+    with row i + B/2).  Against the one-process run."""
+    from cfl.synthetic import make_double_dataset
+    root = str(tmp_path / 'data')
+    make_double_dataset(os.path.join(root, 'im'), image_shape=(16, 16, 1), n_items=120, n_pos=160, n_neg=160, k=2, seed=6, double=False)
+    port = 37000 + os.getpid() % 2000
+    base = ['--model-type', 'linear', '--data-type', 'sigmoid', '--data-is-image', '--input-shape', '16', '16', '1', '--dist-type',
+            'pcd', '--use-threshold', '--num-components', '2', '--latent-size', '8', '--batch-size', '16', '--lr', '0.01', '--seed', '4']
+    gan = ['--gan', '--cgan', '--gan-type', 'conv', '--lambda-gp', '0.5', '--z-dim', '6', '--t-dim', '5']
+    gname = 'cfl_pcd_linear_sigmoid_ls_8_nc_2_ut_cgan_z_6_t_5_dra_0.5_0.5'
+    rows = {}
+    for tag, ranks in (('one', 1), ('two', 2)):
+        out = str(tmp_path / tag)
+        fl = _flags(root, out, 'im') + base
+        _run('cfl.bin.train', fl + ['--epochs', '2', '--reset', '--disable-eval'], ranks, port)
+        _run('cfl.bin.train', fl + gan + ['--epochs', '0', '--post-epochs', '1', '--disable-eval'], ranks, port + 1)
+        enc = torch.load(os.path.join(out, 'ck', 'im', 'cfl_pcd_linear_sigmoid_ls_8_nc_2_ut', 'model-20.pt'), weights_only=False)
+        st = torch.load(os.path.join(out, 'ck', 'im', gname, 'model-10.pt'), weights_only=False)
+        assert all(np.isfinite(np.asarray(v)).all() for v in st['variables'].values())
+        tsv = open(os.path.join(out, 'logs', 'im', gname, 'gan_scalars.tsv')).read().splitlines()
+        rows[tag] = (enc, st, dict(zip(tsv[0].split('\t'), [float(c) for c in tsv[1].split('\t')])))
+    (e1, s1, r1), (e2, s2, r2) = rows['one'], rows['two']
+    k = 'CFL/DistEncoder/outputs/fully_connected/V'
+    v, w = np.asarray(e1['variables'][k]), np.asarray(e2['variables'][k])
+    assert np.abs(v - w).max() <= 2e-3 * max(1.0, np.abs(v).max())           # 20 distance steps from host-batch shards
+    # (this post epoch starts from a FRESH encoder in both runs -- no --load-pre-weights --, so its first iteration sees the same
+    # weights everywhere: the two-rank global-batch means equal the one-process numbers up to the summation order)
+    for key in ('d_total_loss', 'g_total_loss', 'd_loss_real', 'd_grad_loss', 'g_loss_int'):
+        assert abs(r1[key] - r2[key]) <= 1e-4 * max(1.0, abs(r1[key])), (key, r1[key], r2[key])
+    k = 'CFL/Discriminator/conv2/Conv/V'
+    d = np.abs(np.asarray(s1['variables'][k]) - np.asarray(s2['variables'][k]))
+    assert np.mean(d <= 2e-3) > 0.99
