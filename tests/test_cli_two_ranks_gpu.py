@@ -20,9 +20,9 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(module, flags, ranks, port=None, timeout=900):
+def _run(module, flags, ranks, port=None, timeout=900, **extra_env):
     env = dict(os.environ, CFL_DIST_BACKEND='gloo', CFL_DP_MAX_BLOCKS='64', CFL_GAN_TUNE_STREAMS='0',
-               PYTHONPATH=os.pathsep.join([ROOT, os.path.join(ROOT, 'compatibility-family-learning_amd')]))
+               PYTHONPATH=os.pathsep.join([ROOT, os.path.join(ROOT, 'compatibility-family-learning_amd')]), **extra_env)
     for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT'):
         env.pop(k, None)
     if ranks == 1:
@@ -58,8 +58,20 @@ def test_train_dist_and_predict_under_two_ranks(tmp_path):
         st = torch.load(os.path.join(ck, 'model-1.pt'), weights_only=False)
         epoch, acc, auc = open(os.path.join(ck, 'best_acc_model', 'best_accuracy')).read().split('\t')
         lines = open(os.path.join(out, 'pred', 'syn', 'toy', name, 'predict_acc.txt')).read().splitlines()
-        got[tag] = (st, float(acc), float(auc), lines)
-    (s1, acc1, auc1, l1), (s2, acc2, auc2, l2) = got['one'], got['two']
+        # resume for one more epoch -- the two-rank run through the ONE-SHOT exchange (sharded Adam slots: the checkpoint it
+        # resumes from holds complete slots, and the one it writes must again)
+        _run('cfl.bin.train_dist', fl + ['--epochs', '3'], ranks, port + 2, CFL_DP_EXCHANGE='oneshot')
+        st3 = torch.load(os.path.join(ck, 'model-2.pt'), weights_only=False)
+        got[tag] = (st, float(acc), float(auc), lines, st3)
+    (s1, acc1, auc1, l1, t1), (s2, acc2, auc2, l2, t2) = got['one'], got['two']
+    assert t1['global_step'] == t2['global_step'] == 90
+    for part in ('variables', 'adam_m', 'adam_v'):
+        for k, v in t1[part].items():
+            v, w = np.asarray(v), np.asarray(t2[part][k])
+            assert np.abs(v - w).max() <= 3e-3 * max(1.0, np.abs(v).max()), (part, k)
+            if part != 'variables' and v.size > 64:
+                # a slot gathered from the ranks' slices has no stale (still zero) stretch where the one-process run moved
+                assert np.mean((w == 0) & (v != 0)) < 1e-3, (part, k)
     assert s1['global_step'] == s2['global_step'] == 60
     # same batches, same initialisation: after 60 Adam steps (lr 0.01) the two runs differ by what the summation order of two partial
     # gradient sums does to a trajectory -- small against the weights' own scale -- and they evaluate alike
