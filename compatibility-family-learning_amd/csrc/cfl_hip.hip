@@ -56,7 +56,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define CFL_MAX_JOBS 16
 #define CFL_MAX_REGIONS 20
 #define CFL_THR_FLOOR 1e-6f
-#define CFL_HANDOFF_SPIN_LIMIT (1 << 22)   // polls (with s_sleep) before an in-launch hand-off is declared lost (default; CFL_DEBUG_SPIN_LIMIT overrides, < 0: give up at once)
+#define CFL_HANDOFF_TIMEOUT_S 60.0   // wall-clock bound of an in-launch hand-off (CFL_HANDOFF_TIMEOUT_S overrides; CFL_DEBUG_SPIN_LIMIT < 0: give up at once)
 // A lost hand-off is LOUD: the kernel that gives up stores 1.0f into scalars[CFL_S_ERROR] -- a sticky word the library only
 // ever sets (the caller zeroes it once) -- and poisons what it was about to write with NaN.  The host finds the word at
 // its next read-back of the scalars (cfl_scalars_status(); PairEngine.read_scalars / DeferredScalars raise CflHipError).
@@ -1325,7 +1325,15 @@ static int run_pairs(const CflShape *s, const CflNorm *norm, const CflLossCfg *l
                 f.lr_t = adam->lr_t; f.b1 = adam->b1; f.b2 = adam->b2; f.eps = adam->eps;
             }
             f.in_mul = in_mul; f.reg_const = loss->reg_const;
-            f.spin_limit = debug_env("CFL_DEBUG_SPIN_LIMIT") != 0 ? debug_env("CFL_DEBUG_SPIN_LIMIT") : CFL_HANDOFF_SPIN_LIMIT;
+            f.spin_limit = debug_env("CFL_DEBUG_SPIN_LIMIT") < 0 ? -1 : 0;
+            {
+                static const double handoff_s = [] {
+                    const char *e = getenv("CFL_HANDOFF_TIMEOUT_S");
+                    const double v = e ? atof(e) : 0.0;
+                    return v > 0.0 ? v : CFL_HANDOFF_TIMEOUT_S;
+                }();
+                f.spin_ticks = (unsigned long long)(handoff_s * 1e8);   // s_memrealtime counts at 100 MHz
+            }
             // kept planes: written by the tile finishers only when the next step's projection will read them
             f.planes = (keeping && adam && (pl.proj_x3 || pl.proj_bx3)) ? (unsigned short *)kept->buf : nullptr;
             int jn = 0;

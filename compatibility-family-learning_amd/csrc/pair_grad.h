@@ -81,7 +81,8 @@ struct GradFuse {
     // (scalars only: one more dynamically indexed array in this argument block and hipcc copies the whole block to
     // scratch -- 2.4 KB per lane, the weight-gradient launch 2.7x slower)
     int pair_jobs;
-    int spin_limit;         // polls before a hand-off is declared lost (CFL_HANDOFF_SPIN_LIMIT; < 0: at once -- the failure test)
+    int spin_limit;         // < 0: a hand-off is declared lost at once (the failure test, CFL_DEBUG_SPIN_LIMIT=-1); else unused
+    unsigned long long spin_ticks;   // s_memrealtime ticks (100 MHz) before an in-launch hand-off is declared lost (CFL_HANDOFF_TIMEOUT_S)
     long long pair_delta;   // floats from side 0's slab array to side 1's (same column chunk, same row range)
     // monomer gate head V[L][kpad] (+ gains) of the SOURCE encoder: finished by the kind-1 / kind-2 reduction blocks
     long long mono_w, mono_g;   // theta offsets (-1: none)
@@ -146,6 +147,23 @@ __device__ __forceinline__ void grad_dp_block_done(const GradFuse &f) {
         if ((int)threadIdx.x < f.dp_world) __hip_atomic_store(f.dp_flags[threadIdx.x], f.dp_gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         if (threadIdx.x == 0) *f.dp_ticket = 0;   // the next launch on this stream starts from zero
     }
+}
+
+// Bounded wait of an in-launch hand-off: counter `ctr` reaches `expect`, or the wall clock runs out (-> false: the caller sets the
+// sticky error word and poisons its output).  Bounded by TIME, not by polls (round 6): the partners are workgroups dispatched
+// BEFORE the waiter, which never wait themselves, so on a GPU this process has to itself the wait is microseconds -- but on a
+// SHARED GPU (several processes: the multi-rank tests, a neighbour job) the queue is preempted and restored piecemeal, a restored
+// waiter can spin while its partner is still saved, and 2^22 polls (~100 ms) ran out in 6 of 8 four-rank runs
+// (profiles/r06_handoff_timeout.txt).  The clock is read every 256 polls.
+__device__ __forceinline__ int handoff_wait(const int *ctr, int expect, const GradFuse &f) {
+    if (f.spin_limit < 0) return 0;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    int spins = 0;
+    while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < expect) {
+        __builtin_amdgcn_s_sleep(1);
+        if ((++spins & 255) == 0 && __builtin_amdgcn_s_memrealtime() - t0 > f.spin_ticks) return 0;
+    }
+    return 1;
 }
 
 struct GradArgs {
@@ -320,24 +338,11 @@ __device__ __forceinline__ void grad_fused_tail(const GradArgs &a, int job, int 
     bool lost = false;   // a partner never arrived (bounded spin): poison instead of hanging or using stale tiles
     if (expect > 0 || f.wn) {
         if (threadIdx.x == 0) {
-            // Bounded: ~2^22 polls with s_sleep is > 100 ms, four orders of magnitude beyond any hand-off of a healthy
-            // launch.  The waits are for workgroups dispatched BEFORE this one (smaller linear id), which never wait
-            // themselves, so a time-out means the dispatch-order assumption or the visibility protocol failed.
+            // Bounded (handoff_wait: wall clock).  The waits are for workgroups dispatched BEFORE this one (smaller linear id),
+            // which never wait themselves, so a time-out means the dispatch-order assumption or the visibility protocol failed.
             int ok = f.spin_limit < 0 ? 0 : 1;
-            if (expect > 0 && ok) {
-                int spins = 0;
-                while (__hip_atomic_load(f.flag + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < expect) {
-                    __builtin_amdgcn_s_sleep(1);
-                    if (++spins > f.spin_limit) { ok = 0; break; }
-                }
-            }
-            if (f.wn && ok) {   // the c_j column sums of this launch's reduction blocks (dispatched first, short)
-                int spins = 0;
-                while (__hip_atomic_load(f.red_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < f.red_expect) {
-                    __builtin_amdgcn_s_sleep(1);
-                    if (++spins > f.spin_limit) { ok = 0; break; }
-                }
-            }
+            if (expect > 0 && ok) ok = handoff_wait(f.flag + slot, expect, f);
+            if (f.wn && ok) ok = handoff_wait(f.red_done, f.red_expect, f);   // the c_j column sums of this launch's reduction blocks (dispatched first, short)
             lds_i[0] = ok;
             if (!ok) f.scalars[CFL_S_ERROR] = 1.f;   // sticky error word: the host raises at its next read-back
         }
@@ -1126,22 +1131,10 @@ __device__ __forceinline__ void grad_body_x3_half(const GradJob &jb, const GradA
     if ((HO && expect > 0) || f.wn) {
         if (threadIdx.x == 0) {   // bounded waits, as in grad_fused_tail
             int ok = f.spin_limit < 0 ? 0 : 1;
-            if (expect > 0 && ok) {
-                int spins = 0;
-                while (__hip_atomic_load(f.flag + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < expect) {
-                    __builtin_amdgcn_s_sleep(1);
-                    if (++spins > f.spin_limit) { ok = 0; break; }
-                }
-            }
-            if (f.wn && ok) {   // the c_j column sums of this launch's reduction blocks (dispatched first, short)
-                int spins = 0;
-                while (__hip_atomic_load(f.red_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < f.red_expect) {
-                    __builtin_amdgcn_s_sleep(1);
-                    if (++spins > f.spin_limit) { ok = 0; break; }
-                }
-            }
+            if (expect > 0 && ok) ok = handoff_wait(f.flag + slot, expect, f);
+            if (f.wn && ok) ok = handoff_wait(f.red_done, f.red_expect, f);   // the c_j column sums of this launch's reduction blocks (dispatched first, short)
             ((int *)lds)[0] = ok;
-            if (!ok) { if (DP) dp_store4(f.scalars + CFL_S_ERROR, 1.f); else f.scalars[CFL_S_ERROR] = 1.f; }   // sticky error word (see CFL_HANDOFF_SPIN_LIMIT)
+            if (!ok) { if (DP) dp_store4(f.scalars + CFL_S_ERROR, 1.f); else f.scalars[CFL_S_ERROR] = 1.f; }   // sticky error word (see handoff_wait)
         }
         __syncthreads();
         lost = lost || ((int *)lds)[0] == 0;
