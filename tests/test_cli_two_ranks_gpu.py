@@ -115,7 +115,17 @@ def test_gan_post_epochs_under_two_ranks(tmp_path):
         head, first = tsv[0].split('\t'), [float(c) for c in tsv[1].split('\t')]
         assert all(np.isfinite(first)) and len(tsv) >= 2
         rows[tag] = (dict(zip(head, first)), st)
-    (r1, s1), (r2, s2) = rows['one'], rows['two']
+        # resume for a second post epoch under the same number of ranks, then cfl.bin.predict (rank 0 alone writes)
+        _run('cfl.bin.train', fl + gan + ['--load-pre-weights', '--epochs', '2', '--post-epochs', '2', '--disable-eval'], ranks, port + 2)
+        st2 = torch.load(os.path.join(gck, 'model-{}.pt'.format(4 * (160 // 16))), weights_only=False)
+        assert all(np.isfinite(np.asarray(v)).all() for v in st2['variables'].values())
+        k = 'CFL/Generator/outputs/Conv/V'
+        assert not np.array_equal(np.asarray(st2['variables'][k]), np.asarray(st['variables'][k]))      # the generator kept training
+        _run('cfl.bin.predict', fl + ['--predict-root', os.path.join(out, 'pred')], ranks, port + 3)
+        pred = open(os.path.join(out, 'pred', 'dy', name, 'predict_acc.txt')).read().splitlines()
+        rows[tag] += (pred,)
+    (r1, s1, p1), (r2, s2, p2) = rows['one'], rows['two']
+    assert len(p1) == len(p2) and [ln.split()[:3] for ln in p1] == [ln.split()[:3] for ln in p2]
     # first logged iteration of the post epoch: the generator / discriminator start from the same seeded initialisation, the encoder
     # from distance epochs that differ by the summation order only -- the global-batch means of the two-rank run sit beside the
     # one-process run's
