@@ -199,3 +199,26 @@ def test_cgan_on_an_image_dataset_under_two_ranks(tmp_path):
     k = 'CFL/Discriminator/conv2/Conv/V'
     d = np.abs(np.asarray(s1['variables'][k]) - np.asarray(s2['variables'][k]))
     assert np.mean(d <= 2e-3) > 0.99
+
+
+def test_streamed_features_under_two_ranks_equal_resident_features(tmp_path):
+    """A feature table that does not fit HBM is memory-mapped and gathered per batch (`CFL_FEATURES=stream`, StreamedFeatures): under
+    two ranks that is the per-iteration loop on the rank's rows of each host batch instead of the fused multi-iteration call on
+    resident features -- the same batches, the same exchange, the same parameters."""
+    from cfl.synthetic import make_dataset
+    root = str(tmp_path / 'data')
+    make_dataset(os.path.join(root, 'syn', 'toy'), D=200, n_items=600, n_pos=2000, n_neg=2000, k=3, latent=8, seed=1, scale=4.0)
+    port = 39000 + os.getpid() % 2000
+    model = ['--input-shape', '200', '--num-components', '3', '--latent-size', '10', '--normalize-value', '16.0', '--seed', '0',
+             '--batch-size', '100', '--lr', '0.01']
+    name = 'linear_dist_ls_10_nc_3_reg_0.0_norm_16.0'
+    got = {}
+    for tag in ('resident', 'stream'):
+        out = str(tmp_path / tag)
+        _run('cfl.bin.train_dist', _flags(root, out, 'syn/toy') + model + ['--epochs', '1', '--reset'], 2, port, CFL_FEATURES=tag)
+        got[tag] = torch.load(os.path.join(out, 'ck', 'syn', 'toy', name, 'model-0.pt'), weights_only=False)
+    a, b = got['resident'], got['stream']
+    assert a['global_step'] == b['global_step'] == 20
+    for k, v in a['variables'].items():
+        v, w = np.asarray(v), np.asarray(b['variables'][k])
+        assert np.abs(v - w).max() <= 2e-6 * max(1.0, np.abs(v).max()), (k, float(np.abs(v - w).max()))
