@@ -222,3 +222,31 @@ def test_streamed_features_under_two_ranks_equal_resident_features(tmp_path):
     for k, v in a['variables'].items():
         v, w = np.asarray(v), np.asarray(b['variables'][k])
         assert np.abs(v - w).max() <= 2e-6 * max(1.0, np.abs(v).max()), (k, float(np.abs(v - w).max()))
+
+
+def test_reference_cadence_under_two_ranks(tmp_path):
+    """`--scalar-every 1` (one validation fetch and one scalar read-back per iteration, the reference's loop) under two ranks: the
+    validation rows ride in every rank's launches, the logged scalars are global-batch means that travelled in the exchange.
+    Row by row against the one-process run of the same command line (same batches; the gradient's summation order differs)."""
+    from cfl.synthetic import make_dataset
+    root = str(tmp_path / 'data')
+    make_dataset(os.path.join(root, 'syn', 'toy'), D=200, n_items=600, n_pos=2000, n_neg=2000, k=3, latent=8, seed=1, scale=4.0)
+    port = 41000 + os.getpid() % 2000
+    model = ['--input-shape', '200', '--num-components', '3', '--latent-size', '10', '--normalize-value', '16.0', '--seed', '0',
+             '--batch-size', '100', '--lr', '0.01', '--scalar-every', '1']
+    name = 'linear_dist_ls_10_nc_3_reg_0.0_norm_16.0'
+    logs = {}
+    for tag, ranks, env in (('one', 1, {}), ('two', 2, {}), ('two_oneshot', 2, {'CFL_DP_EXCHANGE': 'oneshot'})):
+        out = str(tmp_path / tag)
+        _run('cfl.bin.train_dist', _flags(root, out, 'syn/toy') + model + ['--epochs', '1', '--reset'], ranks, port, **env)
+        rows = open(os.path.join(out, 'logs', 'syn', 'toy', name, 'scalars.tsv')).read().splitlines()
+        logs[tag] = np.array([[float(c) for c in r.split('\t')] for r in rows])
+    one = logs['one']
+    assert one.shape == (20, 4) and list(one[:, 0]) == list(range(20))          # a row per iteration
+    for tag in ('two', 'two_oneshot'):
+        two = logs[tag]
+        assert two.shape == one.shape and np.array_equal(two[:, 0], one[:, 0])
+        assert np.abs(two[0, 1:] - one[0, 1:]).max() <= 1e-5 * max(1.0, np.abs(one[0, 1:]).max())     # same weights at iteration 0
+        assert np.abs(two[:, 1] - one[:, 1]).max() <= 2e-3 * max(1.0, np.abs(one[:, 1]).max())        # loss, 20 Adam steps of lr 0.01
+        assert np.abs(two[:, 2] - one[:, 2]).max() <= 0.011                                             # accuracy: one row of 200 may flip
+        assert np.abs(two[:, 3] - one[:, 3]).max() <= 2e-3 * max(1.0, np.abs(one[:, 3]).max())        # threshold
