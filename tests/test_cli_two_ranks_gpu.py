@@ -1,4 +1,4 @@
-"""The command lines of the reference's scripts under `torch.distributed.run` with TWO ranks (the box has one GPU: the ranks
+"""The command lines of the reference's scripts under `torch.distributed.run` with TWO (one test: three) ranks (the box has one GPU: the ranks
 share it and talk over gloo -- the code the RCCL ranks of an N-GPU job run, end to end through the CLI):
 
 * `cfl.bin.train_dist` / `predict_dist`: every rank trains its rows of each seeded global batch, evaluation is collective,
@@ -250,3 +250,28 @@ def test_reference_cadence_under_two_ranks(tmp_path):
         assert np.abs(two[:, 1] - one[:, 1]).max() <= 2e-3 * max(1.0, np.abs(one[:, 1]).max())        # loss, 20 Adam steps of lr 0.01
         assert np.abs(two[:, 2] - one[:, 2]).max() <= 0.011                                             # accuracy: one row of 200 may flip
         assert np.abs(two[:, 3] - one[:, 3]).max() <= 2e-3 * max(1.0, np.abs(one[:, 3]).max())        # threshold
+
+
+def test_three_ranks_through_the_one_shot_exchange(tmp_path):
+    """Three ranks (slices of the exchange buffer padded: its length is no multiple of three) sharing the GPU, batch 102 = 3 x 34 rows,
+    one epoch of train_dist through the one-shot exchange, against the one-process run."""
+    from cfl.synthetic import make_dataset
+    root = str(tmp_path / 'data')
+    make_dataset(os.path.join(root, 'syn', 'toy'), D=200, n_items=600, n_pos=2040, n_neg=2040, k=3, latent=8, seed=1, scale=4.0)
+    port = 43000 + os.getpid() % 2000
+    model = ['--input-shape', '200', '--num-components', '3', '--latent-size', '10', '--normalize-value', '16.0', '--seed', '0',
+             '--batch-size', '102', '--lr', '0.01']
+    name = 'linear_dist_ls_10_nc_3_reg_0.0_norm_16.0'
+    got = {}
+    for tag, ranks, env in (('one', 1, {}), ('three', 3, {'CFL_DP_EXCHANGE': 'oneshot'})):
+        out = str(tmp_path / tag)
+        _run('cfl.bin.train_dist', _flags(root, out, 'syn/toy') + model + ['--epochs', '1', '--reset'], ranks, port, **env)
+        ck = os.path.join(out, 'ck', 'syn', 'toy', name)
+        got[tag] = (torch.load(os.path.join(ck, 'model-0.pt'), weights_only=False),
+                    float(open(os.path.join(ck, 'best_acc_model', 'best_accuracy')).read().split('\t')[2]))
+    (a, auc1), (b, auc3) = got['one'], got['three']
+    assert a['global_step'] == b['global_step'] == 20 and abs(auc1 - auc3) < 5e-3
+    for part in ('variables', 'adam_m', 'adam_v'):
+        for k, v in a[part].items():
+            v, w = np.asarray(v), np.asarray(b[part][k])
+            assert np.abs(v - w).max() <= 2e-3 * max(1.0, np.abs(v).max()), (part, k)
